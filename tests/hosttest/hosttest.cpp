@@ -1,0 +1,103 @@
+// TEST INFRASTRUCTURE: compiles the device math headers (csrc/*.cuh) for the
+// HOST with g++ so tests/ can unit-test the exact device functions without a
+// GPU.  Never linked into the product library.
+#include <cstring>
+#include "../../snark-verifier_amd/csrc/g1.cuh"
+#include "../../snark-verifier_amd/csrc/pairing.cuh"
+
+using namespace snarkv;
+
+static Fq load_fq(const uint8_t* b) {
+  uint32_t w[8];
+  memcpy(w, b, 32);
+  return fq_from_canonical(w);
+}
+static void store_fq(const Fq& a, uint8_t* b) {
+  uint32_t w[8];
+  fq_to_canonical(a, w);
+  memcpy(b, w, 32);
+}
+static Fq2 load_fq2(const uint8_t* b) { return Fq2{load_fq(b), load_fq(b + 32)}; }
+static void store_fq2(const Fq2& a, uint8_t* b) {
+  store_fq(a.c0, b);
+  store_fq(a.c1, b + 32);
+}
+static G1Affine load_g1(const uint8_t* b) {
+  uint32_t w[16];
+  memcpy(w, b, 64);
+  return g1a_from_canonical(w);
+}
+static void store_g1(const G1Affine& p, uint8_t* b) {
+  uint32_t w[16];
+  g1a_to_canonical(p, w);
+  memcpy(b, w, 64);
+}
+static void store_fq12(const Fq12& f, uint8_t* b) {
+  const Fq6* h[2] = {&f.c0, &f.c1};
+  for (int i = 0; i < 2; ++i) {
+    store_fq2(h[i]->c0, b + (i * 3 + 0) * 64);
+    store_fq2(h[i]->c1, b + (i * 3 + 1) * 64);
+    store_fq2(h[i]->c2, b + (i * 3 + 2) * 64);
+  }
+}
+static Fq12 load_fq12(const uint8_t* b) {
+  Fq12 f;
+  Fq6* h[2] = {&f.c0, &f.c1};
+  for (int i = 0; i < 2; ++i) {
+    h[i]->c0 = load_fq2(b + (i * 3 + 0) * 64);
+    h[i]->c1 = load_fq2(b + (i * 3 + 1) * 64);
+    h[i]->c2 = load_fq2(b + (i * 3 + 2) * 64);
+  }
+  return f;
+}
+
+extern "C" {
+void ht_fq_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) { store_fq(fq_mul(load_fq(a), load_fq(b)), out); }
+void ht_fq_add(const uint8_t* a, const uint8_t* b, uint8_t* out) { store_fq(fq_add(load_fq(a), load_fq(b)), out); }
+void ht_fq_sub(const uint8_t* a, const uint8_t* b, uint8_t* out) { store_fq(fq_sub(load_fq(a), load_fq(b)), out); }
+void ht_fq_inv(const uint8_t* a, uint8_t* out) { store_fq(fq_inv(load_fq(a)), out); }
+int ht_g1_on_curve(const uint8_t* p) { return g1a_is_on_curve(load_g1(p)) ? 1 : 0; }
+void ht_g1_add(const uint8_t* p, const uint8_t* q, uint8_t* out) {
+  G1Xyzz a = xyzz_from_affine(load_g1(p));
+  xyzz_add_mixed(a, load_g1(q));
+  store_g1(xyzz_to_affine(a), out);
+}
+// (k1*P) + (k2*Q) through the full projective adder
+void ht_g1_lincomb(const uint8_t* p, const uint8_t* k1, const uint8_t* q, const uint8_t* k2, uint8_t* out) {
+  uint32_t w1[8], w2[8];
+  memcpy(w1, k1, 32);
+  memcpy(w2, k2, 32);
+  G1Xyzz a = g1_scalar_mul(load_g1(p), w1);
+  G1Xyzz b = g1_scalar_mul(load_g1(q), w2);
+  xyzz_add(a, b);
+  store_g1(xyzz_to_affine(a), out);
+}
+void ht_g1_mul(const uint8_t* p, const uint8_t* k, uint8_t* out) {
+  uint32_t w[8];
+  memcpy(w, k, 32);
+  store_g1(xyzz_to_affine(g1_scalar_mul(load_g1(p), w)), out);
+}
+void ht_fq12_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  store_fq12(fq12_mul(load_fq12(a), load_fq12(b)), out);
+}
+void ht_fq12_sqr(const uint8_t* a, uint8_t* out) { store_fq12(fq12_sqr(load_fq12(a)), out); }
+void ht_fq12_inv(const uint8_t* a, uint8_t* out) { store_fq12(fq12_inv(load_fq12(a)), out); }
+void ht_fq12_frob(const uint8_t* a, int k, uint8_t* out) { store_fq12(fq12_frobenius(load_fq12(a), k), out); }
+void ht_final_exp(const uint8_t* a, uint8_t* out) { store_fq12(final_exponentiation(load_fq12(a)), out); }
+// e(P1,Q1)*e(P2,Q2) fully exponentiated; npairs in {1,2}
+void ht_pairing_product(const uint8_t* p, const uint8_t* q, int npairs, uint8_t* out) {
+  G2Prepared* prep = new G2Prepared[npairs];
+  G1AffineM ps[2];
+  const G2Prepared* qs[2];
+  for (int k = 0; k < npairs; ++k) {
+    G2Affine qa{load_fq2(q + 128 * k), load_fq2(q + 128 * k + 64)};
+    g2_prepare(qa, prep[k]);
+    G1Affine pa = load_g1(p + 64 * k);
+    ps[k] = G1AffineM{pa.x, pa.y};
+    qs[k] = &prep[k];
+  }
+  Fq12 f = multi_miller_loop(ps, qs, npairs);
+  store_fq12(final_exponentiation(f), out);
+  delete[] prep;
+}
+}
