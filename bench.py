@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- BN254 G1 MSM points/sec at 2^20 on MI355X (BASELINE.json metric).
+
+A "step" is ONE pass of the hot path over one batch of synthetic input: every
+rank reduces its own 2^20-point shard (inputs resident in HBM, generated there
+by the seeded SplitMix64 sampler of SURVEY.md 8d) to a projective partial with
+the HIP Pippenger; for N > 1 the partials (128 B per rank) are all-gathered
+over RCCL/xGMI and every rank folds them to the same affine point (SURVEY.md
+8e).  value = N * 2^20 * steps / wall time (max over ranks) -> weak scaling.
+
+Launch:  python bench.py [--gpus N --steps K --warmup W]
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+BYTES_PER_POINT = 96    # 64 B affine point + 32 B scalar, read once
+
+
+def cpu_baseline(ctx, d_scalars, d_points, sample_log2):
+    """Reference algorithm restated in C (oracle/c/bn254_oracle.c <- util/msm.rs:259-343),
+    timed on the host cores over a bounded sample of the SAME inputs.
+    Not a halo2curves measurement."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import coracle  # the only use of oracle/ in this file: the reported CPU baseline
+
+    m = 1 << sample_log2
+    s = bytes(d_scalars[: 32 * m].cpu().numpy())
+    p = bytes(d_points[: 64 * m].cpu().numpy())
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    out = coracle.msm_pippenger(s, p, cores)
+    dt = time.perf_counter() - t0
+    return {
+        "value": m / dt,
+        "unit": "points/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "2^%d points of the same seeded inputs, util::msm Pippenger restated in C "
+                  "(window ceil(ln n)+2, chunk-per-thread as msm.rs:311-336), %d threads, %.2f s; "
+                  "not a halo2curves measurement" % (sample_log2, cores, dt),
+    }, out, (s, p)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=20, help="points per GPU = 2^log2n")
+    ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--cpu-sample-log2", type=int, default=18)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import snark_verifier_amd as sv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = 1 << args.log2n
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = sv.Context(local_rank, stream=stream)
+
+    d_scalars = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+    d_points = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+    # disjoint index ranges of one global stream per rank: rank r owns [r*n, (r+1)*n)
+    ctx.sample_scalars_dev(0x5EED0001, n, d_scalars.data_ptr(), first=rank * n)
+    ctx.sample_points_dev(0x5EED0002, n, d_points.data_ptr(), first=rank * n)
+    partial = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    gathered = torch.zeros(world * 128, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+
+    def step():
+        if world == 1:
+            ctx.msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, out.data_ptr(), args.window_bits)
+        else:
+            ctx.msm_pippenger_partial_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, partial.data_ptr(),
+                                          args.window_bits)
+            dist.all_gather_into_tensor(gathered, partial)
+            ctx.fold_partials_dev(gathered.data_ptr(), world, out.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+
+    # timed region: exactly K steps; per-stage HIP events live on the same stream
+    ctx.set_stage_timing(True)
+    stage_sum = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        st = ctx.get_stage_timing()  # syncs the stream: the result of a step is consumed before the next
+        for k, v in st.items():
+            stage_sum[k] = stage_sum.get(k, 0.0) + v
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.set_stage_timing(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    result_hex = bytes(out.cpu().numpy()).hex()
+
+    if rank == 0:
+        stages = {k: v / args.steps for k, v in stage_sum.items()}
+        dom = max((k for k in stages if k != "total"), key=lambda k: stages[k])
+        dom_ms = stages[dom]
+        achieved = BYTES_PER_POINT * n / (dom_ms * 1e-3) / 1e9
+        line = {
+            "metric": "BN254 G1 MSM points/sec at 2^%d" % args.log2n,
+            "value": world * n * args.steps / dt,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32x8 (254-bit Montgomery Fq on the integer VALU)",
+            "data": "synthetic",
+            "config": {
+                "workload": "BN254 G1 Pippenger MSM, 2^%d random points/scalars per GPU, inputs resident in HBM, "
+                            "affine result (configs[1])" % args.log2n,
+                "points_per_gpu": n,
+                "window_bits": args.window_bits or "default",
+                "parallelism": "point-sharded x%d, all-gather of 128 B partials + local fold" % world,
+                "result": result_hex,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_accumulate (stage '%s')" % dom,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "note": "algorithmic 96 B/point x 2^%d points / avg HIP-event duration of the dominant stage; "
+                        "the path is integer-VALU-bound (~160 Fq products per point), see DESIGN.md" % args.log2n,
+            },
+            "stages_ms": stages,
+        }
+        if not args.no_cpu_baseline:
+            cb, cpu_out, (s, p) = cpu_baseline(ctx, d_scalars, d_points, min(args.cpu_sample_log2, args.log2n))
+            # the GPU must agree with the CPU restatement on that same sample
+            m = len(s) // 32
+            chk = torch.zeros(64, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            ctx.msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), m, chk.data_ptr(), 0)
+            ctx.sync()
+            cb["gpu_matches_on_sample"] = bytes(chk.cpu().numpy()) == cpu_out
+            line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,153 @@
+/* snarkv_amd.h -- C ABI of the MI355X-native KZG-accumulation hot path.
+ *
+ * This is the drop-in boundary SURVEY.md section 8(b) defines: the entry points
+ * a Rust `impl EcPointLoader / AccumulationDecider for GpuNativeLoader` would
+ * bind through `extern "C"` (binding stub: INTEGRATION.md).  Plain pointers and
+ * sizes only; caller owns every buffer; nothing allocated here crosses back.
+ *
+ * Byte layouts (what the reference serialises):
+ *   Fr, Fq    32-byte little-endian CANONICAL integer  (= `PrimeField::to_repr`,
+ *             reference snark-verifier/src/util/msm.rs:264)
+ *   G1Affine  x || y, 64 bytes; identity = 64 zero bytes (halo2curves (0,0))
+ *   Fq2       c0 || c1, 64 bytes;  G2Affine  x || y, 128 bytes
+ *   KzgAccumulator  lhs || rhs, 128 bytes
+ *             (reference snark-verifier/src/pcs/kzg/accumulator.rs:6-26)
+ *
+ * Scalars and coordinates MUST be canonical (< r resp. < p) and points on the
+ * curve -- the reference's types guarantee this at its boundary; pass
+ * SNARKV_FLAG_VALIDATE to have it checked (returns SNARKV_ERR_ENCODING).
+ *
+ * Return convention: 0 = SNARKV_OK, negative = error.  `decide` returns
+ * 1 accept / 0 reject / negative error  (reference: Ok(()) /
+ * Err(Error::AssertionFailure), snark-verifier/src/pcs/kzg/decider.rs:78-81).
+ * The reference PANICS on an empty MSM (native.rs:69 `reduce().unwrap()`,
+ * msm.rs:265 `scalars[0]`) and on a length mismatch (msm.rs:309); here those
+ * are SNARKV_ERR_EMPTY / SNARKV_ERR_LENGTH.
+ *
+ * Threading: a context owns one HIP stream and its scratch; calls on one
+ * context are serialised by the caller (one context per host thread).  The
+ * context-free `bn254_*` entry points use a lazily created process-global
+ * context on device 0 / HIP_VISIBLE_DEVICES, matching the reference's static
+ * dispatch (`EcPointLoader::multi_scalar_multiplication` has no `&self`,
+ * snark-verifier/src/loader.rs:108).
+ */
+#ifndef SNARKV_AMD_H
+#define SNARKV_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNARKV_OK 0
+#define SNARKV_ERR_EMPTY (-1)    /* n == 0 or an empty segment           */
+#define SNARKV_ERR_LENGTH (-2)   /* inconsistent sizes / offsets          */
+#define SNARKV_ERR_ENCODING (-3) /* non-canonical field element, off-curve */
+#define SNARKV_ERR_DEVICE (-4)   /* HIP error; see snarkv_last_error()    */
+#define SNARKV_ERR_ARG (-5)      /* null pointer / bad handle             */
+
+#define SNARKV_FLAG_VALIDATE 1u
+
+typedef struct snarkv_ctx snarkv_ctx;
+typedef struct snarkv_dk snarkv_dk;
+
+/* ---- context ---------------------------------------------------------- */
+/* `hip_stream` may be NULL (the context creates its own stream) or an
+ * existing hipStream_t the caller wants the work enqueued on (e.g. the
+ * current torch stream).                                                   */
+int snarkv_ctx_create(int device, void* hip_stream, snarkv_ctx** out);
+void snarkv_ctx_destroy(snarkv_ctx* ctx);
+int snarkv_ctx_sync(snarkv_ctx* ctx);
+const char* snarkv_last_error(void);
+const char* snarkv_version(void);
+
+/* ---- A3: NativeLoader::multi_scalar_multiplication --------------------- *
+ * replaces snark-verifier/src/loader/native.rs:61-71
+ *   pairs.iter().map(|(s, b)| *b * s).reduce(|a, v| a + v).unwrap().to_affine()
+ * host buffers in, 64-byte affine point out.                               */
+int snarkv_g1_msm_naive(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8_t* points64, size_t n,
+                        uint32_t flags, uint8_t out64[64]);
+
+/* Segmented form: n_msm independent MSMs in ONE launch.  MSM k owns terms
+ * [offsets[k], offsets[k+1]); offsets has n_msm+1 entries, offsets[0] = 0.
+ * This is the shape of the accumulation path: per proof the two `evaluate`
+ * calls of Gwc19/Bdfg21::verify (gwc19.rs:79-80, bdfg21.rs:80-81) and the two
+ * of KzgAs::verify (accumulation.rs:53-60).  out = n_msm * 64 bytes.        */
+int snarkv_g1_msm_batched(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8_t* points64,
+                          const uint32_t* offsets, size_t n_msm, uint32_t flags, uint8_t* out);
+
+/* ---- A1: util::msm::multi_scalar_multiplication ------------------------ *
+ * replaces snark-verifier/src/util/msm.rs:308-343 (windowed-bucket
+ * Pippenger).  The reference returns a projective `C::Curve`; this returns
+ * its `to_affine()` (the only representation-independent form).            */
+int snarkv_g1_msm_pippenger(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8_t* points64, size_t n,
+                            uint32_t flags, uint8_t out64[64]);
+
+/* Device-resident variants (inputs and output already in HBM; asynchronous
+ * on the context stream -- call snarkv_ctx_sync or sync the stream).  These
+ * are what bench.py times.  `window_bits` = 0 picks the default.           */
+int snarkv_g1_msm_pippenger_dev(snarkv_ctx* ctx, const void* d_scalars32, const void* d_points64, size_t n,
+                                int window_bits, void* d_out64);
+int snarkv_g1_msm_batched_dev(snarkv_ctx* ctx, const void* d_scalars32, const void* d_points64,
+                              const void* d_offsets, size_t n_msm, size_t n_terms, void* d_out);
+
+/* Multi-GPU building blocks: each rank reduces ITS shard of
+ * the points to one projective partial (128 bytes, internal XYZZ Montgomery
+ * form, opaque), the partials are all-gathered (RCCL), and every rank folds
+ * them to the same affine result.                                           */
+#define SNARKV_G1_PARTIAL_BYTES 128
+int snarkv_g1_msm_pippenger_partial_dev(snarkv_ctx* ctx, const void* d_scalars32, const void* d_points64,
+                                        size_t n, int window_bits, void* d_partial128);
+int snarkv_g1_fold_partials_dev(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64);
+
+/* ---- A8: KzgAs::decide / decide_all ------------------------------------ *
+ * replaces snark-verifier/src/pcs/kzg/decider.rs:70-93.  The deciding key
+ * (KzgDecidingKey{svk.g, g2, s_g2}, decider.rs:6-42) is loaded once; its two
+ * G2 line tables (the reference's per-call `G2Prepared::from`, decider.rs:74)
+ * are computed on the device at load time.                                  */
+int snarkv_dk_create(snarkv_ctx* ctx, const uint8_t g1_64[64], const uint8_t g2_128[128],
+                     const uint8_t s_g2_128[128], uint32_t flags, snarkv_dk** out);
+void snarkv_dk_destroy(snarkv_dk* dk);
+/* 1 = accept, 0 = reject (reference: Err(AssertionFailure)), <0 = error */
+int snarkv_kzg_decide(snarkv_ctx* ctx, const snarkv_dk* dk, const uint8_t acc128[128], uint32_t flags);
+/* decide_all: ok[i] in {0,1} per accumulator; returns 1 iff all accept.     */
+int snarkv_kzg_decide_batch(snarkv_ctx* ctx, const snarkv_dk* dk, const uint8_t* accs128, size_t m,
+                            uint32_t flags, uint8_t* ok);
+int snarkv_kzg_decide_batch_dev(snarkv_ctx* ctx, const snarkv_dk* dk, const void* d_accs128, size_t m,
+                                void* d_ok);
+/* Test hook: the fully exponentiated Gt value (12 x 32 bytes, tower order
+ * c0.c0.c0 .. c1.c2.c1) of e(lhs,g2)*e(rhs,-s_g2).                          */
+int snarkv_kzg_pairing_value(snarkv_ctx* ctx, const snarkv_dk* dk, const uint8_t acc128[128], uint8_t gt384[384]);
+
+/* ---- context-free entry points (process-global default context) -------- */
+int bn254_g1_msm_naive(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]);
+int bn254_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, const uint32_t* offsets, size_t n_msm,
+                         uint8_t* out);
+int bn254_g1_msm_pippenger(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]);
+int bn254_kzg_decide(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],
+                     const uint8_t acc128[128]);
+int bn254_kzg_decide_batch(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],
+                           const uint8_t* accs128, size_t m, uint8_t* ok);
+
+/* ---- synthetic inputs generated in HBM (bench/test utility) --- *
+ * Seeded SplitMix64 streams -> canonical Fr scalars / G1 points, element
+ * indices [first, first+n).  Not a reference function: the reference draws
+ * its test inputs from OsRng / ChaCha20 (system/halo2/test.rs:191).          */
+int snarkv_sample_scalars_dev(snarkv_ctx* ctx, uint64_t seed, uint64_t first, size_t n, void* d_scalars32);
+int snarkv_sample_points_dev(snarkv_ctx* ctx, uint64_t seed, uint64_t first, size_t n, void* d_points64);
+
+/* ---- profiling hooks used by bench.py --------------------------------- *
+ * Per-stage HIP-event timings (ms) of the last *_dev Pippenger call on this
+ * context when enabled: [0]=total [1]=to_montgomery [2]=digits+count
+ * [3]=scan [4]=scatter [5]=bucket accumulate [6]=bucket combine
+ * [7]=bucket reduce [8]=window fold + to_affine.                            */
+#define SNARKV_PIP_STAGES 9
+int snarkv_set_stage_timing(snarkv_ctx* ctx, int enabled);
+int snarkv_get_stage_timing(snarkv_ctx* ctx, float ms[SNARKV_PIP_STAGES]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNARKV_AMD_H */

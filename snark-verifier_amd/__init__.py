@@ -1,0 +1,29 @@
+"""MI355X-native KZG accumulation hot path (after privacy-scaling-explorations/snark-verifier).
+
+Thin Python binding over the C ABI in `include/snarkv_amd.h` (ctypes).  The
+product is `libsnarkv_amd.so` -- hand-written HIP kernels for gfx950 -- and the
+C++ host mirror in `host/`; Python only moves bytes and device pointers and
+provides `torch.distributed` plumbing for the multi-GPU fold.
+
+There is NO CPU fallback: importing works anywhere, but creating a `Context`
+without the built library or without a HIP device raises.
+"""
+from ._lib import (  # noqa: F401
+    Context,
+    DecidingKey,
+    SnarkvError,
+    lib_path,
+    load_library,
+    SNARKV_FLAG_VALIDATE,
+    PIP_STAGE_NAMES,
+)
+
+__all__ = [
+    "Context",
+    "DecidingKey",
+    "SnarkvError",
+    "lib_path",
+    "load_library",
+    "SNARKV_FLAG_VALIDATE",
+    "PIP_STAGE_NAMES",
+]

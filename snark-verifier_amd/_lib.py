@@ -1,0 +1,245 @@
+"""ctypes binding of include/snarkv_amd.h.  Every symbol the header declares is
+bound in `_SIGNATURES`; `tests/test_capi_symbols.py` checks the two agree."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libsnarkv_amd.so"
+
+SNARKV_OK = 0
+SNARKV_ERR_EMPTY = -1
+SNARKV_ERR_LENGTH = -2
+SNARKV_ERR_ENCODING = -3
+SNARKV_ERR_DEVICE = -4
+SNARKV_ERR_ARG = -5
+SNARKV_FLAG_VALIDATE = 1
+SNARKV_PIP_STAGES = 9
+PIP_STAGE_NAMES = [
+    "total", "to_montgomery", "digit_count", "scan", "digit_scatter",
+    "bucket_accumulate", "bucket_combine", "bucket_reduce", "window_fold",
+]
+
+_ERR_NAMES = {
+    SNARKV_ERR_EMPTY: "EMPTY (the reference panics here: native.rs:69 / msm.rs:265)",
+    SNARKV_ERR_LENGTH: "LENGTH",
+    SNARKV_ERR_ENCODING: "ENCODING",
+    SNARKV_ERR_DEVICE: "DEVICE",
+    SNARKV_ERR_ARG: "ARG",
+}
+
+
+class SnarkvError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        super().__init__("snarkv error %d %s %s" % (code, _ERR_NAMES.get(code, "?"), detail))
+
+
+_vp = ctypes.c_void_p
+_cp = ctypes.c_char_p
+_sz = ctypes.c_size_t
+_u32 = ctypes.c_uint32
+_int = ctypes.c_int
+_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes); must list every function include/snarkv_amd.h declares
+_SIGNATURES = {
+    "snarkv_ctx_create": (_int, [_int, _vp, _pp]),
+    "snarkv_ctx_destroy": (None, [_vp]),
+    "snarkv_ctx_sync": (_int, [_vp]),
+    "snarkv_last_error": (_cp, []),
+    "snarkv_version": (_cp, []),
+    "snarkv_g1_msm_naive": (_int, [_vp, _cp, _cp, _sz, _u32, _vp]),
+    "snarkv_g1_msm_batched": (_int, [_vp, _cp, _cp, _vp, _sz, _u32, _vp]),
+    "snarkv_g1_msm_pippenger": (_int, [_vp, _cp, _cp, _sz, _u32, _vp]),
+    "snarkv_g1_msm_pippenger_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
+    "snarkv_g1_msm_batched_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp]),
+    "snarkv_g1_msm_pippenger_partial_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
+    "snarkv_g1_fold_partials_dev": (_int, [_vp, _vp, _sz, _vp]),
+    "snarkv_dk_create": (_int, [_vp, _cp, _cp, _cp, _u32, _pp]),
+    "snarkv_dk_destroy": (None, [_vp]),
+    "snarkv_kzg_decide": (_int, [_vp, _vp, _cp, _u32]),
+    "snarkv_kzg_decide_batch": (_int, [_vp, _vp, _cp, _sz, _u32, _vp]),
+    "snarkv_kzg_decide_batch_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "snarkv_kzg_pairing_value": (_int, [_vp, _vp, _cp, _vp]),
+    "bn254_g1_msm_naive": (_int, [_cp, _cp, _sz, _vp]),
+    "bn254_g1_msm_batched": (_int, [_cp, _cp, _vp, _sz, _vp]),
+    "bn254_g1_msm_pippenger": (_int, [_cp, _cp, _sz, _vp]),
+    "bn254_kzg_decide": (_int, [_cp, _cp, _cp, _cp]),
+    "bn254_kzg_decide_batch": (_int, [_cp, _cp, _cp, _cp, _sz, _vp]),
+    "snarkv_sample_scalars_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
+    "snarkv_sample_points_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
+    "snarkv_set_stage_timing": (_int, [_vp, _int]),
+    "snarkv_get_stage_timing": (_int, [_vp, _vp]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return os.path.join(HERE, _LIB_NAME)
+
+
+def load_library():
+    """Loads libsnarkv_amd.so; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s is missing: build it with `python snark-verifier_amd/build.py` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path
+        )
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library drift
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise SnarkvError(rc, load_library().snarkv_last_error().decode(errors="replace"))
+    return rc
+
+
+def _as_bytes(x):
+    if isinstance(x, (bytes, bytearray, memoryview)):
+        return bytes(x)
+    tb = getattr(x, "tobytes", None)  # numpy
+    if tb is not None:
+        return tb()
+    raise TypeError("expected bytes-like, got %r" % type(x))
+
+
+class DecidingKey:
+    """`KzgDecidingKey { svk.g, g2, s_g2 }` (reference
+    snark-verifier/src/pcs/kzg/decider.rs:6-42) with its G2 line tables
+    resident in HBM."""
+
+    def __init__(self, ctx, g1, g2, s_g2, flags=0):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        g1, g2, s_g2 = _as_bytes(g1), _as_bytes(g2), _as_bytes(s_g2)
+        assert len(g1) == 64 and len(g2) == 128 and len(s_g2) == 128
+        _check(self._lib.snarkv_dk_create(ctx._h, g1, g2, s_g2, flags, ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.snarkv_dk_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One HIP stream + scratch (see include/snarkv_amd.h "Threading")."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        _check(self._lib.snarkv_ctx_create(int(device), ctypes.c_void_p(stream or 0), ctypes.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            self._lib.snarkv_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(self._lib.snarkv_ctx_sync(self._h))
+
+    # ---- host-buffer entry points ------------------------------------
+    def msm_naive(self, scalars, points, flags=0):
+        """`NativeLoader::multi_scalar_multiplication` (native.rs:61-71)."""
+        s, p = _as_bytes(scalars), _as_bytes(points)
+        if len(s) % 32 or len(p) % 64 or len(s) // 32 != len(p) // 64:
+            raise SnarkvError(SNARKV_ERR_LENGTH, "scalars/points length mismatch (reference: assert_eq!, msm.rs:309)")
+        out = ctypes.create_string_buffer(64)
+        _check(self._lib.snarkv_g1_msm_naive(self._h, s, p, len(s) // 32, flags, out))
+        return out.raw
+
+    def msm_batched(self, scalars, points, offsets, flags=0):
+        import array
+
+        s, p = _as_bytes(scalars), _as_bytes(points)
+        offs = array.array("I", [int(o) for o in offsets])
+        n_msm = len(offs) - 1
+        if n_msm < 0 or len(s) % 32 or len(p) % 64 or len(s) // 32 != len(p) // 64:
+            raise SnarkvError(SNARKV_ERR_LENGTH, "bad sizes")
+        if n_msm >= 0 and len(offs) and offs[-1] != len(s) // 32:
+            raise SnarkvError(SNARKV_ERR_LENGTH, "offsets[-1] != number of terms")
+        out = ctypes.create_string_buffer(max(64 * n_msm, 1))
+        addr, _ = offs.buffer_info()
+        _check(self._lib.snarkv_g1_msm_batched(self._h, s, p, ctypes.c_void_p(addr), n_msm, flags, out))
+        return out.raw[: 64 * n_msm]
+
+    def msm_pippenger(self, scalars, points, flags=0):
+        """`util::msm::multi_scalar_multiplication` (msm.rs:308-343), affine."""
+        s, p = _as_bytes(scalars), _as_bytes(points)
+        if len(s) % 32 or len(p) % 64 or len(s) // 32 != len(p) // 64:
+            raise SnarkvError(SNARKV_ERR_LENGTH, "scalars/points length mismatch (reference: assert_eq!, msm.rs:309)")
+        out = ctypes.create_string_buffer(64)
+        _check(self._lib.snarkv_g1_msm_pippenger(self._h, s, p, len(s) // 32, flags, out))
+        return out.raw
+
+    def decide(self, dk, acc, flags=0):
+        acc = _as_bytes(acc)
+        assert len(acc) == 128
+        return bool(_check(self._lib.snarkv_kzg_decide(self._h, dk._h, acc, flags)))
+
+    def decide_batch(self, dk, accs, flags=0):
+        accs = _as_bytes(accs)
+        assert len(accs) % 128 == 0
+        m = len(accs) // 128
+        ok = ctypes.create_string_buffer(max(m, 1))
+        allok = _check(self._lib.snarkv_kzg_decide_batch(self._h, dk._h, accs, m, flags, ok))
+        return bool(allok), [b != 0 for b in ok.raw[:m]]
+
+    def pairing_value(self, dk, acc):
+        acc = _as_bytes(acc)
+        out = ctypes.create_string_buffer(384)
+        _check(self._lib.snarkv_kzg_pairing_value(self._h, dk._h, acc, out))
+        return out.raw
+
+    # ---- device-pointer entry points (ints from tensor.data_ptr()) ----
+    def msm_pippenger_dev(self, d_scalars, d_points, n, d_out, window_bits=0):
+        _check(self._lib.snarkv_g1_msm_pippenger_dev(self._h, d_scalars, d_points, n, window_bits, d_out))
+
+    def msm_pippenger_partial_dev(self, d_scalars, d_points, n, d_partial, window_bits=0):
+        _check(self._lib.snarkv_g1_msm_pippenger_partial_dev(self._h, d_scalars, d_points, n, window_bits, d_partial))
+
+    def fold_partials_dev(self, d_partials, count, d_out):
+        _check(self._lib.snarkv_g1_fold_partials_dev(self._h, d_partials, count, d_out))
+
+    def msm_batched_dev(self, d_scalars, d_points, d_offsets, n_msm, n_terms, d_out):
+        _check(self._lib.snarkv_g1_msm_batched_dev(self._h, d_scalars, d_points, d_offsets, n_msm, n_terms, d_out))
+
+    def decide_batch_dev(self, dk, d_accs, m, d_ok):
+        _check(self._lib.snarkv_kzg_decide_batch_dev(self._h, dk._h, d_accs, m, d_ok))
+
+    def sample_scalars_dev(self, seed, n, d_out, first=0):
+        _check(self._lib.snarkv_sample_scalars_dev(self._h, seed, first, n, d_out))
+
+    def sample_points_dev(self, seed, n, d_out, first=0):
+        _check(self._lib.snarkv_sample_points_dev(self._h, seed, first, n, d_out))
+
+    def set_stage_timing(self, enabled=True):
+        _check(self._lib.snarkv_set_stage_timing(self._h, 1 if enabled else 0))
+
+    def get_stage_timing(self):
+        arr = (ctypes.c_float * SNARKV_PIP_STAGES)()
+        _check(self._lib.snarkv_get_stage_timing(self._h, arr))
+        return dict(zip(PIP_STAGE_NAMES, [float(x) for x in arr]))

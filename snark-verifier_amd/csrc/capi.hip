@@ -1,0 +1,377 @@
+// C ABI glue (include/snarkv_amd.h): context, staging, error reporting.
+// No arithmetic happens on the host; every entry point stages bytes to HBM,
+// enqueues the HIP kernels and copies the (tiny) result back.
+#include <stdarg.h>
+#include <string.h>
+#include <mutex>
+#include "ctx.hpp"
+
+namespace snarkv {
+
+static thread_local char g_err[512] = "";
+
+void set_last_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int ctx_reserve(snarkv_ctx* ctx, int slot, size_t bytes, void** out) {
+  if (bytes == 0) bytes = 16;
+  if (ctx->cap[slot] < bytes) {
+    if (ctx->buf[slot]) {
+      // earlier launches on the stream may still use the old buffer
+      SNARKV_HIP(hipStreamSynchronize(ctx->stream));
+      SNARKV_HIP(hipFree(ctx->buf[slot]));
+      ctx->buf[slot] = nullptr;
+      ctx->cap[slot] = 0;
+    }
+    size_t cap = bytes + bytes / 8 + 256;
+    SNARKV_HIP(hipMalloc(&ctx->buf[slot], cap));
+    ctx->cap[slot] = cap;
+  }
+  *out = ctx->buf[slot];
+  return SNARKV_OK;
+}
+
+static int stage_in(snarkv_ctx* ctx, int slot, const void* host, size_t bytes, void** d) {
+  SNARKV_TRY(ctx_reserve(ctx, slot, bytes, d));
+  SNARKV_HIP(hipMemcpyAsync(*d, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return SNARKV_OK;
+}
+
+static int fetch_out(snarkv_ctx* ctx, const void* d, void* host, size_t bytes) {
+  SNARKV_HIP(hipMemcpyAsync(host, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SNARKV_HIP(hipStreamSynchronize(ctx->stream));
+  return SNARKV_OK;
+}
+
+static std::mutex g_default_mu;
+static snarkv_ctx* g_default_ctx = nullptr;
+
+static int default_ctx(snarkv_ctx** out) {
+  std::lock_guard<std::mutex> lk(g_default_mu);
+  if (!g_default_ctx) {
+    int rc = snarkv_ctx_create(0, nullptr, &g_default_ctx);
+    if (rc < 0) return rc;
+  }
+  *out = g_default_ctx;
+  return SNARKV_OK;
+}
+
+}  // namespace snarkv
+
+using namespace snarkv;
+
+extern "C" {
+
+const char* snarkv_last_error(void) { return g_err; }
+const char* snarkv_version(void) { return "snarkv_amd 0.1 (gfx950)"; }
+
+int snarkv_ctx_create(int device, void* hip_stream, snarkv_ctx** out) {
+  if (!out) return SNARKV_ERR_ARG;
+  int count = 0;
+  SNARKV_HIP(hipGetDeviceCount(&count));
+  if (count <= 0 || device < 0 || device >= count) {
+    set_last_error("no HIP device %d (count=%d): the MI355X path has no CPU fallback", device, count);
+    return SNARKV_ERR_DEVICE;
+  }
+  SNARKV_HIP(hipSetDevice(device));
+  snarkv_ctx* c = new snarkv_ctx();
+  memset(c, 0, sizeof(*c));
+  c->device = device;
+  if (hip_stream) {
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      set_last_error("hipStreamCreate: %s", hipGetErrorString(e));
+      delete c;
+      return SNARKV_ERR_DEVICE;
+    }
+    c->own_stream = true;
+  }
+  *out = c;
+  return SNARKV_OK;
+}
+
+void snarkv_ctx_destroy(snarkv_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < SLOT_COUNT; ++i)
+    if (ctx->buf[i]) (void)hipFree(ctx->buf[i]);
+  if (ctx->ev_ready)
+    for (int i = 0; i <= SNARKV_PIP_STAGES; ++i) (void)hipEventDestroy(ctx->ev[i]);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int snarkv_ctx_sync(snarkv_ctx* ctx) {
+  if (!ctx) return SNARKV_ERR_ARG;
+  SNARKV_HIP(hipStreamSynchronize(ctx->stream));
+  return SNARKV_OK;
+}
+
+int snarkv_set_stage_timing(snarkv_ctx* ctx, int enabled) {
+  if (!ctx) return SNARKV_ERR_ARG;
+  ctx->stage_timing = enabled != 0;
+  return SNARKV_OK;
+}
+
+int snarkv_get_stage_timing(snarkv_ctx* ctx, float ms[SNARKV_PIP_STAGES]) {
+  if (!ctx || !ctx->ev_ready) return SNARKV_ERR_ARG;
+  SNARKV_HIP(hipStreamSynchronize(ctx->stream));
+  SNARKV_HIP(hipEventElapsedTime(&ms[0], ctx->ev[0], ctx->ev[SNARKV_PIP_STAGES - 1]));
+  for (int i = 1; i < SNARKV_PIP_STAGES; ++i) SNARKV_HIP(hipEventElapsedTime(&ms[i], ctx->ev[i - 1], ctx->ev[i]));
+  return SNARKV_OK;
+}
+
+static int check_validate(snarkv_ctx* ctx, const void* d_s, const void* d_p, size_t n, uint32_t flags) {
+  if (!(flags & SNARKV_FLAG_VALIDATE)) return SNARKV_OK;
+  int bad = 0;
+  SNARKV_TRY(launch_validate(ctx, d_s, d_p, n, &bad));
+  if (bad) {
+    set_last_error("%d of %zu inputs are non-canonical or off-curve", bad, n);
+    return SNARKV_ERR_ENCODING;
+  }
+  return SNARKV_OK;
+}
+
+int snarkv_g1_msm_batched(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8_t* points64,
+                          const uint32_t* offsets, size_t n_msm, uint32_t flags, uint8_t* out) {
+  if (!ctx || !scalars32 || !points64 || !offsets || !out) return SNARKV_ERR_ARG;
+  if (n_msm == 0) return SNARKV_ERR_EMPTY;
+  if (offsets[0] != 0) return SNARKV_ERR_LENGTH;
+  for (size_t k = 0; k < n_msm; ++k) {
+    if (offsets[k + 1] < offsets[k]) return SNARKV_ERR_LENGTH;
+    if (offsets[k + 1] == offsets[k]) return SNARKV_ERR_EMPTY;  // reference panics: native.rs:69
+  }
+  size_t n = offsets[n_msm];
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  void *d_s, *d_p, *d_o, *d_out;
+  SNARKV_TRY(stage_in(ctx, SLOT_IN_SCALARS, scalars32, n * 32, &d_s));
+  SNARKV_TRY(stage_in(ctx, SLOT_IN_POINTS, points64, n * 64, &d_p));
+  SNARKV_TRY(stage_in(ctx, SLOT_IN_OFFSETS, offsets, (n_msm + 1) * 4, &d_o));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_OUT, n_msm * 64, &d_out));
+  SNARKV_TRY(check_validate(ctx, d_s, d_p, n, flags));
+  SNARKV_TRY(launch_msm_batched(ctx, d_s, d_p, d_o, n_msm, n, d_out));
+  return fetch_out(ctx, d_out, out, n_msm * 64);
+}
+
+int snarkv_g1_msm_naive(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8_t* points64, size_t n,
+                        uint32_t flags, uint8_t out64[64]) {
+  if (n == 0) return SNARKV_ERR_EMPTY;
+  if (n > 0xFFFFFFFFull) return SNARKV_ERR_LENGTH;
+  uint32_t offsets[2] = {0, (uint32_t)n};
+  return snarkv_g1_msm_batched(ctx, scalars32, points64, offsets, 1, flags, out64);
+}
+
+int snarkv_g1_msm_batched_dev(snarkv_ctx* ctx, const void* d_scalars32, const void* d_points64,
+                              const void* d_offsets, size_t n_msm, size_t n_terms, void* d_out) {
+  if (!ctx || !d_scalars32 || !d_points64 || !d_offsets || !d_out) return SNARKV_ERR_ARG;
+  if (n_msm == 0 || n_terms == 0) return SNARKV_ERR_EMPTY;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  return launch_msm_batched(ctx, d_scalars32, d_points64, d_offsets, n_msm, n_terms, d_out);
+}
+
+int snarkv_g1_msm_pippenger(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8_t* points64, size_t n,
+                            uint32_t flags, uint8_t out64[64]) {
+  if (!ctx || !scalars32 || !points64 || !out64) return SNARKV_ERR_ARG;
+  if (n == 0) return SNARKV_ERR_EMPTY;  // reference panics: msm.rs:265
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  void *d_s, *d_p, *d_out;
+  SNARKV_TRY(stage_in(ctx, SLOT_IN_SCALARS, scalars32, n * 32, &d_s));
+  SNARKV_TRY(stage_in(ctx, SLOT_IN_POINTS, points64, n * 64, &d_p));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_OUT, 64, &d_out));
+  SNARKV_TRY(check_validate(ctx, d_s, d_p, n, flags));
+  SNARKV_TRY(launch_msm_pippenger(ctx, d_s, d_p, n, 0, d_out, false));
+  return fetch_out(ctx, d_out, out64, 64);
+}
+
+int snarkv_g1_msm_pippenger_dev(snarkv_ctx* ctx, const void* d_scalars32, const void* d_points64, size_t n,
+                                int window_bits, void* d_out64) {
+  if (!ctx || !d_scalars32 || !d_points64 || !d_out64) return SNARKV_ERR_ARG;
+  if (n == 0) return SNARKV_ERR_EMPTY;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  return launch_msm_pippenger(ctx, d_scalars32, d_points64, n, window_bits, d_out64, false);
+}
+
+int snarkv_g1_msm_pippenger_partial_dev(snarkv_ctx* ctx, const void* d_scalars32, const void* d_points64,
+                                        size_t n, int window_bits, void* d_partial128) {
+  if (!ctx || !d_scalars32 || !d_points64 || !d_partial128) return SNARKV_ERR_ARG;
+  if (n == 0) return SNARKV_ERR_EMPTY;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  return launch_msm_pippenger(ctx, d_scalars32, d_points64, n, window_bits, d_partial128, true);
+}
+
+int snarkv_g1_fold_partials_dev(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64) {
+  if (!ctx || !d_partials || !d_out64) return SNARKV_ERR_ARG;
+  if (count == 0) return SNARKV_ERR_EMPTY;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  return launch_fold_partials(ctx, d_partials, count, d_out64);
+}
+
+int snarkv_dk_create(snarkv_ctx* ctx, const uint8_t g1_64[64], const uint8_t g2_128[128],
+                     const uint8_t s_g2_128[128], uint32_t flags, snarkv_dk** out) {
+  if (!ctx || !g1_64 || !g2_128 || !s_g2_128 || !out) return SNARKV_ERR_ARG;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  uint8_t both[256];
+  memcpy(both, g2_128, 128);
+  memcpy(both + 128, s_g2_128, 128);
+  void* d_in;
+  SNARKV_TRY(stage_in(ctx, SLOT_IN_POINTS, both, 256, &d_in));
+  // staging source is a stack buffer: finish the copy before returning
+  SNARKV_HIP(hipStreamSynchronize(ctx->stream));
+  if (flags & SNARKV_FLAG_VALIDATE) {
+    int bad = 0;
+    SNARKV_TRY(launch_validate_g2(ctx, d_in, &bad));
+    if (bad) {
+      set_last_error("deciding key: G2 point non-canonical or off the twist");
+      return SNARKV_ERR_ENCODING;
+    }
+    void* d_g1;
+    SNARKV_TRY(stage_in(ctx, SLOT_IN_SCALARS, g1_64, 64, &d_g1));
+    SNARKV_TRY(launch_validate(ctx, nullptr, d_g1, 1, &bad));
+    if (bad) {
+      set_last_error("deciding key: G1 generator non-canonical or off-curve");
+      return SNARKV_ERR_ENCODING;
+    }
+  }
+  snarkv_dk* dk = new snarkv_dk();
+  dk->device = ctx->device;
+  memcpy(dk->g1, g1_64, 64);
+  hipError_t e = hipMalloc(&dk->d_prep, 2 * g2_prepared_bytes());
+  if (e != hipSuccess) {
+    set_last_error("hipMalloc(dk): %s", hipGetErrorString(e));
+    delete dk;
+    return SNARKV_ERR_DEVICE;
+  }
+  int rc = launch_g2_prepare(ctx, d_in, dk->d_prep);
+  if (rc == SNARKV_OK) {
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (e2 != hipSuccess) {
+      set_last_error("g2_prepare: %s", hipGetErrorString(e2));
+      rc = SNARKV_ERR_DEVICE;
+    }
+  }
+  if (rc < 0) {
+    (void)hipFree(dk->d_prep);
+    delete dk;
+    return rc;
+  }
+  *out = dk;
+  return SNARKV_OK;
+}
+
+void snarkv_dk_destroy(snarkv_dk* dk) {
+  if (!dk) return;
+  (void)hipSetDevice(dk->device);
+  if (dk->d_prep) (void)hipFree(dk->d_prep);
+  delete dk;
+}
+
+int snarkv_kzg_decide_batch_dev(snarkv_ctx* ctx, const snarkv_dk* dk, const void* d_accs128, size_t m,
+                                void* d_ok) {
+  if (!ctx || !dk || !d_accs128 || !d_ok) return SNARKV_ERR_ARG;
+  if (m == 0) return SNARKV_ERR_EMPTY;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  return launch_decide(ctx, dk->d_prep, d_accs128, m, d_ok, nullptr);
+}
+
+int snarkv_kzg_decide_batch(snarkv_ctx* ctx, const snarkv_dk* dk, const uint8_t* accs128, size_t m,
+                            uint32_t flags, uint8_t* ok) {
+  if (!ctx || !dk || !accs128 || !ok) return SNARKV_ERR_ARG;
+  if (m == 0) return 1;  // decide_all over an empty list is Ok(()) (decider.rs:84-93)
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  void *d_a, *d_ok;
+  SNARKV_TRY(stage_in(ctx, SLOT_IN_POINTS, accs128, m * 128, &d_a));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_OUT, m, &d_ok));
+  if (flags & SNARKV_FLAG_VALIDATE) {
+    int bad = 0;
+    SNARKV_TRY(launch_validate(ctx, nullptr, d_a, 2 * m, &bad));
+    if (bad) {
+      set_last_error("%d accumulator points non-canonical or off-curve", bad);
+      return SNARKV_ERR_ENCODING;
+    }
+  }
+  SNARKV_TRY(launch_decide(ctx, dk->d_prep, d_a, m, d_ok, nullptr));
+  SNARKV_TRY(fetch_out(ctx, d_ok, ok, m));
+  int all = 1;
+  for (size_t i = 0; i < m; ++i) all &= ok[i] ? 1 : 0;
+  return all;
+}
+
+int snarkv_kzg_decide(snarkv_ctx* ctx, const snarkv_dk* dk, const uint8_t acc128[128], uint32_t flags) {
+  uint8_t ok = 0;
+  int rc = snarkv_kzg_decide_batch(ctx, dk, acc128, 1, flags, &ok);
+  if (rc < 0) return rc;
+  return ok ? 1 : 0;
+}
+
+int snarkv_kzg_pairing_value(snarkv_ctx* ctx, const snarkv_dk* dk, const uint8_t acc128[128], uint8_t gt384[384]) {
+  if (!ctx || !dk || !acc128 || !gt384) return SNARKV_ERR_ARG;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  void *d_a, *d_gt;
+  SNARKV_TRY(stage_in(ctx, SLOT_IN_POINTS, acc128, 128, &d_a));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_OUT, 384, &d_gt));
+  SNARKV_TRY(launch_decide(ctx, dk->d_prep, d_a, 1, nullptr, d_gt));
+  return fetch_out(ctx, d_gt, gt384, 384);
+}
+
+int snarkv_sample_scalars_dev(snarkv_ctx* ctx, uint64_t seed, uint64_t first, size_t n, void* d_scalars32) {
+  if (!ctx || !d_scalars32) return SNARKV_ERR_ARG;
+  if (n == 0) return SNARKV_OK;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  return launch_sample_scalars(ctx, seed, first, n, d_scalars32);
+}
+
+int snarkv_sample_points_dev(snarkv_ctx* ctx, uint64_t seed, uint64_t first, size_t n, void* d_points64) {
+  if (!ctx || !d_points64) return SNARKV_ERR_ARG;
+  if (n == 0) return SNARKV_OK;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  return launch_sample_points(ctx, seed, first, n, d_points64);
+}
+
+// ---- context-free entry points -------------------------------------------
+int bn254_g1_msm_naive(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]) {
+  snarkv_ctx* c;
+  SNARKV_TRY(default_ctx(&c));
+  return snarkv_g1_msm_naive(c, scalars32, points64, n, 0, out64);
+}
+
+int bn254_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, const uint32_t* offsets, size_t n_msm,
+                         uint8_t* out) {
+  snarkv_ctx* c;
+  SNARKV_TRY(default_ctx(&c));
+  return snarkv_g1_msm_batched(c, scalars32, points64, offsets, n_msm, 0, out);
+}
+
+int bn254_g1_msm_pippenger(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]) {
+  snarkv_ctx* c;
+  SNARKV_TRY(default_ctx(&c));
+  return snarkv_g1_msm_pippenger(c, scalars32, points64, n, 0, out64);
+}
+
+int bn254_kzg_decide_batch(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],
+                           const uint8_t* accs128, size_t m, uint8_t* ok) {
+  snarkv_ctx* c;
+  SNARKV_TRY(default_ctx(&c));
+  snarkv_dk* dk = nullptr;
+  SNARKV_TRY(snarkv_dk_create(c, g1_64, g2_128, s_g2_128, 0, &dk));
+  int rc = snarkv_kzg_decide_batch(c, dk, accs128, m, 0, ok);
+  snarkv_dk_destroy(dk);
+  return rc;
+}
+
+int bn254_kzg_decide(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],
+                     const uint8_t acc128[128]) {
+  uint8_t ok = 0;
+  int rc = bn254_kzg_decide_batch(g1_64, g2_128, s_g2_128, acc128, 1, &ok);
+  if (rc < 0) return rc;
+  return ok ? 1 : 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+// Internal: context object behind the C ABI (include/snarkv_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/snarkv_amd.h"
+
+namespace snarkv {
+
+void set_last_error(const char* fmt, ...);
+
+#define SNARKV_HIP(expr)                                                                   \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      ::snarkv::set_last_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return SNARKV_ERR_DEVICE;                                                            \
+    }                                                                                      \
+  } while (0)
+
+#define SNARKV_TRY(expr)      \
+  do {                        \
+    int _rc = (expr);         \
+    if (_rc < 0) return _rc;  \
+  } while (0)
+
+// Scratch slots (grow-only device buffers owned by the context).
+enum Slot {
+  SLOT_IN_SCALARS = 0,
+  SLOT_IN_POINTS,
+  SLOT_IN_OFFSETS,
+  SLOT_OUT,
+  SLOT_POINTS_MONT,
+  SLOT_COUNTS,
+  SLOT_OFFSETS,
+  SLOT_CURSOR,
+  SLOT_BLOCKSUMS,
+  SLOT_ENTRIES,
+  SLOT_SEG_IDS,
+  SLOT_SEG_PARTIALS,
+  SLOT_BUCKETS,
+  SLOT_CHUNK_PARTIALS,
+  SLOT_WINDOW_SUMS,
+  SLOT_TERM_PARTIALS,
+  SLOT_FLAGS,
+  SLOT_MISC,
+  SLOT_COUNT
+};
+
+}  // namespace snarkv
+
+struct snarkv_ctx {
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  void* buf[snarkv::SLOT_COUNT];
+  size_t cap[snarkv::SLOT_COUNT];
+  void* pinned;  // small pinned host staging area
+  size_t pinned_cap;
+  bool stage_timing;
+  float stage_ms[SNARKV_PIP_STAGES];
+  hipEvent_t ev[SNARKV_PIP_STAGES + 1];
+  bool ev_ready;
+};
+
+struct snarkv_dk {
+  int device;
+  void* d_prep;  // 2 x G2Prepared (g2, -s_g2)
+  uint8_t g1[64];
+};
+
+namespace snarkv {
+
+// Ensure slot capacity; returns device pointer through *out.
+int ctx_reserve(snarkv_ctx* ctx, int slot, size_t bytes, void** out);
+
+// kernels' host-side launchers (each enqueues on ctx->stream)
+int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, const void* d_offsets,
+                       size_t n_msm, size_t n_terms, void* d_out);
+int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
+                         void* d_out, bool partial_out);
+int launch_fold_partials(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64);
+int launch_validate(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int* bad_host);
+int launch_g2_prepare(snarkv_ctx* ctx, const void* d_g2x2_256, void* d_prep);
+int launch_decide(snarkv_ctx* ctx, const void* d_prep, const void* d_accs, size_t m, void* d_ok, void* d_gt);
+int launch_validate_g2(snarkv_ctx* ctx, const void* d_g2x2_256, int* bad_host);
+size_t g2_prepared_bytes();
+int launch_sample_scalars(snarkv_ctx* ctx, uint64_t seed, uint64_t first, size_t n, void* d_out);
+int launch_sample_points(snarkv_ctx* ctx, uint64_t seed, uint64_t first, size_t n, void* d_out);
+
+}  // namespace snarkv

@@ -17,7 +17,7 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define SNARKV_HD __host__ __device__ __forceinline__
-#define SNARKV_HD_NOINLINE __host__ __device__ __noinline__
+#define SNARKV_HD_NOINLINE static __host__ __device__ __noinline__
 #else
 #define SNARKV_HD inline
 #define SNARKV_HD_NOINLINE inline
@@ -181,6 +181,19 @@ SNARKV_HD bool fq_canonical_in_range(const uint32_t w[8]) {
     borrow = (x >> 32) & 1u;
   }
   return borrow != 0;
+}
+
+// a^e for a 256-bit exponent given as 8 LE words (lane-uniform control flow).
+SNARKV_HD_NOINLINE Fq fq_pow(const Fq& a, const uint32_t* e) {
+  Fq res = fq_one();
+  for (int i = 7; i >= 0; --i) {
+    uint32_t w = e[i];
+    for (int b = 31; b >= 0; --b) {
+      res = fq_sqr(res);
+      if ((w >> b) & 1u) res = fq_mul(res, a);
+    }
+  }
+  return res;
 }
 
 // a^(p-2): Fermat inversion, fixed (lane-uniform) exponent.  inv(0) = 0.

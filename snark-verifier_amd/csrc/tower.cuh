@@ -8,7 +8,7 @@
 #include "fq.cuh"
 
 #if defined(__HIPCC__)
-#define SNARKV_TW __host__ __device__ __noinline__
+#define SNARKV_TW static __host__ __device__ __noinline__
 #else
 #define SNARKV_TW inline
 #endif

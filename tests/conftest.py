@@ -1,0 +1,51 @@
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_msm():
+    with open(os.path.join(ROOT, "tests", "golden", "g1_msm.json")) as f:
+        return json.load(f)["cases"]
+
+
+@pytest.fixture(scope="session")
+def golden_decider():
+    with open(os.path.join(ROOT, "tests", "golden", "kzg_decider.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def hosttest_lib():
+    """Device math headers (csrc/*.cuh) compiled for the HOST: unit tests of
+    the exact device functions without a GPU.  Test infrastructure only."""
+    import ctypes
+
+    d = os.path.join(ROOT, "tests", "hosttest")
+    so = os.path.join(d, "libhosttest.so")
+    src = os.path.join(d, "hosttest.cpp")
+    csrc = os.path.join(ROOT, "snark-verifier_amd", "csrc")
+    newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith((".cuh", ".h"))])
+    if not os.path.exists(so) or os.path.getmtime(so) < newest:
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src], check=True)
+    return ctypes.CDLL(so)
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    import snark_verifier_amd as sv
+
+    ctx = sv.Context(0)
+    yield ctx
+    ctx.close()
