@@ -90,6 +90,15 @@ def load_library():
             "%s is missing: build it with `python snark-verifier_amd/build.py` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path
         )
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7
+    # (same SONAME as /opt/rocm's).  If ours were loaded first, torch would bind
+    # to it and fail to see the GPU; loading torch first makes this library bind
+    # to the runtime torch already brought in, so device pointers and streams
+    # can be shared between the two.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is plumbing, not a requirement of the C ABI
+        pass
     lib = ctypes.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library drift
