@@ -94,12 +94,12 @@ int snarkv_g1_msm_batched_dev(snarkv_ctx* ctx, const void* d_scalars32, const vo
                               const void* d_offsets, size_t n_msm, size_t n_terms, void* d_out);
 
 /* Multi-GPU building blocks: each rank reduces ITS shard of
- * the points to one projective partial (128 bytes, internal XYZZ Montgomery
- * form, opaque), the partials are all-gathered (RCCL), and every rank folds
+ * the points to one projective partial (SNARKV_G1_PARTIAL_BYTES, internal XYZZ
+ * 9x29-bit Montgomery form, opaque), the partials are all-gathered (RCCL), and every rank folds
  * them to the same affine result.                                           */
-#define SNARKV_G1_PARTIAL_BYTES 128
+#define SNARKV_G1_PARTIAL_BYTES 144
 int snarkv_g1_msm_pippenger_partial_dev(snarkv_ctx* ctx, const void* d_scalars32, const void* d_points64,
-                                        size_t n, int window_bits, void* d_partial128);
+                                        size_t n, int window_bits, void* d_partial);
 int snarkv_g1_fold_partials_dev(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64);
 
 /* ---- A8: KzgAs::decide / decide_all ------------------------------------ *
@@ -140,9 +140,11 @@ int snarkv_sample_points_dev(snarkv_ctx* ctx, uint64_t seed, uint64_t first, siz
 
 /* ---- profiling hooks used by bench.py --------------------------------- *
  * Per-stage HIP-event timings (ms) of the last *_dev Pippenger call on this
- * context when enabled: [0]=total [1]=to_montgomery [2]=digits+count
- * [3]=scan [4]=scatter [5]=bucket accumulate [6]=bucket combine
- * [7]=bucket reduce [8]=window fold + to_affine.                            */
+ * context when enabled: [0]=total [1]=to_montgomery [2]=digit histogram
+ * [3]=scan [4]=partition + level-2 sort [5]=launch marker [6]=bulk: bucket
+ * accumulate + combine + reduce + window sums + window-shift chains of all
+ * window groups (each group on its own stream) [7]=final sum + to_affine
+ * [8]=spare.                                                                 */
 #define SNARKV_PIP_STAGES 9
 int snarkv_set_stage_timing(snarkv_ctx* ctx, int enabled);
 int snarkv_get_stage_timing(snarkv_ctx* ctx, float ms[SNARKV_PIP_STAGES]);

@@ -16,6 +16,7 @@ from ._lib import (  # noqa: F401
     load_library,
     SNARKV_FLAG_VALIDATE,
     PIP_STAGE_NAMES,
+    G1_PARTIAL_BYTES,
 )
 
 __all__ = [
@@ -26,4 +27,5 @@ __all__ = [
     "load_library",
     "SNARKV_FLAG_VALIDATE",
     "PIP_STAGE_NAMES",
+    "G1_PARTIAL_BYTES",
 ]

@@ -15,9 +15,10 @@ SNARKV_ERR_ARG = -5
 SNARKV_FLAG_VALIDATE = 1
 SNARKV_PIP_STAGES = 9
 PIP_STAGE_NAMES = [
-    "total", "to_montgomery", "digit_count", "scan", "digit_scatter",
-    "bucket_accumulate", "bucket_combine", "bucket_reduce", "window_fold",
+    "total", "to_montgomery", "digit_histogram", "scan", "partition_sort",
+    "launch_marker", "bulk_accumulate_combine_reduce_shift", "final_to_affine", "spare",
 ]
+G1_PARTIAL_BYTES = 144
 
 _ERR_NAMES = {
     SNARKV_ERR_EMPTY: "EMPTY (the reference panics here: native.rs:69 / msm.rs:265)",

@@ -105,6 +105,12 @@ void snarkv_ctx_destroy(snarkv_ctx* ctx) {
     if (ctx->buf[i]) (void)hipFree(ctx->buf[i]);
   if (ctx->ev_ready)
     for (int i = 0; i <= SNARKV_PIP_STAGES; ++i) (void)hipEventDestroy(ctx->ev[i]);
+  if (ctx->side_ready)
+    for (int i = 0; i < SNARKV_MAX_GROUPS; ++i) {
+      (void)hipStreamDestroy(ctx->side[i]);
+      (void)hipEventDestroy(ctx->ev_group[i]);
+      (void)hipEventDestroy(ctx->ev_side[i]);
+    }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -200,11 +206,11 @@ int snarkv_g1_msm_pippenger_dev(snarkv_ctx* ctx, const void* d_scalars32, const 
 }
 
 int snarkv_g1_msm_pippenger_partial_dev(snarkv_ctx* ctx, const void* d_scalars32, const void* d_points64,
-                                        size_t n, int window_bits, void* d_partial128) {
-  if (!ctx || !d_scalars32 || !d_points64 || !d_partial128) return SNARKV_ERR_ARG;
+                                        size_t n, int window_bits, void* d_partial) {
+  if (!ctx || !d_scalars32 || !d_points64 || !d_partial) return SNARKV_ERR_ARG;
   if (n == 0) return SNARKV_ERR_EMPTY;
   SNARKV_HIP(hipSetDevice(ctx->device));
-  return launch_msm_pippenger(ctx, d_scalars32, d_points64, n, window_bits, d_partial128, true);
+  return launch_msm_pippenger(ctx, d_scalars32, d_points64, n, window_bits, d_partial, true);
 }
 
 int snarkv_g1_fold_partials_dev(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64) {

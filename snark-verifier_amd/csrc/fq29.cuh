@@ -37,15 +37,8 @@ struct Fq29 {
 
 constexpr int32_t kMask29 = (1 << 29) - 1;
 
-// p in radix 2^29
-#define BN254_P29_LIMBS \
-  { 0x187cfd47, 0x10460b6c, 0x1c72a34f, 0x02d522d0, 0x1585d978, 0x02db40c0, 0x00a6e141, 0x0e5c2634, 0x0030644e }
-#define BN254_P29_NINV 0x1ba79989 /* -p^-1 mod 2^29 */
-// 2^261 mod p and 2^522 mod p, radix 2^29
-#define BN254_ONE29_LIMBS \
-  { 0x1d9d84b8, 0x0e5aed08, 0x0c8dd0c4, 0x16c7a13b, 0x0f1f8e1b, 0x17e4a5d7, 0x18e5f4df, 0x0bc6e61c, 0x0016a3ea }
-#define BN254_R2_29_LIMBS \
-  { 0x1e9bba24, 0x1a5c9d3c, 0x1bb36fa1, 0x08d5a4a1, 0x1a8cc51a, 0x1f3d0f79, 0x1a5ccd6a, 0x05c49fc4, 0x0001a7b8 }
+// radix-2^29 constants (BN254_P29_LIMBS, BN254_P29_NINV, BN254_ONE29_LIMBS,
+// BN254_R2_29_LIMBS) come from bn254_consts.h (gen_consts.py).
 
 SNARKV_HD int32_t fq29_p(int i) {
   constexpr int32_t p[9] = BN254_P29_LIMBS;

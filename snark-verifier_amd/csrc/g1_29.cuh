@@ -1,0 +1,282 @@
+// G1 group law over the lazy 9x29-bit field (fq29.cuh) -- the MSM hot loops.
+//
+// Two flavours of every adder:
+//   *_fast     branch-free formulas, NO exceptional-case tests.  If an addition
+//              ever meets P = +-Q (or a result is the identity) its ZZ becomes
+//              = 0 (mod p) and stays so through every later addition (ZZ3 =
+//              ZZ1*ZZ2*PP), so a caller checks `xyzz29_is_degenerate` ONCE at
+//              the end of its run and, if set, redoes the run with
+//   *_careful  the same formulas with the explicit P = Q / P = -Q / identity
+//              cases (duplicate and opposite bases are legal inputs: SURVEY.md
+//              section 7 "Exceptional cases").
+// Stored identity = all limbs of ZZ zero (exact), tested with a cheap OR.
+//
+// Limb/value bounds kept by the formulas (N = product output: limbs 0..7 in
+// [0,2^29), value in (-p/4, 5p/4)):
+//   acc.x   carry-normalised, value in (-4p, 2p)
+//   acc.y   lazy difference of two N: |limb| < 2^29, value in (-2p, 2p)
+//   acc.zz, acc.zzz   N
+// Every product below has one carry-normalised operand (< 2^29) and one with
+// |limb| < 2^30, inside the 2^59.6 budget of fq29_mul.
+#pragma once
+#include "fq29.cuh"
+
+namespace snarkv {
+
+struct G1Affine29 {  // Montgomery (R = 2^261), canonical limbs; identity = all zero
+  Fq29 x, y;
+};
+
+struct G1Xyzz29 {
+  Fq29 x, y, zz, zzz;
+};
+
+SNARKV_HD bool g1a29_is_identity(const G1Affine29& p) { return fq29_limbs_all_zero(p.x) && fq29_limbs_all_zero(p.y); }
+
+SNARKV_HD G1Xyzz29 xyzz29_identity() {
+  G1Xyzz29 r;
+  r.x = fq29_zero();
+  r.y = fq29_zero();
+  r.zz = fq29_zero();
+  r.zzz = fq29_zero();
+  return r;
+}
+
+// stored-identity test (exact zero limbs)
+SNARKV_HD bool xyzz29_is_identity(const G1Xyzz29& p) { return fq29_limbs_all_zero(p.zz); }
+
+// end-of-run test: ZZ = 0 (mod p) <=> an exceptional case happened (or the
+// true result is the identity)
+SNARKV_HD bool xyzz29_is_degenerate(const G1Xyzz29& p) { return fq29_is_zero_mod_p(p.zz); }
+
+SNARKV_HD G1Xyzz29 xyzz29_from_affine(const G1Affine29& p) {
+  if (g1a29_is_identity(p)) return xyzz29_identity();
+  G1Xyzz29 r;
+  r.x = p.x;
+  r.y = p.y;
+  r.zz = fq29_one();
+  r.zzz = fq29_one();
+  return r;
+}
+
+// ---- shared tail of madd / add: given U1 (=X1 scaled), S1, P, R (normalised) --
+//   X3 = R^2 - PPP - 2Q,  Y3 = R (Q - X3) - S1 PPP
+SNARKV_HD void xyzz29_finish(G1Xyzz29& acc, const Fq29& u1, const Fq29& s1, const Fq29& pn, const Fq29& rn,
+                             Fq29& pp, Fq29& ppp) {
+  pp = fq29_sqr(pn);
+  ppp = fq29_mul(pn, pp);
+  Fq29 q = fq29_mul(u1, pp);
+  Fq29 rr = fq29_sqr(rn);
+  Fq29 x3 = fq29_norm(fq29_sub(fq29_sub(rr, ppp), fq29_dbl(q)));  // limbs before norm in (-3*2^29, 2^29)
+  Fq29 t = fq29_sub(q, x3);                                         // |limb| < 2^29
+  Fq29 y3 = fq29_sub(fq29_mul(rn, t), fq29_mul(s1, ppp));
+  acc.x = x3;
+  acc.y = y3;
+}
+
+// acc += P (affine, non-identity), acc non-identity.  madd-2008-s, 8M + 2S.
+SNARKV_HD void xyzz29_madd_fast(G1Xyzz29& acc, const G1Affine29& p) {
+  Fq29 u2 = fq29_mul(p.x, acc.zz);
+  Fq29 s2 = fq29_mul(p.y, acc.zzz);
+  Fq29 pn = fq29_norm(fq29_sub(u2, acc.x));  // limbs (-2^29, 2^30) -> norm
+  Fq29 rn = fq29_norm(fq29_sub(s2, acc.y));
+  Fq29 pp, ppp;
+  Fq29 x1 = acc.x, y1 = acc.y;
+  xyzz29_finish(acc, x1, y1, pn, rn, pp, ppp);
+  acc.zz = fq29_mul(acc.zz, pp);
+  acc.zzz = fq29_mul(acc.zzz, ppp);
+}
+
+// acc += b, both non-identity.  add-2008-s, 12M + 2S.
+SNARKV_HD void xyzz29_add_fast(G1Xyzz29& acc, const G1Xyzz29& b) {
+  Fq29 u1 = fq29_mul(acc.x, b.zz);
+  Fq29 u2 = fq29_mul(b.x, acc.zz);
+  Fq29 s1 = fq29_mul(acc.y, b.zzz);
+  Fq29 s2 = fq29_mul(b.y, acc.zzz);
+  Fq29 pn = fq29_norm(fq29_sub(u2, u1));
+  Fq29 rn = fq29_norm(fq29_sub(s2, s1));
+  Fq29 pp, ppp;
+  xyzz29_finish(acc, u1, s1, pn, rn, pp, ppp);
+  acc.zz = fq29_mul(fq29_mul(acc.zz, b.zz), pp);
+  acc.zzz = fq29_mul(fq29_mul(acc.zzz, b.zzz), ppp);
+}
+
+// 2*P (dbl-2008-s-1, a = 0), P non-identity.
+SNARKV_HD G1Xyzz29 xyzz29_double(const G1Xyzz29& p) {
+  G1Xyzz29 r;
+  Fq29 u = fq29_norm(fq29_dbl(p.y));
+  Fq29 v = fq29_sqr(u);
+  Fq29 w = fq29_mul(u, v);
+  Fq29 s = fq29_mul(p.x, v);
+  Fq29 xx = fq29_sqr(p.x);  // p.x is carry-normalised by invariant
+  Fq29 m = fq29_norm(fq29_add(fq29_dbl(xx), xx));
+  r.x = fq29_norm(fq29_sub(fq29_sqr(m), fq29_dbl(s)));
+  r.y = fq29_sub(fq29_mul(m, fq29_sub(s, r.x)), fq29_mul(w, p.y));
+  r.zz = fq29_mul(v, p.zz);
+  r.zzz = fq29_mul(w, p.zzz);
+  return r;
+}
+
+SNARKV_HD G1Xyzz29 xyzz29_double_affine(const G1Affine29& p) {
+  G1Xyzz29 t;
+  t.x = p.x;
+  t.y = p.y;
+  t.zz = fq29_one();
+  t.zzz = fq29_one();
+  return xyzz29_double(t);
+}
+
+// ---- careful flavours: explicit exceptional cases --------------------------
+SNARKV_HD void xyzz29_madd_careful(G1Xyzz29& acc, const G1Affine29& p) {
+  if (g1a29_is_identity(p)) return;
+  if (xyzz29_is_identity(acc)) {
+    acc = xyzz29_from_affine(p);
+    return;
+  }
+  Fq29 u2 = fq29_mul(p.x, acc.zz);
+  Fq29 s2 = fq29_mul(p.y, acc.zzz);
+  Fq29 pn = fq29_norm(fq29_sub(u2, acc.x));
+  Fq29 rn = fq29_norm(fq29_sub(s2, acc.y));
+  if (fq29_is_zero_mod_p(pn)) {
+    if (fq29_is_zero_mod_p(rn)) {
+      acc = xyzz29_double_affine(p);
+    } else {
+      acc = xyzz29_identity();
+    }
+    return;
+  }
+  Fq29 pp, ppp;
+  Fq29 x1 = acc.x, y1 = acc.y;
+  xyzz29_finish(acc, x1, y1, pn, rn, pp, ppp);
+  acc.zz = fq29_mul(acc.zz, pp);
+  acc.zzz = fq29_mul(acc.zzz, ppp);
+}
+
+SNARKV_HD void xyzz29_add_careful(G1Xyzz29& acc, const G1Xyzz29& b) {
+  if (xyzz29_is_identity(b)) return;
+  if (xyzz29_is_identity(acc)) {
+    acc = b;
+    return;
+  }
+  Fq29 u1 = fq29_mul(acc.x, b.zz);
+  Fq29 u2 = fq29_mul(b.x, acc.zz);
+  Fq29 s1 = fq29_mul(acc.y, b.zzz);
+  Fq29 s2 = fq29_mul(b.y, acc.zzz);
+  Fq29 pn = fq29_norm(fq29_sub(u2, u1));
+  Fq29 rn = fq29_norm(fq29_sub(s2, s1));
+  if (fq29_is_zero_mod_p(pn)) {
+    if (fq29_is_zero_mod_p(rn)) {
+      acc = xyzz29_double(acc);
+    } else {
+      acc = xyzz29_identity();
+    }
+    return;
+  }
+  Fq29 pp, ppp;
+  xyzz29_finish(acc, u1, s1, pn, rn, pp, ppp);
+  acc.zz = fq29_mul(fq29_mul(acc.zz, b.zz), pp);
+  acc.zzz = fq29_mul(fq29_mul(acc.zzz, b.zzz), ppp);
+}
+
+// acc += b where either may be the stored identity (exact zero ZZ); fast
+// formulas otherwise.  A fast addition that meets an exceptional case leaves
+// ZZ = 0 (mod p), i.e. the integer 0 or p.  The integer 0 would later pass for
+// the stored identity, so it is caught HERE (`bad`, sticky); the value p keeps
+// its non-zero limbs, poisons everything it is added to, and is caught by the
+// caller's final `xyzz29_is_degenerate`.
+SNARKV_HD void xyzz29_add_skipid_fast(G1Xyzz29& acc, const G1Xyzz29& b, bool& bad) {
+  if (xyzz29_is_identity(b)) return;
+  if (xyzz29_is_identity(acc)) {
+    acc = b;
+    return;
+  }
+  xyzz29_add_fast(acc, b);
+  bad = bad || fq29_limbs_all_zero(acc.zz);
+}
+
+// Make a result storable: a degenerate ZZ (= 0 mod p but non-zero limbs) must
+// never reach memory as a non-identity.  Callers use it after a careful run.
+SNARKV_HD G1Xyzz29 xyzz29_sanitize(const G1Xyzz29& p) {
+  if (xyzz29_is_identity(p)) return xyzz29_identity();
+  return p;
+}
+
+// `to_affine`: canonical Montgomery affine; identity -> (0,0)
+SNARKV_HD G1Affine29 xyzz29_to_affine(const G1Xyzz29& p) {
+  G1Affine29 r;
+  if (xyzz29_is_identity(p) || xyzz29_is_degenerate(p)) {
+    r.x = fq29_zero();
+    r.y = fq29_zero();
+    return r;
+  }
+  Fq29 zn = fq29_norm(fq29_mul(p.zz, p.zzz));
+  Fq29 i = fq29_inv(zn);
+  Fq29 izz = fq29_mul(i, p.zzz);
+  Fq29 izzz = fq29_mul(i, p.zz);
+  r.x = fq29_mul(p.x, izz);
+  r.y = fq29_mul(fq29_norm(p.y), izzz);
+  return r;
+}
+
+SNARKV_HD G1Affine29 g1a29_from_canonical(const uint32_t w[16]) {
+  G1Affine29 r;
+  bool id = true;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) id = id && (w[i] == 0);
+  if (id) {
+    r.x = fq29_zero();
+    r.y = fq29_zero();
+    return r;
+  }
+  // canonical residues so that the stored affine point has limbs in [0, 2^29)
+  r.x = fq29_canon_residue(fq29_from_canonical(w));
+  r.y = fq29_canon_residue(fq29_from_canonical(w + 8));
+  return r;
+}
+
+SNARKV_HD void g1a29_to_canonical(const G1Affine29& p, uint32_t w[16]) {
+  fq29_to_canonical(p.x, w);
+  fq29_to_canonical(p.y, w + 8);
+}
+
+SNARKV_HD G1Affine29 g1a29_neg(const G1Affine29& p) {
+  G1Affine29 r;
+  r.x = p.x;
+  r.y = fq29_neg(p.y);
+  return r;
+}
+
+// k*P, 256-step double-and-add (`*base * scalar`, reference native.rs:67).
+// Canonical scalars (< r) never meet an exceptional case after the first
+// addition; non-canonical ones are caught by the degenerate check + careful redo.
+template <bool CAREFUL>
+SNARKV_HD G1Xyzz29 g1_29_scalar_mul(const G1Affine29& p, const uint32_t k[8]) {
+  G1Xyzz29 acc = xyzz29_identity();
+  if (g1a29_is_identity(p)) return acc;
+  bool started = false;
+  for (int i = 7; i >= 0; --i) {
+    uint32_t w = k[i];
+    for (int b = 31; b >= 0; --b) {
+      if (started) {
+        if (CAREFUL) {
+          if (!xyzz29_is_identity(acc)) acc = xyzz29_double(acc);
+        } else {
+          acc = xyzz29_double(acc);
+        }
+      }
+      if ((w >> b) & 1u) {
+        if (!started) {
+          acc = xyzz29_from_affine(p);
+          started = true;
+        } else if (CAREFUL) {
+          xyzz29_madd_careful(acc, p);
+        } else {
+          xyzz29_madd_fast(acc, p);
+        }
+      }
+    }
+  }
+  return acc;
+}
+
+}  // namespace snarkv

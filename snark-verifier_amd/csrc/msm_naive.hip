@@ -70,32 +70,6 @@ __global__ void __launch_bounds__(64) k_segment_fold(const G1Xyzz* __restrict__ 
   }
 }
 
-// Fold `count` projective partials (multi-GPU combine) into one
-// affine canonical point.  One block of 64 lanes.
-__global__ void __launch_bounds__(64) k_fold_partials(const G1Xyzz* __restrict__ partials, uint32_t count,
-                                                       uint32_t* __restrict__ out) {
-  __shared__ G1Xyzz sh[64];
-  uint32_t lane = threadIdx.x;
-  G1Xyzz acc = xyzz_identity();
-  for (uint32_t i = lane; i < count; i += 64) xyzz_add(acc, partials[i]);
-  sh[lane] = acc;
-  __syncthreads();
-  for (uint32_t s = 32; s >= 1; s >>= 1) {
-    if (lane < s) {
-      G1Xyzz a = sh[lane];
-      xyzz_add(a, sh[lane + s]);
-      sh[lane] = a;
-    }
-    __syncthreads();
-  }
-  if (lane == 0) {
-    G1Affine r = xyzz_to_affine(sh[0]);
-    uint32_t w[16];
-    g1a_to_canonical(r, w);
-    for (int i = 0; i < 16; ++i) out[i] = w[i];
-  }
-}
-
 // Optional input validation (SNARKV_FLAG_VALIDATE): canonical scalars (< r),
 // canonical coordinates (< p), on-curve.  bad[0] counts offenders.
 __global__ void k_validate(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points, uint32_t n,
@@ -133,13 +107,6 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
                      (const uint32_t*)d_points, (G1Xyzz*)d_terms, (uint32_t)n_terms);
   hipLaunchKernelGGL(k_segment_fold, dim3((uint32_t)n_msm), dim3(64), 0, ctx->stream, (const G1Xyzz*)d_terms,
                      (const uint32_t*)d_offsets, (uint32_t*)d_out);
-  SNARKV_HIP(hipGetLastError());
-  return SNARKV_OK;
-}
-
-int launch_fold_partials(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64) {
-  hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, ctx->stream, (const G1Xyzz*)d_partials,
-                     (uint32_t)count, (uint32_t*)d_out64);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }

@@ -8,42 +8,66 @@
 // shape has no parallelism, so the device algorithm is different while
 // producing the same group element (canonical after `to_affine`):
 //
-//   P0 k_to_mont        points: canonical LE -> Montgomery, once (HBM-resident copy)
-//   P1 k_digit_count    signed c-bit digits (half the buckets of msm.rs:269),
-//                       histogram of (window, |digit|) with device atomics
-//   P2 k_scan_*         exclusive scan of the histogram -> bucket offsets
-//   P3 k_digit_scatter  counting-sort scatter of (bucket, point index, sign)
-//   P4 k_accumulate     every lane owns a FIXED-LENGTH run of the sorted
-//                       stream (S entries) -- perfectly load-balanced whatever
-//                       the scalar distribution -- and emits a head partial, a
-//                       tail partial and complete interior buckets
-//                       (the `buckets[d-1].add_assign(base)` of msm.rs:291-296)
-//   P5 k_combine        per bucket: stitch the partials of the runs it spans
-//   P6 k_bucket_reduce  running-sum trick of msm.rs:298-302, chunked so that
-//                       >= 64 K lanes work; each chunk's sum is weighted by its
-//                       base index with a short double-and-add
-//   P7 k_sum_groups     per-window tree sum of the chunk partials (LDS)
-//   P8 k_window_fold    Horner over windows (the `result.double()` x c of
-//                       msm.rs:285-287) + `to_affine`, or the projective
-//                       partial for the multi-GPU fold.
+//   P0 k_to_mont         points: canonical LE -> 9x29-bit Montgomery, once
+//   S1 k_sort_level1<0>  signed c-bit digits (half the buckets of msm.rs:269);
+//                        per-tile LDS histogram of (window, high digit bits)
+//   S2 k_scan_*          exclusive scan of the key x tile matrix
+//   S3 k_sort_level1<1>  stable partition of (bucket, point, sign) by
+//                        (window, high bits) -- LDS cursors, no global atomics
+//   S4 k_sort_level2     one workgroup per (window, high bits): LDS counting
+//                        sort by the low digit bits; emits the bucket-sorted
+//                        stream plus per-bucket counts/offsets
+//   then, window GROUP by window group, top windows first:
+//   P4 k_accumulate      every lane owns a FIXED-LENGTH run of the sorted
+//                        stream (kRun entries) -- load-balanced whatever the
+//                        scalar distribution -- and emits a head partial, a
+//                        tail partial and complete interior buckets
+//                        (the `buckets[d-1].add_assign(base)` of msm.rs:291-296)
+//   P5 k_combine         per bucket: stitch the partials of the runs it spans
+//   P6 k_bucket_reduce   running-sum trick of msm.rs:298-302, chunked so that
+//                        >= 64 K lanes work; each chunk's sum is weighted by
+//                        its base index with a short double-and-add
+//   P7 k_sum_groups      per-window tree sum of the chunk partials (LDS)
+//   P8 k_shift_windows   T_w = 2^(c w) S_w, one lane per window (the
+//                        `result.double()` x c of msm.rs:285-287).  This is a
+//                        254-doubling dependency chain that no amount of lanes
+//                        shortens, so it runs on a SIDE STREAM, overlapped with
+//                        the bulk kernels of the lower window groups.
+//   P9 k_final           sum of the shifted window sums + `to_affine`, or the
+//                        projective partial for the multi-GPU fold.
+//
+// Field arithmetic is the lazy 9x29-bit form (fq29.cuh, g1_29.cuh): branch-free
+// "fast" adders, one degenerate-ZZ check per run and a careful redo only when an
+// exceptional case (P = +-Q, identity) was met.
 //
 // MFMA is deliberately unused: there is no dense contraction, the work is
-// 254-bit modular multiplication on the integer VALU (v_mad_u64_u32).
+// 254-bit modular multiplication on the integer VALU (v_mad_i64_i32).
 #include "ctx.hpp"
-#include "g1.cuh"
+#include "g1_29.cuh"
 
 namespace snarkv {
 
-constexpr int kRun = 32;         // P4: entries per lane
-constexpr int kChunk = 8;        // P6: buckets per lane
+constexpr int kRun = 32;          // P4: entries per lane
+constexpr int kChunk = 8;         // P6: buckets per lane
+constexpr int kTile = 4096;       // S1/S3: scalars per workgroup
+constexpr int kMaxHighBits = 7;   // S1: (window, high bits) keys per window <= 128
 constexpr uint32_t kNoBucket = 0xFFFFFFFFu;
 
 struct PipParams {
   uint32_t n;
-  int c;          // window bits
-  int W;          // windows = ceil(255 / c)
-  uint32_t B;     // buckets per window = 2^(c-1)  (signed digits)
-  uint32_t nb;    // W * B
+  int c;           // window bits
+  int W;           // windows = ceil(255 / c)
+  uint32_t B;      // buckets per window = 2^(c-1)  (signed digits)
+  uint32_t nb;     // W * B
+  int low_bits;    // S4 sorts by these low bits of (|digit|-1)
+  uint32_t SB;     // keys per window at level 1 = B >> low_bits
+  uint32_t nkeys;  // W * SB
+  uint32_t nblk;   // tiles
+};
+
+struct GroupParams {
+  int w_lo, w_hi;       // windows [w_lo, w_hi)
+  uint32_t run_base;    // first slot of this group in seg_ids / seg_parts
 };
 
 __device__ __forceinline__ uint32_t scalar_bits(const uint32_t* __restrict__ k, int lo, int c) {
@@ -54,8 +78,14 @@ __device__ __forceinline__ uint32_t scalar_bits(const uint32_t* __restrict__ k, 
   return (uint32_t)(v >> sh) & ((1u << c) - 1u);
 }
 
+__device__ __forceinline__ bool point_is_identity(const uint32_t* __restrict__ points, uint32_t i) {
+  const uint4* q = reinterpret_cast<const uint4*>(points + (size_t)i * 16);
+  uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+  return (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w | c.x | c.y | c.z | c.w | d.x | d.y | d.z | d.w) == 0;
+}
+
 // --------------------------------------------------------------- P0
-__global__ void k_to_mont(const uint32_t* __restrict__ points, G1Affine* __restrict__ out, uint32_t n) {
+__global__ void k_to_mont(const uint32_t* __restrict__ points, G1Affine29* __restrict__ out, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint4* s = reinterpret_cast<const uint4*>(points + (size_t)i * 16);
@@ -68,48 +98,66 @@ __global__ void k_to_mont(const uint32_t* __restrict__ points, G1Affine* __restr
     w[4 * j + 2] = v.z;
     w[4 * j + 3] = v.w;
   }
-  out[i] = g1a_from_canonical(w);
+  out[i] = g1a29_from_canonical(w);
 }
 
-// --------------------------------------------------------------- P1 / P3
+// --------------------------------------------------------------- S1 / S3
 // Signed-digit recoding: raw = bits + carry in [0, 2^c]; raw > 2^(c-1) becomes
 // raw - 2^c (negative) with a carry into the next window.  With W*c >= 255 and
-// scalars < r < 2^254 the top window never carries out.
+// scalars < r < 2^254 the top window never carries out.  Zero digits and
+// identity points contribute nothing and are dropped here.
+//
+// One workgroup = one tile of kTile scalars.  HIST: LDS histogram over the
+// (window, high digit bits) keys -> column `blockIdx` of the matrix M.
+// SCATTER: M has been scanned (key-major, tile-minor), so M[key][tile] is where
+// this tile's items of that key start; LDS cursors hand out the slots.
 template <bool SCATTER>
-__global__ void k_digits(const uint32_t* __restrict__ scalars, PipParams p, uint32_t* __restrict__ counts_or_cursor,
-                         uint2* __restrict__ entries) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.n) return;
-  const uint32_t* k = scalars + (size_t)i * 8;
-  uint32_t carry = 0;
-  for (int w = 0; w < p.W; ++w) {
-    uint32_t raw = scalar_bits(k, w * p.c, p.c) + carry;
-    uint32_t neg = raw > p.B ? 1u : 0u;
-    uint32_t d = neg ? ((1u << p.c) - raw) : raw;
-    carry = neg;
-    if (d != 0) {
-      uint32_t b = (uint32_t)w * p.B + d - 1;
-      if (SCATTER) {
-        uint32_t pos = atomicAdd(&counts_or_cursor[b], 1u);
-        entries[pos] = make_uint2(b, i | (neg << 31));
-      } else {
-        atomicAdd(&counts_or_cursor[b], 1u);
+__global__ void __launch_bounds__(256)
+    k_sort_level1(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points, PipParams p,
+                  uint32_t* __restrict__ M, uint2* __restrict__ tmp) {
+  extern __shared__ uint32_t lds[];  // nkeys counters / cursors
+  for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x)
+    lds[k] = SCATTER ? M[(size_t)k * p.nblk + blockIdx.x] : 0u;
+  __syncthreads();
+  uint32_t lo = blockIdx.x * kTile;
+  uint32_t hi = lo + kTile < p.n ? lo + kTile : p.n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    if (point_is_identity(points, i)) continue;
+    const uint32_t* k = scalars + (size_t)i * 8;
+    uint32_t carry = 0;
+    for (int w = 0; w < p.W; ++w) {
+      uint32_t raw = scalar_bits(k, w * p.c, p.c) + carry;
+      uint32_t neg = raw > p.B ? 1u : 0u;
+      uint32_t d = neg ? ((1u << p.c) - raw) : raw;
+      carry = neg;
+      if (d != 0) {
+        uint32_t key = (uint32_t)w * p.SB + ((d - 1) >> p.low_bits);
+        if (SCATTER) {
+          uint32_t pos = atomicAdd(&lds[key], 1u);
+          tmp[pos] = make_uint2((uint32_t)w * p.B + d - 1, i | (neg << 31));
+        } else {
+          atomicAdd(&lds[key], 1u);
+        }
       }
     }
   }
+  if (!SCATTER) {
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) M[(size_t)k * p.nblk + blockIdx.x] = lds[k];
+  }
 }
 
-// --------------------------------------------------------------- P2
-// Exclusive scan of `nb` counters: 1024 per block (256 lanes x 4), block sums
-// scanned by one block, then added back.  offsets[nb] = total.
-__global__ void __launch_bounds__(256) k_scan_local(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                    uint32_t* __restrict__ blocksum, uint32_t nb) {
+// --------------------------------------------------------------- S2
+// In-place exclusive scan of `nb` counters: 1024 per block (256 lanes x 4),
+// block sums scanned by one block, then added back.
+__global__ void __launch_bounds__(256) k_scan_local(uint32_t* __restrict__ data, uint32_t* __restrict__ blocksum,
+                                                    uint32_t nb) {
   __shared__ uint32_t sh[256];
   uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
   uint32_t v[4], s = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    v[j] = (base + j < nb) ? in[base + j] : 0;
+    v[j] = (base + j < nb) ? data[base + j] : 0;
     s += v[j];
   }
   sh[threadIdx.x] = s;
@@ -123,7 +171,7 @@ __global__ void __launch_bounds__(256) k_scan_local(const uint32_t* __restrict__
   uint32_t excl = sh[threadIdx.x] - s;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (base + j < nb) out[base + j] = excl;
+    if (base + j < nb) data[base + j] = excl;
     excl += v[j];
   }
   if (threadIdx.x == 255) blocksum[blockIdx.x] = sh[255];
@@ -155,83 +203,178 @@ __global__ void __launch_bounds__(1024) k_scan_blocksums(uint32_t* __restrict__ 
   if (threadIdx.x == 0) *total_out = running;
 }
 
-__global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
-                                                  const uint32_t* __restrict__ blocksum, uint32_t nb) {
+__global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ data, const uint32_t* __restrict__ blocksum,
+                                                  uint32_t nb) {
   uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
   uint32_t add = blocksum[blockIdx.x];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    if (base + j < nb) {
-      uint32_t v = offsets[base + j] + add;
-      offsets[base + j] = v;
-      cursor[base + j] = v;
-    }
+    if (base + j < nb) data[base + j] += add;
+}
+
+// --------------------------------------------------------------- S4
+// One workgroup per level-1 key (window, high bits): counting sort of its
+// slice of `tmp` by the low digit bits, entirely with LDS counters.
+__global__ void __launch_bounds__(256)
+    k_sort_level2(const uint2* __restrict__ tmp, const uint32_t* __restrict__ M, const uint32_t* __restrict__ total_ptr,
+                  PipParams p, uint2* __restrict__ entries, uint32_t* __restrict__ counts,
+                  uint32_t* __restrict__ offsets) {
+  extern __shared__ uint32_t lds[];  // (1 << low_bits) counters, then 256 scan words
+  const uint32_t nbins = 1u << p.low_bits;
+  uint32_t* hist = lds;
+  uint32_t* scan = lds + nbins;
+  uint32_t key = blockIdx.x;
+  uint32_t begin = M[(size_t)key * p.nblk];
+  uint32_t end = (key + 1 < p.nkeys) ? M[(size_t)(key + 1) * p.nblk] : *total_ptr;
+  for (uint32_t k = threadIdx.x; k < nbins; k += 256) hist[k] = 0;
+  __syncthreads();
+  const uint32_t low_mask = nbins - 1;
+  for (uint32_t e = begin + threadIdx.x; e < end; e += 256) atomicAdd(&hist[tmp[e].x & low_mask], 1u);
+  __syncthreads();
+  // exclusive scan of hist: each lane owns a contiguous strip
+  uint32_t per = (nbins + 255) / 256;
+  uint32_t s0 = threadIdx.x * per;
+  uint32_t sum = 0;
+  for (uint32_t k = s0; k < s0 + per && k < nbins; ++k) sum += hist[k];
+  scan[threadIdx.x] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < 256; off <<= 1) {
+    uint32_t t = (threadIdx.x >= off) ? scan[threadIdx.x - off] : 0;
+    __syncthreads();
+    scan[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t run = begin + scan[threadIdx.x] - sum;
+  uint32_t w = key / p.SB, sb = key % p.SB;
+  uint32_t bucket0 = w * p.B + (sb << p.low_bits);
+  for (uint32_t k = s0; k < s0 + per && k < nbins; ++k) {
+    uint32_t cnt = hist[k];
+    counts[bucket0 + k] = cnt;
+    offsets[bucket0 + k] = run;
+    hist[k] = run;  // becomes the cursor
+    run += cnt;
+  }
+  __syncthreads();
+  for (uint32_t e = begin + threadIdx.x; e < end; e += 256) {
+    uint2 it = tmp[e];
+    uint32_t pos = atomicAdd(&hist[it.x & low_mask], 1u);
+    entries[pos] = it;
+  }
 }
 
 // --------------------------------------------------------------- P4
-__global__ void __launch_bounds__(64)
-    k_accumulate(const uint2* __restrict__ entries, const uint32_t* __restrict__ total_ptr,
-                 const G1Affine* __restrict__ pts, G1Xyzz* __restrict__ buckets, uint32_t* __restrict__ seg_ids,
-                 G1Xyzz* __restrict__ seg_parts) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t total = *total_ptr;
-  uint64_t begin64 = (uint64_t)t * kRun;
-  if (begin64 >= total) return;
-  uint32_t begin = (uint32_t)begin64;
-  uint32_t end = (total - begin > (uint32_t)kRun) ? begin + kRun : total;
+// One lane = one run of kRun consecutive sorted entries of the window group.
+// Emits the partial of the run's first bucket (head), of its last bucket if
+// different (tail), and writes complete interior buckets straight to `buckets`.
+template <bool CAREFUL>
+__device__ __forceinline__ bool accumulate_run(const uint2* __restrict__ entries, uint32_t begin, uint32_t end,
+                                               const G1Affine29* __restrict__ pts, G1Xyzz29* __restrict__ buckets,
+                                               uint32_t* __restrict__ seg_ids, G1Xyzz29* __restrict__ seg_parts,
+                                               size_t slot) {
   uint32_t cur = entries[begin].x;
-  bool first = true;
-  G1Xyzz acc = xyzz_identity();
+  bool first = true, fresh = true, bad = false;
+  G1Xyzz29 acc = xyzz29_identity();
   for (uint32_t e = begin; e < end; ++e) {
     uint2 ent = entries[e];
     if (ent.x != cur) {
+      if (!CAREFUL) bad = bad || xyzz29_is_degenerate(acc);
       if (first) {
-        seg_ids[2 * (size_t)t] = cur;
-        seg_parts[2 * (size_t)t] = acc;
+        seg_ids[2 * slot] = cur;
+        seg_parts[2 * slot] = acc;
         first = false;
       } else {
         buckets[cur] = acc;  // complete interior bucket
       }
       cur = ent.x;
-      acc = xyzz_identity();
+      fresh = true;
+      if (CAREFUL) acc = xyzz29_identity();
     }
-    G1Affine p = pts[ent.y & 0x7FFFFFFFu];
-    if (ent.y >> 31) p.y = fq_neg(p.y);
-    xyzz_add_mixed(acc, p);
+    G1Affine29 p = pts[ent.y & 0x7FFFFFFFu];
+    if (ent.y >> 31) p.y = fq29_neg(p.y);
+    if (CAREFUL) {
+      xyzz29_madd_careful(acc, p);
+    } else if (fresh) {
+      acc.x = p.x;
+      acc.y = p.y;
+      acc.zz = fq29_one();
+      acc.zzz = fq29_one();
+      fresh = false;
+    } else {
+      xyzz29_madd_fast(acc, p);
+    }
   }
+  if (!CAREFUL) bad = bad || xyzz29_is_degenerate(acc);
   if (first) {
-    seg_ids[2 * (size_t)t] = cur;
-    seg_parts[2 * (size_t)t] = acc;
-    seg_ids[2 * (size_t)t + 1] = kNoBucket;
+    seg_ids[2 * slot] = cur;
+    seg_parts[2 * slot] = acc;
+    seg_ids[2 * slot + 1] = kNoBucket;
   } else {
-    seg_ids[2 * (size_t)t + 1] = cur;
-    seg_parts[2 * (size_t)t + 1] = acc;
+    seg_ids[2 * slot + 1] = cur;
+    seg_parts[2 * slot + 1] = acc;
   }
+  return bad;
+}
+
+__device__ __forceinline__ void group_range(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ total_ptr,
+                                            const PipParams& p, const GroupParams& g, uint32_t& start, uint32_t& end) {
+  start = offsets[(size_t)g.w_lo * p.B];
+  end = (g.w_hi < p.W) ? offsets[(size_t)g.w_hi * p.B] : *total_ptr;
+}
+
+__global__ void __launch_bounds__(64)
+    k_accumulate(const uint2* __restrict__ entries, const uint32_t* __restrict__ offsets,
+                 const uint32_t* __restrict__ total_ptr, PipParams p, GroupParams g,
+                 const G1Affine29* __restrict__ pts, G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ seg_ids,
+                 G1Xyzz29* __restrict__ seg_parts) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t start, stop;
+  group_range(offsets, total_ptr, p, g, start, stop);
+  uint64_t begin64 = (uint64_t)start + (uint64_t)t * kRun;
+  if (begin64 >= stop) return;
+  uint32_t begin = (uint32_t)begin64;
+  uint32_t end = (stop - begin > (uint32_t)kRun) ? begin + kRun : stop;
+  size_t slot = (size_t)g.run_base + t;
+  bool bad = accumulate_run<false>(entries, begin, end, pts, buckets, seg_ids, seg_parts, slot);
+  if (bad) accumulate_run<true>(entries, begin, end, pts, buckets, seg_ids, seg_parts, slot);  // rare: P = +-Q met
 }
 
 // --------------------------------------------------------------- P5
-__global__ void __launch_bounds__(64)
-    k_combine(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-              const uint32_t* __restrict__ seg_ids, const G1Xyzz* __restrict__ seg_parts,
-              G1Xyzz* __restrict__ buckets, uint32_t nb) {
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nb) return;
-  uint32_t cnt = counts[b];
-  if (cnt == 0) return;  // bucket array was zero-filled = identity
-  uint32_t o = offsets[b];
-  uint32_t t0 = o / kRun, t1 = (o + cnt - 1) / kRun;
-  G1Xyzz acc = xyzz_identity();
-  bool touched = false;
-  for (uint32_t t = t0; t <= t1; ++t) {
-    if (seg_ids[2 * (size_t)t] == b) {
-      xyzz_add(acc, seg_parts[2 * (size_t)t]);
-      touched = true;
-    }
-    if (seg_ids[2 * (size_t)t + 1] == b) {
-      xyzz_add(acc, seg_parts[2 * (size_t)t + 1]);
-      touched = true;
+template <bool CAREFUL>
+__device__ __forceinline__ bool combine_bucket(uint32_t b, size_t s0, size_t s1, const uint32_t* __restrict__ seg_ids,
+                                               const G1Xyzz29* __restrict__ seg_parts, G1Xyzz29& acc, bool& touched) {
+  acc = xyzz29_identity();
+  touched = false;
+  bool bad = false;
+  for (size_t s = s0; s <= s1; ++s) {
+    for (int h = 0; h < 2; ++h) {
+      if (seg_ids[2 * s + h] == b) {
+        if (CAREFUL) xyzz29_add_careful(acc, seg_parts[2 * s + h]);
+        else xyzz29_add_skipid_fast(acc, seg_parts[2 * s + h], bad);
+        touched = true;
+      }
     }
   }
+  if (CAREFUL) return false;
+  return bad || (!xyzz29_is_identity(acc) && xyzz29_is_degenerate(acc));
+}
+
+__global__ void __launch_bounds__(64)
+    k_combine(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+              const uint32_t* __restrict__ total_ptr, PipParams p, GroupParams g,
+              const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
+              G1Xyzz29* __restrict__ buckets) {
+  uint32_t b = (uint32_t)g.w_lo * p.B + blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= (uint32_t)g.w_hi * p.B) return;
+  uint32_t cnt = counts[b];
+  if (cnt == 0) return;  // bucket array was zero-filled = identity
+  uint32_t start, stop;
+  group_range(offsets, total_ptr, p, g, start, stop);
+  uint32_t o = offsets[b] - start;
+  size_t s0 = (size_t)g.run_base + o / kRun, s1 = (size_t)g.run_base + (o + cnt - 1) / kRun;
+  G1Xyzz29 acc;
+  bool touched;
+  if (combine_bucket<false>(b, s0, s1, seg_ids, seg_parts, acc, touched))
+    combine_bucket<true>(b, s0, s1, seg_ids, seg_parts, acc, touched);
   if (touched) buckets[b] = acc;
 }
 
@@ -239,68 +382,132 @@ __global__ void __launch_bounds__(64)
 // Lane (w, j) folds buckets [j*kChunk, (j+1)*kChunk) of window w:
 //   run = sum B_i ;  acc = sum (i - base + 1) B_i   (running-sum trick)
 //   partial = acc + base * run,   base = j*kChunk   (bucket i has weight i+1)
+template <bool CAREFUL>
+__device__ __forceinline__ bool reduce_chunk(const G1Xyzz29* __restrict__ bw, uint32_t base, uint32_t top,
+                                             G1Xyzz29& out) {
+  G1Xyzz29 run = xyzz29_identity(), acc = xyzz29_identity();
+  bool bad = false;
+  for (uint32_t i = top; i-- > base;) {
+    if (CAREFUL) {
+      xyzz29_add_careful(run, bw[i]);
+      xyzz29_add_careful(acc, run);
+    } else {
+      xyzz29_add_skipid_fast(run, bw[i], bad);
+      xyzz29_add_skipid_fast(acc, run, bad);
+    }
+  }
+  // base * run by double-and-add over the bits of base
+  G1Xyzz29 m = xyzz29_identity();
+  if (!xyzz29_is_identity(run)) {
+    for (int bit = 31 - __clz((int)(base | 1u)); bit >= 0; --bit) {
+      if (!xyzz29_is_identity(m)) m = xyzz29_double(m);
+      if ((base >> bit) & 1u) {
+        if (CAREFUL) xyzz29_add_careful(m, run);
+        else xyzz29_add_skipid_fast(m, run, bad);
+      }
+    }
+  }
+  if (CAREFUL) xyzz29_add_careful(acc, m);
+  else xyzz29_add_skipid_fast(acc, m, bad);
+  out = acc;
+  if (CAREFUL) return false;
+  // any degenerate intermediate poisons everything downstream of it
+  return bad || (!xyzz29_is_identity(run) && xyzz29_is_degenerate(run)) ||
+         (!xyzz29_is_identity(m) && xyzz29_is_degenerate(m)) ||
+         (!xyzz29_is_identity(acc) && xyzz29_is_degenerate(acc));
+}
+
 __global__ void __launch_bounds__(64)
-    k_bucket_reduce(const G1Xyzz* __restrict__ buckets, G1Xyzz* __restrict__ chunk_parts, PipParams p,
-                    uint32_t chunks_per_window) {
-  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= chunks_per_window * (uint32_t)p.W) return;
-  uint32_t w = g / chunks_per_window, j = g % chunks_per_window;
+    k_bucket_reduce(const G1Xyzz29* __restrict__ buckets, G1Xyzz29* __restrict__ chunk_parts, PipParams p,
+                    GroupParams g, uint32_t chunks_per_window) {
+  uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= chunks_per_window * (uint32_t)(g.w_hi - g.w_lo)) return;
+  uint32_t w = (uint32_t)g.w_lo + gi / chunks_per_window, j = gi % chunks_per_window;
   uint32_t base = j * kChunk;
   uint32_t top = base + kChunk < p.B ? base + kChunk : p.B;
-  const G1Xyzz* bw = buckets + (size_t)w * p.B;
-  G1Xyzz run = xyzz_identity(), acc = xyzz_identity();
-  for (uint32_t i = top; i-- > base;) {
-    xyzz_add(run, bw[i]);
-    xyzz_add(acc, run);
-  }
-  // base * run by double-and-add over the (<= 20) bits of base
-  G1Xyzz m = xyzz_identity();
-  for (int bit = 31 - __clz((int)(base | 1u)); bit >= 0; --bit) {
-    m = xyzz_double(m);
-    if ((base >> bit) & 1u) xyzz_add(m, run);
-  }
-  xyzz_add(acc, m);
-  chunk_parts[g] = acc;
+  const G1Xyzz29* bw = buckets + (size_t)w * p.B;
+  G1Xyzz29 out;
+  if (reduce_chunk<false>(bw, base, top, out)) reduce_chunk<true>(bw, base, top, out);
+  chunk_parts[(size_t)w * chunks_per_window + j] = out;
 }
 
 // --------------------------------------------------------------- P7
-// out[g] = sum of in[g*group .. (g+1)*group): 256 lanes stride + LDS tree.
+// out[w] = sum of the chunk partials of window w: 256 lanes stride + LDS tree.
+// (careful adders: tiny work, and a cooperative redo would cost more)
 __global__ void __launch_bounds__(256)
-    k_sum_groups(const G1Xyzz* __restrict__ in, G1Xyzz* __restrict__ out, uint32_t group) {
-  __shared__ G1Xyzz sh[256];
-  const G1Xyzz* src = in + (size_t)blockIdx.x * group;
-  G1Xyzz acc = xyzz_identity();
-  for (uint32_t i = threadIdx.x; i < group; i += 256) xyzz_add(acc, src[i]);
+    k_sum_groups(const G1Xyzz29* __restrict__ in, G1Xyzz29* __restrict__ out, uint32_t group, int w_lo) {
+  __shared__ G1Xyzz29 sh[256];
+  uint32_t w = (uint32_t)w_lo + blockIdx.x;
+  const G1Xyzz29* src = in + (size_t)w * group;
+  G1Xyzz29 acc = xyzz29_identity();
+  for (uint32_t i = threadIdx.x; i < group; i += 256) xyzz29_add_careful(acc, src[i]);
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (uint32_t s = 128; s >= 1; s >>= 1) {
     if (threadIdx.x < s) {
-      G1Xyzz a = sh[threadIdx.x];
-      xyzz_add(a, sh[threadIdx.x + s]);
+      G1Xyzz29 a = sh[threadIdx.x];
+      xyzz29_add_careful(a, sh[threadIdx.x + s]);
       sh[threadIdx.x] = a;
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+  if (threadIdx.x == 0) out[w] = sh[0];
 }
 
 // --------------------------------------------------------------- P8
+// shifted[w] = 2^(c w) * window_sums[w] for the windows of one group, one lane
+// per window (lane-divergent trip counts keep the arithmetic on the VALU: a
+// single-lane kernel is scalarised by the compiler into SALU multiply
+// emulation, 3x slower).
 __global__ void __launch_bounds__(64)
-    k_window_fold(const G1Xyzz* __restrict__ window_sums, PipParams p, uint32_t* __restrict__ out, int partial_out) {
-  if (threadIdx.x != 0) return;
-  G1Xyzz r = xyzz_identity();
-  for (int w = p.W - 1; w >= 0; --w) {
-    for (int k = 0; k < p.c; ++k) r = xyzz_double(r);
-    xyzz_add(r, window_sums[w]);
+    k_shift_windows(const G1Xyzz29* __restrict__ window_sums, G1Xyzz29* __restrict__ shifted, PipParams p,
+                    GroupParams g) {
+  int w = g.w_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (w >= g.w_hi) return;
+  G1Xyzz29 r = window_sums[w];
+  if (!xyzz29_is_identity(r)) {
+    int n = p.c * w;
+    for (int k = 0; k < n; ++k) r = xyzz29_double(r);
   }
-  if (partial_out) {
-    *reinterpret_cast<G1Xyzz*>(out) = r;
-  } else {
-    G1Affine a = xyzz_to_affine(r);
-    uint32_t w16[16];
-    g1a_to_canonical(a, w16);
-    for (int i = 0; i < 16; ++i) out[i] = w16[i];
+  shifted[w] = r;
+}
+
+// --------------------------------------------------------------- P9
+// result = sum_w shifted[w]; 64 lanes, LDS tree, then `to_affine` (or the
+// projective partial for the multi-GPU fold).  Also used for the fold itself.
+__global__ void __launch_bounds__(64)
+    k_final(const G1Xyzz29* __restrict__ parts, uint32_t count, uint32_t* __restrict__ out, int partial_out) {
+  __shared__ G1Xyzz29 sh[64];
+  uint32_t lane = threadIdx.x;
+  G1Xyzz29 acc = xyzz29_identity();
+  for (uint32_t i = lane; i < count; i += 64) xyzz29_add_careful(acc, parts[i]);
+  sh[lane] = acc;
+  __syncthreads();
+  for (uint32_t s = 32; s >= 1; s >>= 1) {
+    if (lane < s) {
+      G1Xyzz29 a = sh[lane];
+      xyzz29_add_careful(a, sh[lane + s]);
+      sh[lane] = a;
+    }
+    __syncthreads();
   }
+  if (lane == 0) {
+    if (partial_out) {
+      *reinterpret_cast<G1Xyzz29*>(out) = sh[0];
+    } else {
+      G1Affine29 r = xyzz29_to_affine(sh[0]);
+      uint32_t w[16];
+      g1a29_to_canonical(r, w);
+      for (int i = 0; i < 16; ++i) out[i] = w[i];
+    }
+  }
+}
+
+int launch_fold_partials(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64) {
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_partials, (uint32_t)count,
+                     (uint32_t*)d_out64, 0);
+  SNARKV_HIP(hipGetLastError());
+  return SNARKV_OK;
 }
 
 static int default_window_bits(size_t n) {
@@ -310,6 +517,17 @@ static int default_window_bits(size_t n) {
   if (c < 2) c = 2;
   if (c > 20) c = 20;
   return c;
+}
+
+static int ensure_side_streams(snarkv_ctx* ctx) {
+  if (ctx->side_ready) return SNARKV_OK;
+  for (int i = 0; i < SNARKV_MAX_GROUPS; ++i) {
+    SNARKV_HIP(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
+    SNARKV_HIP(hipEventCreateWithFlags(&ctx->ev_group[i], hipEventDisableTiming));
+    SNARKV_HIP(hipEventCreateWithFlags(&ctx->ev_side[i], hipEventDisableTiming));
+  }
+  ctx->side_ready = true;
+  return SNARKV_OK;
 }
 
 int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
@@ -322,30 +540,53 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   p.W = (255 + p.c - 1) / p.c;
   p.B = 1u << (p.c - 1);
   p.nb = (uint32_t)p.W * p.B;
+  int high = p.c - 1 < kMaxHighBits ? p.c - 1 : kMaxHighBits;
+  p.low_bits = (p.c - 1) - high;
+  p.SB = p.B >> p.low_bits;
+  p.nkeys = (uint32_t)p.W * p.SB;
+  p.nblk = (uint32_t)((n + kTile - 1) / kTile);
   uint64_t max_entries = (uint64_t)n * (uint64_t)p.W;
   if (n == 0 || max_entries >= 0xFFFFFFFFull || n >= 0x80000000ull) {
     set_last_error("pippenger: n=%zu out of range", n);
     return SNARKV_ERR_LENGTH;
   }
-  uint32_t nruns = (uint32_t)((max_entries + kRun - 1) / kRun);
-  uint32_t scan_blocks = (p.nb + 1023) / 1024;
+  // window groups, processed top-down; the shift chain of a group overlaps the
+  // bulk kernels of the groups below it
+  int ngroups = (n >= (1u << 16)) ? SNARKV_MAX_GROUPS : 1;
+  if (ngroups > p.W) ngroups = p.W;
+  GroupParams grp[SNARKV_MAX_GROUPS];
+  uint32_t max_runs[SNARKV_MAX_GROUPS];
+  uint32_t total_runs = 0;
+  for (int g = 0; g < ngroups; ++g) {
+    grp[g].w_lo = (int)((int64_t)p.W * g / ngroups);
+    grp[g].w_hi = (int)((int64_t)p.W * (g + 1) / ngroups);
+    uint64_t ent = (uint64_t)n * (uint64_t)(grp[g].w_hi - grp[g].w_lo);
+    max_runs[g] = (uint32_t)((ent + kRun - 1) / kRun);
+    grp[g].run_base = total_runs;
+    total_runs += max_runs[g];
+  }
+  uint32_t mcount = p.nkeys * p.nblk;
+  uint32_t scan_blocks = (mcount + 1023) / 1024;
   uint32_t chunks_per_window = (p.B + kChunk - 1) / kChunk;
 
-  void *d_pts, *d_counts, *d_offsets, *d_cursor, *d_blocksum, *d_entries, *d_seg_ids, *d_seg_parts, *d_buckets,
-      *d_chunk, *d_wsum, *d_misc;
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_POINTS_MONT, n * sizeof(G1Affine), &d_pts));
+  void *d_pts, *d_counts, *d_offsets, *d_M, *d_blocksum, *d_entries, *d_tmp, *d_seg_ids, *d_seg_parts, *d_buckets,
+      *d_chunk, *d_wsum, *d_shift, *d_misc;
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_POINTS_MONT, n * sizeof(G1Affine29), &d_pts));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_COUNTS, (size_t)p.nb * 4, &d_counts));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_OFFSETS, (size_t)p.nb * 4, &d_offsets));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_CURSOR, (size_t)p.nb * 4, &d_cursor));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_CURSOR, (size_t)mcount * 4, &d_M));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_BLOCKSUMS, (size_t)scan_blocks * 4 + 64, &d_blocksum));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_ENTRIES, max_entries * 8, &d_entries));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_SEG_IDS, (size_t)nruns * 8, &d_seg_ids));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_SEG_PARTIALS, (size_t)nruns * 2 * sizeof(G1Xyzz), &d_seg_parts));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_BUCKETS, (size_t)p.nb * sizeof(G1Xyzz), &d_buckets));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_CHUNK_PARTIALS, (size_t)chunks_per_window * p.W * sizeof(G1Xyzz), &d_chunk));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_WINDOW_SUMS, (size_t)p.W * sizeof(G1Xyzz), &d_wsum));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_SORT_TMP, max_entries * 8, &d_tmp));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_SEG_IDS, (size_t)total_runs * 8, &d_seg_ids));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_SEG_PARTIALS, (size_t)total_runs * 2 * sizeof(G1Xyzz29), &d_seg_parts));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_BUCKETS, (size_t)p.nb * sizeof(G1Xyzz29), &d_buckets));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_CHUNK_PARTIALS, (size_t)chunks_per_window * p.W * sizeof(G1Xyzz29), &d_chunk));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_WINDOW_SUMS, (size_t)p.W * sizeof(G1Xyzz29), &d_wsum));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_SHIFTED, (size_t)p.W * sizeof(G1Xyzz29), &d_shift));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_MISC, 64, &d_misc));
   uint32_t* d_total = (uint32_t*)d_misc;
+  if (ngroups > 1) SNARKV_TRY(ensure_side_streams(ctx));
 
   hipStream_t st = ctx->stream;
   bool tm = ctx->stage_timing;
@@ -360,38 +601,55 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   }
   STAGE_MARK();  // 0
   hipLaunchKernelGGL(k_to_mont, dim3((p.n + 255) / 256), dim3(256), 0, st, (const uint32_t*)d_points,
-                     (G1Affine*)d_pts, p.n);
-  STAGE_MARK();  // 1
-  SNARKV_HIP(hipMemsetAsync(d_counts, 0, (size_t)p.nb * 4, st));
-  hipLaunchKernelGGL(k_digits<false>, dim3((p.n + 255) / 256), dim3(256), 0, st, (const uint32_t*)d_scalars, p,
-                     (uint32_t*)d_counts, (uint2*)nullptr);
-  STAGE_MARK();  // 2
-  hipLaunchKernelGGL(k_scan_local, dim3(scan_blocks), dim3(256), 0, st, (const uint32_t*)d_counts,
-                     (uint32_t*)d_offsets, (uint32_t*)d_blocksum, p.nb);
+                     (G1Affine29*)d_pts, p.n);
+  STAGE_MARK();  // 1: to_montgomery
+  size_t lds1 = (size_t)p.nkeys * 4;
+  hipLaunchKernelGGL(k_sort_level1<false>, dim3(p.nblk), dim3(256), lds1, st, (const uint32_t*)d_scalars,
+                     (const uint32_t*)d_points, p, (uint32_t*)d_M, (uint2*)nullptr);
+  STAGE_MARK();  // 2: digit histogram
+  hipLaunchKernelGGL(k_scan_local, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (uint32_t*)d_blocksum, mcount);
   hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, st, (uint32_t*)d_blocksum, scan_blocks, d_total);
-  hipLaunchKernelGGL(k_scan_add, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_offsets, (uint32_t*)d_cursor,
-                     (const uint32_t*)d_blocksum, p.nb);
-  STAGE_MARK();  // 3
-  hipLaunchKernelGGL(k_digits<true>, dim3((p.n + 255) / 256), dim3(256), 0, st, (const uint32_t*)d_scalars, p,
-                     (uint32_t*)d_cursor, (uint2*)d_entries);
-  STAGE_MARK();  // 4
-  SNARKV_HIP(hipMemsetAsync(d_buckets, 0, (size_t)p.nb * sizeof(G1Xyzz), st));
-  hipLaunchKernelGGL(k_accumulate, dim3((nruns + 63) / 64), dim3(64), 0, st, (const uint2*)d_entries,
-                     (const uint32_t*)d_total, (const G1Affine*)d_pts, (G1Xyzz*)d_buckets, (uint32_t*)d_seg_ids,
-                     (G1Xyzz*)d_seg_parts);
-  STAGE_MARK();  // 5
-  hipLaunchKernelGGL(k_combine, dim3((p.nb + 63) / 64), dim3(64), 0, st, (const uint32_t*)d_counts,
-                     (const uint32_t*)d_offsets, (const uint32_t*)d_seg_ids, (const G1Xyzz*)d_seg_parts,
-                     (G1Xyzz*)d_buckets, p.nb);
-  STAGE_MARK();  // 6
-  hipLaunchKernelGGL(k_bucket_reduce, dim3((chunks_per_window * p.W + 63) / 64), dim3(64), 0, st,
-                     (const G1Xyzz*)d_buckets, (G1Xyzz*)d_chunk, p, chunks_per_window);
-  STAGE_MARK();  // 7
-  hipLaunchKernelGGL(k_sum_groups, dim3(p.W), dim3(256), 0, st, (const G1Xyzz*)d_chunk, (G1Xyzz*)d_wsum,
-                     chunks_per_window);
-  hipLaunchKernelGGL(k_window_fold, dim3(1), dim3(64), 0, st, (const G1Xyzz*)d_wsum, p, (uint32_t*)d_out,
+  hipLaunchKernelGGL(k_scan_add, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (const uint32_t*)d_blocksum,
+                     mcount);
+  STAGE_MARK();  // 3: scan
+  hipLaunchKernelGGL(k_sort_level1<true>, dim3(p.nblk), dim3(256), lds1, st, (const uint32_t*)d_scalars,
+                     (const uint32_t*)d_points, p, (uint32_t*)d_M, (uint2*)d_tmp);
+  size_t lds2 = ((size_t)(1u << p.low_bits) + 256) * 4;
+  hipLaunchKernelGGL(k_sort_level2, dim3(p.nkeys), dim3(256), lds2, st, (const uint2*)d_tmp, (const uint32_t*)d_M,
+                     (const uint32_t*)d_total, p, (uint2*)d_entries, (uint32_t*)d_counts, (uint32_t*)d_offsets);
+  STAGE_MARK();  // 4: partition + level-2 sort
+  SNARKV_HIP(hipMemsetAsync(d_buckets, 0, (size_t)p.nb * sizeof(G1Xyzz29), st));
+  // Each window group runs its whole bulk pipeline AND its shift chain on its
+  // own stream: the latency-bound stages of one group (reduce, window sums, the
+  // doubling chain) overlap the throughput-bound accumulate of the others.
+  if (ngroups > 1) SNARKV_HIP(hipEventRecord(ctx->ev_group[0], st));
+  for (int gi = ngroups - 1; gi >= 0; --gi) {
+    const GroupParams& g = grp[gi];
+    uint32_t nw = (uint32_t)(g.w_hi - g.w_lo);
+    hipStream_t gs = ngroups > 1 ? ctx->side[gi] : st;
+    if (ngroups > 1) SNARKV_HIP(hipStreamWaitEvent(gs, ctx->ev_group[0], 0));
+    hipLaunchKernelGGL(k_accumulate, dim3((max_runs[gi] + 63) / 64), dim3(64), 0, gs, (const uint2*)d_entries,
+                       (const uint32_t*)d_offsets, (const uint32_t*)d_total, p, g, (const G1Affine29*)d_pts,
+                       (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids, (G1Xyzz29*)d_seg_parts);
+    hipLaunchKernelGGL(k_combine, dim3((nw * p.B + 63) / 64), dim3(64), 0, gs, (const uint32_t*)d_counts,
+                       (const uint32_t*)d_offsets, (const uint32_t*)d_total, p, g, (const uint32_t*)d_seg_ids,
+                       (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets);
+    hipLaunchKernelGGL(k_bucket_reduce, dim3((chunks_per_window * nw + 63) / 64), dim3(64), 0, gs,
+                       (const G1Xyzz29*)d_buckets, (G1Xyzz29*)d_chunk, p, g, chunks_per_window);
+    hipLaunchKernelGGL(k_sum_groups, dim3(nw), dim3(256), 0, gs, (const G1Xyzz29*)d_chunk, (G1Xyzz29*)d_wsum,
+                       chunks_per_window, g.w_lo);
+    hipLaunchKernelGGL(k_shift_windows, dim3((nw + 63) / 64), dim3(64), 0, gs, (const G1Xyzz29*)d_wsum,
+                       (G1Xyzz29*)d_shift, p, g);
+    if (ngroups > 1) SNARKV_HIP(hipEventRecord(ctx->ev_side[gi], gs));
+  }
+  STAGE_MARK();  // 5: (launch marker; the group pipelines run on their own streams)
+  if (ngroups > 1)
+    for (int gi = 0; gi < ngroups; ++gi) SNARKV_HIP(hipStreamWaitEvent(st, ctx->ev_side[gi], 0));
+  STAGE_MARK();  // 6: bulk: accumulate + combine + reduce + window sums + shift chains, all groups
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, st, (const G1Xyzz29*)d_shift, (uint32_t)p.W, (uint32_t*)d_out,
                      partial_out ? 1 : 0);
-  STAGE_MARK();  // 8
+  STAGE_MARK();  // 7: final sum + to_affine
+  STAGE_MARK();  // 8: (spare)
 #undef STAGE_MARK
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;

@@ -92,3 +92,107 @@ def test_pairing_matches_oracle_value(hosttest_lib, golden_decider):
         L.ht_pairing_product(acc, g2 + ns_g2, 2, o)
         assert o.raw == bytes.fromhex(case["gt"]), case["name"]
         assert (o.raw == O.FQ12_ONE.to_bytes()) == case["accept"]
+
+
+# ---------------------------------------------------------------------------
+# 9x29-bit lazy field + group law (csrc/fq29.cuh, g1_29.cuh): the MSM hot path
+# ---------------------------------------------------------------------------
+def _rand_point(rng):
+    while True:
+        x = rng.randrange(O.P)
+        r = (x ** 3 + 3) % O.P
+        y = pow(r, (O.P + 1) // 4, O.P)
+        if y * y % O.P == r:
+            return (x, y)
+
+
+def test_fq29_mul_sqr_lazy(hosttest_lib):
+    L = hosttest_lib
+    rng = random.Random(5)
+    fb = O.fe_to_bytes
+    vals = [0, 1, 2, O.P - 1, O.P - 2, 1 << 253, (1 << 253) + 12345] + [rng.randrange(O.P) for _ in range(120)]
+    o = _buf(32)
+    for a in vals:
+        for b in vals[:10] + [rng.choice(vals)]:
+            L.ht29_fq_mul(fb(a), fb(b), o)
+            assert O.fe_from_bytes(o.raw) == a * b % O.P
+        L.ht29_fq_sqr(fb(a), o)
+        assert O.fe_from_bytes(o.raw) == a * a % O.P
+    for _ in range(200):
+        a, b, c, d, e = [rng.choice(vals) for _ in range(5)]
+        L.ht29_fq_lazy_expr(fb(a), fb(b), fb(c), fb(d), fb(e), o)
+        assert O.fe_from_bytes(o.raw) == ((a - b) * (c + d) - e) % O.P
+        assert L.ht29_is_zero_mod_p_of_diff(fb(a), fb(b)) == (1 if a == b else 0)
+        assert L.ht29_is_zero_mod_p_of_diff(fb(a), fb(a)) == 1
+    a = rng.randrange(1, O.P)
+    L.ht29_fq_inv(fb(a), o)
+    assert O.fe_from_bytes(o.raw) == pow(a, -1, O.P)
+
+
+def test_g1_29_fast_and_careful_adders(hosttest_lib):
+    L = hosttest_lib
+    rng = random.Random(6)
+    o = _buf(64)
+    for n in (1, 2, 3, 10, 40):
+        pts = [_rand_point(rng) for _ in range(n)]
+        sg = bytes(rng.randrange(2) for _ in range(n))
+        exp = None
+        for p, s in zip(pts, sg):
+            exp = O.g1_add(exp, O.g1_neg(p) if s else p)
+        raw = b"".join(O.g1_to_bytes(p) for p in pts)
+        for careful in (0, 1):
+            assert L.ht29_madd_chain(raw, sg, n, careful, o) == 0
+            assert O.g1_from_bytes(o.raw) == exp
+        tot = None
+        for p in pts:
+            tot = O.g1_add(tot, p)
+        for h in (0, 1, n // 2, n):
+            for careful in (0, 1):
+                assert L.ht29_add_halves(raw, n, h, careful, o) == 0
+                assert O.g1_from_bytes(o.raw) == tot
+
+
+def test_g1_29_exceptional_cases_are_flagged_then_handled(hosttest_lib):
+    """The fast adders must FLAG (degenerate ZZ) whatever they cannot compute;
+    the careful adders must compute it (duplicate / opposite bases are legal)."""
+    L = hosttest_lib
+    rng = random.Random(7)
+    p0, p1 = _rand_point(rng), _rand_point(rng)
+    s01 = O.g1_add(p0, p1)
+    o = _buf(64)
+    cases = [
+        ([p0, p0], [0, 0]), ([p0, p0], [0, 1]), ([p0, p1, p0], [0, 0, 0]), ([p0, p1, s01], [0, 0, 1]),
+        ([p0, None, p1], [0, 0, 0]), ([None, None], [0, 0]), ([p0, p1, s01, p1], [0, 0, 1, 0]),
+        ([p0, p1, s01], [0, 0, 0]),
+    ]
+    for pts, sg in cases:
+        exp = None
+        for p, s in zip(pts, sg):
+            exp = O.g1_add(exp, O.g1_neg(p) if s else p)
+        raw = b"".join(O.g1_to_bytes(p) for p in pts)
+        L.ht29_madd_chain(raw, bytes(sg), len(pts), 1, o)
+        assert O.g1_from_bytes(o.raw) == exp
+        if None not in pts:
+            flagged = L.ht29_madd_chain(raw, bytes(sg), len(pts), 0, o)
+            assert flagged == 1 or O.g1_from_bytes(o.raw) == exp
+    raw = O.g1_to_bytes(p0) + O.g1_to_bytes(p0)
+    assert L.ht29_add_halves(raw, 2, 1, 1, o) == 0 and O.g1_from_bytes(o.raw) == O.g1_double(p0)
+    assert L.ht29_add_halves(raw, 2, 1, 0, o) == 1
+    raw = O.g1_to_bytes(p0) + O.g1_to_bytes(O.g1_neg(p0))
+    L.ht29_add_halves(raw, 2, 1, 1, o)
+    assert O.g1_from_bytes(o.raw) is None
+    assert L.ht29_add_halves(raw, 2, 1, 0, o) == 1
+
+
+def test_g1_29_scalar_mul(hosttest_lib):
+    L = hosttest_lib
+    rng = random.Random(8)
+    p0 = _rand_point(rng)
+    o = _buf(64)
+    for k in [0, 1, 2, 3, 5, O.R - 1, rng.randrange(O.R), rng.randrange(O.R)]:
+        for careful in (0, 1):
+            L.ht29_g1_mul(O.g1_to_bytes(p0), int(k).to_bytes(32, "little"), careful, o)
+            assert O.g1_from_bytes(o.raw) == O.g1_mul(p0, k)
+    for k in [O.R, O.R + 1, O.R + 2, (1 << 256) - 1]:  # non-canonical scalars hit P = +-Q: careful path
+        L.ht29_g1_mul(O.g1_to_bytes(p0), int(k).to_bytes(32, "little"), 1, o)
+        assert O.g1_from_bytes(o.raw) == O.g1_mul(p0, k)

@@ -149,6 +149,8 @@ def test_full_size_2p20_properties(gpu_ctx):
     2^12-point prefix agrees with the C oracle."""
     import torch
 
+    import snark_verifier_amd as sv
+
     n = 1 << 20
     ds = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
     dp = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
@@ -156,7 +158,7 @@ def test_full_size_2p20_properties(gpu_ctx):
     gpu_ctx.sample_scalars_dev(0x5EED0001, n, ds.data_ptr())
     gpu_ctx.sample_points_dev(0x5EED0002, n, dp.data_ptr())
     out = torch.zeros(2, 64, dtype=torch.uint8, device="cuda")
-    parts = torch.zeros(2, 128, dtype=torch.uint8, device="cuda")
+    parts = torch.zeros(2, sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()  # the context runs on its own stream
     gpu_ctx.msm_pippenger_dev(ds.data_ptr(), dp.data_ptr(), n, out[0].data_ptr())
     gpu_ctx.sync()
