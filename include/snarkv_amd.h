@@ -140,11 +140,10 @@ int snarkv_sample_points_dev(snarkv_ctx* ctx, uint64_t seed, uint64_t first, siz
 
 /* ---- profiling hooks used by bench.py --------------------------------- *
  * Per-stage HIP-event timings (ms) of the last *_dev Pippenger call on this
- * context when enabled: [0]=total [1]=to_montgomery [2]=digit histogram
- * [3]=scan [4]=partition + level-2 sort [5]=launch marker [6]=bulk: bucket
- * accumulate + combine + reduce + window sums + window-shift chains of all
- * window groups (each group on its own stream) [7]=final sum + to_affine
- * [8]=spare.                                                                 */
+ * context when enabled: [0]=total [1]=prepare (GLV split, phi(P), Montgomery)
+ * [2]=digit histogram + scan [3]=partition + level-2 sort [4]=bucket
+ * accumulate [5]=bucket combine [6]=bucket reduce [7]=window sums + 2^(cw)
+ * shift chains [8]=final sum + to_affine.                                    */
 #define SNARKV_PIP_STAGES 9
 int snarkv_set_stage_timing(snarkv_ctx* ctx, int enabled);
 int snarkv_get_stage_timing(snarkv_ctx* ctx, float ms[SNARKV_PIP_STAGES]);

@@ -15,8 +15,8 @@ SNARKV_ERR_ARG = -5
 SNARKV_FLAG_VALIDATE = 1
 SNARKV_PIP_STAGES = 9
 PIP_STAGE_NAMES = [
-    "total", "to_montgomery", "digit_histogram", "scan", "partition_sort",
-    "launch_marker", "bulk_accumulate_combine_reduce_shift", "final_to_affine", "spare",
+    "total", "prepare_glv_montgomery", "digit_histogram_scan", "partition_sort", "bucket_accumulate",
+    "bucket_combine", "bucket_reduce", "window_shift_chain", "final_to_affine",
 ]
 G1_PARTIAL_BYTES = 144
 

@@ -105,12 +105,6 @@ void snarkv_ctx_destroy(snarkv_ctx* ctx) {
     if (ctx->buf[i]) (void)hipFree(ctx->buf[i]);
   if (ctx->ev_ready)
     for (int i = 0; i <= SNARKV_PIP_STAGES; ++i) (void)hipEventDestroy(ctx->ev[i]);
-  if (ctx->side_ready)
-    for (int i = 0; i < SNARKV_MAX_GROUPS; ++i) {
-      (void)hipStreamDestroy(ctx->side[i]);
-      (void)hipEventDestroy(ctx->ev_group[i]);
-      (void)hipEventDestroy(ctx->ev_side[i]);
-    }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

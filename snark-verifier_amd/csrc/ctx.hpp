@@ -6,8 +6,6 @@
 #include <stdio.h>
 #include "../../include/snarkv_amd.h"
 
-#define SNARKV_MAX_GROUPS 4
-
 namespace snarkv {
 
 void set_last_error(const char* fmt, ...);
@@ -49,6 +47,7 @@ enum Slot {
   SLOT_MISC,
   SLOT_SORT_TMP,
   SLOT_SHIFTED,
+  SLOT_GLV,
   SLOT_COUNT
 };
 
@@ -66,11 +65,6 @@ struct snarkv_ctx {
   float stage_ms[SNARKV_PIP_STAGES];
   hipEvent_t ev[SNARKV_PIP_STAGES + 1];
   bool ev_ready;
-  // side streams for the window-shift chains (one per window group)
-  hipStream_t side[SNARKV_MAX_GROUPS];
-  hipEvent_t ev_group[SNARKV_MAX_GROUPS];
-  hipEvent_t ev_side[SNARKV_MAX_GROUPS];
-  bool side_ready;
 };
 
 struct snarkv_dk {

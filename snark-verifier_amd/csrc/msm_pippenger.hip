@@ -8,7 +8,10 @@
 // shape has no parallelism, so the device algorithm is different while
 // producing the same group element (canonical after `to_affine`):
 //
-//   P0 k_to_mont         points: canonical LE -> 9x29-bit Montgomery, once
+//   P0 k_prepare        GLV split k = k1 + k2*lambda (|k_i| < 2^127, glv.cuh) and
+//                        points P, phi(P) = (beta x, y): canonical LE -> 9x29-bit
+//                        Montgomery, once.  2n half-width terms: the same number
+//                        of bucket additions, half the windows.
 //   S1 k_sort_level1<0>  signed c-bit digits (half the buckets of msm.rs:269);
 //                        per-tile LDS histogram of (window, high digit bits)
 //   S2 k_scan_*          exclusive scan of the key x tile matrix
@@ -17,7 +20,6 @@
 //   S4 k_sort_level2     one workgroup per (window, high bits): LDS counting
 //                        sort by the low digit bits; emits the bucket-sorted
 //                        stream plus per-bucket counts/offsets
-//   then, window GROUP by window group, top windows first:
 //   P4 k_accumulate      every lane owns a FIXED-LENGTH run of the sorted
 //                        stream (kRun entries) -- load-balanced whatever the
 //                        scalar distribution -- and emits a head partial, a
@@ -25,14 +27,12 @@
 //                        (the `buckets[d-1].add_assign(base)` of msm.rs:291-296)
 //   P5 k_combine         per bucket: stitch the partials of the runs it spans
 //   P6 k_bucket_reduce   running-sum trick of msm.rs:298-302, chunked so that
-//                        >= 64 K lanes work; each chunk's sum is weighted by
-//                        its base index with a short double-and-add
-//   P7 k_sum_groups      per-window tree sum of the chunk partials (LDS)
-//   P8 k_shift_windows   T_w = 2^(c w) S_w, one lane per window (the
-//                        `result.double()` x c of msm.rs:285-287).  This is a
-//                        254-doubling dependency chain that no amount of lanes
-//                        shortens, so it runs on a SIDE STREAM, overlapped with
-//                        the bulk kernels of the lower window groups.
+//                        >= 32 K lanes work; each chunk's sum is weighted by
+//                        its base index with a short double-and-add, then a
+//                        wave-level LDS tree leaves one partial per wavefront
+//   P8 k_shift_windows   one wavefront per window: tree-sum of the partials,
+//                        then T_w = 2^(c w) S_w (the `result.double()` x c of
+//                        msm.rs:285-287) -- the dependency chain GLV halves
 //   P9 k_final           sum of the shifted window sums + `to_affine`, or the
 //                        projective partial for the multi-GPU fold.
 //
@@ -44,6 +44,7 @@
 // 254-bit modular multiplication on the integer VALU (v_mad_i64_i32).
 #include "ctx.hpp"
 #include "g1_29.cuh"
+#include "glv.cuh"
 
 namespace snarkv {
 
@@ -56,7 +57,7 @@ constexpr uint32_t kNoBucket = 0xFFFFFFFFu;
 struct PipParams {
   uint32_t n;
   int c;           // window bits
-  int W;           // windows = ceil(255 / c)
+  int W;           // windows = ceil(128 / c)  (GLV half-scalars, |k| < 2^127)
   uint32_t B;      // buckets per window = 2^(c-1)  (signed digits)
   uint32_t nb;     // W * B
   int low_bits;    // S4 sorts by these low bits of (|digit|-1)
@@ -65,16 +66,13 @@ struct PipParams {
   uint32_t nblk;   // tiles
 };
 
-struct GroupParams {
-  int w_lo, w_hi;       // windows [w_lo, w_hi)
-  uint32_t run_base;    // first slot of this group in seg_ids / seg_parts
-};
-
-__device__ __forceinline__ uint32_t scalar_bits(const uint32_t* __restrict__ k, int lo, int c) {
-  if (lo >= 256) return 0;
+// c bits at offset lo of a 128-bit magnitude held in 4 registers
+__device__ __forceinline__ uint32_t half_bits(const uint32_t k[4], int lo, int c) {
+  if (lo >= 128) return 0;
   int word = lo >> 5, sh = lo & 31;
-  uint64_t v = k[word];
-  if (word + 1 < 8) v |= (uint64_t)k[word + 1] << 32;
+  uint32_t w0 = word == 0 ? k[0] : word == 1 ? k[1] : word == 2 ? k[2] : k[3];
+  uint32_t w1 = word == 0 ? k[1] : word == 1 ? k[2] : word == 2 ? k[3] : 0u;
+  uint64_t v = ((uint64_t)w1 << 32) | w0;
   return (uint32_t)(v >> sh) & ((1u << c) - 1u);
 }
 
@@ -85,7 +83,8 @@ __device__ __forceinline__ bool point_is_identity(const uint32_t* __restrict__ p
 }
 
 // --------------------------------------------------------------- P0
-__global__ void k_to_mont(const uint32_t* __restrict__ points, G1Affine29* __restrict__ out, uint32_t n) {
+__global__ void k_prepare(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points,
+                          G1Affine29* __restrict__ pts, uint4* __restrict__ glv, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint4* s = reinterpret_cast<const uint4*>(points + (size_t)i * 16);
@@ -98,14 +97,28 @@ __global__ void k_to_mont(const uint32_t* __restrict__ points, G1Affine29* __res
     w[4 * j + 2] = v.z;
     w[4 * j + 3] = v.w;
   }
-  out[i] = g1a29_from_canonical(w);
+  G1Affine29 a = g1a29_from_canonical(w);
+  pts[2 * (size_t)i] = a;
+  constexpr int32_t bl[9] = BN254_GLV_BETA29_LIMBS;
+  Fq29 beta;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) beta.v[j] = bl[j];
+  a.x = fq29_canon_residue(fq29_mul(a.x, beta));  // phi(P) = (beta x, y); identity stays (0,0)
+  pts[2 * (size_t)i + 1] = a;
+  const uint4* ks = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  uint4 k0 = ks[0], k1 = ks[1];
+  uint32_t k[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w}, o[8];
+  glv_decompose(k, o);
+  glv[2 * (size_t)i] = make_uint4(o[0], o[1], o[2], o[3]);
+  glv[2 * (size_t)i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
 // --------------------------------------------------------------- S1 / S3
 // Signed-digit recoding: raw = bits + carry in [0, 2^c]; raw > 2^(c-1) becomes
-// raw - 2^c (negative) with a carry into the next window.  With W*c >= 255 and
-// scalars < r < 2^254 the top window never carries out.  Zero digits and
-// identity points contribute nothing and are dropped here.
+// raw - 2^c (negative) with a carry into the next window.  With W*c >= 128 and
+// GLV magnitudes < 2^127 the top window never carries out.  A negative half
+// (sign in bit 127) flips every digit's sign.  Zero digits and identity points
+// contribute nothing and are dropped here.
 //
 // One workgroup = one tile of kTile scalars.  HIST: LDS histogram over the
 // (window, high digit bits) keys -> column `blockIdx` of the matrix M.
@@ -113,7 +126,7 @@ __global__ void k_to_mont(const uint32_t* __restrict__ points, G1Affine29* __res
 // this tile's items of that key start; LDS cursors hand out the slots.
 template <bool SCATTER>
 __global__ void __launch_bounds__(256)
-    k_sort_level1(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points, PipParams p,
+    k_sort_level1(const uint4* __restrict__ glv, const uint32_t* __restrict__ points, PipParams p,
                   uint32_t* __restrict__ M, uint2* __restrict__ tmp) {
   extern __shared__ uint32_t lds[];  // nkeys counters / cursors
   for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x)
@@ -123,20 +136,25 @@ __global__ void __launch_bounds__(256)
   uint32_t hi = lo + kTile < p.n ? lo + kTile : p.n;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     if (point_is_identity(points, i)) continue;
-    const uint32_t* k = scalars + (size_t)i * 8;
-    uint32_t carry = 0;
-    for (int w = 0; w < p.W; ++w) {
-      uint32_t raw = scalar_bits(k, w * p.c, p.c) + carry;
-      uint32_t neg = raw > p.B ? 1u : 0u;
-      uint32_t d = neg ? ((1u << p.c) - raw) : raw;
-      carry = neg;
-      if (d != 0) {
-        uint32_t key = (uint32_t)w * p.SB + ((d - 1) >> p.low_bits);
-        if (SCATTER) {
-          uint32_t pos = atomicAdd(&lds[key], 1u);
-          tmp[pos] = make_uint2((uint32_t)w * p.B + d - 1, i | (neg << 31));
-        } else {
-          atomicAdd(&lds[key], 1u);
+    for (uint32_t h = 0; h < 2; ++h) {
+      uint4 kv = glv[2 * (size_t)i + h];
+      uint32_t sgn = kv.w >> 31;
+      uint32_t k[4] = {kv.x, kv.y, kv.z, kv.w & 0x7FFFFFFFu};
+      uint32_t v = 2 * i + h;  // virtual point: P (h=0) or phi(P) (h=1)
+      uint32_t carry = 0;
+      for (int w = 0; w < p.W; ++w) {
+        uint32_t raw = half_bits(k, w * p.c, p.c) + carry;
+        uint32_t neg = raw > p.B ? 1u : 0u;
+        uint32_t d = neg ? ((1u << p.c) - raw) : raw;
+        carry = neg;
+        if (d != 0) {
+          uint32_t key = (uint32_t)w * p.SB + ((d - 1) >> p.low_bits);
+          if (SCATTER) {
+            uint32_t pos = atomicAdd(&lds[key], 1u);
+            tmp[pos] = make_uint2((uint32_t)w * p.B + d - 1, v | ((neg ^ sgn) << 31));
+          } else {
+            atomicAdd(&lds[key], 1u);
+          }
         }
       }
     }
@@ -315,25 +333,17 @@ __device__ __forceinline__ bool accumulate_run(const uint2* __restrict__ entries
   return bad;
 }
 
-__device__ __forceinline__ void group_range(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ total_ptr,
-                                            const PipParams& p, const GroupParams& g, uint32_t& start, uint32_t& end) {
-  start = offsets[(size_t)g.w_lo * p.B];
-  end = (g.w_hi < p.W) ? offsets[(size_t)g.w_hi * p.B] : *total_ptr;
-}
-
 __global__ void __launch_bounds__(64)
-    k_accumulate(const uint2* __restrict__ entries, const uint32_t* __restrict__ offsets,
-                 const uint32_t* __restrict__ total_ptr, PipParams p, GroupParams g,
+    k_accumulate(const uint2* __restrict__ entries, const uint32_t* __restrict__ total_ptr,
                  const G1Affine29* __restrict__ pts, G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ seg_ids,
                  G1Xyzz29* __restrict__ seg_parts) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t start, stop;
-  group_range(offsets, total_ptr, p, g, start, stop);
-  uint64_t begin64 = (uint64_t)start + (uint64_t)t * kRun;
+  uint32_t stop = *total_ptr;
+  uint64_t begin64 = (uint64_t)t * kRun;
   if (begin64 >= stop) return;
   uint32_t begin = (uint32_t)begin64;
   uint32_t end = (stop - begin > (uint32_t)kRun) ? begin + kRun : stop;
-  size_t slot = (size_t)g.run_base + t;
+  size_t slot = t;
   bool bad = accumulate_run<false>(entries, begin, end, pts, buckets, seg_ids, seg_parts, slot);
   if (bad) accumulate_run<true>(entries, begin, end, pts, buckets, seg_ids, seg_parts, slot);  // rare: P = +-Q met
 }
@@ -359,18 +369,15 @@ __device__ __forceinline__ bool combine_bucket(uint32_t b, size_t s0, size_t s1,
 }
 
 __global__ void __launch_bounds__(64)
-    k_combine(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-              const uint32_t* __restrict__ total_ptr, PipParams p, GroupParams g,
+    k_combine(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, PipParams p,
               const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
               G1Xyzz29* __restrict__ buckets) {
-  uint32_t b = (uint32_t)g.w_lo * p.B + blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= (uint32_t)g.w_hi * p.B) return;
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.nb) return;
   uint32_t cnt = counts[b];
   if (cnt == 0) return;  // bucket array was zero-filled = identity
-  uint32_t start, stop;
-  group_range(offsets, total_ptr, p, g, start, stop);
-  uint32_t o = offsets[b] - start;
-  size_t s0 = (size_t)g.run_base + o / kRun, s1 = (size_t)g.run_base + (o + cnt - 1) / kRun;
+  uint32_t o = offsets[b];
+  size_t s0 = o / kRun, s1 = (o + cnt - 1) / kRun;
   G1Xyzz29 acc;
   bool touched;
   if (combine_bucket<false>(b, s0, s1, seg_ids, seg_parts, acc, touched))
@@ -417,33 +424,25 @@ __device__ __forceinline__ bool reduce_chunk(const G1Xyzz29* __restrict__ bw, ui
          (!xyzz29_is_identity(acc) && xyzz29_is_degenerate(acc));
 }
 
+// One 64-lane block = 64 consecutive chunks of one window; the block's 64
+// partials are folded by an LDS tree (careful adders: tiny, and a cooperative
+// redo would cost more) -> wave_parts[w][blockInWindow].
 __global__ void __launch_bounds__(64)
-    k_bucket_reduce(const G1Xyzz29* __restrict__ buckets, G1Xyzz29* __restrict__ chunk_parts, PipParams p,
-                    GroupParams g, uint32_t chunks_per_window) {
-  uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gi >= chunks_per_window * (uint32_t)(g.w_hi - g.w_lo)) return;
-  uint32_t w = (uint32_t)g.w_lo + gi / chunks_per_window, j = gi % chunks_per_window;
-  uint32_t base = j * kChunk;
-  uint32_t top = base + kChunk < p.B ? base + kChunk : p.B;
-  const G1Xyzz29* bw = buckets + (size_t)w * p.B;
-  G1Xyzz29 out;
-  if (reduce_chunk<false>(bw, base, top, out)) reduce_chunk<true>(bw, base, top, out);
-  chunk_parts[(size_t)w * chunks_per_window + j] = out;
-}
-
-// --------------------------------------------------------------- P7
-// out[w] = sum of the chunk partials of window w: 256 lanes stride + LDS tree.
-// (careful adders: tiny work, and a cooperative redo would cost more)
-__global__ void __launch_bounds__(256)
-    k_sum_groups(const G1Xyzz29* __restrict__ in, G1Xyzz29* __restrict__ out, uint32_t group, int w_lo) {
-  __shared__ G1Xyzz29 sh[256];
-  uint32_t w = (uint32_t)w_lo + blockIdx.x;
-  const G1Xyzz29* src = in + (size_t)w * group;
-  G1Xyzz29 acc = xyzz29_identity();
-  for (uint32_t i = threadIdx.x; i < group; i += 256) xyzz29_add_careful(acc, src[i]);
-  sh[threadIdx.x] = acc;
+    k_bucket_reduce(const G1Xyzz29* __restrict__ buckets, G1Xyzz29* __restrict__ wave_parts, PipParams p,
+                    uint32_t chunks_per_window, uint32_t blocks_per_window) {
+  __shared__ G1Xyzz29 sh[64];
+  uint32_t w = blockIdx.x / blocks_per_window, bj = blockIdx.x % blocks_per_window;
+  uint32_t j = bj * 64 + threadIdx.x;
+  G1Xyzz29 out = xyzz29_identity();
+  if (j < chunks_per_window) {
+    uint32_t base = j * kChunk;
+    uint32_t top = base + kChunk < p.B ? base + kChunk : p.B;
+    const G1Xyzz29* bw = buckets + (size_t)w * p.B;
+    if (reduce_chunk<false>(bw, base, top, out)) reduce_chunk<true>(bw, base, top, out);
+  }
+  sh[threadIdx.x] = out;
   __syncthreads();
-  for (uint32_t s = 128; s >= 1; s >>= 1) {
+  for (uint32_t s = 32; s >= 1; s >>= 1) {
     if (threadIdx.x < s) {
       G1Xyzz29 a = sh[threadIdx.x];
       xyzz29_add_careful(a, sh[threadIdx.x + s]);
@@ -451,25 +450,44 @@ __global__ void __launch_bounds__(256)
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[w] = sh[0];
+  if (threadIdx.x == 0) wave_parts[blockIdx.x] = sh[0];
 }
 
 // --------------------------------------------------------------- P8
-// shifted[w] = 2^(c w) * window_sums[w] for the windows of one group, one lane
-// per window (lane-divergent trip counts keep the arithmetic on the VALU: a
-// single-lane kernel is scalarised by the compiler into SALU multiply
-// emulation, 3x slower).
+// One wavefront per window: S_w = sum of the window's wave partials (lane
+// stride + LDS tree), then shifted[w] = 2^(c w) S_w on lane 0.  The loop trip
+// count differs per block, never per lane, but the data is lane-private so the
+// arithmetic stays on the VALU (a uniform single-lane kernel gets scalarised
+// into SALU multiply emulation, 3x slower).
 __global__ void __launch_bounds__(64)
-    k_shift_windows(const G1Xyzz29* __restrict__ window_sums, G1Xyzz29* __restrict__ shifted, PipParams p,
-                    GroupParams g) {
-  int w = g.w_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (w >= g.w_hi) return;
-  G1Xyzz29 r = window_sums[w];
+    k_shift_windows(const G1Xyzz29* __restrict__ wave_parts, G1Xyzz29* __restrict__ shifted, PipParams p,
+                    uint32_t blocks_per_window) {
+  __shared__ G1Xyzz29 sh[64];
+  uint32_t w = blockIdx.x, lane = threadIdx.x;
+  const G1Xyzz29* src = wave_parts + (size_t)w * blocks_per_window;
+  G1Xyzz29 acc = xyzz29_identity();
+  for (uint32_t i = lane; i < blocks_per_window; i += 64) xyzz29_add_careful(acc, src[i]);
+  sh[lane] = acc;
+  __syncthreads();
+  for (uint32_t s = 32; s >= 1; s >>= 1) {
+    if (lane < s) {
+      G1Xyzz29 a = sh[lane];
+      xyzz29_add_careful(a, sh[lane + s]);
+      sh[lane] = a;
+    }
+    __syncthreads();
+  }
+  // every lane runs the chain on its own copy (lane-private registers)
+  G1Xyzz29 r = sh[0];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {  // pin the chain state to VGPRs (opaque to the uniformity analysis)
+    asm volatile("" : "+v"(r.x.v[i]), "+v"(r.y.v[i]), "+v"(r.zz.v[i]), "+v"(r.zzz.v[i]));
+  }
   if (!xyzz29_is_identity(r)) {
-    int n = p.c * w;
+    int n = p.c * (int)w;
     for (int k = 0; k < n; ++k) r = xyzz29_double(r);
   }
-  shifted[w] = r;
+  if (lane == 0) shifted[w] = r;
 }
 
 // --------------------------------------------------------------- P9
@@ -519,17 +537,6 @@ static int default_window_bits(size_t n) {
   return c;
 }
 
-static int ensure_side_streams(snarkv_ctx* ctx) {
-  if (ctx->side_ready) return SNARKV_OK;
-  for (int i = 0; i < SNARKV_MAX_GROUPS; ++i) {
-    SNARKV_HIP(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
-    SNARKV_HIP(hipEventCreateWithFlags(&ctx->ev_group[i], hipEventDisableTiming));
-    SNARKV_HIP(hipEventCreateWithFlags(&ctx->ev_side[i], hipEventDisableTiming));
-  }
-  ctx->side_ready = true;
-  return SNARKV_OK;
-}
-
 int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
                          void* d_out, bool partial_out) {
   PipParams p;
@@ -537,7 +544,7 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   p.c = window_bits > 0 ? window_bits : default_window_bits(n);
   if (p.c < 2) p.c = 2;
   if (p.c > 22) p.c = 22;
-  p.W = (255 + p.c - 1) / p.c;
+  p.W = (128 + p.c - 1) / p.c;
   p.B = 1u << (p.c - 1);
   p.nb = (uint32_t)p.W * p.B;
   int high = p.c - 1 < kMaxHighBits ? p.c - 1 : kMaxHighBits;
@@ -545,48 +552,34 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   p.SB = p.B >> p.low_bits;
   p.nkeys = (uint32_t)p.W * p.SB;
   p.nblk = (uint32_t)((n + kTile - 1) / kTile);
-  uint64_t max_entries = (uint64_t)n * (uint64_t)p.W;
-  if (n == 0 || max_entries >= 0xFFFFFFFFull || n >= 0x80000000ull) {
+  uint64_t max_entries = 2ull * (uint64_t)n * (uint64_t)p.W;
+  if (n == 0 || max_entries >= 0xFFFFFFFFull || n >= 0x40000000ull) {
     set_last_error("pippenger: n=%zu out of range", n);
     return SNARKV_ERR_LENGTH;
   }
-  // window groups, processed top-down; the shift chain of a group overlaps the
-  // bulk kernels of the groups below it
-  int ngroups = (n >= (1u << 16)) ? SNARKV_MAX_GROUPS : 1;
-  if (ngroups > p.W) ngroups = p.W;
-  GroupParams grp[SNARKV_MAX_GROUPS];
-  uint32_t max_runs[SNARKV_MAX_GROUPS];
-  uint32_t total_runs = 0;
-  for (int g = 0; g < ngroups; ++g) {
-    grp[g].w_lo = (int)((int64_t)p.W * g / ngroups);
-    grp[g].w_hi = (int)((int64_t)p.W * (g + 1) / ngroups);
-    uint64_t ent = (uint64_t)n * (uint64_t)(grp[g].w_hi - grp[g].w_lo);
-    max_runs[g] = (uint32_t)((ent + kRun - 1) / kRun);
-    grp[g].run_base = total_runs;
-    total_runs += max_runs[g];
-  }
+  uint32_t max_runs = (uint32_t)((max_entries + kRun - 1) / kRun);
   uint32_t mcount = p.nkeys * p.nblk;
   uint32_t scan_blocks = (mcount + 1023) / 1024;
   uint32_t chunks_per_window = (p.B + kChunk - 1) / kChunk;
+  uint32_t blocks_per_window = (chunks_per_window + 63) / 64;
 
-  void *d_pts, *d_counts, *d_offsets, *d_M, *d_blocksum, *d_entries, *d_tmp, *d_seg_ids, *d_seg_parts, *d_buckets,
-      *d_chunk, *d_wsum, *d_shift, *d_misc;
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_POINTS_MONT, n * sizeof(G1Affine29), &d_pts));
+  void *d_pts, *d_glv, *d_counts, *d_offsets, *d_M, *d_blocksum, *d_entries, *d_tmp, *d_seg_ids, *d_seg_parts,
+      *d_buckets, *d_wave, *d_shift, *d_misc;
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_POINTS_MONT, 2 * n * sizeof(G1Affine29), &d_pts));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_GLV, n * 32, &d_glv));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_COUNTS, (size_t)p.nb * 4, &d_counts));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_OFFSETS, (size_t)p.nb * 4, &d_offsets));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_CURSOR, (size_t)mcount * 4, &d_M));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_BLOCKSUMS, (size_t)scan_blocks * 4 + 64, &d_blocksum));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_ENTRIES, max_entries * 8, &d_entries));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SORT_TMP, max_entries * 8, &d_tmp));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_SEG_IDS, (size_t)total_runs * 8, &d_seg_ids));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_SEG_PARTIALS, (size_t)total_runs * 2 * sizeof(G1Xyzz29), &d_seg_parts));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_SEG_IDS, (size_t)max_runs * 8, &d_seg_ids));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_SEG_PARTIALS, (size_t)max_runs * 2 * sizeof(G1Xyzz29), &d_seg_parts));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_BUCKETS, (size_t)p.nb * sizeof(G1Xyzz29), &d_buckets));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_CHUNK_PARTIALS, (size_t)chunks_per_window * p.W * sizeof(G1Xyzz29), &d_chunk));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_WINDOW_SUMS, (size_t)p.W * sizeof(G1Xyzz29), &d_wsum));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_CHUNK_PARTIALS, (size_t)blocks_per_window * p.W * sizeof(G1Xyzz29), &d_wave));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SHIFTED, (size_t)p.W * sizeof(G1Xyzz29), &d_shift));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_MISC, 64, &d_misc));
   uint32_t* d_total = (uint32_t*)d_misc;
-  if (ngroups > 1) SNARKV_TRY(ensure_side_streams(ctx));
 
   hipStream_t st = ctx->stream;
   bool tm = ctx->stage_timing;
@@ -600,56 +593,41 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
     ctx->ev_ready = true;
   }
   STAGE_MARK();  // 0
-  hipLaunchKernelGGL(k_to_mont, dim3((p.n + 255) / 256), dim3(256), 0, st, (const uint32_t*)d_points,
-                     (G1Affine29*)d_pts, p.n);
-  STAGE_MARK();  // 1: to_montgomery
+  hipLaunchKernelGGL(k_prepare, dim3((p.n + 127) / 128), dim3(128), 0, st, (const uint32_t*)d_scalars,
+                     (const uint32_t*)d_points, (G1Affine29*)d_pts, (uint4*)d_glv, p.n);
+  STAGE_MARK();  // 1: prepare (GLV split, phi(P), to Montgomery)
   size_t lds1 = (size_t)p.nkeys * 4;
-  hipLaunchKernelGGL(k_sort_level1<false>, dim3(p.nblk), dim3(256), lds1, st, (const uint32_t*)d_scalars,
+  hipLaunchKernelGGL(k_sort_level1<false>, dim3(p.nblk), dim3(256), lds1, st, (const uint4*)d_glv,
                      (const uint32_t*)d_points, p, (uint32_t*)d_M, (uint2*)nullptr);
-  STAGE_MARK();  // 2: digit histogram
   hipLaunchKernelGGL(k_scan_local, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (uint32_t*)d_blocksum, mcount);
   hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, st, (uint32_t*)d_blocksum, scan_blocks, d_total);
   hipLaunchKernelGGL(k_scan_add, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (const uint32_t*)d_blocksum,
                      mcount);
-  STAGE_MARK();  // 3: scan
-  hipLaunchKernelGGL(k_sort_level1<true>, dim3(p.nblk), dim3(256), lds1, st, (const uint32_t*)d_scalars,
+  STAGE_MARK();  // 2: digit histogram + scan
+  hipLaunchKernelGGL(k_sort_level1<true>, dim3(p.nblk), dim3(256), lds1, st, (const uint4*)d_glv,
                      (const uint32_t*)d_points, p, (uint32_t*)d_M, (uint2*)d_tmp);
   size_t lds2 = ((size_t)(1u << p.low_bits) + 256) * 4;
   hipLaunchKernelGGL(k_sort_level2, dim3(p.nkeys), dim3(256), lds2, st, (const uint2*)d_tmp, (const uint32_t*)d_M,
                      (const uint32_t*)d_total, p, (uint2*)d_entries, (uint32_t*)d_counts, (uint32_t*)d_offsets);
-  STAGE_MARK();  // 4: partition + level-2 sort
+  STAGE_MARK();  // 3: partition + level-2 sort
   SNARKV_HIP(hipMemsetAsync(d_buckets, 0, (size_t)p.nb * sizeof(G1Xyzz29), st));
-  // Each window group runs its whole bulk pipeline AND its shift chain on its
-  // own stream: the latency-bound stages of one group (reduce, window sums, the
-  // doubling chain) overlap the throughput-bound accumulate of the others.
-  if (ngroups > 1) SNARKV_HIP(hipEventRecord(ctx->ev_group[0], st));
-  for (int gi = ngroups - 1; gi >= 0; --gi) {
-    const GroupParams& g = grp[gi];
-    uint32_t nw = (uint32_t)(g.w_hi - g.w_lo);
-    hipStream_t gs = ngroups > 1 ? ctx->side[gi] : st;
-    if (ngroups > 1) SNARKV_HIP(hipStreamWaitEvent(gs, ctx->ev_group[0], 0));
-    hipLaunchKernelGGL(k_accumulate, dim3((max_runs[gi] + 63) / 64), dim3(64), 0, gs, (const uint2*)d_entries,
-                       (const uint32_t*)d_offsets, (const uint32_t*)d_total, p, g, (const G1Affine29*)d_pts,
-                       (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids, (G1Xyzz29*)d_seg_parts);
-    hipLaunchKernelGGL(k_combine, dim3((nw * p.B + 63) / 64), dim3(64), 0, gs, (const uint32_t*)d_counts,
-                       (const uint32_t*)d_offsets, (const uint32_t*)d_total, p, g, (const uint32_t*)d_seg_ids,
-                       (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets);
-    hipLaunchKernelGGL(k_bucket_reduce, dim3((chunks_per_window * nw + 63) / 64), dim3(64), 0, gs,
-                       (const G1Xyzz29*)d_buckets, (G1Xyzz29*)d_chunk, p, g, chunks_per_window);
-    hipLaunchKernelGGL(k_sum_groups, dim3(nw), dim3(256), 0, gs, (const G1Xyzz29*)d_chunk, (G1Xyzz29*)d_wsum,
-                       chunks_per_window, g.w_lo);
-    hipLaunchKernelGGL(k_shift_windows, dim3((nw + 63) / 64), dim3(64), 0, gs, (const G1Xyzz29*)d_wsum,
-                       (G1Xyzz29*)d_shift, p, g);
-    if (ngroups > 1) SNARKV_HIP(hipEventRecord(ctx->ev_side[gi], gs));
-  }
-  STAGE_MARK();  // 5: (launch marker; the group pipelines run on their own streams)
-  if (ngroups > 1)
-    for (int gi = 0; gi < ngroups; ++gi) SNARKV_HIP(hipStreamWaitEvent(st, ctx->ev_side[gi], 0));
-  STAGE_MARK();  // 6: bulk: accumulate + combine + reduce + window sums + shift chains, all groups
+  hipLaunchKernelGGL(k_accumulate, dim3((max_runs + 63) / 64), dim3(64), 0, st, (const uint2*)d_entries,
+                     (const uint32_t*)d_total, (const G1Affine29*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
+                     (G1Xyzz29*)d_seg_parts);
+  STAGE_MARK();  // 4: bucket accumulate
+  hipLaunchKernelGGL(k_combine, dim3((p.nb + 63) / 64), dim3(64), 0, st, (const uint32_t*)d_counts,
+                     (const uint32_t*)d_offsets, p, (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts,
+                     (G1Xyzz29*)d_buckets);
+  STAGE_MARK();  // 5: bucket combine
+  hipLaunchKernelGGL(k_bucket_reduce, dim3(blocks_per_window * p.W), dim3(64), 0, st, (const G1Xyzz29*)d_buckets,
+                     (G1Xyzz29*)d_wave, p, chunks_per_window, blocks_per_window);
+  STAGE_MARK();  // 6: bucket reduce
+  hipLaunchKernelGGL(k_shift_windows, dim3(p.W), dim3(64), 0, st, (const G1Xyzz29*)d_wave, (G1Xyzz29*)d_shift, p,
+                     blocks_per_window);
+  STAGE_MARK();  // 7: window sums + 2^(cw) shift chains
   hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, st, (const G1Xyzz29*)d_shift, (uint32_t)p.W, (uint32_t*)d_out,
                      partial_out ? 1 : 0);
-  STAGE_MARK();  // 7: final sum + to_affine
-  STAGE_MARK();  // 8: (spare)
+  STAGE_MARK();  // 8: final sum + to_affine
 #undef STAGE_MARK
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;

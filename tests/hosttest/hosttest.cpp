@@ -5,6 +5,7 @@
 #include "../../snark-verifier_amd/csrc/g1.cuh"
 #include "../../snark-verifier_amd/csrc/pairing.cuh"
 #include "../../snark-verifier_amd/csrc/g1_29.cuh"
+#include "../../snark-verifier_amd/csrc/glv.cuh"
 
 using namespace snarkv;
 
@@ -175,5 +176,20 @@ void ht29_g1_mul(const uint8_t* p, const uint8_t* k, int careful, uint8_t* out) 
   memcpy(w, k, 32);
   G1Xyzz29 r = careful ? g1_29_scalar_mul<true>(load_g1_29(p), w) : g1_29_scalar_mul<false>(load_g1_29(p), w);
   store_g1_29(xyzz29_to_affine(r), out);
+}
+void ht_glv_decompose(const uint8_t* k, uint8_t* out32) {
+  uint32_t w[8], o[8];
+  memcpy(w, k, 32);
+  glv_decompose(w, o);
+  memcpy(out32, o, 32);
+}
+// phi(P) = (beta x, y) through the 29-bit field
+void ht29_glv_phi(const uint8_t* p, uint8_t* out) {
+  G1Affine29 a = load_g1_29(p);
+  constexpr int32_t b[9] = BN254_GLV_BETA29_LIMBS;
+  Fq29 beta;
+  for (int i = 0; i < 9; ++i) beta.v[i] = b[i];
+  a.x = fq29_mul(a.x, beta);
+  store_g1_29(a, out);
 }
 }
