@@ -121,6 +121,11 @@ int snarkv_kzg_decide_batch_dev(snarkv_ctx* ctx, const snarkv_dk* dk, const void
  * c0.c0.c0 .. c1.c2.c1) of e(lhs,g2)*e(rhs,-s_g2).                          */
 int snarkv_kzg_pairing_value(snarkv_ctx* ctx, const snarkv_dk* dk, const uint8_t acc128[128], uint8_t gt384[384]);
 
+/* Canonical-coordinate + on-curve check of n G1 points (the `C::from_xy(..)`
+ * of snark-verifier/src/pcs/kzg/accumulator.rs:76-77): SNARKV_OK or
+ * SNARKV_ERR_ENCODING.                                                      */
+int snarkv_g1_validate(snarkv_ctx* ctx, const uint8_t* points64, size_t n);
+
 /* ---- context-free entry points (process-global default context) -------- */
 int bn254_g1_msm_naive(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]);
 int bn254_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, const uint32_t* offsets, size_t n_msm,
@@ -130,6 +135,11 @@ int bn254_kzg_decide(const uint8_t g1_64[64], const uint8_t g2_128[128], const u
                      const uint8_t acc128[128]);
 int bn254_kzg_decide_batch(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],
                            const uint8_t* accs128, size_t m, uint8_t* ok);
+/* deciding key kept across calls (its G2 line tables stay in HBM) */
+int bn254_kzg_dk_create(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],
+                        snarkv_dk** out);
+int bn254_kzg_dk_decide_batch(const snarkv_dk* dk, const uint8_t* accs128, size_t m, uint8_t* ok);
+int bn254_g1_validate(const uint8_t* points64, size_t n);
 
 /* ---- synthetic inputs generated in HBM (bench/test utility) --- *
  * Seeded SplitMix64 streams -> canonical Fr scalars / G1 points, element

@@ -67,6 +67,10 @@ _SIGNATURES = {
     "bn254_g1_msm_pippenger": (_int, [_cp, _cp, _sz, _vp]),
     "bn254_kzg_decide": (_int, [_cp, _cp, _cp, _cp]),
     "bn254_kzg_decide_batch": (_int, [_cp, _cp, _cp, _cp, _sz, _vp]),
+    "snarkv_g1_validate": (_int, [_vp, _cp, _sz]),
+    "bn254_g1_validate": (_int, [_cp, _sz]),
+    "bn254_kzg_dk_create": (_int, [_cp, _cp, _cp, _pp]),
+    "bn254_kzg_dk_decide_batch": (_int, [_vp, _cp, _sz, _vp]),
     "snarkv_sample_scalars_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
     "snarkv_sample_points_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
     "snarkv_set_stage_timing": (_int, [_vp, _int]),

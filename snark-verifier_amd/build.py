@@ -53,7 +53,28 @@ def build(verbose=False):
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)
             raise RuntimeError("link failed")
+    build_host_driver()
     return LIB
+
+
+HOST = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(HERE, "libsnarkv_host.so")
+
+
+def build_host_driver():
+    """C++ host mirror (host/*.hpp) + its test driver -> libsnarkv_host.so,
+    linked against libsnarkv_amd.so next to it (rpath $ORIGIN)."""
+    srcs = [os.path.join(HOST, f) for f in os.listdir(HOST)]
+    newest = max([os.path.getmtime(f) for f in srcs] + [os.path.getmtime(LIB)])
+    if os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) >= newest:
+        return HOST_LIB
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", HOST_LIB, os.path.join(HOST, "test_driver.cpp"),
+           "-L" + HERE, "-lsnarkv_amd", "-Wl,-rpath,$ORIGIN"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("host driver build failed")
+    return HOST_LIB
 
 
 if __name__ == "__main__":

@@ -335,7 +335,41 @@ int snarkv_sample_points_dev(snarkv_ctx* ctx, uint64_t seed, uint64_t first, siz
   return launch_sample_points(ctx, seed, first, n, d_points64);
 }
 
+int snarkv_g1_validate(snarkv_ctx* ctx, const uint8_t* points64, size_t n) {
+  if (!ctx || !points64) return SNARKV_ERR_ARG;
+  if (n == 0) return SNARKV_OK;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  void* d_p;
+  SNARKV_TRY(stage_in(ctx, SLOT_IN_POINTS, points64, n * 64, &d_p));
+  int bad = 0;
+  SNARKV_TRY(launch_validate(ctx, nullptr, d_p, n, &bad));
+  if (bad) {
+    set_last_error("%d of %zu points are non-canonical or off-curve", bad, n);
+    return SNARKV_ERR_ENCODING;
+  }
+  return SNARKV_OK;
+}
+
 // ---- context-free entry points -------------------------------------------
+int bn254_g1_validate(const uint8_t* points64, size_t n) {
+  snarkv_ctx* c;
+  SNARKV_TRY(default_ctx(&c));
+  return snarkv_g1_validate(c, points64, n);
+}
+
+int bn254_kzg_dk_create(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],
+                        snarkv_dk** out) {
+  snarkv_ctx* c;
+  SNARKV_TRY(default_ctx(&c));
+  return snarkv_dk_create(c, g1_64, g2_128, s_g2_128, 0, out);
+}
+
+int bn254_kzg_dk_decide_batch(const snarkv_dk* dk, const uint8_t* accs128, size_t m, uint8_t* ok) {
+  snarkv_ctx* c;
+  SNARKV_TRY(default_ctx(&c));
+  return snarkv_kzg_decide_batch(c, dk, accs128, m, 0, ok);
+}
+
 int bn254_g1_msm_naive(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]) {
   snarkv_ctx* c;
   SNARKV_TRY(default_ctx(&c));

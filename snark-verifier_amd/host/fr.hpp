@@ -1,0 +1,182 @@
+// BN254 scalar field Fr on the HOST: the `LoadedScalar` of the native loader.
+//
+// The reference keeps every Fr computation of the accumulation path on the
+// host CPU (powers of r/u/v/mu/gamma, barycentric weights, batch inversion:
+// snark-verifier/src/pcs/kzg/accumulation.rs:52, multiopen/gwc19.rs:52-76,
+// multiopen/bdfg21.rs:173-223) and only the EC work reaches the loader's
+// `multi_scalar_multiplication`.  This mirror does the same: Fr here, G1/pairing
+// on the MI355X.  4 x 64-bit Montgomery (R = 2^256), the halo2curves layout.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace snarkv_host {
+
+class Fr {
+ public:
+  uint64_t v[4];  // Montgomery form
+
+  static constexpr uint64_t MOD[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull,
+                                      0x30644e72e131a029ull};
+  static constexpr uint64_t INV = 0xc2e1f593efffffffull;  // -r^-1 mod 2^64
+  static constexpr uint64_t ONE_M[4] = {0xac96341c4ffffffbull, 0x36fc76959f60cd29ull, 0x666ea36f7879462eull,
+                                        0x0e0a77c19a07df2full};
+  static constexpr uint64_t R2[4] = {0x1bb8e645ae216da7ull, 0x53fe3ab1e35c59e3ull, 0x8c49833d53bb8085ull,
+                                     0x0216d0b17f4e44a5ull};
+
+  Fr() : v{0, 0, 0, 0} {}
+  static Fr zero() { return Fr(); }
+  static Fr one() {
+    Fr r;
+    memcpy(r.v, ONE_M, 32);
+    return r;
+  }
+  static Fr from_u64(uint64_t x) {
+    Fr t;
+    t.v[0] = x;
+    return mont_mul(t, r2());
+  }
+  // 32-byte little-endian canonical (`PrimeField::from_repr`); false if >= r
+  static bool from_bytes(const uint8_t b[32], Fr* out) {
+    Fr t;
+    memcpy(t.v, b, 32);
+    if (!lt_mod(t.v)) return false;
+    *out = mont_mul(t, r2());
+    return true;
+  }
+  void to_bytes(uint8_t b[32]) const {  // `PrimeField::to_repr`
+    Fr one_raw;
+    one_raw.v[0] = 1;
+    Fr t = mont_mul(*this, one_raw);
+    memcpy(b, t.v, 32);
+  }
+  bool is_zero() const { return (v[0] | v[1] | v[2] | v[3]) == 0; }
+  bool operator==(const Fr& o) const { return memcmp(v, o.v, 32) == 0; }
+  bool operator!=(const Fr& o) const { return !(*this == o); }
+
+  Fr operator+(const Fr& o) const {
+    Fr r;
+    unsigned __int128 c = 0;
+    for (int i = 0; i < 4; ++i) {
+      c += (unsigned __int128)v[i] + o.v[i];
+      r.v[i] = (uint64_t)c;
+      c >>= 64;
+    }
+    reduce_once(r.v);
+    return r;
+  }
+  Fr operator-(const Fr& o) const {
+    Fr r;
+    unsigned __int128 br = 0;
+    for (int i = 0; i < 4; ++i) {
+      unsigned __int128 x = (unsigned __int128)v[i] - o.v[i] - (uint64_t)br;
+      r.v[i] = (uint64_t)x;
+      br = (x >> 64) & 1;
+    }
+    if (br) {
+      unsigned __int128 c = 0;
+      for (int i = 0; i < 4; ++i) {
+        c += (unsigned __int128)r.v[i] + MOD[i];
+        r.v[i] = (uint64_t)c;
+        c >>= 64;
+      }
+    }
+    return r;
+  }
+  Fr operator-() const { return Fr() - *this; }
+  Fr operator*(const Fr& o) const { return mont_mul(*this, o); }
+  Fr& operator+=(const Fr& o) { return *this = *this + o; }
+  Fr& operator-=(const Fr& o) { return *this = *this - o; }
+  Fr& operator*=(const Fr& o) { return *this = *this * o; }
+  Fr square() const { return mont_mul(*this, *this); }
+
+  Fr pow(const uint64_t e[4]) const {
+    Fr res = one();
+    for (int i = 3; i >= 0; --i)
+      for (int b = 63; b >= 0; --b) {
+        res = res.square();
+        if ((e[i] >> b) & 1) res = res * *this;
+      }
+    return res;
+  }
+  // `Field::invert`: None (false) for zero
+  bool invert(Fr* out) const {
+    if (is_zero()) return false;
+    uint64_t e[4] = {MOD[0] - 2, MOD[1], MOD[2], MOD[3]};
+    *out = pow(e);
+    return true;
+  }
+  // `LoadedScalar::powers` (reference loader.rs:71-78): 1, x, ..., x^(n-1)
+  std::vector<Fr> powers(size_t n) const {
+    std::vector<Fr> out;
+    out.reserve(n);
+    Fr cur = one();
+    for (size_t i = 0; i < n; ++i) {
+      out.push_back(cur);
+      cur = cur * *this;
+    }
+    return out;
+  }
+  // total order on canonical values (the reference needs `Ord` for BTreeSet/Map keys)
+  bool operator<(const Fr& o) const {
+    uint8_t a[32], b[32];
+    to_bytes(a);
+    o.to_bytes(b);
+    for (int i = 31; i >= 0; --i)
+      if (a[i] != b[i]) return a[i] < b[i];
+    return false;
+  }
+
+ private:
+  static Fr r2() {
+    Fr r;
+    memcpy(r.v, R2, 32);
+    return r;
+  }
+  static bool lt_mod(const uint64_t t[4]) {
+    for (int i = 3; i >= 0; --i)
+      if (t[i] != MOD[i]) return t[i] < MOD[i];
+    return false;
+  }
+  static void reduce_once(uint64_t t[4]) {
+    if (lt_mod(t)) return;
+    unsigned __int128 br = 0;
+    for (int i = 0; i < 4; ++i) {
+      unsigned __int128 x = (unsigned __int128)t[i] - MOD[i] - (uint64_t)br;
+      t[i] = (uint64_t)x;
+      br = (x >> 64) & 1;
+    }
+  }
+  static Fr mont_mul(const Fr& a, const Fr& b) {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+      unsigned __int128 c = 0;
+      for (int j = 0; j < 4; ++j) {
+        c += (unsigned __int128)a.v[i] * b.v[j] + t[j];
+        t[j] = (uint64_t)c;
+        c >>= 64;
+      }
+      c += t[4];
+      t[4] = (uint64_t)c;
+      t[5] = (uint64_t)(c >> 64);
+      uint64_t m = t[0] * INV;
+      c = ((unsigned __int128)m * MOD[0] + t[0]) >> 64;
+      for (int j = 1; j < 4; ++j) {
+        c += (unsigned __int128)m * MOD[j] + t[j];
+        t[j - 1] = (uint64_t)c;
+        c >>= 64;
+      }
+      c += t[4];
+      t[3] = (uint64_t)c;
+      t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    Fr r;
+    memcpy(r.v, t, 32);
+    reduce_once(r.v);
+    return r;
+  }
+};
+
+}  // namespace snarkv_host

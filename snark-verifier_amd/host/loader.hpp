@@ -1,0 +1,140 @@
+// Mirror of the reference's Loader abstraction for the native (value) loader,
+// with the EC work routed to the MI355X through the C ABI.
+//
+//   reference                                         here
+//   `EcPointLoader` / `ScalarLoader` / `Loader`       GpuNativeLoader
+//     snark-verifier/src/loader.rs:82-274
+//   `NativeLoader` (unit struct, global LOADER)       GpuNativeLoader (static fns,
+//     snark-verifier/src/loader/native.rs:11-93         process-global device context)
+//   `LoadedEcPoint = C`, `LoadedScalar = F`           G1Affine (64 canonical bytes), Fr
+//
+// `multi_scalar_multiplication` has no `&self` in the reference (loader.rs:108),
+// so the device state is process-global here too (the C ABI's default context).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/snarkv_amd.h"
+#include "fr.hpp"
+
+namespace snarkv_host {
+
+// `snark_verifier::Error` (reference snark-verifier/src/lib.rs:18-28)
+struct Error {
+  enum Kind { None = 0, InvalidInstances, InvalidProtocol, AssertionFailure, Transcript } kind = None;
+  std::string msg;
+  bool ok() const { return kind == None; }
+  static Error assertion(const std::string& m) { return Error{AssertionFailure, m}; }
+};
+
+// The reference PANICS in these spots (unwrap/assert); the mirror throws.
+struct Panic : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+// `G1Affine` as it crosses the boundary: x || y canonical LE; identity = zeros.
+struct G1Affine {
+  uint8_t b[64];
+  G1Affine() { memset(b, 0, 64); }
+  static G1Affine from_bytes(const uint8_t* p) {
+    G1Affine r;
+    memcpy(r.b, p, 64);
+    return r;
+  }
+  static G1Affine generator() {
+    G1Affine r;
+    r.b[0] = 1;
+    r.b[32] = 2;
+    return r;
+  }
+  static G1Affine identity() { return G1Affine(); }
+  bool is_identity() const {
+    for (int i = 0; i < 64; ++i)
+      if (b[i]) return false;
+    return true;
+  }
+  bool operator==(const G1Affine& o) const { return memcmp(b, o.b, 64) == 0; }
+};
+
+struct G2Affine {
+  uint8_t b[128];
+  static G2Affine from_bytes(const uint8_t* p) {
+    G2Affine r;
+    memcpy(r.b, p, 128);
+    return r;
+  }
+};
+
+struct GpuNativeLoader {
+  using LoadedScalar = Fr;
+  using LoadedEcPoint = G1Affine;
+
+  // ---- ScalarLoader (loader.rs:116-263)
+  static Fr load_const(const Fr& v) { return v; }
+  static Fr load_zero() { return Fr::zero(); }
+  static Fr load_one() { return Fr::one(); }
+  static Error assert_eq(const std::string& annotation, const Fr& l, const Fr& r) {
+    return l == r ? Error{} : Error::assertion(annotation);
+  }
+  // default `batch_invert`: per-element invert, zeros stay (loader.rs:255-262)
+  static void batch_invert(std::vector<Fr*>& values) {
+    for (Fr* v : values) {
+      Fr inv;
+      if (v->invert(&inv)) *v = inv;
+    }
+  }
+  static Fr sum_products(const std::vector<std::pair<Fr, Fr>>& terms) {
+    Fr acc;
+    for (auto& t : terms) acc += t.first * t.second;
+    return acc;
+  }
+
+  // ---- EcPointLoader (loader.rs:82-113)
+  static G1Affine ec_point_load_const(const G1Affine& v) { return v; }
+  static Error ec_point_assert_eq(const std::string& annotation, const G1Affine& l, const G1Affine& r) {
+    return l == r ? Error{} : Error::assertion(annotation);
+  }
+
+  // THE drop-in point: `NativeLoader::multi_scalar_multiplication`
+  // (reference snark-verifier/src/loader/native.rs:61-71) on the MI355X.
+  static G1Affine multi_scalar_multiplication(const std::vector<std::pair<const Fr*, const G1Affine*>>& pairs) {
+    if (pairs.empty()) throw Panic("multi_scalar_multiplication of no pairs (reference: reduce().unwrap(), native.rs:69)");
+    std::vector<uint8_t> s(32 * pairs.size()), p(64 * pairs.size());
+    for (size_t i = 0; i < pairs.size(); ++i) {
+      pairs[i].first->to_bytes(&s[32 * i]);
+      memcpy(&p[64 * i], pairs[i].second->b, 64);
+    }
+    G1Affine out;
+    int rc = bn254_g1_msm_naive(s.data(), p.data(), pairs.size(), out.b);
+    if (rc != SNARKV_OK) throw std::runtime_error(std::string("bn254_g1_msm_naive: ") + snarkv_last_error());
+    return out;
+  }
+
+  // Beyond the reference surface: several deferred MSMs in ONE segmented launch
+  // (what makes the GPU worthwhile for the many small MSMs of accumulation).
+  static std::vector<G1Affine> multi_scalar_multiplication_batch(
+      const std::vector<std::vector<std::pair<Fr, G1Affine>>>& msms) {
+    std::vector<uint8_t> s, p;
+    std::vector<uint32_t> offs(1, 0);
+    for (auto& m : msms) {
+      if (m.empty()) throw Panic("empty MSM in batch (reference: native.rs:69)");
+      for (auto& t : m) {
+        size_t o = s.size();
+        s.resize(o + 32);
+        t.first.to_bytes(&s[o]);
+        p.insert(p.end(), t.second.b, t.second.b + 64);
+      }
+      offs.push_back((uint32_t)(s.size() / 32));
+    }
+    std::vector<G1Affine> out(msms.size());
+    int rc = bn254_g1_msm_batched(s.data(), p.data(), offs.data(), msms.size(), out.empty() ? nullptr : out[0].b);
+    if (rc != SNARKV_OK) throw std::runtime_error(std::string("bn254_g1_msm_batched: ") + snarkv_last_error());
+    return out;
+  }
+};
+
+}  // namespace snarkv_host

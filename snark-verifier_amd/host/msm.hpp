@@ -1,0 +1,125 @@
+// Mirror of `util::msm::Msm` (reference snark-verifier/src/util/msm.rs:20-226):
+// the deferred linear combination  constant * G + sum scalar_i * base_i.
+#pragma once
+#include <optional>
+#include <vector>
+
+#include "loader.hpp"
+
+namespace snarkv_host {
+
+template <class L = GpuNativeLoader>
+class Msm {
+ public:
+  using Scalar = typename L::LoadedScalar;
+  using Point = typename L::LoadedEcPoint;
+
+  std::optional<Scalar> constant;
+  std::vector<Scalar> scalars;
+  std::vector<const Point*> bases;  // borrowed, as `&'a L::LoadedEcPoint`
+
+  Msm() = default;
+  // msm.rs:46-51
+  static Msm from_constant(const Scalar& c) {
+    Msm m;
+    m.constant = c;
+    return m;
+  }
+  // msm.rs:54-61
+  static Msm base(const Point* b) {
+    Msm m;
+    m.scalars.push_back(L::load_one());
+    m.bases.push_back(b);
+    return m;
+  }
+  size_t size() const { return bases.size(); }
+  // msm.rs:72-74
+  std::optional<Scalar> try_into_constant() const {
+    if (!bases.empty()) return std::nullopt;
+    if (!constant) throw Panic("try_into_constant on empty Msm (reference: unwrap, msm.rs:73)");
+    return constant;
+  }
+
+  // The (scalar, base) pairs `evaluate` hands to the loader: constant * gen
+  // first, then the terms in insertion order (msm.rs:81-98).
+  std::vector<std::pair<Scalar, Point>> pairs(const std::optional<Point>& gen) const {
+    std::vector<std::pair<Scalar, Point>> out;
+    if (constant) {
+      if (!gen) throw Panic("Msm has a constant but no generator was given (reference: unwrap, msm.rs:93)");
+      out.emplace_back(*constant, L::ec_point_load_const(*gen));
+    }
+    for (size_t i = 0; i < scalars.size(); ++i) out.emplace_back(scalars[i], *bases[i]);
+    return out;
+  }
+
+  // msm.rs:81-98
+  Point evaluate(const std::optional<Point>& gen) const {
+    auto prs = pairs(gen);
+    std::vector<std::pair<const Scalar*, const Point*>> refs;
+    refs.reserve(prs.size());
+    for (auto& pr : prs) refs.emplace_back(&pr.first, &pr.second);
+    return L::multi_scalar_multiplication(refs);
+  }
+
+  // msm.rs:100-107
+  void scale(const Scalar& f) {
+    if (constant) *constant *= f;
+    for (auto& s : scalars) s *= f;
+  }
+  // msm.rs:109-116: equal bases are merged
+  void push(const Scalar& s, const Point* b) {
+    for (size_t i = 0; i < bases.size(); ++i)
+      if (*bases[i] == *b) {
+        scalars[i] += s;
+        return;
+      }
+    scalars.push_back(s);
+    bases.push_back(b);
+  }
+  // msm.rs:118-127
+  void extend(const Msm& o) {
+    if (o.constant) {
+      if (constant) *constant += *o.constant;
+      else constant = o.constant;
+    }
+    for (size_t i = 0; i < o.scalars.size(); ++i) push(o.scalars[i], o.bases[i]);
+  }
+
+  // msm.rs:130-226
+  Msm operator+(const Msm& o) const {
+    Msm r = *this;
+    r.extend(o);
+    return r;
+  }
+  Msm& operator+=(const Msm& o) {
+    extend(o);
+    return *this;
+  }
+  Msm operator-() const {
+    Msm r = *this;
+    if (r.constant) r.constant = -*r.constant;
+    for (auto& s : r.scalars) s = -s;
+    return r;
+  }
+  Msm operator-(const Msm& o) const { return *this + (-o); }
+  Msm& operator-=(const Msm& o) { return *this += (-o); }
+  Msm operator*(const Scalar& f) const {
+    Msm r = *this;
+    r.scale(f);
+    return r;
+  }
+  Msm& operator*=(const Scalar& f) {
+    scale(f);
+    return *this;
+  }
+  template <class It>
+  static Msm sum(It first, It last) {
+    if (first == last) return Msm();
+    Msm acc = *first;
+    for (++first; first != last; ++first) acc.extend(*first);
+    return acc;
+  }
+  static Msm sum(const std::vector<Msm>& v) { return sum(v.begin(), v.end()); }
+};
+
+}  // namespace snarkv_host

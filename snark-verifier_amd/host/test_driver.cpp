@@ -1,0 +1,275 @@
+// Test driver for the C++ host mirror: exposes scenario functions with plain
+// byte buffers so the pytest suite can drive `Msm`, `KzgAs<Gwc19|Bdfg21>`,
+// `LimbsEncoding` and the decider exactly as the reference's callers do
+// (snark-verifier/examples/evm-verifier-with-accumulator.rs:357-380) and compare
+// with oracle/kzg.py.  Links against libsnarkv_amd.so (the HIP path).
+#include <cstdio>
+#include <cstring>
+
+#include "pcs.hpp"
+
+using namespace snarkv_host;
+
+namespace {
+
+struct Reader {
+  const uint8_t* p;
+  Fr fr() {
+    Fr x;
+    if (!Fr::from_bytes(p, &x)) throw Panic("non-canonical Fr in test input");
+    p += 32;
+    return x;
+  }
+  G1Affine g1() {
+    G1Affine x = G1Affine::from_bytes(p);
+    p += 64;
+    return x;
+  }
+  uint32_t u32() {
+    uint32_t v;
+    memcpy(&v, p, 4);
+    p += 4;
+    return v;
+  }
+};
+
+// Deterministic stand-in for the hash transcripts (out of the hot path): the
+// test supplies the challenges / points it wants "read".
+struct ScriptedTranscript : Transcript {
+  std::vector<Fr> challenges;
+  std::vector<G1Affine> points;
+  size_t ci = 0, pi = 0;
+  std::vector<G1Affine> absorbed, written;
+  Fr squeeze_challenge() override { return challenges.at(ci++); }
+  Error common_ec_point(const G1Affine& p) override {
+    absorbed.push_back(p);
+    return {};
+  }
+  Error common_scalar(const Fr&) override { return {}; }
+  Result<G1Affine> read_ec_point() override {
+    if (pi >= points.size()) return Result<G1Affine>::Err(Error{Error::Transcript, "eof"});
+    return Result<G1Affine>::Ok(points[pi++]);
+  }
+  Result<Fr> read_scalar() override { return Result<Fr>::Err(Error{Error::Transcript, "eof"}); }
+  Error write_ec_point(const G1Affine& p) override {
+    written.push_back(p);
+    return {};
+  }
+  Error write_scalar(const Fr&) override { return {}; }
+};
+
+// commitments: n, then per commitment: has_const(u32) [const] k(u32) {scalar, point} x k
+void read_commitments(Reader& rd, std::vector<std::vector<G1Affine>>& store, std::vector<MsmT>& out) {
+  uint32_t n = rd.u32();
+  store.resize(n);
+  std::vector<std::pair<std::optional<Fr>, std::vector<Fr>>> tmp(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (rd.u32()) tmp[i].first = rd.fr();
+    uint32_t k = rd.u32();
+    for (uint32_t j = 0; j < k; ++j) {
+      tmp[i].second.push_back(rd.fr());
+      store[i].push_back(rd.g1());
+    }
+  }
+  for (uint32_t i = 0; i < n; ++i) {
+    MsmT m;
+    if (tmp[i].first) m = MsmT::from_constant(*tmp[i].first);
+    for (size_t j = 0; j < store[i].size(); ++j) m += MsmT::base(&store[i][j]) * tmp[i].second[j];
+    out.push_back(m);
+  }
+}
+
+std::vector<Query<Fr>> read_queries(Reader& rd) {
+  uint32_t n = rd.u32();
+  std::vector<Query<Fr>> q;
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t poly = rd.u32();
+    Fr shift = rd.fr();
+    Fr ev = rd.fr();
+    q.push_back(Query<Fr>{poly, shift, ev});
+  }
+  return q;
+}
+
+int guarded(const std::function<int()>& f) {
+  try {
+    return f();
+  } catch (const Panic& e) {
+    fprintf(stderr, "panic: %s\n", e.what());
+    return -100;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "error: %s\n", e.what());
+    return -101;
+  }
+}
+
+}  // namespace
+
+#include <functional>
+
+extern "C" {
+
+// Fr self-test hooks
+void hd_fr_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  Fr x, y;
+  Fr::from_bytes(a, &x);
+  Fr::from_bytes(b, &y);
+  (x * y).to_bytes(out);
+}
+int hd_fr_inv(const uint8_t* a, uint8_t* out) {
+  Fr x, y;
+  Fr::from_bytes(a, &x);
+  if (!x.invert(&y)) return 0;
+  y.to_bytes(out);
+  return 1;
+}
+
+// Msm::evaluate through the loader (msm.rs:81-98): in = g(64) commitments-format with ONE Msm
+int hd_msm_evaluate(const uint8_t* in, int with_gen, uint8_t* out64) {
+  return guarded([&] {
+    Reader rd{in};
+    G1Affine g = rd.g1();
+    std::vector<std::vector<G1Affine>> store;
+    std::vector<MsmT> ms;
+    read_commitments(rd, store, ms);
+    G1Affine r = ms.at(0).evaluate(with_gen ? std::optional<G1Affine>(g) : std::nullopt);
+    memcpy(out64, r.b, 64);
+    return 0;
+  });
+}
+
+// Gwc19: in = g | commitments | z | queries | v | nws | ws | u ; out = lhs||rhs ; sizes[2] = MSM term counts
+int hd_gwc19_verify(const uint8_t* in, uint8_t* out128, uint32_t* sizes) {
+  return guarded([&] {
+    Reader rd{in};
+    KzgSuccinctVerifyingKey svk{rd.g1()};
+    std::vector<std::vector<G1Affine>> store;
+    std::vector<MsmT> commitments;
+    read_commitments(rd, store, commitments);
+    Fr z = rd.fr();
+    auto queries = read_queries(rd);
+    Gwc19Proof proof;
+    proof.v = rd.fr();
+    uint32_t nw = rd.u32();
+    for (uint32_t i = 0; i < nw; ++i) proof.ws.push_back(rd.g1());
+    proof.u = rd.fr();
+    auto ms = gwc19::msms(commitments, z, queries, proof);
+    sizes[0] = (uint32_t)ms.first.pairs(svk.g).size();
+    sizes[1] = (uint32_t)ms.second.pairs(svk.g).size();
+    auto acc = KzgAs<Gwc19>::pcs_verify(svk, commitments, z, queries, proof);
+    acc.value->to_bytes(out128);
+    return 0;
+  });
+}
+
+// Bdfg21: in = g | commitments | z | queries | mu | gamma | w | z_prime | w_prime
+int hd_bdfg21_verify(const uint8_t* in, uint8_t* out128, uint32_t* sizes) {
+  return guarded([&] {
+    Reader rd{in};
+    KzgSuccinctVerifyingKey svk{rd.g1()};
+    std::vector<std::vector<G1Affine>> store;
+    std::vector<MsmT> commitments;
+    read_commitments(rd, store, commitments);
+    Fr z = rd.fr();
+    auto queries = read_queries(rd);
+    Bdfg21Proof proof;
+    proof.mu = rd.fr();
+    proof.gamma = rd.fr();
+    proof.w = rd.g1();
+    proof.z_prime = rd.fr();
+    proof.w_prime = rd.g1();
+    auto ms = bdfg21::msms(commitments, z, queries, proof);
+    sizes[0] = (uint32_t)ms.first.pairs(svk.g).size();
+    sizes[1] = (uint32_t)ms.second.pairs(svk.g).size();
+    auto acc = KzgAs<Bdfg21>::pcs_verify(svk, commitments, z, queries, proof);
+    acc.value->to_bytes(out128);
+    return 0;
+  });
+}
+
+// KzgAs::read_proof + verify (accumulation.rs:30-63): m accumulators, challenge r,
+// optional blind pair read from the (scripted) transcript.
+int hd_kzg_as_verify(const uint8_t* accs128, uint32_t m, const uint8_t* r32, const uint8_t* blind128_or_null,
+                     uint8_t* out128) {
+  return guarded([&] {
+    std::vector<KzgAccumulator> instances;
+    for (uint32_t i = 0; i < m; ++i)
+      instances.push_back(KzgAccumulator{G1Affine::from_bytes(accs128 + 128 * i), G1Affine::from_bytes(accs128 + 128 * i + 64)});
+    ScriptedTranscript t;
+    Fr r;
+    if (!Fr::from_bytes(r32, &r)) return -3;
+    t.challenges.push_back(r);
+    KzgAsVerifyingKey vk{blind128_or_null != nullptr};
+    if (blind128_or_null) {
+      t.points.push_back(G1Affine::from_bytes(blind128_or_null));
+      t.points.push_back(G1Affine::from_bytes(blind128_or_null + 64));
+    }
+    auto proof = KzgAs<Gwc19>::read_proof(vk, instances, t);
+    if (!proof.ok()) return -4;
+    if (t.absorbed.size() != 2 * m) return -5;  // every lhs/rhs absorbed (accumulation.rs:124-127)
+    auto acc = KzgAs<Gwc19>::verify(vk, instances, *proof.value);
+    acc.value->to_bytes(out128);
+    return 0;
+  });
+}
+
+// prover twin (accumulation.rs:148-197), zk: pk = (g, s*g), blind scalar given
+int hd_kzg_as_create_proof(const uint8_t* accs128, uint32_t m, const uint8_t* r32, const uint8_t* pk128_or_null,
+                           const uint8_t* blind_scalar32, uint8_t* out128, uint8_t* written128) {
+  return guarded([&] {
+    std::vector<KzgAccumulator> instances;
+    for (uint32_t i = 0; i < m; ++i)
+      instances.push_back(KzgAccumulator{G1Affine::from_bytes(accs128 + 128 * i), G1Affine::from_bytes(accs128 + 128 * i + 64)});
+    ScriptedTranscript t;
+    Fr r, bs;
+    Fr::from_bytes(r32, &r);
+    t.challenges.push_back(r);
+    KzgAsProvingKey pk;
+    if (pk128_or_null) {
+      pk.g = std::make_pair(G1Affine::from_bytes(pk128_or_null), G1Affine::from_bytes(pk128_or_null + 64));
+      Fr::from_bytes(blind_scalar32, &bs);
+    }
+    auto acc = KzgAs<Bdfg21>::create_proof(pk, instances, t, bs);
+    acc.value->to_bytes(out128);
+    if (pk128_or_null && written128) {
+      memcpy(written128, t.written.at(0).b, 64);
+      memcpy(written128 + 64, t.written.at(1).b, 64);
+    }
+    return 0;
+  });
+}
+
+// decide / decide_all (decider.rs:70-93): returns 1 Ok(()), 0 Err(AssertionFailure)
+int hd_decide_all(const uint8_t* g1, const uint8_t* g2, const uint8_t* s_g2, const uint8_t* accs128, uint32_t m,
+                  int one_by_one) {
+  return guarded([&] {
+    KzgDecidingKey dk(G1Affine::from_bytes(g1), G2Affine::from_bytes(g2), G2Affine::from_bytes(s_g2));
+    std::vector<KzgAccumulator> accs;
+    for (uint32_t i = 0; i < m; ++i)
+      accs.push_back(KzgAccumulator{G1Affine::from_bytes(accs128 + 128 * i), G1Affine::from_bytes(accs128 + 128 * i + 64)});
+    if (one_by_one) {
+      for (auto& a : accs)
+        if (!KzgAs<Gwc19>::decide(dk, a).ok()) return 0;
+      return 1;
+    }
+    return KzgAs<Gwc19>::decide_all(dk, accs).ok() ? 1 : 0;
+  });
+}
+
+// LimbsEncoding<4,68>: 16 Fr limbs -> accumulator -> 16 limbs again
+int hd_limbs_roundtrip(const uint8_t* limbs16x32, uint8_t* out128, uint8_t* limbs_out16x32) {
+  return guarded([&] {
+    std::vector<Fr> ls(16);
+    std::vector<const Fr*> refs;
+    for (int i = 0; i < 16; ++i) {
+      if (!Fr::from_bytes(limbs16x32 + 32 * i, &ls[i])) return -3;
+      refs.push_back(&ls[i]);
+    }
+    auto acc = LimbsEncoding<4, 68>::from_repr(refs);
+    acc.value->to_bytes(out128);
+    auto back = LimbsEncoding<4, 68>::to_limbs(*acc.value);
+    for (int i = 0; i < 16; ++i) back[i].to_bytes(limbs_out16x32 + 32 * i);
+    return 0;
+  });
+}
+}
