@@ -95,6 +95,7 @@ def main():
         if world == 1:
             ctx.msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, out.data_ptr(), args.window_bits)
         else:
+            # snark-verifier_amd/distributed.py: shard -> HIP partial -> RCCL all-gather (144 B/rank) -> HIP fold
             ctx.msm_pippenger_partial_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, partial.data_ptr(),
                                           args.window_bits)
             dist.all_gather_into_tensor(gathered, partial)

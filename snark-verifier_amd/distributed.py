@@ -1,0 +1,75 @@
+"""Multi-GPU MSM: point-sharded Pippenger + all-gather of projective partials.
+
+MSM is linear, so the sum over points splits into per-rank sub-sums -- exactly
+the reference's rayon chunking (`chunk = ceil(n / threads)`, each chunk runs the
+whole serial Pippenger, results added: snark-verifier/src/util/msm.rs:311-336),
+with GPUs in place of threads.  Each rank reduces ITS contiguous shard to one
+projective partial (144 B), the partials are all-gathered (RCCL over xGMI when
+the backend is "nccl"; 144 B per rank -> latency-bound, link bandwidth is
+irrelevant) and every rank folds them locally, so all ranks hold the identical
+affine result (all-reduce semantics; `ncclAllReduce` itself cannot be used: EC
+addition is not an RCCL reduction operator).  SURVEY.md section 8(e).
+
+One process per GPU; `torch.distributed` is only the transport.
+"""
+from dataclasses import dataclass
+from typing import Callable
+
+
+def shard_range(n_total: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of rank `rank`: chunk = ceil(n / world), as
+    `Integer::div_ceil(&scalars.len(), &num_threads)` (msm.rs:322)."""
+    chunk = -(-n_total // world)
+    lo = min(rank * chunk, n_total)
+    hi = min(lo + chunk, n_total)
+    return lo, hi
+
+
+@dataclass
+class ShardedMsm:
+    """`partial_fn(lo, hi) -> tensor[partial_bytes]` reduces the local shard;
+    `fold_fn(tensor[world * partial_bytes], world) -> tensor[64]` folds the
+    gathered partials.  On a GPU box these are the HIP entry points
+    (`Context.msm_pippenger_partial_dev`, `Context.fold_partials_dev`); the gloo
+    CPU tests inject oracle-backed doubles to exercise the plumbing."""
+
+    partial_fn: Callable
+    fold_fn: Callable
+    partial_bytes: int = 144
+
+    def run(self, n_total: int):
+        import torch
+        import torch.distributed as dist
+
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        lo, hi = shard_range(n_total, rank, world)
+        part = self.partial_fn(lo, hi)
+        assert part.numel() == self.partial_bytes and part.dtype == torch.uint8
+        if world == 1:
+            gathered = part
+        else:
+            gathered = torch.empty(world * self.partial_bytes, dtype=torch.uint8, device=part.device)
+            dist.all_gather_into_tensor(gathered, part)
+        return self.fold_fn(gathered, world)
+
+
+def gpu_sharded_msm(ctx, d_scalars, d_points, n_total, window_bits=0):
+    """Product wiring: shard -> HIP Pippenger partial -> all_gather -> HIP fold.
+    `d_scalars` / `d_points` hold THIS rank's shard only (weak scaling)."""
+    import torch
+
+    from . import G1_PARTIAL_BYTES
+
+    part = torch.zeros(G1_PARTIAL_BYTES, dtype=torch.uint8, device=d_scalars.device)
+    out = torch.zeros(64, dtype=torch.uint8, device=d_scalars.device)
+
+    def partial_fn(lo, hi):
+        ctx.msm_pippenger_partial_dev(d_scalars.data_ptr(), d_points.data_ptr(), hi - lo, part.data_ptr(), window_bits)
+        return part
+
+    def fold_fn(gathered, world):
+        ctx.fold_partials_dev(gathered.data_ptr(), world, out.data_ptr())
+        return out
+
+    return ShardedMsm(partial_fn, fold_fn, G1_PARTIAL_BYTES).run(n_total)

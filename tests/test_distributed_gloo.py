@@ -1,0 +1,83 @@
+"""CPU, world_size 2, gloo: the multi-GPU plumbing of the sharded MSM
+(snark-verifier_amd/distributed.py) -- shard ranges, all-gather order, every
+rank folding to the same result -- with oracle-backed doubles standing in for
+the two HIP entry points (there is no GPU here)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+
+    import coracle as C
+    from snark_verifier_amd.distributed import ShardedMsm, shard_range
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s, p = C.sample_scalars(7, n), C.sample_points(8, n)
+
+    def partial_fn(lo, hi):
+        # oracle double: the shard's MSM as affine bytes, zero-padded to 144
+        if hi > lo:
+            pt = C.msm_pippenger(s[32 * lo:32 * hi], p[64 * lo:64 * hi], 1)
+        else:
+            pt = b"\x00" * 64
+        return torch.frombuffer(bytearray(pt + b"\x00" * 80), dtype=torch.uint8)
+
+    def fold_fn(gathered, w):
+        acc = b"\x00" * 64
+        raw = bytes(gathered.numpy())
+        for k in range(w):
+            acc = C.g1_add(acc, raw[144 * k:144 * k + 64])
+        return torch.frombuffer(bytearray(acc), dtype=torch.uint8)
+
+    out = ShardedMsm(partial_fn, fold_fn).run(n)
+    q.put((rank, bytes(out.numpy()), shard_range(n, rank, world)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1, 2, 101, 1000])
+def test_sharded_msm_two_ranks_agree_with_single_process(n):
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import coracle as C
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + n) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    expected = C.msm_pippenger(C.sample_scalars(7, n), C.sample_points(8, n), 1)
+    ranges = sorted(r[2] for r in res)
+    assert ranges[0][0] == 0 and ranges[-1][1] == n and ranges[0][1] == ranges[1][0]  # disjoint cover
+    for _, out, _ in res:
+        assert out == expected  # all ranks hold the same (all-reduce semantics)
+
+
+def test_shard_range_is_reference_chunking():
+    from snark_verifier_amd.distributed import shard_range
+
+    for n, w in [(10, 3), (16, 8), (5, 8), (1 << 24, 8)]:
+        chunk = -(-n // w)
+        cover = []
+        for r in range(w):
+            lo, hi = shard_range(n, r, w)
+            assert hi - lo <= chunk
+            cover += list(range(lo, min(hi, lo + 3)))
+        los = [shard_range(n, r, w)[0] for r in range(w)]
+        assert los == sorted(los) and shard_range(n, w - 1, w)[1] == n
