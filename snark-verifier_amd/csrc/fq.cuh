@@ -30,7 +30,7 @@ struct Fq {
 };
 
 // Inline-constant tables (the compiler folds these into literals / s_mov).
-SNARKV_HD uint32_t fq_p(int i) {
+SNARKV_HD constexpr uint32_t fq_p(int i) {
   constexpr uint32_t p[8] = BN254_P_LIMBS;
   return p[i];
 }
@@ -121,11 +121,11 @@ SNARKV_HD Fq fq_neg(const Fq& a) {
 
 SNARKV_HD Fq fq_dbl(const Fq& a) { return fq_add(a, a); }
 
-// Montgomery product a*b*R^-1 mod p.  CIOS with the "no-carry" merge that is
-// valid because p < 2^255 (top bit of limb 7 clear): the running carries A
-// (from a_i*b_j) and C (from m*p_j) never overflow a 32-bit word when summed.
-// Each inner step is one 32x32+64 multiply-add (`v_mad_u64_u32` on gfx950).
-SNARKV_HD Fq fq_mul(const Fq& a, const Fq& b) {
+// Montgomery product a*b*R^-1 mod p -- portable form.  CIOS with the "no-carry"
+// merge that is valid because p < 2^255 (top bit of limb 7 clear): the running
+// carries A (from a_i*b_j) and C (from m*p_j) never overflow a 32-bit word when
+// summed.  This is what the HOST build (tests/hosttest) runs.
+SNARKV_HD Fq fq_mul_portable(const Fq& a, const Fq& b) {
   uint32_t t[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) t[i] = 0;
@@ -148,6 +148,27 @@ SNARKV_HD Fq fq_mul(const Fq& a, const Fq& b) {
   for (int i = 0; i < 8; ++i) r.v[i] = t[i];
   return r;
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Device form: column-wise (product-scanning) Montgomery with a 96-bit column
+// accumulator; one `v_mad_u64_u32` + one `v_addc_co_u32` per partial product,
+// carries software-pipelined through SGPR pairs (gen_fq_mul_asm.py explains
+// the wait-state rule).  hipcc compiles the portable CIOS to 128 mad + 128
+// `v_lshl_add_u64` + ~370 `v_mov` (zero-extension of 32-bit addends into
+// register pairs): ~660 instructions; this form is ~330.
+SNARKV_HD Fq fq_mul(const Fq& a, const Fq& b) {
+  constexpr uint32_t kP0 = fq_p(0), kP1 = fq_p(1), kP2 = fq_p(2), kP3 = fq_p(3), kP4 = fq_p(4), kP5 = fq_p(5),
+                     kP6 = fq_p(6), kP7 = fq_p(7);
+#include "fq_mul_asm.inc"
+  fq_reduce_once(t);
+  Fq r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = t[i];
+  return r;
+}
+#else
+SNARKV_HD Fq fq_mul(const Fq& a, const Fq& b) { return fq_mul_portable(a, b); }
+#endif
 
 SNARKV_HD Fq fq_sqr(const Fq& a) { return fq_mul(a, a); }
 

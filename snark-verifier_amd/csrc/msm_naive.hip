@@ -6,13 +6,19 @@
 // ~21-term and a ~3-term one from Gwc19/Bdfg21::verify, then two (m+1)-term
 // ones from KzgAs::verify -- SURVEY.md section 0 item 6), so the launch unit
 // is a SEGMENTED MSM:
-//   K1  k_term_scalar_mul : one lane per (scalar, base) term, 256-step
-//                           double-and-add in XYZZ (`*base * scalar`, native.rs:67)
-//   K2  k_segment_fold    : one wave per MSM folds its terms (`reduce(|a,v| a+v)`,
+//   K1  k_term_scalar_mul : one lane per (term, GLV half): k = k1 + k2*lambda
+//                           splits `*base * scalar` (native.rs:67) into two
+//                           independent 127-step double-and-add chains on P and
+//                           phi(P), on the lazy 9x29-bit field
+//   K2  k_segment_fold    : one wave per MSM folds its partials (`reduce(|a,v| a+v)`,
 //                           native.rs:68), then `to_affine()` (native.rs:70) and
 //                           canonical little-endian store.
+// A single small MSM is latency-bound by construction (one dependency chain);
+// the segmented launch is what fills the machine.
 #include "ctx.hpp"
 #include "g1.cuh"
+#include "g1_29.cuh"
+#include "glv.cuh"
 
 namespace snarkv {
 
@@ -28,42 +34,95 @@ __device__ __forceinline__ void load_words16(const uint32_t* __restrict__ src, u
   }
 }
 
-__global__ void __launch_bounds__(64) k_term_scalar_mul(const uint32_t* __restrict__ scalars,
-                                                         const uint32_t* __restrict__ points,
-                                                         G1Xyzz* __restrict__ out, uint32_t n) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t k[8], pw[16];
-  load_words16(scalars + (size_t)i * 8, k, 2);
-  load_words16(points + (size_t)i * 16, pw, 4);
-  G1Affine p = g1a_from_canonical(pw);
-  out[i] = g1_scalar_mul(p, k);
+// |k| * Q for a 127-bit magnitude: left-to-right double-and-add on the lazy
+// 9x29-bit field.  FAST: branch-free adders, the caller checks the degenerate
+// flag; CAREFUL: explicit exceptional cases.
+template <bool CAREFUL>
+__device__ __forceinline__ G1Xyzz29 half_scalar_mul(const G1Affine29& q, const uint32_t k[4]) {
+  G1Xyzz29 acc = xyzz29_identity();
+  bool started = false;
+  for (int i = 3; i >= 0; --i) {
+    uint32_t w = k[i];
+    for (int b = 31; b >= 0; --b) {
+      if (started) {
+        if (!CAREFUL || !xyzz29_is_identity(acc)) acc = xyzz29_double(acc);
+      }
+      if ((w >> b) & 1u) {
+        if (!started) {
+          acc = xyzz29_from_affine(q);
+          started = true;
+        } else if (CAREFUL) {
+          xyzz29_madd_careful(acc, q);
+        } else {
+          xyzz29_madd_fast(acc, q);
+        }
+      }
+    }
+  }
+  return acc;
 }
 
-// One 64-lane block (= one wavefront) per MSM.
-__global__ void __launch_bounds__(64) k_segment_fold(const G1Xyzz* __restrict__ terms,
+// K1: one lane per (term, GLV half).  k = k1 + k2*lambda with |k_i| < 2^127
+// (glv.cuh) turns `*base * scalar` (reference native.rs:67), a 254-step chain,
+// into two independent 127-step chains on P and phi(P) = (beta x, y).
+__global__ void __launch_bounds__(64) k_term_scalar_mul(const uint32_t* __restrict__ scalars,
+                                                         const uint32_t* __restrict__ points,
+                                                         G1Xyzz29* __restrict__ out, uint32_t n_terms) {
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= 2 * n_terms) return;
+  uint32_t t = g >> 1, h = g & 1u;
+  uint32_t k[8], pw[16], halves[8];
+  load_words16(scalars + (size_t)t * 8, k, 2);
+  load_words16(points + (size_t)t * 16, pw, 4);
+  glv_decompose(k, halves);
+  uint32_t mag[4] = {halves[4 * h], halves[4 * h + 1], halves[4 * h + 2], halves[4 * h + 3] & 0x7FFFFFFFu};
+  uint32_t neg = halves[4 * h + 3] >> 31;
+  G1Affine29 q = g1a29_from_canonical(pw);
+  if (g1a29_is_identity(q) || (mag[0] | mag[1] | mag[2] | mag[3]) == 0) {
+    out[g] = xyzz29_identity();
+    return;
+  }
+  if (h) {
+    constexpr int32_t bl[9] = BN254_GLV_BETA29_LIMBS;
+    Fq29 beta;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) beta.v[j] = bl[j];
+    q.x = fq29_canon_residue(fq29_mul(q.x, beta));
+  }
+  if (neg) q.y = fq29_neg(q.y);
+  G1Xyzz29 r = half_scalar_mul<false>(q, mag);
+  if (xyzz29_is_degenerate(r)) {  // P = +-Q met on the way (or a true identity): redo carefully
+    r = half_scalar_mul<true>(q, mag);
+    if (!xyzz29_is_identity(r) && xyzz29_is_degenerate(r)) r = xyzz29_identity();
+  }
+  out[g] = r;
+}
+
+// K2: one 64-lane block (= one wavefront) per MSM folds its 2 x terms partials
+// (`reduce(|a,v| a+v)`, native.rs:68), then `to_affine()` (native.rs:70).
+__global__ void __launch_bounds__(64) k_segment_fold(const G1Xyzz29* __restrict__ parts,
                                                       const uint32_t* __restrict__ offsets,
                                                       uint32_t* __restrict__ out) {
-  __shared__ G1Xyzz sh[64];
+  __shared__ G1Xyzz29 sh[64];
   uint32_t k = blockIdx.x;
-  uint32_t lo = offsets[k], hi = offsets[k + 1];
+  uint32_t lo = 2 * offsets[k], hi = 2 * offsets[k + 1];
   uint32_t lane = threadIdx.x;
-  G1Xyzz acc = xyzz_identity();
-  for (uint32_t i = lo + lane; i < hi; i += 64) xyzz_add(acc, terms[i]);
+  G1Xyzz29 acc = xyzz29_identity();
+  for (uint32_t i = lo + lane; i < hi; i += 64) xyzz29_add_careful(acc, parts[i]);
   sh[lane] = acc;
   __syncthreads();
   for (uint32_t s = 32; s >= 1; s >>= 1) {
     if (lane < s) {
-      G1Xyzz a = sh[lane];
-      xyzz_add(a, sh[lane + s]);
+      G1Xyzz29 a = sh[lane];
+      xyzz29_add_careful(a, sh[lane + s]);
       sh[lane] = a;
     }
     __syncthreads();
   }
   if (lane == 0) {
-    G1Affine r = xyzz_to_affine(sh[0]);
+    G1Affine29 r = xyzz29_to_affine(sh[0]);
     uint32_t w[16];
-    g1a_to_canonical(r, w);
+    g1a29_to_canonical(r, w);
     uint4* o = reinterpret_cast<uint4*>(out + (size_t)k * 16);
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
@@ -101,11 +160,11 @@ __global__ void k_validate(const uint32_t* __restrict__ scalars, const uint32_t*
 int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, const void* d_offsets,
                        size_t n_msm, size_t n_terms, void* d_out) {
   void* d_terms = nullptr;
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_PARTIALS, n_terms * sizeof(G1Xyzz), &d_terms));
-  uint32_t blocks = (uint32_t)((n_terms + 63) / 64);
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_PARTIALS, 2 * n_terms * sizeof(G1Xyzz29), &d_terms));
+  uint32_t blocks = (uint32_t)((2 * n_terms + 63) / 64);
   hipLaunchKernelGGL(k_term_scalar_mul, dim3(blocks), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,
-                     (const uint32_t*)d_points, (G1Xyzz*)d_terms, (uint32_t)n_terms);
-  hipLaunchKernelGGL(k_segment_fold, dim3((uint32_t)n_msm), dim3(64), 0, ctx->stream, (const G1Xyzz*)d_terms,
+                     (const uint32_t*)d_points, (G1Xyzz29*)d_terms, (uint32_t)n_terms);
+  hipLaunchKernelGGL(k_segment_fold, dim3((uint32_t)n_msm), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_terms,
                      (const uint32_t*)d_offsets, (uint32_t*)d_out);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
