@@ -16,6 +16,7 @@ LIB = os.path.join(HERE, "libsnarkv_amd.so")
 UNITS = ["capi", "msm_naive", "msm_pippenger", "decider", "sample"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+FLAGS += os.environ.get("SNARKV_EXTRA_FLAGS", "").split()
 
 
 def _deps():

@@ -48,10 +48,22 @@
 
 namespace snarkv {
 
-constexpr int kRun = 32;          // P4: entries per lane
-constexpr int kChunk = 8;         // P6: buckets per lane
+#ifndef SNARKV_KRUN
+#define SNARKV_KRUN 32
+#endif
+#ifndef SNARKV_KCHUNK
+#define SNARKV_KCHUNK 4
+#endif
+#ifndef SNARKV_ACC_WAVES
+#define SNARKV_ACC_WAVES 4
+#endif
+constexpr int kRun = SNARKV_KRUN;      // P4: entries per lane
+constexpr int kChunk = SNARKV_KCHUNK;  // P6: buckets per lane
 constexpr int kTile = 4096;       // S1/S3: scalars per workgroup
-constexpr int kMaxHighBits = 7;   // S1: (window, high bits) keys per window <= 128
+#ifndef SNARKV_HIGHBITS
+#define SNARKV_HIGHBITS 7
+#endif
+constexpr int kMaxHighBits = SNARKV_HIGHBITS;   // S1: (window, high bits) keys per window <= 128
 constexpr uint32_t kNoBucket = 0xFFFFFFFFu;
 
 struct PipParams {
@@ -333,7 +345,7 @@ __device__ __forceinline__ bool accumulate_run(const uint2* __restrict__ entries
   return bad;
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, SNARKV_ACC_WAVES)
     k_accumulate(const uint2* __restrict__ entries, const uint32_t* __restrict__ total_ptr,
                  const G1Affine29* __restrict__ pts, G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ seg_ids,
                  G1Xyzz29* __restrict__ seg_parts) {
@@ -483,10 +495,7 @@ __global__ void __launch_bounds__(64)
   for (int i = 0; i < 9; ++i) {  // pin the chain state to VGPRs (opaque to the uniformity analysis)
     asm volatile("" : "+v"(r.x.v[i]), "+v"(r.y.v[i]), "+v"(r.zz.v[i]), "+v"(r.zzz.v[i]));
   }
-  if (!xyzz29_is_identity(r)) {
-    int n = p.c * (int)w;
-    for (int k = 0; k < n; ++k) r = xyzz29_double(r);
-  }
+  if (!xyzz29_is_identity(r)) r = xyzz29_double_n(r, p.c * (int)w);
   if (lane == 0) shifted[w] = r;
 }
 

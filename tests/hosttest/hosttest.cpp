@@ -192,4 +192,11 @@ void ht29_glv_phi(const uint8_t* p, uint8_t* out) {
   a.x = fq29_mul(a.x, beta);
   store_g1_29(a, out);
 }
+// 2^n * P via the Jacobian repeated-doubling chain
+void ht29_double_n(const uint8_t* p, int n, uint8_t* out) {
+  G1Xyzz29 a = xyzz29_from_affine(load_g1_29(p));
+  // start from a non-trivial XYZZ representation: a = P + P' - P' would need more plumbing; use 2P (ZZ != 1)
+  a = xyzz29_double(a);
+  store_g1_29(xyzz29_to_affine(xyzz29_double_n(a, n)), out);
+}
 }

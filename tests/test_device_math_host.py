@@ -196,3 +196,11 @@ def test_g1_29_scalar_mul(hosttest_lib):
     for k in [O.R, O.R + 1, O.R + 2, (1 << 256) - 1]:  # non-canonical scalars hit P = +-Q: careful path
         L.ht29_g1_mul(O.g1_to_bytes(p0), int(k).to_bytes(32, "little"), 1, o)
         assert O.g1_from_bytes(o.raw) == O.g1_mul(p0, k)
+
+
+def test_g1_29_jacobian_double_chain(hosttest_lib):
+    P = O.g1_mul(O.G1_GEN, 987654321)
+    o = _buf(64)
+    for n in (0, 1, 2, 16, 112, 240):
+        hosttest_lib.ht29_double_n(O.g1_to_bytes(P), n, o)
+        assert O.g1_from_bytes(o.raw) == O.g1_mul(P, pow(2, n + 1, O.R))
