@@ -48,6 +48,7 @@ enum Slot {
   SLOT_SORT_TMP,
   SLOT_SHIFTED,
   SLOT_GLV,
+  SLOT_BIG_LIST,
   SLOT_COUNT
 };
 

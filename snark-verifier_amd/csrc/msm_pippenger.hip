@@ -59,11 +59,11 @@ namespace snarkv {
 #endif
 constexpr int kRun = SNARKV_KRUN;      // P4: entries per lane
 constexpr int kChunk = SNARKV_KCHUNK;  // P6: buckets per lane
-constexpr int kTile = 4096;       // S1/S3: scalars per workgroup
-#ifndef SNARKV_HIGHBITS
-#define SNARKV_HIGHBITS 7
-#endif
-constexpr int kMaxHighBits = SNARKV_HIGHBITS;   // S1: (window, high bits) keys per window <= 128
+constexpr uint32_t kSortCap = 7168;     // S4: items a workgroup sorts entirely in LDS (56 KiB of the 64 KiB dynamic limit)
+constexpr uint32_t kSortTarget = 3072;  // S1: average items per (window, high bits) key
+constexpr uint32_t kMaxKeys = 16384;    // S1: LDS counters per tile workgroup (64 KiB)
+constexpr uint32_t kBigSpan = 24;       // P5: buckets spanning more runs go to the cooperative kernel
+constexpr uint32_t kMaxBig = 8192;   // S1: (window, high bits) keys per window <= 128
 constexpr uint32_t kNoBucket = 0xFFFFFFFFu;
 
 struct PipParams {
@@ -76,6 +76,8 @@ struct PipParams {
   uint32_t SB;     // keys per window at level 1 = B >> low_bits
   uint32_t nkeys;  // W * SB
   uint32_t nblk;   // tiles
+  uint32_t tile;   // scalars per tile workgroup
+  uint32_t mstride;  // row stride of the key x tile matrix (odd: no power-of-two channel aliasing)
 };
 
 // c bits at offset lo of a 128-bit magnitude held in 4 registers
@@ -142,10 +144,10 @@ __global__ void __launch_bounds__(256)
                   uint32_t* __restrict__ M, uint2* __restrict__ tmp) {
   extern __shared__ uint32_t lds[];  // nkeys counters / cursors
   for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x)
-    lds[k] = SCATTER ? M[(size_t)k * p.nblk + blockIdx.x] : 0u;
+    lds[k] = SCATTER ? M[(size_t)k * p.mstride + blockIdx.x] : 0u;
   __syncthreads();
-  uint32_t lo = blockIdx.x * kTile;
-  uint32_t hi = lo + kTile < p.n ? lo + kTile : p.n;
+  uint32_t lo = blockIdx.x * p.tile;
+  uint32_t hi = lo + p.tile < p.n ? lo + p.tile : p.n;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     if (point_is_identity(points, i)) continue;
     for (uint32_t h = 0; h < 2; ++h) {
@@ -173,7 +175,7 @@ __global__ void __launch_bounds__(256)
   }
   if (!SCATTER) {
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) M[(size_t)k * p.nblk + blockIdx.x] = lds[k];
+    for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) M[(size_t)k * p.mstride + blockIdx.x] = lds[k];
   }
 }
 
@@ -244,51 +246,82 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ data, c
 
 // --------------------------------------------------------------- S4
 // One workgroup per level-1 key (window, high bits): counting sort of its
-// slice of `tmp` by the low digit bits, entirely with LDS counters.
-__global__ void __launch_bounds__(256)
+// slice of `tmp` by the low digit bits with LDS counters.  Slices of up to
+// kSortCap items (the normal case: S1 sizes the keys for it) are sorted
+// ENTIRELY in LDS and written back as one coalesced stream -- a random 8-byte
+// scatter to HBM costs a 128-byte read-modify-write once the working set
+// outgrows L2/Infinity Cache.  Larger slices (skewed scalars) take the
+// two-pass global path.
+__global__ void __launch_bounds__(512)
     k_sort_level2(const uint2* __restrict__ tmp, const uint32_t* __restrict__ M, const uint32_t* __restrict__ total_ptr,
                   PipParams p, uint2* __restrict__ entries, uint32_t* __restrict__ counts,
                   uint32_t* __restrict__ offsets) {
-  extern __shared__ uint32_t lds[];  // (1 << low_bits) counters, then 256 scan words
+  extern __shared__ uint32_t lds[];  // nbins counters | 512 scan words | kSortCap items (uint2)
   const uint32_t nbins = 1u << p.low_bits;
   uint32_t* hist = lds;
   uint32_t* scan = lds + nbins;
+  uint2* stage = reinterpret_cast<uint2*>(lds + nbins + 512);
+  const uint32_t T = blockDim.x;
   uint32_t key = blockIdx.x;
-  uint32_t begin = M[(size_t)key * p.nblk];
-  uint32_t end = (key + 1 < p.nkeys) ? M[(size_t)(key + 1) * p.nblk] : *total_ptr;
-  for (uint32_t k = threadIdx.x; k < nbins; k += 256) hist[k] = 0;
+  uint32_t begin = M[(size_t)key * p.mstride];
+  uint32_t end = (key + 1 < p.nkeys) ? M[(size_t)(key + 1) * p.mstride] : *total_ptr;
+  uint32_t cnt_items = end - begin;
+  bool fast = cnt_items <= kSortCap;
+  for (uint32_t k = threadIdx.x; k < nbins; k += T) hist[k] = 0;
   __syncthreads();
   const uint32_t low_mask = nbins - 1;
-  for (uint32_t e = begin + threadIdx.x; e < end; e += 256) atomicAdd(&hist[tmp[e].x & low_mask], 1u);
+  constexpr int kPer = kSortCap / 512;  // items a lane keeps in registers on the fast path
+  uint2 mine[kPer];
+  if (fast) {
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      uint32_t e = threadIdx.x + j * T;
+      if (e < cnt_items) {
+        mine[j] = tmp[begin + e];
+        atomicAdd(&hist[mine[j].x & low_mask], 1u);
+      }
+    }
+  } else {
+    for (uint32_t e = begin + threadIdx.x; e < end; e += T) atomicAdd(&hist[tmp[e].x & low_mask], 1u);
+  }
   __syncthreads();
   // exclusive scan of hist: each lane owns a contiguous strip
-  uint32_t per = (nbins + 255) / 256;
+  uint32_t per = (nbins + T - 1) / T;
   uint32_t s0 = threadIdx.x * per;
   uint32_t sum = 0;
   for (uint32_t k = s0; k < s0 + per && k < nbins; ++k) sum += hist[k];
   scan[threadIdx.x] = sum;
   __syncthreads();
-  for (uint32_t off = 1; off < 256; off <<= 1) {
+  for (uint32_t off = 1; off < T; off <<= 1) {
     uint32_t t = (threadIdx.x >= off) ? scan[threadIdx.x - off] : 0;
     __syncthreads();
     scan[threadIdx.x] += t;
     __syncthreads();
   }
-  uint32_t run = begin + scan[threadIdx.x] - sum;
+  uint32_t run = scan[threadIdx.x] - sum;  // position inside the slice
   uint32_t w = key / p.SB, sb = key % p.SB;
   uint32_t bucket0 = w * p.B + (sb << p.low_bits);
   for (uint32_t k = s0; k < s0 + per && k < nbins; ++k) {
     uint32_t cnt = hist[k];
     counts[bucket0 + k] = cnt;
-    offsets[bucket0 + k] = run;
-    hist[k] = run;  // becomes the cursor
+    offsets[bucket0 + k] = begin + run;
+    hist[k] = run;  // becomes the cursor (slice-relative)
     run += cnt;
   }
   __syncthreads();
-  for (uint32_t e = begin + threadIdx.x; e < end; e += 256) {
-    uint2 it = tmp[e];
-    uint32_t pos = atomicAdd(&hist[it.x & low_mask], 1u);
-    entries[pos] = it;
+  if (fast) {
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      uint32_t e = threadIdx.x + j * T;
+      if (e < cnt_items) stage[atomicAdd(&hist[mine[j].x & low_mask], 1u)] = mine[j];
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < cnt_items; e += T) entries[begin + e] = stage[e];
+  } else {
+    for (uint32_t e = begin + threadIdx.x; e < end; e += T) {
+      uint2 it = tmp[e];
+      entries[begin + atomicAdd(&hist[it.x & low_mask], 1u)] = it;
+    }
   }
 }
 
@@ -383,18 +416,56 @@ __device__ __forceinline__ bool combine_bucket(uint32_t b, size_t s0, size_t s1,
 __global__ void __launch_bounds__(64)
     k_combine(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, PipParams p,
               const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
-              G1Xyzz29* __restrict__ buckets) {
+              G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list) {
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= p.nb) return;
   uint32_t cnt = counts[b];
   if (cnt == 0) return;  // bucket array was zero-filled = identity
   uint32_t o = offsets[b];
   size_t s0 = o / kRun, s1 = (o + cnt - 1) / kRun;
+  if (s1 - s0 >= kBigSpan) {  // skewed scalars: hand the bucket to k_combine_big
+    uint32_t slot = atomicAdd(big_count, 1u);
+    if (slot < kMaxBig) {
+      big_list[slot] = b;
+      return;
+    }
+  }
   G1Xyzz29 acc;
   bool touched;
   if (combine_bucket<false>(b, s0, s1, seg_ids, seg_parts, acc, touched))
     combine_bucket<true>(b, s0, s1, seg_ids, seg_parts, acc, touched);
   if (touched) buckets[b] = acc;
+}
+
+// Buckets that span many runs (skewed scalar distributions: e.g. all scalars
+// equal puts n entries into one bucket per window): one 256-lane workgroup per
+// bucket, lane-strided careful adds + LDS tree.
+__global__ void __launch_bounds__(256)
+    k_combine_big(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                  const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
+                  G1Xyzz29* __restrict__ buckets, const uint32_t* __restrict__ big_count,
+                  const uint32_t* __restrict__ big_list) {
+  __shared__ G1Xyzz29 sh[256];
+  uint32_t nbig = *big_count < kMaxBig ? *big_count : kMaxBig;
+  if (blockIdx.x >= nbig) return;
+  uint32_t b = big_list[blockIdx.x];
+  uint32_t o = offsets[b], cnt = counts[b];
+  size_t s0 = o / kRun, s1 = (o + cnt - 1) / kRun;
+  G1Xyzz29 acc = xyzz29_identity();
+  for (size_t s = s0 + threadIdx.x; s <= s1; s += 256)
+    for (int h = 0; h < 2; ++h)
+      if (seg_ids[2 * s + h] == b) xyzz29_add_careful(acc, seg_parts[2 * s + h]);
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t st = 128; st >= 1; st >>= 1) {
+    if (threadIdx.x < st) {
+      G1Xyzz29 a = sh[threadIdx.x];
+      xyzz29_add_careful(a, sh[threadIdx.x + st]);
+      sh[threadIdx.x] = a;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) buckets[b] = sh[0];
 }
 
 // --------------------------------------------------------------- P6
@@ -542,38 +613,53 @@ static int default_window_bits(size_t n) {
   while (((size_t)1 << (lg + 1)) <= n) ++lg;
   int c = lg - 4;
   if (c < 2) c = 2;
-  if (c > 20) c = 20;
+  if (c > 16) c = 16;  // beyond 2^20 points the bucket count, not n, sets the reduce cost
   return c;
+}
+
+// Smallest window size with the same number of windows: keeps the TOP window
+// populated (c = 18 would leave it one useful bit of a 127-bit half-scalar, i.e.
+// one bucket holding half of all entries).
+static int balance_window_bits(int c) {
+  int W = (128 + c - 1) / c;
+  return (128 + W - 1) / W;
 }
 
 int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
                          void* d_out, bool partial_out) {
   PipParams p;
   p.n = (uint32_t)n;
-  p.c = window_bits > 0 ? window_bits : default_window_bits(n);
+  p.c = window_bits > 0 ? window_bits : balance_window_bits(default_window_bits(n));
   if (p.c < 2) p.c = 2;
   if (p.c > 22) p.c = 22;
   p.W = (128 + p.c - 1) / p.c;
   p.B = 1u << (p.c - 1);
   p.nb = (uint32_t)p.W * p.B;
-  int high = p.c - 1 < kMaxHighBits ? p.c - 1 : kMaxHighBits;
+  // level-1 keys: ~kSortTarget items each so that a level-2 workgroup sorts its
+  // slice inside LDS; bounded by the LDS counters of a tile workgroup
+  int high = p.c - 1 > 10 ? p.c - 1 - 10 : 0;  // at most 1024 level-2 bins (LDS)
+  while (high < p.c - 1 && ((2 * n) >> (high + 1)) >= kSortTarget && ((uint64_t)p.W << (high + 1)) <= kMaxKeys) ++high;
   p.low_bits = (p.c - 1) - high;
   p.SB = p.B >> p.low_bits;
   p.nkeys = (uint32_t)p.W * p.SB;
-  p.nblk = (uint32_t)((n + kTile - 1) / kTile);
+  // tile: >= 16 items per (tile, key) stream so partition writes fill 128-byte lines
+  p.tile = 4096;
+  while (p.tile < 65536 && (uint64_t)p.tile * 2 * p.W < 16ull * p.nkeys) p.tile *= 2;
+  p.nblk = (uint32_t)((n + p.tile - 1) / p.tile);
+  p.mstride = p.nblk | 1u;
   uint64_t max_entries = 2ull * (uint64_t)n * (uint64_t)p.W;
   if (n == 0 || max_entries >= 0xFFFFFFFFull || n >= 0x40000000ull) {
     set_last_error("pippenger: n=%zu out of range", n);
     return SNARKV_ERR_LENGTH;
   }
   uint32_t max_runs = (uint32_t)((max_entries + kRun - 1) / kRun);
-  uint32_t mcount = p.nkeys * p.nblk;
+  uint32_t mcount = p.nkeys * p.mstride;
   uint32_t scan_blocks = (mcount + 1023) / 1024;
   uint32_t chunks_per_window = (p.B + kChunk - 1) / kChunk;
   uint32_t blocks_per_window = (chunks_per_window + 63) / 64;
 
   void *d_pts, *d_glv, *d_counts, *d_offsets, *d_M, *d_blocksum, *d_entries, *d_tmp, *d_seg_ids, *d_seg_parts,
-      *d_buckets, *d_wave, *d_shift, *d_misc;
+      *d_buckets, *d_wave, *d_shift, *d_misc, *d_big;
   SNARKV_TRY(ctx_reserve(ctx, SLOT_POINTS_MONT, 2 * n * sizeof(G1Affine29), &d_pts));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_GLV, n * 32, &d_glv));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_COUNTS, (size_t)p.nb * 4, &d_counts));
@@ -588,7 +674,12 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   SNARKV_TRY(ctx_reserve(ctx, SLOT_CHUNK_PARTIALS, (size_t)blocks_per_window * p.W * sizeof(G1Xyzz29), &d_wave));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SHIFTED, (size_t)p.W * sizeof(G1Xyzz29), &d_shift));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_MISC, 64, &d_misc));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_BIG_LIST, (size_t)kMaxBig * 4, &d_big));
   uint32_t* d_total = (uint32_t*)d_misc;
+  if ((size_t)p.nkeys * 4 > 65536) {
+    set_last_error("pippenger: key table too large (nkeys=%u)", p.nkeys);
+    return SNARKV_ERR_LENGTH;
+  }
 
   hipStream_t st = ctx->stream;
   bool tm = ctx->stage_timing;
@@ -606,6 +697,7 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
                      (const uint32_t*)d_points, (G1Affine29*)d_pts, (uint4*)d_glv, p.n);
   STAGE_MARK();  // 1: prepare (GLV split, phi(P), to Montgomery)
   size_t lds1 = (size_t)p.nkeys * 4;
+  SNARKV_HIP(hipMemsetAsync(d_M, 0, (size_t)mcount * 4, st));  // padding columns must read as zero
   hipLaunchKernelGGL(k_sort_level1<false>, dim3(p.nblk), dim3(256), lds1, st, (const uint4*)d_glv,
                      (const uint32_t*)d_points, p, (uint32_t*)d_M, (uint2*)nullptr);
   hipLaunchKernelGGL(k_scan_local, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (uint32_t*)d_blocksum, mcount);
@@ -615,8 +707,8 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   STAGE_MARK();  // 2: digit histogram + scan
   hipLaunchKernelGGL(k_sort_level1<true>, dim3(p.nblk), dim3(256), lds1, st, (const uint4*)d_glv,
                      (const uint32_t*)d_points, p, (uint32_t*)d_M, (uint2*)d_tmp);
-  size_t lds2 = ((size_t)(1u << p.low_bits) + 256) * 4;
-  hipLaunchKernelGGL(k_sort_level2, dim3(p.nkeys), dim3(256), lds2, st, (const uint2*)d_tmp, (const uint32_t*)d_M,
+  size_t lds2 = ((size_t)(1u << p.low_bits) + 512) * 4 + (size_t)kSortCap * 8;
+  hipLaunchKernelGGL(k_sort_level2, dim3(p.nkeys), dim3(512), lds2, st, (const uint2*)d_tmp, (const uint32_t*)d_M,
                      (const uint32_t*)d_total, p, (uint2*)d_entries, (uint32_t*)d_counts, (uint32_t*)d_offsets);
   STAGE_MARK();  // 3: partition + level-2 sort
   SNARKV_HIP(hipMemsetAsync(d_buckets, 0, (size_t)p.nb * sizeof(G1Xyzz29), st));
@@ -624,9 +716,17 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
                      (const uint32_t*)d_total, (const G1Affine29*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
                      (G1Xyzz29*)d_seg_parts);
   STAGE_MARK();  // 4: bucket accumulate
+  uint32_t* d_big_count = d_total + 4;
+  SNARKV_HIP(hipMemsetAsync(d_big_count, 0, 4, st));
   hipLaunchKernelGGL(k_combine, dim3((p.nb + 63) / 64), dim3(64), 0, st, (const uint32_t*)d_counts,
                      (const uint32_t*)d_offsets, p, (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts,
-                     (G1Xyzz29*)d_buckets);
+                     (G1Xyzz29*)d_buckets, d_big_count, (uint32_t*)d_big);
+  // one workgroup per oversized bucket; idle workgroups exit at once
+  uint32_t big_grid = (uint32_t)(max_runs / kBigSpan + 1);
+  if (big_grid > kMaxBig) big_grid = kMaxBig;
+  hipLaunchKernelGGL(k_combine_big, dim3(big_grid), dim3(256), 0, st, (const uint32_t*)d_counts,
+                     (const uint32_t*)d_offsets, (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts,
+                     (G1Xyzz29*)d_buckets, (const uint32_t*)d_big_count, (const uint32_t*)d_big);
   STAGE_MARK();  // 5: bucket combine
   hipLaunchKernelGGL(k_bucket_reduce, dim3(blocks_per_window * p.W), dim3(64), 0, st, (const G1Xyzz29*)d_buckets,
                      (G1Xyzz29*)d_wave, p, chunks_per_window, blocks_per_window);
