@@ -6,6 +6,7 @@
 #include "../../snark-verifier_amd/csrc/pairing.cuh"
 #include "../../snark-verifier_amd/csrc/g1_29.cuh"
 #include "../../snark-verifier_amd/csrc/glv.cuh"
+#include "../../snark-verifier_amd/csrc/pairing_coop.cuh"
 
 using namespace snarkv;
 
@@ -198,5 +199,16 @@ void ht29_double_n(const uint8_t* p, int n, uint8_t* out) {
   // start from a non-trivial XYZZ representation: a = P + P' - P' would need more plumbing; use 2P (ZZ != 1)
   a = xyzz29_double(a);
   store_g1_29(xyzz29_to_affine(xyzz29_double_n(a, n)), out);
+}
+// lane-by-lane emulation of the cooperative Fq12 product (pairing_coop.cuh tables)
+void ht_coop_fq12_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  Fq fa[12], fa9[12], fb[12], prods[COOP_NPROD], parts[48], fc[12];
+  coop_flat_from_tower(load_fq12(a), fa);
+  coop_flat_from_tower(load_fq12(b), fb);
+  for (int c = 0; c < 12; ++c) fa9[c] = fq_mul9(fa[c]);
+  for (int l = 0; l < COOP_NPROD; ++l) prods[l] = coop_product(l, fa, fa9, fb);
+  for (int q = 0; q < 48; ++q) parts[q] = coop_stage1(q, prods);
+  for (int c = 0; c < 12; ++c) fc[c] = coop_stage2(c, parts);
+  store_fq12(coop_tower_from_flat(fc), out);
 }
 }

@@ -204,3 +204,14 @@ def test_g1_29_jacobian_double_chain(hosttest_lib):
     for n in (0, 1, 2, 16, 112, 240):
         hosttest_lib.ht29_double_n(O.g1_to_bytes(P), n, o)
         assert O.g1_from_bytes(o.raw) == O.g1_mul(P, pow(2, n + 1, O.R))
+
+
+def test_cooperative_fq12_tables(hosttest_lib):
+    """Lane-by-lane emulation of the workgroup-cooperative Fq12 product
+    (csrc/pairing_coop.cuh + generated tables) vs the tower product."""
+    rng = random.Random(12)
+    o = _buf(384)
+    for _ in range(5):
+        A, B = _rfq12(rng), _rfq12(rng)
+        hosttest_lib.ht_coop_fq12_mul(A.to_bytes(), B.to_bytes(), o)
+        assert o.raw == (A * B).to_bytes()
