@@ -50,6 +50,66 @@ def cpu_baseline(ctx, d_scalars, d_points, sample_log2):
     }, out, (s, p)
 
 
+def secondary_metrics(sv, torch, ctx):
+    """BASELINE.json's second metric ("aggregated proofs verified/sec") on shape-faithful
+    synthetic work: per proof a 21-term and a 3-term MSM
+    (Gwc19::verify), then KzgAs::verify's two (m+1)-term MSMs, then ONE decide.
+    All EC work on the device through the same C-ABI entry points the C++ host
+    mirror uses; the host-side Fr algebra (microseconds per proof) is not included."""
+    import ctypes
+
+    out = {}
+
+    def t_ms(fn, reps=5, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    # deciding key: any valid (g1, g2, s*g2); the toy secret only matters for accept/reject
+    g2 = bytes.fromhex(
+        "edf692d95cbdde46ddda5ef7d422436779445c5e66006a42761e1f12efde0018c212f3aeb785e49712e7a9353349aaf1255dfb31b7bf60723a480d9293938e19"
+        "aa7dfa6601cce64c7bd3430c69e7d1e38f40cb8d8071ab4aeb6d8cdba55ec8125b9722d1dcdaac55f38eb37033314bbc95330c69ad999eec75f05f58d0890609")
+    g1 = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
+    dk = sv.DecidingKey(ctx, g1, g2, g2)  # s = 1: (P, P) is a valid accumulator
+    for nproofs in (64, 1024):
+        offs = [0]
+        for _ in range(nproofs):
+            offs += [offs[-1] + 21, offs[-1] + 24]
+        n1, n2 = offs[-1], 2 * (nproofs + 1)
+        ds = torch.empty(32 * max(n1, n2), dtype=torch.uint8, device="cuda")
+        dp = torch.empty(64 * max(n1, n2), dtype=torch.uint8, device="cuda")
+        ctx.sample_scalars_dev(0x5EED0003, max(n1, n2), ds.data_ptr())
+        ctx.sample_points_dev(0x5EED0004, max(n1, n2), dp.data_ptr())
+        o1 = torch.tensor(offs, dtype=torch.int32, device="cuda")
+        o2 = torch.tensor([0, nproofs + 1, n2], dtype=torch.int32, device="cuda")
+        out1 = torch.zeros(64 * (len(offs) - 1), dtype=torch.uint8, device="cuda")
+        acc = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        ok = torch.zeros(1, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+
+        def run():
+            ctx.msm_batched_dev(ds.data_ptr(), dp.data_ptr(), o1.data_ptr(), len(offs) - 1, n1, out1.data_ptr())
+            ctx.msm_batched_dev(ds.data_ptr(), dp.data_ptr(), o2.data_ptr(), 2, n2, acc.data_ptr())
+            ctx.decide_batch_dev(dk, acc.data_ptr(), 1, ok.data_ptr())
+
+        ms = t_ms(run)
+        out["aggregate_%d_proofs" % nproofs] = {"ms": ms, "proofs_per_s": nproofs / ms * 1e3,
+                                                 "msm_terms": n1 + n2, "includes_decide": True}
+    one = torch.frombuffer(bytearray((g1 + g1) * 1024), dtype=torch.uint8).cuda()
+    oks = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for m in (1, 1024):
+        ms = t_ms(lambda: ctx.decide_batch_dev(dk, one.data_ptr(), m, oks.data_ptr()), reps=3, warm=1)
+        out["decide_all_%d" % m] = {"ms": ms, "decides_per_s": m / ms * 1e3, "all_accept": bool(oks[:m].cpu().all())}
+    dk.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +119,8 @@ def main():
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--cpu-sample-log2", type=int, default=18)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path even at world size 1 (testing)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="independent MSMs kept in flight (one context + HIP stream each); 1 = strictly sequential")
     args = ap.parse_args()
@@ -75,15 +137,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n = 1 << args.log2n
     # One context per in-flight MSM, each on its own HIP stream: the latency-bound
     # tail of one MSM (bucket reduce, 2^(cw) doubling chains, to_affine: a few
     # wavefronts) overlaps the VALU-bound bucket accumulation of the next.
-    inflight = max(1, args.inflight) if world == 1 else 1
+    inflight = max(1, args.inflight) if not use_dist else 1
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(inflight - 1)]
     ctxs = [sv.Context(local_rank, stream=s.cuda_stream) for s in streams]
     ctx = ctxs[0]
@@ -101,7 +167,7 @@ def main():
     step_no = [0]
 
     def step():
-        if world == 1:
+        if not use_dist:
             k = step_no[0] % inflight
             step_no[0] += 1
             ctxs[k].msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, outs[k].data_ptr(), args.window_bits)
@@ -113,7 +179,7 @@ def main():
             ctx.fold_partials_dev(gathered.data_ptr(), world, out.data_ptr())
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -130,7 +196,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step()
-        if inflight == 1 or world > 1:
+        if inflight == 1 or use_dist:
             st = ctx.get_stage_timing()  # sequential mode: consume each step before the next
             stage_cnt += 1
             for k, v in st.items():
@@ -150,7 +216,7 @@ def main():
 
     # single-MSM latency (strictly sequential), outside the timed region, for the record
     lat_ms = None
-    if world == 1:
+    if not use_dist:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(5):
@@ -158,7 +224,7 @@ def main():
             ctx.sync()
         lat_ms = (time.perf_counter() - t1) / 5 * 1e3
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -215,9 +281,11 @@ def main():
             ctx.sync()
             cb["gpu_matches_on_sample"] = bytes(chk.cpu().numpy()) == cpu_out
             line["cpu_baseline"] = cb
+        if not use_dist and not args.no_secondary:
+            line["secondary"] = secondary_metrics(sv, torch, ctx)
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
