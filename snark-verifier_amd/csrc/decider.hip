@@ -19,10 +19,23 @@
 #include "g1.cuh"
 #include "pairing.cuh"
 #include "pairing_coop.cuh"
+#include "pairing_coop29.cuh"
 
 namespace snarkv {
 
-size_t g2_prepared_bytes() { return sizeof(G2Prepared); }
+// line table in the lazy 29-bit form the decide kernel consumes:
+// c[0..5] = cy.c0, cy.c1, cx.c0, cx.c1, cw.c0, cw.c1 (canonical residues)
+struct LineCoeff29 {
+  Fq29 c[6];
+};
+struct G2Prepared29 {
+  LineCoeff29 line[kLinesPerG2];
+  uint32_t is_identity;
+  uint32_t pad[3];
+};
+
+size_t g2_prepared_bytes() { return sizeof(G2Prepared) + sizeof(G2Prepared29); }
+static size_t prep29_offset() { return 2 * sizeof(G2Prepared); }
 
 __device__ __forceinline__ Fq load_fq_canonical(const uint32_t* __restrict__ src) {
   uint32_t w[8];
@@ -82,31 +95,44 @@ __global__ void __launch_bounds__(64) k_validate_g2(const uint32_t* __restrict__
   if (!ok) atomicAdd(bad, 1);
 }
 
+// 8x32 Montgomery (R = 2^256) line tables -> 29-bit Montgomery (R = 2^261)
+__global__ void __launch_bounds__(256) k_g2_to29(const G2Prepared* __restrict__ prep, G2Prepared29* __restrict__ out) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= 2 * kLinesPerG2 * 6) return;
+  int k = j / (kLinesPerG2 * 6), rem = j % (kLinesPerG2 * 6), idx = rem / 6, c = rem % 6;
+  const LineCoeff& l = prep[k].line[idx];
+  const Fq& src = c == 0 ? l.cy.c0 : c == 1 ? l.cy.c1 : c == 2 ? l.cx.c0 : c == 3 ? l.cx.c1 : c == 4 ? l.cw.c0 : l.cw.c1;
+  uint32_t w[8];
+  fq_to_canonical(src, w);
+  out[k].line[idx].c[c] = fq29_canon_residue(fq29_from_canonical(w));
+  if (rem == 0) out[k].is_identity = prep[k].is_identity;
+}
+
 // ------------------------------------------------------------------ D1
-struct CoopReg {  // an Fq12 in the flat basis, plus 9x (operand form for the w^6 wrap)
-  Fq v[12];
-  Fq v9[12];
+struct CoopReg {  // an Fq12 in the flat basis (c = 2i+e <-> u^e w^i), plus 9x
+  Fq29 v[12];
+  Fq29 v9[12];
 };
 
 enum { RF = 0, RT, RINV, RFX, RFX2, RFX3, RY0, RY1, RY2, RY3, RY4, RY5, RY6, RT0, RT1, RCOUNT };
 
 struct CoopShared {
   CoopReg r[RCOUNT];
-  Fq prods[COOP_NPROD];
-  Fq parts[48];
-  Fq lines[2][kLinesPerG2][6];  // per pair, per line: l0 (2), l1 (2), l2 (2) already times yP / xP
-  G1AffineM pt[2];
+  Fq29 prods[COOP_NPROD];
+  Fq29 parts[48];
+  Fq29 lines[2][kLinesPerG2][4];  // per pair, per line: l0 = cy*yP (2), l1 = cx*xP (2); l2 = cw is read from the key
+  Fq29 pt[2][2];                  // (x, y) of lhs, rhs
+  Fq29 scal[2];                   // an Fq2 scalar (inverse of the norm)
   int live[2];
 };
 
-// One workgroup = one accumulator; the whole state lives in LDS (file-scope so
+// One workgroup = one accumulator; the whole state lives in LDS (file scope so
 // that every helper addresses it with ds_* instructions, not flat pointers).
 __shared__ CoopShared g_sh;
 
-// Per-lane descriptors, loaded once into registers (never re-read from memory).
-struct CoopLane {
-  uint32_t prod;      // s | t<<4 | use9<<8, or 0xFFFF
-  uint32_t st1[3];    // six 16-bit stage-1 entries
+struct CoopLane {  // per-lane table entries, loaded once into registers
+  uint32_t prod;
+  unsigned short st1[COOP_STAGE1_TERMS];
 };
 
 static __device__ __forceinline__ CoopLane coop_lane_init() {
@@ -114,65 +140,45 @@ static __device__ __forceinline__ CoopLane coop_lane_init() {
   int tid = threadIdx.x;
   L.prod = tid < COOP_NPROD ? kCoopProd[tid] : 0xFFFFu;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    uint32_t lo = tid < 48 ? kCoopStage1[tid][2 * k] : 0xFFFFu;
-    uint32_t hi = tid < 48 ? kCoopStage1[tid][2 * k + 1] : 0xFFFFu;
-    L.st1[k] = lo | (hi << 16);
-  }
+  for (int k = 0; k < COOP_STAGE1_TERMS; ++k) L.st1[k] = tid < 48 ? kCoopStage1[tid][k] : (unsigned short)0xFFFFu;
   return L;
 }
-
-// b operand of a product round: a register of g_sh.r, or a sparse line
-struct CoopB {
-  int reg;   // >= 0: g_sh.r[reg].v
-  int pair;  // line operand: g_sh.lines[pair][idx]
-  int idx;
-};
 
 // flat slot t of a sparse line (non-zero slots 0,1,2,3,6,7 -> 0..5), -1 = zero
 static __device__ __forceinline__ int line_slot(unsigned t) { return t < 4 ? (int)t : (t == 6 ? 4 : (t == 7 ? 5 : -1)); }
 
-// dst = a * b.  All 256 lanes call it.
-static __device__ __forceinline__ void coop_mul_b(const CoopLane& L, int dst, int a, CoopB b) {
+static __device__ __forceinline__ void coop_store(int dst, int c, const Fq29& val) {
+  g_sh.r[dst].v[c] = val;
+  g_sh.r[dst].v9[c] = coop29_times9(val);
+}
+
+// dst = a * b, b a register (b_reg >= 0) or the sparse line (pair, idx).  All 256 lanes.
+static __device__ __forceinline__ void coop_mul_b(const CoopLane& L, int dst, int a, int b_reg, int pair, int idx,
+                                                  const G2Prepared29* __restrict__ prep) {
   int tid = threadIdx.x;
   if (tid < COOP_NPROD) {
     unsigned s = L.prod & 15u, t = (L.prod >> 4) & 15u;
-    const Fq& x = (L.prod >> 8) ? g_sh.r[a].v9[s] : g_sh.r[a].v[s];
-    if (b.reg >= 0) {
-      g_sh.prods[tid] = fq_mul(x, g_sh.r[b.reg].v[t]);
+    const Fq29& x = (L.prod >> 8) ? g_sh.r[a].v9[s] : g_sh.r[a].v[s];
+    if (b_reg >= 0) {
+      g_sh.prods[tid] = fq29_mul(x, g_sh.r[b_reg].v[t]);
     } else {
       int sl = line_slot(t);
-      g_sh.prods[tid] = sl >= 0 ? fq_mul(x, g_sh.lines[b.pair][b.idx][sl]) : fq_zero();
+      g_sh.prods[tid] = sl < 0 ? fq29_zero()
+                                : fq29_mul(x, sl < 4 ? g_sh.lines[pair][idx][sl] : prep[pair].line[idx].c[sl]);
     }
   }
   __syncthreads();
-  if (tid < 48) {
-    Fq acc = fq_zero();
-#pragma unroll
-    for (int k = 0; k < COOP_STAGE1_TERMS; ++k) {
-      unsigned e = (L.st1[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-      if (e != 0xFFFFu) {
-        const Fq& pr = g_sh.prods[e & 0x7FFFu];
-        acc = (e & 0x8000u) ? fq_sub(acc, pr) : fq_add(acc, pr);
-      }
-    }
-    g_sh.parts[tid] = acc;
-  }
+  if (tid < 48) g_sh.parts[tid] = coop29_stage1(L.st1, g_sh.prods);
   __syncthreads();
-  if (tid < 12) {
-    Fq c = fq_add(fq_add(g_sh.parts[4 * tid], g_sh.parts[4 * tid + 1]),
-                  fq_add(g_sh.parts[4 * tid + 2], g_sh.parts[4 * tid + 3]));
-    g_sh.r[dst].v[tid] = c;
-    g_sh.r[dst].v9[tid] = fq_mul9(c);
-  }
+  if (tid < 12) coop_store(dst, tid, coop29_stage2(tid, g_sh.parts));
   __syncthreads();
 }
 
 static __device__ __noinline__ void coop_mulr(const CoopLane& L, int dst, int a, int b) {
-  coop_mul_b(L, dst, a, CoopB{b, 0, 0});
+  coop_mul_b(L, dst, a, b, 0, 0, nullptr);
 }
-static __device__ __noinline__ void coop_mull(const CoopLane& L, int pair, int idx) {
-  coop_mul_b(L, RF, RF, CoopB{-1, pair, idx});
+static __device__ __noinline__ void coop_mull(const CoopLane& L, int pair, int idx, const G2Prepared29* __restrict__ prep) {
+  coop_mul_b(L, RF, RF, -1, pair, idx, prep);
 }
 
 // dst = conj(a): negate the odd powers of w (the c1 half of the tower)
@@ -180,48 +186,73 @@ static __device__ __noinline__ void coop_conj(int dst, int a) {
   int tid = threadIdx.x;
   if (tid < 12) {
     bool odd = ((tid >> 1) & 1) != 0;
-    Fq x = g_sh.r[a].v[tid], x9 = g_sh.r[a].v9[tid];
-    g_sh.r[dst].v[tid] = odd ? fq_neg(x) : x;
-    g_sh.r[dst].v9[tid] = odd ? fq_neg(x9) : x9;
+    Fq29 x = g_sh.r[a].v[tid], x9 = g_sh.r[a].v9[tid];
+    g_sh.r[dst].v[tid] = odd ? fq29_neg(x) : x;
+    g_sh.r[dst].v9[tid] = odd ? fq29_neg(x9) : x9;
   }
   __syncthreads();
+}
+
+// dst_i = conj^cj(a_i) * (g0 + g1 u) for the Fq2 coefficients i >= first (others copied)
+static __device__ __forceinline__ Fq29 fq2_scale_lane(const Fq29& x, const Fq29& y, const Fq29& g0, const Fq29& g1, int e) {
+  // (x + y u)(g0 + g1 u) = (x g0 - y g1) + (x g1 + y g0) u ; every product N, so the lazy sum stays < 2^30
+  return e ? fq29_add(fq29_mul(x, g1), fq29_mul(y, g0)) : fq29_sub(fq29_mul(x, g0), fq29_mul(y, g1));
 }
 
 // dst = a^(p^k), k in {1,2,3}: g_i -> conj^k(g_i) * gamma_{k,i}
 static __device__ __noinline__ void coop_frob(int dst, int a, int k) {
   int tid = threadIdx.x;
-  Fq out = fq_zero();
+  Fq29 out = fq29_zero();
   if (tid < 12) {
     int i = tid >> 1, e = tid & 1;
-    Fq x = g_sh.r[a].v[2 * i], y = g_sh.r[a].v[2 * i + 1];
-    if (k & 1) y = fq_neg(y);
+    Fq29 x = g_sh.r[a].v[2 * i], y = g_sh.r[a].v[2 * i + 1];
+    if (k & 1) y = fq29_neg(y);
     if (i == 0) {
       out = e ? y : x;
     } else {
-      Fq2 g = frob_gamma(k, i);
-      out = e ? fq_add(fq_mul(x, g.c1), fq_mul(y, g.c0)) : fq_sub(fq_mul(x, g.c0), fq_mul(y, g.c1));
+      Fq2_29 g = frob29_gamma(k, i);
+      out = fq2_scale_lane(x, y, g.c0, g.c1, e);
     }
+    out = fq29_norm(out);
   }
   __syncthreads();  // all reads of a done before dst (possibly == a) is written
-  if (tid < 12) {
-    g_sh.r[dst].v[tid] = out;
-    g_sh.r[dst].v9[tid] = fq_mul9(out);
-  }
+  if (tid < 12) coop_store(dst, tid, out);
   __syncthreads();
 }
 
-// dst = a^-1: tower inversion on lane 0 (one Fq inversion chain dominates it)
-static __device__ __noinline__ void coop_inv(int dst, int a) {
-  if (threadIdx.x == 0) {
-    Fq flat[12];
-    for (int c = 0; c < 12; ++c) flat[c] = g_sh.r[a].v[c];
-    Fq12 ti = fq12_inv(coop_tower_from_flat(flat));
-    coop_flat_from_tower(ti, flat);
-    for (int c = 0; c < 12; ++c) g_sh.r[dst].v[c] = flat[c];
+// dst = a * (scal[0] + scal[1] u), an Fq2 scalar
+static __device__ __noinline__ void coop_scale(int dst, int a) {
+  int tid = threadIdx.x;
+  Fq29 out = fq29_zero();
+  if (tid < 12) {
+    int i = tid >> 1, e = tid & 1;
+    out = fq29_norm(fq2_scale_lane(g_sh.r[a].v[2 * i], g_sh.r[a].v[2 * i + 1], g_sh.scal[0], g_sh.scal[1], e));
   }
   __syncthreads();
-  if (threadIdx.x < 12) g_sh.r[dst].v9[threadIdx.x] = fq_mul9(g_sh.r[dst].v[threadIdx.x]);
+  if (tid < 12) coop_store(dst, tid, out);
   __syncthreads();
+}
+
+// dst = a^-1 through the norms Fq12 -> Fq6 -> Fq2 -> Fq:
+//   N = a conj(a) in Fq6;  adj = N^(p^2) N^(p^4);  d = N adj in Fq2;
+//   a^-1 = conj(a) adj / d.      (uses RT0, RT1, RY0 as scratch; one Fq inversion chain on lane 0)
+static __device__ __noinline__ void coop_inv(const CoopLane& L, int dst, int a) {
+  coop_conj(RT0, a);                 // RT0 = conj(a)
+  coop_mulr(L, RT1, a, RT0);         // RT1 = N
+  coop_frob(RY0, RT1, 2);            // N^(p^2)
+  coop_frob(dst, RY0, 2);            // N^(p^4)
+  coop_mulr(L, RY0, RY0, dst);       // adj
+  coop_mulr(L, RT1, RT1, RY0);       // d (Fq2: coefficients 0, 1)
+  if (threadIdx.x == 0) {
+    Fq29 d0 = g_sh.r[RT1].v[0], d1 = g_sh.r[RT1].v[1];
+    Fq29 nrm = fq29_norm(fq29_add(fq29_sqr(d0), fq29_sqr(d1)));
+    Fq29 ni = fq29_inv(fq29_canon_residue(nrm));
+    g_sh.scal[0] = fq29_mul(d0, ni);
+    g_sh.scal[1] = fq29_neg(fq29_mul(d1, ni));
+  }
+  __syncthreads();
+  coop_mulr(L, dst, RT0, RY0);       // conj(a) adj
+  coop_scale(dst, dst);              // / d
 }
 
 static __device__ __noinline__ void coop_exp_by_x(const CoopLane& L, int dst, int a) {
@@ -238,7 +269,7 @@ static __device__ __noinline__ void coop_exp_by_x(const CoopLane& L, int dst, in
 }
 
 __global__ void __launch_bounds__(256)
-    k_decide(const G2Prepared* __restrict__ prep, const uint32_t* __restrict__ accs, uint32_t m,
+    k_decide(const G2Prepared29* __restrict__ prep, const uint32_t* __restrict__ accs, uint32_t m,
              uint8_t* __restrict__ ok, uint32_t* __restrict__ gt_out) {
   const int tid = threadIdx.x;
   const uint32_t i = blockIdx.x;
@@ -246,33 +277,21 @@ __global__ void __launch_bounds__(256)
   const CoopLane L = coop_lane_init();
   const uint32_t* a = accs + (size_t)i * 32;
   if (tid < 4) {  // lhs.x, lhs.y, rhs.x, rhs.y -> Montgomery
-    Fq v = load_fq_canonical(a + 8 * tid);
-    if (tid == 0) g_sh.pt[0].x = v;
-    if (tid == 1) g_sh.pt[0].y = v;
-    if (tid == 2) g_sh.pt[1].x = v;
-    if (tid == 3) g_sh.pt[1].y = v;
+    uint32_t w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = a[8 * tid + j];
+    g_sh.pt[tid >> 1][tid & 1] = fq29_canon_residue(fq29_from_canonical(w));
   }
-  if (tid < 12) {
-    Fq one = fq_one();
-    g_sh.r[RF].v[tid] = tid == 0 ? one : fq_zero();
-    g_sh.r[RF].v9[tid] = tid == 0 ? fq_mul9(one) : fq_zero();
-  }
+  if (tid < 12) coop_store(RF, tid, tid == 0 ? fq29_one() : fq29_zero());
   __syncthreads();
   if (tid < 2)
-    g_sh.live[tid] = !(fq_is_zero(g_sh.pt[tid].x) && fq_is_zero(g_sh.pt[tid].y)) && !prep[tid].is_identity;
+    g_sh.live[tid] = !(fq29_limbs_all_zero(g_sh.pt[tid][0]) && fq29_limbs_all_zero(g_sh.pt[tid][1])) &&
+                     !prep[tid].is_identity;
   // every line of both pairs evaluated at this accumulator's points, up front
-  // and in parallel (2 x 102 x 6 coefficients): l0 = cy*yP, l1 = cx*xP, l2 = cw
-  for (int j = tid; j < 2 * kLinesPerG2 * 6; j += 256) {
-    int k = j / (kLinesPerG2 * 6), rem = j % (kLinesPerG2 * 6), idx = rem / 6, c = rem % 6;
-    const LineCoeff& l = prep[k].line[idx];
-    Fq v;
-    if (c == 0) v = fq_mul(l.cy.c0, g_sh.pt[k].y);
-    else if (c == 1) v = fq_mul(l.cy.c1, g_sh.pt[k].y);
-    else if (c == 2) v = fq_mul(l.cx.c0, g_sh.pt[k].x);
-    else if (c == 3) v = fq_mul(l.cx.c1, g_sh.pt[k].x);
-    else if (c == 4) v = l.cw.c0;
-    else v = l.cw.c1;
-    g_sh.lines[k][idx][c] = v;
+  // and in parallel (2 x 102 x 4 products): l0 = cy*yP, l1 = cx*xP
+  for (int j = tid; j < 2 * kLinesPerG2 * 4; j += 256) {
+    int k = j / (kLinesPerG2 * 4), rem = j % (kLinesPerG2 * 4), idx = rem / 4, c = rem % 4;
+    g_sh.lines[k][idx][c] = fq29_mul(prep[k].line[idx].c[c], g_sh.pt[k][c < 2 ? 1 : 0]);
   }
   __syncthreads();
 
@@ -281,23 +300,23 @@ __global__ void __launch_bounds__(256)
   for (int b = kAteBits - 2; b >= 0; --b) {
     coop_mulr(L, RF, RF, RF);
     for (int k = 0; k < 2; ++k)
-      if (g_sh.live[k]) coop_mull(L, k, idx);
+      if (g_sh.live[k]) coop_mull(L, k, idx, prep);
     ++idx;
     if (ate_bit(b)) {
       for (int k = 0; k < 2; ++k)
-        if (g_sh.live[k]) coop_mull(L, k, idx);
+        if (g_sh.live[k]) coop_mull(L, k, idx, prep);
       ++idx;
     }
   }
   for (int s = 0; s < 2; ++s) {
     for (int k = 0; k < 2; ++k)
-      if (g_sh.live[k]) coop_mull(L, k, idx);
+      if (g_sh.live[k]) coop_mull(L, k, idx, prep);
     ++idx;
   }
 
   // ---- final exponentiation, exact exponent (p^12-1)/r (see pairing.cuh)
+  coop_inv(L, RINV, RF);
   coop_conj(RT, RF);
-  coop_inv(RINV, RF);
   coop_mulr(L, RF, RT, RINV);          // f^(p^6-1)
   coop_frob(RT, RF, 2);
   coop_mulr(L, RF, RT, RF);            // ^(p^2+1)
@@ -334,22 +353,31 @@ __global__ void __launch_bounds__(256)
   coop_mulr(L, RT0, RT0, RT0);
   coop_mulr(L, RF, RT0, RT1);          // result = t0^2 t1
 
+  // canonical words of the 12 coefficients (lane c), then the verdict
+  __shared__ uint32_t canon[12][8];
+  if (tid < 12) fq29_to_canonical(g_sh.r[RF].v[tid], canon[tid]);
+  __syncthreads();
   if (tid == 0 && ok) {
-    bool one = fq_eq(g_sh.r[RF].v[0], fq_one());
-    for (int c = 1; c < 12; ++c) one = one && fq_is_zero(g_sh.r[RF].v[c]);
+    bool one = canon[0][0] == 1u;
+    for (int c = 0; c < 12; ++c)
+      for (int j = (c == 0 ? 1 : 0); j < 8; ++j) one = one && canon[c][j] == 0u;
     ok[i] = one ? 1 : 0;
   }
   if (gt_out && tid < 12) {
     // tower byte order: c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2  =  w^0, w^2, w^4, w^1, w^3, w^5
     const int wexp[6] = {0, 2, 4, 1, 3, 5};
     int pos = tid >> 1, e = tid & 1;
-    store_fq_canonical(g_sh.r[RF].v[2 * wexp[pos] + e], gt_out + (size_t)i * 96 + (size_t)(2 * pos + e) * 8);
+    uint32_t* dstw = gt_out + (size_t)i * 96 + (size_t)(2 * pos + e) * 8;
+    for (int j = 0; j < 8; ++j) dstw[j] = canon[2 * wexp[pos] + e][j];
   }
 }
 
 int launch_g2_prepare(snarkv_ctx* ctx, const void* d_g2x2_256, void* d_prep) {
   hipLaunchKernelGGL(k_g2_prepare, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)d_g2x2_256,
                      (G2Prepared*)d_prep);
+  G2Prepared29* d29 = reinterpret_cast<G2Prepared29*>((char*)d_prep + prep29_offset());
+  hipLaunchKernelGGL(k_g2_to29, dim3((2 * kLinesPerG2 * 6 + 255) / 256), dim3(256), 0, ctx->stream,
+                     (const G2Prepared*)d_prep, d29);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }
@@ -366,7 +394,8 @@ int launch_validate_g2(snarkv_ctx* ctx, const void* d_g2x2_256, int* bad_host) {
 }
 
 int launch_decide(snarkv_ctx* ctx, const void* d_prep, const void* d_accs, size_t m, void* d_ok, void* d_gt) {
-  hipLaunchKernelGGL(k_decide, dim3((uint32_t)m), dim3(256), 0, ctx->stream, (const G2Prepared*)d_prep,
+  const G2Prepared29* d29 = reinterpret_cast<const G2Prepared29*>((const char*)d_prep + prep29_offset());
+  hipLaunchKernelGGL(k_decide, dim3((uint32_t)m), dim3(256), 0, ctx->stream, d29,
                      (const uint32_t*)d_accs, (uint32_t)m, (uint8_t*)d_ok, (uint32_t*)d_gt);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;

@@ -254,6 +254,40 @@ SNARKV_HD void fq29_to_canonical(const Fq29& a, uint32_t w[8]) {
   }
 }
 
+// x - round(x/p) p for |x| up to ~64p, x carry-normalised: the quotient is
+// estimated from the top limb (bits 232..), exact to +-1, so |result| < 1.5p.
+// Result carry-normalised.  (Cheap modular squeeze after a lazy sum of many
+// products; one float multiply, nine 64-bit mads.)
+SNARKV_HD Fq29 fq29_reduce_small(const Fq29& x) {
+  const float inv_ptop = 1.0f / (float)(0x0030644e);  // p >> 232
+  float qf = (float)x.v[8] * inv_ptop;
+  int32_t q = (int32_t)(qf + (qf >= 0 ? 0.5f : -0.5f));
+  Fq29 r;
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int64_t t = (int64_t)x.v[i] - (int64_t)q * fq29_p(i) + c;
+    r.v[i] = (int32_t)t & kMask29;
+    c = t >> 29;
+  }
+  r.v[8] = (int32_t)((int64_t)x.v[8] - (int64_t)q * fq29_p(8) + c);
+  return r;
+}
+
+// carry-normalised k*x for a small constant k (|k| < 2^20), x carry-normalised
+SNARKV_HD Fq29 fq29_mul_small_norm(const Fq29& x, int32_t k) {
+  Fq29 r;
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int64_t t = (int64_t)x.v[i] * k + c;
+    r.v[i] = (int32_t)t & kMask29;
+    c = t >> 29;
+  }
+  r.v[8] = (int32_t)((int64_t)x.v[8] * k + c);
+  return r;
+}
+
 // a^(p-2) (lane-uniform exponent); a must be carry-normalised, result too.
 SNARKV_HD_NOINLINE Fq29 fq29_inv(const Fq29& a) {
   constexpr uint32_t e[8] = BN254_P_MINUS_2_LIMBS;

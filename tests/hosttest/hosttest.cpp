@@ -7,6 +7,7 @@
 #include "../../snark-verifier_amd/csrc/g1_29.cuh"
 #include "../../snark-verifier_amd/csrc/glv.cuh"
 #include "../../snark-verifier_amd/csrc/pairing_coop.cuh"
+#include "../../snark-verifier_amd/csrc/pairing_coop29.cuh"
 
 using namespace snarkv;
 
@@ -209,6 +210,37 @@ void ht_coop_fq12_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
   for (int l = 0; l < COOP_NPROD; ++l) prods[l] = coop_product(l, fa, fa9, fb);
   for (int q = 0; q < 48; ++q) parts[q] = coop_stage1(q, prods);
   for (int c = 0; c < 12; ++c) fc[c] = coop_stage2(c, parts);
+  store_fq12(coop_tower_from_flat(fc), out);
+}
+// the same emulation on the lazy 29-bit field, iterated `rounds` times
+// (f <- f*b) to exercise the magnitude invariants across rounds
+void ht_coop29_fq12_mul_iter(const uint8_t* a, const uint8_t* b, int rounds, uint8_t* out) {
+  Fq fa8[12], fb8[12];
+  coop_flat_from_tower(load_fq12(a), fa8);
+  coop_flat_from_tower(load_fq12(b), fb8);
+  Fq29 fa[12], fa9[12], fb[12], prods[COOP_NPROD], parts[48];
+  for (int c = 0; c < 12; ++c) {
+    uint32_t w[8];
+    fq_to_canonical(fa8[c], w);
+    fa[c] = fq29_canon_residue(fq29_from_canonical(w));
+    fa9[c] = coop29_times9(fa[c]);
+    fq_to_canonical(fb8[c], w);
+    fb[c] = fq29_canon_residue(fq29_from_canonical(w));
+  }
+  for (int r = 0; r < rounds; ++r) {
+    for (int l = 0; l < COOP_NPROD; ++l) prods[l] = coop29_product(kCoopProd[l], fa, fa9, fb);
+    for (int q = 0; q < 48; ++q) parts[q] = coop29_stage1(kCoopStage1[q], prods);
+    for (int c = 0; c < 12; ++c) {
+      fa[c] = coop29_stage2(c, parts);
+      fa9[c] = coop29_times9(fa[c]);
+    }
+  }
+  Fq fc[12];
+  for (int c = 0; c < 12; ++c) {
+    uint32_t w[8];
+    fq29_to_canonical(fa[c], w);
+    fc[c] = fq_from_canonical(w);
+  }
   store_fq12(coop_tower_from_flat(fc), out);
 }
 }

@@ -215,3 +215,25 @@ def test_cooperative_fq12_tables(hosttest_lib):
         A, B = _rfq12(rng), _rfq12(rng)
         hosttest_lib.ht_coop_fq12_mul(A.to_bytes(), B.to_bytes(), o)
         assert o.raw == (A * B).to_bytes()
+
+
+def test_cooperative_fq12_rounds_on_lazy_field(hosttest_lib):
+    """The shipped decide kernel's arithmetic (csrc/pairing_coop29.cuh): chained
+    cooperative products on the 9x29-bit lazy field keep their magnitude
+    invariants and stay exact, including all-(p-1) coefficients."""
+    rng = random.Random(13)
+    o = _buf(384)
+    for rounds in (1, 2, 5, 40):
+        A, B = _rfq12(rng), _rfq12(rng)
+        hosttest_lib.ht_coop29_fq12_mul_iter(A.to_bytes(), B.to_bytes(), rounds, o)
+        exp = A
+        for _ in range(rounds):
+            exp = exp * B
+        assert o.raw == exp.to_bytes()
+    m = O.Fq2(O.P - 1, O.P - 1)
+    M = O.Fq12(O.Fq6(m, m, m), O.Fq6(m, m, m))
+    hosttest_lib.ht_coop29_fq12_mul_iter(M.to_bytes(), M.to_bytes(), 30, o)
+    exp = M
+    for _ in range(30):
+        exp = exp * M
+    assert o.raw == exp.to_bytes()
