@@ -4,9 +4,14 @@
 A "step" is ONE pass of the hot path over one batch of synthetic input: every
 rank reduces its own 2^20-point shard (inputs resident in HBM, generated there
 by the seeded SplitMix64 sampler of SURVEY.md 8d) to a projective partial with
-the HIP Pippenger; for N > 1 the partials (128 B per rank) are all-gathered
+the HIP Pippenger; for N > 1 the partials (144 B per rank) are all-gathered
 over RCCL/xGMI and every rank folds them to the same affine point (SURVEY.md
 8e).  value = N * 2^20 * steps / wall time (max over ranks) -> weak scaling.
+Several independent MSMs are kept in flight (one context + HIP stream each,
+default 4): bucket accumulation is VALU-bound while the bucket reduce, the
+2^(cw) doubling chains and to_affine are dependency chains on a few wavefronts,
+so consecutive steps overlap.  `config.single_msm_latency_ms` gives the strictly
+sequential figure.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -121,7 +126,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path even at world size 1 (testing)")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="independent MSMs kept in flight (one context + HIP stream each); 1 = strictly sequential")
     args = ap.parse_args()
 
@@ -149,7 +154,7 @@ def main():
     # One context per in-flight MSM, each on its own HIP stream: the latency-bound
     # tail of one MSM (bucket reduce, 2^(cw) doubling chains, to_affine: a few
     # wavefronts) overlaps the VALU-bound bucket accumulation of the next.
-    inflight = max(1, args.inflight) if not use_dist else 1
+    inflight = max(1, args.inflight)
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(inflight - 1)]
     ctxs = [sv.Context(local_rank, stream=s.cuda_stream) for s in streams]
     ctx = ctxs[0]
@@ -159,24 +164,26 @@ def main():
     # disjoint index ranges of one global stream per rank: rank r owns [r*n, (r+1)*n)
     ctx.sample_scalars_dev(0x5EED0001, n, d_scalars.data_ptr(), first=rank * n)
     ctx.sample_points_dev(0x5EED0002, n, d_points.data_ptr(), first=rank * n)
-    partial = torch.zeros(sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
-    gathered = torch.zeros(world * sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+    partials = [torch.zeros(sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda") for _ in range(inflight)]
+    gathereds = [torch.zeros(world * sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda") for _ in range(inflight)]
     out = torch.zeros(64, dtype=torch.uint8, device="cuda")
     outs = [out] + [torch.zeros(64, dtype=torch.uint8, device="cuda") for _ in range(inflight - 1)]
     torch.cuda.synchronize()
     step_no = [0]
 
     def step():
+        k = step_no[0] % inflight
+        step_no[0] += 1
         if not use_dist:
-            k = step_no[0] % inflight
-            step_no[0] += 1
             ctxs[k].msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, outs[k].data_ptr(), args.window_bits)
         else:
-            # snark-verifier_amd/distributed.py: shard -> HIP partial -> RCCL all-gather (144 B/rank) -> HIP fold
-            ctx.msm_pippenger_partial_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, partial.data_ptr(),
-                                          args.window_bits)
-            dist.all_gather_into_tensor(gathered, partial)
-            ctx.fold_partials_dev(gathered.data_ptr(), world, out.data_ptr())
+            # snark-verifier_amd/distributed.py: shard -> HIP partial -> RCCL all-gather (144 B/rank) -> HIP fold,
+            # all three enqueued on slot k's stream (every rank issues the collectives in the same order)
+            with torch.cuda.stream(streams[k]):
+                ctxs[k].msm_pippenger_partial_dev(d_scalars.data_ptr(), d_points.data_ptr(), n,
+                                                  partials[k].data_ptr(), args.window_bits)
+                dist.all_gather_into_tensor(gathereds[k], partials[k])
+                ctxs[k].fold_partials_dev(gathereds[k].data_ptr(), world, outs[k].data_ptr())
 
     def barrier():
         if use_dist:
@@ -196,7 +203,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step()
-        if inflight == 1 or use_dist:
+        if inflight == 1:
             st = ctx.get_stage_timing()  # sequential mode: consume each step before the next
             stage_cnt += 1
             for k, v in st.items():
