@@ -222,14 +222,19 @@ def main():
         assert bytes(o.cpu().numpy()) == bytes(out.cpu().numpy())
 
     # single-MSM latency (strictly sequential), outside the timed region, for the record
-    lat_ms = None
+    lat_ms, seq_stages = None, None
     if not use_dist:
         torch.cuda.synchronize()
+        ctx.set_stage_timing(True)
+        seq_sum = {}
         t1 = time.perf_counter()
         for _ in range(5):
             ctx.msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, out.data_ptr(), args.window_bits)
-            ctx.sync()
+            for k, v in ctx.get_stage_timing().items():  # syncs
+                seq_sum[k] = seq_sum.get(k, 0.0) + v
         lat_ms = (time.perf_counter() - t1) / 5 * 1e3
+        ctx.set_stage_timing(False)
+        seq_stages = {k: v / 5 for k, v in seq_sum.items()}
 
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -273,11 +278,18 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": None,
-                "note": "algorithmic 96 B/point x 2^%d points / avg HIP-event duration of the dominant stage; "
-                        "the path is integer-VALU-bound (~160 Fq products per point), see DESIGN.md" % args.log2n,
+                "note": "algorithmic 96 B/point x 2^%d points / avg HIP-event duration of the dominant stage in the "
+                        "timed region (where %d MSMs overlap, so one launch shares the GPU); the path is "
+                        "integer-VALU-bound (~160 Fq products per point), see DESIGN.md" % (args.log2n, inflight),
             },
             "stages_ms": stages,
         }
+        if seq_stages:
+            dseq = seq_stages.get(dom, 0.0)
+            line["stages_ms_sequential"] = seq_stages
+            if dseq > 0:
+                line["roofline"]["achieved_unshared"] = BYTES_PER_POINT * n / (dseq * 1e-3) / 1e9
+                line["roofline"]["frac_unshared"] = line["roofline"]["achieved_unshared"] / HBM_PEAK_GBPS
         if not args.no_cpu_baseline:
             cb, cpu_out, (s, p) = cpu_baseline(ctx, d_scalars, d_points, min(args.cpu_sample_log2, args.log2n))
             # the GPU must agree with the CPU restatement on that same sample
