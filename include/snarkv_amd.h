@@ -151,7 +151,7 @@ int snarkv_sample_points_dev(snarkv_ctx* ctx, uint64_t seed, uint64_t first, siz
 /* ---- profiling hooks used by bench.py --------------------------------- *
  * Per-stage HIP-event timings (ms) of the last *_dev Pippenger call on this
  * context when enabled: [0]=total [1]=prepare (GLV split, phi(P), Montgomery)
- * [2]=digit histogram + scan [3]=partition + level-2 sort [4]=bucket
+ * + digit histogram [2]=scan [3]=partition + level-2 sort [4]=bucket
  * accumulate [5]=bucket combine [6]=bucket reduce [7]=window sums + 2^(cw)
  * shift chains [8]=final sum + to_affine.                                    */
 #define SNARKV_PIP_STAGES 9

@@ -15,7 +15,7 @@ SNARKV_ERR_ARG = -5
 SNARKV_FLAG_VALIDATE = 1
 SNARKV_PIP_STAGES = 9
 PIP_STAGE_NAMES = [
-    "total", "prepare_glv_montgomery", "digit_histogram_scan", "partition_sort", "bucket_accumulate",
+    "total", "prepare_glv_montgomery_histogram", "scan", "partition_sort", "bucket_accumulate",
     "bucket_combine", "bucket_reduce", "window_shift_chain", "final_to_affine",
 ]
 G1_PARTIAL_BYTES = 144

@@ -11,11 +11,11 @@
 //   P0 k_prepare        GLV split k = k1 + k2*lambda (|k_i| < 2^127, glv.cuh) and
 //                        points P, phi(P) = (beta x, y): canonical LE -> 9x29-bit
 //                        Montgomery, once.  2n half-width terms: the same number
-//                        of bucket additions, half the windows.
-//   S1 k_sort_level1<0>  signed c-bit digits (half the buckets of msm.rs:269);
+//                        of bucket additions, half the windows.  Fused with S1:
+//                        signed c-bit digits (half the buckets of msm.rs:269),
 //                        per-tile LDS histogram of (window, high digit bits)
 //   S2 k_scan_*          exclusive scan of the key x tile matrix
-//   S3 k_sort_level1<1>  stable partition of (bucket, point, sign) by
+//   S3 k_sort_scatter    stable partition of (bucket, point, sign) by
 //                        (window, high bits) -- LDS cursors, no global atomics
 //   S4 k_sort_level2     one workgroup per (window, high bits): LDS counting
 //                        sort by the low digit bits; emits the bucket-sorted
@@ -90,92 +90,96 @@ __device__ __forceinline__ uint32_t half_bits(const uint32_t k[4], int lo, int c
   return (uint32_t)(v >> sh) & ((1u << c) - 1u);
 }
 
-__device__ __forceinline__ bool point_is_identity(const uint32_t* __restrict__ points, uint32_t i) {
-  const uint4* q = reinterpret_cast<const uint4*>(points + (size_t)i * 16);
-  uint4 a = q[0], b = q[1], c = q[2], d = q[3];
-  return (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w | c.x | c.y | c.z | c.w | d.x | d.y | d.z | d.w) == 0;
-}
-
-// --------------------------------------------------------------- P0
-__global__ void k_prepare(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points,
-                          G1Affine29* __restrict__ pts, uint4* __restrict__ glv, uint32_t n) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint4* s = reinterpret_cast<const uint4*>(points + (size_t)i * 16);
-  uint32_t w[16];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    uint4 v = s[j];
-    w[4 * j] = v.x;
-    w[4 * j + 1] = v.y;
-    w[4 * j + 2] = v.z;
-    w[4 * j + 3] = v.w;
+// --------------------------------------------------------------- P0 + S1
+// Signed-digit recoding of a 127-bit magnitude: raw = bits + carry in [0, 2^c];
+// raw > 2^(c-1) becomes raw - 2^c (negative) with a carry into the next window.
+// With W*c >= 128 the top window never carries out.  A negative half (sign in
+// bit 127) flips every digit's sign.  `emit(key, bucket, neg)` per non-zero digit.
+template <class F>
+__device__ __forceinline__ void for_each_digit(const uint4 kv, const PipParams& p, F emit) {
+  uint32_t sgn = kv.w >> 31;
+  uint32_t k[4] = {kv.x, kv.y, kv.z, kv.w & 0x7FFFFFFFu};
+  uint32_t carry = 0;
+  for (int w = 0; w < p.W; ++w) {
+    uint32_t raw = half_bits(k, w * p.c, p.c) + carry;
+    uint32_t neg = raw > p.B ? 1u : 0u;
+    uint32_t d = neg ? ((1u << p.c) - raw) : raw;
+    carry = neg;
+    if (d != 0) emit((uint32_t)w * p.SB + ((d - 1) >> p.low_bits), (uint32_t)w * p.B + d - 1, neg ^ sgn);
   }
-  G1Affine29 a = g1a29_from_canonical(w);
-  pts[2 * (size_t)i] = a;
-  constexpr int32_t bl[9] = BN254_GLV_BETA29_LIMBS;
-  Fq29 beta;
-#pragma unroll
-  for (int j = 0; j < 9; ++j) beta.v[j] = bl[j];
-  a.x = fq29_canon_residue(fq29_mul(a.x, beta));  // phi(P) = (beta x, y); identity stays (0,0)
-  pts[2 * (size_t)i + 1] = a;
-  const uint4* ks = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
-  uint4 k0 = ks[0], k1 = ks[1];
-  uint32_t k[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w}, o[8];
-  glv_decompose(k, o);
-  glv[2 * (size_t)i] = make_uint4(o[0], o[1], o[2], o[3]);
-  glv[2 * (size_t)i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
-// --------------------------------------------------------------- S1 / S3
-// Signed-digit recoding: raw = bits + carry in [0, 2^c]; raw > 2^(c-1) becomes
-// raw - 2^c (negative) with a carry into the next window.  With W*c >= 128 and
-// GLV magnitudes < 2^127 the top window never carries out.  A negative half
-// (sign in bit 127) flips every digit's sign.  Zero digits and identity points
-// contribute nothing and are dropped here.
-//
-// One workgroup = one tile of kTile scalars.  HIST: LDS histogram over the
-// (window, high digit bits) keys -> column `blockIdx` of the matrix M.
-// SCATTER: M has been scanned (key-major, tile-minor), so M[key][tile] is where
-// this tile's items of that key start; LDS cursors hand out the slots.
-template <bool SCATTER>
+// One workgroup = one tile of p.tile scalars: GLV split k = k1 + k2*lambda,
+// P and phi(P) = (beta x, y) to 9x29-bit Montgomery, and the LDS histogram of
+// the (window, high digit bits) keys -> column `blockIdx` of the matrix M.
+// The identity (64 zero bytes) contributes nothing: its half-scalars are
+// stored as zero, so the sort never has to look at the points again.
 __global__ void __launch_bounds__(256)
-    k_sort_level1(const uint4* __restrict__ glv, const uint32_t* __restrict__ points, PipParams p,
-                  uint32_t* __restrict__ M, uint2* __restrict__ tmp) {
-  extern __shared__ uint32_t lds[];  // nkeys counters / cursors
-  for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x)
-    lds[k] = SCATTER ? M[(size_t)k * p.mstride + blockIdx.x] : 0u;
+    k_prepare(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points,
+              G1Affine29* __restrict__ pts, uint4* __restrict__ glv, PipParams p, uint32_t* __restrict__ M) {
+  extern __shared__ uint32_t lds[];  // nkeys counters
+  for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) lds[k] = 0u;
   __syncthreads();
   uint32_t lo = blockIdx.x * p.tile;
   uint32_t hi = lo + p.tile < p.n ? lo + p.tile : p.n;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    if (point_is_identity(points, i)) continue;
-    for (uint32_t h = 0; h < 2; ++h) {
-      uint4 kv = glv[2 * (size_t)i + h];
-      uint32_t sgn = kv.w >> 31;
-      uint32_t k[4] = {kv.x, kv.y, kv.z, kv.w & 0x7FFFFFFFu};
-      uint32_t v = 2 * i + h;  // virtual point: P (h=0) or phi(P) (h=1)
-      uint32_t carry = 0;
-      for (int w = 0; w < p.W; ++w) {
-        uint32_t raw = half_bits(k, w * p.c, p.c) + carry;
-        uint32_t neg = raw > p.B ? 1u : 0u;
-        uint32_t d = neg ? ((1u << p.c) - raw) : raw;
-        carry = neg;
-        if (d != 0) {
-          uint32_t key = (uint32_t)w * p.SB + ((d - 1) >> p.low_bits);
-          if (SCATTER) {
-            uint32_t pos = atomicAdd(&lds[key], 1u);
-            tmp[pos] = make_uint2((uint32_t)w * p.B + d - 1, v | ((neg ^ sgn) << 31));
-          } else {
-            atomicAdd(&lds[key], 1u);
-          }
-        }
-      }
+    const uint4* s = reinterpret_cast<const uint4*>(points + (size_t)i * 16);
+    uint32_t w[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint4 v = s[j];
+      w[4 * j] = v.x;
+      w[4 * j + 1] = v.y;
+      w[4 * j + 2] = v.z;
+      w[4 * j + 3] = v.w;
     }
+    G1Affine29 a = g1a29_from_canonical(w);
+    bool ident = g1a29_is_identity(a);
+    pts[2 * (size_t)i] = a;
+    constexpr int32_t bl[9] = BN254_GLV_BETA29_LIMBS;
+    Fq29 beta;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) beta.v[j] = bl[j];
+    a.x = fq29_canon_residue(fq29_mul(a.x, beta));  // phi(P) = (beta x, y)
+    pts[2 * (size_t)i + 1] = a;
+    const uint4* ks = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+    uint4 k0 = ks[0], k1 = ks[1];
+    uint32_t k[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w}, o[8];
+    glv_decompose(k, o);
+    if (ident) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = 0;
+    }
+    uint4 h0 = make_uint4(o[0], o[1], o[2], o[3]), h1 = make_uint4(o[4], o[5], o[6], o[7]);
+    glv[2 * (size_t)i] = h0;
+    glv[2 * (size_t)i + 1] = h1;
+    for_each_digit(h0, p, [&](uint32_t key, uint32_t, uint32_t) { atomicAdd(&lds[key], 1u); });
+    for_each_digit(h1, p, [&](uint32_t key, uint32_t, uint32_t) { atomicAdd(&lds[key], 1u); });
   }
-  if (!SCATTER) {
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) M[(size_t)k * p.mstride + blockIdx.x] = lds[k];
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) M[(size_t)k * p.mstride + blockIdx.x] = lds[k];
+}
+
+// --------------------------------------------------------------- S3
+// Stable partition by (window, high bits).  M has been scanned (key-major,
+// tile-minor), so M[key][tile] is where this tile's items of that key start;
+// LDS cursors hand out the slots -- no global atomics.
+__global__ void __launch_bounds__(256)
+    k_sort_scatter(const uint4* __restrict__ glv, PipParams p, const uint32_t* __restrict__ M,
+                   uint2* __restrict__ tmp) {
+  extern __shared__ uint32_t lds[];  // nkeys cursors
+  for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) lds[k] = M[(size_t)k * p.mstride + blockIdx.x];
+  __syncthreads();
+  uint32_t lo = blockIdx.x * p.tile;
+  uint32_t hi = lo + p.tile < p.n ? lo + p.tile : p.n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    for (uint32_t h = 0; h < 2; ++h) {
+      uint32_t v = 2 * i + h;  // virtual point: P (h=0) or phi(P) (h=1)
+      for_each_digit(glv[2 * (size_t)i + h], p, [&](uint32_t key, uint32_t bucket, uint32_t neg) {
+        uint32_t pos = atomicAdd(&lds[key], 1u);
+        tmp[pos] = make_uint2(bucket, v | (neg << 31));
+      });
+    }
   }
 }
 
@@ -693,20 +697,18 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
     ctx->ev_ready = true;
   }
   STAGE_MARK();  // 0
-  hipLaunchKernelGGL(k_prepare, dim3((p.n + 127) / 128), dim3(128), 0, st, (const uint32_t*)d_scalars,
-                     (const uint32_t*)d_points, (G1Affine29*)d_pts, (uint4*)d_glv, p.n);
-  STAGE_MARK();  // 1: prepare (GLV split, phi(P), to Montgomery)
   size_t lds1 = (size_t)p.nkeys * 4;
   SNARKV_HIP(hipMemsetAsync(d_M, 0, (size_t)mcount * 4, st));  // padding columns must read as zero
-  hipLaunchKernelGGL(k_sort_level1<false>, dim3(p.nblk), dim3(256), lds1, st, (const uint4*)d_glv,
-                     (const uint32_t*)d_points, p, (uint32_t*)d_M, (uint2*)nullptr);
+  hipLaunchKernelGGL(k_prepare, dim3(p.nblk), dim3(256), lds1, st, (const uint32_t*)d_scalars,
+                     (const uint32_t*)d_points, (G1Affine29*)d_pts, (uint4*)d_glv, p, (uint32_t*)d_M);
+  STAGE_MARK();  // 1: prepare (GLV split, phi(P), to Montgomery) + digit histogram
   hipLaunchKernelGGL(k_scan_local, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (uint32_t*)d_blocksum, mcount);
   hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, st, (uint32_t*)d_blocksum, scan_blocks, d_total);
   hipLaunchKernelGGL(k_scan_add, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (const uint32_t*)d_blocksum,
                      mcount);
-  STAGE_MARK();  // 2: digit histogram + scan
-  hipLaunchKernelGGL(k_sort_level1<true>, dim3(p.nblk), dim3(256), lds1, st, (const uint4*)d_glv,
-                     (const uint32_t*)d_points, p, (uint32_t*)d_M, (uint2*)d_tmp);
+  STAGE_MARK();  // 2: scan
+  hipLaunchKernelGGL(k_sort_scatter, dim3(p.nblk), dim3(256), lds1, st, (const uint4*)d_glv, p,
+                     (const uint32_t*)d_M, (uint2*)d_tmp);
   size_t lds2 = ((size_t)(1u << p.low_bits) + 512) * 4 + (size_t)kSortCap * 8;
   hipLaunchKernelGGL(k_sort_level2, dim3(p.nkeys), dim3(512), lds2, st, (const uint2*)d_tmp, (const uint32_t*)d_M,
                      (const uint32_t*)d_total, p, (uint2*)d_entries, (uint32_t*)d_counts, (uint32_t*)d_offsets);
