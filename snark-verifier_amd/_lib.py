@@ -81,7 +81,8 @@ _lib = None
 
 
 def lib_path():
-    return os.path.join(HERE, _LIB_NAME)
+    # SNARKV_AMD_LIB: alternate build of the same library (A/B runs of kernel variants)
+    return os.environ.get("SNARKV_AMD_LIB") or os.path.join(HERE, _LIB_NAME)
 
 
 def load_library():

@@ -341,8 +341,17 @@ __device__ __forceinline__ bool accumulate_run(const uint2* __restrict__ entries
   uint32_t cur = entries[begin].x;
   bool first = true, fresh = true, bad = false;
   G1Xyzz29 acc = xyzz29_identity();
+  // software pipeline: the (entry -> point) gather of step e+1 is issued before
+  // the ~2 300-instruction mixed addition of step e
+  uint2 ent_n = entries[begin];
+  G1Affine29 p_n = pts[ent_n.y & 0x7FFFFFFFu];
   for (uint32_t e = begin; e < end; ++e) {
-    uint2 ent = entries[e];
+    uint2 ent = ent_n;
+    G1Affine29 p = p_n;
+    if (e + 1 < end) {
+      ent_n = entries[e + 1];
+      p_n = pts[ent_n.y & 0x7FFFFFFFu];
+    }
     if (ent.x != cur) {
       if (!CAREFUL) bad = bad || xyzz29_is_degenerate(acc);
       if (first) {
@@ -356,7 +365,6 @@ __device__ __forceinline__ bool accumulate_run(const uint2* __restrict__ entries
       fresh = true;
       if (CAREFUL) acc = xyzz29_identity();
     }
-    G1Affine29 p = pts[ent.y & 0x7FFFFFFFu];
     if (ent.y >> 31) p.y = fq29_neg(p.y);
     if (CAREFUL) {
       xyzz29_madd_careful(acc, p);

@@ -84,3 +84,29 @@ def test_python_vs_c_random():
         p = b"".join(O.g1_to_bytes(x) for x in pts)
         exp = O.g1_to_bytes(O.g1_msm_naive(sc, pts))
         assert C.msm_naive(s, p) == exp and C.msm_pippenger(s, p, 2) == exp
+
+
+def test_golden_kzg_layer_oracle_reproduces():
+    """The committed KZG-layer fixture is what oracle/kzg.py computes today, and
+    every accumulator in it is a valid opening under the toy SRS."""
+    import json
+    import os
+
+    import kzg as K
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = json.load(open(os.path.join(root, "tests", "golden", "kzg_layer.json")))
+    secret = int(g["secret"], 16)
+    ka = g["kzg_as"]
+    raw = bytes.fromhex(ka["accumulators"])
+    accs = [(O.g1_from_bytes(raw[128 * i:128 * i + 64]), O.g1_from_bytes(raw[128 * i + 64:128 * i + 128]))
+            for i in range(len(raw) // 128)]
+    for lhs, rhs in accs:
+        assert lhs == O.g1_mul(rhs, secret)
+    r = O.fe_from_bytes(bytes.fromhex(ka["r"]))
+    res = K.kzg_as_verify(accs, r)
+    assert (O.g1_to_bytes(res[0]) + O.g1_to_bytes(res[1])).hex() == ka["result"]
+    lim = bytes.fromhex(g["limbs"]["limbs"])
+    limbs = [O.fe_from_bytes(lim[32 * i:32 * i + 32]) for i in range(16)]
+    back = K.limbs_from_repr(limbs)
+    assert (O.g1_to_bytes(back[0]) + O.g1_to_bytes(back[1])).hex() == g["limbs"]["accumulator"]
