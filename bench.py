@@ -284,6 +284,23 @@ def main():
             },
             "stages_ms": stages,
         }
+        if not use_dist:
+            # Integer-VALU roofline (the binding constraint): the same
+            # mixed addition as k_accumulate in isolation, 4 waves/SIMD on every CU.
+            W = -(-128 // 16) if not args.window_bits else -(-128 // args.window_bits)
+            adds = 2.0 * n * W  # one bucket addition per (half-scalar, window)
+            peak_madd = ctx.ubench_valu(1, 300)
+            peak_mul = ctx.ubench_valu(0, 2000)
+            acc_ms = (seq_stages or stages).get("bucket_accumulate", 0.0)
+            if acc_ms > 0:
+                line["valu_roofline"] = {
+                    "kernel": "k_accumulate", "unit": "G1 mixed additions/s",
+                    "achieved": adds / (acc_ms * 1e-3), "peak": peak_madd,
+                    "frac": adds / (acc_ms * 1e-3) / peak_madd,
+                    "peak_fq_mul_per_s": peak_mul,
+                    "note": "peak = xyzz29_madd_fast chains with no memory traffic, measured live "
+                            "(snarkv_ubench_valu); achieved uses the unshared (sequential) launch duration",
+                }
         if seq_stages:
             dseq = seq_stages.get(dom, 0.0)
             line["stages_ms_sequential"] = seq_stages

@@ -155,6 +155,11 @@ int snarkv_sample_points_dev(snarkv_ctx* ctx, uint64_t seed, uint64_t first, siz
  * accumulate [5]=bucket combine [6]=bucket reduce [7]=window sums + 2^(cw)
  * shift chains [8]=final sum + to_affine.                                    */
 #define SNARKV_PIP_STAGES 9
+/* Integer-VALU roofline probe (bench.py): peak rate, with 4 wavefronts per SIMD
+ * on every CU, of which = 0: dependent 254-bit Montgomery products (Fq-mul/s),
+ * which = 1: whole mixed G1 additions (madd/s) -- the multiplier / adder of the
+ * bucket-accumulate kernel in isolation (no memory traffic).                  */
+int snarkv_ubench_valu(snarkv_ctx* ctx, int which, int iters, double* ops_per_s);
 int snarkv_set_stage_timing(snarkv_ctx* ctx, int enabled);
 int snarkv_get_stage_timing(snarkv_ctx* ctx, float ms[SNARKV_PIP_STAGES]);
 

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "bn254_kzg_dk_decide_batch": (_int, [_vp, _cp, _sz, _vp]),
     "snarkv_sample_scalars_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
     "snarkv_sample_points_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
+    "snarkv_ubench_valu": (_int, [_vp, _int, _int, ctypes.POINTER(ctypes.c_double)]),
     "snarkv_set_stage_timing": (_int, [_vp, _int]),
     "snarkv_get_stage_timing": (_int, [_vp, _vp]),
 }
@@ -250,6 +251,11 @@ class Context:
 
     def sample_points_dev(self, seed, n, d_out, first=0):
         _check(self._lib.snarkv_sample_points_dev(self._h, seed, first, n, d_out))
+
+    def ubench_valu(self, which, iters=400):
+        v = ctypes.c_double()
+        _check(self._lib.snarkv_ubench_valu(self._h, which, iters, ctypes.byref(v)))
+        return v.value
 
     def set_stage_timing(self, enabled=True):
         _check(self._lib.snarkv_set_stage_timing(self._h, 1 if enabled else 0))

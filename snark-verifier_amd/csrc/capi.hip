@@ -335,6 +335,12 @@ int snarkv_sample_points_dev(snarkv_ctx* ctx, uint64_t seed, uint64_t first, siz
   return launch_sample_points(ctx, seed, first, n, d_points64);
 }
 
+int snarkv_ubench_valu(snarkv_ctx* ctx, int which, int iters, double* ops_per_s) {
+  if (!ctx || !ops_per_s || iters <= 0 || which < 0 || which > 1) return SNARKV_ERR_ARG;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  return launch_ubench(ctx, which, iters, ops_per_s);
+}
+
 int snarkv_g1_validate(snarkv_ctx* ctx, const uint8_t* points64, size_t n) {
   if (!ctx || !points64) return SNARKV_ERR_ARG;
   if (n == 0) return SNARKV_OK;

@@ -49,6 +49,7 @@ enum Slot {
   SLOT_SHIFTED,
   SLOT_GLV,
   SLOT_BIG_LIST,
+  SLOT_MISC2,
   SLOT_COUNT
 };
 
@@ -92,5 +93,6 @@ int launch_validate_g2(snarkv_ctx* ctx, const void* d_g2x2_256, int* bad_host);
 size_t g2_prepared_bytes();
 int launch_sample_scalars(snarkv_ctx* ctx, uint64_t seed, uint64_t first, size_t n, void* d_out);
 int launch_sample_points(snarkv_ctx* ctx, uint64_t seed, uint64_t first, size_t n, void* d_out);
+int launch_ubench(snarkv_ctx* ctx, int which, int iters, double* ops_per_s);
 
 }  // namespace snarkv

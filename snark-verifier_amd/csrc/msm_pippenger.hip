@@ -55,7 +55,7 @@ namespace snarkv {
 #define SNARKV_KCHUNK 4
 #endif
 #ifndef SNARKV_ACC_WAVES
-#define SNARKV_ACC_WAVES 4
+#define SNARKV_ACC_WAVES 3
 #endif
 constexpr int kRun = SNARKV_KRUN;      // P4: entries per lane
 constexpr int kChunk = SNARKV_KCHUNK;  // P6: buckets per lane
@@ -330,16 +330,25 @@ __global__ void __launch_bounds__(512)
 }
 
 // --------------------------------------------------------------- P4
-// One lane = one run of kRun consecutive sorted entries of the window group.
-// Emits the partial of the run's first bucket (head), of its last bucket if
-// different (tail), and writes complete interior buckets straight to `buckets`.
-template <bool CAREFUL>
-__device__ __forceinline__ bool accumulate_run(const uint2* __restrict__ entries, uint32_t begin, uint32_t end,
-                                               const G1Affine29* __restrict__ pts, G1Xyzz29* __restrict__ buckets,
-                                               uint32_t* __restrict__ seg_ids, G1Xyzz29* __restrict__ seg_parts,
-                                               size_t slot) {
+// One lane = one run of kRun consecutive sorted entries.  Emits the partial of
+// the run's first bucket (head), of its last bucket if different (tail), and
+// writes complete interior buckets straight to `buckets`.  Branch-free adders
+// and NO degeneracy test here: a flush is a plain store, so the lanes of a wave
+// (which change bucket at different iterations) never wait for each other's
+// checks.  P5 tests every bucket once and redoes the rare bad one carefully.
+__global__ void __launch_bounds__(64, SNARKV_ACC_WAVES)
+    k_accumulate(const uint2* __restrict__ entries, const uint32_t* __restrict__ total_ptr,
+                 const G1Affine29* __restrict__ pts, G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ seg_ids,
+                 G1Xyzz29* __restrict__ seg_parts) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t stop = *total_ptr;
+  uint64_t begin64 = (uint64_t)t * kRun;
+  if (begin64 >= stop) return;
+  uint32_t begin = (uint32_t)begin64;
+  uint32_t end = (stop - begin > (uint32_t)kRun) ? begin + kRun : stop;
+  size_t slot = t;
   uint32_t cur = entries[begin].x;
-  bool first = true, fresh = true, bad = false;
+  bool first = true, fresh = true;
   G1Xyzz29 acc = xyzz29_identity();
   // software pipeline: the (entry -> point) gather of step e+1 is issued before
   // the ~2 300-instruction mixed addition of step e
@@ -353,7 +362,6 @@ __device__ __forceinline__ bool accumulate_run(const uint2* __restrict__ entries
       p_n = pts[ent_n.y & 0x7FFFFFFFu];
     }
     if (ent.x != cur) {
-      if (!CAREFUL) bad = bad || xyzz29_is_degenerate(acc);
       if (first) {
         seg_ids[2 * slot] = cur;
         seg_parts[2 * slot] = acc;
@@ -363,12 +371,9 @@ __device__ __forceinline__ bool accumulate_run(const uint2* __restrict__ entries
       }
       cur = ent.x;
       fresh = true;
-      if (CAREFUL) acc = xyzz29_identity();
     }
     if (ent.y >> 31) p.y = fq29_neg(p.y);
-    if (CAREFUL) {
-      xyzz29_madd_careful(acc, p);
-    } else if (fresh) {
+    if (fresh) {
       acc.x = p.x;
       acc.y = p.y;
       acc.zz = fq29_one();
@@ -378,7 +383,6 @@ __device__ __forceinline__ bool accumulate_run(const uint2* __restrict__ entries
       xyzz29_madd_fast(acc, p);
     }
   }
-  if (!CAREFUL) bad = bad || xyzz29_is_degenerate(acc);
   if (first) {
     seg_ids[2 * slot] = cur;
     seg_parts[2 * slot] = acc;
@@ -387,46 +391,32 @@ __device__ __forceinline__ bool accumulate_run(const uint2* __restrict__ entries
     seg_ids[2 * slot + 1] = cur;
     seg_parts[2 * slot + 1] = acc;
   }
-  return bad;
-}
-
-__global__ void __launch_bounds__(64, SNARKV_ACC_WAVES)
-    k_accumulate(const uint2* __restrict__ entries, const uint32_t* __restrict__ total_ptr,
-                 const G1Affine29* __restrict__ pts, G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ seg_ids,
-                 G1Xyzz29* __restrict__ seg_parts) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t stop = *total_ptr;
-  uint64_t begin64 = (uint64_t)t * kRun;
-  if (begin64 >= stop) return;
-  uint32_t begin = (uint32_t)begin64;
-  uint32_t end = (stop - begin > (uint32_t)kRun) ? begin + kRun : stop;
-  size_t slot = t;
-  bool bad = accumulate_run<false>(entries, begin, end, pts, buckets, seg_ids, seg_parts, slot);
-  if (bad) accumulate_run<true>(entries, begin, end, pts, buckets, seg_ids, seg_parts, slot);  // rare: P = +-Q met
 }
 
 // --------------------------------------------------------------- P5
-template <bool CAREFUL>
-__device__ __forceinline__ bool combine_bucket(uint32_t b, size_t s0, size_t s1, const uint32_t* __restrict__ seg_ids,
-                                               const G1Xyzz29* __restrict__ seg_parts, G1Xyzz29& acc, bool& touched) {
-  acc = xyzz29_identity();
-  touched = false;
-  bool bad = false;
-  for (size_t s = s0; s <= s1; ++s) {
-    for (int h = 0; h < 2; ++h) {
-      if (seg_ids[2 * s + h] == b) {
-        if (CAREFUL) xyzz29_add_careful(acc, seg_parts[2 * s + h]);
-        else xyzz29_add_skipid_fast(acc, seg_parts[2 * s + h], bad);
-        touched = true;
-      }
-    }
+// Careful recomputation of one bucket straight from its sorted entries (the
+// rare bucket in which a fast addition met P = +-Q: duplicate / opposite bases).
+__device__ __noinline__ G1Xyzz29 bucket_from_entries_careful(const uint2* __restrict__ entries,
+                                                             const G1Affine29* __restrict__ pts, uint32_t o,
+                                                             uint32_t cnt, uint32_t first, uint32_t stride) {
+  G1Xyzz29 acc = xyzz29_identity();
+  for (uint32_t e = o + first; e < o + cnt; e += stride) {
+    uint2 ent = entries[e];
+    G1Affine29 p = pts[ent.y & 0x7FFFFFFFu];
+    if (ent.y >> 31) p.y = fq29_neg(p.y);
+    xyzz29_madd_careful(acc, p);
   }
-  if (CAREFUL) return false;
-  return bad || (!xyzz29_is_identity(acc) && xyzz29_is_degenerate(acc));
+  return acc;
 }
 
+// One lane per bucket: stitch the partials of the runs it spans (or pick up the
+// value P4 wrote for an interior bucket), then the ONE degeneracy test of the
+// bucket: a fast addition that met an exceptional case left ZZ = 0 (mod p)
+// (sticky through every later addition; an exact-zero ZZ partial is the same
+// signal, a run never legitimately produces the identity).
 __global__ void __launch_bounds__(64)
     k_combine(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, PipParams p,
+              const uint2* __restrict__ entries, const G1Affine29* __restrict__ pts,
               const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
               G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list) {
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -442,31 +432,55 @@ __global__ void __launch_bounds__(64)
       return;
     }
   }
-  G1Xyzz29 acc;
-  bool touched;
-  if (combine_bucket<false>(b, s0, s1, seg_ids, seg_parts, acc, touched))
-    combine_bucket<true>(b, s0, s1, seg_ids, seg_parts, acc, touched);
-  if (touched) buckets[b] = acc;
+  G1Xyzz29 acc = xyzz29_identity();
+  bool touched = false, bad = false;
+  for (size_t s = s0; s <= s1; ++s) {
+    for (int h = 0; h < 2; ++h) {
+      if (seg_ids[2 * s + h] == b) {
+        G1Xyzz29 part = seg_parts[2 * s + h];
+        bad = bad || xyzz29_is_identity(part);
+        xyzz29_add_skipid_fast(acc, part, bad);
+        touched = true;
+      }
+    }
+  }
+  if (!touched) acc = buckets[b];  // interior to one run: P4 stored it
+  bad = bad || xyzz29_is_degenerate(acc);
+  if (bad) acc = xyzz29_sanitize(bucket_from_entries_careful(entries, pts, o, cnt, 0, 1));
+  if (touched || bad) buckets[b] = acc;
 }
 
 // Buckets that span many runs (skewed scalar distributions: e.g. all scalars
 // equal puts n entries into one bucket per window): one 256-lane workgroup per
-// bucket, lane-strided careful adds + LDS tree.
+// bucket, lane-strided careful adds + LDS tree.  If any partial is degenerate
+// the whole bucket is recomputed carefully from its entries.
 __global__ void __launch_bounds__(256)
     k_combine_big(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                  const uint2* __restrict__ entries, const G1Affine29* __restrict__ pts,
                   const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
                   G1Xyzz29* __restrict__ buckets, const uint32_t* __restrict__ big_count,
                   const uint32_t* __restrict__ big_list) {
   __shared__ G1Xyzz29 sh[256];
+  __shared__ int any_bad;
   uint32_t nbig = *big_count < kMaxBig ? *big_count : kMaxBig;
   if (blockIdx.x >= nbig) return;
   uint32_t b = big_list[blockIdx.x];
   uint32_t o = offsets[b], cnt = counts[b];
   size_t s0 = o / kRun, s1 = (o + cnt - 1) / kRun;
+  if (threadIdx.x == 0) any_bad = 0;
+  __syncthreads();
   G1Xyzz29 acc = xyzz29_identity();
+  bool bad = false;
   for (size_t s = s0 + threadIdx.x; s <= s1; s += 256)
     for (int h = 0; h < 2; ++h)
-      if (seg_ids[2 * s + h] == b) xyzz29_add_careful(acc, seg_parts[2 * s + h]);
+      if (seg_ids[2 * s + h] == b) {
+        G1Xyzz29 part = seg_parts[2 * s + h];
+        bad = bad || xyzz29_is_degenerate(part);
+        xyzz29_add_careful(acc, part);
+      }
+  if (bad) atomicOr(&any_bad, 1);
+  __syncthreads();
+  if (any_bad) acc = bucket_from_entries_careful(entries, pts, o, cnt, threadIdx.x, 256);
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (uint32_t st = 128; st >= 1; st >>= 1) {
@@ -477,7 +491,7 @@ __global__ void __launch_bounds__(256)
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) buckets[b] = sh[0];
+  if (threadIdx.x == 0) buckets[b] = xyzz29_sanitize(sh[0]);
 }
 
 // --------------------------------------------------------------- P6
@@ -729,14 +743,16 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   uint32_t* d_big_count = d_total + 4;
   SNARKV_HIP(hipMemsetAsync(d_big_count, 0, 4, st));
   hipLaunchKernelGGL(k_combine, dim3((p.nb + 63) / 64), dim3(64), 0, st, (const uint32_t*)d_counts,
-                     (const uint32_t*)d_offsets, p, (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts,
-                     (G1Xyzz29*)d_buckets, d_big_count, (uint32_t*)d_big);
+                     (const uint32_t*)d_offsets, p, (const uint2*)d_entries, (const G1Affine29*)d_pts,
+                     (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets, d_big_count,
+                     (uint32_t*)d_big);
   // one workgroup per oversized bucket; idle workgroups exit at once
   uint32_t big_grid = (uint32_t)(max_runs / kBigSpan + 1);
   if (big_grid > kMaxBig) big_grid = kMaxBig;
   hipLaunchKernelGGL(k_combine_big, dim3(big_grid), dim3(256), 0, st, (const uint32_t*)d_counts,
-                     (const uint32_t*)d_offsets, (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts,
-                     (G1Xyzz29*)d_buckets, (const uint32_t*)d_big_count, (const uint32_t*)d_big);
+                     (const uint32_t*)d_offsets, (const uint2*)d_entries, (const G1Affine29*)d_pts,
+                     (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets,
+                     (const uint32_t*)d_big_count, (const uint32_t*)d_big);
   STAGE_MARK();  // 5: bucket combine
   hipLaunchKernelGGL(k_bucket_reduce, dim3(blocks_per_window * p.W), dim3(64), 0, st, (const G1Xyzz29*)d_buckets,
                      (G1Xyzz29*)d_wave, p, chunks_per_window, blocks_per_window);

@@ -6,6 +6,7 @@
 // restates the same streams so tests can check device inputs byte for byte.
 #include "ctx.hpp"
 #include "g1.cuh"
+#include "g1_29.cuh"
 
 namespace snarkv {
 
@@ -86,6 +87,80 @@ __global__ void __launch_bounds__(64) k_sample_points(uint64_t seed, uint64_t fi
   o[1] = make_uint4(xw[4], xw[5], xw[6], xw[7]);
   o[2] = make_uint4(yw[0], yw[1], yw[2], yw[3]);
   o[3] = make_uint4(yw[4], yw[5], yw[6], yw[7]);
+}
+
+// Integer-VALU roofline probe: every lane runs a dependent chain of Montgomery
+// products (the hot loop's multiplier, fq29_mul) with 4 waves per SIMD on every
+// CU -- the peak Fq-product rate the bucket-accumulate kernel can be held against.
+__global__ void __launch_bounds__(256) k_ubench_fq29_mul(int32_t* __restrict__ out, uint32_t seed, int iters) {
+  Fq29 x, y;
+  for (int i = 0; i < 9; ++i) {
+    x.v[i] = (int32_t)((seed * (threadIdx.x + 1) + i * 7919u) & 0x1FFFFFFFu);
+    y.v[i] = (int32_t)(((seed ^ blockIdx.x) + i * 104729u) & 0x1FFFFFFFu);
+  }
+  x.v[8] &= 0xFFFFF;
+  y.v[8] &= 0xFFFFF;
+  for (int i = 0; i < iters; ++i) {
+    x = fq29_mul(x, y);
+    y = fq29_mul(y, x);
+  }
+  int32_t acc = 0;
+  for (int i = 0; i < 9; ++i) acc ^= x.v[i] ^ y.v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+// same for the whole mixed addition (8M + 2S + lazy adds + carry passes)
+__global__ void __launch_bounds__(64, 4) k_ubench_madd29(int32_t* __restrict__ out, uint32_t seed, int iters) {
+  G1Affine29 p;
+  G1Xyzz29 acc;
+  for (int i = 0; i < 9; ++i) {
+    p.x.v[i] = (int32_t)((seed * (threadIdx.x + 1) + i * 7919u) & 0x1FFFFFFFu);
+    p.y.v[i] = (int32_t)(((seed ^ blockIdx.x) + i * 104729u) & 0x1FFFFFFFu);
+    acc.x.v[i] = (int32_t)((i * 31u + threadIdx.x) & 0x1FFFFFFFu);
+    acc.y.v[i] = 3 * i + 1;
+    acc.zz.v[i] = 5 * i + 2;
+    acc.zzz.v[i] = 7 * i + 3;
+  }
+  p.x.v[8] &= 0xFFFFF;
+  p.y.v[8] &= 0xFFFFF;
+  for (int i = 0; i < iters; ++i) {
+    xyzz29_madd_fast(acc, p);
+    p.x.v[0] = (p.x.v[0] + 1) & 0x1FFFFFFF;
+  }
+  int32_t a = 0;
+  for (int i = 0; i < 9; ++i) a ^= acc.x.v[i] ^ acc.y.v[i] ^ acc.zz.v[i] ^ acc.zzz.v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a;
+}
+
+int launch_ubench(snarkv_ctx* ctx, int which, int iters, double* ops_per_s) {
+  hipDeviceProp_t prop;
+  SNARKV_HIP(hipGetDeviceProperties(&prop, ctx->device));
+  int cus = prop.multiProcessorCount;
+  void* d_out;
+  uint32_t blocks = which == 0 ? (uint32_t)cus * 4u : (uint32_t)cus * 16u;  // 4 waves per SIMD either way
+  uint32_t threads = which == 0 ? 256u : 64u;
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_MISC2, (size_t)blocks * threads * 4, &d_out));
+  hipEvent_t a, b;
+  SNARKV_HIP(hipEventCreate(&a));
+  SNARKV_HIP(hipEventCreate(&b));
+  double best = 0;
+  for (int rep = 0; rep < 3; ++rep) {
+    SNARKV_HIP(hipEventRecord(a, ctx->stream));
+    if (which == 0)
+      hipLaunchKernelGGL(k_ubench_fq29_mul, dim3(blocks), dim3(threads), 0, ctx->stream, (int32_t*)d_out, 77u + rep, iters);
+    else
+      hipLaunchKernelGGL(k_ubench_madd29, dim3(blocks), dim3(threads), 0, ctx->stream, (int32_t*)d_out, 77u + rep, iters);
+    SNARKV_HIP(hipEventRecord(b, ctx->stream));
+    SNARKV_HIP(hipEventSynchronize(b));
+    float ms = 0;
+    SNARKV_HIP(hipEventElapsedTime(&ms, a, b));
+    double ops = (double)blocks * threads * (double)iters * (which == 0 ? 2.0 : 1.0) / (ms * 1e-3);
+    if (ops > best) best = ops;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  *ops_per_s = best;
+  return SNARKV_OK;
 }
 
 int launch_sample_scalars(snarkv_ctx* ctx, uint64_t seed, uint64_t first, size_t n, void* d_out) {
