@@ -1,0 +1,124 @@
+"""GPU: robustness of the C-ABI entry points -- random segmentations, validation
+flags, concurrent contexts, determinism, adversarial duplicates at scale."""
+import random
+import threading
+
+import pytest
+
+import bn254 as O
+import coracle as C
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batched_random_segmentations(gpu_ctx):
+    rng = random.Random(21)
+    n = 700
+    s, p = C.sample_scalars(41, n), C.sample_points(42, n)
+    for _ in range(4):
+        cuts = sorted(rng.sample(range(1, n), rng.randrange(1, 60)))
+        offs = [0] + cuts + [n]
+        assert gpu_ctx.msm_batched(s, p, offs) == C.msm_batched(s, p, offs)
+    # every segment of size 1: k*P for each term
+    offs = list(range(0, 65))
+    assert gpu_ctx.msm_batched(s[:32 * 64], p[:64 * 64], offs) == C.msm_batched(s[:32 * 64], p[:64 * 64], offs)
+
+
+def test_pippenger_random_sizes_and_determinism(gpu_ctx):
+    rng = random.Random(22)
+    for _ in range(6):
+        n = rng.randrange(1, 3000)
+        s, p = C.sample_scalars(rng.randrange(1 << 30), n), C.sample_points(rng.randrange(1 << 30), n)
+        a = gpu_ctx.msm_pippenger(s, p)
+        assert a == C.msm_pippenger(s, p, 2)
+        assert gpu_ctx.msm_pippenger(s, p) == a  # scratch reuse across calls changes nothing
+
+
+def test_validate_flag_on_every_msm_entry_point(gpu_ctx):
+    import snark_verifier_amd as sv
+
+    n = 40
+    s, p = C.sample_scalars(51, n), bytearray(C.sample_points(52, n))
+    ok = gpu_ctx.msm_pippenger(s, bytes(p), flags=sv.SNARKV_FLAG_VALIDATE)
+    assert ok == C.msm_pippenger(s, bytes(p), 1)
+    assert gpu_ctx.msm_batched(s, bytes(p), [0, 10, n], flags=sv.SNARKV_FLAG_VALIDATE) == C.msm_batched(s, bytes(p), [0, 10, n])
+    p[64 * 17 + 5] ^= 0x10  # x of point 17 perturbed: off-curve
+    for call in (lambda: gpu_ctx.msm_pippenger(s, bytes(p), flags=sv.SNARKV_FLAG_VALIDATE),
+                 lambda: gpu_ctx.msm_batched(s, bytes(p), [0, 10, n], flags=sv.SNARKV_FLAG_VALIDATE),
+                 lambda: gpu_ctx.msm_naive(s, bytes(p), flags=sv.SNARKV_FLAG_VALIDATE)):
+        with pytest.raises(sv.SnarkvError) as e:
+            call()
+        assert e.value.code == -3
+    # coordinate >= p is rejected even when "on curve" modulo p
+    q = bytearray(C.sample_points(53, 1))
+    x = int.from_bytes(q[:32], "little") + O.P
+    if x < (1 << 256):
+        q[:32] = x.to_bytes(32, "little")
+        with pytest.raises(sv.SnarkvError):
+            gpu_ctx.msm_naive(C.sample_scalars(1, 1), bytes(q), flags=sv.SNARKV_FLAG_VALIDATE)
+
+
+def test_duplicates_and_opposites_at_scale(gpu_ctx):
+    """Many equal and opposite bases with equal scalars: the fast adders meet
+    P = +-Q in a large fraction of buckets; every such bucket must be caught by
+    the degeneracy test and recomputed carefully."""
+    n = 4096
+    base = C.sample_points(61, 8)
+    pts = []
+    for i in range(n):
+        q = base[64 * (i % 8):64 * (i % 8) + 64]
+        if (i // 8) % 3 == 2:  # every third group negated
+            y = (O.P - int.from_bytes(q[32:], "little")) % O.P
+            q = q[:32] + y.to_bytes(32, "little")
+        pts.append(q)
+    p = b"".join(pts)
+    sc = [((i % 5) + 1) * 0x0123456789ABCDEF for i in range(n)]
+    s = b"".join(O.fe_to_bytes(x) for x in sc)
+    exp = C.msm_pippenger(s, p, 4)
+    assert gpu_ctx.msm_pippenger(s, p) == exp
+    assert gpu_ctx.msm_naive(s, p) == exp
+    # total cancellation: P and -P with the same scalar
+    half = b"".join(pts[i] for i in range(0, 16))
+    neg = b"".join(q[:32] + ((O.P - int.from_bytes(q[32:], "little")) % O.P).to_bytes(32, "little") for q in
+                   (half[64 * i:64 * i + 64] for i in range(16)))
+    s2 = C.sample_scalars(62, 16)
+    assert gpu_ctx.msm_pippenger(s2 + s2, half + neg) == b"\x00" * 64
+    assert gpu_ctx.msm_naive(s2 + s2, half + neg) == b"\x00" * 64
+
+
+def test_two_contexts_from_two_threads():
+    """include/snarkv_amd.h "Threading": one context per host thread."""
+    import snark_verifier_amd as sv
+
+    n = 3000
+    inputs = [(C.sample_scalars(70 + k, n), C.sample_points(80 + k, n)) for k in range(2)]
+    expected = [C.msm_pippenger(s, p, 2) for s, p in inputs]
+    results, errors = [None, None], []
+
+    def work(k):
+        try:
+            ctx = sv.Context(0)
+            for _ in range(3):
+                results[k] = ctx.msm_pippenger(*inputs[k])
+            ctx.close()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors and results == expected
+
+
+def test_decide_batch_mixed_and_identity_cases(gpu_ctx, golden_decider):
+    import snark_verifier_amd as sv
+
+    g = golden_decider
+    dk = sv.DecidingKey(gpu_ctx, bytes.fromhex(g["g1"]), bytes.fromhex(g["g2"]), bytes.fromhex(g["s_g2"]))
+    cases = g["cases"] * 9  # 72 accumulators, accept/reject interleaved, identity cases included
+    accs = b"".join(bytes.fromhex(c["acc"]) for c in cases)
+    allok, oks = gpu_ctx.decide_batch(dk, accs)
+    assert oks == [c["accept"] for c in cases] and not allok
+    dk.close()
