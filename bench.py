@@ -55,15 +55,16 @@ def cpu_baseline(ctx, d_scalars, d_points, sample_log2):
     }, out, (s, p)
 
 
-def secondary_metrics(sv, torch, ctx):
+def secondary_metrics(sv, torch, ctxs, cpu=True):
     """BASELINE.json's second metric ("aggregated proofs verified/sec") on shape-faithful
     synthetic work: per proof a 21-term and a 3-term MSM
     (Gwc19::verify), then KzgAs::verify's two (m+1)-term MSMs, then ONE decide.
     All EC work on the device through the same C-ABI entry points the C++ host
-    mirror uses; the host-side Fr algebra (microseconds per proof) is not included."""
-    import ctypes
-
+    mirror uses; the host-side Fr algebra (microseconds per proof) is not included.
+    Reported twice: one aggregation job at a time (latency: three dependent
+    latency-bound launches) and with one job in flight per context (throughput)."""
     out = {}
+    ctx = ctxs[0]
 
     def t_ms(fn, reps=5, warm=2):
         for _ in range(warm):
@@ -80,7 +81,8 @@ def secondary_metrics(sv, torch, ctx):
         "edf692d95cbdde46ddda5ef7d422436779445c5e66006a42761e1f12efde0018c212f3aeb785e49712e7a9353349aaf1255dfb31b7bf60723a480d9293938e19"
         "aa7dfa6601cce64c7bd3430c69e7d1e38f40cb8d8071ab4aeb6d8cdba55ec8125b9722d1dcdaac55f38eb37033314bbc95330c69ad999eec75f05f58d0890609")
     g1 = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
-    dk = sv.DecidingKey(ctx, g1, g2, g2)  # s = 1: (P, P) is a valid accumulator
+    dks = [sv.DecidingKey(c, g1, g2, g2) for c in ctxs]  # s = 1: (P, P) is a valid accumulator
+    dk = dks[0]
     for nproofs in (64, 1024):
         offs = [0]
         for _ in range(nproofs):
@@ -92,27 +94,59 @@ def secondary_metrics(sv, torch, ctx):
         ctx.sample_points_dev(0x5EED0004, max(n1, n2), dp.data_ptr())
         o1 = torch.tensor(offs, dtype=torch.int32, device="cuda")
         o2 = torch.tensor([0, nproofs + 1, n2], dtype=torch.int32, device="cuda")
-        out1 = torch.zeros(64 * (len(offs) - 1), dtype=torch.uint8, device="cuda")
-        acc = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        ok = torch.zeros(1, dtype=torch.uint8, device="cuda")
+        out1 = [torch.zeros(64 * (len(offs) - 1), dtype=torch.uint8, device="cuda") for _ in ctxs]
+        acc = [torch.zeros(128, dtype=torch.uint8, device="cuda") for _ in ctxs]
+        ok = [torch.zeros(1, dtype=torch.uint8, device="cuda") for _ in ctxs]
         torch.cuda.synchronize()
 
-        def run():
-            ctx.msm_batched_dev(ds.data_ptr(), dp.data_ptr(), o1.data_ptr(), len(offs) - 1, n1, out1.data_ptr())
-            ctx.msm_batched_dev(ds.data_ptr(), dp.data_ptr(), o2.data_ptr(), 2, n2, acc.data_ptr())
-            ctx.decide_batch_dev(dk, acc.data_ptr(), 1, ok.data_ptr())
+        def job(k):
+            c = ctxs[k]
+            c.msm_batched_dev(ds.data_ptr(), dp.data_ptr(), o1.data_ptr(), len(offs) - 1, n1, out1[k].data_ptr())
+            c.msm_batched_dev(ds.data_ptr(), dp.data_ptr(), o2.data_ptr(), 2, n2, acc[k].data_ptr())
+            c.decide_batch_dev(dks[k], acc[k].data_ptr(), 1, ok[k].data_ptr())
 
-        ms = t_ms(run)
+        ms = t_ms(lambda: job(0))
         out["aggregate_%d_proofs" % nproofs] = {"ms": ms, "proofs_per_s": nproofs / ms * 1e3,
-                                                 "msm_terms": n1 + n2, "includes_decide": True}
+                                                 "msm_terms": n1 + n2, "includes_decide": True,
+                                                 "jobs_in_flight": 1}
+        if len(ctxs) > 1:
+            def wave():
+                for k in range(len(ctxs)):
+                    job(k)
+            ms = t_ms(wave, reps=4, warm=1) / len(ctxs)
+            same = all(bytes(a.cpu().numpy()) == bytes(acc[0].cpu().numpy()) for a in acc[1:])
+            out["aggregate_%d_proofs_pipelined" % nproofs] = {
+                "ms_per_job": ms, "proofs_per_s": nproofs / ms * 1e3, "msm_terms": n1 + n2,
+                "includes_decide": True, "jobs_in_flight": len(ctxs), "results_identical": same}
+        if cpu and nproofs == 64:
+            out["aggregate_64_proofs"]["cpu_baseline"] = cpu_baseline_aggregate(ds, dp, offs, n1, nproofs, n2)
     one = torch.frombuffer(bytearray((g1 + g1) * 1024), dtype=torch.uint8).cuda()
     oks = torch.zeros(1024, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     for m in (1, 1024):
         ms = t_ms(lambda: ctx.decide_batch_dev(dk, one.data_ptr(), m, oks.data_ptr()), reps=3, warm=1)
         out["decide_all_%d" % m] = {"ms": ms, "decides_per_s": m / ms * 1e3, "all_accept": bool(oks[:m].cpu().all())}
-    dk.close()
+    for d in dks:
+        d.close()
     return out
+
+
+def cpu_baseline_aggregate(ds, dp, offs, n1, nproofs, n2):
+    """CPU leg of the aggregate metric: the reference's naive
+    NativeLoader loop (native.rs:61-71) restated in C, ONE thread (the reference
+    has no threading on this path), MSM part only (the C restatement has no pairing)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import coracle  # cpu_baseline leg only
+
+    s = bytes(ds[: 32 * max(n1, n2)].cpu().numpy())
+    p = bytes(dp[: 64 * max(n1, n2)].cpu().numpy())
+    t0 = time.perf_counter()
+    coracle.msm_batched(s[: 32 * n1], p[: 64 * n1], offs)
+    coracle.msm_batched(s[: 32 * n2], p[: 64 * n2], [0, nproofs + 1, n2])
+    dt = time.perf_counter() - t0
+    return {"value": nproofs / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
+            "sample": "the 64-proof job's %d MSM terms, naive double-and-add loop of native.rs:61-71 restated in C, "
+                      "1 thread, %.2f s; decide not included; not a halo2curves measurement" % (n1 + n2, dt)}
 
 
 def main():
@@ -318,7 +352,9 @@ def main():
             cb["gpu_matches_on_sample"] = bytes(chk.cpu().numpy()) == cpu_out
             line["cpu_baseline"] = cb
         if not use_dist and not args.no_secondary:
-            line["secondary"] = secondary_metrics(sv, torch, ctx)
+            extra_streams = [torch.cuda.Stream() for _ in range(max(0, 8 - len(ctxs)))]  # kept alive
+            extra = [sv.Context(local_rank, stream=st.cuda_stream) for st in extra_streams]
+            line["secondary"] = secondary_metrics(sv, torch, ctxs + extra, cpu=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
 
     if use_dist:

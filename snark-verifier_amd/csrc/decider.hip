@@ -7,12 +7,15 @@
 //   D0 k_g2_prepare : once per deciding key -- line tables of g2 and -s_g2
 //                     (the reference's `G2Prepared::from`, redone there on
 //                     every call, decider.rs:74)
-//   D1 k_decide     : ONE 256-lane WORKGROUP per accumulator (pairing_coop.cuh):
+//   D1 k_decide     : ONE 128-lane WORKGROUP per accumulator (pairing_coop29.cuh):
 //                     2-pair Miller loop with shared squarings + exact final
 //                     exponentiation + `is_identity`; every Fq12 product is one
-//                     parallel round of 204 Fq products + a two-stage LDS sum.
+//                     parallel round of 72 fused two-product Montgomery steps,
+//                     summed by DPP butterflies inside 8-lane groups (no LDS
+//                     traffic for the reduction, one store + two barriers).
 //                     (v1 gave one lane per accumulator: 45-55 ms per decide,
-//                     whatever the batch size; this form: ~2 ms.)
+//                     whatever the batch size; v2 = 204 products + two LDS
+//                     reduction stages: 1.64 ms.)
 // Batches of independent accumulators (decide_all) are the second parallel axis
 // (SURVEY.md 8e).
 #include "ctx.hpp"
@@ -109,17 +112,16 @@ __global__ void __launch_bounds__(256) k_g2_to29(const G2Prepared* __restrict__ 
 }
 
 // ------------------------------------------------------------------ D1
-struct CoopReg {  // an Fq12 in the flat basis (c = 2i+e <-> u^e w^i), plus 9x
+constexpr int kDecideThreads = 128;  // 96 lanes carry the round (pairing_coop29.cuh coop3), 2 wavefronts
+
+struct CoopReg {  // an Fq12 in the flat basis (c = 2i+e <-> u^e w^i)
   Fq29 v[12];
-  Fq29 v9[12];
 };
 
 enum { RF = 0, RT, RINV, RFX, RFX2, RFX3, RY0, RY1, RY2, RY3, RY4, RY5, RY6, RT0, RT1, RCOUNT };
 
 struct CoopShared {
   CoopReg r[RCOUNT];
-  Fq29 prods[COOP_NPROD];
-  Fq29 parts[48];
   Fq29 lines[2][kLinesPerG2][4];  // per pair, per line: l0 = cy*yP (2), l1 = cx*xP (2); l2 = cw is read from the key
   Fq29 pt[2][2];                  // (x, y) of lhs, rhs
   Fq29 scal[2];                   // an Fq2 scalar (inverse of the norm)
@@ -130,55 +132,69 @@ struct CoopShared {
 // that every helper addresses it with ds_* instructions, not flat pointers).
 __shared__ CoopShared g_sh;
 
-struct CoopLane {  // per-lane table entries, loaded once into registers
-  uint32_t prod;
-  unsigned short st1[COOP_STAGE1_TERMS];
-};
+static __device__ __forceinline__ void coop_store(int dst, int c, const Fq29& val) { g_sh.r[dst].v[c] = val; }
 
-static __device__ __forceinline__ CoopLane coop_lane_init() {
-  CoopLane L;
-  int tid = threadIdx.x;
-  L.prod = tid < COOP_NPROD ? kCoopProd[tid] : 0xFFFFu;
+// DPP lane exchange inside a 16-lane row (no LDS, no barrier)
+template <int CTRL>
+static __device__ __forceinline__ uint32_t dpp_u32(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, true);
+}
+
+// every lane of an aligned 8-lane group gets the limb-wise sum over the group
+// (limbs as unsigned: <= 6 live terms of < 2^29 each)
+static __device__ __forceinline__ Fq29 group8_sum(Fq29 x) {
 #pragma unroll
-  for (int k = 0; k < COOP_STAGE1_TERMS; ++k) L.st1[k] = tid < 48 ? kCoopStage1[tid][k] : (unsigned short)0xFFFFu;
-  return L;
+  for (int i = 0; i < 9; ++i) x.v[i] = (int32_t)((uint32_t)x.v[i] + dpp_u32<0xB1>((uint32_t)x.v[i]));   // quad_perm [1,0,3,2]
+#pragma unroll
+  for (int i = 0; i < 9; ++i) x.v[i] = (int32_t)((uint32_t)x.v[i] + dpp_u32<0x4E>((uint32_t)x.v[i]));   // quad_perm [2,3,0,1]
+#pragma unroll
+  for (int i = 0; i < 9; ++i) x.v[i] = (int32_t)((uint32_t)x.v[i] + dpp_u32<0x141>((uint32_t)x.v[i]));  // row_half_mirror
+  return x;
 }
 
-// flat slot t of a sparse line (non-zero slots 0,1,2,3,6,7 -> 0..5), -1 = zero
-static __device__ __forceinline__ int line_slot(unsigned t) { return t < 4 ? (int)t : (t == 6 ? 4 : (t == 7 ? 5 : -1)); }
-
-static __device__ __forceinline__ void coop_store(int dst, int c, const Fq29& val) {
-  g_sh.r[dst].v[c] = val;
-  g_sh.r[dst].v9[c] = coop29_times9(val);
-}
-
-// dst = a * b, b a register (b_reg >= 0) or the sparse line (pair, idx).  All 256 lanes.
-static __device__ __forceinline__ void coop_mul_b(const CoopLane& L, int dst, int a, int b_reg, int pair, int idx,
+// dst = a * b, b a register (b_reg >= 0) or the sparse line (pair, idx): only
+// w^0, w^1, w^3 non-zero.  All lanes of the workgroup call it.
+static __device__ __forceinline__ void coop_mul_b(int dst, int a, int b_reg, int pair, int idx,
                                                   const G2Prepared29* __restrict__ prep) {
-  int tid = threadIdx.x;
-  if (tid < COOP_NPROD) {
-    unsigned s = L.prod & 15u, t = (L.prod >> 4) & 15u;
-    const Fq29& x = (L.prod >> 8) ? g_sh.r[a].v9[s] : g_sh.r[a].v[s];
+  const int tid = threadIdx.x;
+  const Coop3Lane L = coop3_lane(tid);
+  Fq29 val = fq29_zero();
+  if (L.active) {
+    const Fq29& a0 = g_sh.r[a].v[2 * L.i1];
+    const Fq29& a1 = g_sh.r[a].v[2 * L.i1 + 1];
+    const int c0 = 2 * L.i2 + L.e, c1 = 2 * L.i2 + 1 - L.e;
     if (b_reg >= 0) {
-      g_sh.prods[tid] = fq29_mul(x, g_sh.r[b_reg].v[t]);
-    } else {
-      int sl = line_slot(t);
-      g_sh.prods[tid] = sl < 0 ? fq29_zero()
-                                : fq29_mul(x, sl < 4 ? g_sh.lines[pair][idx][sl] : prep[pair].line[idx].c[sl]);
+      val = coop3_product(L.e, a0, a1, g_sh.r[b_reg].v[c0], g_sh.r[b_reg].v[c1]);
+    } else if (L.i2 < 2 || L.i2 == 3) {
+      // one instruction stream for the three non-zero line coefficients (generic pointers:
+      // l0, l1 live in LDS, l2 = cw in the key)
+      const Fq29* y0 = L.i2 < 2 ? &g_sh.lines[pair][idx][c0] : &prep[pair].line[idx].c[4 + L.e];
+      const Fq29* y1 = L.i2 < 2 ? &g_sh.lines[pair][idx][c1] : &prep[pair].line[idx].c[5 - L.e];
+      val = coop3_product(L.e, a0, a1, *y0, *y1);
     }
   }
-  __syncthreads();
-  if (tid < 48) g_sh.parts[tid] = coop29_stage1(L.st1, g_sh.prods);
-  __syncthreads();
-  if (tid < 12) coop_store(dst, tid, coop29_stage2(tid, g_sh.parts));
+  Fq29 lo, hi;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    lo.v[i] = L.high ? 0 : val.v[i];
+    hi.v[i] = L.high ? val.v[i] : 0;
+  }
+  lo = group8_sum(lo);
+  hi = group8_sum(hi);
+  Fq29 hp;  // the high sum of the other u-power: 8 lanes away in the same row
+#pragma unroll
+  for (int i = 0; i < 9; ++i) hp.v[i] = (int32_t)dpp_u32<0x128>((uint32_t)hi.v[i]);  // row_ror:8
+  const bool writer = (tid & 7) == 0 && L.k < 6;
+  Fq29 res = fq29_zero();
+  if (writer) res = coop3_finalize(L.e, lo, hi, hp);
+  __syncthreads();  // every operand read is done before dst (possibly == a or b) changes
+  if (writer) coop_store(dst, 2 * L.k + L.e, res);
   __syncthreads();
 }
 
-static __device__ __noinline__ void coop_mulr(const CoopLane& L, int dst, int a, int b) {
-  coop_mul_b(L, dst, a, b, 0, 0, nullptr);
-}
-static __device__ __noinline__ void coop_mull(const CoopLane& L, int pair, int idx, const G2Prepared29* __restrict__ prep) {
-  coop_mul_b(L, RF, RF, -1, pair, idx, prep);
+static __device__ __noinline__ void coop_mulr(int dst, int a, int b) { coop_mul_b(dst, a, b, 0, 0, nullptr); }
+static __device__ __noinline__ void coop_mull(int pair, int idx, const G2Prepared29* __restrict__ prep) {
+  coop_mul_b(RF, RF, -1, pair, idx, prep);
 }
 
 // dst = conj(a): negate the odd powers of w (the c1 half of the tower)
@@ -186,9 +202,8 @@ static __device__ __noinline__ void coop_conj(int dst, int a) {
   int tid = threadIdx.x;
   if (tid < 12) {
     bool odd = ((tid >> 1) & 1) != 0;
-    Fq29 x = g_sh.r[a].v[tid], x9 = g_sh.r[a].v9[tid];
-    g_sh.r[dst].v[tid] = odd ? fq29_neg(x) : x;
-    g_sh.r[dst].v9[tid] = odd ? fq29_neg(x9) : x9;
+    Fq29 x = g_sh.r[a].v[tid];
+    g_sh.r[dst].v[tid] = odd ? fq29_norm(fq29_neg(x)) : x;
   }
   __syncthreads();
 }
@@ -236,13 +251,13 @@ static __device__ __noinline__ void coop_scale(int dst, int a) {
 // dst = a^-1 through the norms Fq12 -> Fq6 -> Fq2 -> Fq:
 //   N = a conj(a) in Fq6;  adj = N^(p^2) N^(p^4);  d = N adj in Fq2;
 //   a^-1 = conj(a) adj / d.      (uses RT0, RT1, RY0 as scratch; one Fq inversion chain on lane 0)
-static __device__ __noinline__ void coop_inv(const CoopLane& L, int dst, int a) {
+static __device__ __noinline__ void coop_inv(int dst, int a) {
   coop_conj(RT0, a);                 // RT0 = conj(a)
-  coop_mulr(L, RT1, a, RT0);         // RT1 = N
+  coop_mulr(RT1, a, RT0);         // RT1 = N
   coop_frob(RY0, RT1, 2);            // N^(p^2)
   coop_frob(dst, RY0, 2);            // N^(p^4)
-  coop_mulr(L, RY0, RY0, dst);       // adj
-  coop_mulr(L, RT1, RT1, RY0);       // d (Fq2: coefficients 0, 1)
+  coop_mulr(RY0, RY0, dst);       // adj
+  coop_mulr(RT1, RT1, RY0);       // d (Fq2: coefficients 0, 1)
   if (threadIdx.x == 0) {
     Fq29 d0 = g_sh.r[RT1].v[0], d1 = g_sh.r[RT1].v[1];
     Fq29 nrm = fq29_norm(fq29_add(fq29_sqr(d0), fq29_sqr(d1)));
@@ -251,30 +266,26 @@ static __device__ __noinline__ void coop_inv(const CoopLane& L, int dst, int a) 
     g_sh.scal[1] = fq29_neg(fq29_mul(d1, ni));
   }
   __syncthreads();
-  coop_mulr(L, dst, RT0, RY0);       // conj(a) adj
+  coop_mulr(dst, RT0, RY0);       // conj(a) adj
   coop_scale(dst, dst);              // / d
 }
 
-static __device__ __noinline__ void coop_exp_by_x(const CoopLane& L, int dst, int a) {
+static __device__ __noinline__ void coop_exp_by_x(int dst, int a) {
   // dst != a
-  if (threadIdx.x < 12) {
-    g_sh.r[dst].v[threadIdx.x] = g_sh.r[a].v[threadIdx.x];
-    g_sh.r[dst].v9[threadIdx.x] = g_sh.r[a].v9[threadIdx.x];
-  }
+  if (threadIdx.x < 12) g_sh.r[dst].v[threadIdx.x] = g_sh.r[a].v[threadIdx.x];
   __syncthreads();
   for (int i = 61; i >= 0; --i) {
-    coop_mulr(L, dst, dst, dst);
-    if ((BN254_X_U64 >> i) & 1ull) coop_mulr(L, dst, dst, a);
+    coop_mulr(dst, dst, dst);
+    if ((BN254_X_U64 >> i) & 1ull) coop_mulr(dst, dst, a);
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kDecideThreads)
     k_decide(const G2Prepared29* __restrict__ prep, const uint32_t* __restrict__ accs, uint32_t m,
              uint8_t* __restrict__ ok, uint32_t* __restrict__ gt_out) {
   const int tid = threadIdx.x;
   const uint32_t i = blockIdx.x;
   if (i >= m) return;
-  const CoopLane L = coop_lane_init();
   const uint32_t* a = accs + (size_t)i * 32;
   if (tid < 4) {  // lhs.x, lhs.y, rhs.x, rhs.y -> Montgomery
     uint32_t w[8];
@@ -289,7 +300,7 @@ __global__ void __launch_bounds__(256)
                      !prep[tid].is_identity;
   // every line of both pairs evaluated at this accumulator's points, up front
   // and in parallel (2 x 102 x 4 products): l0 = cy*yP, l1 = cx*xP
-  for (int j = tid; j < 2 * kLinesPerG2 * 4; j += 256) {
+  for (int j = tid; j < 2 * kLinesPerG2 * 4; j += kDecideThreads) {
     int k = j / (kLinesPerG2 * 4), rem = j % (kLinesPerG2 * 4), idx = rem / 4, c = rem % 4;
     g_sh.lines[k][idx][c] = fq29_mul(prep[k].line[idx].c[c], g_sh.pt[k][c < 2 ? 1 : 0]);
   }
@@ -298,60 +309,60 @@ __global__ void __launch_bounds__(256)
   // ---- Miller loop (2 pairs, shared squarings); identity pairs contribute 1
   int idx = 0;
   for (int b = kAteBits - 2; b >= 0; --b) {
-    coop_mulr(L, RF, RF, RF);
+    coop_mulr(RF, RF, RF);
     for (int k = 0; k < 2; ++k)
-      if (g_sh.live[k]) coop_mull(L, k, idx, prep);
+      if (g_sh.live[k]) coop_mull(k, idx, prep);
     ++idx;
     if (ate_bit(b)) {
       for (int k = 0; k < 2; ++k)
-        if (g_sh.live[k]) coop_mull(L, k, idx, prep);
+        if (g_sh.live[k]) coop_mull(k, idx, prep);
       ++idx;
     }
   }
   for (int s = 0; s < 2; ++s) {
     for (int k = 0; k < 2; ++k)
-      if (g_sh.live[k]) coop_mull(L, k, idx, prep);
+      if (g_sh.live[k]) coop_mull(k, idx, prep);
     ++idx;
   }
 
   // ---- final exponentiation, exact exponent (p^12-1)/r (see pairing.cuh)
-  coop_inv(L, RINV, RF);
+  coop_inv(RINV, RF);
   coop_conj(RT, RF);
-  coop_mulr(L, RF, RT, RINV);          // f^(p^6-1)
+  coop_mulr(RF, RT, RINV);          // f^(p^6-1)
   coop_frob(RT, RF, 2);
-  coop_mulr(L, RF, RT, RF);            // ^(p^2+1)
-  coop_exp_by_x(L, RFX, RF);
-  coop_exp_by_x(L, RFX2, RFX);
-  coop_exp_by_x(L, RFX3, RFX2);
+  coop_mulr(RF, RT, RF);            // ^(p^2+1)
+  coop_exp_by_x(RFX, RF);
+  coop_exp_by_x(RFX2, RFX);
+  coop_exp_by_x(RFX3, RFX2);
   coop_frob(RY0, RF, 1);
   coop_frob(RT, RF, 2);
-  coop_mulr(L, RY0, RY0, RT);
+  coop_mulr(RY0, RY0, RT);
   coop_frob(RT, RF, 3);
-  coop_mulr(L, RY0, RY0, RT);          // y0 = f^p f^(p^2) f^(p^3)
+  coop_mulr(RY0, RY0, RT);          // y0 = f^p f^(p^2) f^(p^3)
   coop_conj(RY1, RF);                  // y1 = 1/f
   coop_frob(RY2, RFX2, 2);             // y2
   coop_frob(RT, RFX, 1);
   coop_conj(RY3, RT);                  // y3
   coop_frob(RT, RFX2, 1);
-  coop_mulr(L, RT, RFX, RT);
+  coop_mulr(RT, RFX, RT);
   coop_conj(RY4, RT);                  // y4
   coop_conj(RY5, RFX2);                // y5
   coop_frob(RT, RFX3, 1);
-  coop_mulr(L, RT, RFX3, RT);
+  coop_mulr(RT, RFX3, RT);
   coop_conj(RY6, RT);                  // y6
-  coop_mulr(L, RT0, RY6, RY6);
-  coop_mulr(L, RT0, RT0, RY4);
-  coop_mulr(L, RT0, RT0, RY5);         // t0 = y6^2 y4 y5
-  coop_mulr(L, RT1, RY3, RY5);
-  coop_mulr(L, RT1, RT1, RT0);         // t1 = y3 y5 t0
-  coop_mulr(L, RT0, RT0, RY2);         // t0 *= y2
-  coop_mulr(L, RT1, RT1, RT1);
-  coop_mulr(L, RT1, RT1, RT0);
-  coop_mulr(L, RT1, RT1, RT1);         // t1 = (t1^2 t0)^2
-  coop_mulr(L, RT0, RT1, RY1);         // t0 = t1 y1
-  coop_mulr(L, RT1, RT1, RY0);         // t1 = t1 y0
-  coop_mulr(L, RT0, RT0, RT0);
-  coop_mulr(L, RF, RT0, RT1);          // result = t0^2 t1
+  coop_mulr(RT0, RY6, RY6);
+  coop_mulr(RT0, RT0, RY4);
+  coop_mulr(RT0, RT0, RY5);         // t0 = y6^2 y4 y5
+  coop_mulr(RT1, RY3, RY5);
+  coop_mulr(RT1, RT1, RT0);         // t1 = y3 y5 t0
+  coop_mulr(RT0, RT0, RY2);         // t0 *= y2
+  coop_mulr(RT1, RT1, RT1);
+  coop_mulr(RT1, RT1, RT0);
+  coop_mulr(RT1, RT1, RT1);         // t1 = (t1^2 t0)^2
+  coop_mulr(RT0, RT1, RY1);         // t0 = t1 y1
+  coop_mulr(RT1, RT1, RY0);         // t1 = t1 y0
+  coop_mulr(RT0, RT0, RT0);
+  coop_mulr(RF, RT0, RT1);          // result = t0^2 t1
 
   // canonical words of the 12 coefficients (lane c), then the verdict
   __shared__ uint32_t canon[12][8];
@@ -395,7 +406,7 @@ int launch_validate_g2(snarkv_ctx* ctx, const void* d_g2x2_256, int* bad_host) {
 
 int launch_decide(snarkv_ctx* ctx, const void* d_prep, const void* d_accs, size_t m, void* d_ok, void* d_gt) {
   const G2Prepared29* d29 = reinterpret_cast<const G2Prepared29*>((const char*)d_prep + prep29_offset());
-  hipLaunchKernelGGL(k_decide, dim3((uint32_t)m), dim3(256), 0, ctx->stream, d29,
+  hipLaunchKernelGGL(k_decide, dim3((uint32_t)m), dim3(kDecideThreads), 0, ctx->stream, d29,
                      (const uint32_t*)d_accs, (uint32_t)m, (uint8_t*)d_ok, (uint32_t*)d_gt);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;

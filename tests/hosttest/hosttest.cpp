@@ -129,6 +129,11 @@ static void store_g1_29(const G1Affine29& p, uint8_t* b) {
 void ht29_fq_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) { store29(fq29_mul(load29(a), load29(b)), out); }
 void ht29_fq_sqr(const uint8_t* a, uint8_t* out) { store29(fq29_sqr(fq29_norm(load29(a))), out); }
 void ht29_fq_inv(const uint8_t* a, uint8_t* out) { store29(fq29_inv(fq29_norm(load29(a))), out); }
+void ht29_fq_inv_fermat(const uint8_t* a, uint8_t* out) { store29(fq29_inv_fermat(fq29_norm(load29(a))), out); }
+// inverse of the lazy (unnormalised, possibly negative) difference a - b
+void ht29_fq_inv_of_diff(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  store29(fq29_inv(fq29_sub(load29(a), load29(b))), out);
+}
 // ((a - b) * (c + d) - e) with lazy add/sub feeding products
 void ht29_fq_lazy_expr(const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d, const uint8_t* e,
                        uint8_t* out) {
@@ -242,5 +247,63 @@ void ht_coop29_fq12_mul_iter(const uint8_t* a, const uint8_t* b, int rounds, uin
     fc[c] = fq_from_canonical(w);
   }
   store_fq12(coop_tower_from_flat(fc), out);
+}
+// the round k_decide runs (pairing_coop29.cuh "coop3"): 96 lanes emulated one by
+// one, butterflies replaced by explicit sums.  mode 0: f <- f*b each round;
+// mode 1: f <- f*f, then f <- f*b (the Miller-loop pattern, both operands lazy).
+static void coop3_round(const Fq29* fa, const Fq29* fb, Fq29* fc) {
+  Fq29 prod[96];
+  Coop3Lane L[96];
+  for (int l = 0; l < 96; ++l) {
+    L[l] = coop3_lane(l);
+    prod[l] = L[l].active ? coop3_product(L[l].e, fa[2 * L[l].i1], fa[2 * L[l].i1 + 1], fb[2 * L[l].i2 + L[l].e],
+                                          fb[2 * L[l].i2 + 1 - L[l].e])
+                          : fq29_zero();
+  }
+  Fq29 lo[12], hi[12];
+  for (int g = 0; g < 12; ++g) {
+    lo[g] = fq29_zero();
+    hi[g] = fq29_zero();
+    for (int j = 0; j < 8; ++j) {
+      int l = 8 * g + j;  // g = 2k + e
+      if (!L[l].active) continue;
+      Fq29& dst = L[l].high ? hi[g] : lo[g];
+      for (int i = 0; i < 9; ++i) dst.v[i] = (int32_t)((uint32_t)dst.v[i] + (uint32_t)prod[l].v[i]);
+    }
+  }
+  for (int g = 0; g < 12; ++g) fc[g] = coop3_finalize(g & 1, lo[g], hi[g], hi[g ^ 1]);
+}
+void ht_coop3_fq12_mul_iter(const uint8_t* a, const uint8_t* b, int rounds, int mode, uint8_t* out) {
+  Fq fa8[12], fb8[12];
+  coop_flat_from_tower(load_fq12(a), fa8);
+  coop_flat_from_tower(load_fq12(b), fb8);
+  Fq29 fa[12], fb[12], ft[12];
+  for (int c = 0; c < 12; ++c) {
+    uint32_t w[8];
+    fq_to_canonical(fa8[c], w);
+    fa[c] = fq29_canon_residue(fq29_from_canonical(w));
+    fq_to_canonical(fb8[c], w);
+    fb[c] = fq29_canon_residue(fq29_from_canonical(w));
+  }
+  for (int r = 0; r < rounds; ++r) {
+    if (mode == 1) {
+      coop3_round(fa, fa, ft);
+      for (int c = 0; c < 12; ++c) fa[c] = ft[c];
+    }
+    coop3_round(fa, fb, ft);
+    for (int c = 0; c < 12; ++c) fa[c] = ft[c];
+  }
+  Fq fc[12];
+  for (int c = 0; c < 12; ++c) {
+    uint32_t w[8];
+    fq29_to_canonical(fa[c], w);
+    fc[c] = fq_from_canonical(w);
+  }
+  store_fq12(coop_tower_from_flat(fc), out);
+}
+void ht29_fq_mul2(const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d, int neg_c, uint8_t* out) {
+  Fq29 cc = load29(c);
+  if (neg_c) cc = fq29_neg(cc);
+  store29(fq29_mul2(load29(a), load29(b), cc, load29(d)), out);
 }
 }

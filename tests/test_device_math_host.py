@@ -124,9 +124,22 @@ def test_fq29_mul_sqr_lazy(hosttest_lib):
         assert O.fe_from_bytes(o.raw) == ((a - b) * (c + d) - e) % O.P
         assert L.ht29_is_zero_mod_p_of_diff(fb(a), fb(b)) == (1 if a == b else 0)
         assert L.ht29_is_zero_mod_p_of_diff(fb(a), fb(a)) == 1
-    a = rng.randrange(1, O.P)
-    L.ht29_fq_inv(fb(a), o)
-    assert O.fe_from_bytes(o.raw) == pow(a, -1, O.P)
+    # binary-Euclid inverse (fq29_inv) vs Python, and vs the Fermat chain it replaced
+    o2 = _buf(32)
+    edge = [1, 2, 3, O.P - 1, O.P - 2, (O.P + 1) // 2, 1 << 253, (1 << 253) - 1, 0x30644e72 << 224]
+    for a in edge + [rng.randrange(1, O.P) for _ in range(200)]:
+        L.ht29_fq_inv(fb(a), o)
+        assert O.fe_from_bytes(o.raw) == pow(a, -1, O.P), hex(a)
+    for a in [rng.randrange(1, O.P) for _ in range(3)]:
+        L.ht29_fq_inv_fermat(fb(a), o2)
+        assert O.fe_from_bytes(o2.raw) == pow(a, -1, O.P)
+    L.ht29_fq_inv(fb(0), o)  # 0 -> 0, as a^(p-2) gives
+    assert O.fe_from_bytes(o.raw) == 0
+    for _ in range(20):  # lazy, possibly negative input
+        a, b = rng.randrange(O.P), rng.randrange(O.P)
+        if a != b:
+            L.ht29_fq_inv_of_diff(fb(a), fb(b), o)
+            assert O.fe_from_bytes(o.raw) == pow(a - b, -1, O.P)
 
 
 def test_g1_29_fast_and_careful_adders(hosttest_lib):
@@ -237,3 +250,58 @@ def test_cooperative_fq12_rounds_on_lazy_field(hosttest_lib):
     for _ in range(30):
         exp = exp * M
     assert o.raw == exp.to_bytes()
+
+
+def test_fq29_fused_two_product(hosttest_lib):
+    """fq29_mul2: a*b + c*d (and a*b - c*d through a limb-wise negated c) with one reduction."""
+    rng = random.Random(21)
+    o = _buf(32)
+    fb = O.fe_to_bytes
+    vals = [0, 1, O.P - 1, O.P - 2] + [rng.randrange(O.P) for _ in range(6)]
+    for a in vals:
+        for c in vals[:6]:
+            b, d = rng.randrange(O.P), O.P - 1
+            for neg in (0, 1):
+                hosttest_lib.ht29_fq_mul2(fb(a), fb(b), fb(c), fb(d), neg, o)
+                exp = (a * b + (-c if neg else c) * d) % O.P
+                assert O.fe_from_bytes(o.raw) == exp
+
+
+def test_cooperative_fq12_coop3_rounds(hosttest_lib):
+    """The round the shipped k_decide runs (pairing_coop29.cuh coop3: 72 fused
+    two-product lanes, low/high sums, xi fix-up in the finalize step), emulated
+    lane by lane: exact over long chains of products and squarings, including
+    all-(p-1) coefficients (worst-case magnitudes)."""
+    rng = random.Random(14)
+    o = _buf(384)
+    for rounds, mode in ((1, 0), (2, 0), (7, 0), (40, 0), (1, 1), (3, 1), (25, 1)):
+        A, B = _rfq12(rng), _rfq12(rng)
+        hosttest_lib.ht_coop3_fq12_mul_iter(A.to_bytes(), B.to_bytes(), rounds, mode, o)
+        exp = A
+        for _ in range(rounds):
+            if mode == 1:
+                exp = exp * exp
+            exp = exp * B
+        assert o.raw == exp.to_bytes(), (rounds, mode)
+    m = O.Fq2(O.P - 1, O.P - 1)
+    M = O.Fq12(O.Fq6(m, m, m), O.Fq6(m, m, m))
+    for mode in (0, 1):
+        hosttest_lib.ht_coop3_fq12_mul_iter(M.to_bytes(), M.to_bytes(), 20, mode, o)
+        exp = M
+        for _ in range(20):
+            if mode == 1:
+                exp = exp * exp
+            exp = exp * M
+        assert o.raw == exp.to_bytes()
+    # sparse line-shaped multiplier (only w^0, w^1, w^3 non-zero), as in the Miller loop
+    z = O.Fq2(0, 0)
+    for _ in range(3):
+        A = _rfq12(rng)
+        c = [O.Fq2(rng.randrange(O.P), rng.randrange(O.P)) for _ in range(3)]
+        # tower: c0 = (w^0, w^2, w^4), c1 = (w^1, w^3, w^5)
+        Lm = O.Fq12(O.Fq6(c[0], z, z), O.Fq6(c[1], c[2], z))
+        hosttest_lib.ht_coop3_fq12_mul_iter(A.to_bytes(), Lm.to_bytes(), 3, 1, o)
+        exp = A
+        for _ in range(3):
+            exp = exp * exp * Lm
+        assert o.raw == exp.to_bytes()
