@@ -50,6 +50,8 @@ enum Slot {
   SLOT_GLV,
   SLOT_BIG_LIST,
   SLOT_MISC2,
+  SLOT_TERM_CHAIN,
+  SLOT_TERM_MAGS,
   SLOT_COUNT
 };
 

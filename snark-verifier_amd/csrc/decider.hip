@@ -118,11 +118,10 @@ struct CoopReg {  // an Fq12 in the flat basis (c = 2i+e <-> u^e w^i)
   Fq29 v[12];
 };
 
-enum { RF = 0, RT, RINV, RFX, RFX2, RFX3, RY0, RY1, RY2, RY3, RY4, RY5, RY6, RT0, RT1, RCOUNT };
+enum { RF = 0, RT, RINV, RFX, RFX2, RFX3, RY0, RY1, RY2, RY3, RY4, RY5, RY6, RT0, RT1, RM0, RM1, RM2, RM3, RS, RONE, RZERO, RCOUNT };
 
 struct CoopShared {
   CoopReg r[RCOUNT];
-  Fq29 lines[2][kLinesPerG2][4];  // per pair, per line: l0 = cy*yP (2), l1 = cx*xP (2); l2 = cw is read from the key
   Fq29 pt[2][2];                  // (x, y) of lhs, rhs
   Fq29 scal[2];                   // an Fq2 scalar (inverse of the norm)
   int live[2];
@@ -131,6 +130,12 @@ struct CoopShared {
 // One workgroup = one accumulator; the whole state lives in LDS (file scope so
 // that every helper addresses it with ds_* instructions, not flat pointers).
 __shared__ CoopShared g_sh;
+// line tables evaluated at this accumulator's points.  One-team kernel: l0 = cy*yP,
+// l1 = cx*xP per pair and line (l2 = cw is read from the key: 29 KB, four
+// workgroups per CU).  Two-team kernel: all three coefficients (44 KB), so that
+// every operand of a round is one LDS address.
+__shared__ Fq29 g_lines4[2][kLinesPerG2][4];
+__shared__ Fq29 g_lines6[2][kLinesPerG2][6];
 
 static __device__ __forceinline__ void coop_store(int dst, int c, const Fq29& val) { g_sh.r[dst].v[c] = val; }
 
@@ -166,11 +171,16 @@ static __device__ __forceinline__ void coop_mul_b(int dst, int a, int b_reg, int
     if (b_reg >= 0) {
       val = coop3_product(L.e, a0, a1, g_sh.r[b_reg].v[c0], g_sh.r[b_reg].v[c1]);
     } else if (L.i2 < 2 || L.i2 == 3) {
-      // one instruction stream for the three non-zero line coefficients (generic pointers:
-      // l0, l1 live in LDS, l2 = cw in the key)
-      const Fq29* y0 = L.i2 < 2 ? &g_sh.lines[pair][idx][c0] : &prep[pair].line[idx].c[4 + L.e];
-      const Fq29* y1 = L.i2 < 2 ? &g_sh.lines[pair][idx][c1] : &prep[pair].line[idx].c[5 - L.e];
-      val = coop3_product(L.e, a0, a1, *y0, *y1);
+      // one product stream for the three non-zero line coefficients: l0, l1 from LDS, l2 = cw from the key
+      Fq29 y0, y1;
+      if (L.i2 < 2) {
+        y0 = g_lines4[pair][idx][c0];
+        y1 = g_lines4[pair][idx][c1];
+      } else {
+        y0 = prep[pair].line[idx].c[4 + L.e];
+        y1 = prep[pair].line[idx].c[5 - L.e];
+      }
+      val = coop3_product(L.e, a0, a1, y0, y1);
     }
   }
   Fq29 lo, hi;
@@ -195,6 +205,91 @@ static __device__ __forceinline__ void coop_mul_b(int dst, int a, int b_reg, int
 static __device__ __noinline__ void coop_mulr(int dst, int a, int b) { coop_mul_b(dst, a, b, 0, 0, nullptr); }
 static __device__ __noinline__ void coop_mull(int pair, int idx, const G2Prepared29* __restrict__ prep) {
   coop_mul_b(RF, RF, -1, pair, idx, prep);
+}
+
+// ---- two-team rounds (latency form, 256 lanes) -------------------------------
+// Team 0 (lanes 0..127) and team 1 (lanes 128..255) each run one product per
+// round, on different operands, between the same two barriers.  Used where the
+// dependency chain leaves a second product free: the pair products l1*l2 of
+// the NEXT Miller lines while f is being squared, and R *= S next to S <- S^2
+// in the right-to-left exponentiations by x.
+enum { OP_REG = 0, OP_LINE = 1 };
+struct CoopOpnd {
+  int kind, x, y;  // REG: x = register; LINE: x = pair, y = line index
+};
+struct CoopOp {
+  int dst;  // < 0: idle
+  CoopOpnd a, b;
+};
+
+static __device__ __forceinline__ CoopOpnd opnd_reg(int r) { return CoopOpnd{OP_REG, r, 0}; }
+static __device__ __forceinline__ CoopOpnd opnd_line(int pair, int idx) { return CoopOpnd{OP_LINE, pair, idx}; }
+static __device__ __forceinline__ CoopOpnd opnd_one() { return CoopOpnd{OP_REG, RONE, 0}; }
+static __device__ __forceinline__ CoopOp op_idle() { return CoopOp{-1, opnd_one(), opnd_one()}; }
+static __device__ __forceinline__ CoopOp op_mul(int dst, CoopOpnd a, CoopOpnd b) { return CoopOp{dst, a, b}; }
+
+// LDS address of coefficient u^e w^i of an operand; zero coefficients of a
+// line (w^2, w^4, w^5) point into the all-zero register.  No branches: the four
+// operand reads of a round issue back to back.
+static __device__ __forceinline__ const Fq29* opnd_coeff(const CoopOpnd& o, int i, int e) {
+  const int slot = i < 2 ? i : (i == 3 ? 2 : -1);
+  const Fq29* reg = &g_sh.r[o.kind == OP_REG ? o.x : RZERO].v[2 * i + e];
+  const Fq29* line = slot >= 0 ? &g_lines6[o.x & 1][o.y][2 * slot + e] : &g_sh.r[RZERO].v[0];
+  return o.kind == OP_LINE ? line : reg;
+}
+
+static __device__ __noinline__ void coop_round2(const CoopOp opA, const CoopOp opB) {
+  const int tid = threadIdx.x;
+  const bool team1 = tid >= 128;
+  CoopOp op = team1 ? opB : opA;  // wavefront-uniform: keep it in scalar registers
+  op.dst = __builtin_amdgcn_readfirstlane(op.dst);
+  op.a.kind = __builtin_amdgcn_readfirstlane(op.a.kind);
+  op.a.x = __builtin_amdgcn_readfirstlane(op.a.x);
+  op.a.y = __builtin_amdgcn_readfirstlane(op.a.y);
+  op.b.kind = __builtin_amdgcn_readfirstlane(op.b.kind);
+  op.b.x = __builtin_amdgcn_readfirstlane(op.b.x);
+  op.b.y = __builtin_amdgcn_readfirstlane(op.b.y);
+  const Coop3Lane L = coop3_lane(tid & 127);
+  Fq29 val = fq29_zero();
+  if (op.dst >= 0 && L.active) {
+    const Fq29 a0 = *opnd_coeff(op.a, L.i1, 0);
+    const Fq29 a1 = *opnd_coeff(op.a, L.i1, 1);
+    const Fq29 y0 = *opnd_coeff(op.b, L.i2, L.e);
+    const Fq29 y1 = *opnd_coeff(op.b, L.i2, 1 - L.e);
+    val = coop3_product(L.e, a0, a1, y0, y1);
+  }
+  Fq29 lo, hi;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    lo.v[i] = L.high ? 0 : val.v[i];
+    hi.v[i] = L.high ? val.v[i] : 0;
+  }
+  lo = group8_sum(lo);
+  hi = group8_sum(hi);
+  Fq29 hp;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) hp.v[i] = (int32_t)dpp_u32<0x128>((uint32_t)hi.v[i]);
+  const bool writer = op.dst >= 0 && (tid & 7) == 0 && L.k < 6;
+  Fq29 res = fq29_zero();
+  if (writer) res = coop3_finalize(L.e, lo, hi, hp);
+  __syncthreads();
+  if (writer) coop_store(op.dst, 2 * L.k + L.e, res);
+  __syncthreads();
+}
+
+// dst = a^x, right to left: S <- S^2 (team 0) next to R <- R*S (team 1); 63 rounds instead of 89
+static __device__ __noinline__ void coop_exp_by_x2(int dst, int a) {
+  const int tid = threadIdx.x;
+  if (tid < 12) {
+    g_sh.r[RS].v[tid] = g_sh.r[a].v[tid];
+    g_sh.r[dst].v[tid] = g_sh.r[RONE].v[tid];
+  }
+  __syncthreads();
+  for (int i = 0; i <= 62; ++i) {
+    CoopOp sq = i < 62 ? op_mul(RS, opnd_reg(RS), opnd_reg(RS)) : op_idle();
+    CoopOp ml = ((BN254_X_U64 >> i) & 1ull) ? op_mul(dst, opnd_reg(dst), opnd_reg(RS)) : op_idle();
+    coop_round2(sq, ml);
+  }
 }
 
 // dst = conj(a): negate the odd powers of w (the c1 half of the tower)
@@ -280,13 +375,21 @@ static __device__ __noinline__ void coop_exp_by_x(int dst, int a) {
   }
 }
 
-__global__ void __launch_bounds__(kDecideThreads)
+#ifdef SNARKV_DECIDE_PROFILE  // dev aid: phase time stamps (100 MHz wall clock) overwrite the Gt output
+#define DECIDE_STAMP(n) do { if (tid == 0 && gt_out) ((unsigned long long*)(gt_out + (size_t)i * 96))[n] = wall_clock64(); } while (0)
+#else
+#define DECIDE_STAMP(n) do { } while (0)
+#endif
+
+template <int TEAMS>
+__global__ void __launch_bounds__(kDecideThreads * TEAMS)
     k_decide(const G2Prepared29* __restrict__ prep, const uint32_t* __restrict__ accs, uint32_t m,
              uint8_t* __restrict__ ok, uint32_t* __restrict__ gt_out) {
   const int tid = threadIdx.x;
   const uint32_t i = blockIdx.x;
   if (i >= m) return;
   const uint32_t* a = accs + (size_t)i * 32;
+  DECIDE_STAMP(0);
   if (tid < 4) {  // lhs.x, lhs.y, rhs.x, rhs.y -> Montgomery
     uint32_t w[8];
 #pragma unroll
@@ -294,46 +397,114 @@ __global__ void __launch_bounds__(kDecideThreads)
     g_sh.pt[tid >> 1][tid & 1] = fq29_canon_residue(fq29_from_canonical(w));
   }
   if (tid < 12) coop_store(RF, tid, tid == 0 ? fq29_one() : fq29_zero());
+  if (tid < 12) {
+    coop_store(RONE, tid, tid == 0 ? fq29_one() : fq29_zero());
+    coop_store(RZERO, tid, fq29_zero());
+  }
   __syncthreads();
   if (tid < 2)
     g_sh.live[tid] = !(fq29_limbs_all_zero(g_sh.pt[tid][0]) && fq29_limbs_all_zero(g_sh.pt[tid][1])) &&
                      !prep[tid].is_identity;
   // every line of both pairs evaluated at this accumulator's points, up front
   // and in parallel (2 x 102 x 4 products): l0 = cy*yP, l1 = cx*xP
-  for (int j = tid; j < 2 * kLinesPerG2 * 4; j += kDecideThreads) {
-    int k = j / (kLinesPerG2 * 4), rem = j % (kLinesPerG2 * 4), idx = rem / 4, c = rem % 4;
-    g_sh.lines[k][idx][c] = fq29_mul(prep[k].line[idx].c[c], g_sh.pt[k][c < 2 ? 1 : 0]);
+  if (TEAMS == 1) {
+    for (int j = tid; j < 2 * kLinesPerG2 * 4; j += kDecideThreads) {
+      int k = j / (kLinesPerG2 * 4), rem = j % (kLinesPerG2 * 4), idx = rem / 4, c = rem % 4;
+      g_lines4[k][idx][c] = fq29_mul(prep[k].line[idx].c[c], g_sh.pt[k][c < 2 ? 1 : 0]);
+    }
+  } else {
+    for (int j = tid; j < 2 * kLinesPerG2 * 6; j += 2 * kDecideThreads) {
+      int k = j / (kLinesPerG2 * 6), rem = j % (kLinesPerG2 * 6), idx = rem / 6, c = rem % 6;
+      Fq29 v = prep[k].line[idx].c[c];
+      g_lines6[k][idx][c] = c < 4 ? fq29_mul(v, g_sh.pt[k][c < 2 ? 1 : 0]) : v;
+    }
   }
   __syncthreads();
 
+  DECIDE_STAMP(1);
   // ---- Miller loop (2 pairs, shared squarings); identity pairs contribute 1
-  int idx = 0;
-  for (int b = kAteBits - 2; b >= 0; --b) {
-    coop_mulr(RF, RF, RF);
-    for (int k = 0; k < 2; ++k)
-      if (g_sh.live[k]) coop_mull(k, idx, prep);
-    ++idx;
-    if (ate_bit(b)) {
+  if (TEAMS == 1) {
+    int idx = 0;
+    for (int b = kAteBits - 2; b >= 0; --b) {
+      coop_mulr(RF, RF, RF);
+      for (int k = 0; k < 2; ++k)
+        if (g_sh.live[k]) coop_mull(k, idx, prep);
+      ++idx;
+      if (ate_bit(b)) {
+        for (int k = 0; k < 2; ++k)
+          if (g_sh.live[k]) coop_mull(k, idx, prep);
+        ++idx;
+      }
+    }
+    for (int s = 0; s < 2; ++s) {
       for (int k = 0; k < 2; ++k)
         if (g_sh.live[k]) coop_mull(k, idx, prep);
       ++idx;
     }
-  }
-  for (int s = 0; s < 2; ++s) {
-    for (int k = 0; k < 2; ++k)
-      if (g_sh.live[k]) coop_mull(k, idx, prep);
-    ++idx;
+  } else {
+    // team 1 runs ahead producing M_k = l1_k * l2_k (line k of both pairs) into a
+    // ring of four registers; team 0 runs f <- f^2, f <- f * M_k [, f <- f * M_k+1].
+    const bool live0 = g_sh.live[0] != 0, live1 = g_sh.live[1] != 0;
+    int made = 0, used = 0;      // pair products finished / consumed (in earlier rounds)
+    int b = kAteBits - 2;        // current bit
+    int phase = 0;               // 0: square; 1: first line; 2: second line (set bits)
+    int tail = 0;                // the two closing lines
+    while (used < kLinesPerG2) {
+      CoopOp main = op_idle(), aux = op_idle();
+      bool main_is_mul = false;
+      if (b >= 0 && phase == 0) {
+        main = op_mul(RF, opnd_reg(RF), opnd_reg(RF));
+      } else if (made > used) {
+        main = op_mul(RF, opnd_reg(RF), opnd_reg(RM0 + (used & 3)));
+        main_is_mul = true;
+      }
+      if (made < kLinesPerG2 && made - used < 4)
+        aux = op_mul(RM0 + (made & 3), live0 ? opnd_line(0, made) : opnd_one(), live1 ? opnd_line(1, made) : opnd_one());
+      coop_round2(main, aux);
+      if (aux.dst >= 0) ++made;
+      if (main.dst >= 0) {
+        if (!main_is_mul) {
+          phase = 1;
+        } else {
+          ++used;
+          if (b >= 0) {
+            if (phase == 1 && ate_bit(b)) {
+              phase = 2;
+            } else {
+              phase = 0;
+              --b;
+            }
+          } else {
+            ++tail;
+          }
+        }
+      }
+    }
   }
 
+  DECIDE_STAMP(2);
   // ---- final exponentiation, exact exponent (p^12-1)/r (see pairing.cuh)
   coop_inv(RINV, RF);
+  DECIDE_STAMP(3);
   coop_conj(RT, RF);
   coop_mulr(RF, RT, RINV);          // f^(p^6-1)
   coop_frob(RT, RF, 2);
   coop_mulr(RF, RT, RF);            // ^(p^2+1)
-  coop_exp_by_x(RFX, RF);
-  coop_exp_by_x(RFX2, RFX);
-  coop_exp_by_x(RFX3, RFX2);
+  DECIDE_STAMP(4);
+#ifdef SNARKV_T2_OLDEXP
+  if (true) {
+#else
+  if (TEAMS == 1) {
+#endif
+    coop_exp_by_x(RFX, RF);
+    coop_exp_by_x(RFX2, RFX);
+    coop_exp_by_x(RFX3, RFX2);
+  } else {
+    coop_exp_by_x2(RFX, RF);
+    coop_exp_by_x2(RFX2, RFX);
+    coop_exp_by_x2(RFX3, RFX2);
+  }
+  DECIDE_STAMP(5);
   coop_frob(RY0, RF, 1);
   coop_frob(RT, RF, 2);
   coop_mulr(RY0, RY0, RT);
@@ -364,6 +535,10 @@ __global__ void __launch_bounds__(kDecideThreads)
   coop_mulr(RT0, RT0, RT0);
   coop_mulr(RF, RT0, RT1);          // result = t0^2 t1
 
+  DECIDE_STAMP(6);
+#ifdef SNARKV_DECIDE_PROFILE
+  if (gt_out) return;
+#endif
   // canonical words of the 12 coefficients (lane c), then the verdict
   __shared__ uint32_t canon[12][8];
   if (tid < 12) fq29_to_canonical(g_sh.r[RF].v[tid], canon[tid]);
@@ -404,10 +579,22 @@ int launch_validate_g2(snarkv_ctx* ctx, const void* d_g2x2_256, int* bad_host) {
   return SNARKV_OK;
 }
 
+// Small batches take the two-team kernel (shorter dependency chain, 4 wavefronts
+// per accumulator); large ones the one-team kernel (2 wavefronts, same products,
+// four workgroups per CU).  Both give the same bits.
 int launch_decide(snarkv_ctx* ctx, const void* d_prep, const void* d_accs, size_t m, void* d_ok, void* d_gt) {
   const G2Prepared29* d29 = reinterpret_cast<const G2Prepared29*>((const char*)d_prep + prep29_offset());
-  hipLaunchKernelGGL(k_decide, dim3((uint32_t)m), dim3(kDecideThreads), 0, ctx->stream, d29,
-                     (const uint32_t*)d_accs, (uint32_t)m, (uint8_t*)d_ok, (uint32_t*)d_gt);
+  int teams = m <= 512 ? 2 : 1;
+  if (const char* e = getenv("SNARKV_DECIDE_TEAMS")) {
+    int v = atoi(e);
+    if (v == 1 || v == 2) teams = v;
+  }
+  if (teams == 2)
+    hipLaunchKernelGGL(k_decide<2>, dim3((uint32_t)m), dim3(2 * kDecideThreads), 0, ctx->stream, d29,
+                       (const uint32_t*)d_accs, (uint32_t)m, (uint8_t*)d_ok, (uint32_t*)d_gt);
+  else
+    hipLaunchKernelGGL(k_decide<1>, dim3((uint32_t)m), dim3(kDecideThreads), 0, ctx->stream, d29,
+                       (const uint32_t*)d_accs, (uint32_t)m, (uint8_t*)d_ok, (uint32_t*)d_gt);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }

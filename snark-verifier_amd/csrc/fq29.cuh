@@ -440,12 +440,203 @@ SNARKV_HD_NOINLINE void fq_words_inv_binary(const uint32_t a[8], uint32_t out[8]
   for (int i = 0; i < 8; ++i) out[i] = uo ? x1.w[i] : x2.w[i];
 }
 
+// ---- safegcd (Bernstein-Yang divsteps), 30 steps per batch -------------------
+// The binary Euclid above spends ~750 branchy 256-bit iterations; here the
+// branchy part runs on the low 30 bits only (a 2x2 transition matrix per batch)
+// and the wide values see two matrix-vector products per batch: ~22 batches of
+// ~500 instructions.  Signed 30-bit limbs, 9 per value.
+struct S30 {
+  int32_t v[9];
+};
+constexpr int32_t kMask30 = (1 << 30) - 1;
+
+SNARKV_HD S30 s30_modulus() {
+  constexpr uint32_t pl[8] = BN254_P_LIMBS;
+  S30 m;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    int bit = 30 * i, word = bit >> 5, sh = bit & 31;
+    uint64_t t = word < 8 ? pl[word] : 0;
+    if (word + 1 < 8) t |= (uint64_t)pl[word + 1] << 32;
+    m.v[i] = (int32_t)((uint32_t)(t >> sh) & (uint32_t)kMask30);
+  }
+  return m;
+}
+
+// p^-1 mod 2^30 (Newton on the low word)
+SNARKV_HD uint32_t s30_modulus_inv30() {
+  constexpr uint32_t pl[8] = BN254_P_LIMBS;
+  uint32_t x = pl[0];  // correct to 3 bits for odd p
+#pragma unroll
+  for (int i = 0; i < 5; ++i) x *= 2u - pl[0] * x;
+  return x & (uint32_t)kMask30;
+}
+
+// 30 divsteps on the low bits; t = (u v; q r) with 2^30 (f', g') = t (f, g).  Returns the new delta.
+SNARKV_HD int32_t s30_divsteps30(int32_t delta, uint32_t f, uint32_t g, int32_t t[4]) {
+  int32_t u = 1, v = 0, q = 0, r = 1;
+  for (int i = 0; i < 30; ++i) {
+    if (g & 1u) {
+      if (delta > 0) {
+        delta = -delta;
+        uint32_t tf = f;
+        f = g;
+        g = g - tf;
+        int32_t tu = u, tv = v;
+        u = q;
+        v = r;
+        q = q - tu;
+        r = r - tv;
+      } else {
+        g += f;
+        q += u;
+        r += v;
+      }
+    }
+    delta += 1;
+    g >>= 1;
+    u *= 2;
+    v *= 2;
+  }
+  t[0] = u;
+  t[1] = v;
+  t[2] = q;
+  t[3] = r;
+  return delta;
+}
+
+// (f, g) <- t (f, g) / 2^30, exact
+SNARKV_HD void s30_update_fg(S30& f, S30& g, const int32_t t[4]) {
+  const int64_t u = t[0], v = t[1], q = t[2], r = t[3];
+  int64_t cf = u * f.v[0] + v * g.v[0];
+  int64_t cg = q * f.v[0] + r * g.v[0];
+  cf >>= 30;
+  cg >>= 30;
+#pragma unroll
+  for (int i = 1; i < 9; ++i) {
+    cf += u * f.v[i] + v * g.v[i];
+    cg += q * f.v[i] + r * g.v[i];
+    f.v[i - 1] = (int32_t)cf & kMask30;
+    g.v[i - 1] = (int32_t)cg & kMask30;
+    cf >>= 30;
+    cg >>= 30;
+  }
+  f.v[8] = (int32_t)cf;
+  g.v[8] = (int32_t)cg;
+}
+
+// (d, e) <- t (d, e) / 2^30 mod p; d, e stay in (-2p, p)
+SNARKV_HD void s30_update_de(S30& d, S30& e, const int32_t t[4], const S30& m, uint32_t minv30) {
+  const int32_t u = t[0], v = t[1], q = t[2], r = t[3];
+  const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
+  int32_t md = (u & sd) + (v & se);
+  int32_t me = (q & sd) + (r & se);
+  int64_t cd = (int64_t)u * d.v[0] + (int64_t)v * e.v[0];
+  int64_t ce = (int64_t)q * d.v[0] + (int64_t)r * e.v[0];
+  md -= (int32_t)((minv30 * (uint32_t)cd + (uint32_t)md) & (uint32_t)kMask30);
+  me -= (int32_t)((minv30 * (uint32_t)ce + (uint32_t)me) & (uint32_t)kMask30);
+  cd += (int64_t)m.v[0] * md;
+  ce += (int64_t)m.v[0] * me;
+  cd >>= 30;
+  ce >>= 30;
+#pragma unroll
+  for (int i = 1; i < 9; ++i) {
+    cd += (int64_t)u * d.v[i] + (int64_t)v * e.v[i] + (int64_t)m.v[i] * md;
+    ce += (int64_t)q * d.v[i] + (int64_t)r * e.v[i] + (int64_t)m.v[i] * me;
+    d.v[i - 1] = (int32_t)cd & kMask30;
+    e.v[i - 1] = (int32_t)ce & kMask30;
+    cd >>= 30;
+    ce >>= 30;
+  }
+  d.v[8] = (int32_t)cd;
+  e.v[8] = (int32_t)ce;
+}
+
+// a^-1 mod p for a in [0, p) (0 -> 0); plain integers, 8 x u32 little-endian
+SNARKV_HD_NOINLINE void fq_words_inv_safegcd(const uint32_t a[8], uint32_t out[8]) {
+  const S30 m = s30_modulus();
+  const uint32_t minv30 = s30_modulus_inv30();
+  S30 f = m, g, d, e;
+  uint32_t nz = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    int bit = 30 * i, word = bit >> 5, sh = bit & 31;
+    uint64_t t = word < 8 ? a[word] : 0;
+    if (word + 1 < 8) t |= (uint64_t)a[word + 1] << 32;
+    g.v[i] = (int32_t)((uint32_t)(t >> sh) & (uint32_t)kMask30);
+    d.v[i] = 0;
+    e.v[i] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) nz |= a[i];
+  e.v[0] = 1;
+  if (nz != 0) {
+    int32_t delta = 1;
+    for (int batch = 0; batch < 40; ++batch) {  // <= 25 batches cover the 741-divstep bound for 256 bits
+      int32_t t[4];
+      delta = s30_divsteps30(delta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+      s30_update_de(d, e, t, m, minv30);
+      s30_update_fg(f, g, t);
+      int32_t gz = 0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) gz |= g.v[i];
+      if (gz == 0) break;
+    }
+  }
+  // g = 0, f = +-1 (gcd), d = +-a^-1 in (-2p, p): fix the sign, then into [0, p)
+  const int32_t fneg = f.v[8] >> 31;
+  int64_t c = 0;
+  S30 x;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {  // x = fneg ? -d : d
+    int64_t tt = (int64_t)((d.v[i] ^ fneg) - fneg) + c;
+    x.v[i] = i < 8 ? ((int32_t)tt & kMask30) : (int32_t)tt;
+    c = i < 8 ? (tt >> 30) : 0;
+  }
+  for (int pass = 0; pass < 2; ++pass) {  // x in (-2p, 2p): add p while negative ...
+    const int32_t neg = x.v[8] >> 31;
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      int64_t tt = (int64_t)x.v[i] + (m.v[i] & neg) + c;
+      x.v[i] = i < 8 ? ((int32_t)tt & kMask30) : (int32_t)tt;
+      c = i < 8 ? (tt >> 30) : 0;
+    }
+  }
+  {  // ... then subtract p once if x >= p
+    S30 y;
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      int64_t tt = (int64_t)x.v[i] - m.v[i] + c;
+      y.v[i] = i < 8 ? ((int32_t)tt & kMask30) : (int32_t)tt;
+      c = i < 8 ? (tt >> 30) : 0;
+    }
+    const int32_t keep = y.v[8] >> 31;  // negative: x < p
+#pragma unroll
+    for (int i = 0; i < 9; ++i) x.v[i] = (x.v[i] & keep) | (y.v[i] & ~keep);
+  }
+  if (nz == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) x.v[i] = 0;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[j] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    int bit = 30 * i, word = bit >> 5, sh = bit & 31;
+    uint64_t tt = (uint64_t)(uint32_t)x.v[i] << sh;
+    if (word < 8) out[word] |= (uint32_t)tt;
+    if (word + 1 < 8) out[word + 1] |= (uint32_t)(tt >> 32);
+  }
+}
+
 // Field inverse in the Montgomery domain; a within (-8p, 8p), result
 // carry-normalised.  0 -> 0 (as Fermat's a^(p-2) gives).
 SNARKV_HD Fq29 fq29_inv(const Fq29& a) {
   uint32_t w[8], r[8];
   fq29_to_canonical(a, w);
-  fq_words_inv_binary(w, r);
+  fq_words_inv_safegcd(w, r);
   return fq29_from_canonical(r);
 }
 

@@ -124,27 +124,26 @@ SNARKV_HD G1Xyzz29 xyzz29_double(const G1Xyzz29& p) {
 // Bounds: x, y, z stay carry-normalised; every value passes through a square
 // or product each round, so magnitudes stay below ~12p and every product
 // result below ~2p (|a*b| / 2^261 < 1.1 p for |a|,|b| < 14p).
-SNARKV_HD G1Xyzz29 xyzz29_double_n(const G1Xyzz29& p, int n) {
-  if (n <= 0) return p;
-  Fq29 x = fq29_mul(p.x, p.zz);
-  Fq29 y = fq29_mul(fq29_norm(p.y), p.zzz);
-  Fq29 z = p.zz;
-  for (int k = 0; k < n; ++k) {
-    Fq29 a = fq29_sqr(x);
-    Fq29 b = fq29_sqr(y);
-    Fq29 c = fq29_sqr(b);
-    Fq29 xb = fq29_norm(fq29_add(x, b));
-    // D = 2((X+B)^2 - A - C): limbs in (-2^31+4, 2^30) before the carry pass
-    Fq29 d = fq29_norm(fq29_dbl(fq29_sub(fq29_sub(fq29_sqr(xb), a), c)));
-    Fq29 e = fq29_norm(fq29_add(fq29_dbl(a), a));                    // E = 3A
-    Fq29 x3 = fq29_norm(fq29_sub(fq29_sqr(e), fq29_dbl(d)));         // F - 2D
-    Fq29 c8 = fq29_dbl(fq29_norm(fq29_dbl(fq29_dbl(c))));            // 8C, limbs < 2^30
-    Fq29 y3 = fq29_norm(fq29_sub(fq29_mul(e, fq29_sub(d, x3)), c8));  // E(D - X3) - 8C
-    Fq29 z3 = fq29_norm(fq29_dbl(fq29_mul(y, z)));                    // 2YZ
-    x = x3;
-    y = y3;
-    z = z3;
-  }
+// one Jacobian doubling in place (dbl-2009-l, a = 0; 2M + 5S); x, y, z carry-normalised
+SNARKV_HD void jac29_double(Fq29& x, Fq29& y, Fq29& z) {
+  Fq29 a = fq29_sqr(x);
+  Fq29 b = fq29_sqr(y);
+  Fq29 c = fq29_sqr(b);
+  Fq29 xb = fq29_norm(fq29_add(x, b));
+  // D = 2((X+B)^2 - A - C): limbs in (-2^31+4, 2^30) before the carry pass
+  Fq29 d = fq29_norm(fq29_dbl(fq29_sub(fq29_sub(fq29_sqr(xb), a), c)));
+  Fq29 e = fq29_norm(fq29_add(fq29_dbl(a), a));                    // E = 3A
+  Fq29 x3 = fq29_norm(fq29_sub(fq29_sqr(e), fq29_dbl(d)));         // F - 2D
+  Fq29 c8 = fq29_dbl(fq29_norm(fq29_dbl(fq29_dbl(c))));            // 8C, limbs < 2^30
+  Fq29 y3 = fq29_norm(fq29_sub(fq29_mul(e, fq29_sub(d, x3)), c8));  // E(D - X3) - 8C
+  Fq29 z3 = fq29_norm(fq29_dbl(fq29_mul(y, z)));                    // 2YZ
+  x = x3;
+  y = y3;
+  z = z3;
+}
+
+// Jacobian (X, Y, Z) -> (X, Y, Z^2, Z^3)
+SNARKV_HD G1Xyzz29 jac29_to_xyzz(const Fq29& x, const Fq29& y, const Fq29& z) {
   G1Xyzz29 r;
   Fq29 zz = fq29_sqr(z);
   r.x = x;
@@ -152,6 +151,15 @@ SNARKV_HD G1Xyzz29 xyzz29_double_n(const G1Xyzz29& p, int n) {
   r.zz = zz;
   r.zzz = fq29_mul(z, zz);
   return r;
+}
+
+SNARKV_HD G1Xyzz29 xyzz29_double_n(const G1Xyzz29& p, int n) {
+  if (n <= 0) return p;
+  Fq29 x = fq29_mul(p.x, p.zz);
+  Fq29 y = fq29_mul(fq29_norm(p.y), p.zzz);
+  Fq29 z = p.zz;
+  for (int k = 0; k < n; ++k) jac29_double(x, y, z);
+  return jac29_to_xyzz(x, y, z);
 }
 
 SNARKV_HD G1Xyzz29 xyzz29_double_affine(const G1Affine29& p) {

@@ -98,6 +98,120 @@ __global__ void __launch_bounds__(64) k_term_scalar_mul(const uint32_t* __restri
   out[g] = r;
 }
 
+// ---- chunked form of K1 for SMALL batches (the machine is far from full) ----
+// A 127-step chain per lane leaves >90 % of the SIMDs idle when a job has a
+// few thousand terms.  Split every half-scalar into J chunks of 128/J bits:
+//   K1a k_term_chain  : lane per (term, half): GLV split, then ONE Jacobian
+//                       doubling chain (7 products per doubling instead of the
+//                       19 of a double-and-add step) that emits the chunk
+//                       bases Q_j = 2^(j*bits) * Q
+//   K1b k_term_chunks : lane per (term, half, chunk): (bits)-step double-and-add
+//                       on Q_j, then a shuffle tree over the J adjacent lanes
+// Dependent field products per term: ~2400 -> ~900 + 23*bits.  Same partial
+// layout as K1 (one XYZZ per (term, half)), so K2 is unchanged.
+__global__ void __launch_bounds__(64) k_term_chain(const uint32_t* __restrict__ scalars,
+                                                    const uint32_t* __restrict__ points,
+                                                    G1Xyzz29* __restrict__ chain, uint4* __restrict__ mags,
+                                                    uint32_t n_terms, uint32_t J, uint32_t bits) {
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= 2 * n_terms) return;
+  uint32_t t = g >> 1, h = g & 1u;
+  uint32_t k[8], pw[16], halves[8];
+  load_words16(scalars + (size_t)t * 8, k, 2);
+  load_words16(points + (size_t)t * 16, pw, 4);
+  glv_decompose(k, halves);
+  uint4 mag = make_uint4(halves[4 * h], halves[4 * h + 1], halves[4 * h + 2], halves[4 * h + 3] & 0x7FFFFFFFu);
+  uint32_t neg = halves[4 * h + 3] >> 31;
+  G1Affine29 q = g1a29_from_canonical(pw);
+  if (g1a29_is_identity(q)) mag = make_uint4(0, 0, 0, 0);  // all digits zero -> identity partial
+  mags[g] = mag;
+  if (h) {
+    constexpr int32_t bl[9] = BN254_GLV_BETA29_LIMBS;
+    Fq29 beta;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) beta.v[j] = bl[j];
+    q.x = fq29_canon_residue(fq29_mul(q.x, beta));
+  }
+  if (neg) q.y = fq29_norm(fq29_neg(q.y));
+  G1Xyzz29* dst = chain + (size_t)g * J;
+  Fq29 x = q.x, y = q.y, z = fq29_one();
+  dst[0] = jac29_to_xyzz(x, y, z);  // (x, y, 1, 1)
+  if ((mag.x | mag.y | mag.z | mag.w) == 0) return;  // bases never read
+  for (uint32_t j = 1; j < J; ++j) {
+    for (uint32_t i = 0; i < bits; ++i) jac29_double(x, y, z);
+    dst[j] = jac29_to_xyzz(x, y, z);
+  }
+}
+
+__device__ __forceinline__ G1Xyzz29 xyzz29_shfl_xor(const G1Xyzz29& p, int mask) {
+  G1Xyzz29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    r.x.v[i] = __shfl_xor(p.x.v[i], mask);
+    r.y.v[i] = __shfl_xor(p.y.v[i], mask);
+    r.zz.v[i] = __shfl_xor(p.zz.v[i], mask);
+    r.zzz.v[i] = __shfl_xor(p.zzz.v[i], mask);
+  }
+  return r;
+}
+
+__device__ __forceinline__ uint32_t mag_bit(const uint4& m, uint32_t b) {
+  uint32_t w = (b >> 5) == 0 ? m.x : (b >> 5) == 1 ? m.y : (b >> 5) == 2 ? m.z : m.w;
+  return (w >> (b & 31u)) & 1u;
+}
+
+__global__ void __launch_bounds__(64) k_term_chunks(const G1Xyzz29* __restrict__ chain,
+                                                     const uint4* __restrict__ mags,
+                                                     G1Xyzz29* __restrict__ out, uint32_t n_lanes, uint32_t J,
+                                                     uint32_t bits) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;  // J divides 64: a chunk group never straddles a wavefront
+  bool live = t < n_lanes;
+  uint32_t g = live ? t / J : 0, j = t % J;
+  uint4 mag = live ? mags[g] : make_uint4(0, 0, 0, 0);
+  G1Xyzz29 acc = xyzz29_identity();
+  bool bad = false;
+  uint32_t any = 0;
+  for (uint32_t i = 0; i < bits; ++i) any |= mag_bit(mag, bits * j + i);
+  if (any) {
+    G1Xyzz29 base = chain[(size_t)g * J + j];
+    base.y = fq29_norm(base.y);
+    bool started = false;
+    for (int i = (int)bits - 1; i >= 0; --i) {
+      if (started) acc = xyzz29_double(acc);
+      if (mag_bit(mag, bits * j + (uint32_t)i)) {
+        if (!started) {
+          acc = base;
+          started = true;
+        } else {
+          // d*Q + Q with 1 < d < 2^bits: never +-Q in a prime-order group
+          xyzz29_add_fast(acc, base);
+        }
+      }
+    }
+    acc.y = fq29_norm(acc.y);
+  }
+  // sum the J chunk results of one (term, half): distinct bit ranges of a
+  // 127-bit integer, so no two partial sums are equal or opposite
+  for (uint32_t s = 1; s < J; s <<= 1) {
+    G1Xyzz29 other = xyzz29_shfl_xor(acc, (int)s);
+    xyzz29_add_skipid_fast(acc, other, bad);
+    acc.y = fq29_norm(acc.y);
+    bad = bad || (__shfl_xor((int)bad, (int)s) != 0);
+  }
+  if (live && j == 0) {
+    if (bad || (!xyzz29_is_identity(acc) && xyzz29_is_degenerate(acc))) {  // off-curve input or the like: redo carefully
+      G1Xyzz29 b0 = chain[(size_t)g * J];
+      G1Affine29 q;
+      q.x = b0.x;
+      q.y = b0.y;
+      uint32_t m4[4] = {mag.x, mag.y, mag.z, mag.w};
+      acc = half_scalar_mul<true>(q, m4);
+      if (!xyzz29_is_identity(acc) && xyzz29_is_degenerate(acc)) acc = xyzz29_identity();
+    }
+    out[g] = acc;
+  }
+}
+
 // K2: one 64-lane block (= one wavefront) per MSM folds its 2 x terms partials
 // (`reduce(|a,v| a+v)`, native.rs:68), then `to_affine()` (native.rs:70).
 __global__ void __launch_bounds__(64) k_segment_fold(const G1Xyzz29* __restrict__ parts,
@@ -157,13 +271,42 @@ __global__ void k_validate(const uint32_t* __restrict__ scalars, const uint32_t*
   if (!ok) atomicAdd(bad, 1);
 }
 
+// chunks per half-scalar: as many as keep the chunk kernel at <= ~1 wavefront
+// per SIMD (beyond that the extra additions cost more than the shorter chain saves)
+static uint32_t chunks_for(size_t n_terms) {
+  if (const char* e = getenv("SNARKV_NAIVE_CHUNKS")) {
+    int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) return (uint32_t)v;
+  }
+  if (n_terms <= 2048) return 16;
+  if (n_terms <= 4096) return 8;
+  if (n_terms <= 8192) return 4;
+  if (n_terms <= 16384) return 2;
+  return 1;
+}
+
 int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, const void* d_offsets,
                        size_t n_msm, size_t n_terms, void* d_out) {
   void* d_terms = nullptr;
   SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_PARTIALS, 2 * n_terms * sizeof(G1Xyzz29), &d_terms));
-  uint32_t blocks = (uint32_t)((2 * n_terms + 63) / 64);
-  hipLaunchKernelGGL(k_term_scalar_mul, dim3(blocks), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,
-                     (const uint32_t*)d_points, (G1Xyzz29*)d_terms, (uint32_t)n_terms);
+  const uint32_t J = chunks_for(n_terms);
+  if (J == 1) {
+    uint32_t blocks = (uint32_t)((2 * n_terms + 63) / 64);
+    hipLaunchKernelGGL(k_term_scalar_mul, dim3(blocks), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,
+                       (const uint32_t*)d_points, (G1Xyzz29*)d_terms, (uint32_t)n_terms);
+  } else {
+    void* d_chain = nullptr;
+    void* d_mags = nullptr;
+    SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_CHAIN, 2 * n_terms * J * sizeof(G1Xyzz29), &d_chain));
+    SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_MAGS, 2 * n_terms * sizeof(uint4), &d_mags));
+    const uint32_t bits = 128 / J;
+    uint32_t blocks_a = (uint32_t)((2 * n_terms + 63) / 64);
+    hipLaunchKernelGGL(k_term_chain, dim3(blocks_a), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,
+                       (const uint32_t*)d_points, (G1Xyzz29*)d_chain, (uint4*)d_mags, (uint32_t)n_terms, J, bits);
+    uint32_t n_lanes = (uint32_t)(2 * n_terms * J);
+    hipLaunchKernelGGL(k_term_chunks, dim3((n_lanes + 63) / 64), dim3(64), 0, ctx->stream,
+                       (const G1Xyzz29*)d_chain, (const uint4*)d_mags, (G1Xyzz29*)d_terms, n_lanes, J, bits);
+  }
   hipLaunchKernelGGL(k_segment_fold, dim3((uint32_t)n_msm), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_terms,
                      (const uint32_t*)d_offsets, (uint32_t*)d_out);
   SNARKV_HIP(hipGetLastError());

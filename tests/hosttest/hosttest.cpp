@@ -129,6 +129,19 @@ static void store_g1_29(const G1Affine29& p, uint8_t* b) {
 void ht29_fq_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) { store29(fq29_mul(load29(a), load29(b)), out); }
 void ht29_fq_sqr(const uint8_t* a, uint8_t* out) { store29(fq29_sqr(fq29_norm(load29(a))), out); }
 void ht29_fq_inv(const uint8_t* a, uint8_t* out) { store29(fq29_inv(fq29_norm(load29(a))), out); }
+// plain-integer inverses (8 x u32 LE in, out): safegcd (shipped) and the binary Euclid cross-check
+void ht_words_inv_safegcd(const uint8_t* a, uint8_t* out) {
+  uint32_t w[8], r[8];
+  memcpy(w, a, 32);
+  fq_words_inv_safegcd(w, r);
+  memcpy(out, r, 32);
+}
+void ht_words_inv_binary(const uint8_t* a, uint8_t* out) {
+  uint32_t w[8], r[8];
+  memcpy(w, a, 32);
+  fq_words_inv_binary(w, r);
+  memcpy(out, r, 32);
+}
 void ht29_fq_inv_fermat(const uint8_t* a, uint8_t* out) { store29(fq29_inv_fermat(fq29_norm(load29(a))), out); }
 // inverse of the lazy (unnormalised, possibly negative) difference a - b
 void ht29_fq_inv_of_diff(const uint8_t* a, const uint8_t* b, uint8_t* out) {

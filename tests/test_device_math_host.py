@@ -133,6 +133,16 @@ def test_fq29_mul_sqr_lazy(hosttest_lib):
     for a in [rng.randrange(1, O.P) for _ in range(3)]:
         L.ht29_fq_inv_fermat(fb(a), o2)
         assert O.fe_from_bytes(o2.raw) == pow(a, -1, O.P)
+    # the plain-integer kernels underneath: safegcd (shipped) and binary Euclid agree with pow()
+    for a in edge + [rng.randrange(1, O.P) for _ in range(2000)] + [(1 << k) % O.P for k in range(0, 254, 7)] + \
+            [O.P - (1 << k) for k in range(0, 253, 11)]:
+        L.ht_words_inv_safegcd(a.to_bytes(32, "little"), o)
+        assert int.from_bytes(o.raw, "little") == pow(a, -1, O.P), hex(a)
+    for a in edge + [rng.randrange(1, O.P) for _ in range(50)]:
+        L.ht_words_inv_binary(a.to_bytes(32, "little"), o)
+        assert int.from_bytes(o.raw, "little") == pow(a, -1, O.P), hex(a)
+    L.ht_words_inv_safegcd(bytes(32), o)
+    assert o.raw == bytes(32)
     L.ht29_fq_inv(fb(0), o)  # 0 -> 0, as a^(p-2) gives
     assert O.fe_from_bytes(o.raw) == 0
     for _ in range(20):  # lazy, possibly negative input

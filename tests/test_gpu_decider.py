@@ -18,7 +18,11 @@ def dk(gpu_ctx, golden_decider):
     k.close()
 
 
-def test_golden_decide_and_gt_value(gpu_ctx, dk, golden_decider):
+@pytest.mark.parametrize("teams", ["1", "2"])
+def test_golden_decide_and_gt_value(gpu_ctx, dk, golden_decider, teams, monkeypatch):
+    """Both kernel forms (decider.hip: one-team throughput form, two-team latency
+    form) must give the exact Gt element, identity pairs included."""
+    monkeypatch.setenv("SNARKV_DECIDE_TEAMS", teams)
     for case in golden_decider["cases"]:
         acc = bytes.fromhex(case["acc"])
         assert gpu_ctx.decide(dk, acc) == case["accept"], case["name"]
@@ -26,7 +30,9 @@ def test_golden_decide_and_gt_value(gpu_ctx, dk, golden_decider):
         assert gpu_ctx.pairing_value(dk, acc) == bytes.fromhex(case["gt"]), case["name"]
 
 
-def test_decide_all_batch(gpu_ctx, dk, golden_decider):
+@pytest.mark.parametrize("teams", ["1", "2"])
+def test_decide_all_batch(gpu_ctx, dk, golden_decider, teams, monkeypatch):
+    monkeypatch.setenv("SNARKV_DECIDE_TEAMS", teams)
     cases = golden_decider["cases"]
     accs = b"".join(bytes.fromhex(c["acc"]) for c in cases)
     allok, oks = gpu_ctx.decide_batch(dk, accs)

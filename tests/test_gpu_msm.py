@@ -179,3 +179,40 @@ def test_full_size_2p20_properties(gpu_ctx):
     gpu_ctx.msm_pippenger_dev(ds.data_ptr(), dp.data_ptr(), m, out[1].data_ptr())
     gpu_ctx.sync()
     assert bytes(out[1].cpu().numpy()) == C.msm_pippenger(s, p, 4)
+
+
+@pytest.mark.parametrize("chunks", [1, 2, 4, 8, 16])
+def test_batched_chunked_scalar_mul_all_chunkings(gpu_ctx, golden_msm, chunks, monkeypatch):
+    """The small-batch form of the naive MSM (msm_naive.hip K1a/K1b: one doubling
+    chain + J chunk lanes per half-scalar) must agree with the oracle for every
+    chunk count, on the goldens and on edge scalars / identity bases."""
+    import random
+
+    monkeypatch.setenv("SNARKV_NAIVE_CHUNKS", str(chunks))
+    s = b"".join(bytes.fromhex(c["scalars"]) for c in golden_msm)
+    p = b"".join(bytes.fromhex(c["points"]) for c in golden_msm)
+    offs = [0]
+    for c in golden_msm:
+        offs.append(offs[-1] + len(c["scalars"]) // 64)
+    out = gpu_ctx.msm_batched(s, p, offs)
+    for i, c in enumerate(golden_msm):
+        assert out[64 * i:64 * i + 64] == bytes.fromhex(c["expected"]), (chunks, c["name"])
+
+    rng = random.Random(100 + chunks)
+    edge = [0, 1, 2, 3, O.R - 1, O.R - 2, (O.R - 1) // 2, 1 << 127, (1 << 127) - 1, 1 << 128, (1 << 253) + 5,
+            0xFFFF, 0x10000, 0xFF00FF00FF00FF00FF00FF00FF00FF00, 1 << 16, 1 << 32, 1 << 64, 1 << 96]
+    scal = edge + [rng.randrange(O.R) for _ in range(46)]
+    pts = C.sample_points(900 + chunks, len(scal))
+    pl = [pts[64 * i:64 * i + 64] for i in range(len(scal))]
+    pl[5] = bytes(64)                       # identity base
+    pl[20] = pl[19]                         # repeated base
+    pl[22] = O.g1_to_bytes(O.g1_neg(O.g1_from_bytes(pl[21])))  # opposite bases
+    scal[22] = scal[21]                     # ... with equal scalars: the pair cancels
+    sb = b"".join(x.to_bytes(32, "little") for x in scal)
+    pb = b"".join(pl)
+    offs2 = [0, 1, 2, 18, 19, 23, 40, len(scal)]
+    got = gpu_ctx.msm_batched(sb, pb, offs2)
+    assert got == C.msm_batched(sb, pb, offs2)
+    # single-term segments: every edge scalar on its own
+    offs3 = list(range(len(scal) + 1))
+    assert gpu_ctx.msm_batched(sb, pb, offs3) == C.msm_batched(sb, pb, offs3)
