@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "pcs.hpp"
+#include "transcript.hpp"
 
 using namespace snarkv_host;
 
@@ -269,6 +270,147 @@ int hd_limbs_roundtrip(const uint8_t* limbs16x32, uint8_t* out128, uint8_t* limb
     acc.value->to_bytes(out128);
     auto back = LimbsEncoding<4, 68>::to_limbs(*acc.value);
     for (int i = 0; i < 16; ++i) back[i].to_bytes(limbs_out16x32 + 32 * i);
+    return 0;
+  });
+}
+
+// ---- Keccak / EVM transcript (transcript.hpp; reference system/halo2/transcript/evm.rs)
+void hd_keccak256(const uint8_t* data, size_t len, uint8_t* out32) { keccak::keccak256(data, len, out32); }
+
+// Runs a scripted sequence of transcript operations on `EvmTranscript(proof)`.
+// script: op bytes, each followed by its LE payload:
+//   1 squeeze -> out += challenge(32 LE)      2 common_scalar [32]       3 common_ec_point [64]
+//   4 read_scalar -> out += 32 LE             5 read_ec_point -> out += 64 LE
+//   6 write_scalar [32]                       7 write_ec_point [64]
+//   8 finalize -> out += len(u32) || stream
+// Returns 0, or 1000 + index of the operation that returned Error::Transcript.
+int hd_evm_transcript_script(const uint8_t* script, size_t script_len, const uint8_t* proof, size_t proof_len,
+                             uint8_t* out, size_t out_cap, size_t* out_len) {
+  return guarded([&] {
+    EvmTranscript t(std::vector<uint8_t>(proof, proof + proof_len));
+    std::vector<uint8_t> o;
+    size_t i = 0;
+    int opi = 0;
+    int rc = 0;
+    while (i < script_len && rc == 0) {
+      uint8_t op = script[i++];
+      Error e;
+      switch (op) {
+        case 1: {
+          uint8_t b[32];
+          t.squeeze_challenge().to_bytes(b);
+          o.insert(o.end(), b, b + 32);
+          break;
+        }
+        case 2: {
+          Fr x;
+          if (!Fr::from_bytes(script + i, &x)) return -3;
+          i += 32;
+          e = t.common_scalar(x);
+          break;
+        }
+        case 3: {
+          e = t.common_ec_point(G1Affine::from_bytes(script + i));
+          i += 64;
+          break;
+        }
+        case 4: {
+          auto r = t.read_scalar();
+          if (!r.ok()) {
+            e = r.err;
+          } else {
+            uint8_t b[32];
+            r.value->to_bytes(b);
+            o.insert(o.end(), b, b + 32);
+          }
+          break;
+        }
+        case 5: {
+          auto r = t.read_ec_point();
+          if (!r.ok()) {
+            e = r.err;
+          } else {
+            o.insert(o.end(), r.value->b, r.value->b + 64);
+          }
+          break;
+        }
+        case 6: {
+          Fr x;
+          if (!Fr::from_bytes(script + i, &x)) return -3;
+          i += 32;
+          e = t.write_scalar(x);
+          break;
+        }
+        case 7: {
+          e = t.write_ec_point(G1Affine::from_bytes(script + i));
+          i += 64;
+          break;
+        }
+        case 8: {
+          auto st = t.stream();
+          uint32_t n = (uint32_t)st.size();
+          uint8_t nb[4];
+          memcpy(nb, &n, 4);
+          o.insert(o.end(), nb, nb + 4);
+          o.insert(o.end(), st.begin(), st.end());
+          break;
+        }
+        default:
+          return -2;
+      }
+      if (!e.ok()) rc = 1000 + opi;
+      ++opi;
+    }
+    if (o.size() > out_cap) return -6;
+    memcpy(out, o.data(), o.size());
+    *out_len = o.size();
+    return rc;
+  });
+}
+
+// KzgAs over the REAL transcript, prover then verifier (accumulation.rs:148-197
+// then :114-137 + :41-63): the prover absorbs the instances, writes the blind
+// pair (zk) and squeezes r; the verifier re-derives r from the proof bytes.
+// out: proof_len(u32) || proof || prover_acc(128) || verifier_acc(128) || r(32)
+int hd_kzg_as_evm_roundtrip(const uint8_t* accs128, uint32_t m, const uint8_t* pk128_or_null,
+                            const uint8_t* blind_scalar32, uint8_t* out, size_t out_cap, size_t* out_len) {
+  return guarded([&] {
+    std::vector<KzgAccumulator> instances;
+    for (uint32_t i = 0; i < m; ++i)
+      instances.push_back(KzgAccumulator{G1Affine::from_bytes(accs128 + 128 * i), G1Affine::from_bytes(accs128 + 128 * i + 64)});
+    KzgAsProvingKey pk;
+    Fr bs;
+    if (pk128_or_null) {
+      pk.g = std::make_pair(G1Affine::from_bytes(pk128_or_null), G1Affine::from_bytes(pk128_or_null + 64));
+      if (!Fr::from_bytes(blind_scalar32, &bs)) return -3;
+    }
+    EvmTranscript wt;
+    auto acc_p = KzgAs<Gwc19>::create_proof(pk, instances, wt, bs);
+    if (!acc_p.ok()) return -4;
+    std::vector<uint8_t> proof = wt.finalize();
+    EvmTranscript rt(proof);
+    KzgAsVerifyingKey vk{pk128_or_null != nullptr};
+    auto pr = KzgAs<Gwc19>::read_proof(vk, instances, rt);
+    if (!pr.ok()) return -5;
+    if (rt.remaining() != 0) return -7;
+    auto acc_v = KzgAs<Gwc19>::verify(vk, instances, *pr.value);
+    std::vector<uint8_t> o;
+    uint32_t n = (uint32_t)proof.size();
+    uint8_t nb[4];
+    memcpy(nb, &n, 4);
+    o.insert(o.end(), nb, nb + 4);
+    o.insert(o.end(), proof.begin(), proof.end());
+    uint8_t a[128];
+    acc_p.value->to_bytes(a);
+    o.insert(o.end(), a, a + 128);
+    acc_v.value->to_bytes(a);
+    o.insert(o.end(), a, a + 128);
+    uint8_t rb[32];
+    pr.value->r.to_bytes(rb);
+    o.insert(o.end(), rb, rb + 32);
+    if (o.size() > out_cap) return -6;
+    memcpy(out, o.data(), o.size());
+    *out_len = o.size();
     return 0;
   });
 }

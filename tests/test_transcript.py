@@ -1,0 +1,129 @@
+"""CPU: the Keccak/EVM transcript of the host mirror (snark-verifier_amd/host/transcript.hpp)
+vs the oracle restatement (oracle/transcript.py) of
+snark-verifier/src/system/halo2/transcript/evm.rs:175-268,373-398, and both vs the
+committed fixture tests/golden/evm_transcript.json."""
+import ctypes
+import hashlib
+import json
+import os
+import random
+
+import pytest
+
+import bn254 as O
+import transcript as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "evm_transcript.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def H():
+    from hostfmt import load_host_lib
+
+    L = load_host_lib()
+    L.hd_keccak256.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+    L.hd_keccak256.restype = None
+    L.hd_evm_transcript_script.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                           ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    return L
+
+
+def run_cpp(H, script, proof):
+    out = ctypes.create_string_buffer(1 << 16)
+    n = ctypes.c_size_t(0)
+    rc = H.hd_evm_transcript_script(script, len(script), proof, len(proof), out, len(out), ctypes.byref(n))
+    return rc, out.raw[:n.value]
+
+
+def test_oracle_keccak_is_pinned(golden):
+    # the permutation + sponge reproduce hashlib's SHA3-256 (same permutation, 0x06 padding) ...
+    rng = random.Random(1)
+    for n in [0, 1, 31, 32, 64, 135, 136, 137, 271, 272, 273, 1000]:
+        m = bytes(rng.randrange(256) for _ in range(n))
+        assert T.sha3_256(m) == hashlib.sha3_256(m).digest()
+    # ... and the public Keccak-256 (0x01 padding, the EVM's) known answers
+    assert T.keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+    assert T.keccak256(b"abc").hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+    for v in golden["keccak256"]:
+        assert T.keccak256(bytes.fromhex(v["msg"])).hex() == v["digest"]
+
+
+def test_cpp_keccak_matches(H, golden):
+    o = ctypes.create_string_buffer(32)
+    for v in golden["keccak256"]:
+        m = bytes.fromhex(v["msg"])
+        H.hd_keccak256(m, len(m), o)
+        assert o.raw.hex() == v["digest"]
+    rng = random.Random(2)
+    for n in list(range(0, 140)) + [271, 272, 273, 407, 408, 409, 5000]:
+        m = bytes(rng.randrange(256) for _ in range(n))
+        H.hd_keccak256(m, n, o)
+        assert o.raw == T.keccak256(m), n
+
+
+def test_golden_cases_cpp_and_oracle(H, golden):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_t", os.path.join(ROOT, "tests", "golden", "gen_golden_transcript.py"))
+    for case in golden["cases"]:
+        script, proof = bytes.fromhex(case["script"]), bytes.fromhex(case["proof"])
+        rc, out = run_cpp(H, script, proof)
+        assert rc == case["rc"], case["name"]
+        assert out.hex() == case["out"], case["name"]
+    assert spec is not None  # the generator that made the fixture is committed next to it
+
+
+def _random_script(rng, pts):
+    ops, proof = [], b""
+    for _ in range(rng.randrange(1, 25)):
+        op = rng.choice([1, 1, 2, 3, 4, 5, 6, 7, 8])
+        if op in (2, 6):
+            ops.append((op, rng.choice([0, 1, O.R - 1, rng.randrange(O.R)])))
+        elif op in (3, 7):
+            ops.append((op, rng.choice(pts)))
+        else:
+            ops.append((op, None))
+    # a proof stream with mostly valid items, sometimes a bad one
+    for op, _ in ops:
+        if op == 4:
+            v = rng.randrange(O.R) if rng.random() < 0.9 else O.R + rng.randrange(1000)
+            proof += v.to_bytes(32, "big")
+        elif op == 5:
+            p = rng.choice(pts[:-1])
+            if rng.random() < 0.1:
+                p = (p[0], (p[1] + 1) % O.P)
+            proof += p[0].to_bytes(32, "big") + p[1].to_bytes(32, "big")
+    if rng.random() < 0.1:
+        proof = proof[:max(0, len(proof) - 7)]
+    return ops, proof
+
+
+def test_random_scripts_cpp_vs_oracle(H):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_t", os.path.join(ROOT, "tests", "golden", "gen_golden_transcript.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    rng = random.Random(77)
+    pts = [O.g1_mul(O.G1_GEN, rng.randrange(1, O.R)) for _ in range(5)] + [None]
+    for _ in range(150):
+        ops, proof = _random_script(rng, pts)
+        exp_rc, exp_out = gen.run_script(ops, proof)
+        rc, out = run_cpp(H, gen.pack_script(ops), proof)
+        assert (rc, out) == (exp_rc, exp_out)
+
+
+def test_challenge_is_hash_mod_r():
+    """u256_to_fe: the challenge is the big-endian hash reduced mod r (hash space is ~5.3 r)."""
+    t = T.EvmTranscript()
+    t.common_scalar(5)
+    c = t.squeeze_challenge()
+    h = T.keccak256((5).to_bytes(32, "big") + b"\x01")  # 32 buffered bytes -> 0x01 suffix (evm.rs:188-193)
+    assert c == int.from_bytes(h, "big") % O.R
+    assert bytes(t.buf) == h
