@@ -141,3 +141,218 @@ class EvmTranscript:
 
     def finalize(self):
         return bytes(self.stream)
+
+
+# ---------------------------------------------------------------------------
+# Poseidon (second half of N2).
+#
+# The reference's hasher (snark-verifier/src/util/hash/poseidon.rs:115-202) runs
+# the OPTIMISED schedule (pre-added constants, sparse MDS) whose tables come from
+# the un-vendored crate `poseidon` (privacy-scaling-explorations/poseidon,
+# `Spec::new(r_f, r_p)`, poseidon.rs:7,128).  That schedule is an exact
+# rewriting of the plain Poseidon permutation (Poseidon paper, appendix B), so
+# this oracle states the PLAIN permutation:
+#   * round constants and the Cauchy MDS from the Grain LFSR exactly as the
+#     Poseidon reference (`generate_parameters_grain.sage 1 0 254 t R_F R_P`),
+#   * full rounds R_F/2, partial rounds R_P, full rounds R_F/2,
+# and the sponge framing of poseidon.rs:150-166 / :44-75 (inputs added to words
+# 1.., a 1 added to the word after the last input, an extra permutation when
+# the input length is a multiple of RATE, output = word 1).
+#
+# Pinned: the generator + permutation reproduce the public t = 3 parameters
+# (first round constant, MDS[0][0]) and the public known answer
+# poseidon([1, 2]) = 0x115cc0f5...189a of that instance (tests/test_transcript.py).
+# UNPINNED (crate internals that cannot be read here): `State::default()` =
+# [2^64, 0, ...] and the 32-byte compressed G1 encoding of halo2curves 0.6.0
+# (bit 7 of byte 31 = identity, bit 6 = parity of y) used by read/write_ec_point.
+def _grain_bits(n, t, r_f, r_p):
+    bits = []
+
+    def put(v, w):
+        for i in range(w - 1, -1, -1):
+            bits.append((v >> i) & 1)
+
+    put(1, 2)    # prime field
+    put(0, 4)    # S-box x^alpha
+    put(n, 12)
+    put(t, 12)
+    put(r_f, 10)
+    put(r_p, 10)
+    bits.extend([1] * 30)
+    st = bits
+
+    def raw():
+        nonlocal st
+        nb = st[62] ^ st[51] ^ st[38] ^ st[23] ^ st[13] ^ st[0]
+        st = st[1:] + [nb]
+        return nb
+
+    for _ in range(160):
+        raw()
+    while True:
+        b1, b2 = raw(), raw()
+        if b1:
+            yield b2
+
+
+_SPEC_CACHE = {}
+
+
+def poseidon_spec(t, r_f, r_p, n_bits=254, modulus=None):
+    """(round constants [(R_F+R_P)*t], MDS t x t) for the prime field `modulus` (default Fr)."""
+    modulus = modulus or O.R
+    key = (t, r_f, r_p, n_bits, modulus)
+    if key in _SPEC_CACHE:
+        return _SPEC_CACHE[key]
+    g = _grain_bits(n_bits, t, r_f, r_p)
+
+    def nbits():
+        v = 0
+        for _ in range(n_bits):
+            v = (v << 1) | next(g)
+        return v
+
+    rc = []
+    while len(rc) < (r_f + r_p) * t:
+        v = nbits()
+        if v < modulus:          # rejection sampling for round constants
+            rc.append(v)
+    while True:                   # MDS: no rejection, reduce mod p; resample until distinct
+        rl = [nbits() % modulus for _ in range(2 * t)]
+        if len(set(rl)) != 2 * t:
+            continue
+        xs, ys = rl[:t], rl[t:]
+        if any((x + y) % modulus == 0 for x in xs for y in ys):
+            continue
+        mds = [[pow((xs[i] + ys[j]) % modulus, -1, modulus) for j in range(t)] for i in range(t)]
+        break
+    _SPEC_CACHE[key] = (rc, mds)
+    return rc, mds
+
+
+def poseidon_permute(state, r_f, r_p, modulus=None):
+    modulus = modulus or O.R
+    t = len(state)
+    rc, mds = poseidon_spec(t, r_f, r_p, modulus=modulus)
+    k = 0
+    for rnd in range(r_f + r_p):
+        state = [(s + rc[k + i]) % modulus for i, s in enumerate(state)]
+        k += t
+        if rnd < r_f // 2 or rnd >= r_f // 2 + r_p:
+            state = [pow(s, 5, modulus) for s in state]
+        else:
+            state[0] = pow(state[0], 5, modulus)
+        state = [sum(mds[i][j] * state[j] for j in range(t)) % modulus for i in range(t)]
+    return state
+
+
+class Poseidon:
+    """poseidon.rs:115-202 (sponge framing) over the plain permutation."""
+
+    def __init__(self, t=5, rate=4, r_f=8, r_p=60):
+        self.t, self.rate, self.r_f, self.r_p = t, rate, r_f, r_p
+        self.state = [1 << 64] + [0] * (t - 1)   # poseidon::State::default() (crate; unpinned)
+        self.buf = []
+
+    def update(self, elements):                   # poseidon.rs:145-147
+        self.buf.extend(elements)
+
+    def squeeze(self):                            # poseidon.rs:151-164
+        buf, self.buf = self.buf, []
+        exact = len(buf) % self.rate == 0
+        for i in range(0, len(buf), self.rate):
+            self._permutation(buf[i:i + self.rate])
+        if exact:
+            self._permutation([])
+        return self.state[1]
+
+    def _permutation(self, inputs):               # poseidon.rs:44-75 + :166-201
+        assert len(inputs) < self.t
+        for i, x in enumerate(inputs):
+            self.state[1 + i] = (self.state[1 + i] + x) % O.R
+        if 1 + len(inputs) < self.t:   # `.skip(1 + inputs.len())` is empty for a full-rate chunk (poseidon.rs:61-74)
+            self.state[1 + len(inputs)] = (self.state[1 + len(inputs)] + 1) % O.R
+        self.state = poseidon_permute(self.state, self.r_f, self.r_p)
+
+
+def g1_compress(pt):
+    """halo2curves 0.6.0 bn256 `G1Affine::to_bytes` as recalled (UNPINNED): x LE,
+    bit 6 of byte 31 = y odd, bit 7 = identity (then x = 0)."""
+    if pt is None:
+        b = bytearray(32)
+        b[31] |= 0x80
+        return bytes(b)
+    b = bytearray(pt[0].to_bytes(32, "little"))
+    b[31] |= (pt[1] & 1) << 6
+    return bytes(b)
+
+
+def g1_decompress(b):
+    """`G1Affine::from_bytes`; None result = invalid encoding (raises)."""
+    b = bytearray(b)
+    is_inf, ysign = b[31] >> 7, (b[31] >> 6) & 1
+    b[31] &= 0x3F
+    x = int.from_bytes(b, "little")
+    if x >= O.P:
+        raise TranscriptError("Invalid elliptic curve point encoding in proof")
+    if x == 0 and is_inf:
+        return None
+    y2 = (x * x * x + 3) % O.P
+    y = pow(y2, (O.P + 1) // 4, O.P)
+    if y * y % O.P != y2:
+        raise TranscriptError("Invalid elliptic curve point encoding in proof")
+    if (y & 1) != ysign:
+        y = O.P - y
+    return (x, y)
+
+
+class PoseidonTranscript:
+    """system/halo2/transcript/halo2.rs:170-321 on the native loader
+    (T=5, RATE=4, R_F=8, R_P=60 are the reference's example parameters,
+    examples/evm-verifier-with-accumulator.rs:36-39)."""
+
+    def __init__(self, stream=b"", t=5, rate=4, r_f=8, r_p=60):
+        self.stream = bytearray(stream)
+        self.pos = 0
+        self.buf = Poseidon(t, rate, r_f, r_p)
+
+    def squeeze_challenge(self):                  # halo2.rs:211-213
+        return self.buf.squeeze()
+
+    def common_scalar(self, s):                   # halo2.rs:215-218
+        self.buf.update([s])
+
+    def common_ec_point(self, pt):                # halo2.rs:220-237: x, y through fe_to_fe (mod r)
+        if pt is None:
+            raise TranscriptError("Invalid elliptic curve point encoding in proof")
+        self.buf.update([pt[0] % O.R, pt[1] % O.R])
+
+    def _read(self, n):
+        if self.pos + n > len(self.stream):
+            raise TranscriptError("failed to fill whole buffer")
+        b = bytes(self.stream[self.pos:self.pos + n])
+        self.pos += n
+        return b
+
+    def read_scalar(self):                        # halo2.rs:247-260
+        v = int.from_bytes(self._read(32), "little")
+        if v >= O.R:
+            raise TranscriptError("Invalid scalar encoding in proof")
+        self.common_scalar(v)
+        return v
+
+    def read_ec_point(self):                      # halo2.rs:262-275
+        pt = g1_decompress(self._read(32))
+        self.common_ec_point(pt)                  # the identity decodes but cannot be absorbed
+        return pt
+
+    def write_scalar(self, s):                    # halo2.rs:300-309
+        self.common_scalar(s)
+        self.stream += s.to_bytes(32, "little")
+
+    def write_ec_point(self, pt):                 # halo2.rs:311-320
+        self.common_ec_point(pt)
+        self.stream += g1_compress(pt)
+
+    def finalize(self):
+        return bytes(self.stream)

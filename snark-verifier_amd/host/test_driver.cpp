@@ -284,10 +284,12 @@ void hd_keccak256(const uint8_t* data, size_t len, uint8_t* out32) { keccak::kec
 //   6 write_scalar [32]                       7 write_ec_point [64]
 //   8 finalize -> out += len(u32) || stream
 // Returns 0, or 1000 + index of the operation that returned Error::Transcript.
-int hd_evm_transcript_script(const uint8_t* script, size_t script_len, const uint8_t* proof, size_t proof_len,
-                             uint8_t* out, size_t out_cap, size_t* out_len) {
+int hd_transcript_script(int kind, const uint8_t* script, size_t script_len, const uint8_t* proof, size_t proof_len,
+                         uint8_t* out, size_t out_cap, size_t* out_len) {
   return guarded([&] {
-    EvmTranscript t(std::vector<uint8_t>(proof, proof + proof_len));
+    EvmTranscript te(kind == 0 ? std::vector<uint8_t>(proof, proof + proof_len) : std::vector<uint8_t>());
+    PoseidonTranscript tp(kind == 1 ? std::vector<uint8_t>(proof, proof + proof_len) : std::vector<uint8_t>());
+    Transcript& t = kind == 0 ? static_cast<Transcript&>(te) : static_cast<Transcript&>(tp);
     std::vector<uint8_t> o;
     size_t i = 0;
     int opi = 0;
@@ -347,7 +349,7 @@ int hd_evm_transcript_script(const uint8_t* script, size_t script_len, const uin
           break;
         }
         case 8: {
-          auto st = t.stream();
+          auto st = kind == 0 ? te.stream() : tp.stream();
           uint32_t n = (uint32_t)st.size();
           uint8_t nb[4];
           memcpy(nb, &n, 4);
@@ -368,11 +370,18 @@ int hd_evm_transcript_script(const uint8_t* script, size_t script_len, const uin
   });
 }
 
+int hd_evm_transcript_script(const uint8_t* script, size_t script_len, const uint8_t* proof, size_t proof_len,
+                             uint8_t* out, size_t out_cap, size_t* out_len) {
+  return hd_transcript_script(0, script, script_len, proof, proof_len, out, out_cap, out_len);
+}
+
 // KzgAs over the REAL transcript, prover then verifier (accumulation.rs:148-197
 // then :114-137 + :41-63): the prover absorbs the instances, writes the blind
 // pair (zk) and squeezes r; the verifier re-derives r from the proof bytes.
 // out: proof_len(u32) || proof || prover_acc(128) || verifier_acc(128) || r(32)
-int hd_kzg_as_evm_roundtrip(const uint8_t* accs128, uint32_t m, const uint8_t* pk128_or_null,
+}  // extern "C" (a template cannot have C linkage)
+template <class TR>
+static int kzg_as_roundtrip(const uint8_t* accs128, uint32_t m, const uint8_t* pk128_or_null,
                             const uint8_t* blind_scalar32, uint8_t* out, size_t out_cap, size_t* out_len) {
   return guarded([&] {
     std::vector<KzgAccumulator> instances;
@@ -384,11 +393,11 @@ int hd_kzg_as_evm_roundtrip(const uint8_t* accs128, uint32_t m, const uint8_t* p
       pk.g = std::make_pair(G1Affine::from_bytes(pk128_or_null), G1Affine::from_bytes(pk128_or_null + 64));
       if (!Fr::from_bytes(blind_scalar32, &bs)) return -3;
     }
-    EvmTranscript wt;
+    TR wt;
     auto acc_p = KzgAs<Gwc19>::create_proof(pk, instances, wt, bs);
     if (!acc_p.ok()) return -4;
     std::vector<uint8_t> proof = wt.finalize();
-    EvmTranscript rt(proof);
+    TR rt(proof);
     KzgAsVerifyingKey vk{pk128_or_null != nullptr};
     auto pr = KzgAs<Gwc19>::read_proof(vk, instances, rt);
     if (!pr.ok()) return -5;
@@ -411,6 +420,40 @@ int hd_kzg_as_evm_roundtrip(const uint8_t* accs128, uint32_t m, const uint8_t* p
     if (o.size() > out_cap) return -6;
     memcpy(out, o.data(), o.size());
     *out_len = o.size();
+    return 0;
+  });
+}
+
+extern "C" {
+int hd_kzg_as_evm_roundtrip(const uint8_t* accs128, uint32_t m, const uint8_t* pk128_or_null,
+                            const uint8_t* blind_scalar32, uint8_t* out, size_t out_cap, size_t* out_len) {
+  return kzg_as_roundtrip<EvmTranscript>(accs128, m, pk128_or_null, blind_scalar32, out, out_cap, out_len);
+}
+int hd_kzg_as_poseidon_roundtrip(const uint8_t* accs128, uint32_t m, const uint8_t* pk128_or_null,
+                                 const uint8_t* blind_scalar32, uint8_t* out, size_t out_cap, size_t* out_len) {
+  return kzg_as_roundtrip<PoseidonTranscript>(accs128, m, pk128_or_null, blind_scalar32, out, out_cap, out_len);
+}
+// round constants and MDS of the Poseidon instance (t, r_f, r_p): rc || mds, 32-byte LE each
+int hd_poseidon_spec(int t, int r_f, int r_p, uint8_t* out, size_t out_cap, size_t* out_len) {
+  return guarded([&] {
+    const PoseidonSpec& sp = poseidon_spec(t, r_f, r_p);
+    size_t n = sp.rc.size() + sp.mds.size();
+    if (32 * n > out_cap) return -6;
+    size_t k = 0;
+    for (auto& x : sp.rc) x.to_bytes(out + 32 * k++);
+    for (auto& x : sp.mds) x.to_bytes(out + 32 * k++);
+    *out_len = 32 * n;
+    return 0;
+  });
+}
+// plain permutation of `t` words (in/out 32-byte LE each)
+int hd_poseidon_permute(int t, int r_f, int r_p, uint8_t* state) {
+  return guarded([&] {
+    std::vector<Fr> st((size_t)t);
+    for (int i = 0; i < t; ++i)
+      if (!Fr::from_bytes(state + 32 * i, &st[i])) return -3;
+    poseidon_permute(st, poseidon_spec(t, r_f, r_p));
+    for (int i = 0; i < t; ++i) st[i].to_bytes(state + 32 * i);
     return 0;
   });
 }

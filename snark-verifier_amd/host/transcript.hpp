@@ -17,6 +17,8 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <map>
+#include <tuple>
 #include <vector>
 
 #include "pcs.hpp"
@@ -255,6 +257,320 @@ class EvmTranscript : public Transcript {
   std::vector<uint8_t> stream_;
   size_t pos_ = 0;
   std::vector<uint8_t> buf_;
+};
+
+// ============================================================================
+// Poseidon transcript (second half).
+//
+//   reference                                                    here
+//   `Poseidon<F, L, T, RATE>`  util/hash/poseidon.rs:115-202       Poseidon
+//   `PoseidonTranscript<C, NativeLoader, S, T, RATE, R_F, R_P>`    PoseidonTranscript
+//      system/halo2/transcript/halo2.rs:170-321
+//   `poseidon::Spec::new(r_f, r_p)` (un-vendored crate)            poseidon_spec(): Grain LFSR
+//
+// The reference runs the optimised round schedule whose tables the external
+// crate derives; it is an exact rewriting of the plain permutation, which is
+// what is implemented here (constants / Cauchy MDS from the Grain LFSR of the
+// Poseidon reference; pinned by the public t = 3 instance, see oracle/transcript.py).
+// Unpinned crate internals: `State::default()` = [2^64, 0, ..] and the
+// compressed G1 encoding of halo2curves 0.6.0 (bit 7 = identity, bit 6 = y odd).
+struct PoseidonSpec {
+  int t = 0, r_f = 0, r_p = 0;
+  std::vector<Fr> rc;   // (r_f + r_p) * t
+  std::vector<Fr> mds;  // t * t, row-major
+};
+
+namespace grain {
+struct Lfsr {
+  bool st[80];
+  Lfsr(int n_bits, int t, int r_f, int r_p) {
+    int k = 0;
+    auto put = [&](unsigned v, int w) {
+      for (int i = w - 1; i >= 0; --i) st[k++] = (v >> i) & 1u;
+    };
+    put(1, 2);   // prime field
+    put(0, 4);   // S-box x^alpha
+    put((unsigned)n_bits, 12);
+    put((unsigned)t, 12);
+    put((unsigned)r_f, 10);
+    put((unsigned)r_p, 10);
+    for (int i = 0; i < 30; ++i) st[k++] = true;
+    for (int i = 0; i < 160; ++i) raw();
+  }
+  bool raw() {
+    bool nb = st[62] ^ st[51] ^ st[38] ^ st[23] ^ st[13] ^ st[0];
+    memmove(st, st + 1, 79 * sizeof(bool));
+    st[79] = nb;
+    return nb;
+  }
+  bool next_bit() {  // self-shrinking output
+    for (;;) {
+      bool b1 = raw(), b2 = raw();
+      if (b1) return b2;
+    }
+  }
+  // n_bits bits, most significant first, as 4 x u64 little-endian words
+  void next_int(int n_bits, uint64_t w[4]) {
+    w[0] = w[1] = w[2] = w[3] = 0;
+    for (int i = n_bits - 1; i >= 0; --i)
+      if (next_bit()) w[i >> 6] |= 1ull << (i & 63);
+  }
+};
+inline bool lt_r(const uint64_t w[4]) {
+  for (int i = 3; i >= 0; --i)
+    if (w[i] != Fr::MOD[i]) return w[i] < Fr::MOD[i];
+  return false;
+}
+inline Fr fr_from_words_mod_r(uint64_t w[4]) {  // w < 2^254 < 2r
+  if (!lt_r(w)) {
+    unsigned __int128 br = 0;
+    for (int i = 0; i < 4; ++i) {
+      unsigned __int128 x = (unsigned __int128)w[i] - Fr::MOD[i] - (uint64_t)br;
+      w[i] = (uint64_t)x;
+      br = (x >> 64) & 1;
+    }
+  }
+  uint8_t le[32];
+  memcpy(le, w, 32);
+  Fr out;
+  Fr::from_bytes(le, &out);
+  return out;
+}
+}  // namespace grain
+
+inline const PoseidonSpec& poseidon_spec(int t, int r_f, int r_p) {
+  static std::map<std::tuple<int, int, int>, PoseidonSpec> cache;
+  auto key = std::make_tuple(t, r_f, r_p);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  const int n_bits = 254;  // Fr::NUM_BITS
+  PoseidonSpec sp;
+  sp.t = t;
+  sp.r_f = r_f;
+  sp.r_p = r_p;
+  grain::Lfsr g(n_bits, t, r_f, r_p);
+  while ((int)sp.rc.size() < (r_f + r_p) * t) {  // round constants: rejection sampling
+    uint64_t w[4];
+    g.next_int(n_bits, w);
+    if (grain::lt_r(w)) sp.rc.push_back(grain::fr_from_words_mod_r(w));
+  }
+  for (;;) {  // Cauchy MDS 1 / (x_i + y_j): no rejection, resample until all 2t values are distinct
+    std::vector<Fr> v;
+    for (int i = 0; i < 2 * t; ++i) {
+      uint64_t w[4];
+      g.next_int(n_bits, w);
+      v.push_back(grain::fr_from_words_mod_r(w));
+    }
+    bool ok = true;
+    for (int i = 0; i < 2 * t && ok; ++i)
+      for (int j = i + 1; j < 2 * t && ok; ++j)
+        if (v[i] == v[j]) ok = false;
+    if (!ok) continue;
+    sp.mds.assign((size_t)t * t, Fr::zero());
+    for (int i = 0; i < t && ok; ++i)
+      for (int j = 0; j < t && ok; ++j) {
+        Fr inv;
+        if (!(v[i] + v[t + j]).invert(&inv)) ok = false;
+        sp.mds[(size_t)i * t + j] = inv;
+      }
+    if (ok) break;
+  }
+  return cache.emplace(key, std::move(sp)).first->second;
+}
+
+inline void poseidon_permute(std::vector<Fr>& state, const PoseidonSpec& sp) {
+  const int t = sp.t;
+  size_t k = 0;
+  std::vector<Fr> next((size_t)t);
+  for (int rnd = 0; rnd < sp.r_f + sp.r_p; ++rnd) {
+    for (int i = 0; i < t; ++i) state[i] = state[i] + sp.rc[k++];
+    const bool full = rnd < sp.r_f / 2 || rnd >= sp.r_f / 2 + sp.r_p;
+    for (int i = 0; i < (full ? t : 1); ++i) {
+      Fr x2 = state[i].square();
+      state[i] = x2.square() * state[i];
+    }
+    for (int i = 0; i < t; ++i) {
+      Fr acc = Fr::zero();
+      for (int j = 0; j < t; ++j) acc = acc + sp.mds[(size_t)i * t + j] * state[j];
+      next[i] = acc;
+    }
+    state = next;
+  }
+}
+
+// poseidon.rs:115-202: sponge framing over the plain permutation
+class Poseidon {
+ public:
+  Poseidon(int t, int rate, int r_f, int r_p) : t_(t), rate_(rate), spec_(&poseidon_spec(t, r_f, r_p)) {
+    state_.assign((size_t)t, Fr::zero());
+    // poseidon::State::default(): first word 2^64
+    Fr two32 = Fr::from_u64(1ull << 32);
+    state_[0] = two32 * two32;
+  }
+  void update(const std::vector<Fr>& elements) { buf_.insert(buf_.end(), elements.begin(), elements.end()); }  // :145-147
+  Fr squeeze() {                                                                                               // :151-164
+    std::vector<Fr> buf;
+    buf.swap(buf_);
+    const bool exact = buf.size() % (size_t)rate_ == 0;
+    for (size_t i = 0; i < buf.size(); i += (size_t)rate_) {
+      size_t n = std::min((size_t)rate_, buf.size() - i);
+      permutation(buf.data() + i, n);
+    }
+    if (exact) permutation(nullptr, 0);
+    return state_[1];
+  }
+
+ private:
+  void permutation(const Fr* inputs, size_t n) {  // :44-75 (absorb + the 1 after the last input), :166-201
+    for (size_t i = 0; i < n; ++i) state_[1 + i] = state_[1 + i] + inputs[i];
+    if (1 + n < (size_t)t_) state_[1 + n] = state_[1 + n] + Fr::one();  // nothing after a full-rate chunk (:61-74)
+    poseidon_permute(state_, *spec_);
+  }
+  int t_, rate_;
+  const PoseidonSpec* spec_;
+  std::vector<Fr> state_;
+  std::vector<Fr> buf_;
+};
+
+namespace fq_host {
+inline void sub_mod(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {  // a, b < p
+  unsigned __int128 br = 0;
+  uint64_t t[4];
+  for (int i = 0; i < 4; ++i) {
+    unsigned __int128 x = (unsigned __int128)a[i] - b[i] - (uint64_t)br;
+    t[i] = (uint64_t)x;
+    br = (x >> 64) & 1;
+  }
+  if (br) {
+    unsigned __int128 c = 0;
+    for (int i = 0; i < 4; ++i) {
+      c += (unsigned __int128)t[i] + P[i];
+      t[i] = (uint64_t)c;
+      c >>= 64;
+    }
+  }
+  memcpy(r, t, 32);
+}
+// sqrt for p = 3 (mod 4): a^((p+1)/4); false if a is not a square
+inline bool sqrt_mod(uint64_t r[4], const uint64_t a[4]) {
+  // (p + 1) / 4
+  static const uint64_t E[4] = {0x4f082305b61f3f52ull, 0x65e05aa45a1c72a3ull, 0x6e14116da0605617ull,
+                                0x0c19139cb84c680aull};
+  uint64_t acc[4] = {1, 0, 0, 0};
+  for (int i = 255; i >= 0; --i) {
+    mul_mod(acc, acc, acc);
+    if ((E[i >> 6] >> (i & 63)) & 1) mul_mod(acc, acc, a);
+  }
+  uint64_t chk[4];
+  mul_mod(chk, acc, acc);
+  if (memcmp(chk, a, 32) != 0) return false;
+  memcpy(r, acc, 32);
+  return true;
+}
+}  // namespace fq_host
+
+// halo2curves 0.6.0 bn256 `G1Affine::{to_bytes, from_bytes}` (compressed, 32 bytes) as recalled
+inline void g1_compress(const G1Affine& p, uint8_t out[32]) {
+  if (p.is_identity()) {
+    memset(out, 0, 32);
+    out[31] |= 0x80;
+    return;
+  }
+  memcpy(out, p.b, 32);
+  out[31] |= (uint8_t)((p.b[32] & 1) << 6);
+}
+// returns false for an invalid encoding; the identity decodes to 64 zero bytes
+inline bool g1_decompress(const uint8_t in[32], G1Affine* out) {
+  uint8_t xb[32];
+  memcpy(xb, in, 32);
+  const int is_inf = xb[31] >> 7, ysign = (xb[31] >> 6) & 1;
+  xb[31] &= 0x3F;
+  uint64_t x[4];
+  memcpy(x, xb, 32);
+  if (!fq_host::lt_p(x)) return false;
+  if ((x[0] | x[1] | x[2] | x[3]) == 0 && is_inf) {
+    *out = G1Affine::identity();
+    return true;
+  }
+  uint64_t x2[4], x3[4], three[4] = {3, 0, 0, 0}, y2[4], y[4];
+  fq_host::mul_mod(x2, x, x);
+  fq_host::mul_mod(x3, x2, x);
+  fq_host::add_mod(y2, x3, three);
+  if (!fq_host::sqrt_mod(y, y2)) return false;
+  if ((int)(y[0] & 1) != ysign) {
+    uint64_t zero[4] = {0, 0, 0, 0};
+    fq_host::sub_mod(y, zero, y);
+  }
+  memcpy(out->b, x, 32);
+  memcpy(out->b + 32, y, 32);
+  return true;
+}
+
+class PoseidonTranscript : public Transcript {
+ public:
+  // T = 5, RATE = 4, R_F = 8, R_P = 60: examples/evm-verifier-with-accumulator.rs:36-39
+  explicit PoseidonTranscript(std::vector<uint8_t> proof = {}, int t = 5, int rate = 4, int r_f = 8, int r_p = 60)
+      : stream_(std::move(proof)), buf_(t, rate, r_f, r_p) {}
+
+  Fr squeeze_challenge() override { return buf_.squeeze(); }  // halo2.rs:211-213
+  Error common_scalar(const Fr& s) override {                 // halo2.rs:215-218
+    buf_.update({s});
+    return Error{};
+  }
+  // halo2.rs:220-237: x and y go through `fe_to_fe` (Fq -> integer -> mod r)
+  Error common_ec_point(const G1Affine& p) override {
+    if (p.is_identity()) return Error{Error::Transcript, "Invalid elliptic curve point encoding in proof"};
+    uint64_t w[4];
+    memcpy(w, p.b, 32);
+    Fr x = grain::fr_from_words_mod_r(w);  // p < 2r: one conditional subtraction
+    memcpy(w, p.b + 32, 32);
+    Fr y = grain::fr_from_words_mod_r(w);
+    buf_.update({x, y});
+    return Error{};
+  }
+  Result<Fr> read_scalar() override {  // halo2.rs:247-260: 32 bytes little-endian canonical
+    if (pos_ + 32 > stream_.size()) return Result<Fr>::Err(Error{Error::Transcript, "failed to fill whole buffer"});
+    Fr s;
+    bool ok = Fr::from_bytes(stream_.data() + pos_, &s);
+    pos_ += 32;
+    if (!ok) return Result<Fr>::Err(Error{Error::Transcript, "Invalid scalar encoding in proof"});
+    common_scalar(s);
+    return Result<Fr>::Ok(s);
+  }
+  Result<G1Affine> read_ec_point() override {  // halo2.rs:262-275: compressed `C::from_bytes`
+    if (pos_ + 32 > stream_.size())
+      return Result<G1Affine>::Err(Error{Error::Transcript, "failed to fill whole buffer"});
+    G1Affine p;
+    bool ok = g1_decompress(stream_.data() + pos_, &p);
+    pos_ += 32;
+    if (!ok) return Result<G1Affine>::Err(Error{Error::Transcript, "Invalid elliptic curve point encoding in proof"});
+    Error e = common_ec_point(p);  // the identity decodes but has no coordinates to absorb
+    if (!e.ok()) return Result<G1Affine>::Err(e);
+    return Result<G1Affine>::Ok(p);
+  }
+  Error write_scalar(const Fr& s) override {  // halo2.rs:300-309
+    common_scalar(s);
+    uint8_t le[32];
+    s.to_bytes(le);
+    stream_.insert(stream_.end(), le, le + 32);
+    return Error{};
+  }
+  Error write_ec_point(const G1Affine& p) override {  // halo2.rs:311-320
+    Error e = common_ec_point(p);
+    if (!e.ok()) return e;
+    uint8_t c[32];
+    g1_compress(p, c);
+    stream_.insert(stream_.end(), c, c + 32);
+    return Error{};
+  }
+  const std::vector<uint8_t>& stream() const { return stream_; }
+  std::vector<uint8_t> finalize() { return std::move(stream_); }
+  size_t remaining() const { return stream_.size() - pos_; }
+
+ private:
+  std::vector<uint8_t> stream_;
+  size_t pos_ = 0;
+  Poseidon buf_;
 };
 
 }  // namespace snarkv_host

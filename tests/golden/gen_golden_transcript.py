@@ -14,9 +14,10 @@ import bn254 as O
 import transcript as T
 
 
-def run_script(ops, proof):
-    """ops: list of (op, payload).  Returns (rc, out_bytes) exactly as the C++ driver does."""
-    t = T.EvmTranscript(proof)
+def run_script(ops, proof, kind=0):
+    """ops: list of (op, payload).  Returns (rc, out_bytes) exactly as the C++ driver does.
+    kind 0 = EvmTranscript, 1 = PoseidonTranscript."""
+    t = T.EvmTranscript(proof) if kind == 0 else T.PoseidonTranscript(proof)
     out = b""
     for i, (op, payload) in enumerate(ops):
         try:
@@ -83,7 +84,39 @@ def main():
     add("write_identity_is_error", [(7, None)])
     # a long absorb crossing several 136-byte rate blocks
     add("long_absorb", [(3, pts[i % 6]) for i in range(9)] + [(2, sc[i % 9]) for i in range(7)] + [(1, None), (1, None)])
-    vectors = {"keccak256": [{"msg": m.hex(), "digest": T.keccak256(m).hex()}
+    # ---- Poseidon transcript (T=5, RATE=4, R_F=8, R_P=60)
+    pcases = []
+
+    def padd(name, ops, proof=b""):
+        rc, out = run_script(ops, proof, kind=1)
+        pcases.append({"name": name, "script": pack_script(ops).hex(), "proof": proof.hex(), "rc": rc, "out": out.hex()})
+
+    padd("squeeze_empty", [(1, None)])
+    padd("squeeze_twice", [(1, None), (1, None)])
+    padd("one_scalar", [(2, sc[0]), (1, None)])
+    padd("exactly_rate_elements", [(2, sc[i]) for i in range(4)] + [(1, None)])
+    padd("rate_plus_one", [(2, sc[i]) for i in range(5)] + [(1, None), (1, None)])
+    padd("points_and_scalars", [(3, pts[0]), (2, sc[1]), (1, None), (3, pts[1]), (3, pts[2]), (1, None)])
+    pproof = T.g1_compress(pts[2]) + sc[3].to_bytes(32, "little") + T.g1_compress(pts[3]) + sc[8].to_bytes(32, "little")
+    padd("read_points_and_scalars", [(5, None), (4, None), (1, None), (5, None), (4, None), (1, None)], pproof)
+    padd("write_then_finalize", [(7, pts[4]), (6, sc[4]), (1, None), (7, pts[5]), (6, sc[6]), (1, None), (8, None)])
+    padd("read_scalar_non_canonical", [(4, None)], O.R.to_bytes(32, "little"))
+    bad_x = next(x for x in range(2, 100) if pow((x ** 3 + 3) % O.P, (O.P - 1) // 2, O.P) != 1)
+    padd("read_point_x_not_on_curve", [(5, None)], bad_x.to_bytes(32, "little"))
+    padd("read_point_x_ge_p", [(5, None)], (O.P + 1).to_bytes(32, "little"))
+    padd("read_identity_cannot_be_absorbed", [(5, None)], T.g1_compress(None))
+    padd("read_past_end", [(4, None)], bytes(31))
+    padd("common_identity_is_error", [(3, None)])
+    rc5, mds5 = T.poseidon_spec(5, 8, 60)
+    rc3, mds3 = T.poseidon_spec(3, 8, 57)
+    poseidon = {
+        "t5_rf8_rp60": {"rc_first": hex(rc5[0]), "rc_last": hex(rc5[-1]), "mds00": hex(mds5[0][0]), "mds44": hex(mds5[4][4]),
+                        "permute_0_1_2_3_4": [hex(x) for x in T.poseidon_permute([0, 1, 2, 3, 4], 8, 60)]},
+        # the public instance every Poseidon library ships (circomlib's t = 3): these three are KNOWN ANSWERS
+        "t3_rf8_rp57_public": {"rc_first": hex(rc3[0]), "mds00": hex(mds3[0][0]),
+                               "permute_0_1_2_word0": hex(T.poseidon_permute([0, 1, 2], 8, 57)[0])},
+    }
+    vectors = {"poseidon_cases": pcases, "poseidon": poseidon, "keccak256": [{"msg": m.hex(), "digest": T.keccak256(m).hex()}
                              for m in [b"", b"abc", bytes(135), bytes(136), bytes(137), bytes(range(256)) * 2]]}
     with open(os.path.join(ROOT, "tests", "golden", "evm_transcript.json"), "w") as f:
         json.dump({"cases": cases, **vectors}, f, indent=1)

@@ -12,6 +12,12 @@ def load_host_lib():
     import snark_verifier_amd as sv
 
     sv.load_library()  # brings in torch's HIP runtime first, then libsnarkv_amd.so
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_snarkv_build", os.path.join(ROOT, "snark-verifier_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build_host_driver()  # g++ only; no-op unless a host header is newer than the library
     return ctypes.CDLL(os.path.join(ROOT, "snark-verifier_amd", "libsnarkv_host.so"))
 
 

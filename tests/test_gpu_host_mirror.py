@@ -179,29 +179,31 @@ def test_golden_kzg_layer_fixture(H):
     assert o.raw.hex() == g["limbs"]["accumulator"] and lo.raw.hex() == g["limbs"]["limbs"]
 
 
-def test_kzg_as_over_the_evm_transcript(H):
-    """KzgAs prover -> proof bytes -> verifier with the REAL Keccak transcript
-    (host/transcript.hpp; reference system/halo2/transcript/evm.rs): the
-    challenge r is derived, not supplied; both sides and the oracle must land on
-    the same accumulator, and it must still satisfy the pairing check."""
+@pytest.mark.parametrize("kind", ["evm", "poseidon"])
+def test_kzg_as_over_the_real_transcripts(H, kind):
+    """KzgAs prover -> proof bytes -> verifier with the REAL transcripts
+    (host/transcript.hpp; reference system/halo2/transcript/evm.rs and halo2.rs):
+    the challenge r is derived, not supplied; both sides and the oracle must land
+    on the same accumulator, and it must still satisfy the pairing check."""
     import transcript as T
 
     rng = random.Random(40)
-    H.hd_kzg_as_evm_roundtrip.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p,
-                                          ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
-    for m, zk in ((1, False), (7, False), (7, True), (64, True)):
+    fn = H.hd_kzg_as_evm_roundtrip if kind == "evm" else H.hd_kzg_as_poseidon_roundtrip
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p,
+                   ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    for m, zk in ((1, False), (7, False), (7, True), (64, True) if kind == "evm" else (9, True)):
         accs = _mock_accumulators(rng, m)
         pairs = [(O.g1_from_bytes(a[:64]), O.g1_from_bytes(a[64:])) for a in accs]
         b = rng.randrange(1, O.R)
         pk = g1(O.G1_GEN) + g1(O.g1_mul(O.G1_GEN, SECRET)) if zk else None
         out = _buf(4096)
         n = ctypes.c_size_t(0)
-        assert H.hd_kzg_as_evm_roundtrip(b"".join(accs), m, pk, fr(b), out, len(out), ctypes.byref(n)) == 0
+        assert fn(b"".join(accs), m, pk, fr(b), out, len(out), ctypes.byref(n)) == 0
         raw = out.raw[:n.value]
         plen = int.from_bytes(raw[:4], "little")
         proof, acc_p, acc_v, r_got = raw[4:4 + plen], raw[4 + plen:132 + plen], raw[132 + plen:260 + plen], raw[260 + plen:]
         # oracle: same transcript, same algebra
-        t = T.EvmTranscript()
+        t = T.EvmTranscript() if kind == "evm" else T.PoseidonTranscript()
         for lhs, rhs in pairs:
             t.common_ec_point(lhs)
             t.common_ec_point(rhs)
@@ -212,7 +214,7 @@ def test_kzg_as_over_the_evm_transcript(H):
             t.write_ec_point(blind[1])
         r = t.squeeze_challenge()
         exp = K.kzg_as_verify(pairs, r, blind)
-        assert proof == t.finalize() and len(proof) == (128 if zk else 0)
+        assert proof == t.finalize() and len(proof) == ((128 if kind == "evm" else 64) if zk else 0)
         assert r_got == fr(r)
         assert acc_p == acc_v == g1(exp[0]) + g1(exp[1])
         g2 = O.g2_to_bytes(O.G2_GEN)

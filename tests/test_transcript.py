@@ -127,3 +127,100 @@ def test_challenge_is_hash_mod_r():
     h = T.keccak256((5).to_bytes(32, "big") + b"\x01")  # 32 buffered bytes -> 0x01 suffix (evm.rs:188-193)
     assert c == int.from_bytes(h, "big") % O.R
     assert bytes(t.buf) == h
+
+
+# ---------------------------------------------------------------- Poseidon
+def _setup_poseidon(H):
+    H.hd_transcript_script.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                       ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    H.hd_poseidon_spec.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t,
+                                   ctypes.POINTER(ctypes.c_size_t)]
+    H.hd_poseidon_permute.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+
+
+def run_cpp_kind(H, kind, script, proof):
+    out = ctypes.create_string_buffer(1 << 16)
+    n = ctypes.c_size_t(0)
+    rc = H.hd_transcript_script(kind, script, len(script), proof, len(proof), out, len(out), ctypes.byref(n))
+    return rc, out.raw[:n.value]
+
+
+def test_poseidon_oracle_is_pinned_by_the_public_instance(golden):
+    """Grain LFSR + Cauchy MDS + permutation reproduce the PUBLIC BN254 t=3 instance
+    (the one circomlib & co. ship): first round constant, MDS[0][0] and the known
+    answer poseidon([1, 2]).  These three hex strings are public constants."""
+    rc, mds = T.poseidon_spec(3, 8, 57)
+    assert rc[0] == 0x0EE9A592BA9A9518D05986D656F40C2114C4993C11BB29938D21D47304CD8E6E
+    assert mds[0][0] == 0x109B7F411BA0E4C9B2B70CAF5C36A7B194BE7C11AD24378BFEDB68592BA8118B
+    assert T.poseidon_permute([0, 1, 2], 8, 57)[0] == 0x115CC0F5E7D690413DF64C6B9662E9CF2A3617F2743245519E19607A4417189A
+    g = golden["poseidon"]["t3_rf8_rp57_public"]
+    assert int(g["rc_first"], 16) == rc[0] and int(g["mds00"], 16) == mds[0][0]
+
+
+def test_cpp_poseidon_spec_and_permutation(H, golden):
+    _setup_poseidon(H)
+    for (t, rf, rp) in ((3, 8, 57), (5, 8, 60)):
+        rc, mds = T.poseidon_spec(t, rf, rp)
+        out = ctypes.create_string_buffer(32 * ((rf + rp) * t + t * t))
+        n = ctypes.c_size_t(0)
+        assert H.hd_poseidon_spec(t, rf, rp, out, len(out), ctypes.byref(n)) == 0
+        vals = [int.from_bytes(out.raw[32 * i:32 * i + 32], "little") for i in range(n.value // 32)]
+        assert vals[:len(rc)] == rc
+        assert vals[len(rc):] == [mds[i][j] for i in range(t) for j in range(t)]
+        rng = random.Random(t)
+        for _ in range(3):
+            st = [rng.randrange(O.R) for _ in range(t)]
+            buf = ctypes.create_string_buffer(b"".join(O.fe_to_bytes(x) for x in st), 32 * t)
+            assert H.hd_poseidon_permute(t, rf, rp, buf) == 0
+            got = [int.from_bytes(buf.raw[32 * i:32 * i + 32], "little") for i in range(t)]
+            assert got == T.poseidon_permute(st, rf, rp)
+    g = golden["poseidon"]["t5_rf8_rp60"]
+    buf = ctypes.create_string_buffer(b"".join(O.fe_to_bytes(x) for x in range(5)), 160)
+    assert H.hd_poseidon_permute(5, 8, 60, buf) == 0
+    assert [hex(int.from_bytes(buf.raw[32 * i:32 * i + 32], "little")) for i in range(5)] == g["permute_0_1_2_3_4"]
+
+
+def test_poseidon_transcript_golden_cpp(H, golden):
+    _setup_poseidon(H)
+    for case in golden["poseidon_cases"]:
+        rc, out = run_cpp_kind(H, 1, bytes.fromhex(case["script"]), bytes.fromhex(case["proof"]))
+        assert rc == case["rc"], case["name"]
+        assert out.hex() == case["out"], case["name"]
+
+
+def test_poseidon_transcript_random_scripts_cpp_vs_oracle(H):
+    import importlib.util
+
+    _setup_poseidon(H)
+    spec = importlib.util.spec_from_file_location("gen_t", os.path.join(ROOT, "tests", "golden", "gen_golden_transcript.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    rng = random.Random(78)
+    pts = [O.g1_mul(O.G1_GEN, rng.randrange(1, O.R)) for _ in range(5)] + [None]
+    for _ in range(40):
+        ops = []
+        proof = b""
+        for _ in range(rng.randrange(1, 14)):
+            op = rng.choice([1, 2, 3, 4, 5, 6, 7, 8])
+            if op in (2, 6):
+                ops.append((op, rng.choice([0, 1, O.R - 1, rng.randrange(O.R)])))
+            elif op in (3, 7):
+                ops.append((op, rng.choice(pts)))
+            else:
+                ops.append((op, None))
+            if op == 4:
+                v = rng.randrange(O.R) if rng.random() < 0.9 else O.R + 5
+                proof += v.to_bytes(32, "little")
+            elif op == 5:
+                proof += T.g1_compress(rng.choice(pts)) if rng.random() < 0.9 else (7).to_bytes(32, "little")
+        exp = gen.run_script(ops, proof, kind=1)
+        assert run_cpp_kind(H, 1, gen.pack_script(ops), proof) == exp
+
+
+def test_compressed_point_roundtrip():
+    rng = random.Random(5)
+    for _ in range(20):
+        p = O.g1_mul(O.G1_GEN, rng.randrange(1, O.R))
+        assert T.g1_decompress(T.g1_compress(p)) == p
+        assert T.g1_decompress(T.g1_compress(O.g1_neg(p))) == O.g1_neg(p)
+    assert T.g1_decompress(T.g1_compress(None)) is None
