@@ -40,6 +40,14 @@ class Msm {
     return constant;
   }
 
+  // msm.rs:63-66: (self without its constant, the constant)
+  std::pair<Msm, std::optional<Scalar>> split() const {
+    Msm m = *this;
+    std::optional<Scalar> c = m.constant;
+    m.constant.reset();
+    return {m, c};
+  }
+
   // The (scalar, base) pairs `evaluate` hands to the loader: constant * gen
   // first, then the terms in insertion order (msm.rs:81-98).
   std::vector<std::pair<Scalar, Point>> pairs(const std::optional<Point>& gen) const {

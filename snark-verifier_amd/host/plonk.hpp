@@ -1,0 +1,490 @@
+// PLONK succinct verifier, front half: turns
+// (protocol, instances, proof bytes) into the (scalar, base) lists the GPU
+// path consumes, then decides.
+//
+//   reference                                                    here
+//   `Rotation`, `Domain`      util/arithmetic.rs:98-160           Rotation (int32_t), Domain
+//   `Query`, `Expression`,    verifier/plonk/protocol.rs:274-420  PQuery, Expression
+//   `CommonPolynomial`
+//   `PlonkProtocol`           protocol.rs:17-111                  PlonkProtocol
+//   `CommonPolynomialEvaluation` protocol.rs:196-272              CommonPolyEval
+//   `PlonkProof::{read, evaluations, commitments, queries}`       PlonkProof<MOS>
+//                             verifier/plonk/proof.rs:52-349
+//   `PlonkSuccinctVerifier`, `PlonkVerifier`  verifier/plonk.rs:58-147   same names
+//
+// Host Fr algebra only; every `evaluate` goes through GpuNativeLoader.  The
+// batch form `verify_batch` collects the two MSMs of EVERY proof into one
+// segmented launch (the data-parallel axis of SURVEY.md 8e).
+#pragma once
+#include <map>
+#include <memory>
+#include <set>
+
+#include "pcs.hpp"
+
+namespace snarkv_host {
+
+// util/arithmetic.rs:123-160
+struct Domain {
+  size_t k = 0, n = 0;
+  Fr n_inv, gen, gen_inv;
+  static Domain make(size_t k, const Fr& gen) {
+    Domain d;
+    d.k = k;
+    d.n = (size_t)1 << k;
+    if (!Fr::from_u64((uint64_t)d.n).invert(&d.n_inv)) throw Panic("Domain: n not invertible");
+    d.gen = gen;
+    if (!gen.invert(&d.gen_inv)) throw Panic("Domain: generator not invertible (reference: unwrap, arithmetic.rs:141)");
+    return d;
+  }
+  static Fr pow_u64(const Fr& b, uint64_t e) {
+    uint64_t w[4] = {e, 0, 0, 0};
+    return b.pow(w);
+  }
+  Fr rotate_scalar(const Fr& scalar, int32_t rotation) const {  // arithmetic.rs:153-159
+    if (rotation == 0) return scalar;
+    if (rotation > 0) return scalar * pow_u64(gen, (uint64_t)rotation);
+    return scalar * pow_u64(gen_inv, (uint64_t)(-(int64_t)rotation));
+  }
+};
+
+// protocol.rs:287-301 (`Query { poly, rotation }`; named PQuery: pcs.hpp already has the PCS `Query`)
+struct PQuery {
+  size_t poly = 0;
+  int32_t rotation = 0;
+  bool operator<(const PQuery& o) const { return poly != o.poly ? poly < o.poly : rotation < o.rotation; }
+  bool operator==(const PQuery& o) const { return poly == o.poly && rotation == o.rotation; }
+};
+
+// protocol.rs:303-315
+struct Expression {
+  enum Kind { Constant, Identity, Lagrange, Polynomial, Challenge, Negated, Sum, Product, Scaled, DistributePowers };
+  Kind kind = Constant;
+  Fr scalar;             // Constant, Scaled
+  int32_t lagrange = 0;  // Lagrange(i)
+  PQuery query;          // Polynomial
+  size_t index = 0;      // Challenge
+  std::vector<std::shared_ptr<Expression>> ch;  // operands; DistributePowers: exprs..., then the scalar expression
+};
+using ExprPtr = std::shared_ptr<Expression>;
+
+struct InvalidProtocol : std::runtime_error {  // Error::InvalidProtocol(String), carried as an exception inside evaluate
+  using std::runtime_error::runtime_error;
+};
+
+// `Expression::evaluate` (protocol.rs:317-373), same operand order
+template <class T, class V>
+T expr_evaluate(const Expression& e, V& v) {
+  auto ev = [&](const ExprPtr& x) { return expr_evaluate<T, V>(*x, v); };
+  switch (e.kind) {
+    case Expression::Constant: return v.constant(e.scalar);
+    case Expression::Identity: return v.common_identity();
+    case Expression::Lagrange: return v.common_lagrange(e.lagrange);
+    case Expression::Polynomial: return v.poly(e.query);
+    case Expression::Challenge: return v.challenge(e.index);
+    case Expression::Negated: return v.negated(ev(e.ch[0]));
+    case Expression::Sum: {
+      T a = ev(e.ch[0]);
+      T b = ev(e.ch[1]);
+      return v.sum(a, b);
+    }
+    case Expression::Product: {
+      T a = ev(e.ch[0]);
+      T b = ev(e.ch[1]);
+      return v.product(a, b);
+    }
+    case Expression::Scaled: return v.scaled(ev(e.ch[0]), e.scalar);
+    case Expression::DistributePowers: {
+      if (e.ch.size() < 2) throw Panic("DistributePowers of no expressions (reference: assert!, protocol.rs:359)");
+      size_t n = e.ch.size() - 1;
+      if (n == 1) return ev(e.ch[0]);
+      T acc = ev(e.ch[0]);
+      T scalar = ev(e.ch[n]);
+      for (size_t i = 1; i < n; ++i) acc = v.sum(v.product(acc, scalar), ev(e.ch[i]));
+      return acc;
+    }
+  }
+  throw Panic("bad expression kind");
+}
+
+// `used_langrange` / `used_query` (protocol.rs:391-420)
+inline void expr_collect(const Expression& e, std::set<int32_t>* lagranges, std::set<PQuery>* queries) {
+  if (e.kind == Expression::Lagrange && lagranges) lagranges->insert(e.lagrange);
+  if (e.kind == Expression::Polynomial && queries) queries->insert(e.query);
+  for (auto& c : e.ch) expr_collect(*c, lagranges, queries);
+}
+
+struct QuotientPolynomial {  // protocol.rs:274-285
+  size_t chunk_degree = 1, num_chunk = 0;
+  ExprPtr numerator;
+};
+struct InstanceCommittingKey {  // protocol.rs:541-547
+  std::vector<G1Affine> bases;
+  std::optional<G1Affine> constant;
+};
+enum class Linearization { None, WithoutConstant, MinusVanishingTimesQuotient };  // protocol.rs:528-539
+
+// protocol.rs:17-72
+struct PlonkProtocol {
+  Domain domain;
+  std::vector<G1Affine> preprocessed;
+  std::vector<size_t> num_instance, num_witness, num_challenge;
+  std::vector<PQuery> evaluations, queries;
+  QuotientPolynomial quotient;
+  std::optional<Fr> transcript_initial_state;
+  std::optional<InstanceCommittingKey> instance_committing_key;
+  Linearization linearization = Linearization::None;
+  std::vector<std::vector<std::pair<size_t, size_t>>> accumulator_indices;
+
+  // protocol.rs:80-111
+  std::set<int32_t> langranges() const {
+    std::set<int32_t> out;
+    std::set<PQuery> used;
+    expr_collect(*quotient.numerator, &out, &used);
+    if (!instance_committing_key) {
+      const size_t off = preprocessed.size();
+      int32_t mn = 0, mx = 0;
+      for (auto& q : used) {  // BTreeSet order
+        if (q.poly < off || q.poly >= off + num_instance.size()) continue;
+        if (q.rotation < mn) mn = q.rotation;
+        else if (q.rotation > mx) mx = q.rotation;
+      }
+      size_t max_len = 0;
+      for (size_t n : num_instance) max_len = std::max(max_len, n);
+      for (int32_t i = -mx; i < (int32_t)max_len + (mn < 0 ? -mn : mn); ++i) out.insert(i);
+    }
+    return out;
+  }
+};
+
+// protocol.rs:196-272; the fractions are evaluated on construction (the native
+// loader's batch inversion, plonk.rs:66-70, here one inversion per denominator)
+struct CommonPolyEval {
+  Fr zn, zn_minus_one, zn_minus_one_inv, identity;
+  std::map<int32_t, Fr> lagrange;
+  CommonPolyEval(const Domain& domain, const std::set<int32_t>& langranges, const Fr& z) {
+    zn = Domain::pow_u64(z, (uint64_t)domain.n);
+    zn_minus_one = zn - Fr::one();
+    zn_minus_one.invert(&zn_minus_one_inv);  // zero stays zero, as `batch_invert` leaves it (loader.rs:255-262)
+    Fr numer = zn_minus_one * domain.n_inv;
+    identity = z;
+    for (int32_t i : langranges) {
+      Fr omega = domain.rotate_scalar(Fr::one(), i);
+      Fr den = z - omega, inv;
+      den.invert(&inv);
+      lagrange[i] = numer * omega * inv;
+    }
+  }
+  const Fr& get_lagrange(int32_t i) const {
+    auto it = lagrange.find(i);
+    if (it == lagrange.end()) throw Panic("missing Lagrange evaluation (reference: unwrap, protocol.rs:253)");
+    return it->second;
+  }
+};
+
+template <class MOS>
+struct MosProof;
+template <>
+struct MosProof<Gwc19> {
+  using type = Gwc19Proof;
+};
+template <>
+struct MosProof<Bdfg21> {
+  using type = Bdfg21Proof;
+};
+
+// proof.rs:18-45
+template <class MOS>
+struct PlonkProof {
+  using PcsProof = typename MosProof<MOS>::type;
+  std::optional<std::vector<G1Affine>> committed_instances;
+  std::vector<G1Affine> witnesses;
+  std::vector<Fr> challenges;
+  std::vector<G1Affine> quotients;
+  Fr z;
+  std::vector<Fr> evaluations;
+  PcsProof pcs;
+  std::vector<KzgAccumulator> old_accumulators;
+
+  // proof.rs:170-181
+  static std::vector<Query<std::monostate>> empty_queries(const PlonkProtocol& pr) {
+    std::vector<Query<std::monostate>> out;
+    for (auto& q : pr.queries) out.push_back(Query<std::monostate>{q.poly, pr.domain.rotate_scalar(Fr::one(), q.rotation), {}});
+    return out;
+  }
+
+  static Result<PcsProof> read_pcs(const PlonkProtocol& pr, Transcript& t);
+
+  // proof.rs:52-168; AE = LimbsEncoding<LIMBS, BITS>
+  template <class AE = LimbsEncoding<4, 68>>
+  static Result<PlonkProof> read(const KzgSuccinctVerifyingKey&, const PlonkProtocol& pr,
+                                 const std::vector<std::vector<Fr>>& instances, Transcript& t) {
+    using R = Result<PlonkProof>;
+    if (pr.transcript_initial_state) {
+      Error e = t.common_scalar(*pr.transcript_initial_state);
+      if (!e.ok()) return R::Err(e);
+    }
+    if (pr.num_instance.size() != instances.size()) return R::Err(Error{Error::InvalidInstances, ""});
+    for (size_t i = 0; i < instances.size(); ++i)
+      if (pr.num_instance[i] != instances[i].size()) return R::Err(Error{Error::InvalidInstances, ""});
+    PlonkProof p;
+    if (pr.instance_committing_key) {
+      const auto& ick = *pr.instance_committing_key;
+      std::vector<std::vector<std::pair<Fr, G1Affine>>> jobs;
+      for (auto& inst : instances) {
+        std::vector<MsmT> terms;
+        for (size_t i = 0; i < inst.size() && i < ick.bases.size(); ++i) terms.push_back(MsmT::base(&ick.bases[i]) * inst[i]);
+        if (ick.constant) terms.push_back(MsmT::base(&*ick.constant));
+        jobs.push_back(MsmT::sum(terms).pairs(std::nullopt));
+      }
+      // one segmented launch for all instance columns (each is an `evaluate(None)`, proof.rs:91-98)
+      p.committed_instances = jobs.empty() ? std::vector<G1Affine>() : L::multi_scalar_multiplication_batch(jobs);
+      for (auto& c : *p.committed_instances) {
+        Error e = t.common_ec_point(c);
+        if (!e.ok()) return R::Err(e);
+      }
+    } else {
+      for (auto& inst : instances)
+        for (auto& x : inst) {
+          Error e = t.common_scalar(x);
+          if (!e.ok()) return R::Err(e);
+        }
+    }
+    const size_t phases = std::min(pr.num_witness.size(), pr.num_challenge.size());  // `zip`
+    for (size_t ph = 0; ph < phases; ++ph) {
+      auto w = t.read_n_ec_points(pr.num_witness[ph]);
+      if (!w.ok()) return R::Err(w.err);
+      p.witnesses.insert(p.witnesses.end(), w.value->begin(), w.value->end());
+      auto c = t.squeeze_n_challenges(pr.num_challenge[ph]);
+      p.challenges.insert(p.challenges.end(), c.begin(), c.end());
+    }
+    auto q = t.read_n_ec_points(pr.quotient.num_chunk);
+    if (!q.ok()) return R::Err(q.err);
+    p.quotients = *q.value;
+    p.z = t.squeeze_challenge();
+    for (size_t i = 0; i < pr.evaluations.size(); ++i) {
+      auto s = t.read_scalar();
+      if (!s.ok()) return R::Err(s.err);
+      p.evaluations.push_back(*s.value);
+    }
+    auto pcs = read_pcs(pr, t);
+    if (!pcs.ok()) return R::Err(pcs.err);
+    p.pcs = *pcs.value;
+    for (auto& idx : pr.accumulator_indices) {
+      std::vector<const Fr*> limbs;
+      for (auto& ij : idx) {
+        if (ij.first >= instances.size() || ij.second >= instances[ij.first].size())
+          throw Panic("accumulator index out of range (reference: slice index panic, proof.rs:150)");
+        limbs.push_back(&instances[ij.first][ij.second]);
+      }
+      auto acc = AE::from_repr(limbs);
+      if (!acc.ok()) return R::Err(acc.err);
+      p.old_accumulators.push_back(*acc.value);
+    }
+    return R::Ok(std::move(p));
+  }
+
+  // proof.rs:299-349
+  std::map<PQuery, Fr> evaluations_map(const PlonkProtocol& pr, const std::vector<std::vector<Fr>>& instances,
+                                       const CommonPolyEval& cpe) const {
+    std::map<PQuery, Fr> evals;
+    if (!pr.instance_committing_key) {
+      const size_t off = pr.preprocessed.size();
+      std::set<PQuery> used;
+      expr_collect(*pr.quotient.numerator, nullptr, &used);
+      for (auto& q : used) {
+        if (q.poly < off || q.poly >= off + pr.num_instance.size()) continue;
+        const auto& inst = instances[q.poly - off];
+        Fr acc = Fr::zero();  // sum_products(instances, l_{i - r})
+        for (size_t i = 0; i < inst.size(); ++i) acc = acc + inst[i] * cpe.get_lagrange((int32_t)i - q.rotation);
+        evals[q] = acc;
+      }
+    }
+    for (size_t i = 0; i < pr.evaluations.size() && i < evaluations.size(); ++i) evals[pr.evaluations[i]] = evaluations[i];
+    return evals;
+  }
+
+  // proof.rs:199-297.  `storage` keeps the points the returned Msm borrow alive.
+  std::vector<MsmT> commitments(const PlonkProtocol& pr, const CommonPolyEval& cpe, std::map<PQuery, Fr>& evals) const {
+    std::vector<MsmT> cm;
+    for (auto& p : pr.preprocessed) cm.push_back(MsmT::base(&p));
+    if (committed_instances) {
+      for (auto& p : *committed_instances) cm.push_back(MsmT::base(&p));
+    } else {
+      for (size_t i = 0; i < pr.num_instance.size(); ++i) cm.push_back(MsmT());
+    }
+    for (auto& p : witnesses) cm.push_back(MsmT::base(&p));
+
+    struct V {
+      const PlonkProof& self;
+      const CommonPolyEval& cpe;
+      std::map<PQuery, Fr>& evals;
+      std::vector<MsmT>& cm;
+      MsmT constant(const Fr& s) { return MsmT::from_constant(s); }
+      MsmT common_identity() { return MsmT::from_constant(cpe.identity); }
+      MsmT common_lagrange(int32_t i) { return MsmT::from_constant(cpe.get_lagrange(i)); }
+      MsmT poly(const PQuery& q) {
+        auto it = evals.find(q);
+        if (it != evals.end()) return MsmT::from_constant(it->second);
+        if (q.rotation == 0 && q.poly < cm.size()) return cm[q.poly];
+        throw InvalidProtocol("Missing query");
+      }
+      MsmT challenge(size_t i) {
+        if (i >= self.challenges.size()) throw InvalidProtocol("Missing challenge");
+        return MsmT::from_constant(self.challenges[i]);
+      }
+      MsmT negated(const MsmT& a) { return -a; }
+      MsmT sum(const MsmT& a, const MsmT& b) { return a + b; }
+      MsmT product(const MsmT& a, const MsmT& b) {
+        if (a.size() == 0) return b * *a.try_into_constant();
+        if (b.size() == 0) return a * *b.try_into_constant();
+        throw InvalidProtocol("Invalid linearization");
+      }
+      MsmT scaled(const MsmT& a, const Fr& s) { return a * s; }
+    } v{*this, cpe, evals, cm};
+    MsmT numerator = expr_evaluate<MsmT>(*pr.quotient.numerator, v);
+
+    PQuery quotient_query{pr.preprocessed.size() + pr.num_instance.size() + witnesses.size(), 0};
+    auto coeffs = Domain::pow_u64(cpe.zn, (uint64_t)pr.quotient.chunk_degree).powers(quotients.size());
+    std::vector<MsmT> chunks;
+    for (size_t i = 0; i < quotients.size(); ++i) chunks.push_back(MsmT::base(&quotients[i]) * coeffs[i]);
+    MsmT quotient = MsmT::sum(chunks);
+    switch (pr.linearization) {
+      case Linearization::WithoutConstant: {
+        PQuery lq{quotient_query.poly + 1, 0};
+        auto [msm, constant] = numerator.split();
+        cm.push_back(quotient);
+        cm.push_back(msm);
+        auto it = evals.find(lq);
+        if (it == evals.end()) throw Panic("missing linearization evaluation (reference: unwrap, proof.rs:267)");
+        evals[quotient_query] = ((constant ? *constant : Fr::zero()) + it->second) * cpe.zn_minus_one_inv;
+        break;
+      }
+      case Linearization::MinusVanishingTimesQuotient: {
+        auto [msm, constant] = (numerator - quotient * cpe.zn_minus_one).split();
+        cm.push_back(msm);
+        evals[quotient_query] = constant ? *constant : Fr::zero();
+        break;
+      }
+      case Linearization::None: {
+        cm.push_back(quotient);
+        if (numerator.size() != 0) throw InvalidProtocol("Invalid linearization");
+        evals[quotient_query] = *numerator.try_into_constant() * cpe.zn_minus_one_inv;
+        break;
+      }
+    }
+    return cm;
+  }
+
+  // proof.rs:183-197
+  std::vector<Query<Fr>> queries(const PlonkProtocol& pr, const std::map<PQuery, Fr>& evals) const {
+    std::vector<Query<Fr>> out;
+    auto eq = empty_queries(pr);
+    for (size_t i = 0; i < eq.size(); ++i) {
+      auto it = evals.find(pr.queries[i]);
+      if (it == evals.end()) throw Panic("query without evaluation (reference: unwrap, proof.rs:193)");
+      out.push_back(Query<Fr>{eq[i].poly, eq[i].shift, it->second});
+    }
+    return out;
+  }
+};
+
+template <>
+inline Result<Gwc19Proof> PlonkProof<Gwc19>::read_pcs(const PlonkProtocol& pr, Transcript& t) {
+  return gwc19::read(empty_queries(pr), t);
+}
+template <>
+inline Result<Bdfg21Proof> PlonkProof<Bdfg21>::read_pcs(const PlonkProtocol&, Transcript& t) {
+  return Bdfg21Proof::read(t);
+}
+
+namespace plonk_detail {
+inline std::pair<MsmT, MsmT> pcs_msms(const std::vector<MsmT>& cm, const Fr& z, const std::vector<Query<Fr>>& q,
+                                      const Gwc19Proof& p) {
+  return gwc19::msms(cm, z, q, p);
+}
+inline std::pair<MsmT, MsmT> pcs_msms(const std::vector<MsmT>& cm, const Fr& z, const std::vector<Query<Fr>>& q,
+                                      const Bdfg21Proof& p) {
+  return bdfg21::msms(cm, z, q, p);
+}
+}  // namespace plonk_detail
+
+// verifier/plonk.rs:32-92
+template <class MOS>
+struct PlonkSuccinctVerifier {
+  using Proof = PlonkProof<MOS>;
+  using Pairs = std::vector<std::pair<Fr, G1Affine>>;
+
+  static Result<Proof> read_proof(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
+                                  const std::vector<std::vector<Fr>>& instances, Transcript& t) {
+    return Proof::read(svk, pr, instances, t);
+  }
+
+  // the host part of `verify`: the (lhs, rhs) pair lists of the PCS accumulator
+  static Result<std::pair<Pairs, Pairs>> msm_pairs(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
+                                                   const std::vector<std::vector<Fr>>& instances, const Proof& proof) {
+    using R = Result<std::pair<Pairs, Pairs>>;
+    try {
+      CommonPolyEval cpe(pr.domain, pr.langranges(), proof.z);
+      auto evals = proof.evaluations_map(pr, instances, cpe);
+      auto cm = proof.commitments(pr, cpe, evals);
+      auto queries = proof.queries(pr, evals);
+      auto [lhs, rhs] = plonk_detail::pcs_msms(cm, proof.z, queries, proof.pcs);
+      return R::Ok({lhs.pairs(svk.g), rhs.pairs(svk.g)});
+    } catch (const InvalidProtocol& e) {
+      return R::Err(Error{Error::InvalidProtocol, e.what()});
+    }
+  }
+
+  // plonk.rs:58-92: [new accumulator] ++ old accumulators
+  static Result<std::vector<KzgAccumulator>> verify(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
+                                                    const std::vector<std::vector<Fr>>& instances, const Proof& proof) {
+    using R = Result<std::vector<KzgAccumulator>>;
+    auto prs = msm_pairs(svk, pr, instances, proof);
+    if (!prs.ok()) return R::Err(prs.err);
+    auto pts = L::multi_scalar_multiplication_batch({prs.value->first, prs.value->second});
+    std::vector<KzgAccumulator> out{KzgAccumulator{pts[0], pts[1]}};
+    out.insert(out.end(), proof.old_accumulators.begin(), proof.old_accumulators.end());
+    return R::Ok(out);
+  }
+
+  // Many proofs (possibly of different protocols): all 2 x N MSMs in ONE segmented launch.
+  static Result<std::vector<std::vector<KzgAccumulator>>> verify_batch(
+      const KzgSuccinctVerifyingKey& svk, const std::vector<const PlonkProtocol*>& protocols,
+      const std::vector<std::vector<std::vector<Fr>>>& instances, const std::vector<Proof>& proofs) {
+    using R = Result<std::vector<std::vector<KzgAccumulator>>>;
+    std::vector<Pairs> jobs;
+    for (size_t i = 0; i < proofs.size(); ++i) {
+      auto prs = msm_pairs(svk, *protocols[i], instances[i], proofs[i]);
+      if (!prs.ok()) return R::Err(prs.err);
+      jobs.push_back(std::move(prs.value->first));
+      jobs.push_back(std::move(prs.value->second));
+    }
+    auto pts = jobs.empty() ? std::vector<G1Affine>() : L::multi_scalar_multiplication_batch(jobs);
+    std::vector<std::vector<KzgAccumulator>> out;
+    for (size_t i = 0; i < proofs.size(); ++i) {
+      std::vector<KzgAccumulator> a{KzgAccumulator{pts[2 * i], pts[2 * i + 1]}};
+      a.insert(a.end(), proofs[i].old_accumulators.begin(), proofs[i].old_accumulators.end());
+      out.push_back(std::move(a));
+    }
+    return R::Ok(out);
+  }
+};
+
+// verifier/plonk.rs:94-147: succinct verify, then `decide_all`
+template <class MOS>
+struct PlonkVerifier {
+  using Proof = PlonkProof<MOS>;
+  static Result<Proof> read_proof(const KzgDecidingKey& vk, const PlonkProtocol& pr,
+                                  const std::vector<std::vector<Fr>>& instances, Transcript& t) {
+    return Proof::read(vk.svk, pr, instances, t);
+  }
+  static Error verify(const KzgDecidingKey& vk, const PlonkProtocol& pr, const std::vector<std::vector<Fr>>& instances,
+                      const Proof& proof) {
+    auto accs = PlonkSuccinctVerifier<MOS>::verify(vk.svk, pr, instances, proof);
+    if (!accs.ok()) return accs.err;
+    return KzgAs<MOS>::decide_all(vk, *accs.value);
+  }
+};
+
+}  // namespace snarkv_host

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "pcs.hpp"
+#include "plonk.hpp"
 #include "transcript.hpp"
 
 using namespace snarkv_host;
@@ -90,6 +91,130 @@ std::vector<Query<Fr>> read_queries(Reader& rd) {
     q.push_back(Query<Fr>{poly, shift, ev});
   }
   return q;
+}
+
+// ---- PLONK protocol / instances wire format of the tests (tests/plonk_synth.py)
+struct PReader {
+  const uint8_t* p;
+  const uint8_t* end;
+  void need(size_t n) {
+    if ((size_t)(end - p) < n) throw Panic("truncated protocol bytes");
+  }
+  uint8_t u8() {
+    need(1);
+    return *p++;
+  }
+  uint32_t u32() {
+    need(4);
+    uint32_t v;
+    memcpy(&v, p, 4);
+    p += 4;
+    return v;
+  }
+  int32_t i32() {
+    need(4);
+    int32_t v;
+    memcpy(&v, p, 4);
+    p += 4;
+    return v;
+  }
+  Fr fr() {
+    need(32);
+    Fr x;
+    if (!Fr::from_bytes(p, &x)) throw Panic("non-canonical Fr in protocol bytes");
+    p += 32;
+    return x;
+  }
+  G1Affine g1() {
+    need(64);
+    G1Affine x = G1Affine::from_bytes(p);
+    p += 64;
+    return x;
+  }
+};
+
+ExprPtr parse_expr(PReader& rd) {
+  auto e = std::make_shared<Expression>();
+  switch (rd.u8()) {
+    case 0: e->kind = Expression::Constant; e->scalar = rd.fr(); break;
+    case 1: e->kind = Expression::Identity; break;
+    case 2: e->kind = Expression::Lagrange; e->lagrange = rd.i32(); break;
+    case 3: e->kind = Expression::Polynomial; e->query.poly = rd.u32(); e->query.rotation = rd.i32(); break;
+    case 4: e->kind = Expression::Challenge; e->index = rd.u32(); break;
+    case 5: e->kind = Expression::Negated; e->ch.push_back(parse_expr(rd)); break;
+    case 6: e->kind = Expression::Sum; e->ch.push_back(parse_expr(rd)); e->ch.push_back(parse_expr(rd)); break;
+    case 7: e->kind = Expression::Product; e->ch.push_back(parse_expr(rd)); e->ch.push_back(parse_expr(rd)); break;
+    case 8: e->kind = Expression::Scaled; e->ch.push_back(parse_expr(rd)); e->scalar = rd.fr(); break;
+    case 9: {
+      e->kind = Expression::DistributePowers;
+      uint32_t n = rd.u32();
+      for (uint32_t i = 0; i < n; ++i) e->ch.push_back(parse_expr(rd));
+      e->ch.push_back(parse_expr(rd));
+      break;
+    }
+    default: throw Panic("bad expression tag");
+  }
+  return e;
+}
+
+PlonkProtocol parse_protocol(const uint8_t* b, size_t len) {
+  PReader rd{b, b + len};
+  PlonkProtocol pr;
+  uint32_t k = rd.u32();
+  pr.domain = Domain::make(k, rd.fr());
+  for (uint32_t n = rd.u32(), i = 0; i < n; ++i) pr.preprocessed.push_back(rd.g1());
+  for (auto* v : {&pr.num_instance, &pr.num_witness, &pr.num_challenge})
+    for (uint32_t n = rd.u32(), i = 0; i < n; ++i) v->push_back(rd.u32());
+  for (auto* v : {&pr.evaluations, &pr.queries})
+    for (uint32_t n = rd.u32(), i = 0; i < n; ++i) {
+      PQuery q;
+      q.poly = rd.u32();
+      q.rotation = rd.i32();
+      v->push_back(q);
+    }
+  pr.quotient.chunk_degree = rd.u32();
+  pr.quotient.num_chunk = rd.u32();
+  pr.quotient.numerator = parse_expr(rd);
+  if (rd.u8()) pr.transcript_initial_state = rd.fr();
+  if (rd.u8()) {
+    InstanceCommittingKey ick;
+    for (uint32_t n = rd.u32(), i = 0; i < n; ++i) ick.bases.push_back(rd.g1());
+    if (rd.u8()) ick.constant = rd.g1();
+    pr.instance_committing_key = ick;
+  }
+  uint8_t lin = rd.u8();
+  pr.linearization = lin == 0 ? Linearization::None : lin == 1 ? Linearization::WithoutConstant : Linearization::MinusVanishingTimesQuotient;
+  for (uint32_t n = rd.u32(), i = 0; i < n; ++i) {
+    std::vector<std::pair<size_t, size_t>> idx;
+    for (uint32_t m = rd.u32(), j = 0; j < m; ++j) {
+      uint32_t a = rd.u32(), c = rd.u32();
+      idx.emplace_back(a, c);
+    }
+    pr.accumulator_indices.push_back(idx);
+  }
+  if (rd.p != rd.end) throw Panic("trailing protocol bytes");
+  return pr;
+}
+
+std::vector<std::vector<Fr>> parse_instances(const uint8_t* b, size_t len) {
+  PReader rd{b, b + len};
+  std::vector<std::vector<Fr>> out;
+  for (uint32_t n = rd.u32(), i = 0; i < n; ++i) {
+    std::vector<Fr> v;
+    for (uint32_t m = rd.u32(), j = 0; j < m; ++j) v.push_back(rd.fr());
+    out.push_back(v);
+  }
+  return out;
+}
+
+int error_code(const Error& e) {
+  switch (e.kind) {
+    case Error::Transcript: return -10;
+    case Error::InvalidInstances: return -11;
+    case Error::InvalidProtocol: return -12;
+    case Error::AssertionFailure: return 0;
+    default: return -13;
+  }
 }
 
 int guarded(const std::function<int()>& f) {
@@ -458,3 +583,77 @@ int hd_poseidon_permute(int t, int r_f, int r_p, uint8_t* state) {
   });
 }
 }
+// `PlonkVerifier::{read_proof, verify}` (verifier/plonk.rs:94-147) on N proofs of ONE protocol.
+//   mos: 0 Gwc19, 1 Bdfg21;  tkind: 0 EvmTranscript, 1 PoseidonTranscript
+//   proofs: N x (u32 len || bytes);  instances: N x packed instances
+//   dk: g1(64) || g2(128) || s_g2(128)
+// Succinct part: ONE segmented MSM launch for all proofs (`verify_batch`); then ONE `decide_all`.
+// accs_out (if non-null): every accumulator (new one first, then the old ones of each proof), 128 B each.
+// Returns 1 accept, 0 reject (decide failed), -10 Transcript, -11 InvalidInstances, -12 InvalidProtocol.
+template <class MOS>
+static int plonk_verify_impl(int tkind, const uint8_t* protocol, size_t plen, const uint8_t* instances, size_t ilen,
+                             const uint8_t* proofs, size_t prlen, uint32_t n, const uint8_t* dk320, uint8_t* accs_out,
+                             size_t accs_cap, uint32_t* n_accs) {
+  return guarded([&] {
+    PlonkProtocol pr = parse_protocol(protocol, plen);
+    KzgDecidingKey dk(G1Affine::from_bytes(dk320), G2Affine::from_bytes(dk320 + 64), G2Affine::from_bytes(dk320 + 192));
+    std::vector<std::vector<std::vector<Fr>>> insts;
+    std::vector<PlonkProof<MOS>> pfs;
+    std::vector<const PlonkProtocol*> prs;
+    const uint8_t* ip = instances;
+    const uint8_t* pp = proofs;
+    for (uint32_t i = 0; i < n; ++i) {
+      // instances: each packed block is self-delimiting (count, then per column count + values)
+      PReader rd{ip, instances + ilen};
+      uint32_t cols = rd.u32();
+      for (uint32_t c = 0; c < cols; ++c) {
+        uint32_t m = rd.u32();
+        rd.need(32 * (size_t)m);
+        rd.p += 32 * (size_t)m;
+      }
+      insts.push_back(parse_instances(ip, (size_t)(rd.p - ip)));
+      ip = rd.p;
+      if ((size_t)(proofs + prlen - pp) < 4) throw Panic("truncated proofs");
+      uint32_t len;
+      memcpy(&len, pp, 4);
+      pp += 4;
+      std::vector<uint8_t> bytes(pp, pp + len);
+      pp += len;
+      Result<PlonkProof<MOS>> pf = Result<PlonkProof<MOS>>::Err(Error{});
+      size_t remaining = 0;
+      if (tkind == 0) {
+        EvmTranscript t(bytes);
+        pf = PlonkVerifier<MOS>::read_proof(dk, pr, insts.back(), t);
+        remaining = t.remaining();
+      } else {
+        PoseidonTranscript t(bytes);
+        pf = PlonkVerifier<MOS>::read_proof(dk, pr, insts.back(), t);
+        remaining = t.remaining();
+      }
+      if (!pf.ok()) return error_code(pf.err);
+      if (remaining != 0) return -14;  // trailing proof bytes (a test-driver check, not a reference rule)
+      pfs.push_back(std::move(*pf.value));
+      prs.push_back(&pr);
+    }
+    auto accs = PlonkSuccinctVerifier<MOS>::verify_batch(dk.svk, prs, insts, pfs);
+    if (!accs.ok()) return error_code(accs.err);
+    std::vector<KzgAccumulator> all;
+    for (auto& v : *accs.value) all.insert(all.end(), v.begin(), v.end());
+    if (n_accs) *n_accs = (uint32_t)all.size();
+    if (accs_out) {
+      if (128 * all.size() > accs_cap) return -6;
+      for (size_t i = 0; i < all.size(); ++i) all[i].to_bytes(accs_out + 128 * i);
+    }
+    return KzgAs<MOS>::decide_all(dk, all).ok() ? 1 : 0;
+  });
+}
+
+extern "C" int hd_plonk_verify(int mos, int tkind, const uint8_t* protocol, size_t plen, const uint8_t* instances,
+                               size_t ilen, const uint8_t* proofs, size_t prlen, uint32_t n, const uint8_t* dk320,
+                               uint8_t* accs_out, size_t accs_cap, uint32_t* n_accs) {
+  return mos == 0 ? plonk_verify_impl<Gwc19>(tkind, protocol, plen, instances, ilen, proofs, prlen, n, dk320, accs_out,
+                                             accs_cap, n_accs)
+                  : plonk_verify_impl<Bdfg21>(tkind, protocol, plen, instances, ilen, proofs, prlen, n, dk320, accs_out,
+                                              accs_cap, n_accs);
+}
+

@@ -1,0 +1,169 @@
+"""Test helper: StandardPlonk-SHAPED protocols (the structure `compile` gives the
+reference's example circuit, snark-verifier/src/system/halo2.rs:100-160,281-304,
+729-744: 5 fixed + 3 permutation commitments, 1 instance column, witnesses in
+phases [3 advice | 0 lookup | 2 perm-z + 1 random], challenges [theta | beta,
+gamma | alpha], quotient in `degree-1` chunks, numerator = DistributePowers of
+gate + permutation constraints) with random contents, for the forger in
+oracle/plonk.py.  Also the byte packing the C++ test driver parses."""
+import struct
+
+import bn254 as O
+import plonk as P
+
+R = O.R
+
+
+def const(v):
+    return ("const", v % R)
+
+
+def poly(p, rot=0):
+    return ("poly", p, rot)
+
+
+def add(*xs):
+    acc = xs[0]
+    for x in xs[1:]:
+        acc = ("sum", acc, x)
+    return acc
+
+
+def mul(*xs):
+    acc = xs[0]
+    for x in xs[1:]:
+        acc = ("prod", acc, x)
+    return acc
+
+
+def neg(x):
+    return ("neg", x)
+
+
+def standard_plonk_protocol(rng, k=6, num_instance=(2,), linearization=None, accumulator_rows=None,
+                            committed_instances=False, initial_state=True):
+    """returns (protocol, preprocessed_dlogs)"""
+    dom = P.Domain(k)
+    pre_dlogs = [rng.randrange(1, R) for _ in range(8)]
+    preprocessed = [O.g1_mul(O.G1_GEN, c) for c in pre_dlogs]
+    n_inst = len(num_instance)
+    I0 = 8                       # first instance poly
+    W = I0 + n_inst              # first witness poly
+    a, b, c, z1, z2, rnd = W, W + 1, W + 2, W + 3, W + 4, W + 5
+    last = -6
+    q_a, q_b, q_c, q_ab, q_k, s1, s2, s3 = range(8)
+    theta, beta, gamma, alpha = 0, 1, 2, 3
+    ch = lambda i: ("challenge", i)
+    l0, llast = ("lagrange", 0), ("lagrange", last)
+    lblind = add(*[("lagrange", i) for i in range(last + 1, 0)])
+    gate = add(mul(poly(q_a), poly(a)), mul(poly(q_b), poly(b)), mul(poly(q_c), poly(c)),
+               mul(poly(q_ab), mul(poly(a), poly(b))), poly(q_k), poly(I0),
+               ("scaled", mul(poly(a, 1), poly(c, -1)), rng.randrange(R)), mul(ch(theta), const(rng.randrange(R))))
+    active = add(const(1), neg(add(llast, lblind)))
+    delta = rng.randrange(2, R)
+    lhs_p = mul(poly(z1, 1), add(poly(a), mul(ch(beta), poly(s1)), ch(gamma)), add(poly(b), mul(ch(beta), poly(s2)), ch(gamma)))
+    rhs_p = mul(poly(z1), add(poly(a), mul(ch(beta), ("identity",)), ch(gamma)),
+                add(poly(b), mul(ch(beta), ("scaled", ("identity",), delta)), ch(gamma)))
+    constraints = [
+        gate,
+        mul(l0, add(const(1), neg(poly(z1)))),
+        mul(llast, add(mul(poly(z2), poly(z2)), neg(poly(z2)))),
+        mul(l0, add(poly(z2), neg(poly(z1, last)))),
+        mul(active, add(lhs_p, neg(rhs_p))),
+        mul(active, add(mul(poly(z2, 1), add(poly(c), mul(ch(beta), poly(s3)), ch(gamma))),
+                        neg(mul(poly(z2), add(poly(c), ch(gamma)))))),
+    ]
+    if n_inst > 1:
+        constraints.append(mul(poly(q_k), add(poly(I0 + 1), neg(poly(I0 + 1, 1)))))
+    numerator = ("dpow", constraints, ch(alpha))
+    evaluations = [(a, 0), (b, 0), (c, 0), (a, 1), (c, -1)] + [(i, 0) for i in range(5)] + [(rnd, 0)] + \
+                  [(s1, 0), (s2, 0), (s3, 0)] + [(z1, 0), (z1, 1), (z1, last), (z2, 0), (z2, 1)]
+    Q = W + 6                    # quotient poly index (proof.rs:243-246)
+    lin_extra = []
+    if linearization == "WithoutConstant":
+        evaluations = evaluations + [(Q + 1, 0)]
+        lin_extra = [(Q + 1, 0)]
+    queries = [(a, 0), (b, 0), (c, 0), (a, 1), (c, -1), (z1, 0), (z1, 1), (z1, last), (z2, 0), (z2, 1)] + \
+              [(i, 0) for i in range(5)] + [(s1, 0), (s2, 0), (s3, 0)] + [(Q, 0)] + lin_extra + [(rnd, 0)]
+    pr = {
+        "domain": dom, "preprocessed": preprocessed, "num_instance": list(num_instance),
+        "num_witness": [3, 0, 3], "num_challenge": [1, 2, 1], "evaluations": evaluations, "queries": queries,
+        "quotient": {"chunk_degree": 1, "num_chunk": 3, "numerator": numerator},
+        "transcript_initial_state": rng.randrange(R) if initial_state else None,
+        "instance_committing_key": None, "linearization": linearization,
+        "accumulator_indices": [[(0, j) for j in rows] for rows in (accumulator_rows or [])],
+    }
+    if committed_instances:
+        bd = [rng.randrange(1, R) for _ in range(max(num_instance) + 1)]
+        pts = [O.g1_mul(O.G1_GEN, c) for c in bd]
+        pr["instance_committing_key"] = {"bases": pts[:-1], "constant": pts[-1]}
+        pr["_known_dlogs"] = dict(zip(pts, bd))   # forger only (toy SRS); not part of the protocol
+        pr["queries"] = [(I0 + t, 0) for t in range(n_inst)] + pr["queries"]
+        pr["evaluations"] = [(I0 + t, 0) for t in range(n_inst)] + pr["evaluations"]
+    return pr, pre_dlogs
+
+
+# ---------------------------------------------------------------- packing for the C++ driver
+def _fr(x):
+    return O.fe_to_bytes(x % R)
+
+
+def _u32(x):
+    return struct.pack("<I", x)
+
+
+def _i32(x):
+    return struct.pack("<i", x)
+
+
+def pack_expr(e):
+    t = e[0]
+    if t == "const":
+        return b"\x00" + _fr(e[1])
+    if t == "identity":
+        return b"\x01"
+    if t == "lagrange":
+        return b"\x02" + _i32(e[1])
+    if t == "poly":
+        return b"\x03" + _u32(e[1]) + _i32(e[2])
+    if t == "challenge":
+        return b"\x04" + _u32(e[1])
+    if t == "neg":
+        return b"\x05" + pack_expr(e[1])
+    if t == "sum":
+        return b"\x06" + pack_expr(e[1]) + pack_expr(e[2])
+    if t == "prod":
+        return b"\x07" + pack_expr(e[1]) + pack_expr(e[2])
+    if t == "scaled":
+        return b"\x08" + pack_expr(e[1]) + _fr(e[2])
+    if t == "dpow":
+        return b"\x09" + _u32(len(e[1])) + b"".join(pack_expr(x) for x in e[1]) + pack_expr(e[2])
+    raise ValueError(t)
+
+
+def pack_protocol(pr):
+    d = pr["domain"]
+    out = _u32(d.k) + _fr(d.gen)
+    out += _u32(len(pr["preprocessed"])) + b"".join(O.g1_to_bytes(p) for p in pr["preprocessed"])
+    for key in ("num_instance", "num_witness", "num_challenge"):
+        out += _u32(len(pr[key])) + b"".join(_u32(x) for x in pr[key])
+    for key in ("evaluations", "queries"):
+        out += _u32(len(pr[key])) + b"".join(_u32(p) + _i32(r) for p, r in pr[key])
+    q = pr["quotient"]
+    out += _u32(q["chunk_degree"]) + _u32(q["num_chunk"]) + pack_expr(q["numerator"])
+    tis = pr.get("transcript_initial_state")
+    out += b"\x01" + _fr(tis) if tis is not None else b"\x00"
+    ick = pr.get("instance_committing_key")
+    if ick is None:
+        out += b"\x00"
+    else:
+        out += b"\x01" + _u32(len(ick["bases"])) + b"".join(O.g1_to_bytes(p) for p in ick["bases"])
+        out += (b"\x01" + O.g1_to_bytes(ick["constant"])) if ick.get("constant") is not None else b"\x00"
+    out += bytes([{None: 0, "WithoutConstant": 1, "MinusVanishingTimesQuotient": 2}[pr.get("linearization")]])
+    out += _u32(len(pr["accumulator_indices"]))
+    for idx in pr["accumulator_indices"]:
+        out += _u32(len(idx)) + b"".join(_u32(i) + _u32(j) for i, j in idx)
+    return out
+
+
+def pack_instances(instances):
+    return _u32(len(instances)) + b"".join(_u32(len(x)) + b"".join(_fr(v) for v in x) for x in instances)
