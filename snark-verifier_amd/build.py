@@ -70,7 +70,7 @@ def build_host_driver():
     if os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) >= newest:
         return HOST_LIB
     cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", HOST_LIB, os.path.join(HOST, "test_driver.cpp"),
-           "-L" + HERE, "-lsnarkv_amd", "-Wl,-rpath,$ORIGIN"]
+           "-L" + HERE, "-lsnarkv_amd", "-pthread", "-Wl,-rpath,$ORIGIN"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)

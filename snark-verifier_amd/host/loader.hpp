@@ -13,8 +13,10 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -69,6 +71,14 @@ struct G2Affine {
   }
 };
 
+// The context-free C-ABI entry points share one process-global device context
+// (`multi_scalar_multiplication` has no `&self`, loader.rs:108): host threads
+// that reach the device through the loader take turns.
+inline std::mutex& device_mutex() {
+  static std::mutex m;
+  return m;
+}
+
 struct GpuNativeLoader {
   using LoadedScalar = Fr;
   using LoadedEcPoint = G1Affine;
@@ -109,6 +119,7 @@ struct GpuNativeLoader {
       memcpy(&p[64 * i], pairs[i].second->b, 64);
     }
     G1Affine out;
+    std::lock_guard<std::mutex> lock(device_mutex());
     int rc = bn254_g1_msm_naive(s.data(), p.data(), pairs.size(), out.b);
     if (rc != SNARKV_OK) throw std::runtime_error(std::string("bn254_g1_msm_naive: ") + snarkv_last_error());
     return out;
@@ -118,19 +129,37 @@ struct GpuNativeLoader {
   // (what makes the GPU worthwhile for the many small MSMs of accumulation).
   static std::vector<G1Affine> multi_scalar_multiplication_batch(
       const std::vector<std::vector<std::pair<Fr, G1Affine>>>& msms) {
-    std::vector<uint8_t> s, p;
     std::vector<uint32_t> offs(1, 0);
     for (auto& m : msms) {
       if (m.empty()) throw Panic("empty MSM in batch (reference: native.rs:69)");
-      for (auto& t : m) {
-        size_t o = s.size();
-        s.resize(o + 32);
-        t.first.to_bytes(&s[o]);
-        p.insert(p.end(), t.second.b, t.second.b + 64);
+      offs.push_back(offs.back() + (uint32_t)m.size());
+    }
+    const size_t total = offs.back();
+    std::vector<uint8_t> s(32 * total), p(64 * total);
+    auto pack = [&](size_t lo, size_t hi) {  // Montgomery -> canonical bytes is one field product per scalar
+      for (size_t k = lo; k < hi; ++k) {
+        size_t o = offs[k];
+        for (auto& t : msms[k]) {
+          t.first.to_bytes(&s[32 * o]);
+          memcpy(&p[64 * o], t.second.b, 64);
+          ++o;
+        }
       }
-      offs.push_back((uint32_t)(s.size() / 32));
+    };
+    unsigned nt = total >= 4096 ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    if (nt <= 1) {
+      pack(0, msms.size());
+    } else {
+      std::vector<std::thread> pool;
+      size_t per = (msms.size() + nt - 1) / nt;
+      for (unsigned t = 0; t < nt; ++t) {
+        size_t lo = std::min(msms.size(), (size_t)t * per), hi = std::min(msms.size(), lo + per);
+        if (lo < hi) pool.emplace_back(pack, lo, hi);
+      }
+      for (auto& th : pool) th.join();
     }
     std::vector<G1Affine> out(msms.size());
+    std::lock_guard<std::mutex> lock(device_mutex());
     int rc = bn254_g1_msm_batched(s.data(), p.data(), offs.data(), msms.size(), out.empty() ? nullptr : out[0].b);
     if (rc != SNARKV_OK) throw std::runtime_error(std::string("bn254_g1_msm_batched: ") + snarkv_last_error());
     return out;

@@ -1,7 +1,9 @@
 // Mirror of `util::msm::Msm` (reference snark-verifier/src/util/msm.rs:20-226):
 // the deferred linear combination  constant * G + sum scalar_i * base_i.
 #pragma once
+#include <cstring>
 #include <optional>
+#include <unordered_map>
 #include <vector>
 
 #include "loader.hpp"
@@ -17,6 +19,21 @@ class Msm {
   std::optional<Scalar> constant;
   std::vector<Scalar> scalars;
   std::vector<const Point*> bases;  // borrowed, as `&'a L::LoadedEcPoint`
+
+ private:
+  static constexpr size_t kIndexThreshold = 48;
+  std::unordered_multimap<uint64_t, size_t> index_;  // first 8 bytes of x -> position (only past the threshold)
+  static uint64_t key_of(const Point& p) {
+    uint64_t k;
+    memcpy(&k, p.b, 8);
+    return k;
+  }
+  void rebuild_index() {
+    index_.clear();
+    for (size_t i = 0; i < bases.size(); ++i) index_.emplace(key_of(*bases[i]), i);
+  }
+
+ public:
 
   Msm() = default;
   // msm.rs:46-51
@@ -74,13 +91,26 @@ class Msm {
     if (constant) *constant *= f;
     for (auto& s : scalars) s *= f;
   }
-  // msm.rs:109-116: equal bases are merged
+  // msm.rs:109-116: equal bases are merged.  The reference scans linearly
+  // (`position`), which is quadratic over the (m+1)-term Msm of KzgAs::verify;
+  // past a few dozen terms the same merge runs through a hash index.
   void push(const Scalar& s, const Point* b) {
-    for (size_t i = 0; i < bases.size(); ++i)
-      if (*bases[i] == *b) {
-        scalars[i] += s;
-        return;
-      }
+    if (bases.size() < kIndexThreshold) {
+      for (size_t i = 0; i < bases.size(); ++i)
+        if (*bases[i] == *b) {
+          scalars[i] += s;
+          return;
+        }
+    } else {
+      if (index_.size() != bases.size()) rebuild_index();
+      auto range = index_.equal_range(key_of(*b));
+      for (auto it = range.first; it != range.second; ++it)
+        if (*bases[it->second] == *b) {
+          scalars[it->second] += s;
+          return;
+        }
+      index_.emplace(key_of(*b), bases.size());
+    }
     scalars.push_back(s);
     bases.push_back(b);
   }

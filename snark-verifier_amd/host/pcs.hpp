@@ -104,6 +104,7 @@ struct KzgDecidingKey {
   snarkv_dk* handle() const {
     if (!dk_) {
       snarkv_dk* h = nullptr;
+      std::lock_guard<std::mutex> lock(device_mutex());
       if (bn254_kzg_dk_create(svk.g.b, g2.b, s_g2.b, &h) != SNARKV_OK)
         throw std::runtime_error(std::string("bn254_kzg_dk_create: ") + snarkv_last_error());
       dk_ = std::shared_ptr<snarkv_dk>(h, [](snarkv_dk* p) { snarkv_dk_destroy(p); });
@@ -218,7 +219,9 @@ struct KzgAs {
   static Error decide(const KzgDecidingKey& dk, const KzgAccumulator& acc) {
     uint8_t a[128], ok = 0;
     acc.to_bytes(a);
-    int rc = bn254_kzg_dk_decide_batch(dk.handle(), a, 1, &ok);
+    snarkv_dk* h = dk.handle();
+    std::lock_guard<std::mutex> lock(device_mutex());
+    int rc = bn254_kzg_dk_decide_batch(h, a, 1, &ok);
     if (rc < 0) throw std::runtime_error(std::string("bn254_kzg_dk_decide_batch: ") + snarkv_last_error());
     return ok ? Error{} : Error::assertion("e(lhs, g2)\xc2\xb7" "e(rhs, -s_g2) == O");
   }
@@ -227,7 +230,9 @@ struct KzgAs {
     if (accs.empty()) return Error{};
     std::vector<uint8_t> a(128 * accs.size()), ok(accs.size());
     for (size_t i = 0; i < accs.size(); ++i) accs[i].to_bytes(&a[128 * i]);
-    int rc = bn254_kzg_dk_decide_batch(dk.handle(), a.data(), accs.size(), ok.data());
+    snarkv_dk* h = dk.handle();
+    std::lock_guard<std::mutex> lock(device_mutex());
+    int rc = bn254_kzg_dk_decide_batch(h, a.data(), accs.size(), ok.data());
     if (rc < 0) throw std::runtime_error(std::string("bn254_kzg_dk_decide_batch: ") + snarkv_last_error());
     for (uint8_t o : ok)
       if (!o) return Error::assertion("e(lhs, g2)\xc2\xb7" "e(rhs, -s_g2) == O");
@@ -548,6 +553,7 @@ struct LimbsEncoding {
       for (size_t i = 0; i < LIMBS; ++i) tmp[i] = *limbs[c * LIMBS + i];
       if (!fe_from_limbs(tmp, pts + 32 * c)) throw Panic("limbs overflow the base field (reference: from_repr().unwrap())");
     }
+    std::lock_guard<std::mutex> lock(device_mutex());
     if (bn254_g1_validate(pts, 2) != SNARKV_OK)
       throw Panic("accumulator point is non-canonical or off-curve (reference: from_xy().unwrap())");
     return Result<KzgAccumulator>::Ok(KzgAccumulator{G1Affine::from_bytes(pts), G1Affine::from_bytes(pts + 64)});

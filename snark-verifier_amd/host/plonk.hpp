@@ -16,13 +16,46 @@
 // batch form `verify_batch` collects the two MSMs of EVERY proof into one
 // segmented launch (the data-parallel axis of SURVEY.md 8e).
 #pragma once
+#include <atomic>
+#include <exception>
 #include <map>
 #include <memory>
 #include <set>
+#include <thread>
 
 #include "pcs.hpp"
 
 namespace snarkv_host {
+
+// Proofs are independent: the host front half (transcript hashing, expression
+// evaluation) is spread over `threads` host threads; the first exception wins.
+template <class F>
+inline void parallel_for(size_t n, unsigned threads, F&& fn) {
+  if (threads <= 1 || n <= 1) {
+    for (size_t i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(1, n / 8));  // a thread start costs ~a dozen proofs
+  std::atomic<size_t> next{0};
+  std::exception_ptr err;
+  std::atomic<bool> failed{false};
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < threads; ++t)
+    pool.emplace_back([&] {
+      for (;;) {
+        size_t i = next.fetch_add(1);
+        if (i >= n || failed.load()) return;
+        try {
+          fn(i);
+        } catch (...) {
+          if (!failed.exchange(true)) err = std::current_exception();
+          return;
+        }
+      }
+    });
+  for (auto& th : pool) th.join();
+  if (err) std::rethrow_exception(err);
+}
 
 // util/arithmetic.rs:123-160
 struct Domain {
@@ -37,9 +70,13 @@ struct Domain {
     if (!gen.invert(&d.gen_inv)) throw Panic("Domain: generator not invertible (reference: unwrap, arithmetic.rs:141)");
     return d;
   }
-  static Fr pow_u64(const Fr& b, uint64_t e) {
-    uint64_t w[4] = {e, 0, 0, 0};
-    return b.pow(w);
+  static Fr pow_u64(const Fr& b, uint64_t e) {  // `pow_vartime([e])`: only the significant bits
+    Fr acc = Fr::one();
+    for (int i = 63 - (e ? __builtin_clzll(e) : 63); i >= 0; --i) {
+      acc = acc.square();
+      if ((e >> i) & 1) acc = acc * b;
+    }
+    return acc;
   }
   Fr rotate_scalar(const Fr& scalar, int32_t rotation) const {  // arithmetic.rs:153-159
     if (rotation == 0) return scalar;
@@ -165,14 +202,35 @@ struct CommonPolyEval {
   CommonPolyEval(const Domain& domain, const std::set<int32_t>& langranges, const Fr& z) {
     zn = Domain::pow_u64(z, (uint64_t)domain.n);
     zn_minus_one = zn - Fr::one();
-    zn_minus_one.invert(&zn_minus_one_inv);  // zero stays zero, as `batch_invert` leaves it (loader.rs:255-262)
     Fr numer = zn_minus_one * domain.n_inv;
     identity = z;
+    // denominators z - w^i and z^n - 1, inverted together (`L::batch_invert(denoms())`, plonk.rs:66-70):
+    // one field inversion; zeros stay zero (loader.rs:255-262)
+    std::vector<Fr> omegas, dens;
     for (int32_t i : langranges) {
-      Fr omega = domain.rotate_scalar(Fr::one(), i);
-      Fr den = z - omega, inv;
-      den.invert(&inv);
-      lagrange[i] = numer * omega * inv;
+      omegas.push_back(domain.rotate_scalar(Fr::one(), i));
+      dens.push_back(z - omegas.back());
+    }
+    dens.push_back(zn_minus_one);
+    std::vector<Fr> prefix(dens.size());
+    Fr acc = Fr::one();
+    for (size_t i = 0; i < dens.size(); ++i) {
+      prefix[i] = acc;
+      if (!dens[i].is_zero()) acc = acc * dens[i];
+    }
+    Fr inv;
+    acc.invert(&inv);
+    for (size_t i = dens.size(); i-- > 0;) {
+      if (dens[i].is_zero()) continue;
+      Fr d = dens[i];
+      dens[i] = inv * prefix[i];
+      inv = inv * d;
+    }
+    zn_minus_one_inv = dens.back();
+    size_t k = 0;
+    for (int32_t i : langranges) {
+      lagrange[i] = numer * omegas[k] * dens[k];
+      ++k;
     }
   }
   const Fr& get_lagrange(int32_t i) const {
@@ -342,7 +400,37 @@ struct PlonkProof {
       }
       MsmT scaled(const MsmT& a, const Fr& s) { return a * s; }
     } v{*this, cpe, evals, cm};
-    MsmT numerator = expr_evaluate<MsmT>(*pr.quotient.numerator, v);
+    // When every polynomial the numerator touches has an evaluation (always so
+    // without linearization) the whole tree is scalar arithmetic: evaluate it on
+    // Fr and wrap the result, instead of building an Msm object per node.
+    struct NeedMsm {};
+    struct VF {
+      const PlonkProof& self;
+      const CommonPolyEval& cpe;
+      std::map<PQuery, Fr>& evals;
+      Fr constant(const Fr& s) { return s; }
+      Fr common_identity() { return cpe.identity; }
+      Fr common_lagrange(int32_t i) { return cpe.get_lagrange(i); }
+      Fr poly(const PQuery& q) {
+        auto it = evals.find(q);
+        if (it == evals.end()) throw NeedMsm{};
+        return it->second;
+      }
+      Fr challenge(size_t i) {
+        if (i >= self.challenges.size()) throw InvalidProtocol("Missing challenge");
+        return self.challenges[i];
+      }
+      Fr negated(const Fr& a) { return -a; }
+      Fr sum(const Fr& a, const Fr& b) { return a + b; }
+      Fr product(const Fr& a, const Fr& b) { return a * b; }
+      Fr scaled(const Fr& a, const Fr& s) { return a * s; }
+    } vf{*this, cpe, evals};
+    MsmT numerator;
+    try {
+      numerator = MsmT::from_constant(expr_evaluate<Fr>(*pr.quotient.numerator, vf));
+    } catch (const NeedMsm&) {
+      numerator = expr_evaluate<MsmT>(*pr.quotient.numerator, v);
+    }
 
     PQuery quotient_query{pr.preprocessed.size() + pr.num_instance.size() + witnesses.size(), 0};
     auto coeffs = Domain::pow_u64(cpe.zn, (uint64_t)pr.quotient.chunk_degree).powers(quotients.size());
@@ -451,15 +539,22 @@ struct PlonkSuccinctVerifier {
   // Many proofs (possibly of different protocols): all 2 x N MSMs in ONE segmented launch.
   static Result<std::vector<std::vector<KzgAccumulator>>> verify_batch(
       const KzgSuccinctVerifyingKey& svk, const std::vector<const PlonkProtocol*>& protocols,
-      const std::vector<std::vector<std::vector<Fr>>>& instances, const std::vector<Proof>& proofs) {
+      const std::vector<std::vector<std::vector<Fr>>>& instances, const std::vector<Proof>& proofs,
+      unsigned threads = 1) {
     using R = Result<std::vector<std::vector<KzgAccumulator>>>;
-    std::vector<Pairs> jobs;
-    for (size_t i = 0; i < proofs.size(); ++i) {
+    std::vector<Pairs> jobs(2 * proofs.size());
+    std::vector<Error> errs(proofs.size());
+    parallel_for(proofs.size(), threads, [&](size_t i) {
       auto prs = msm_pairs(svk, *protocols[i], instances[i], proofs[i]);
-      if (!prs.ok()) return R::Err(prs.err);
-      jobs.push_back(std::move(prs.value->first));
-      jobs.push_back(std::move(prs.value->second));
-    }
+      if (!prs.ok()) {
+        errs[i] = prs.err;
+        return;
+      }
+      jobs[2 * i] = std::move(prs.value->first);
+      jobs[2 * i + 1] = std::move(prs.value->second);
+    });
+    for (auto& e : errs)
+      if (!e.ok()) return R::Err(e);
     auto pts = jobs.empty() ? std::vector<G1Affine>() : L::multi_scalar_multiplication_batch(jobs);
     std::vector<std::vector<KzgAccumulator>> out;
     for (size_t i = 0; i < proofs.size(); ++i) {

@@ -3,6 +3,7 @@
 // `LimbsEncoding` and the decider exactly as the reference's callers do
 // (snark-verifier/examples/evm-verifier-with-accumulator.rs:357-380) and compare
 // with oracle/kzg.py.  Links against libsnarkv_amd.so (the HIP path).
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 
@@ -617,6 +618,7 @@ static int plonk_verify_impl(int tkind, const uint8_t* protocol, size_t plen, co
       uint32_t len;
       memcpy(&len, pp, 4);
       pp += 4;
+      if ((size_t)(proofs + prlen - pp) < (size_t)len) throw Panic("proof length runs past the buffer");
       std::vector<uint8_t> bytes(pp, pp + len);
       pp += len;
       Result<PlonkProof<MOS>> pf = Result<PlonkProof<MOS>>::Err(Error{});
@@ -646,6 +648,114 @@ static int plonk_verify_impl(int tkind, const uint8_t* protocol, size_t plen, co
     }
     return KzgAs<MOS>::decide_all(dk, all).ok() ? 1 : 0;
   });
+}
+
+// The reference's aggregation flow on N proofs of one protocol, natively and end to end
+// (examples/evm-verifier-with-accumulator.rs:357-385 without the circuit):
+//   per proof  PlonkSuccinctVerifier::{read_proof, verify}     host (threads) + ONE segmented MSM launch
+//   then       KzgAs::create_proof over the N accumulators      host + one segmented MSM launch
+//   then       KzgAs::decide                                    one pairing check on the device
+// timings_ms[0..5] = read_proof, host algebra (msm pair lists), device MSMs, KzgAs, decide, total.
+template <class MOS>
+static int aggregate_impl(int tkind, const uint8_t* protocol, size_t plen, const uint8_t* instances, size_t ilen,
+                          const uint8_t* proofs, size_t prlen, uint32_t n, const uint8_t* dk320, unsigned threads,
+                          double* timings_ms, uint8_t* acc_out128) {
+  return guarded([&] {
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    PlonkProtocol pr = parse_protocol(protocol, plen);
+    KzgDecidingKey dk(G1Affine::from_bytes(dk320), G2Affine::from_bytes(dk320 + 64), G2Affine::from_bytes(dk320 + 192));
+    dk.handle();  // the G2 line tables are per-key setup, not per-proof work
+    // split the concatenated inputs (cheap, serial)
+    std::vector<std::pair<const uint8_t*, size_t>> ispan, pspan;
+    const uint8_t* ip = instances;
+    const uint8_t* pp = proofs;
+    for (uint32_t i = 0; i < n; ++i) {
+      PReader rd{ip, instances + ilen};
+      uint32_t cols = rd.u32();
+      for (uint32_t c = 0; c < cols; ++c) {
+        uint32_t m = rd.u32();
+        rd.need(32 * (size_t)m);
+        rd.p += 32 * (size_t)m;
+      }
+      ispan.emplace_back(ip, (size_t)(rd.p - ip));
+      ip = rd.p;
+      if ((size_t)(proofs + prlen - pp) < 4) throw Panic("truncated proofs");
+      uint32_t len;
+      memcpy(&len, pp, 4);
+      if ((size_t)(proofs + prlen - pp) < 4 + (size_t)len) throw Panic("proof length runs past the buffer");
+      pspan.emplace_back(pp + 4, len);
+      pp += 4 + len;
+    }
+    auto t0 = clk::now();
+    std::vector<std::vector<std::vector<Fr>>> insts(n);
+    std::vector<PlonkProof<MOS>> pfs(n);
+    std::vector<const PlonkProtocol*> prs(n, &pr);
+    std::vector<Error> errs(n);
+    parallel_for(n, threads, [&](size_t i) {
+      insts[i] = parse_instances(ispan[i].first, ispan[i].second);
+      std::vector<uint8_t> bytes(pspan[i].first, pspan[i].first + pspan[i].second);
+      Result<PlonkProof<MOS>> pf = Result<PlonkProof<MOS>>::Err(Error{});
+      if (tkind == 0) {
+        EvmTranscript t(std::move(bytes));
+        pf = PlonkSuccinctVerifier<MOS>::read_proof(dk.svk, pr, insts[i], t);
+      } else {
+        PoseidonTranscript t(std::move(bytes));
+        pf = PlonkSuccinctVerifier<MOS>::read_proof(dk.svk, pr, insts[i], t);
+      }
+      if (!pf.ok()) errs[i] = pf.err;
+      else pfs[i] = std::move(*pf.value);
+    });
+    for (auto& e : errs)
+      if (!e.ok()) return error_code(e);
+    auto t1 = clk::now();
+    using SV = PlonkSuccinctVerifier<MOS>;
+    std::vector<typename SV::Pairs> jobs(2 * (size_t)n);
+    parallel_for(n, threads, [&](size_t i) {
+      auto p2 = SV::msm_pairs(dk.svk, pr, insts[i], pfs[i]);
+      if (!p2.ok()) {
+        errs[i] = p2.err;
+        return;
+      }
+      jobs[2 * i] = std::move(p2.value->first);
+      jobs[2 * i + 1] = std::move(p2.value->second);
+    });
+    for (auto& e : errs)
+      if (!e.ok()) return error_code(e);
+    auto t2 = clk::now();
+    auto pts = L::multi_scalar_multiplication_batch(jobs);
+    auto t3 = clk::now();
+    std::vector<KzgAccumulator> accs;
+    for (uint32_t i = 0; i < n; ++i) {
+      accs.push_back(KzgAccumulator{pts[2 * i], pts[2 * i + 1]});
+      accs.insert(accs.end(), pfs[i].old_accumulators.begin(), pfs[i].old_accumulators.end());
+    }
+    EvmTranscript at;
+    auto acc = KzgAs<MOS>::create_proof(KzgAsProvingKey{}, accs, at, Fr());
+    if (!acc.ok()) return error_code(acc.err);
+    auto t4 = clk::now();
+    bool ok = KzgAs<MOS>::decide(dk, *acc.value).ok();
+    auto t5 = clk::now();
+    if (timings_ms) {
+      timings_ms[0] = ms(t0, t1);
+      timings_ms[1] = ms(t1, t2);
+      timings_ms[2] = ms(t2, t3);
+      timings_ms[3] = ms(t3, t4);
+      timings_ms[4] = ms(t4, t5);
+      timings_ms[5] = ms(t0, t5);
+    }
+    if (acc_out128) acc.value->to_bytes(acc_out128);
+    return ok ? 1 : 0;
+  });
+}
+
+extern "C" int hd_aggregate_end_to_end(int mos, int tkind, const uint8_t* protocol, size_t plen, const uint8_t* instances,
+                                       size_t ilen, const uint8_t* proofs, size_t prlen, uint32_t n, const uint8_t* dk320,
+                                       unsigned threads, double* timings_ms, uint8_t* acc_out128) {
+  return mos == 0 ? aggregate_impl<Gwc19>(tkind, protocol, plen, instances, ilen, proofs, prlen, n, dk320, threads,
+                                          timings_ms, acc_out128)
+                  : aggregate_impl<Bdfg21>(tkind, protocol, plen, instances, ilen, proofs, prlen, n, dk320, threads,
+                                           timings_ms, acc_out128);
 }
 
 extern "C" int hd_plonk_verify(int mos, int tkind, const uint8_t* protocol, size_t plen, const uint8_t* instances,

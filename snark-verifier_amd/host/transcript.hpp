@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <vector>
 
@@ -37,25 +38,45 @@ inline void f1600(uint64_t a[25]) {
       0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull, 0x8000000000008003ull,
       0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
       0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+  // rho rotation of lane x + 5y and its pi destination, both derived once from
+  // the orbit (x, y) -> (y, 2x + 3y) of (1, 0) with offsets (t+1)(t+2)/2
+  static const struct Tables {
+    int rot[25], dst[25];
+    Tables() {
+      rot[0] = 0;
+      dst[0] = 0;
+      int x = 1, y = 0;
+      for (int t = 0; t < 24; ++t) {
+        int nx = y, ny = (2 * x + 3 * y) % 5;
+        rot[x + 5 * y] = ((t + 1) * (t + 2) / 2) % 64;
+        dst[x + 5 * y] = nx + 5 * ny;
+        x = nx;
+        y = ny;
+      }
+    }
+  } T;
   for (int rnd = 0; rnd < 24; ++rnd) {
-    uint64_t c[5], b[25];
-    for (int x = 0; x < 5; ++x) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
-    for (int x = 0; x < 5; ++x) {
-      uint64_t d = c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);
-      for (int y = 0; y < 25; y += 5) a[x + y] ^= d;
+    uint64_t c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20];
+    uint64_t c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21];
+    uint64_t c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22];
+    uint64_t c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23];
+    uint64_t c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
+    const uint64_t d[5] = {c4 ^ rotl64(c1, 1), c0 ^ rotl64(c2, 1), c1 ^ rotl64(c3, 1), c2 ^ rotl64(c4, 1),
+                           c3 ^ rotl64(c0, 1)};
+    uint64_t b[25];
+    for (int y = 0; y < 25; y += 5)
+      for (int x = 0; x < 5; ++x) {
+        const int i = x + y;
+        b[T.dst[i]] = rotl64(a[i] ^ d[x], T.rot[i]);  // theta, rho, pi
+      }
+    for (int y = 0; y < 25; y += 5) {                 // chi
+      const uint64_t b0 = b[y], b1 = b[y + 1], b2 = b[y + 2], b3 = b[y + 3], b4 = b[y + 4];
+      a[y] = b0 ^ (~b1 & b2);
+      a[y + 1] = b1 ^ (~b2 & b3);
+      a[y + 2] = b2 ^ (~b3 & b4);
+      a[y + 3] = b3 ^ (~b4 & b0);
+      a[y + 4] = b4 ^ (~b0 & b1);
     }
-    // rho and pi: B[y][2x+3y] = rot(A[x][y], (t+1)(t+2)/2) along the orbit of (1, 0)
-    b[0] = a[0];
-    int x = 1, y = 0;
-    for (int t = 0; t < 24; ++t) {
-      int r = ((t + 1) * (t + 2) / 2) % 64;
-      int nx = y, ny = (2 * x + 3 * y) % 5;
-      b[nx + 5 * ny] = rotl64(a[x + 5 * y], r);
-      x = nx;
-      y = ny;
-    }
-    for (int yy = 0; yy < 25; yy += 5)
-      for (int xx = 0; xx < 5; ++xx) a[xx + yy] = b[xx + yy] ^ (~b[(xx + 1) % 5 + yy] & b[(xx + 2) % 5 + yy]);
     a[0] ^= RC[rnd];
   }
 }
@@ -67,8 +88,8 @@ inline void keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
   memset(st, 0, sizeof st);
   auto absorb_block = [&](const uint8_t* blk) {
     for (size_t i = 0; i < rate / 8; ++i) {
-      uint64_t w = 0;
-      for (int k = 7; k >= 0; --k) w = (w << 8) | blk[8 * i + k];
+      uint64_t w;
+      memcpy(&w, blk + 8 * i, 8);  // little-endian host (x86-64)
       st[i] ^= w;
     }
     f1600(st);
@@ -117,14 +138,47 @@ inline void add_mod(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {  
   }
   memcpy(r, t, 32);
 }
-// a*b mod p by double-and-add (a few dozen points per proof: speed is irrelevant, obviousness is not)
-inline void mul_mod(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
-  uint64_t acc[4] = {0, 0, 0, 0};
-  for (int i = 255; i >= 0; --i) {
-    add_mod(acc, acc, acc);
-    if ((b[i >> 6] >> (i & 63)) & 1) add_mod(acc, acc, a);
+// a*b mod p on plain integers: two Montgomery products (a b / R, then times R^2 / R)
+inline void mont_mul(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+  static constexpr uint64_t INV = 0x87d20782e4866389ull;  // -p^-1 mod 2^64
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
+    unsigned __int128 c = 0;
+    for (int j = 0; j < 4; ++j) {
+      c += (unsigned __int128)a[i] * b[j] + t[j];
+      t[j] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[4] = (uint64_t)c;
+    t[5] = (uint64_t)(c >> 64);
+    uint64_t m = t[0] * INV;
+    c = ((unsigned __int128)m * P[0] + t[0]) >> 64;
+    for (int j = 1; j < 4; ++j) {
+      c += (unsigned __int128)m * P[j] + t[j];
+      t[j - 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[3] = (uint64_t)c;
+    t[4] = t[5] + (uint64_t)(c >> 64);
   }
-  memcpy(r, acc, 32);
+  if (!lt_p(t)) {
+    unsigned __int128 br = 0;
+    for (int i = 0; i < 4; ++i) {
+      unsigned __int128 x = (unsigned __int128)t[i] - P[i] - (uint64_t)br;
+      t[i] = (uint64_t)x;
+      br = (x >> 64) & 1;
+    }
+  }
+  memcpy(r, t, 32);
+}
+inline void mul_mod(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+  static constexpr uint64_t R2[4] = {0xf32cfc5b538afa89ull, 0xb5e71911d44501fbull, 0x47ab1eff0a417ff6ull,
+                                     0x06d89f71cab8351full};  // 2^512 mod p
+  uint64_t t[4];
+  mont_mul(t, a, b);
+  mont_mul(r, t, R2);
 }
 // `C::from_xy`: canonical coordinates and y^2 = x^3 + 3 (the point at infinity has no coordinates)
 inline bool g1_from_xy_ok(const uint8_t x_le[32], const uint8_t y_le[32]) {
@@ -339,7 +393,9 @@ inline Fr fr_from_words_mod_r(uint64_t w[4]) {  // w < 2^254 < 2r
 }  // namespace grain
 
 inline const PoseidonSpec& poseidon_spec(int t, int r_f, int r_p) {
-  static std::map<std::tuple<int, int, int>, PoseidonSpec> cache;
+  static std::map<std::tuple<int, int, int>, PoseidonSpec> cache;  // node-based: references stay valid
+  static std::mutex mu;                                            // transcripts are built from many host threads
+  std::lock_guard<std::mutex> lock(mu);
   auto key = std::make_tuple(t, r_f, r_p);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;

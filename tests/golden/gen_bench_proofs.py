@@ -1,0 +1,58 @@
+"""Generates tests/golden/bench_plonk_gwc19_evm_64.bin: the C3 workload of
+BASELINE.json as REAL INPUT BYTES -- one StandardPlonk-shaped protocol, 64
+instance sets and 64 proofs forged under the toy SRS (oracle/plonk.py), Keccak
+transcript, GWC19 multi-open -- so that bench.py can time the verifier end to
+end (proof bytes in, accept out) without importing the oracle.
+Layout: magic 'SVB1' | u32 n | u32 plen | protocol | u32 ilen | instances | u32 prlen | proofs (u32 len || bytes each)
+        | dk (64 + 128 + 128) | expected aggregated accumulator (128)
+Run from the repo root:  python tests/golden/gen_bench_proofs.py"""
+import os
+import random
+import struct
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bn254 as O
+import kzg as K
+import plonk as P
+import plonk_synth as S
+import transcript as T
+
+SECRET = 0x1F2E3D4C5B6A79887766554433221100AABBCCDDEEFF
+
+
+def main(n=64):
+    rng = random.Random(0xBE2C)
+    pr, dl = S.standard_plonk_protocol(rng)
+    insts, proofs, accs = [], [], []
+    for i in range(n):
+        inst = [[rng.randrange(O.R) for _ in range(m)] for m in pr["num_instance"]]
+        proof = P.forge_proof(pr, inst, SECRET, lambda: T.EvmTranscript(), "gwc19", rng, dl)
+        pf = P.plonk_proof_read(pr, inst, T.EvmTranscript(proof), "gwc19")
+        accs += P.succinct_verify(O.G1_GEN, pr, inst, pf, "gwc19")
+        insts.append(inst)
+        proofs.append(proof)
+    # KzgAs::create_proof (non-zk) over the n accumulators with a fresh Keccak transcript (accumulation.rs:148-197)
+    t = T.EvmTranscript()
+    for lhs, rhs in accs:
+        t.common_ec_point(lhs)
+        t.common_ec_point(rhs)
+    r = t.squeeze_challenge()
+    agg = K.kzg_as_verify(accs, r)
+    assert agg[0] == O.g1_mul(agg[1], SECRET)
+    pb = S.pack_protocol(pr)
+    ib = b"".join(S.pack_instances(i) for i in insts)
+    prb = b"".join(struct.pack("<I", len(p)) + p for p in proofs)
+    dk = O.g1_to_bytes(O.G1_GEN) + O.g2_to_bytes(O.G2_GEN) + O.g2_to_bytes(O.g2_mul(O.G2_GEN, SECRET))
+    blob = (b"SVB1" + struct.pack("<I", n) + struct.pack("<I", len(pb)) + pb + struct.pack("<I", len(ib)) + ib
+            + struct.pack("<I", len(prb)) + prb + dk + O.g1_to_bytes(agg[0]) + O.g1_to_bytes(agg[1]))
+    path = os.path.join(ROOT, "tests", "golden", "bench_plonk_gwc19_evm_%d.bin" % n)
+    with open(path, "wb") as f:
+        f.write(blob)
+    print("wrote", path, len(blob), "bytes")
+
+
+if __name__ == "__main__":
+    main()

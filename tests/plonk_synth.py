@@ -40,7 +40,7 @@ def neg(x):
 
 
 def standard_plonk_protocol(rng, k=6, num_instance=(2,), linearization=None, accumulator_rows=None,
-                            committed_instances=False, initial_state=True):
+                            committed_instances=False, initial_state=True, linearize_fixed=False):
     """returns (protocol, preprocessed_dlogs)"""
     dom = P.Domain(k)
     pre_dlogs = [rng.randrange(1, R) for _ in range(8)]
@@ -84,6 +84,11 @@ def standard_plonk_protocol(rng, k=6, num_instance=(2,), linearization=None, acc
         lin_extra = [(Q + 1, 0)]
     queries = [(a, 0), (b, 0), (c, 0), (a, 1), (c, -1), (z1, 0), (z1, 1), (z1, last), (z2, 0), (z2, 1)] + \
               [(i, 0) for i in range(5)] + [(s1, 0), (s2, 0), (s3, 0)] + [(Q, 0)] + lin_extra + [(rnd, 0)]
+    if linearize_fixed:
+        # q_k is not evaluated: with a linearization strategy its COMMITMENT enters the numerator Msm
+        assert linearization is not None
+        evaluations = [q for q in evaluations if q != (q_k, 0)]
+        queries = [q for q in queries if q != (q_k, 0)]
     pr = {
         "domain": dom, "preprocessed": preprocessed, "num_instance": list(num_instance),
         "num_witness": [3, 0, 3], "num_challenge": [1, 2, 1], "evaluations": evaluations, "queries": queries,

@@ -92,6 +92,21 @@ def test_forged_proofs_verify_and_match_the_oracle(H, mos, kind, lin):
     assert rc == 0
 
 
+@pytest.mark.parametrize("mos", [0, 1])
+@pytest.mark.parametrize("lin", ["WithoutConstant", "MinusVanishingTimesQuotient"])
+def test_linearized_numerator_with_a_commitment_term(H, mos, lin):
+    """A fixed column without an evaluation: its commitment flows through the
+    numerator as an Msm (proof.rs:218-252), the linearization commitment carries it."""
+    rng = random.Random(300 + mos + len(lin))
+    pr, dl = S.standard_plonk_protocol(rng, linearization=lin, num_instance=(2, 2), linearize_fixed=True)
+    inst = [[rng.randrange(O.R) for _ in range(n)] for n in pr["num_instance"]]
+    proof = P.forge_proof(pr, inst, SECRET, lambda: mk_transcript(0), MOS[mos], rng, dl)
+    exp = oracle_accs(MOS[mos], 0, pr, inst, proof)
+    assert exp[0][0] == O.g1_mul(exp[0][1], SECRET)
+    rc, accs = run(H, mos, 0, pr, [inst], [proof])
+    assert rc == 1 and accs == b"".join(g1(a) + g1(b) for a, b in exp)
+
+
 def test_old_accumulators_from_instance_limbs_and_committed_instances(H):
     rng = random.Random(7)
     a = rng.randrange(1, O.R)
@@ -179,3 +194,46 @@ def test_golden_fixture_cpp(H):
                                len(accs), ctypes.byref(n))
         assert rc == 1, case["name"]
         assert accs.raw[:128 * n.value].hex() == "".join(case["accumulators"]), case["name"]
+
+
+def load_bench_blob():
+    import os
+    import struct
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_plonk_gwc19_evm_64.bin")
+    b = open(path, "rb").read()
+    assert b[:4] == b"SVB1"
+    n, = struct.unpack_from("<I", b, 4)
+    off = 8
+    parts = []
+    for _ in range(3):
+        ln, = struct.unpack_from("<I", b, off)
+        parts.append(b[off + 4:off + 4 + ln])
+        off += 4 + ln
+    dk, exp = b[off:off + 320], b[off + 320:off + 448]
+    return n, parts[0], parts[1], parts[2], dk, exp
+
+
+@pytest.mark.parametrize("threads", [1, 8])
+def test_end_to_end_aggregation_of_64_proofs(H, threads):
+    """BASELINE.json config C3 as real bytes (tests/golden/bench_plonk_gwc19_evm_64.bin):
+    64 x PlonkSuccinctVerifier -> KzgAs::create_proof -> decide, host front half
+    on `threads` threads, every EC operation on the device."""
+    H.hd_aggregate_end_to_end.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
+                                          ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32,
+                                          ctypes.c_char_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p]
+    n, pb, ib, prb, dk, exp = load_bench_blob()
+    tm = (ctypes.c_double * 6)()
+    acc = ctypes.create_string_buffer(128)
+    rc = H.hd_aggregate_end_to_end(0, 0, pb, len(pb), ib, len(ib), prb, len(prb), n, dk, threads, tm, acc)
+    assert rc == 1
+    assert acc.raw == exp  # the oracle's aggregated accumulator (gen_bench_proofs.py)
+    # replicate the batch 4x (256 proofs): still one launch per stage, still accepted
+    rc = H.hd_aggregate_end_to_end(0, 0, pb, len(pb), ib * 4, 4 * len(ib), prb * 4, 4 * len(prb), 4 * n, dk, threads, tm, acc)
+    assert rc == 1
+    # a corrupted proof anywhere in the batch poisons the aggregate
+    bad = bytearray(prb)
+    first_len = int.from_bytes(prb[:4], "little")
+    bad[4 + first_len + 4 + 700] ^= 2  # inside the payload of the second proof
+    rc = H.hd_aggregate_end_to_end(0, 0, pb, len(pb), ib, len(ib), bytes(bad), len(bad), n, dk, threads, tm, acc)
+    assert rc in (0, -10)
