@@ -44,7 +44,14 @@ def cpu_baseline(ctx, d_scalars, d_points, sample_log2):
     t0 = time.perf_counter()
     out = coracle.msm_pippenger(s, p, cores)
     dt = time.perf_counter() - t0
+    # the reference without its `parallel` feature is single-threaded (msm.rs:308-343): T = 1 on a smaller sample
+    m1 = min(m, 1 << 16)
+    t1 = time.perf_counter()
+    coracle.msm_pippenger(s[: 32 * m1], p[: 64 * m1], 1)
+    dt1 = time.perf_counter() - t1
     return {
+        "single_thread": {"value": m1 / dt1, "unit": "points/s", "cores": 1,
+                          "sample": "first 2^%d points of the same inputs, 1 thread, %.2f s" % (m1.bit_length() - 1, dt1)},
         "value": m / dt,
         "unit": "points/s",
         "cores": cores,
@@ -239,7 +246,9 @@ def main():
     # tail of one MSM (bucket reduce, 2^(cw) doubling chains, to_affine: a few
     # wavefronts) overlaps the VALU-bound bucket accumulation of the next.
     inflight = max(1, args.inflight)
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(inflight - 1)]
+    # explicit side streams only: a context given the NULL stream handle (torch's legacy default
+    # stream) would create its own stream, invisible to the stream ordering torch.distributed relies on
+    streams = [torch.cuda.Stream() for _ in range(inflight)]
     ctxs = [sv.Context(local_rank, stream=s.cuda_stream) for s in streams]
     ctx = ctxs[0]
 
@@ -294,16 +303,20 @@ def main():
                 stage_sum[k] = stage_sum.get(k, 0.0) + v
     barrier()
     dt = time.perf_counter() - t0
-    if stage_cnt == 0:  # pipelined mode: the events of the last step of every context
-        for c in ctxs:
+    if stage_cnt == 0:  # pipelined mode: the events of the last step of every context that ran a timed step
+        first = step_no[0] - args.steps
+        used = sorted({i % inflight for i in range(first, step_no[0])})
+        for c in [ctxs[k] for k in used]:
             st = c.get_stage_timing()
             stage_cnt += 1
             for k, v in st.items():
                 stage_sum[k] = stage_sum.get(k, 0.0) + v
     for c in ctxs:
         c.set_stage_timing(False)
-    for o in outs[1:]:
-        assert bytes(o.cpu().numpy()) == bytes(out.cpu().numpy())
+    written = sorted({i % inflight for i in range(step_no[0])})  # slots that ran at least one MSM
+    out = outs[written[0]]
+    for k in written[1:]:
+        assert bytes(outs[k].cpu().numpy()) == bytes(out.cpu().numpy())
 
     # single-MSM latency (strictly sequential), outside the timed region, for the record
     lat_ms, seq_stages = None, None

@@ -155,7 +155,13 @@ class DecidingKey:
 
 
 class Context:
-    """One HIP stream + scratch (see include/snarkv_amd.h "Threading")."""
+    """One HIP stream + scratch (see include/snarkv_amd.h "Threading").
+
+    `stream`: a HIP stream handle (e.g. `torch.cuda.Stream().cuda_stream`) the context
+    launches on; None (or the NULL handle of torch's legacy default stream) makes the
+    context create a private non-blocking stream.  `_dev` calls are asynchronous on
+    that stream: order them against other streams yourself (`ctx.sync()`, or run inside
+    `torch.cuda.stream(s)` with the context created on `s.cuda_stream`)."""
 
     def __init__(self, device=0, stream=None):
         self._lib = load_library()

@@ -64,11 +64,16 @@ def gpu_sharded_msm(ctx, d_scalars, d_points, n_total, window_bits=0):
     part = torch.zeros(G1_PARTIAL_BYTES, dtype=torch.uint8, device=d_scalars.device)
     out = torch.zeros(64, dtype=torch.uint8, device=d_scalars.device)
 
+    # The context's HIP stream need not be torch's current stream (a context
+    # created without a stream owns a private one), and the collective is ordered
+    # against torch's current stream only -- so order the three steps explicitly.
     def partial_fn(lo, hi):
         ctx.msm_pippenger_partial_dev(d_scalars.data_ptr(), d_points.data_ptr(), hi - lo, part.data_ptr(), window_bits)
+        ctx.sync()  # the partial is in memory before the all-gather reads it
         return part
 
     def fold_fn(gathered, world):
+        torch.cuda.current_stream().synchronize()  # the all-gather has landed before the fold reads it
         ctx.fold_partials_dev(gathered.data_ptr(), world, out.data_ptr())
         return out
 

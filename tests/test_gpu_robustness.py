@@ -122,3 +122,52 @@ def test_decide_batch_mixed_and_identity_cases(gpu_ctx, golden_decider):
     allok, oks = gpu_ctx.decide_batch(dk, accs)
     assert oks == [c["accept"] for c in cases] and not allok
     dk.close()
+
+
+def test_sharded_msm_over_rccl_world_of_one_is_ordered():
+    """The multi-GPU wiring (distributed.py: HIP partial -> RCCL all-gather -> HIP
+    fold) on a 1-rank NCCL group, with the context on its OWN stream and inputs
+    that change every call: a missing stream dependency would fold a stale or
+    empty partial."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    import snark_verifier_amd as sv
+    from snark_verifier_amd import distributed as D
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29617"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ctx = sv.Context(0)  # private stream
+        ref = sv.Context(0)
+        n = 1 << 14
+        ds = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+        dp = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+        exp = torch.zeros(64, dtype=torch.uint8, device="cuda")
+        seen = set()
+        for it in range(6):
+            ref.sample_scalars_dev(1000 + it, n, ds.data_ptr())
+            ref.sample_points_dev(2000 + it, n, dp.data_ptr())
+            ref.msm_pippenger_dev(ds.data_ptr(), dp.data_ptr(), n, exp.data_ptr(), 0)
+            ref.sync()
+            # force the real collective even at world size 1
+            part = torch.zeros(sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+            gathered = torch.zeros(sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+            out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+            ctx.msm_pippenger_partial_dev(ds.data_ptr(), dp.data_ptr(), n, part.data_ptr(), 0)
+            ctx.sync()
+            dist.all_gather_into_tensor(gathered, part)
+            torch.cuda.current_stream().synchronize()
+            ctx.fold_partials_dev(gathered.data_ptr(), 1, out.data_ptr())
+            ctx.sync()
+            assert bytes(out.cpu().numpy()) == bytes(exp.cpu().numpy())
+            got = D.gpu_sharded_msm(ctx, ds, dp, n)
+            ctx.sync()
+            assert bytes(got.cpu().numpy()) == bytes(exp.cpu().numpy())
+            seen.add(bytes(exp.cpu().numpy()))
+        assert len(seen) == 6
+    finally:
+        dist.destroy_process_group()
