@@ -212,20 +212,23 @@ __global__ void __launch_bounds__(64) k_term_chunks(const G1Xyzz29* __restrict__
   }
 }
 
-// K2: one 64-lane block (= one wavefront) per MSM folds its 2 x terms partials
-// (`reduce(|a,v| a+v)`, native.rs:68), then `to_affine()` (native.rs:70).
-__global__ void __launch_bounds__(64) k_segment_fold(const G1Xyzz29* __restrict__ parts,
-                                                      const uint32_t* __restrict__ offsets,
-                                                      uint32_t* __restrict__ out) {
-  __shared__ G1Xyzz29 sh[64];
+// K2: one block per MSM folds its 2 x terms partials (`reduce(|a,v| a+v)`,
+// native.rs:68), then `to_affine()` (native.rs:70).  One wavefront for the
+// ~21-term MSMs of a proof; four for long segments (the (m+1)-term MSMs of
+// KzgAs::verify), where the strided pre-sum is the critical path.
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) k_segment_fold(const G1Xyzz29* __restrict__ parts,
+                                                           const uint32_t* __restrict__ offsets,
+                                                           uint32_t* __restrict__ out) {
+  __shared__ G1Xyzz29 sh[THREADS];
   uint32_t k = blockIdx.x;
   uint32_t lo = 2 * offsets[k], hi = 2 * offsets[k + 1];
   uint32_t lane = threadIdx.x;
   G1Xyzz29 acc = xyzz29_identity();
-  for (uint32_t i = lo + lane; i < hi; i += 64) xyzz29_add_careful(acc, parts[i]);
+  for (uint32_t i = lo + lane; i < hi; i += THREADS) xyzz29_add_careful(acc, parts[i]);
   sh[lane] = acc;
   __syncthreads();
-  for (uint32_t s = 32; s >= 1; s >>= 1) {
+  for (uint32_t s = THREADS / 2; s >= 1; s >>= 1) {
     if (lane < s) {
       G1Xyzz29 a = sh[lane];
       xyzz29_add_careful(a, sh[lane + s]);
@@ -307,8 +310,12 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
     hipLaunchKernelGGL(k_term_chunks, dim3((n_lanes + 63) / 64), dim3(64), 0, ctx->stream,
                        (const G1Xyzz29*)d_chain, (const uint4*)d_mags, (G1Xyzz29*)d_terms, n_lanes, J, bits);
   }
-  hipLaunchKernelGGL(k_segment_fold, dim3((uint32_t)n_msm), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_terms,
-                     (const uint32_t*)d_offsets, (uint32_t*)d_out);
+  if (n_terms >= 128 * n_msm)
+    hipLaunchKernelGGL(k_segment_fold<256>, dim3((uint32_t)n_msm), dim3(256), 0, ctx->stream,
+                       (const G1Xyzz29*)d_terms, (const uint32_t*)d_offsets, (uint32_t*)d_out);
+  else
+    hipLaunchKernelGGL(k_segment_fold<64>, dim3((uint32_t)n_msm), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_terms,
+                       (const uint32_t*)d_offsets, (uint32_t*)d_out);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }
