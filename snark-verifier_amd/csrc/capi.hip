@@ -3,7 +3,9 @@
 // enqueues the HIP kernels and copies the (tiny) result back.
 #include <stdarg.h>
 #include <string.h>
+#include <algorithm>
 #include <mutex>
+#include <stdlib.h>
 #include "ctx.hpp"
 
 namespace snarkv {
@@ -105,6 +107,10 @@ void snarkv_ctx_destroy(snarkv_ctx* ctx) {
     if (ctx->buf[i]) (void)hipFree(ctx->buf[i]);
   if (ctx->ev_ready)
     for (int i = 0; i <= SNARKV_PIP_STAGES; ++i) (void)hipEventDestroy(ctx->ev[i]);
+  if (ctx->sub_ready) {
+    for (int i = 0; i < 3; ++i) snarkv_ctx_destroy(ctx->sub[i]);
+    for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ctx->sub_ev[i]);
+  }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -177,6 +183,55 @@ int snarkv_g1_msm_batched_dev(snarkv_ctx* ctx, const void* d_scalars32, const vo
   return launch_msm_batched(ctx, d_scalars32, d_points64, d_offsets, n_msm, n_terms, d_out);
 }
 
+}  // extern "C"
+
+// A Pippenger MSM of 2^20 points leaves the machine half idle during its
+// latency-bound tail (bucket reduce, 2^(cw) doubling chains, to_affine); several
+// MSMs in flight fill it.  A LARGE MSM gets the same benefit
+// from itself: MSM is linear (the reference's own chunking, msm.rs:311-336), so
+// n >= 2^22 points run as 2^20-point chunks round-robin on four lanes (the
+// caller's stream and three private sub-contexts, one HIP stream + scratch
+// each), and the 144-byte projective partials are folded on the caller's stream.  Same group element, same bytes.
+static int pippenger_maybe_split(snarkv_ctx* ctx, const void* d_s, const void* d_p, size_t n, int window_bits,
+                                 void* d_out, bool partial_out) {
+  constexpr size_t kChunk = (size_t)1 << 20;
+  // OPT-IN (SNARKV_PIP_SPLIT=1).  Measured on MI355X: with HIP's default 4 hardware queues the lanes
+  // collide and the split form LOSES (2^24: 39.0 vs 36.5 ms); with GPU_MAX_HW_QUEUES=8 it wins 7 %
+  // at 2^24 (34.1 ms, 4.9e8 points/s) and is level at 2^22.  The single-launch form stays the default.
+  const char* env = getenv("SNARKV_PIP_SPLIT");
+  bool allow = env && env[0] == '1';
+  if (!allow || n < 4 * kChunk || window_bits != 0 || ctx->stage_timing)
+    return launch_msm_pippenger(ctx, d_s, d_p, n, window_bits, d_out, partial_out);
+  // Four lanes: the caller's own stream + three private ones.  (Not four private
+  // ones: HIP multiplexes streams onto 4 hardware queues by default, and a fifth
+  // busy stream would share a queue with one of the lanes.)
+  if (!ctx->sub_ready) {
+    for (int i = 0; i < 3; ++i) SNARKV_TRY(snarkv_ctx_create(ctx->device, nullptr, &ctx->sub[i]));
+    ctx->sub[3] = nullptr;
+    for (int i = 0; i < 5; ++i) SNARKV_HIP(hipEventCreateWithFlags(&ctx->sub_ev[i], hipEventDisableTiming));
+    ctx->sub_ready = true;
+  }
+  const size_t chunks = (n + kChunk - 1) / kChunk;
+  void* d_parts;
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_SPLIT_PARTIALS, chunks * (size_t)SNARKV_G1_PARTIAL_BYTES, &d_parts));
+  // inputs (and the partials buffer) may still be in flight on the caller's stream
+  SNARKV_HIP(hipEventRecord(ctx->sub_ev[4], ctx->stream));
+  for (int i = 0; i < 3; ++i) SNARKV_HIP(hipStreamWaitEvent(ctx->sub[i]->stream, ctx->sub_ev[4], 0));
+  for (size_t c = 0; c < chunks; ++c) {
+    size_t lo = c * kChunk, len = std::min(kChunk, n - lo);
+    snarkv_ctx* lane = (c % 4 == 3) ? ctx : ctx->sub[c % 4];
+    SNARKV_TRY(launch_msm_pippenger(lane, (const char*)d_s + 32 * lo, (const char*)d_p + 64 * lo, len, 0,
+                                    (char*)d_parts + c * (size_t)SNARKV_G1_PARTIAL_BYTES, true));
+  }
+  for (int i = 0; i < 3; ++i) {
+    SNARKV_HIP(hipEventRecord(ctx->sub_ev[i], ctx->sub[i]->stream));
+    SNARKV_HIP(hipStreamWaitEvent(ctx->stream, ctx->sub_ev[i], 0));
+  }
+  return launch_fold_partials(ctx, d_parts, chunks, d_out, partial_out);
+}
+
+extern "C" {
+
 int snarkv_g1_msm_pippenger(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8_t* points64, size_t n,
                             uint32_t flags, uint8_t out64[64]) {
   if (!ctx || !scalars32 || !points64 || !out64) return SNARKV_ERR_ARG;
@@ -187,7 +242,7 @@ int snarkv_g1_msm_pippenger(snarkv_ctx* ctx, const uint8_t* scalars32, const uin
   SNARKV_TRY(stage_in(ctx, SLOT_IN_POINTS, points64, n * 64, &d_p));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_OUT, 64, &d_out));
   SNARKV_TRY(check_validate(ctx, d_s, d_p, n, flags));
-  SNARKV_TRY(launch_msm_pippenger(ctx, d_s, d_p, n, 0, d_out, false));
+  SNARKV_TRY(pippenger_maybe_split(ctx, d_s, d_p, n, 0, d_out, false));
   return fetch_out(ctx, d_out, out64, 64);
 }
 
@@ -196,7 +251,7 @@ int snarkv_g1_msm_pippenger_dev(snarkv_ctx* ctx, const void* d_scalars32, const 
   if (!ctx || !d_scalars32 || !d_points64 || !d_out64) return SNARKV_ERR_ARG;
   if (n == 0) return SNARKV_ERR_EMPTY;
   SNARKV_HIP(hipSetDevice(ctx->device));
-  return launch_msm_pippenger(ctx, d_scalars32, d_points64, n, window_bits, d_out64, false);
+  return pippenger_maybe_split(ctx, d_scalars32, d_points64, n, window_bits, d_out64, false);
 }
 
 int snarkv_g1_msm_pippenger_partial_dev(snarkv_ctx* ctx, const void* d_scalars32, const void* d_points64,
@@ -204,7 +259,7 @@ int snarkv_g1_msm_pippenger_partial_dev(snarkv_ctx* ctx, const void* d_scalars32
   if (!ctx || !d_scalars32 || !d_points64 || !d_partial) return SNARKV_ERR_ARG;
   if (n == 0) return SNARKV_ERR_EMPTY;
   SNARKV_HIP(hipSetDevice(ctx->device));
-  return launch_msm_pippenger(ctx, d_scalars32, d_points64, n, window_bits, d_partial, true);
+  return pippenger_maybe_split(ctx, d_scalars32, d_points64, n, window_bits, d_partial, true);
 }
 
 int snarkv_g1_fold_partials_dev(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64) {

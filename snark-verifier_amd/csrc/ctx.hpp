@@ -52,6 +52,7 @@ enum Slot {
   SLOT_MISC2,
   SLOT_TERM_CHAIN,
   SLOT_TERM_MAGS,
+  SLOT_SPLIT_PARTIALS,
   SLOT_COUNT
 };
 
@@ -69,6 +70,10 @@ struct snarkv_ctx {
   float stage_ms[SNARKV_PIP_STAGES];
   hipEvent_t ev[SNARKV_PIP_STAGES + 1];
   bool ev_ready;
+  // large MSMs run as pipelined 2^20-point chunks on private sub-contexts (capi.hip)
+  snarkv_ctx* sub[4];
+  hipEvent_t sub_ev[5];
+  bool sub_ready;
 };
 
 struct snarkv_dk {
@@ -87,7 +92,7 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
                        size_t n_msm, size_t n_terms, void* d_out);
 int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
                          void* d_out, bool partial_out);
-int launch_fold_partials(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64);
+int launch_fold_partials(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64, bool partial_out = false);
 int launch_validate(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int* bad_host);
 int launch_g2_prepare(snarkv_ctx* ctx, const void* d_g2x2_256, void* d_prep);
 int launch_decide(snarkv_ctx* ctx, const void* d_prep, const void* d_accs, size_t m, void* d_ok, void* d_gt);

@@ -627,9 +627,9 @@ __global__ void __launch_bounds__(64)
   }
 }
 
-int launch_fold_partials(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64) {
+int launch_fold_partials(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64, bool partial_out) {
   hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_partials, (uint32_t)count,
-                     (uint32_t*)d_out64, 0);
+                     (uint32_t*)d_out64, partial_out ? 1 : 0);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }

@@ -216,3 +216,35 @@ def test_batched_chunked_scalar_mul_all_chunkings(gpu_ctx, golden_msm, chunks, m
     # single-term segments: every edge scalar on its own
     offs3 = list(range(len(scal) + 1))
     assert gpu_ctx.msm_batched(sb, pb, offs3) == C.msm_batched(sb, pb, offs3)
+
+
+def test_large_msm_chunk_pipelined_form_matches_unsplit(gpu_ctx, monkeypatch):
+    """n >= 2^22 runs as pipelined 2^20-point chunks on sub-contexts (capi.hip
+    pippenger_maybe_split): same bytes as the single-launch form, for an exact
+    multiple and a ragged size, affine result and projective partial."""
+    import torch
+
+    import snark_verifier_amd as sv
+
+    n = (1 << 22) + 12345
+    ds = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+    dp = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+    gpu_ctx.sample_scalars_dev(31, n, ds.data_ptr())
+    gpu_ctx.sample_points_dev(32, n, dp.data_ptr())
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    res = {}
+    for split in ("0", "1"):
+        monkeypatch.setenv("SNARKV_PIP_SPLIT", split)
+        for m in (1 << 22, n):
+            gpu_ctx.msm_pippenger_dev(ds.data_ptr(), dp.data_ptr(), m, out.data_ptr(), 0)
+            gpu_ctx.sync()
+            res[(split, m)] = bytes(out.cpu().numpy())
+    for m in (1 << 22, n):
+        assert res[("0", m)] == res[("1", m)] != bytes(64)
+    # partial + fold (the multi-GPU building blocks) through the split path
+    monkeypatch.setenv("SNARKV_PIP_SPLIT", "1")
+    part = torch.zeros(sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+    gpu_ctx.msm_pippenger_partial_dev(ds.data_ptr(), dp.data_ptr(), n, part.data_ptr(), 0)
+    gpu_ctx.fold_partials_dev(part.data_ptr(), 1, out.data_ptr())
+    gpu_ctx.sync()
+    assert bytes(out.cpu().numpy()) == res[("1", n)]
