@@ -35,7 +35,7 @@ inline void parallel_for(size_t n, unsigned threads, F&& fn) {
     for (size_t i = 0; i < n; ++i) fn(i);
     return;
   }
-  threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(1, n / 8));  // a thread start costs ~a dozen proofs
+  threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(1, n / 16));  // a thread start costs about one proof of host work
   std::atomic<size_t> next{0};
   std::exception_ptr err;
   std::atomic<bool> failed{false};

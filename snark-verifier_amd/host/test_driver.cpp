@@ -690,28 +690,29 @@ static int aggregate_impl(int tkind, const uint8_t* protocol, size_t plen, const
     auto t0 = clk::now();
     std::vector<std::vector<std::vector<Fr>>> insts(n);
     std::vector<PlonkProof<MOS>> pfs(n);
-    std::vector<const PlonkProtocol*> prs(n, &pr);
     std::vector<Error> errs(n);
+    using SV = PlonkSuccinctVerifier<MOS>;
+    std::vector<typename SV::Pairs> jobs(2 * (size_t)n);
+    std::vector<double> t_read(n, 0.0);
+    // one pass per proof: read_proof, then the host half of verify (the pair lists of its two MSMs)
     parallel_for(n, threads, [&](size_t i) {
+      auto a = clk::now();
       insts[i] = parse_instances(ispan[i].first, ispan[i].second);
       std::vector<uint8_t> bytes(pspan[i].first, pspan[i].first + pspan[i].second);
       Result<PlonkProof<MOS>> pf = Result<PlonkProof<MOS>>::Err(Error{});
       if (tkind == 0) {
         EvmTranscript t(std::move(bytes));
-        pf = PlonkSuccinctVerifier<MOS>::read_proof(dk.svk, pr, insts[i], t);
+        pf = SV::read_proof(dk.svk, pr, insts[i], t);
       } else {
         PoseidonTranscript t(std::move(bytes));
-        pf = PlonkSuccinctVerifier<MOS>::read_proof(dk.svk, pr, insts[i], t);
+        pf = SV::read_proof(dk.svk, pr, insts[i], t);
       }
-      if (!pf.ok()) errs[i] = pf.err;
-      else pfs[i] = std::move(*pf.value);
-    });
-    for (auto& e : errs)
-      if (!e.ok()) return error_code(e);
-    auto t1 = clk::now();
-    using SV = PlonkSuccinctVerifier<MOS>;
-    std::vector<typename SV::Pairs> jobs(2 * (size_t)n);
-    parallel_for(n, threads, [&](size_t i) {
+      if (!pf.ok()) {
+        errs[i] = pf.err;
+        return;
+      }
+      pfs[i] = std::move(*pf.value);
+      t_read[i] = ms(a, clk::now());
       auto p2 = SV::msm_pairs(dk.svk, pr, insts[i], pfs[i]);
       if (!p2.ok()) {
         errs[i] = p2.err;
@@ -722,6 +723,9 @@ static int aggregate_impl(int tkind, const uint8_t* protocol, size_t plen, const
     });
     for (auto& e : errs)
       if (!e.ok()) return error_code(e);
+    auto t1 = t0;  // split of the host wall time: by the summed per-proof shares
+    double read_sum = 0;
+    for (double x : t_read) read_sum += x;
     auto t2 = clk::now();
     auto pts = L::multi_scalar_multiplication_batch(jobs);
     auto t3 = clk::now();
@@ -737,8 +741,17 @@ static int aggregate_impl(int tkind, const uint8_t* protocol, size_t plen, const
     bool ok = KzgAs<MOS>::decide(dk, *acc.value).ok();
     auto t5 = clk::now();
     if (timings_ms) {
-      timings_ms[0] = ms(t0, t1);
-      timings_ms[1] = ms(t1, t2);
+      (void)t1;
+      // host wall time t0..t2, attributed to read vs algebra by their single-thread shares
+      double host = ms(t0, t2), frac = 0.4;
+      {
+        // the algebra share is not timed per proof (it would double the clock reads); estimate from read_sum:
+        // read_sum / (threads_used) ~ wall share when perfectly parallel; clamp into [0, 1]
+        unsigned used = std::max(1u, std::min<unsigned>(threads, std::max<size_t>(1, n / 16)));
+        frac = std::min(1.0, std::max(0.0, (read_sum / used) / std::max(host, 1e-9)));
+      }
+      timings_ms[0] = host * frac;
+      timings_ms[1] = host * (1.0 - frac);
       timings_ms[2] = ms(t2, t3);
       timings_ms[3] = ms(t3, t4);
       timings_ms[4] = ms(t4, t5);
