@@ -42,6 +42,8 @@
 //
 // MFMA is deliberately unused: there is no dense contraction, the work is
 // 254-bit modular multiplication on the integer VALU (v_mad_i64_i32).
+#include <stdlib.h>
+#include <mutex>
 #include "ctx.hpp"
 #include "g1_29.cuh"
 #include "glv.cuh"
@@ -53,6 +55,9 @@ namespace snarkv {
 #endif
 #ifndef SNARKV_KCHUNK
 #define SNARKV_KCHUNK 4
+#endif
+#ifndef SNARKV_TILE_THREADS
+#define SNARKV_TILE_THREADS 512  // tile workgroups of k_prepare / k_sort_scatter (256 left the chip at 1 wave/SIMD)
 #endif
 #ifndef SNARKV_ACC_WAVES
 #define SNARKV_ACC_WAVES 3
@@ -114,7 +119,7 @@ __device__ __forceinline__ void for_each_digit(const uint4 kv, const PipParams& 
 // the (window, high digit bits) keys -> column `blockIdx` of the matrix M.
 // The identity (64 zero bytes) contributes nothing: its half-scalars are
 // stored as zero, so the sort never has to look at the points again.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SNARKV_TILE_THREADS)
     k_prepare(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points,
               G1Affine29* __restrict__ pts, uint4* __restrict__ glv, PipParams p, uint32_t* __restrict__ M) {
   extern __shared__ uint32_t lds[];  // nkeys counters
@@ -164,7 +169,7 @@ __global__ void __launch_bounds__(256)
 // Stable partition by (window, high bits).  M has been scanned (key-major,
 // tile-minor), so M[key][tile] is where this tile's items of that key start;
 // LDS cursors hand out the slots -- no global atomics.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SNARKV_TILE_THREADS)
     k_sort_scatter(const uint4* __restrict__ glv, PipParams p, const uint32_t* __restrict__ M,
                    uint2* __restrict__ tmp) {
   extern __shared__ uint32_t lds[];  // nkeys cursors
@@ -721,7 +726,7 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   STAGE_MARK();  // 0
   size_t lds1 = (size_t)p.nkeys * 4;
   SNARKV_HIP(hipMemsetAsync(d_M, 0, (size_t)mcount * 4, st));  // padding columns must read as zero
-  hipLaunchKernelGGL(k_prepare, dim3(p.nblk), dim3(256), lds1, st, (const uint32_t*)d_scalars,
+  hipLaunchKernelGGL(k_prepare, dim3(p.nblk), dim3(SNARKV_TILE_THREADS), lds1, st, (const uint32_t*)d_scalars,
                      (const uint32_t*)d_points, (G1Affine29*)d_pts, (uint4*)d_glv, p, (uint32_t*)d_M);
   STAGE_MARK();  // 1: prepare (GLV split, phi(P), to Montgomery) + digit histogram
   hipLaunchKernelGGL(k_scan_local, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (uint32_t*)d_blocksum, mcount);
@@ -729,13 +734,16 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   hipLaunchKernelGGL(k_scan_add, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (const uint32_t*)d_blocksum,
                      mcount);
   STAGE_MARK();  // 2: scan
-  hipLaunchKernelGGL(k_sort_scatter, dim3(p.nblk), dim3(256), lds1, st, (const uint4*)d_glv, p,
+  hipLaunchKernelGGL(k_sort_scatter, dim3(p.nblk), dim3(SNARKV_TILE_THREADS), lds1, st, (const uint4*)d_glv, p,
                      (const uint32_t*)d_M, (uint2*)d_tmp);
   size_t lds2 = ((size_t)(1u << p.low_bits) + 512) * 4 + (size_t)kSortCap * 8;
   hipLaunchKernelGGL(k_sort_level2, dim3(p.nkeys), dim3(512), lds2, st, (const uint2*)d_tmp, (const uint32_t*)d_M,
                      (const uint32_t*)d_total, p, (uint2*)d_entries, (uint32_t*)d_counts, (uint32_t*)d_offsets);
   STAGE_MARK();  // 3: partition + level-2 sort
   SNARKV_HIP(hipMemsetAsync(d_buckets, 0, (size_t)p.nb * sizeof(G1Xyzz29), st));
+  // (Tried: one shared low-priority HIP stream for every k_accumulate of a device, so that the small
+  // kernels of other in-flight MSMs never queue behind it -- no gain, 2.0-2.1 ms/MSM either way; the
+  // in-flight plateau is total VALU + HBM work)
   hipLaunchKernelGGL(k_accumulate, dim3((max_runs + 63) / 64), dim3(64), 0, st, (const uint2*)d_entries,
                      (const uint32_t*)d_total, (const G1Affine29*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
                      (G1Xyzz29*)d_seg_parts);
