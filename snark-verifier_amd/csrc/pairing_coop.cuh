@@ -1,20 +1,8 @@
-// Lane-level pieces of the workgroup-cooperative pairing (decider_coop.hip).
-//
-// Why: a pairing is ~20 000 dependent Fq products.  One lane per pairing
-// (decider.hip v1) leaves a single `decide` at 45-55 ms on MI355X -- 30x slower
-// than a CPU core -- because a lone lane issues one instruction every ~5
-// cycles.  Here ONE workgroup of 256 lanes serves ONE accumulator and every
-// Fq12 multiplication is a single parallel round:
-//   round 1  204 lanes: one Fq product each  (144 a_s b_t  + 60 (9 a_s) b_t for
-//            the terms that wrap through w^6 = 9 + u)
-//   round 2  48 lanes: signed sums of <= 6 products  (tables: gen_coop_tables.py)
-//   round 3  12 lanes: sum of 4 partials -> coefficient c, and 9c for later
-// Flat basis: coefficient index c = 2 i + e  <->  u^e w^i.
-// These functions are host-compilable so tests/hosttest can emulate the lanes
-// and validate the tables against the tower arithmetic.
+// Flat basis of the workgroup-cooperative pairing: coefficient index
+// c = 2 i + e  <->  u^e w^i  (the rounds themselves: pairing_coop29.cuh, decider.hip).
+// Host-compilable so tests/hosttest can emulate the lanes against the tower arithmetic.
 #pragma once
 #include "pairing.cuh"
-#include "pairing_coop_tables.h"
 
 namespace snarkv {
 
@@ -34,35 +22,6 @@ SNARKV_HD Fq12 coop_tower_from_flat(const Fq flat[12]) {
     g[i]->c1 = flat[2 * i + 1];
   }
   return f;
-}
-
-SNARKV_HD Fq fq_mul9(const Fq& x) {
-  Fq x2 = fq_dbl(x), x4 = fq_dbl(x2), x8 = fq_dbl(x4);
-  return fq_add(x8, x);
-}
-
-// round 1, lane l < COOP_NPROD
-SNARKV_HD Fq coop_product(int l, const Fq* a, const Fq* a9, const Fq* b) {
-  unsigned e = kCoopProd[l];
-  unsigned s = e & 15u, t = (e >> 4) & 15u;
-  return fq_mul((e >> 8) ? a9[s] : a[s], b[t]);
-}
-
-// round 2, lane q < 48: partial sum for coefficient q/4
-SNARKV_HD Fq coop_stage1(int q, const Fq* prods) {
-  Fq acc = fq_zero();
-  for (int k = 0; k < COOP_STAGE1_TERMS; ++k) {
-    unsigned e = kCoopStage1[q][k];
-    if (e == 0xFFFFu) break;
-    const Fq& p = prods[e & 0x7FFFu];
-    acc = (e & 0x8000u) ? fq_sub(acc, p) : fq_add(acc, p);
-  }
-  return acc;
-}
-
-// round 3, lane c < 12
-SNARKV_HD Fq coop_stage2(int c, const Fq* parts) {
-  return fq_add(fq_add(parts[4 * c], parts[4 * c + 1]), fq_add(parts[4 * c + 2], parts[4 * c + 3]));
 }
 
 }  // namespace snarkv

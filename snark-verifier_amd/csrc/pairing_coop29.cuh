@@ -1,20 +1,18 @@
 // Lane-level pieces of the workgroup-cooperative pairing on the lazy 9x29-bit
-// field (see pairing_coop.cuh for the round structure and the tables; this is
-// the arithmetic the shipped `k_decide` uses).
+// field: the arithmetic the shipped `k_decide` uses.
 //
-// Why 29-bit here too: on the exact 8x32 field every signed sum of the two
-// reduction stages is a dependent carry chain, and gfx950 needs two wait
-// states between a VALU writing a carry and the VALU consuming it -- the
-// cheap-looking additions cost as much as the products.  In the lazy form a
-// sum is nine independent `v_add_u32`, and one float-estimated quotient
-// (`fq29_reduce_small`) squeezes the 22-term coefficient back below 1.5p.
+// Why 29-bit here too: on the exact 8x32 field every signed sum of a reduction
+// is a dependent carry chain, and gfx950 needs two wait states between a VALU
+// writing a carry and the VALU consuming it -- the cheap-looking additions cost
+// as much as the products.  In the lazy form a sum is nine independent
+// `v_add_u32`, and one float-estimated quotient (`fq29_reduce_small`) squeezes
+// the up-to-22-term coefficient back below 1.5p.
 //
-// Invariants of a coefficient c held in LDS: carry-normalised, |c| < 1.5p;
-// c9 = 9c carry-normalised.  Products (a or 9a) * b then stay inside the mul
-// budget (|limb| < 2^29 both sides) and every product value inside (-p/8, 9p/8).
+// Invariant of a coefficient c held in LDS: carry-normalised, |c| < 1.5p, so both
+// operands of a product stay inside the multiplier budget (|limb| < 2^29) and every
+// fused two-product value inside (-p/16, 17p/16).
 #pragma once
 #include "fq29.cuh"
-#include "pairing_coop_tables.h"
 
 namespace snarkv {
 
@@ -34,39 +32,9 @@ SNARKV_HD Fq2_29 frob29_gamma(int k, int i) {
   return r;
 }
 
-// round 1, lane l < COOP_NPROD
-SNARKV_HD Fq29 coop29_product(unsigned desc, const Fq29* a, const Fq29* a9, const Fq29* b) {
-  unsigned s = desc & 15u, t = (desc >> 4) & 15u;
-  return fq29_mul((desc >> 8) ? a9[s] : a[s], b[t]);
-}
-
-// round 2, lane q < 48: signed sum of <= 6 products, three at a time so the
-// lazy limbs stay below 2^31; result carry-normalised
-SNARKV_HD Fq29 coop29_stage1(const unsigned short* ent, const Fq29* prods) {
-  Fq29 h[2];
-  for (int half = 0; half < 2; ++half) {
-    Fq29 acc = fq29_zero();
-    for (int k = 3 * half; k < 3 * half + 3; ++k) {
-      unsigned e = ent[k];
-      if (e == 0xFFFFu) continue;
-      const Fq29& p = prods[e & 0x7FFFu];
-      acc = (e & 0x8000u) ? fq29_sub(acc, p) : fq29_add(acc, p);
-    }
-    h[half] = fq29_norm(acc);
-  }
-  return fq29_norm(fq29_add(h[0], h[1]));
-}
-
-// round 3, lane c < 12: sum of four partials, modular squeeze
-SNARKV_HD Fq29 coop29_stage2(int c, const Fq29* parts) {
-  Fq29 s = fq29_add(fq29_add(parts[4 * c], parts[4 * c + 1]), fq29_add(parts[4 * c + 2], parts[4 * c + 3]));
-  return fq29_reduce_small(fq29_norm(s));
-}
-
-SNARKV_HD Fq29 coop29_times9(const Fq29& c) { return fq29_mul_small_norm(c, 9); }
-
 // ---------------------------------------------------------------------------
-// Second-generation round ("coop3"), the one `k_decide` runs.
+// The round `k_decide` runs ("coop3"; the first version of this round, 204 single
+// products + two LDS reduction stages driven by generated tables, was 1.5x slower).
 //
 // A = sum_i (a[2i] + a[2i+1] u) w^i, same for B.  With V(k') = sum_{i1+i2=k'}
 // a_{i1} b_{i2} (an Fq2 value, k' = 0..10) the product is

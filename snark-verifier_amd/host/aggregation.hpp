@@ -1,0 +1,109 @@
+// Native proof aggregation, end to end: the flow of the reference's
+// examples/evm-verifier-with-accumulator.rs:357-385 without the circuit --
+//   per proof   PlonkSuccinctVerifier::{read_proof, verify}   -> one KzgAccumulator (+ its old ones)
+//   then        KzgAs::create_proof over all accumulators      -> ONE accumulator
+//   then        KzgAs::decide                                  -> accept / reject
+// arranged for the device: the host front half (transcript hashing, Fr algebra)
+// of all proofs runs on `threads` host threads, ALL their MSMs go out as one
+// segmented launch, the accumulation step is a second launch, the pairing a third.
+#pragma once
+#include <chrono>
+
+#include "plonk.hpp"
+#include "transcript.hpp"
+
+namespace snarkv_host {
+
+struct AggregationTimings {  // milliseconds, wall clock
+  double read_proofs = 0, fr_algebra = 0, msm_device = 0, accumulate = 0, decide = 0, total = 0;
+};
+
+// MOS: Gwc19 | Bdfg21.  TR: EvmTranscript | PoseidonTranscript (the transcript of the INNER proofs;
+// the accumulation step uses a fresh EvmTranscript, as the outer EVM proof would).
+template <class MOS, class TR>
+struct Aggregator {
+  using SV = PlonkSuccinctVerifier<MOS>;
+
+  // succinct-verify every proof and fold the accumulators into one
+  static Result<KzgAccumulator> aggregate(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
+                                          const std::vector<std::vector<std::vector<Fr>>>& instances,
+                                          const std::vector<std::vector<uint8_t>>& proofs, unsigned threads,
+                                          AggregationTimings* tm = nullptr) {
+    using R = Result<KzgAccumulator>;
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const size_t n = proofs.size();
+    if (n == 0 || instances.size() != n) return R::Err(Error{Error::InvalidInstances, "one instance set per proof"});
+    auto t0 = clk::now();
+    std::vector<PlonkProof<MOS>> pfs(n);
+    std::vector<Error> errs(n);
+    std::vector<typename SV::Pairs> jobs(2 * n);
+    std::vector<double> t_read(n, 0.0);
+    // one pass per proof: read_proof, then the host half of verify (the pair lists of its two MSMs)
+    parallel_for(n, threads, [&](size_t i) {
+      auto a = clk::now();
+      TR t(proofs[i]);
+      auto pf = SV::read_proof(svk, pr, instances[i], t);
+      if (!pf.ok()) {
+        errs[i] = pf.err;
+        return;
+      }
+      pfs[i] = std::move(*pf.value);
+      t_read[i] = ms(a, clk::now());
+      auto p2 = SV::msm_pairs(svk, pr, instances[i], pfs[i]);
+      if (!p2.ok()) {
+        errs[i] = p2.err;
+        return;
+      }
+      jobs[2 * i] = std::move(p2.value->first);
+      jobs[2 * i + 1] = std::move(p2.value->second);
+    });
+    for (auto& e : errs)
+      if (!e.ok()) return R::Err(e);
+    auto t2 = clk::now();
+    auto pts = L::multi_scalar_multiplication_batch(jobs);
+    auto t3 = clk::now();
+    std::vector<KzgAccumulator> accs;
+    for (size_t i = 0; i < n; ++i) {
+      accs.push_back(KzgAccumulator{pts[2 * i], pts[2 * i + 1]});
+      accs.insert(accs.end(), pfs[i].old_accumulators.begin(), pfs[i].old_accumulators.end());
+    }
+    EvmTranscript at;
+    auto acc = KzgAs<MOS>::create_proof(KzgAsProvingKey{}, accs, at, Fr());
+    auto t4 = clk::now();
+    if (tm) {
+      double host = ms(t0, t2), read_sum = 0;
+      for (double x : t_read) read_sum += x;
+      // the per-proof read share is timed; the algebra share is the rest of the parallel pass
+      unsigned used = std::max(1u, std::min<unsigned>(threads, (unsigned)std::max<size_t>(1, n / 16)));
+      double frac = std::min(1.0, std::max(0.0, (read_sum / used) / std::max(host, 1e-9)));
+      tm->read_proofs = host * frac;
+      tm->fr_algebra = host * (1.0 - frac);
+      tm->msm_device = ms(t2, t3);
+      tm->accumulate = ms(t3, t4);
+      tm->total = ms(t0, t4);
+    }
+    return acc;
+  }
+
+  // ... and decide it: Ok(()) / Err(AssertionFailure), as `PlonkVerifier::verify` + `decide`
+  static Error aggregate_and_decide(const KzgDecidingKey& dk, const PlonkProtocol& pr,
+                                    const std::vector<std::vector<std::vector<Fr>>>& instances,
+                                    const std::vector<std::vector<uint8_t>>& proofs, unsigned threads,
+                                    AggregationTimings* tm = nullptr, KzgAccumulator* acc_out = nullptr) {
+    using clk = std::chrono::steady_clock;
+    dk.handle();  // G2 line tables: per-key setup, not per-proof work
+    auto acc = aggregate(dk.svk, pr, instances, proofs, threads, tm);
+    if (!acc.ok()) return acc.err;
+    if (acc_out) *acc_out = *acc.value;
+    auto a = clk::now();
+    Error e = KzgAs<MOS>::decide(dk, *acc.value);
+    if (tm) {
+      tm->decide = std::chrono::duration<double, std::milli>(clk::now() - a).count();
+      tm->total += tm->decide;
+    }
+    return e;
+  }
+};
+
+}  // namespace snarkv_host

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 
+#include "aggregation.hpp"
 #include "pcs.hpp"
 #include "plonk.hpp"
 #include "transcript.hpp"
@@ -650,24 +651,41 @@ static int plonk_verify_impl(int tkind, const uint8_t* protocol, size_t plen, co
   });
 }
 
-// The reference's aggregation flow on N proofs of one protocol, natively and end to end
-// (examples/evm-verifier-with-accumulator.rs:357-385 without the circuit):
-//   per proof  PlonkSuccinctVerifier::{read_proof, verify}     host (threads) + ONE segmented MSM launch
-//   then       KzgAs::create_proof over the N accumulators      host + one segmented MSM launch
-//   then       KzgAs::decide                                    one pairing check on the device
-// timings_ms[0..5] = read_proof, host algebra (msm pair lists), device MSMs, KzgAs, decide, total.
+// `Aggregator::aggregate_and_decide` (host/aggregation.hpp) on N proofs of one protocol, inputs in the
+// tests' wire format.  timings_ms[0..5] = read_proof, host algebra, device MSMs, KzgAs, decide, total.
+template <class MOS, class TR>
+static int aggregate_run(const PlonkProtocol& pr, const KzgDecidingKey& dk,
+                         const std::vector<std::vector<std::vector<Fr>>>& insts,
+                         const std::vector<std::vector<uint8_t>>& proofs, unsigned threads, double* timings_ms,
+                         uint8_t* acc_out128) {
+  AggregationTimings tm;
+  KzgAccumulator acc;
+  Error e = Aggregator<MOS, TR>::aggregate_and_decide(dk, pr, insts, proofs, threads, &tm, &acc);
+  if (timings_ms) {
+    timings_ms[0] = tm.read_proofs;
+    timings_ms[1] = tm.fr_algebra;
+    timings_ms[2] = tm.msm_device;
+    timings_ms[3] = tm.accumulate;
+    timings_ms[4] = tm.decide;
+    timings_ms[5] = tm.total;
+  }
+  if (e.ok()) {
+    if (acc_out128) acc.to_bytes(acc_out128);
+    return 1;
+  }
+  if (e.kind == Error::AssertionFailure && acc_out128) acc.to_bytes(acc_out128);
+  return error_code(e);
+}
+
 template <class MOS>
 static int aggregate_impl(int tkind, const uint8_t* protocol, size_t plen, const uint8_t* instances, size_t ilen,
                           const uint8_t* proofs, size_t prlen, uint32_t n, const uint8_t* dk320, unsigned threads,
                           double* timings_ms, uint8_t* acc_out128) {
   return guarded([&] {
-    using clk = std::chrono::steady_clock;
-    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     PlonkProtocol pr = parse_protocol(protocol, plen);
     KzgDecidingKey dk(G1Affine::from_bytes(dk320), G2Affine::from_bytes(dk320 + 64), G2Affine::from_bytes(dk320 + 192));
-    dk.handle();  // the G2 line tables are per-key setup, not per-proof work
-    // split the concatenated inputs (cheap, serial)
-    std::vector<std::pair<const uint8_t*, size_t>> ispan, pspan;
+    std::vector<std::vector<std::vector<Fr>>> insts;
+    std::vector<std::vector<uint8_t>> pbytes;
     const uint8_t* ip = instances;
     const uint8_t* pp = proofs;
     for (uint32_t i = 0; i < n; ++i) {
@@ -678,87 +696,17 @@ static int aggregate_impl(int tkind, const uint8_t* protocol, size_t plen, const
         rd.need(32 * (size_t)m);
         rd.p += 32 * (size_t)m;
       }
-      ispan.emplace_back(ip, (size_t)(rd.p - ip));
+      insts.push_back(parse_instances(ip, (size_t)(rd.p - ip)));
       ip = rd.p;
       if ((size_t)(proofs + prlen - pp) < 4) throw Panic("truncated proofs");
       uint32_t len;
       memcpy(&len, pp, 4);
       if ((size_t)(proofs + prlen - pp) < 4 + (size_t)len) throw Panic("proof length runs past the buffer");
-      pspan.emplace_back(pp + 4, len);
+      pbytes.emplace_back(pp + 4, pp + 4 + len);
       pp += 4 + len;
     }
-    auto t0 = clk::now();
-    std::vector<std::vector<std::vector<Fr>>> insts(n);
-    std::vector<PlonkProof<MOS>> pfs(n);
-    std::vector<Error> errs(n);
-    using SV = PlonkSuccinctVerifier<MOS>;
-    std::vector<typename SV::Pairs> jobs(2 * (size_t)n);
-    std::vector<double> t_read(n, 0.0);
-    // one pass per proof: read_proof, then the host half of verify (the pair lists of its two MSMs)
-    parallel_for(n, threads, [&](size_t i) {
-      auto a = clk::now();
-      insts[i] = parse_instances(ispan[i].first, ispan[i].second);
-      std::vector<uint8_t> bytes(pspan[i].first, pspan[i].first + pspan[i].second);
-      Result<PlonkProof<MOS>> pf = Result<PlonkProof<MOS>>::Err(Error{});
-      if (tkind == 0) {
-        EvmTranscript t(std::move(bytes));
-        pf = SV::read_proof(dk.svk, pr, insts[i], t);
-      } else {
-        PoseidonTranscript t(std::move(bytes));
-        pf = SV::read_proof(dk.svk, pr, insts[i], t);
-      }
-      if (!pf.ok()) {
-        errs[i] = pf.err;
-        return;
-      }
-      pfs[i] = std::move(*pf.value);
-      t_read[i] = ms(a, clk::now());
-      auto p2 = SV::msm_pairs(dk.svk, pr, insts[i], pfs[i]);
-      if (!p2.ok()) {
-        errs[i] = p2.err;
-        return;
-      }
-      jobs[2 * i] = std::move(p2.value->first);
-      jobs[2 * i + 1] = std::move(p2.value->second);
-    });
-    for (auto& e : errs)
-      if (!e.ok()) return error_code(e);
-    auto t1 = t0;  // split of the host wall time: by the summed per-proof shares
-    double read_sum = 0;
-    for (double x : t_read) read_sum += x;
-    auto t2 = clk::now();
-    auto pts = L::multi_scalar_multiplication_batch(jobs);
-    auto t3 = clk::now();
-    std::vector<KzgAccumulator> accs;
-    for (uint32_t i = 0; i < n; ++i) {
-      accs.push_back(KzgAccumulator{pts[2 * i], pts[2 * i + 1]});
-      accs.insert(accs.end(), pfs[i].old_accumulators.begin(), pfs[i].old_accumulators.end());
-    }
-    EvmTranscript at;
-    auto acc = KzgAs<MOS>::create_proof(KzgAsProvingKey{}, accs, at, Fr());
-    if (!acc.ok()) return error_code(acc.err);
-    auto t4 = clk::now();
-    bool ok = KzgAs<MOS>::decide(dk, *acc.value).ok();
-    auto t5 = clk::now();
-    if (timings_ms) {
-      (void)t1;
-      // host wall time t0..t2, attributed to read vs algebra by their single-thread shares
-      double host = ms(t0, t2), frac = 0.4;
-      {
-        // the algebra share is not timed per proof (it would double the clock reads); estimate from read_sum:
-        // read_sum / (threads_used) ~ wall share when perfectly parallel; clamp into [0, 1]
-        unsigned used = std::max(1u, std::min<unsigned>(threads, std::max<size_t>(1, n / 16)));
-        frac = std::min(1.0, std::max(0.0, (read_sum / used) / std::max(host, 1e-9)));
-      }
-      timings_ms[0] = host * frac;
-      timings_ms[1] = host * (1.0 - frac);
-      timings_ms[2] = ms(t2, t3);
-      timings_ms[3] = ms(t3, t4);
-      timings_ms[4] = ms(t4, t5);
-      timings_ms[5] = ms(t0, t5);
-    }
-    if (acc_out128) acc.value->to_bytes(acc_out128);
-    return ok ? 1 : 0;
+    return tkind == 0 ? aggregate_run<MOS, EvmTranscript>(pr, dk, insts, pbytes, threads, timings_ms, acc_out128)
+                      : aggregate_run<MOS, PoseidonTranscript>(pr, dk, insts, pbytes, threads, timings_ms, acc_out128);
   });
 }
 

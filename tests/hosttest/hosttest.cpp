@@ -219,48 +219,6 @@ void ht29_double_n(const uint8_t* p, int n, uint8_t* out) {
   a = xyzz29_double(a);
   store_g1_29(xyzz29_to_affine(xyzz29_double_n(a, n)), out);
 }
-// lane-by-lane emulation of the cooperative Fq12 product (pairing_coop.cuh tables)
-void ht_coop_fq12_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
-  Fq fa[12], fa9[12], fb[12], prods[COOP_NPROD], parts[48], fc[12];
-  coop_flat_from_tower(load_fq12(a), fa);
-  coop_flat_from_tower(load_fq12(b), fb);
-  for (int c = 0; c < 12; ++c) fa9[c] = fq_mul9(fa[c]);
-  for (int l = 0; l < COOP_NPROD; ++l) prods[l] = coop_product(l, fa, fa9, fb);
-  for (int q = 0; q < 48; ++q) parts[q] = coop_stage1(q, prods);
-  for (int c = 0; c < 12; ++c) fc[c] = coop_stage2(c, parts);
-  store_fq12(coop_tower_from_flat(fc), out);
-}
-// the same emulation on the lazy 29-bit field, iterated `rounds` times
-// (f <- f*b) to exercise the magnitude invariants across rounds
-void ht_coop29_fq12_mul_iter(const uint8_t* a, const uint8_t* b, int rounds, uint8_t* out) {
-  Fq fa8[12], fb8[12];
-  coop_flat_from_tower(load_fq12(a), fa8);
-  coop_flat_from_tower(load_fq12(b), fb8);
-  Fq29 fa[12], fa9[12], fb[12], prods[COOP_NPROD], parts[48];
-  for (int c = 0; c < 12; ++c) {
-    uint32_t w[8];
-    fq_to_canonical(fa8[c], w);
-    fa[c] = fq29_canon_residue(fq29_from_canonical(w));
-    fa9[c] = coop29_times9(fa[c]);
-    fq_to_canonical(fb8[c], w);
-    fb[c] = fq29_canon_residue(fq29_from_canonical(w));
-  }
-  for (int r = 0; r < rounds; ++r) {
-    for (int l = 0; l < COOP_NPROD; ++l) prods[l] = coop29_product(kCoopProd[l], fa, fa9, fb);
-    for (int q = 0; q < 48; ++q) parts[q] = coop29_stage1(kCoopStage1[q], prods);
-    for (int c = 0; c < 12; ++c) {
-      fa[c] = coop29_stage2(c, parts);
-      fa9[c] = coop29_times9(fa[c]);
-    }
-  }
-  Fq fc[12];
-  for (int c = 0; c < 12; ++c) {
-    uint32_t w[8];
-    fq29_to_canonical(fa[c], w);
-    fc[c] = fq_from_canonical(w);
-  }
-  store_fq12(coop_tower_from_flat(fc), out);
-}
 // the round k_decide runs (pairing_coop29.cuh "coop3"): 96 lanes emulated one by
 // one, butterflies replaced by explicit sums.  mode 0: f <- f*b each round;
 // mode 1: f <- f*f, then f <- f*b (the Miller-loop pattern, both operands lazy).

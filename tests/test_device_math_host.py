@@ -229,39 +229,6 @@ def test_g1_29_jacobian_double_chain(hosttest_lib):
         assert O.g1_from_bytes(o.raw) == O.g1_mul(P, pow(2, n + 1, O.R))
 
 
-def test_cooperative_fq12_tables(hosttest_lib):
-    """Lane-by-lane emulation of the workgroup-cooperative Fq12 product
-    (csrc/pairing_coop.cuh + generated tables) vs the tower product."""
-    rng = random.Random(12)
-    o = _buf(384)
-    for _ in range(5):
-        A, B = _rfq12(rng), _rfq12(rng)
-        hosttest_lib.ht_coop_fq12_mul(A.to_bytes(), B.to_bytes(), o)
-        assert o.raw == (A * B).to_bytes()
-
-
-def test_cooperative_fq12_rounds_on_lazy_field(hosttest_lib):
-    """The shipped decide kernel's arithmetic (csrc/pairing_coop29.cuh): chained
-    cooperative products on the 9x29-bit lazy field keep their magnitude
-    invariants and stay exact, including all-(p-1) coefficients."""
-    rng = random.Random(13)
-    o = _buf(384)
-    for rounds in (1, 2, 5, 40):
-        A, B = _rfq12(rng), _rfq12(rng)
-        hosttest_lib.ht_coop29_fq12_mul_iter(A.to_bytes(), B.to_bytes(), rounds, o)
-        exp = A
-        for _ in range(rounds):
-            exp = exp * B
-        assert o.raw == exp.to_bytes()
-    m = O.Fq2(O.P - 1, O.P - 1)
-    M = O.Fq12(O.Fq6(m, m, m), O.Fq6(m, m, m))
-    hosttest_lib.ht_coop29_fq12_mul_iter(M.to_bytes(), M.to_bytes(), 30, o)
-    exp = M
-    for _ in range(30):
-        exp = exp * M
-    assert o.raw == exp.to_bytes()
-
-
 def test_fq29_fused_two_product(hosttest_lib):
     """fq29_mul2: a*b + c*d (and a*b - c*d through a limb-wise negated c) with one reduction."""
     rng = random.Random(21)
