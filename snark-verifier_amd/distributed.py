@@ -78,3 +78,67 @@ def gpu_sharded_msm(ctx, d_scalars, d_points, n_total, window_bits=0):
         return out
 
     return ShardedMsm(partial_fn, fold_fn, G1_PARTIAL_BYTES).run(n_total)
+
+
+@dataclass
+class ShardedAggregation:
+    """Proof-sharded aggregation: proofs are independent,
+    so rank g succinct-verifies ITS contiguous shard of the proofs
+    (`verify_fn(lo, hi) -> bytes`, 128 bytes per accumulator), the accumulators are
+    all-gathered (a few KiB: latency-bound) and every rank folds them and decides
+    (`combine_fn(all_accumulator_bytes) -> (acc128, ok)`), so all ranks hold the same
+    verdict.  No other exchange: the per-proof MSMs never leave their GPU."""
+
+    verify_fn: Callable
+    combine_fn: Callable
+
+    def run(self, n_proofs: int):
+        import torch
+        import torch.distributed as dist
+
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        lo, hi = shard_range(n_proofs, rank, world)
+        local = bytes(self.verify_fn(lo, hi)) if hi > lo else b""
+        assert len(local) % 128 == 0
+        if world == 1:
+            return self.combine_fn(local)
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+        mine = torch.tensor([len(local)], dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(sizes, mine)
+        cap = int(sizes.max().item())
+        buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        if local:
+            buf[: len(local)] = torch.frombuffer(bytearray(local), dtype=torch.uint8).to(dev)
+        gathered = torch.zeros(world * cap, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(gathered, buf)
+        g = bytes(gathered.cpu().numpy())
+        allb = b"".join(g[r * cap: r * cap + int(sizes[r].item())] for r in range(world))  # rank order = proof order
+        return self.combine_fn(allb)
+
+
+def gpu_sharded_aggregation(host_lib, mos, tkind, protocol_bytes, instances_packed, proofs, dk320):
+    """Product wiring over the host mirror (libsnarkv_host.so): `instances_packed[i]` and
+    `proofs[i]` are the i-th proof's packed instances / proof bytes; returns (acc128, ok)."""
+    import ctypes
+
+    def verify_fn(lo, hi):
+        ib = b"".join(instances_packed[lo:hi])
+        prb = b"".join(len(p).to_bytes(4, "little") + p for p in proofs[lo:hi])
+        out = ctypes.create_string_buffer(128 * 8 * (hi - lo))
+        n = ctypes.c_uint32(0)
+        rc = host_lib.hd_plonk_succinct_verify(mos, tkind, protocol_bytes, len(protocol_bytes), ib, len(ib), prb, len(prb),
+                                               hi - lo, dk320, out, len(out), ctypes.byref(n))
+        if rc != 1:
+            raise RuntimeError("succinct verification failed on this shard: %d" % rc)
+        return out.raw[: 128 * n.value]
+
+    def combine_fn(allb):
+        acc = ctypes.create_string_buffer(128)
+        rc = host_lib.hd_kzg_as_accumulate_and_decide(allb, len(allb) // 128, dk320, acc)
+        if rc < 0:
+            raise RuntimeError("accumulation failed: %d" % rc)
+        return acc.raw, rc == 1
+
+    return ShardedAggregation(verify_fn, combine_fn).run(len(proofs))

@@ -595,7 +595,7 @@ int hd_poseidon_permute(int t, int r_f, int r_p, uint8_t* state) {
 template <class MOS>
 static int plonk_verify_impl(int tkind, const uint8_t* protocol, size_t plen, const uint8_t* instances, size_t ilen,
                              const uint8_t* proofs, size_t prlen, uint32_t n, const uint8_t* dk320, uint8_t* accs_out,
-                             size_t accs_cap, uint32_t* n_accs) {
+                             size_t accs_cap, uint32_t* n_accs, bool decide = true) {
   return guarded([&] {
     PlonkProtocol pr = parse_protocol(protocol, plen);
     KzgDecidingKey dk(G1Affine::from_bytes(dk320), G2Affine::from_bytes(dk320 + 64), G2Affine::from_bytes(dk320 + 192));

@@ -81,3 +81,83 @@ def test_shard_range_is_reference_chunking():
             cover += list(range(lo, min(hi, lo + 3)))
         los = [shard_range(n, r, w)[0] for r in range(w)]
         assert los == sorted(los) and shard_range(n, w - 1, w)[1] == n
+
+
+def _agg_worker(rank, world, port, n_proofs, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import random
+
+    import torch.distributed as dist
+
+    import bn254 as O
+    import kzg as K
+    import transcript as T
+    from snark_verifier_amd.distributed import ShardedAggregation, shard_range
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    secret = 0x5EC2E7
+    rng = random.Random(99)  # every rank derives the same "proofs": one valid accumulator each
+    accs = []
+    for _ in range(n_proofs):
+        a = rng.randrange(1, O.R)
+        accs.append((O.g1_mul(O.G1_GEN, secret * a % O.R), O.g1_mul(O.G1_GEN, a)))
+
+    def verify_fn(lo, hi):  # oracle double of the succinct verifier: the shard's accumulators
+        return b"".join(O.g1_to_bytes(l) + O.g1_to_bytes(r) for l, r in accs[lo:hi])
+
+    def combine_fn(allb):  # oracle double of KzgAs::create_proof + decide
+        pairs = [(O.g1_from_bytes(allb[128 * i:128 * i + 64]), O.g1_from_bytes(allb[128 * i + 64:128 * i + 128]))
+                 for i in range(len(allb) // 128)]
+        t = T.EvmTranscript()
+        for l, r in pairs:
+            t.common_ec_point(l)
+            t.common_ec_point(r)
+        lhs, rhs = K.kzg_as_verify(pairs, t.squeeze_challenge())
+        return O.g1_to_bytes(lhs) + O.g1_to_bytes(rhs), lhs == O.g1_mul(rhs, secret)
+
+    acc, ok = ShardedAggregation(verify_fn, combine_fn).run(n_proofs)
+    q.put((rank, acc, ok, shard_range(n_proofs, rank, world)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_proofs", [1, 2, 7])
+def test_sharded_aggregation_two_ranks_agree(n_proofs):
+    """Proof-sharded aggregation (distributed.py ShardedAggregation): uneven shards, an empty
+    shard (n = 1), gather order = proof order, both ranks reach the same accumulator + verdict."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + n_proofs) % 2000
+    procs = [ctx.Process(target=_agg_worker, args=(r, 2, port, n_proofs, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+    assert res[0][1] == res[1][1] and res[0][2] is True and res[1][2] is True
+    assert res[0][3][1] == res[1][3][0]  # contiguous shards
+    # single-process reference: same fold over all accumulators in proof order
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import random
+
+    import bn254 as O
+    import kzg as K
+    import transcript as T
+
+    rng = random.Random(99)
+    accs = []
+    for _ in range(n_proofs):
+        a = rng.randrange(1, O.R)
+        accs.append((O.g1_mul(O.G1_GEN, 0x5EC2E7 * a % O.R), O.g1_mul(O.G1_GEN, a)))
+    t = T.EvmTranscript()
+    for l, r in accs:
+        t.common_ec_point(l)
+        t.common_ec_point(r)
+    lhs, rhs = K.kzg_as_verify(accs, t.squeeze_challenge())
+    assert res[0][1] == O.g1_to_bytes(lhs) + O.g1_to_bytes(rhs)

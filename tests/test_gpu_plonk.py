@@ -237,3 +237,32 @@ def test_end_to_end_aggregation_of_64_proofs(H, threads):
     bad[4 + first_len + 4 + 700] ^= 2  # inside the payload of the second proof
     rc = H.hd_aggregate_end_to_end(0, 0, pb, len(pb), ib, len(ib), bytes(bad), len(bad), n, dk, threads, tm, acc)
     assert rc in (0, -10)
+
+
+def test_proof_sharded_aggregation_wiring(H):
+    """distributed.gpu_sharded_aggregation at world size 1 (the driver runs N > 1): succinct
+    verify of the fixture's 64 proofs -> KzgAs -> decide through the host mirror, equal to the
+    fixture's aggregated accumulator."""
+    import struct
+
+    from snark_verifier_amd import distributed as D
+
+    H.hd_plonk_succinct_verify.argtypes = H.hd_plonk_verify.argtypes
+    H.hd_kzg_as_accumulate_and_decide.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p]
+    n, pb, ib, prb, dk, exp = load_bench_blob()
+    insts, proofs, off = [], [], 0
+    for _ in range(n):  # split the packed streams per proof
+        cols, = struct.unpack_from("<I", ib, off)
+        o2 = off + 4
+        for _ in range(cols):
+            m, = struct.unpack_from("<I", ib, o2)
+            o2 += 4 + 32 * m
+        insts.append(ib[off:o2])
+        off = o2
+    off = 0
+    for _ in range(n):
+        ln, = struct.unpack_from("<I", prb, off)
+        proofs.append(prb[off + 4:off + 4 + ln])
+        off += 4 + ln
+    acc, ok = D.gpu_sharded_aggregation(H, 0, 0, pb, insts, proofs, dk)
+    assert ok and acc == exp
