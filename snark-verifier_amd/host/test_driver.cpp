@@ -647,6 +647,7 @@ static int plonk_verify_impl(int tkind, const uint8_t* protocol, size_t plen, co
       if (128 * all.size() > accs_cap) return -6;
       for (size_t i = 0; i < all.size(); ++i) all[i].to_bytes(accs_out + 128 * i);
     }
+    if (!decide) return 1;
     return KzgAs<MOS>::decide_all(dk, all).ok() ? 1 : 0;
   });
 }
@@ -717,6 +718,33 @@ extern "C" int hd_aggregate_end_to_end(int mos, int tkind, const uint8_t* protoc
                                           timings_ms, acc_out128)
                   : aggregate_impl<Bdfg21>(tkind, protocol, plen, instances, ilen, proofs, prlen, n, dk320, threads,
                                            timings_ms, acc_out128);
+}
+
+// `PlonkSuccinctVerifier` only (no pairing): the per-rank step of proof-sharded aggregation
+extern "C" int hd_plonk_succinct_verify(int mos, int tkind, const uint8_t* protocol, size_t plen, const uint8_t* instances,
+                                        size_t ilen, const uint8_t* proofs, size_t prlen, uint32_t n,
+                                        const uint8_t* dk320, uint8_t* accs_out, size_t accs_cap, uint32_t* n_accs) {
+  return mos == 0 ? plonk_verify_impl<Gwc19>(tkind, protocol, plen, instances, ilen, proofs, prlen, n, dk320, accs_out,
+                                             accs_cap, n_accs, false)
+                  : plonk_verify_impl<Bdfg21>(tkind, protocol, plen, instances, ilen, proofs, prlen, n, dk320, accs_out,
+                                              accs_cap, n_accs, false);
+}
+
+// KzgAs::create_proof (non-zk, fresh Keccak transcript) over m accumulators, then decide: the combine
+// step every rank runs on the gathered accumulators.  Returns 1 / 0; acc_out128 = the folded accumulator.
+extern "C" int hd_kzg_as_accumulate_and_decide(const uint8_t* accs128, uint32_t m, const uint8_t* dk320,
+                                               uint8_t* acc_out128) {
+  return guarded([&] {
+    KzgDecidingKey dk(G1Affine::from_bytes(dk320), G2Affine::from_bytes(dk320 + 64), G2Affine::from_bytes(dk320 + 192));
+    std::vector<KzgAccumulator> accs;
+    for (uint32_t i = 0; i < m; ++i)
+      accs.push_back(KzgAccumulator{G1Affine::from_bytes(accs128 + 128 * i), G1Affine::from_bytes(accs128 + 128 * i + 64)});
+    EvmTranscript t;
+    auto acc = KzgAs<Gwc19>::create_proof(KzgAsProvingKey{}, accs, t, Fr());
+    if (!acc.ok()) return error_code(acc.err);
+    if (acc_out128) acc.value->to_bytes(acc_out128);
+    return KzgAs<Gwc19>::decide(dk, *acc.value).ok() ? 1 : 0;
+  });
 }
 
 extern "C" int hd_plonk_verify(int mos, int tkind, const uint8_t* protocol, size_t plen, const uint8_t* instances,
