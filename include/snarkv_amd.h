@@ -29,7 +29,9 @@
  * context-free `bn254_*` entry points use a lazily created process-global
  * context on device 0 / HIP_VISIBLE_DEVICES, matching the reference's static
  * dispatch (`EcPointLoader::multi_scalar_multiplication` has no `&self`,
- * snark-verifier/src/loader.rs:108).
+ * snark-verifier/src/loader.rs:108); they are thread-safe (calls from
+ * different host threads take turns on that one context -- the reference's
+ * NativeLoader is `Sync`).
  */
 #ifndef SNARKV_AMD_H
 #define SNARKV_AMD_H

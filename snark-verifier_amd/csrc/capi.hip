@@ -51,6 +51,10 @@ static int fetch_out(snarkv_ctx* ctx, const void* d, void* host, size_t bytes) {
 
 static std::mutex g_default_mu;
 static snarkv_ctx* g_default_ctx = nullptr;
+// The context-free entry points share ONE context (stream + scratch): calls from different host
+// threads take turns.  Recursive: bn254_kzg_decide -> bn254_kzg_decide_batch.
+static std::recursive_mutex g_default_call_mu;
+#define SNARKV_DEFAULT_CALL_LOCK() std::lock_guard<std::recursive_mutex> _default_call_lock(g_default_call_mu)
 
 static int default_ctx(snarkv_ctx** out) {
   std::lock_guard<std::mutex> lk(g_default_mu);
@@ -413,6 +417,7 @@ int snarkv_g1_validate(snarkv_ctx* ctx, const uint8_t* points64, size_t n) {
 
 // ---- context-free entry points -------------------------------------------
 int bn254_g1_validate(const uint8_t* points64, size_t n) {
+  SNARKV_DEFAULT_CALL_LOCK();
   snarkv_ctx* c;
   SNARKV_TRY(default_ctx(&c));
   return snarkv_g1_validate(c, points64, n);
@@ -420,18 +425,21 @@ int bn254_g1_validate(const uint8_t* points64, size_t n) {
 
 int bn254_kzg_dk_create(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],
                         snarkv_dk** out) {
+  SNARKV_DEFAULT_CALL_LOCK();
   snarkv_ctx* c;
   SNARKV_TRY(default_ctx(&c));
   return snarkv_dk_create(c, g1_64, g2_128, s_g2_128, 0, out);
 }
 
 int bn254_kzg_dk_decide_batch(const snarkv_dk* dk, const uint8_t* accs128, size_t m, uint8_t* ok) {
+  SNARKV_DEFAULT_CALL_LOCK();
   snarkv_ctx* c;
   SNARKV_TRY(default_ctx(&c));
   return snarkv_kzg_decide_batch(c, dk, accs128, m, 0, ok);
 }
 
 int bn254_g1_msm_naive(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]) {
+  SNARKV_DEFAULT_CALL_LOCK();
   snarkv_ctx* c;
   SNARKV_TRY(default_ctx(&c));
   return snarkv_g1_msm_naive(c, scalars32, points64, n, 0, out64);
@@ -439,12 +447,14 @@ int bn254_g1_msm_naive(const uint8_t* scalars32, const uint8_t* points64, size_t
 
 int bn254_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, const uint32_t* offsets, size_t n_msm,
                          uint8_t* out) {
+  SNARKV_DEFAULT_CALL_LOCK();
   snarkv_ctx* c;
   SNARKV_TRY(default_ctx(&c));
   return snarkv_g1_msm_batched(c, scalars32, points64, offsets, n_msm, 0, out);
 }
 
 int bn254_g1_msm_pippenger(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]) {
+  SNARKV_DEFAULT_CALL_LOCK();
   snarkv_ctx* c;
   SNARKV_TRY(default_ctx(&c));
   return snarkv_g1_msm_pippenger(c, scalars32, points64, n, 0, out64);
@@ -452,6 +462,7 @@ int bn254_g1_msm_pippenger(const uint8_t* scalars32, const uint8_t* points64, si
 
 int bn254_kzg_decide_batch(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],
                            const uint8_t* accs128, size_t m, uint8_t* ok) {
+  SNARKV_DEFAULT_CALL_LOCK();
   snarkv_ctx* c;
   SNARKV_TRY(default_ctx(&c));
   snarkv_dk* dk = nullptr;

@@ -171,3 +171,32 @@ def test_sharded_msm_over_rccl_world_of_one_is_ordered():
         assert len(seen) == 6
     finally:
         dist.destroy_process_group()
+
+
+def test_context_free_entry_points_from_many_threads(golden_msm):
+    """`bn254_*` share one process-global context; concurrent callers must take turns, not race."""
+    import ctypes
+    import threading
+
+    import snark_verifier_amd as sv
+
+    lib = sv.load_library()
+    cases = [c for c in golden_msm if len(c["scalars"]) // 64 >= 2][:6]
+    errs = []
+
+    def worker(k):
+        for it in range(12):
+            c = cases[(k + it) % len(cases)]
+            s, p = bytes.fromhex(c["scalars"]), bytes.fromhex(c["points"])
+            out = ctypes.create_string_buffer(64)
+            fn = lib.bn254_g1_msm_naive if (k + it) % 2 else lib.bn254_g1_msm_pippenger
+            rc = fn(s, p, len(s) // 32, out)
+            if rc != 0 or out.raw != bytes.fromhex(c["expected"]):
+                errs.append((k, it, rc))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs
