@@ -573,7 +573,18 @@ int hd_poseidon_spec(int t, int r_f, int r_p, uint8_t* out, size_t out_cap, size
     return 0;
   });
 }
-// plain permutation of `t` words (in/out 32-byte LE each)
+// permutation of `t` words (in/out 32-byte LE each): plain = 1 the textbook rounds, 0 the optimised schedule
+int hd_poseidon_permute2(int t, int r_f, int r_p, int plain, uint8_t* state) {
+  return guarded([&] {
+    std::vector<Fr> st((size_t)t);
+    for (int i = 0; i < t; ++i)
+      if (!Fr::from_bytes(state + 32 * i, &st[i])) return -3;
+    if (plain) poseidon_permute_plain(st, poseidon_spec(t, r_f, r_p));
+    else poseidon_permute(st, poseidon_spec(t, r_f, r_p));
+    for (int i = 0; i < t; ++i) st[i].to_bytes(state + 32 * i);
+    return 0;
+  });
+}
 int hd_poseidon_permute(int t, int r_f, int r_p, uint8_t* state) {
   return guarded([&] {
     std::vector<Fr> st((size_t)t);

@@ -434,7 +434,10 @@ inline const PoseidonSpec& poseidon_spec(int t, int r_f, int r_p) {
   return cache.emplace(key, std::move(sp)).first->second;
 }
 
-inline void poseidon_permute(std::vector<Fr>& state, const PoseidonSpec& sp) {
+// The plain permutation: R_F/2 full rounds, R_P partial rounds, R_F/2 full rounds, each
+// "add constants, S-box, MDS".  Reference semantics; the sponge runs `poseidon_permute`
+// below (the optimised schedule), which tests pin against this one.
+inline void poseidon_permute_plain(std::vector<Fr>& state, const PoseidonSpec& sp) {
   const int t = sp.t;
   size_t k = 0;
   std::vector<Fr> next((size_t)t);
@@ -451,6 +454,177 @@ inline void poseidon_permute(std::vector<Fr>& state, const PoseidonSpec& sp) {
       next[i] = acc;
     }
     state = next;
+  }
+}
+
+// ---- optimised schedule (the shape the reference runs, poseidon.rs:166-201) ----
+// Constants move behind the S-boxes (k_r = M^-1 e_{r+1}; in a partial round only the
+// word-0 component stays there, the rest slides in front of that round's S-box, which does
+// not touch words 1..), and the partial rounds' dense MDS is factored  M~ = M'' M'  with
+// M' = diag(1, m^) commuting with the word-0 S-box: M' merges into the previous round's
+// matrix, M'' = [[a, v], [w, I]] is sparse (2t - 1 products instead of t^2).  Derived here
+// from the plain spec; the external crate's tables are the same rewriting.
+struct PoseidonOpt {
+  int t = 0, r_f = 0, r_p = 0;
+  std::vector<Fr> pre;                    // t: constants added with the input
+  std::vector<std::vector<Fr>> full_k;    // post-S-box constants of the full rounds, in order (last one absent = 0)
+  std::vector<Fr> partial_k;              // r_p scalars (word 0)
+  std::vector<Fr> mds, pre_sparse;        // t*t
+  std::vector<std::vector<Fr>> sparse_row, sparse_col;  // per partial round: row (t), col_hat (t-1)
+};
+
+namespace poseidon_detail {
+using Mat = std::vector<Fr>;  // row-major n x n
+inline Mat mat_mul(const Mat& a, const Mat& b, int n) {
+  Mat c((size_t)n * n, Fr::zero());
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < n; ++k)
+      for (int j = 0; j < n; ++j) c[(size_t)i * n + j] = c[(size_t)i * n + j] + a[(size_t)i * n + k] * b[(size_t)k * n + j];
+  return c;
+}
+inline Mat mat_inv(Mat a, int n) {  // Gauss-Jordan; throws if singular
+  Mat inv((size_t)n * n, Fr::zero());
+  for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = Fr::one();
+  for (int col = 0; col < n; ++col) {
+    int piv = -1;
+    for (int r = col; r < n; ++r)
+      if (!a[(size_t)r * n + col].is_zero()) {
+        piv = r;
+        break;
+      }
+    if (piv < 0) throw Panic("poseidon: singular matrix in the optimised schedule");
+    for (int j = 0; j < n; ++j) {
+      std::swap(a[(size_t)piv * n + j], a[(size_t)col * n + j]);
+      std::swap(inv[(size_t)piv * n + j], inv[(size_t)col * n + j]);
+    }
+    Fr pinv;
+    a[(size_t)col * n + col].invert(&pinv);
+    for (int j = 0; j < n; ++j) {
+      a[(size_t)col * n + j] = a[(size_t)col * n + j] * pinv;
+      inv[(size_t)col * n + j] = inv[(size_t)col * n + j] * pinv;
+    }
+    for (int r = 0; r < n; ++r) {
+      if (r == col || a[(size_t)r * n + col].is_zero()) continue;
+      Fr f = a[(size_t)r * n + col];
+      for (int j = 0; j < n; ++j) {
+        a[(size_t)r * n + j] = a[(size_t)r * n + j] - f * a[(size_t)col * n + j];
+        inv[(size_t)r * n + j] = inv[(size_t)r * n + j] - f * inv[(size_t)col * n + j];
+      }
+    }
+  }
+  return inv;
+}
+inline std::vector<Fr> mat_vec(const Mat& m, const std::vector<Fr>& v, int n) {
+  std::vector<Fr> o((size_t)n, Fr::zero());
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) o[i] = o[i] + m[(size_t)i * n + j] * v[j];
+  return o;
+}
+}  // namespace poseidon_detail
+
+inline const PoseidonOpt& poseidon_opt(int t, int r_f, int r_p) {
+  static std::map<std::tuple<int, int, int>, PoseidonOpt> cache;
+  static std::mutex mu;
+  const PoseidonSpec& sp = poseidon_spec(t, r_f, r_p);
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_tuple(t, r_f, r_p);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  using namespace poseidon_detail;
+  PoseidonOpt o;
+  o.t = t;
+  o.r_f = r_f;
+  o.r_p = r_p;
+  o.mds = sp.mds;
+  const int h = r_f / 2, R = r_f + r_p;
+  auto c = [&](int r) { return std::vector<Fr>(sp.rc.begin() + (size_t)r * t, sp.rc.begin() + (size_t)(r + 1) * t); };
+  const Mat minv = mat_inv(sp.mds, t);
+  // constants, backwards: e = the pre-S-box vector wanted at round r + 1
+  std::vector<std::vector<Fr>> kfull((size_t)R);  // post-S-box vector of full round r
+  o.partial_k.assign((size_t)r_p, Fr::zero());
+  std::vector<Fr> e = c(R - 1);
+  for (int r = R - 2; r >= 0; --r) {
+    std::vector<Fr> back = mat_vec(minv, e, t);  // M^-1 e_{r+1}
+    const bool partial = r >= h && r < h + r_p;
+    e = c(r);
+    if (partial) {
+      o.partial_k[(size_t)(r - h)] = back[0];
+      for (int i = 1; i < t; ++i) e[i] = e[i] + back[i];  // slides in front of this round's (word-0 only) S-box
+    } else {
+      kfull[(size_t)r] = back;
+    }
+  }
+  o.pre = e;  // = c(0): round 0 is full
+  for (int r = 0; r < R - 1; ++r)
+    if (!(r >= h && r < h + r_p)) o.full_k.push_back(kfull[(size_t)r]);
+  // matrices, backwards over the partial rounds
+  Mat cur = sp.mds;
+  o.sparse_row.assign((size_t)r_p, {});
+  o.sparse_col.assign((size_t)r_p, {});
+  for (int r = r_p - 1; r >= 0; --r) {
+    const int m = t - 1;
+    Mat mhat((size_t)m * m);
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < m; ++j) mhat[(size_t)i * m + j] = cur[(size_t)(i + 1) * t + (j + 1)];
+    Mat mhat_inv = mat_inv(mhat, m);
+    std::vector<Fr> row((size_t)t), col((size_t)m);
+    row[0] = cur[0];
+    for (int j = 0; j < m; ++j) {  // v = M~[0,1:] m^^-1
+      Fr acc = Fr::zero();
+      for (int k = 0; k < m; ++k) acc = acc + cur[(size_t)(k + 1)] * mhat_inv[(size_t)k * m + j];
+      row[(size_t)j + 1] = acc;
+    }
+    for (int i = 0; i < m; ++i) col[i] = cur[(size_t)(i + 1) * t];  // w = M~[1:,0]
+    o.sparse_row[(size_t)r] = row;
+    o.sparse_col[(size_t)r] = col;
+    Mat mprime((size_t)t * t, Fr::zero());  // diag(1, m^)
+    mprime[0] = Fr::one();
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < m; ++j) mprime[(size_t)(i + 1) * t + (j + 1)] = mhat[(size_t)i * m + j];
+    cur = mat_mul(mprime, sp.mds, t);  // the previous round's matrix absorbs M'
+  }
+  o.pre_sparse = cur;
+  return cache.emplace(key, std::move(o)).first->second;
+}
+
+// state <- permutation(state): identical values to poseidon_permute_plain, about half the products
+inline void poseidon_permute(std::vector<Fr>& state, const PoseidonSpec& sp) {
+  const PoseidonOpt& o = poseidon_opt(sp.t, sp.r_f, sp.r_p);
+  const int t = o.t, h = o.r_f / 2;
+  std::vector<Fr> next((size_t)t);
+  auto sbox = [](const Fr& x) {
+    Fr x2 = x.square();
+    return x2.square() * x;
+  };
+  auto dense = [&](const std::vector<Fr>& m) {
+    for (int i = 0; i < t; ++i) {
+      Fr acc = Fr::zero();
+      for (int j = 0; j < t; ++j) acc = acc + m[(size_t)i * t + j] * state[j];
+      next[i] = acc;
+    }
+    state = next;
+  };
+  for (int i = 0; i < t; ++i) state[i] = state[i] + o.pre[i];
+  size_t fk = 0;
+  for (int r = 0; r < h; ++r) {  // first half: full rounds, the last one with the pre-sparse matrix
+    for (int i = 0; i < t; ++i) state[i] = sbox(state[i]) + o.full_k[fk][i];
+    ++fk;
+    dense(r + 1 < h ? o.mds : o.pre_sparse);
+  }
+  for (int r = 0; r < o.r_p; ++r) {  // partial rounds: one S-box, sparse matrix
+    state[0] = sbox(state[0]) + o.partial_k[(size_t)r];
+    const auto& row = o.sparse_row[(size_t)r];
+    const auto& col = o.sparse_col[(size_t)r];
+    Fr s0 = state[0], acc = row[0] * s0;
+    for (int j = 1; j < t; ++j) acc = acc + row[(size_t)j] * state[j];
+    for (int i = 1; i < t; ++i) state[i] = state[i] + col[(size_t)i - 1] * s0;
+    state[0] = acc;
+  }
+  for (int r = 0; r < h; ++r) {  // second half: full rounds, no constant after the last S-box
+    const bool last = r + 1 == h;
+    for (int i = 0; i < t; ++i) state[i] = last ? sbox(state[i]) : sbox(state[i]) + o.full_k[fk][i];
+    if (!last) ++fk;
+    dense(o.mds);
   }
 }
 

@@ -1,7 +1,7 @@
-"""Generates tests/golden/bench_plonk_gwc19_evm_64.bin: the C3 workload of
+"""Generates tests/golden/bench_plonk_gwc19_{evm,poseidon}_64.bin: the C3 workload of
 BASELINE.json as REAL INPUT BYTES -- one StandardPlonk-shaped protocol, 64
 instance sets and 64 proofs forged under the toy SRS (oracle/plonk.py), Keccak
-transcript, GWC19 multi-open -- so that bench.py can time the verifier end to
+or Poseidon transcript for the proofs, GWC19 multi-open -- so that bench.py can time the verifier end to
 end (proof bytes in, accept out) without importing the oracle.
 Layout: magic 'SVB1' | u32 n | u32 plen | protocol | u32 ilen | instances | u32 prlen | proofs (u32 len || bytes each)
         | dk (64 + 128 + 128) | expected aggregated accumulator (128)
@@ -23,14 +23,15 @@ import transcript as T
 SECRET = 0x1F2E3D4C5B6A79887766554433221100AABBCCDDEEFF
 
 
-def main(n=64):
-    rng = random.Random(0xBE2C)
+def main(n=64, kind="evm"):
+    rng = random.Random(0xBE2C if kind == "evm" else 0xBE2D)
+    TR = T.EvmTranscript if kind == "evm" else T.PoseidonTranscript
     pr, dl = S.standard_plonk_protocol(rng)
     insts, proofs, accs = [], [], []
     for i in range(n):
         inst = [[rng.randrange(O.R) for _ in range(m)] for m in pr["num_instance"]]
-        proof = P.forge_proof(pr, inst, SECRET, lambda: T.EvmTranscript(), "gwc19", rng, dl)
-        pf = P.plonk_proof_read(pr, inst, T.EvmTranscript(proof), "gwc19")
+        proof = P.forge_proof(pr, inst, SECRET, lambda: TR(), "gwc19", rng, dl)
+        pf = P.plonk_proof_read(pr, inst, TR(proof), "gwc19")
         accs += P.succinct_verify(O.G1_GEN, pr, inst, pf, "gwc19")
         insts.append(inst)
         proofs.append(proof)
@@ -48,11 +49,12 @@ def main(n=64):
     dk = O.g1_to_bytes(O.G1_GEN) + O.g2_to_bytes(O.G2_GEN) + O.g2_to_bytes(O.g2_mul(O.G2_GEN, SECRET))
     blob = (b"SVB1" + struct.pack("<I", n) + struct.pack("<I", len(pb)) + pb + struct.pack("<I", len(ib)) + ib
             + struct.pack("<I", len(prb)) + prb + dk + O.g1_to_bytes(agg[0]) + O.g1_to_bytes(agg[1]))
-    path = os.path.join(ROOT, "tests", "golden", "bench_plonk_gwc19_evm_%d.bin" % n)
+    path = os.path.join(ROOT, "tests", "golden", "bench_plonk_gwc19_%s_%d.bin" % (kind, n))
     with open(path, "wb") as f:
         f.write(blob)
     print("wrote", path, len(blob), "bytes")
 
 
 if __name__ == "__main__":
-    main()
+    main(kind="evm")
+    main(kind="poseidon")

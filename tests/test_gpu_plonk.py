@@ -196,11 +196,11 @@ def test_golden_fixture_cpp(H):
         assert accs.raw[:128 * n.value].hex() == "".join(case["accumulators"]), case["name"]
 
 
-def load_bench_blob():
+def load_bench_blob(kind="evm"):
     import os
     import struct
 
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_plonk_gwc19_evm_64.bin")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_plonk_gwc19_%s_64.bin" % kind)
     b = open(path, "rb").read()
     assert b[:4] == b"SVB1"
     n, = struct.unpack_from("<I", b, 4)
@@ -228,6 +228,10 @@ def test_end_to_end_aggregation_of_64_proofs(H, threads):
     rc = H.hd_aggregate_end_to_end(0, 0, pb, len(pb), ib, len(ib), prb, len(prb), n, dk, threads, tm, acc)
     assert rc == 1
     assert acc.raw == exp  # the oracle's aggregated accumulator (gen_bench_proofs.py)
+    # the same workload with Poseidon transcripts inside the proofs (the reference's recursion setting)
+    n2, pb2, ib2, prb2, dk2, exp2 = load_bench_blob("poseidon")
+    rc = H.hd_aggregate_end_to_end(0, 1, pb2, len(pb2), ib2, len(ib2), prb2, len(prb2), n2, dk2, threads, tm, acc)
+    assert rc == 1 and acc.raw == exp2
     # replicate the batch 4x (256 proofs): still one launch per stage, still accepted
     rc = H.hd_aggregate_end_to_end(0, 0, pb, len(pb), ib * 4, 4 * len(ib), prb * 4, 4 * len(prb), 4 * n, dk, threads, tm, acc)
     assert rc == 1

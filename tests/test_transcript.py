@@ -224,3 +224,21 @@ def test_compressed_point_roundtrip():
         assert T.g1_decompress(T.g1_compress(p)) == p
         assert T.g1_decompress(T.g1_compress(O.g1_neg(p))) == O.g1_neg(p)
     assert T.g1_decompress(T.g1_compress(None)) is None
+
+
+@pytest.mark.parametrize("params", [(3, 8, 57), (5, 8, 60), (2, 8, 56), (4, 8, 56), (6, 8, 57), (5, 4, 3)])
+def test_poseidon_optimised_schedule_equals_plain_permutation(H, params):
+    """transcript.hpp runs the optimised schedule (constants behind the S-boxes, sparse
+    MDS in the partial rounds -- the shape of the reference's `permutation`, poseidon.rs:166-201);
+    it must give the same state as the textbook rounds AND the oracle for any input."""
+    _setup_poseidon(H)
+    H.hd_poseidon_permute2.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    t, rf, rp = params
+    rng = random.Random(sum(params))
+    for st in ([0] * t, [O.R - 1] * t, [rng.randrange(O.R) for _ in range(t)], [rng.randrange(O.R) for _ in range(t)]):
+        outs = []
+        for plain in (1, 0):
+            buf = ctypes.create_string_buffer(b"".join(O.fe_to_bytes(x) for x in st), 32 * t)
+            assert H.hd_poseidon_permute2(t, rf, rp, plain, buf) == 0
+            outs.append([int.from_bytes(buf.raw[32 * i:32 * i + 32], "little") for i in range(t)])
+        assert outs[0] == outs[1] == T.poseidon_permute(list(st), rf, rp)
