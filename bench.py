@@ -156,7 +156,7 @@ def end_to_end_metrics():
     H.hd_aggregate_end_to_end.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
                                           ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32,
                                           ctypes.c_char_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p]
-    threads = max(1, min(32, os.cpu_count() or 1))
+    threads = max(1, min(64, os.cpu_count() or 1))
     out = {}
     for tkind, tname in ((0, "evm"), (1, "poseidon")):
         path = os.path.join(ROOT, "tests", "golden", "bench_plonk_gwc19_%s_64.bin" % tname)

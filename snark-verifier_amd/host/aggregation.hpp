@@ -8,6 +8,7 @@
 // segmented launch, the accumulation step is a second launch, the pairing a third.
 #pragma once
 #include <chrono>
+#include <type_traits>
 
 #include "plonk.hpp"
 #include "transcript.hpp"
@@ -39,6 +40,8 @@ struct Aggregator {
     std::vector<Error> errs(n);
     std::vector<typename SV::Pairs> jobs(2 * n);
     std::vector<double> t_read(n, 0.0);
+    // a Keccak proof costs ~30 us of host work (a thread start ~ one proof), a Poseidon one ~0.5 ms
+    constexpr size_t grain = std::is_same<TR, PoseidonTranscript>::value ? 1 : 16;
     // one pass per proof: read_proof, then the host half of verify (the pair lists of its two MSMs)
     parallel_for(n, threads, [&](size_t i) {
       auto a = clk::now();
@@ -57,7 +60,7 @@ struct Aggregator {
       }
       jobs[2 * i] = std::move(p2.value->first);
       jobs[2 * i + 1] = std::move(p2.value->second);
-    });
+    }, grain);
     for (auto& e : errs)
       if (!e.ok()) return R::Err(e);
     auto t2 = clk::now();
@@ -75,7 +78,7 @@ struct Aggregator {
       double host = ms(t0, t2), read_sum = 0;
       for (double x : t_read) read_sum += x;
       // the per-proof read share is timed; the algebra share is the rest of the parallel pass
-      unsigned used = std::max(1u, std::min<unsigned>(threads, (unsigned)std::max<size_t>(1, n / 16)));
+      unsigned used = std::max(1u, std::min<unsigned>(threads, (unsigned)std::max<size_t>(1, n / grain)));
       double frac = std::min(1.0, std::max(0.0, (read_sum / used) / std::max(host, 1e-9)));
       tm->read_proofs = host * frac;
       tm->fr_algebra = host * (1.0 - frac);

@@ -29,13 +29,14 @@ namespace snarkv_host {
 
 // Proofs are independent: the host front half (transcript hashing, expression
 // evaluation) is spread over `threads` host threads; the first exception wins.
+// `grain`: items per thread below which another thread is not worth its start-up cost.
 template <class F>
-inline void parallel_for(size_t n, unsigned threads, F&& fn) {
+inline void parallel_for(size_t n, unsigned threads, F&& fn, size_t grain = 16) {
   if (threads <= 1 || n <= 1) {
     for (size_t i = 0; i < n; ++i) fn(i);
     return;
   }
-  threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(1, n / 16));  // a thread start costs about one proof of host work
+  threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(1, n / std::max<size_t>(1, grain)));
   std::atomic<size_t> next{0};
   std::exception_ptr err;
   std::atomic<bool> failed{false};

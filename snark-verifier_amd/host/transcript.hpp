@@ -681,20 +681,27 @@ inline void sub_mod(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {  
   }
   memcpy(r, t, 32);
 }
-// sqrt for p = 3 (mod 4): a^((p+1)/4); false if a is not a square
+// sqrt for p = 3 (mod 4): a^((p+1)/4); false if a is not a square.  The ladder runs in the
+// Montgomery domain (one product per step).
 inline bool sqrt_mod(uint64_t r[4], const uint64_t a[4]) {
   // (p + 1) / 4
   static const uint64_t E[4] = {0x4f082305b61f3f52ull, 0x65e05aa45a1c72a3ull, 0x6e14116da0605617ull,
                                 0x0c19139cb84c680aull};
-  uint64_t acc[4] = {1, 0, 0, 0};
-  for (int i = 255; i >= 0; --i) {
-    mul_mod(acc, acc, acc);
-    if ((E[i >> 6] >> (i & 63)) & 1) mul_mod(acc, acc, a);
+  static constexpr uint64_t R2[4] = {0xf32cfc5b538afa89ull, 0xb5e71911d44501fbull, 0x47ab1eff0a417ff6ull,
+                                     0x06d89f71cab8351full};
+  const uint64_t one[4] = {1, 0, 0, 0};
+  uint64_t am[4], acc[4];
+  mont_mul(am, a, R2);     // a R
+  mont_mul(acc, one, R2);  // 1 R
+  for (int i = 252; i >= 0; --i) {  // E < 2^253
+    mont_mul(acc, acc, acc);
+    if ((E[i >> 6] >> (i & 63)) & 1) mont_mul(acc, acc, am);
   }
-  uint64_t chk[4];
-  mul_mod(chk, acc, acc);
+  uint64_t y[4], chk[4];
+  mont_mul(y, acc, one);  // out of the Montgomery domain
+  mul_mod(chk, y, y);
   if (memcmp(chk, a, 32) != 0) return false;
-  memcpy(r, acc, 32);
+  memcpy(r, y, 32);
   return true;
 }
 }  // namespace fq_host
