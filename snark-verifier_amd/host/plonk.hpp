@@ -498,6 +498,34 @@ inline std::pair<MsmT, MsmT> pcs_msms(const std::vector<MsmT>& cm, const Fr& z, 
 }
 }  // namespace plonk_detail
 
+// cost.rs:5-33 + the `CostEstimation` impls (gwc19.rs:168-175, bdfg21.rs:379-385, plonk.rs:149-188)
+struct Cost {
+  size_t num_instance = 0, num_commitment = 0, num_evaluation = 0, num_msm = 0, num_pairing = 0;
+  Cost operator+(const Cost& o) const {
+    return Cost{num_instance + o.num_instance, num_commitment + o.num_commitment, num_evaluation + o.num_evaluation,
+                num_msm + o.num_msm, num_pairing + o.num_pairing};
+  }
+  bool operator==(const Cost& o) const {
+    return num_instance == o.num_instance && num_commitment == o.num_commitment && num_evaluation == o.num_evaluation &&
+           num_msm == o.num_msm && num_pairing == o.num_pairing;
+  }
+};
+inline Cost pcs_estimate_cost(Gwc19, const std::vector<Query<std::monostate>>& queries) {
+  std::vector<Query<Fr>> qs;
+  for (auto& q : queries) qs.push_back(Query<Fr>{q.poly, q.shift, Fr()});
+  size_t num_w = gwc19::query_sets(qs).size();
+  Cost c;
+  c.num_commitment = num_w;
+  c.num_msm = num_w;
+  return c;
+}
+inline Cost pcs_estimate_cost(Bdfg21, const std::vector<Query<std::monostate>>&) {
+  Cost c;
+  c.num_commitment = 2;
+  c.num_msm = 2;
+  return c;
+}
+
 // verifier/plonk.rs:32-92
 template <class MOS>
 struct PlonkSuccinctVerifier {
@@ -535,6 +563,18 @@ struct PlonkSuccinctVerifier {
     std::vector<KzgAccumulator> out{KzgAccumulator{pts[0], pts[1]}};
     out.insert(out.end(), proof.old_accumulators.begin(), proof.old_accumulators.end());
     return R::Ok(out);
+  }
+
+  // plonk.rs:149-176
+  static Cost estimate_cost(const PlonkProtocol& pr) {
+    Cost c;
+    size_t nw = 0;
+    for (size_t x : pr.num_witness) nw += x;
+    for (size_t x : pr.num_instance) c.num_instance += x;
+    c.num_commitment = nw + pr.quotient.num_chunk;
+    c.num_evaluation = pr.evaluations.size();
+    c.num_msm = pr.preprocessed.size() + c.num_commitment + 1 + 2 * pr.accumulator_indices.size();
+    return c + pcs_estimate_cost(MOS{}, Proof::empty_queries(pr));
   }
 
   // Many proofs (possibly of different protocols): all 2 x N MSMs in ONE segmented launch.
@@ -580,6 +620,12 @@ struct PlonkVerifier {
     auto accs = PlonkSuccinctVerifier<MOS>::verify(vk.svk, pr, instances, proof);
     if (!accs.ok()) return accs.err;
     return KzgAs<MOS>::decide_all(vk, *accs.value);
+  }
+  // plonk.rs:178-188
+  static Cost estimate_cost(const PlonkProtocol& pr) {
+    Cost c = PlonkSuccinctVerifier<MOS>::estimate_cost(pr);
+    c.num_pairing += 2;
+    return c;
   }
 };
 

@@ -758,6 +758,20 @@ extern "C" int hd_kzg_as_accumulate_and_decide(const uint8_t* accs128, uint32_t 
   });
 }
 
+// `CostEstimation` of PlonkVerifier<MOS> (verifier/plonk.rs:149-188): out[0..4] = instance, commitment, evaluation, msm, pairing
+extern "C" int hd_plonk_estimate_cost(int mos, const uint8_t* protocol, size_t plen, uint64_t* out5) {
+  return guarded([&] {
+    PlonkProtocol pr = parse_protocol(protocol, plen);
+    Cost c = mos == 0 ? PlonkVerifier<Gwc19>::estimate_cost(pr) : PlonkVerifier<Bdfg21>::estimate_cost(pr);
+    out5[0] = c.num_instance;
+    out5[1] = c.num_commitment;
+    out5[2] = c.num_evaluation;
+    out5[3] = c.num_msm;
+    out5[4] = c.num_pairing;
+    return 0;
+  });
+}
+
 extern "C" int hd_plonk_verify(int mos, int tkind, const uint8_t* protocol, size_t plen, const uint8_t* instances,
                                size_t ilen, const uint8_t* proofs, size_t prlen, uint32_t n, const uint8_t* dk320,
                                uint8_t* accs_out, size_t accs_cap, uint32_t* n_accs) {

@@ -242,3 +242,22 @@ def test_poseidon_optimised_schedule_equals_plain_permutation(H, params):
             assert H.hd_poseidon_permute2(t, rf, rp, plain, buf) == 0
             outs.append([int.from_bytes(buf.raw[32 * i:32 * i + 32], "little") for i in range(t)])
         assert outs[0] == outs[1] == T.poseidon_permute(list(st), rf, rp)
+
+
+def test_cost_estimation_of_the_standard_plonk_shape(H):
+    """`CostEstimation` (cost.rs, verifier/plonk.rs:149-188, gwc19.rs:168-175, bdfg21.rs:379-385) on
+    the StandardPlonk-shaped protocol of tests/plonk_synth.py: 6 witnesses + 3 quotient chunks,
+    19 evaluations, rotations {0, 1, -1, last} -> 4 GWC19 opening commitments, 2 for BDFG21; 2 pairings."""
+    import sys as _sys
+
+    _sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import plonk_synth as S
+
+    H.hd_plonk_estimate_cost.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
+    pr, _ = S.standard_plonk_protocol(random.Random(1), num_instance=(2,), accumulator_rows=None)
+    pb = S.pack_protocol(pr)
+    out = (ctypes.c_uint64 * 5)()
+    assert H.hd_plonk_estimate_cost(0, pb, len(pb), out) == 0
+    assert list(out) == [2, 9 + 4, 19, 8 + 9 + 1 + 4, 2]
+    assert H.hd_plonk_estimate_cost(1, pb, len(pb), out) == 0
+    assert list(out) == [2, 9 + 2, 19, 8 + 9 + 1 + 2, 2]
