@@ -158,7 +158,7 @@ def end_to_end_metrics():
                                           ctypes.c_char_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p]
     threads = max(1, min(64, os.cpu_count() or 1))
     out = {}
-    for tkind, tname in ((0, "evm"), (1, "poseidon")):
+    for tkind, tname in ((0, "evm"), (1, "poseidon"), (2, "poseidon")):
         path = os.path.join(ROOT, "tests", "golden", "bench_plonk_gwc19_%s_64.bin" % tname)
         if not os.path.exists(path):
             continue
@@ -182,10 +182,12 @@ def end_to_end_metrics():
                     return {"error": "verifier returned %d" % rc}
                 if best is None or tm[5] < best[5]:
                     best = list(tm)
-            key = "end_to_end_aggregate_%d_proofs" % (n * rep) + ("" if tkind == 0 else "_poseidon_transcript")
+            key = "end_to_end_aggregate_%d_proofs" % (n * rep) + (
+                "", "_poseidon_transcript_host_hashed", "_poseidon_transcript_device_hashed")[tkind]
             out[key] = {
                 "ms": best[5], "proofs_per_s": n * rep / best[5] * 1e3, "host_threads": threads,
-                "ms_read_proofs_host": best[0], "ms_fr_algebra_host": best[1], "ms_msm_device_incl_h2d": best[2],
+                ("ms_read_proofs_incl_device_hashing" if tkind == 2 else "ms_read_proofs_host"): best[0],
+                "ms_fr_algebra_host": best[1], "ms_msm_device_incl_h2d": best[2],
                 "ms_kzg_accumulate": best[3], "ms_decide": best[4],
                 "accepted": True, "matches_fixture_accumulator": (acc.raw == exp) if rep == 1 else None,
                 "input": os.path.basename(path) + (" x%d" % rep if rep > 1 else "")}

@@ -54,6 +54,7 @@ extern "C" {
 
 typedef struct snarkv_ctx snarkv_ctx;
 typedef struct snarkv_dk snarkv_dk;
+typedef struct snarkv_poseidon snarkv_poseidon;
 
 /* ---- context ---------------------------------------------------------- */
 /* `hip_stream` may be NULL (the context creates its own stream) or an
@@ -162,6 +163,38 @@ int snarkv_sample_points_dev(snarkv_ctx* ctx, uint64_t seed, uint64_t first, siz
  * which = 1: whole mixed G1 additions (madd/s) -- the multiplier / adder of the
  * bucket-accumulate kernel in isolation (no memory traffic).                  */
 int snarkv_ubench_valu(snarkv_ctx* ctx, int which, int iters, double* ops_per_s);
+/* ---- Poseidon transcripts, batched (SURVEY.md 8f row N2 on the device) ----
+ * Replaces, for MANY proofs at once, the hashing of the reference's native
+ * `PoseidonTranscript` (snark-verifier/src/system/halo2/transcript/halo2.rs:170-321
+ * over `Poseidon::{update, squeeze}`, snark-verifier/src/util/hash/poseidon.rs:145-202).
+ * `snarkv_poseidon_create` takes the tables of the optimised schedule exactly as the
+ * reference's `poseidon::Spec` holds them (poseidon.rs:166-201 reads
+ * `spec.constants().{start, partial, end}` and
+ * `spec.mds_matrices().{mds, pre_sparse_mds, sparse_matrices}`): every value a
+ * 32-byte little-endian canonical Fr; matrices row-major; `start` has r_f/2 + 1
+ * rows of t, `end` r_f/2 - 1 rows, one `row` (t) and one `col_hat` (t - 1) per
+ * partial round.  2 <= t <= 8, rate < t.                                        */
+int snarkv_poseidon_create(snarkv_ctx* ctx, uint32_t t, uint32_t rate, uint32_t r_f, uint32_t r_p,
+                           const uint8_t* start, const uint8_t* partial, const uint8_t* end, const uint8_t* mds,
+                           const uint8_t* pre_sparse_mds, const uint8_t* sparse_rows, const uint8_t* sparse_col_hats,
+                           snarkv_poseidon** out);
+void snarkv_poseidon_destroy(snarkv_poseidon* ps);
+/* n transcripts of one shape: transcript i absorbs its L elements (elems + 32*L*i,
+ * canonical Fr each) in S segments of seg_len[s] elements and squeezes after each
+ * segment (sum of seg_len == L; a segment may be empty).  State starts at
+ * `poseidon::State::default()` = [2^64, 0, ..].  out: n x S challenges, 32-byte LE. */
+int snarkv_poseidon_transcript_batch(snarkv_ctx* ctx, const snarkv_poseidon* ps, const uint8_t* elems, size_t n,
+                                     size_t L, const uint32_t* seg_len, size_t S, uint8_t* out);
+int snarkv_poseidon_transcript_batch_dev(snarkv_ctx* ctx, const snarkv_poseidon* ps, const void* d_elems, size_t n,
+                                         size_t L, const void* d_seg_len, size_t S, void* d_out);
+
+/* context-free forms (process-global context, thread-safe) */
+int bn254_poseidon_create(uint32_t t, uint32_t rate, uint32_t r_f, uint32_t r_p, const uint8_t* start,
+                          const uint8_t* partial, const uint8_t* end, const uint8_t* mds, const uint8_t* pre_sparse_mds,
+                          const uint8_t* sparse_rows, const uint8_t* sparse_col_hats, snarkv_poseidon** out);
+int bn254_poseidon_transcript_batch(const snarkv_poseidon* ps, const uint8_t* elems, size_t n, size_t L,
+                                    const uint32_t* seg_len, size_t S, uint8_t* out);
+
 int snarkv_set_stage_timing(snarkv_ctx* ctx, int enabled);
 int snarkv_get_stage_timing(snarkv_ctx* ctx, float ms[SNARKV_PIP_STAGES]);
 

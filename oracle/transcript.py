@@ -356,3 +356,95 @@ class PoseidonTranscript:
 
     def finalize(self):
         return bytes(self.stream)
+
+
+# ---------------------------------------------------------------------------
+# The optimised schedule's tables (what the reference's `poseidon::Spec` holds and
+# poseidon.rs:166-201 consumes), derived from the plain spec; used to feed the device
+# kernel (`snarkv_poseidon_create`) in tests.  Derivation: constants slide behind the
+# S-boxes (k_r = M^-1 e_{r+1}; in a partial round only the word-0 component stays, the
+# rest moves in front of that round's S-box), the partial rounds' dense matrix factors
+# as M~ = M'' M' with M' = diag(1, m^) pushed into the previous round.
+def _mat_inv(a, mod):
+    n = len(a)
+    a = [row[:] + [1 if i == j else 0 for j in range(n)] for i, row in enumerate(a)]
+    for c in range(n):
+        p = next(r for r in range(c, n) if a[r][c] % mod)
+        a[c], a[p] = a[p], a[c]
+        inv = pow(a[c][c], -1, mod)
+        a[c] = [x * inv % mod for x in a[c]]
+        for r in range(n):
+            if r != c and a[r][c]:
+                f = a[r][c]
+                a[r] = [(x - f * y) % mod for x, y in zip(a[r], a[c])]
+    return [row[n:] for row in a]
+
+
+def _mat_mul(a, b, mod):
+    return [[sum(a[i][k] * b[k][j] for k in range(len(b))) % mod for j in range(len(b[0]))] for i in range(len(a))]
+
+
+def poseidon_opt_tables(t, r_f, r_p, modulus=None):
+    mod = modulus or O.R
+    rc, mds = poseidon_spec(t, r_f, r_p, modulus=mod)
+    h, R = r_f // 2, r_f + r_p
+    c = lambda r: rc[r * t:(r + 1) * t]
+    minv = _mat_inv(mds, mod)
+    mv = lambda m, v: [sum(m[i][j] * v[j] for j in range(t)) % mod for i in range(t)]
+    kfull, partial = {}, [0] * r_p
+    e = c(R - 1)
+    for r in range(R - 2, -1, -1):
+        back = mv(minv, e)
+        e = c(r)[:]
+        if h <= r < h + r_p:
+            partial[r - h] = back[0]
+            for i in range(1, t):
+                e[i] = (e[i] + back[i]) % mod
+        else:
+            kfull[r] = back
+    start = [e] + [kfull[r] for r in range(h)]
+    end = [kfull[r] for r in range(h + r_p, R - 1)]
+    cur = [row[:] for row in mds]
+    rows, cols = [None] * r_p, [None] * r_p
+    for r in range(r_p - 1, -1, -1):
+        mhat = [row[1:] for row in cur[1:]]
+        mhat_inv = _mat_inv(mhat, mod)
+        v = [sum(cur[0][1 + k] * mhat_inv[k][j] for k in range(t - 1)) % mod for j in range(t - 1)]
+        rows[r] = [cur[0][0]] + v
+        cols[r] = [cur[i][0] for i in range(1, t)]
+        mprime = [[1] + [0] * (t - 1)] + [[0] + mhat[i] for i in range(t - 1)]
+        cur = _mat_mul(mprime, mds, mod)
+    return {"start": start, "partial": partial, "end": end, "mds": mds, "pre_sparse_mds": cur,
+            "sparse_rows": rows, "sparse_col_hats": cols}
+
+
+def poseidon_permute_opt(state, t, r_f, r_p, modulus=None):
+    """The permutation through the optimised tables -- must equal poseidon_permute."""
+    mod = modulus or O.R
+    T = poseidon_opt_tables(t, r_f, r_p, modulus=mod)
+    h = r_f // 2
+    sb = lambda x: pow(x, 5, mod)
+    mv = lambda m, v: [sum(m[i][j] * v[j] for j in range(t)) % mod for i in range(t)]
+    s = [(x + k) % mod for x, k in zip(state, T["start"][0])]
+    for r in range(h):
+        s = [(sb(x) + k) % mod for x, k in zip(s, T["start"][r + 1])]
+        s = mv(T["mds"] if r + 1 < h else T["pre_sparse_mds"], s)
+    for r in range(r_p):
+        s0 = (sb(s[0]) + T["partial"][r]) % mod
+        new0 = (T["sparse_rows"][r][0] * s0 + sum(a * b for a, b in zip(T["sparse_rows"][r][1:], s[1:]))) % mod
+        s = [new0] + [(s[i] + T["sparse_col_hats"][r][i - 1] * s0) % mod for i in range(1, t)]
+    for r in range(h):
+        s = [sb(x) for x in s] if r + 1 == h else [(sb(x) + k) % mod for x, k in zip(s, T["end"][r])]
+        s = mv(T["mds"], s)
+    return s
+
+
+def poseidon_transcript_challenges(elems, seg_len, t=5, rate=4, r_f=8, r_p=60):
+    """Oracle of `snarkv_poseidon_transcript_batch` for ONE transcript: absorb the segments, squeeze after each."""
+    p = Poseidon(t, rate, r_f, r_p)
+    out, pos = [], 0
+    for n in seg_len:
+        p.update(elems[pos:pos + n])
+        pos += n
+        out.append(p.squeeze())
+    return out

@@ -11,6 +11,7 @@ without the built library or without a HIP device raises.
 from ._lib import (  # noqa: F401
     Context,
     DecidingKey,
+    PoseidonSpec,
     SnarkvError,
     lib_path,
     load_library,
@@ -22,6 +23,7 @@ from ._lib import (  # noqa: F401
 __all__ = [
     "Context",
     "DecidingKey",
+    "PoseidonSpec",
     "SnarkvError",
     "lib_path",
     "load_library",

@@ -74,6 +74,12 @@ _SIGNATURES = {
     "snarkv_sample_scalars_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
     "snarkv_sample_points_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
     "snarkv_ubench_valu": (_int, [_vp, _int, _int, ctypes.POINTER(ctypes.c_double)]),
+    "snarkv_poseidon_create": (_int, [_vp, _u32, _u32, _u32, _u32, _cp, _cp, _cp, _cp, _cp, _cp, _cp, _pp]),
+    "snarkv_poseidon_destroy": (None, [_vp]),
+    "snarkv_poseidon_transcript_batch": (_int, [_vp, _vp, _cp, _sz, _sz, _vp, _sz, _vp]),
+    "snarkv_poseidon_transcript_batch_dev": (_int, [_vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp]),
+    "bn254_poseidon_create": (_int, [_u32, _u32, _u32, _u32, _cp, _cp, _cp, _cp, _cp, _cp, _cp, _pp]),
+    "bn254_poseidon_transcript_batch": (_int, [_vp, _cp, _sz, _sz, _vp, _sz, _vp]),
     "snarkv_set_stage_timing": (_int, [_vp, _int]),
     "snarkv_get_stage_timing": (_int, [_vp, _vp]),
 }
@@ -145,6 +151,44 @@ class DecidingKey:
     def close(self):
         if self._h:
             self._lib.snarkv_dk_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PoseidonSpec:
+    """Device-resident tables of one Poseidon instance (include/snarkv_amd.h
+    `snarkv_poseidon_create`); `tables` = dict of the optimised schedule, every
+    entry a list (of lists) of integers < r:
+    start [(r_f/2+1) x t], partial [r_p], end [(r_f/2-1) x t], mds [t x t],
+    pre_sparse_mds [t x t], sparse_rows [r_p x t], sparse_col_hats [r_p x (t-1)]."""
+
+    def __init__(self, ctx, t, rate, r_f, r_p, tables):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        self.t, self.rate, self.r_f, self.r_p = t, rate, r_f, r_p
+
+        def flat(x):
+            out = b""
+            for row in x:
+                if isinstance(row, (list, tuple)):
+                    out += b"".join(int(v).to_bytes(32, "little") for v in row)
+                else:
+                    out += int(row).to_bytes(32, "little")
+            return out if out else b"\x00"
+
+        _check(self._lib.snarkv_poseidon_create(
+            ctx._h, t, rate, r_f, r_p, flat(tables["start"]), flat(tables["partial"]), flat(tables["end"]),
+            flat(tables["mds"]), flat(tables["pre_sparse_mds"]), flat(tables["sparse_rows"]),
+            flat(tables["sparse_col_hats"]), ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.snarkv_poseidon_destroy(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):
@@ -257,6 +301,21 @@ class Context:
 
     def sample_points_dev(self, seed, n, d_out, first=0):
         _check(self._lib.snarkv_sample_points_dev(self._h, seed, first, n, d_out))
+
+    def poseidon_transcript_batch(self, spec, elems, n, seg_len):
+        """n transcripts: `elems` = n*L canonical 32-byte Fr, absorbed in len(seg_len) segments with a
+        squeeze after each; returns n*len(seg_len) challenges (32 bytes LE each)."""
+        import array
+
+        elems = _as_bytes(elems)
+        L = sum(seg_len)
+        assert len(elems) == 32 * n * L
+        segs = array.array("I", seg_len)
+        addr, _ = segs.buffer_info()
+        out = ctypes.create_string_buffer(32 * n * len(seg_len))
+        _check(self._lib.snarkv_poseidon_transcript_batch(self._h, spec._h, elems if elems else b"\x00", n, L,
+                                                          ctypes.c_void_p(addr), len(seg_len), out))
+        return out.raw
 
     def ubench_valu(self, which, iters=400):
         v = ctypes.c_double()

@@ -480,4 +480,22 @@ int bn254_kzg_decide(const uint8_t g1_64[64], const uint8_t g2_128[128], const u
   return ok ? 1 : 0;
 }
 
+int bn254_poseidon_create(uint32_t t, uint32_t rate, uint32_t r_f, uint32_t r_p, const uint8_t* start,
+                          const uint8_t* partial, const uint8_t* end, const uint8_t* mds, const uint8_t* pre_sparse_mds,
+                          const uint8_t* sparse_rows, const uint8_t* sparse_col_hats, snarkv_poseidon** out) {
+  SNARKV_DEFAULT_CALL_LOCK();
+  snarkv_ctx* c;
+  SNARKV_TRY(default_ctx(&c));
+  return snarkv_poseidon_create(c, t, rate, r_f, r_p, start, partial, end, mds, pre_sparse_mds, sparse_rows,
+                                sparse_col_hats, out);
+}
+
+int bn254_poseidon_transcript_batch(const snarkv_poseidon* ps, const uint8_t* elems, size_t n, size_t L,
+                                    const uint32_t* seg_len, size_t S, uint8_t* out) {
+  SNARKV_DEFAULT_CALL_LOCK();
+  snarkv_ctx* c;
+  SNARKV_TRY(default_ctx(&c));
+  return snarkv_poseidon_transcript_batch(c, ps, elems, n, L, seg_len, S, out);
+}
+
 }  // extern "C"

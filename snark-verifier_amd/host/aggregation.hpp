@@ -8,6 +8,9 @@
 // segmented launch, the accumulation step is a second launch, the pairing a third.
 #pragma once
 #include <chrono>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <type_traits>
 
 #include "plonk.hpp"
@@ -21,9 +24,87 @@ struct AggregationTimings {  // milliseconds, wall clock
 
 // MOS: Gwc19 | Bdfg21.  TR: EvmTranscript | PoseidonTranscript (the transcript of the INNER proofs;
 // the accumulation step uses a fresh EvmTranscript, as the outer EVM proof would).
+// The device-resident Poseidon tables (one per parameter set, created on first use).
+inline const snarkv_poseidon* device_poseidon(int t, int rate, int r_f, int r_p) {
+  static std::map<std::tuple<int, int, int, int>, const snarkv_poseidon*> cache;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_tuple(t, rate, r_f, r_p);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  PoseidonTableBytes b = poseidon_table_bytes(t, r_f, r_p);
+  snarkv_poseidon* h = nullptr;
+  std::lock_guard<std::mutex> dev(device_mutex());
+  if (bn254_poseidon_create((uint32_t)t, (uint32_t)rate, (uint32_t)r_f, (uint32_t)r_p, b.start.data(), b.partial.data(),
+                            b.end.data(), b.mds.data(), b.pre_sparse.data(), b.rows.data(), b.cols.data(), &h) != SNARKV_OK)
+    throw std::runtime_error(std::string("bn254_poseidon_create: ") + snarkv_last_error());
+  cache[key] = h;
+  return h;
+}
+
+// Tag: Poseidon transcripts inside the proofs, hashed on the DEVICE for the whole batch
+// (two host parsing passes around one `snarkv_poseidon_transcript_batch` launch).
+struct PoseidonTranscriptOnDevice {};
+
 template <class MOS, class TR>
 struct Aggregator {
   using SV = PlonkSuccinctVerifier<MOS>;
+
+  // `read_proof` of every proof with the hashing on the device.  Fills pfs; returns the first error.
+  static Error read_proofs_device_hashed(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
+                                         const std::vector<std::vector<std::vector<Fr>>>& instances,
+                                         const std::vector<std::vector<uint8_t>>& proofs, unsigned threads,
+                                         std::vector<PlonkProof<MOS>>& pfs) {
+    const size_t n = proofs.size();
+    const int T = 5, RATE = 4, R_F = 8, R_P = 60;  // examples/evm-verifier-with-accumulator.rs:36-39
+    std::vector<Error> errs(n);
+    std::vector<std::vector<Fr>> elems(n);
+    std::vector<std::vector<uint32_t>> segs(n);
+    std::vector<std::vector<G1Affine>> decoded(n);
+    // pass 1: parse (points are decompressed here) and record what the sponge would see
+    parallel_for(n, threads, [&](size_t i) {
+      PoseidonTranscriptT<RecordingSponge> t(proofs[i], T, RATE, R_F, R_P);
+      auto pf = SV::read_proof(svk, pr, instances[i], t);
+      if (!pf.ok()) {
+        errs[i] = pf.err;
+        return;
+      }
+      elems[i] = std::move(t.sponge().elems);
+      segs[i] = std::move(t.sponge().seg_len);
+      decoded[i] = std::move(t.decoded_points());
+    }, 4);
+    for (auto& e : errs)
+      if (!e.ok()) return e;
+    for (size_t i = 1; i < n; ++i)
+      if (segs[i] != segs[0]) return Error{Error::InvalidProtocol, "proofs of one protocol with different transcript shapes"};
+    const size_t L = elems[0].size(), S = segs[0].size();
+    std::vector<uint8_t> packed(std::max<size_t>(32, 32 * L * n)), out(32 * S * n);
+    parallel_for(n, threads, [&](size_t i) {
+      for (size_t k = 0; k < L; ++k) elems[i][k].to_bytes(&packed[32 * (i * L + k)]);
+    }, 64);
+    {
+      const snarkv_poseidon* ps = device_poseidon(T, RATE, R_F, R_P);
+      std::lock_guard<std::mutex> dev(device_mutex());
+      if (bn254_poseidon_transcript_batch(ps, packed.data(), n, L, segs[0].data(), S, out.data()) != SNARKV_OK)
+        throw std::runtime_error(std::string("bn254_poseidon_transcript_batch: ") + snarkv_last_error());
+    }
+    // pass 2: parse again with the real challenges
+    parallel_for(n, threads, [&](size_t i) {
+      PoseidonTranscriptT<ReplaySponge> t(proofs[i], T, RATE, R_F, R_P);
+      t.set_decoded_points(std::move(decoded[i]));
+      t.sponge().challenges.resize(S);
+      for (size_t q = 0; q < S; ++q) Fr::from_bytes(&out[32 * (i * S + q)], &t.sponge().challenges[q]);
+      auto pf = SV::read_proof(svk, pr, instances[i], t);
+      if (!pf.ok()) {
+        errs[i] = pf.err;
+        return;
+      }
+      pfs[i] = std::move(*pf.value);
+    }, 4);
+    for (auto& e : errs)
+      if (!e.ok()) return e;
+    return Error{};
+  }
 
   // succinct-verify every proof and fold the accumulators into one
   static Result<KzgAccumulator> aggregate(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
@@ -40,18 +121,27 @@ struct Aggregator {
     std::vector<Error> errs(n);
     std::vector<typename SV::Pairs> jobs(2 * n);
     std::vector<double> t_read(n, 0.0);
+    constexpr bool kDeviceHash = std::is_same<TR, PoseidonTranscriptOnDevice>::value;
     // a Keccak proof costs ~30 us of host work (a thread start ~ one proof), a Poseidon one ~0.5 ms
     constexpr size_t grain = std::is_same<TR, PoseidonTranscript>::value ? 1 : 16;
+    double device_hash_ms = 0;
+    if constexpr (kDeviceHash) {
+      Error e = read_proofs_device_hashed(svk, pr, instances, proofs, threads, pfs);
+      if (!e.ok()) return R::Err(e);
+      device_hash_ms = ms(t0, clk::now());
+    }
     // one pass per proof: read_proof, then the host half of verify (the pair lists of its two MSMs)
     parallel_for(n, threads, [&](size_t i) {
       auto a = clk::now();
-      TR t(proofs[i]);
-      auto pf = SV::read_proof(svk, pr, instances[i], t);
-      if (!pf.ok()) {
-        errs[i] = pf.err;
-        return;
+      if constexpr (!kDeviceHash) {
+        TR t(proofs[i]);
+        auto pf = SV::read_proof(svk, pr, instances[i], t);
+        if (!pf.ok()) {
+          errs[i] = pf.err;
+          return;
+        }
+        pfs[i] = std::move(*pf.value);
       }
-      pfs[i] = std::move(*pf.value);
       t_read[i] = ms(a, clk::now());
       auto p2 = SV::msm_pairs(svk, pr, instances[i], pfs[i]);
       if (!p2.ok()) {
@@ -82,6 +172,10 @@ struct Aggregator {
       double frac = std::min(1.0, std::max(0.0, (read_sum / used) / std::max(host, 1e-9)));
       tm->read_proofs = host * frac;
       tm->fr_algebra = host * (1.0 - frac);
+      if (kDeviceHash) {  // the read phase was timed as a whole (two parsing passes + the device launch)
+        tm->read_proofs = device_hash_ms;
+        tm->fr_algebra = host - device_hash_ms;
+      }
       tm->msm_device = ms(t2, t3);
       tm->accumulate = ms(t3, t4);
       tm->total = ms(t0, t4);

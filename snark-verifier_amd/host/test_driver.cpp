@@ -717,8 +717,10 @@ static int aggregate_impl(int tkind, const uint8_t* protocol, size_t plen, const
       pbytes.emplace_back(pp + 4, pp + 4 + len);
       pp += 4 + len;
     }
-    return tkind == 0 ? aggregate_run<MOS, EvmTranscript>(pr, dk, insts, pbytes, threads, timings_ms, acc_out128)
-                      : aggregate_run<MOS, PoseidonTranscript>(pr, dk, insts, pbytes, threads, timings_ms, acc_out128);
+    // tkind: 0 Keccak, 1 Poseidon hashed on the host, 2 Poseidon hashed on the device
+    if (tkind == 0) return aggregate_run<MOS, EvmTranscript>(pr, dk, insts, pbytes, threads, timings_ms, acc_out128);
+    if (tkind == 1) return aggregate_run<MOS, PoseidonTranscript>(pr, dk, insts, pbytes, threads, timings_ms, acc_out128);
+    return aggregate_run<MOS, PoseidonTranscriptOnDevice>(pr, dk, insts, pbytes, threads, timings_ms, acc_out128);
   });
 }
 

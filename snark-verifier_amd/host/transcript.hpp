@@ -743,11 +743,44 @@ inline bool g1_decompress(const uint8_t in[32], G1Affine* out) {
   return true;
 }
 
-class PoseidonTranscript : public Transcript {
+// Sponge policies for the transcript below.  `Poseidon` (above) hashes on the host.  The other
+// two split a transcript into "what was absorbed, where were the squeezes" and "parse again with
+// the challenges known": the sequence of absorb / squeeze operations of a proof is fixed by the
+// protocol, so the hashing of MANY proofs can be one device launch
+// (`snarkv_poseidon_transcript_batch`, csrc/poseidon.hip) between two cheap parsing passes.
+struct RecordingSponge {
+  std::vector<Fr> elems;          // every absorbed element, in order
+  std::vector<uint32_t> seg_len;  // elements absorbed before each squeeze
+  uint32_t cur = 0;
+  RecordingSponge(int, int, int, int) {}
+  void update(const std::vector<Fr>& e) {
+    elems.insert(elems.end(), e.begin(), e.end());
+    cur += (uint32_t)e.size();
+  }
+  Fr squeeze() {
+    seg_len.push_back(cur);
+    cur = 0;
+    return Fr::one();  // placeholder: reading a proof only STORES challenges
+  }
+};
+struct ReplaySponge {
+  std::vector<Fr> challenges;
+  size_t next = 0;
+  ReplaySponge(int, int, int, int) {}
+  void update(const std::vector<Fr>&) {}
+  Fr squeeze() {
+    if (next >= challenges.size()) throw Panic("ReplaySponge: more squeezes than recorded challenges");
+    return challenges[next++];
+  }
+};
+
+template <class Sponge>
+class PoseidonTranscriptT : public Transcript {
  public:
   // T = 5, RATE = 4, R_F = 8, R_P = 60: examples/evm-verifier-with-accumulator.rs:36-39
-  explicit PoseidonTranscript(std::vector<uint8_t> proof = {}, int t = 5, int rate = 4, int r_f = 8, int r_p = 60)
+  explicit PoseidonTranscriptT(std::vector<uint8_t> proof = {}, int t = 5, int rate = 4, int r_f = 8, int r_p = 60)
       : stream_(std::move(proof)), buf_(t, rate, r_f, r_p) {}
+  Sponge& sponge() { return buf_; }
 
   Fr squeeze_challenge() override { return buf_.squeeze(); }  // halo2.rs:211-213
   Error common_scalar(const Fr& s) override {                 // halo2.rs:215-218
@@ -778,9 +811,15 @@ class PoseidonTranscript : public Transcript {
     if (pos_ + 32 > stream_.size())
       return Result<G1Affine>::Err(Error{Error::Transcript, "failed to fill whole buffer"});
     G1Affine p;
-    bool ok = g1_decompress(stream_.data() + pos_, &p);
+    bool ok = true;
+    if (next_decoded_ < decoded_in_.size()) {
+      p = decoded_in_[next_decoded_++];  // second parsing pass: the square root was taken in the first
+    } else {
+      ok = g1_decompress(stream_.data() + pos_, &p);
+    }
     pos_ += 32;
     if (!ok) return Result<G1Affine>::Err(Error{Error::Transcript, "Invalid elliptic curve point encoding in proof"});
+    decoded_.push_back(p);
     Error e = common_ec_point(p);  // the identity decodes but has no coordinates to absorb
     if (!e.ok()) return Result<G1Affine>::Err(e);
     return Result<G1Affine>::Ok(p);
@@ -807,7 +846,47 @@ class PoseidonTranscript : public Transcript {
  private:
   std::vector<uint8_t> stream_;
   size_t pos_ = 0;
-  Poseidon buf_;
+  Sponge buf_;
+  std::vector<G1Affine> decoded_, decoded_in_;  // points decompressed by this pass / handed over by an earlier one
+  size_t next_decoded_ = 0;
+
+ public:
+  std::vector<G1Affine>& decoded_points() { return decoded_; }
+  void set_decoded_points(std::vector<G1Affine> pts) {
+    decoded_in_ = std::move(pts);
+    next_decoded_ = 0;
+  }
 };
+using PoseidonTranscript = PoseidonTranscriptT<Poseidon>;
+
+// The optimised tables as 32-byte LE rows, in the order `snarkv_poseidon_create` takes them
+// (= the fields of the reference's `poseidon::Spec`).
+struct PoseidonTableBytes {
+  std::vector<uint8_t> start, partial, end, mds, pre_sparse, rows, cols;
+};
+inline PoseidonTableBytes poseidon_table_bytes(int t, int r_f, int r_p) {
+  const PoseidonOpt& o = poseidon_opt(t, r_f, r_p);
+  PoseidonTableBytes b;
+  auto put = [](std::vector<uint8_t>& v, const Fr& x) {
+    size_t k = v.size();
+    v.resize(k + 32);
+    x.to_bytes(&v[k]);
+  };
+  const int h = r_f / 2;
+  for (auto& x : o.pre) put(b.start, x);
+  for (int r = 0; r < h; ++r)
+    for (auto& x : o.full_k[(size_t)r]) put(b.start, x);
+  for (auto& x : o.partial_k) put(b.partial, x);
+  for (size_t r = (size_t)h; r < o.full_k.size(); ++r)
+    for (auto& x : o.full_k[r]) put(b.end, x);
+  for (auto& x : o.mds) put(b.mds, x);
+  for (auto& x : o.pre_sparse) put(b.pre_sparse, x);
+  for (auto& row : o.sparse_row)
+    for (auto& x : row) put(b.rows, x);
+  for (auto& col : o.sparse_col)
+    for (auto& x : col) put(b.cols, x);
+  if (b.end.empty()) b.end.resize(32);  // r_f = 2: no rows, but a valid pointer
+  return b;
+}
 
 }  // namespace snarkv_host

@@ -8,6 +8,7 @@
 #include "../../snark-verifier_amd/csrc/glv.cuh"
 #include "../../snark-verifier_amd/csrc/pairing_coop.cuh"
 #include "../../snark-verifier_amd/csrc/pairing_coop29.cuh"
+#include "../../snark-verifier_amd/csrc/fr29.cuh"
 
 using namespace snarkv;
 
@@ -276,5 +277,25 @@ void ht29_fq_mul2(const uint8_t* a, const uint8_t* b, const uint8_t* c, const ui
   Fq29 cc = load29(c);
   if (neg_c) cc = fq29_neg(cc);
   store29(fq29_mul2(load29(a), load29(b), cc, load29(d)), out);
+}
+// scalar field on the 29-bit form (fr29.cuh): ((a * b) + c)^5, canonical in / out
+void ht_fr29_expr(const uint8_t* a, const uint8_t* b, const uint8_t* c, uint8_t* out) {
+  uint32_t w[8];
+  memcpy(w, a, 32);
+  Fr29 x = fr29_from_canonical(w);
+  memcpy(w, b, 32);
+  Fr29 y = fr29_from_canonical(w);
+  memcpy(w, c, 32);
+  Fr29 z = fr29_from_canonical(w);
+  Fr29 r = fr29_pow5(fr29_norm(fr29_add(fr29_mul(x, y), z)));
+  fr29_to_canonical(r, w);
+  memcpy(out, w, 32);
+}
+void ht_fr29_roundtrip(const uint8_t* a, uint8_t* out) {
+  uint32_t w[8];
+  memcpy(w, a, 32);
+  Fr29 x = fr29_canon_residue(fr29_from_canonical(w));
+  fr29_to_canonical(x, w);
+  memcpy(out, w, 32);
 }
 }

@@ -282,3 +282,17 @@ def test_cooperative_fq12_coop3_rounds(hosttest_lib):
         for _ in range(3):
             exp = exp * exp * Lm
         assert o.raw == exp.to_bytes()
+
+
+def test_fr29_scalar_field(hosttest_lib):
+    """fr29.cuh (the Poseidon kernel's field): Montgomery product, lazy add, x^5, codecs, vs Python mod r."""
+    rng = random.Random(31)
+    o = _buf(32)
+    fb = lambda x: (x % O.R).to_bytes(32, "little")
+    vals = [0, 1, 2, O.R - 1, O.R - 2, (O.R - 1) // 2] + [rng.randrange(O.R) for _ in range(40)]
+    for a in vals:
+        hosttest_lib.ht_fr29_roundtrip(fb(a), o)
+        assert int.from_bytes(o.raw, "little") == a
+        b, c = rng.choice(vals), rng.choice(vals)
+        hosttest_lib.ht_fr29_expr(fb(a), fb(b), fb(c), o)
+        assert int.from_bytes(o.raw, "little") == pow((a * b + c) % O.R, 5, O.R)

@@ -232,6 +232,14 @@ def test_end_to_end_aggregation_of_64_proofs(H, threads):
     n2, pb2, ib2, prb2, dk2, exp2 = load_bench_blob("poseidon")
     rc = H.hd_aggregate_end_to_end(0, 1, pb2, len(pb2), ib2, len(ib2), prb2, len(prb2), n2, dk2, threads, tm, acc)
     assert rc == 1 and acc.raw == exp2
+    # ... and with the Poseidon hashing of all 64 transcripts in ONE device launch (csrc/poseidon.hip)
+    acc2 = ctypes.create_string_buffer(128)
+    rc = H.hd_aggregate_end_to_end(0, 2, pb2, len(pb2), ib2, len(ib2), prb2, len(prb2), n2, dk2, threads, tm, acc2)
+    assert rc == 1 and acc2.raw == exp2
+    bad2 = bytearray(prb2)
+    bad2[4 + 40] ^= 1  # inside the first proof
+    rc = H.hd_aggregate_end_to_end(0, 2, pb2, len(pb2), ib2, len(ib2), bytes(bad2), len(bad2), n2, dk2, threads, tm, acc2)
+    assert rc in (0, -10)
     # replicate the batch 4x (256 proofs): still one launch per stage, still accepted
     rc = H.hd_aggregate_end_to_end(0, 0, pb, len(pb), ib * 4, 4 * len(ib), prb * 4, 4 * len(prb), 4 * n, dk, threads, tm, acc)
     assert rc == 1
