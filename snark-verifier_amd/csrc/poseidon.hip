@@ -81,17 +81,52 @@ struct PoseidonShape {
   uint32_t o_start, o_partial, o_end, o_mds, o_pre, o_rows, o_cols, n_tables;
 };
 
-__device__ __forceinline__ Fr29 shfl8(const Fr29& x, int src) {
+// Exchanges inside the 8-lane group of one transcript, as DPP modifiers (no LDS crossbar):
+//   broadcast of lane I: quad_perm [i,i,i,i] fills I's quad, a bank-masked row_shr:4 / row_shl:4
+//   copies it into the other quad of the group (banks = quads of a 16-lane row);
+//   sum over the group: xor-1 and xor-2 inside quads, then row_half_mirror swaps the two quads.
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ int32_t dpp_keep(int32_t old, int32_t x) {
+  return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xF, BANK_MASK, false);
+}
+template <int I>
+__device__ __forceinline__ Fr29 bcast8(const Fr29& x) {
+  constexpr int q = I & 3;
+  constexpr int quad = q | (q << 2) | (q << 4) | (q << 6);
   Fr29 r;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) r.v[i] = __shfl(x.v[i], src, 8);
+  for (int k = 0; k < 9; ++k) {
+    int32_t v = __builtin_amdgcn_update_dpp(0, x.v[k], quad, 0xF, 0xF, true);  // every quad: its own lane q
+    // the quad that does NOT hold lane I takes the value from the one that does
+    r.v[k] = I < 4 ? dpp_keep<0x114, 0xA>(v, v)   // row_shr:4 into the upper quads (banks 1, 3)
+                   : dpp_keep<0x104, 0x5>(v, v);  // row_shl:4 into the lower quads (banks 0, 2)
+  }
   return r;
 }
-__device__ __forceinline__ Fr29 shfl8_xor(const Fr29& x, int mask) {
-  Fr29 r;
+__device__ __forceinline__ Fr29 shfl8(const Fr29& x, int src) {  // src is wavefront-uniform
+  switch (src) {
+    case 0: return bcast8<0>(x);
+    case 1: return bcast8<1>(x);
+    case 2: return bcast8<2>(x);
+    case 3: return bcast8<3>(x);
+    case 4: return bcast8<4>(x);
+    case 5: return bcast8<5>(x);
+    case 6: return bcast8<6>(x);
+    default: return bcast8<7>(x);
+  }
+}
+// every lane of the group gets the limb-wise sum over its 8 lanes (limbs as unsigned)
+__device__ __forceinline__ Fr29 group8_sum_u(Fr29 x) {
 #pragma unroll
-  for (int i = 0; i < 9; ++i) r.v[i] = __shfl_xor(x.v[i], mask, 8);
-  return r;
+  for (int k = 0; k < 9; ++k)
+    x.v[k] = (int32_t)((uint32_t)x.v[k] + (uint32_t)__builtin_amdgcn_update_dpp(0, x.v[k], 0xB1, 0xF, 0xF, true));
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+    x.v[k] = (int32_t)((uint32_t)x.v[k] + (uint32_t)__builtin_amdgcn_update_dpp(0, x.v[k], 0x4E, 0xF, 0xF, true));
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+    x.v[k] = (int32_t)((uint32_t)x.v[k] + (uint32_t)__builtin_amdgcn_update_dpp(0, x.v[k], 0x141, 0xF, 0xF, true));
+  return x;
 }
 
 // new word j = sum_i M[j][i] * s_i : pairs of products fused, lazy sum, one carry pass
@@ -164,12 +199,7 @@ __global__ void __launch_bounds__(256)
       // word 0: row . state  (butterfly over the 8 lanes; lanes >= t contribute zero)
       Fr29 sum = w0 ? p2 : p1;
       if ((uint32_t)j >= t) sum = fr29_zero();
-#pragma unroll
-      for (int m = 1; m < 8; m <<= 1) {
-        Fr29 o = shfl8_xor(sum, m);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) sum.v[k] = (int32_t)((uint32_t)sum.v[k] + (uint32_t)o.v[k]);
-      }
+      sum = group8_sum_u(sum);
       // limbs 0..7 of `sum` are sums of <= 8 values in [0, 2^29): read them as unsigned
       Fr29 n0;
       {
