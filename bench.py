@@ -368,7 +368,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32x8 (254-bit Montgomery Fq on the integer VALU)",
+            "dtype": "i32x9 (254-bit Montgomery Fq as 9 x 29-bit signed lazy limbs on the integer VALU, 64-bit column accumulators)",
             "data": "synthetic",
             "config": {
                 "workload": "BN254 G1 Pippenger MSM, 2^%d random points/scalars per GPU, inputs resident in HBM, "
