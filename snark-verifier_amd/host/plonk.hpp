@@ -29,111 +29,6 @@
 
 namespace snarkv_host {
 
-// Proofs are independent: the host front half (transcript hashing, expression
-// evaluation) is spread over host threads.  A persistent pool: starting a thread costs
-// about as much as the host work of one Keccak-transcript proof, and an aggregation
-// makes several passes.
-class HostPool {
- public:
-  static HostPool& get() {
-    static HostPool p;
-    return p;
-  }
-  unsigned size() const { return (unsigned)workers_.size(); }
-  // runs fn(i) for i in [0, n) on up to `threads` pool workers (the caller blocks); the first exception wins
-  template <class F>
-  void run(size_t n, unsigned threads, F&& fn) {
-    threads = std::min<unsigned>(threads, size());
-    if (threads <= 1 || n <= 1) {
-      for (size_t i = 0; i < n; ++i) fn(i);
-      return;
-    }
-    std::lock_guard<std::mutex> one_job(submit_mu_);  // one job at a time keeps the bookkeeping trivial
-    Job job;
-    job.n = n;
-    job.fn = [&](size_t i) { fn(i); };
-    job.slots = threads;
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      job_ = &job;
-      ++generation_;
-    }
-    cv_.notify_all();
-    std::unique_lock<std::mutex> lk(mu_);
-    done_cv_.wait(lk, [&] { return job.finished == job.started && job.next.load() >= n && job.slots_left() == false; });
-    job_ = nullptr;
-    lk.unlock();
-    if (job.err) std::rethrow_exception(job.err);
-  }
-
- private:
-  struct Job {
-    size_t n = 0;
-    std::function<void(size_t)> fn;
-    std::atomic<size_t> next{0};
-    unsigned slots = 0, started = 0, finished = 0;  // guarded by mu_
-    std::exception_ptr err;
-    std::atomic<bool> failed{false};
-    bool slots_left() const { return started < slots && next.load() < n; }
-  };
-  HostPool() {
-    unsigned hc = std::max(1u, std::thread::hardware_concurrency());
-    unsigned k = std::min(64u, hc);
-    for (unsigned i = 0; i < k; ++i) workers_.emplace_back([this] { loop(); });
-  }
-  ~HostPool() {
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      stop_ = true;
-    }
-    cv_.notify_all();
-    for (auto& w : workers_) w.join();
-  }
-  void loop() {
-    uint64_t seen = 0;
-    for (;;) {
-      Job* job = nullptr;
-      {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return stop_ || (job_ && generation_ != seen && job_->slots_left()); });
-        if (stop_) return;
-        seen = generation_;
-        job = job_;
-        ++job->started;
-      }
-      for (;;) {
-        size_t i = job->next.fetch_add(1);
-        if (i >= job->n || job->failed.load()) break;
-        try {
-          job->fn(i);
-        } catch (...) {
-          if (!job->failed.exchange(true)) job->err = std::current_exception();
-          job->next.store(job->n);  // nothing more to hand out
-          break;
-        }
-      }
-      {
-        std::lock_guard<std::mutex> lk(mu_);
-        ++job->finished;
-      }
-      done_cv_.notify_all();
-    }
-  }
-  std::vector<std::thread> workers_;
-  std::mutex mu_, submit_mu_;
-  std::condition_variable cv_, done_cv_;
-  Job* job_ = nullptr;
-  uint64_t generation_ = 0;
-  bool stop_ = false;
-};
-
-// `grain`: items per thread below which another thread is not worth waking.
-template <class F>
-inline void parallel_for(size_t n, unsigned threads, F&& fn, size_t grain = 16) {
-  threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(1, n / std::max<size_t>(1, grain)));
-  HostPool::get().run(n, threads, std::forward<F>(fn));
-}
-
 // util/arithmetic.rs:123-160
 struct Domain {
   size_t k = 0, n = 0;
