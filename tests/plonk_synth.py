@@ -172,3 +172,92 @@ def pack_protocol(pr):
 
 def pack_instances(instances):
     return _u32(len(instances)) + b"".join(_u32(len(x)) + b"".join(_fr(v) for v in x) for x in instances)
+
+
+# ---------------------------------------------------------------- random shapes (fuzzing the mirror against the oracle)
+def random_protocol(rng, linearization=None):
+    """A random but well-formed protocol: random counts of preprocessed / instance / witness
+    polynomials over random phases, random rotations, a random expression tree over every node
+    kind as numerator, random quotient chunking.  Every polynomial query the numerator makes has
+    an evaluation (so it is a constant, as without linearization), except -- in linearized modes --
+    a few rotation-0 queries that appear only linearly."""
+    k = rng.randrange(3, 8)
+    dom = P.Domain(k)
+    n_pre = rng.randrange(1, 6)
+    pre_dlogs = [rng.randrange(1, R) for _ in range(n_pre)]
+    preprocessed = [O.g1_mul(O.G1_GEN, c) for c in pre_dlogs]
+    num_instance = [rng.randrange(1, 4) for _ in range(rng.randrange(1, 3))]
+    phases = rng.randrange(1, 4)
+    num_witness = [rng.randrange(0, 4) for _ in range(phases)]
+    if sum(num_witness) == 0:
+        num_witness[0] = 1
+    num_challenge = [rng.randrange(0, 3) for _ in range(phases)]
+    if sum(num_challenge) == 0:
+        num_challenge[-1] = 1
+    n_ch = sum(num_challenge)
+    I0 = n_pre
+    W0 = I0 + len(num_instance)
+    n_w = sum(num_witness)
+    Q = W0 + n_w
+    rots = [0, 1, -1, rng.randrange(-9, -2), 2]
+    committed = [i for i in range(n_pre)] + [W0 + i for i in range(n_w)]
+    qpool = [(p, rng.choice(rots)) for p in committed for _ in range(2)]
+    qpool = list(dict.fromkeys(qpool))
+    rng.shuffle(qpool)
+    evaluated = qpool[:max(2, len(qpool) * 2 // 3)]
+    inst_q = [(I0 + t, rng.choice([0, 0, 1, -1])) for t in range(len(num_instance))]
+    linear_only = []
+    if linearization is not None:
+        cand = [(p, 0) for p in committed if (p, 0) not in evaluated]
+        linear_only = cand[:2]
+
+    def leaf():
+        c = rng.randrange(7)
+        if c == 0:
+            return ("const", rng.randrange(R))
+        if c == 1:
+            return ("identity",)
+        if c == 2:
+            return ("lagrange", rng.choice([0, -1, 1, -4, 3]))
+        if c == 3:
+            return ("challenge", rng.randrange(n_ch))
+        if c == 4:
+            q = rng.choice(inst_q)
+            return ("poly", q[0], q[1])
+        q = rng.choice(evaluated)
+        return ("poly", q[0], q[1])
+
+    def tree(d):
+        if d == 0 or rng.random() < 0.25:
+            return leaf()
+        c = rng.randrange(6)
+        if c == 0:
+            return ("neg", tree(d - 1))
+        if c == 1:
+            return ("sum", tree(d - 1), tree(d - 1))
+        if c == 2:
+            return ("prod", tree(d - 1), tree(d - 1))
+        if c == 3:
+            return ("scaled", tree(d - 1), rng.randrange(R))
+        if c == 4:
+            return ("dpow", [tree(d - 1) for _ in range(rng.randrange(1, 4))], leaf() if rng.random() < 0.5 else ("challenge", rng.randrange(n_ch)))
+        return ("sum", tree(d - 1), leaf())
+
+    numerator = ("dpow", [tree(3) for _ in range(rng.randrange(1, 5))], ("challenge", rng.randrange(n_ch)))
+    for p, _ in linear_only:  # commitments entering linearly: (constant tree) * poly + ...
+        numerator = ("sum", numerator, ("prod", ("scaled", ("challenge", rng.randrange(n_ch)), rng.randrange(R)), ("poly", p, 0)))
+    evaluations = list(evaluated)
+    num_chunk = rng.randrange(1, 5)
+    queries = list(evaluated) + [(Q, 0)]
+    if linearization == "WithoutConstant":
+        evaluations.append((Q + 1, 0))
+        queries.append((Q + 1, 0))
+    rng.shuffle(queries)
+    pr = {
+        "domain": dom, "preprocessed": preprocessed, "num_instance": num_instance,
+        "num_witness": num_witness, "num_challenge": num_challenge, "evaluations": evaluations, "queries": queries,
+        "quotient": {"chunk_degree": rng.randrange(1, 4), "num_chunk": num_chunk, "numerator": numerator},
+        "transcript_initial_state": rng.randrange(R) if rng.random() < 0.5 else None,
+        "instance_committing_key": None, "linearization": linearization, "accumulator_indices": [],
+    }
+    return pr, pre_dlogs

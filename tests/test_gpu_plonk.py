@@ -278,3 +278,22 @@ def test_proof_sharded_aggregation_wiring(H):
         off += 4 + ln
     acc, ok = D.gpu_sharded_aggregation(H, 0, 0, pb, insts, proofs, dk)
     assert ok and acc == exp
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_protocol_shapes_cpp_vs_oracle(H, seed):
+    """Fuzzing the mirror against the oracle: random polynomial counts, phases, rotations,
+    expression trees over every node kind (nested DistributePowers, Scaled, Negated, ...),
+    quotient chunking, both multi-open schemes, both transcripts, all linearization modes."""
+    rng = random.Random(5000 + seed)
+    lin = rng.choice([None, None, "WithoutConstant", "MinusVanishingTimesQuotient"])
+    mos = rng.randrange(2)
+    kind = rng.randrange(2)
+    pr, dl = S.random_protocol(rng, lin)
+    inst = [[rng.randrange(O.R) for _ in range(n)] for n in pr["num_instance"]]
+    proof = P.forge_proof(pr, inst, SECRET, lambda: mk_transcript(kind), MOS[mos], rng, dl)
+    exp = oracle_accs(MOS[mos], kind, pr, inst, proof)
+    assert exp[0][0] == O.g1_mul(exp[0][1], SECRET)
+    rc, accs = run(H, mos, kind, pr, [inst], [proof])
+    assert rc == 1, (seed, lin, mos, kind)
+    assert accs == b"".join(g1(a) + g1(b) for a, b in exp)

@@ -93,3 +93,21 @@ def test_golden_fixture_reproduces():
         assert hex(pf["z"]) == case["z"]
         accs = P.succinct_verify(O.G1_GEN, pr, inst, pf, mos)
         assert [(O.g1_to_bytes(a) + O.g1_to_bytes(b)).hex() for a, b in accs] == case["accumulators"]
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_protocol_shapes_verify_in_the_oracle(seed):
+    """The forger + oracle verifier on random protocol shapes (the same generator the GPU
+    fuzz test drives the C++ mirror with)."""
+    rng = random.Random(7000 + seed)
+    lin = rng.choice([None, None, "WithoutConstant", "MinusVanishingTimesQuotient"])
+    mos = rng.choice(["gwc19", "bdfg21"])
+    kind = rng.randrange(2)
+    pr, dl = S.random_protocol(rng, lin)
+    inst = [[rng.randrange(O.R) for _ in range(n)] for n in pr["num_instance"]]
+    proof = P.forge_proof(pr, inst, SECRET, lambda: _t(kind), mos, rng, dl)
+    t = _t(kind, proof)
+    pf = P.plonk_proof_read(pr, inst, t, mos)
+    assert t.pos == len(t.stream)
+    lhs, rhs = P.succinct_verify(O.G1_GEN, pr, inst, pf, mos)[0]
+    assert lhs == O.g1_mul(rhs, SECRET)
