@@ -295,7 +295,9 @@ def g1_decompress(b):
     x = int.from_bytes(b, "little")
     if x >= O.P:
         raise TranscriptError("Invalid elliptic curve point encoding in proof")
-    if x == 0 and is_inf:
+    if is_inf:  # the identity has exactly one encoding: flag set, everything else zero
+        if x != 0 or ysign:
+            raise TranscriptError("Invalid elliptic curve point encoding in proof")
         return None
     y2 = (x * x * x + 3) % O.P
     y = pow(y2, (O.P + 1) // 4, O.P)

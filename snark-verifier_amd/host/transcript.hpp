@@ -725,7 +725,8 @@ inline bool g1_decompress(const uint8_t in[32], G1Affine* out) {
   uint64_t x[4];
   memcpy(x, xb, 32);
   if (!fq_host::lt_p(x)) return false;
-  if ((x[0] | x[1] | x[2] | x[3]) == 0 && is_inf) {
+  if (is_inf) {  // the identity has exactly one encoding: flag set, everything else zero
+    if ((x[0] | x[1] | x[2] | x[3]) != 0 || ysign) return false;
     *out = G1Affine::identity();
     return true;
   }

@@ -106,6 +106,9 @@ def main():
     padd("read_point_x_ge_p", [(5, None)], (O.P + 1).to_bytes(32, "little"))
     padd("read_identity_cannot_be_absorbed", [(5, None)], T.g1_compress(None))
     padd("read_past_end", [(4, None)], bytes(31))
+    flagged = bytearray(T.g1_compress(pts[0]))
+    flagged[31] |= 0x80
+    padd("read_point_identity_flag_on_a_finite_point", [(5, None)], bytes(flagged))
     padd("common_identity_is_error", [(3, None)])
     rc5, mds5 = T.poseidon_spec(5, 8, 60)
     rc3, mds3 = T.poseidon_spec(3, 8, 57)
