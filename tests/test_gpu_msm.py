@@ -248,3 +248,32 @@ def test_large_msm_chunk_pipelined_form_matches_unsplit(gpu_ctx, monkeypatch):
     gpu_ctx.fold_partials_dev(part.data_ptr(), 1, out.data_ptr())
     gpu_ctx.sync()
     assert bytes(out.cpu().numpy()) == res[("1", n)]
+
+
+def test_largest_config_2p24_split_linearity(gpu_ctx):
+    """BASELINE's largest size (2^24 points): too big for the CPU oracle in test time, so the
+    size-independent property -- MSM(all) == MSM(first part) + MSM(rest), through the
+    projective-partial + fold entry points the multi-GPU path uses -- at an uneven split."""
+    import torch
+
+    import snark_verifier_amd as sv
+
+    n = 1 << 24
+    ds = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+    dp = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+    gpu_ctx.sample_scalars_dev(0x5EED0001, n, ds.data_ptr())
+    gpu_ctx.sample_points_dev(0x5EED0002, n, dp.data_ptr())
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    gpu_ctx.msm_pippenger_dev(ds.data_ptr(), dp.data_ptr(), n, out.data_ptr(), 0)
+    h = (n // 3) | 1
+    parts = torch.zeros(2 * sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+    gpu_ctx.msm_pippenger_partial_dev(ds.data_ptr(), dp.data_ptr(), h, parts.data_ptr(), 0)
+    gpu_ctx.msm_pippenger_partial_dev(ds.data_ptr() + 32 * h, dp.data_ptr() + 64 * h, n - h,
+                                      parts.data_ptr() + sv.G1_PARTIAL_BYTES, 0)
+    out2 = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    gpu_ctx.fold_partials_dev(parts.data_ptr(), 2, out2.data_ptr())
+    gpu_ctx.sync()
+    a = bytes(out.cpu().numpy())
+    assert a == bytes(out2.cpu().numpy()) and a != bytes(64)
+    del ds, dp
+    torch.cuda.empty_cache()
