@@ -163,6 +163,22 @@ int snarkv_sample_points_dev(snarkv_ctx* ctx, uint64_t seed, uint64_t first, siz
  * which = 1: whole mixed G1 additions (madd/s) -- the multiplier / adder of the
  * bucket-accumulate kernel in isolation (no memory traffic).                  */
 int snarkv_ubench_valu(snarkv_ctx* ctx, int which, int iters, double* ops_per_s);
+/* ---- bucket-sharded MSM, the "bucket-sum allreduce" of config 4 ----
+ * Alternative to point-sharding + fold: every GPU accumulates the GLOBAL bucket grid
+ * (windows x 2^(c-1) signed-digit buckets, c agreed through `..._bucket_geometry`
+ * for the TOTAL n) from its shard of the points -- the `buckets[d-1].add_assign(base)`
+ * half of util/msm.rs:291-296 -- the grids are exchanged by window range and added,
+ * and each GPU runs the running-sum + `double()` half (msm.rs:285-302) on the
+ * windows it owns; the projective partials are folded as in the point-sharded path.
+ * A bucket is SNARKV_G1_PARTIAL_BYTES (144) bytes, the identity all-zero.            */
+int snarkv_g1_msm_bucket_geometry(size_t n_total, int window_bits, uint32_t* c, uint32_t* windows,
+                                  uint32_t* buckets_per_window);
+int snarkv_g1_msm_fill_buckets_dev(snarkv_ctx* ctx, const void* d_scalars32, const void* d_points64, size_t n,
+                                   int window_bits, void* d_buckets);
+int snarkv_g1_buckets_add_dev(snarkv_ctx* ctx, void* d_dst, const void* d_src, size_t count);
+int snarkv_g1_buckets_reduce_dev(snarkv_ctx* ctx, const void* d_buckets, uint32_t c, uint32_t w0, uint32_t wcount,
+                                 void* d_partial);
+
 /* ---- Poseidon transcripts, batched (SURVEY.md 8f row N2 on the device) ----
  * Replaces, for MANY proofs at once, the hashing of the reference's native
  * `PoseidonTranscript` (snark-verifier/src/system/halo2/transcript/halo2.rs:170-321

@@ -74,6 +74,10 @@ _SIGNATURES = {
     "snarkv_sample_scalars_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
     "snarkv_sample_points_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
     "snarkv_ubench_valu": (_int, [_vp, _int, _int, ctypes.POINTER(ctypes.c_double)]),
+    "snarkv_g1_msm_bucket_geometry": (_int, [_sz, _int, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
+    "snarkv_g1_msm_fill_buckets_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
+    "snarkv_g1_buckets_add_dev": (_int, [_vp, _vp, _vp, _sz]),
+    "snarkv_g1_buckets_reduce_dev": (_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
     "snarkv_poseidon_create": (_int, [_vp, _u32, _u32, _u32, _u32, _cp, _cp, _cp, _cp, _cp, _cp, _cp, _pp]),
     "snarkv_poseidon_destroy": (None, [_vp]),
     "snarkv_poseidon_transcript_batch": (_int, [_vp, _vp, _cp, _sz, _sz, _vp, _sz, _vp]),
@@ -301,6 +305,23 @@ class Context:
 
     def sample_points_dev(self, seed, n, d_out, first=0):
         _check(self._lib.snarkv_sample_points_dev(self._h, seed, first, n, d_out))
+
+    @staticmethod
+    def bucket_geometry(n_total, window_bits=0):
+        """(c, windows, buckets_per_window) every rank must use for a bucket-sharded MSM of n_total points."""
+        c, w, b = _u32(0), _u32(0), _u32(0)
+        _check(load_library().snarkv_g1_msm_bucket_geometry(n_total, window_bits, ctypes.byref(c), ctypes.byref(w),
+                                                            ctypes.byref(b)))
+        return c.value, w.value, b.value
+
+    def fill_buckets_dev(self, d_scalars, d_points, n, c, d_buckets):
+        _check(self._lib.snarkv_g1_msm_fill_buckets_dev(self._h, d_scalars, d_points, n, c, d_buckets))
+
+    def buckets_add_dev(self, d_dst, d_src, count):
+        _check(self._lib.snarkv_g1_buckets_add_dev(self._h, d_dst, d_src, count))
+
+    def buckets_reduce_dev(self, d_buckets, c, w0, wcount, d_partial):
+        _check(self._lib.snarkv_g1_buckets_reduce_dev(self._h, d_buckets, c, w0, wcount, d_partial))
 
     def poseidon_transcript_batch(self, spec, elems, n, seg_len):
         """n transcripts: `elems` = n*L canonical 32-byte Fr, absorbed in len(seg_len) segments with a

@@ -273,6 +273,38 @@ int snarkv_g1_fold_partials_dev(snarkv_ctx* ctx, const void* d_partials, size_t 
   return launch_fold_partials(ctx, d_partials, count, d_out64);
 }
 
+int snarkv_g1_msm_bucket_geometry(size_t n_total, int window_bits, uint32_t* c, uint32_t* windows,
+                                  uint32_t* buckets_per_window) {
+  if (!c || !windows || !buckets_per_window) return SNARKV_ERR_ARG;
+  if (n_total == 0) return SNARKV_ERR_EMPTY;
+  return pip_geometry(n_total, window_bits, c, windows, buckets_per_window);
+}
+
+int snarkv_g1_msm_fill_buckets_dev(snarkv_ctx* ctx, const void* d_scalars32, const void* d_points64, size_t n,
+                                   int window_bits, void* d_buckets) {
+  if (!ctx || !d_scalars32 || !d_points64 || !d_buckets || window_bits < 2 || window_bits > 22) return SNARKV_ERR_ARG;
+  if (n == 0) return SNARKV_ERR_EMPTY;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  return launch_msm_pippenger(ctx, d_scalars32, d_points64, n, window_bits, nullptr, false, d_buckets);
+}
+
+int snarkv_g1_buckets_add_dev(snarkv_ctx* ctx, void* d_dst, const void* d_src, size_t count) {
+  if (!ctx || !d_dst || !d_src) return SNARKV_ERR_ARG;
+  if (count == 0) return SNARKV_ERR_EMPTY;
+  if (count >= ((size_t)1 << 31)) return SNARKV_ERR_LENGTH;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  return launch_buckets_add(ctx, d_dst, d_src, count);
+}
+
+int snarkv_g1_buckets_reduce_dev(snarkv_ctx* ctx, const void* d_buckets, uint32_t c, uint32_t w0, uint32_t wcount,
+                                 void* d_partial) {
+  if (!ctx || !d_buckets || !d_partial || c < 2 || c > 22) return SNARKV_ERR_ARG;
+  if (wcount == 0) return SNARKV_ERR_EMPTY;
+  if ((uint64_t)w0 + wcount > (128 + c - 1) / c) return SNARKV_ERR_LENGTH;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  return launch_buckets_reduce(ctx, d_buckets, c, w0, wcount, d_partial);
+}
+
 int snarkv_dk_create(snarkv_ctx* ctx, const uint8_t g1_64[64], const uint8_t g2_128[128],
                      const uint8_t s_g2_128[128], uint32_t flags, snarkv_dk** out) {
   if (!ctx || !g1_64 || !g2_128 || !s_g2_128 || !out) return SNARKV_ERR_ARG;

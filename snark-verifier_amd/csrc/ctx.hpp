@@ -91,7 +91,10 @@ int ctx_reserve(snarkv_ctx* ctx, int slot, size_t bytes, void** out);
 int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, const void* d_offsets,
                        size_t n_msm, size_t n_terms, void* d_out);
 int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
-                         void* d_out, bool partial_out);
+                         void* d_out, bool partial_out, void* d_buckets_out = nullptr);
+int pip_geometry(size_t n_total, int window_bits, uint32_t* c, uint32_t* windows, uint32_t* buckets_per_window);
+int launch_buckets_add(snarkv_ctx* ctx, void* d_dst, const void* d_src, size_t count);
+int launch_buckets_reduce(snarkv_ctx* ctx, const void* d_buckets, uint32_t c, uint32_t w0, uint32_t wcount, void* d_partial);
 int launch_fold_partials(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64, bool partial_out = false);
 int launch_validate(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int* bad_host);
 int launch_g2_prepare(snarkv_ctx* ctx, const void* d_g2x2_256, void* d_prep);

@@ -69,7 +69,7 @@ SNARKV_HD void xyzz29_finish(G1Xyzz29& acc, const Fq29& u1, const Fq29& s1, cons
   Fq29 rr = fq29_sqr(rn);
   Fq29 x3 = fq29_norm(fq29_sub(fq29_sub(rr, ppp), fq29_dbl(q)));  // limbs before norm in (-3*2^29, 2^29)
   Fq29 t = fq29_sub(q, x3);                                         // |limb| < 2^29
-  Fq29 y3 = fq29_sub(fq29_mul(rn, t), fq29_mul(s1, ppp));
+  Fq29 y3 = fq29_mul2(rn, t, fq29_neg(s1), ppp);                    // one Montgomery reduction for both products
   acc.x = x3;
   acc.y = y3;
 }
@@ -111,7 +111,7 @@ SNARKV_HD G1Xyzz29 xyzz29_double(const G1Xyzz29& p) {
   Fq29 xx = fq29_sqr(p.x);  // p.x is carry-normalised by invariant
   Fq29 m = fq29_norm(fq29_add(fq29_dbl(xx), xx));
   r.x = fq29_norm(fq29_sub(fq29_sqr(m), fq29_dbl(s)));
-  r.y = fq29_sub(fq29_mul(m, fq29_sub(s, r.x)), fq29_mul(w, p.y));
+  r.y = fq29_mul2(m, fq29_sub(s, r.x), fq29_neg(w), p.y);
   r.zz = fq29_mul(v, p.zz);
   r.zzz = fq29_mul(w, p.zzz);
   return r;

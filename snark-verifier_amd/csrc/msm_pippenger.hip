@@ -43,6 +43,7 @@
 // MFMA is deliberately unused: there is no dense contraction, the work is
 // 254-bit modular multiplication on the integer VALU (v_mad_i64_i32).
 #include <stdlib.h>
+#include <string.h>
 #include <mutex>
 #include "ctx.hpp"
 #include "g1_29.cuh"
@@ -83,6 +84,7 @@ struct PipParams {
   uint32_t nblk;   // tiles
   uint32_t tile;   // scalars per tile workgroup
   uint32_t mstride;  // row stride of the key x tile matrix (odd: no power-of-two channel aliasing)
+  uint32_t w0;       // index of the first window held (bucket-sharded reduce of a window range; 0 otherwise)
 };
 
 // c bits at offset lo of a 128-bit magnitude held in 4 registers
@@ -597,7 +599,7 @@ __global__ void __launch_bounds__(64)
   for (int i = 0; i < 9; ++i) {  // pin the chain state to VGPRs (opaque to the uniformity analysis)
     asm volatile("" : "+v"(r.x.v[i]), "+v"(r.y.v[i]), "+v"(r.zz.v[i]), "+v"(r.zzz.v[i]));
   }
-  if (!xyzz29_is_identity(r)) r = xyzz29_double_n(r, p.c * (int)w);
+  if (!xyzz29_is_identity(r)) r = xyzz29_double_n(r, p.c * (int)(w + p.w0));
   if (lane == 0) shifted[w] = r;
 }
 
@@ -657,8 +659,9 @@ static int balance_window_bits(int c) {
 }
 
 int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
-                         void* d_out, bool partial_out) {
+                         void* d_out, bool partial_out, void* d_buckets_out) {
   PipParams p;
+  p.w0 = 0;
   p.n = (uint32_t)n;
   p.c = window_bits > 0 ? window_bits : balance_window_bits(default_window_bits(n));
   if (p.c < 2) p.c = 2;
@@ -762,6 +765,11 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
                      (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets,
                      (const uint32_t*)d_big_count, (const uint32_t*)d_big);
   STAGE_MARK();  // 5: bucket combine
+  if (d_buckets_out) {  // bucket-sharded variant: hand the (sanitised) bucket sums out and stop here
+    SNARKV_HIP(hipMemcpyAsync(d_buckets_out, d_buckets, (size_t)p.nb * sizeof(G1Xyzz29), hipMemcpyDeviceToDevice, st));
+    SNARKV_HIP(hipGetLastError());
+    return SNARKV_OK;
+  }
   hipLaunchKernelGGL(k_bucket_reduce, dim3(blocks_per_window * p.W), dim3(64), 0, st, (const G1Xyzz29*)d_buckets,
                      (G1Xyzz29*)d_wave, p, chunks_per_window, blocks_per_window);
   STAGE_MARK();  // 6: bucket reduce
@@ -772,6 +780,59 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
                      partial_out ? 1 : 0);
   STAGE_MARK();  // 8: final sum + to_affine
 #undef STAGE_MARK
+  SNARKV_HIP(hipGetLastError());
+  return SNARKV_OK;
+}
+
+// ---- bucket-sharded variant ("bucket-sum allreduce") ---------------------------
+// Every GPU fills the GLOBAL bucket grid (same c for all) from its point shard; the
+// grids are exchanged by window range and summed; each GPU reduces the windows it owns.
+int pip_geometry(size_t n_total, int window_bits, uint32_t* c, uint32_t* windows, uint32_t* buckets_per_window) {
+  int cc = window_bits > 0 ? window_bits : balance_window_bits(default_window_bits(n_total));
+  if (cc < 2) cc = 2;
+  if (cc > 22) cc = 22;
+  *c = (uint32_t)cc;
+  *windows = (uint32_t)((128 + cc - 1) / cc);
+  *buckets_per_window = 1u << (cc - 1);
+  return SNARKV_OK;
+}
+
+__global__ void __launch_bounds__(256) k_buckets_add(G1Xyzz29* __restrict__ dst, const G1Xyzz29* __restrict__ src, uint32_t count) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  G1Xyzz29 a = dst[i];
+  xyzz29_add_careful(a, src[i]);  // the same point may sit in both shards' buckets: doubling / cancellation handled
+  dst[i] = xyzz29_sanitize(a);
+}
+
+int launch_buckets_add(snarkv_ctx* ctx, void* d_dst, const void* d_src, size_t count) {
+  hipLaunchKernelGGL(k_buckets_add, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, (G1Xyzz29*)d_dst,
+                     (const G1Xyzz29*)d_src, (uint32_t)count);
+  SNARKV_HIP(hipGetLastError());
+  return SNARKV_OK;
+}
+
+// sum_{w in [w0, w0 + wcount)} 2^(c w) * sum_b b * buckets[w - w0][b]  ->  one projective partial
+int launch_buckets_reduce(snarkv_ctx* ctx, const void* d_buckets, uint32_t c, uint32_t w0, uint32_t wcount,
+                          void* d_partial) {
+  PipParams p;
+  memset(&p, 0, sizeof p);
+  p.c = (int)c;
+  p.W = (int)wcount;
+  p.B = 1u << (c - 1);
+  p.nb = wcount * p.B;
+  p.w0 = w0;
+  uint32_t chunks_per_window = (p.B + kChunk - 1) / kChunk;
+  uint32_t blocks_per_window = (chunks_per_window + 63) / 64;
+  void *d_wave, *d_shift;
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_CHUNK_PARTIALS, (size_t)blocks_per_window * wcount * sizeof(G1Xyzz29), &d_wave));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_SHIFTED, (size_t)wcount * sizeof(G1Xyzz29), &d_shift));
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(k_bucket_reduce, dim3(blocks_per_window * wcount), dim3(64), 0, st, (const G1Xyzz29*)d_buckets,
+                     (G1Xyzz29*)d_wave, p, chunks_per_window, blocks_per_window);
+  hipLaunchKernelGGL(k_shift_windows, dim3(wcount), dim3(64), 0, st, (const G1Xyzz29*)d_wave, (G1Xyzz29*)d_shift, p,
+                     blocks_per_window);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, st, (const G1Xyzz29*)d_shift, wcount, (uint32_t*)d_partial, 1);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }

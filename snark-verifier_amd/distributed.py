@@ -81,6 +81,112 @@ def gpu_sharded_msm(ctx, d_scalars, d_points, n_total, window_bits=0):
 
 
 @dataclass
+class BucketShardedMsm:
+    """The "bucket-sum allreduce" alternative of SURVEY.md 8(e): ranks still hold disjoint
+    POINT shards, but instead of finishing their own Pippenger they all fill the same
+    global bucket grid (`windows x buckets_per_window`, the `buckets[d-1].add_assign`
+    half of msm.rs:291-296), exchange it by WINDOW range (an all-to-all: rank g receives
+    every rank's copy of the windows g owns -- a reduce-scatter whose reduction is EC
+    addition, which RCCL cannot do in-flight), add the copies, and run the running-sum +
+    `double()` half (msm.rs:285-302) on their windows only.  The per-rank projective
+    partials are then all-gathered and folded as in `ShardedMsm`.
+
+    Against point-sharding it saves (1 - 1/world) of the bucket-reduce work per rank and
+    costs an exchange of the whole grid (windows * buckets * 144 B, tens of MB, against
+    144 B per rank): see DESIGN.md section 6 for the measured trade.
+
+    `fill_fn(lo, hi) -> uint8[windows * B * bucket_bytes]` (window-major),
+    `add_fn(dst, src)` in place, `reduce_fn(buckets, w0, wcount) -> uint8[partial_bytes]`,
+    `fold_fn(gathered, world) -> uint8[64]`."""
+
+    windows: int
+    buckets_per_window: int
+    fill_fn: Callable
+    add_fn: Callable
+    reduce_fn: Callable
+    fold_fn: Callable
+    bucket_bytes: int = 144
+    partial_bytes: int = 144
+
+    def run(self, n_total: int):
+        import torch
+        import torch.distributed as dist
+
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        lo, hi = shard_range(n_total, rank, world)
+        wbytes = self.buckets_per_window * self.bucket_bytes
+        grid = self.fill_fn(lo, hi)
+        assert grid.numel() == self.windows * wbytes and grid.dtype == torch.uint8
+        w0, w1 = shard_range(self.windows, rank, world)
+        if world == 1:
+            mine = grid
+        else:
+            counts = [shard_range(self.windows, r, world) for r in range(world)]
+            own = (w1 - w0) * wbytes
+            recv = torch.empty(world * own, dtype=torch.uint8, device=grid.device)
+            dist.all_to_all_single(recv, grid, output_split_sizes=[own] * world,
+                                   input_split_sizes=[(b - a) * wbytes for a, b in counts])
+            mine = recv[:own]
+            for r in range(1, world):
+                if own:
+                    self.add_fn(mine, recv[r * own:(r + 1) * own])
+        if w1 > w0:
+            part = self.reduce_fn(mine, w0, w1 - w0)
+        else:  # more ranks than windows: this rank contributes the identity
+            part = torch.zeros(self.partial_bytes, dtype=torch.uint8, device=grid.device)
+        assert part.numel() == self.partial_bytes
+        if world == 1:
+            gathered = part
+        else:
+            gathered = torch.empty(world * self.partial_bytes, dtype=torch.uint8, device=part.device)
+            dist.all_gather_into_tensor(gathered, part)
+        return self.fold_fn(gathered, world)
+
+
+def gpu_bucket_sharded_msm(ctx, d_scalars, d_points, n_total, window_bits=0):
+    """Product wiring of `BucketShardedMsm` over the HIP entry points.  `d_scalars` /
+    `d_points` hold THIS rank's shard only; the window size is the one of the TOTAL n so
+    that all ranks fill the same grid."""
+    import torch
+
+    from . import G1_PARTIAL_BYTES, Context
+
+    c, windows, bpw = Context.bucket_geometry(n_total, window_bits)
+    dev = d_scalars.device
+    grid = torch.empty(windows * bpw * G1_PARTIAL_BYTES, dtype=torch.uint8, device=dev)
+    part = torch.zeros(G1_PARTIAL_BYTES, dtype=torch.uint8, device=dev)
+    out = torch.zeros(64, dtype=torch.uint8, device=dev)
+
+    def fill_fn(lo, hi):
+        if hi > lo:
+            ctx.fill_buckets_dev(d_scalars.data_ptr(), d_points.data_ptr(), hi - lo, c, grid.data_ptr())
+            ctx.sync()  # the grid is in memory before the all-to-all reads it
+        else:
+            grid.zero_()
+            torch.cuda.current_stream().synchronize()
+        return grid
+
+    def add_fn(dst, src):
+        torch.cuda.current_stream().synchronize()  # the exchange has landed
+        ctx.buckets_add_dev(dst.data_ptr(), src.data_ptr(), dst.numel() // G1_PARTIAL_BYTES)
+
+    def reduce_fn(buckets, w0, wcount):
+        torch.cuda.current_stream().synchronize()
+        ctx.buckets_reduce_dev(buckets.data_ptr(), c, w0, wcount, part.data_ptr())
+        ctx.sync()
+        return part
+
+    def fold_fn(gathered, world):
+        torch.cuda.current_stream().synchronize()
+        ctx.fold_partials_dev(gathered.data_ptr(), world, out.data_ptr())
+        return out
+
+    return BucketShardedMsm(windows, bpw, fill_fn, add_fn, reduce_fn, fold_fn, G1_PARTIAL_BYTES,
+                            G1_PARTIAL_BYTES).run(n_total)
+
+
+@dataclass
 class ShardedAggregation:
     """Proof-sharded aggregation: proofs are independent,
     so rank g succinct-verifies ITS contiguous shard of the proofs

@@ -161,3 +161,84 @@ def test_sharded_aggregation_two_ranks_agree(n_proofs):
         t.common_ec_point(r)
     lhs, rhs = K.kzg_as_verify(accs, t.squeeze_challenge())
     assert res[0][1] == O.g1_to_bytes(lhs) + O.g1_to_bytes(rhs)
+
+
+# ---- bucket-sharded variant ("bucket-sum allreduce") ----------------------------
+_BC, _BW = 8, 32  # doubles: unsigned 8-bit windows over the 256-bit scalar, 255 buckets each
+
+
+def _bucket_worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+
+    import coracle as C
+    from snark_verifier_amd.distributed import BucketShardedMsm
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s, p = C.sample_scalars(7, n), C.sample_points(8, n)
+    B = (1 << _BC) - 1
+    Z = b"\x00" * 64
+
+    def fill_fn(lo, hi):  # oracle double of the bucket fill: affine 64-byte buckets, zero = identity
+        grid = [Z] * (_BW * B)
+        for i in range(lo, hi):
+            k = int.from_bytes(s[32 * i:32 * i + 32], "little")
+            for w in range(_BW):
+                d = (k >> (_BC * w)) & B
+                if d:
+                    grid[w * B + d - 1] = C.g1_add(grid[w * B + d - 1], p[64 * i:64 * i + 64])
+        return torch.frombuffer(bytearray(b"".join(grid)), dtype=torch.uint8)
+
+    def add_fn(dst, src):
+        a, b = bytes(dst.numpy()), bytes(src.numpy())
+        r = b"".join(C.g1_add(a[o:o + 64], b[o:o + 64]) for o in range(0, len(a), 64))
+        dst.copy_(torch.frombuffer(bytearray(r), dtype=torch.uint8))
+
+    def reduce_fn(buckets, w0, wcount):
+        raw = bytes(buckets.numpy())
+        acc = Z
+        for w in range(wcount):
+            run, tot = Z, Z
+            for b in range(B - 1, -1, -1):  # running-sum trick, msm.rs:298-302
+                run = C.g1_add(run, raw[(w * B + b) * 64:(w * B + b) * 64 + 64])
+                tot = C.g1_add(tot, run)
+            acc = C.g1_add(acc, C.g1_mul(tot, (1 << (_BC * (w0 + w))).to_bytes(32, "little")))
+        return torch.frombuffer(bytearray(acc + b"\x00" * 80), dtype=torch.uint8)
+
+    def fold_fn(gathered, w):
+        acc = Z
+        raw = bytes(gathered.numpy())
+        for k in range(w):
+            acc = C.g1_add(acc, raw[144 * k:144 * k + 64])
+        return torch.frombuffer(bytearray(acc), dtype=torch.uint8)
+
+    out = BucketShardedMsm(_BW, B, fill_fn, add_fn, reduce_fn, fold_fn, bucket_bytes=64).run(n)
+    q.put((rank, bytes(out.numpy())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world", [(1, 2), (37, 2), (37, 3)])
+def test_bucket_sharded_msm_ranks_agree_with_single_process(n, world):
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import coracle as C
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + 7 * n + world) % 2000
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    expected = C.msm_pippenger(C.sample_scalars(7, n), C.sample_points(8, n), 1)
+    for _, out in res:
+        assert out == expected

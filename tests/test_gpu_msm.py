@@ -277,3 +277,60 @@ def test_largest_config_2p24_split_linearity(gpu_ctx):
     assert a == bytes(out2.cpu().numpy()) and a != bytes(64)
     del ds, dp
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n,world", [(1, 2), (777, 2), (5000, 3), (1 << 16, 4), (4097, 11)])
+def test_bucket_sharded_building_blocks_emulated_ranks(gpu_ctx, n, world):
+    """The "bucket-sum allreduce" variant emulated on one device: `world` point
+    shards fill the GLOBAL bucket grid, the grids are added, each emulated rank reduces the
+    windows it owns, the partials are folded -- equal to the C oracle's Pippenger.  Identical
+    points appear in several shards (cut into a repeated pattern) so the careful bucket add
+    meets doublings; world=11 > windows/2 exercises uneven and empty window ranges."""
+    import torch
+
+    import snark_verifier_amd as sv
+    from snark_verifier_amd.distributed import shard_range
+
+    s = C.sample_scalars(0x51, n)
+    base = C.sample_points(0x52, max(1, n // 3))
+    p = (base * 4)[: 64 * n]  # every point repeated across the shards
+    c, W, B = sv.Context.bucket_geometry(n)
+    assert W == -(-128 // c) and B == 1 << (c - 1)
+    ds = torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda()
+    dp = torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda()
+    PB = sv.G1_PARTIAL_BYTES
+    grids = torch.zeros(world, W * B * PB, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for r in range(world):
+        lo, hi = shard_range(n, r, world)
+        if hi > lo:
+            gpu_ctx.fill_buckets_dev(ds.data_ptr() + 32 * lo, dp.data_ptr() + 64 * lo, hi - lo, c, grids[r].data_ptr())
+    for r in range(1, world):
+        gpu_ctx.buckets_add_dev(grids[0].data_ptr(), grids[r].data_ptr(), W * B)
+    parts = torch.zeros(world, PB, dtype=torch.uint8, device="cuda")
+    gpu_ctx.sync()
+    torch.cuda.synchronize()
+    for r in range(world):
+        w0, w1 = shard_range(W, r, world)
+        if w1 > w0:
+            gpu_ctx.buckets_reduce_dev(grids[0].data_ptr() + w0 * B * PB, c, w0, w1 - w0, parts[r].data_ptr())
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    gpu_ctx.fold_partials_dev(parts.data_ptr(), world, out.data_ptr())
+    gpu_ctx.sync()
+    assert bytes(out.cpu().numpy()) == C.msm_pippenger(s, p, 4)
+
+
+def test_bucket_sharded_error_paths(gpu_ctx):
+    import torch
+
+    import snark_verifier_amd as sv
+
+    d = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    with pytest.raises(sv.SnarkvError):
+        gpu_ctx.fill_buckets_dev(d.data_ptr(), d.data_ptr(), 0, 8, d.data_ptr())  # empty
+    with pytest.raises(sv.SnarkvError):
+        gpu_ctx.fill_buckets_dev(d.data_ptr(), d.data_ptr(), 4, 0, d.data_ptr())  # c must be explicit
+    with pytest.raises(sv.SnarkvError):
+        gpu_ctx.buckets_reduce_dev(d.data_ptr(), 8, 15, 2, d.data_ptr())  # window range past the top window
+    with pytest.raises(sv.SnarkvError):
+        gpu_ctx.buckets_add_dev(d.data_ptr(), d.data_ptr(), 0)

@@ -1,5 +1,6 @@
 """GPU: robustness of the C-ABI entry points -- random segmentations, validation
 flags, concurrent contexts, determinism, adversarial duplicates at scale."""
+import os
 import random
 import threading
 
@@ -200,3 +201,38 @@ def test_context_free_entry_points_from_many_threads(golden_msm):
     for t in ts:
         t.join()
     assert not errs
+
+
+def test_bucket_sharded_msm_world1_rccl_wiring():
+    """`gpu_bucket_sharded_msm` end to end over a 1-rank RCCL group (the 8-GPU run is the
+    driver's): fill -> (no exchange at world 1) -> reduce -> fold equals the plain MSM."""
+    import torch
+    import torch.distributed as dist
+
+    import snark_verifier_amd as sv
+    from snark_verifier_amd.distributed import gpu_bucket_sharded_msm
+
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        n = 30000
+        st = torch.cuda.Stream()
+        ctx = sv.Context(0, st.cuda_stream)
+        ds = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+        dp = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.sample_scalars_dev(3, n, ds.data_ptr())
+        ctx.sample_points_dev(4, n, dp.data_ptr())
+        ref = torch.zeros(64, dtype=torch.uint8, device="cuda")
+        ctx.msm_pippenger_dev(ds.data_ptr(), dp.data_ptr(), n, ref.data_ptr())
+        ctx.sync()
+        out = gpu_bucket_sharded_msm(ctx, ds, dp, n)
+        ctx.sync()
+        assert bytes(out.cpu().numpy()) == bytes(ref.cpu().numpy()) != bytes(64)
+    finally:
+        if created:
+            dist.destroy_process_group()
