@@ -27,12 +27,15 @@
 //                        (the `buckets[d-1].add_assign(base)` of msm.rs:291-296)
 //   P5 k_combine         per bucket: stitch the partials of the runs it spans
 //   P6 k_bucket_reduce   running-sum trick of msm.rs:298-302, chunked so that
-//                        >= 32 K lanes work; each chunk's sum is weighted by
-//                        its base index with a short double-and-add, then a
-//                        wave-level LDS tree leaves one partial per wavefront
-//   P8 k_shift_windows   one wavefront per window: tree-sum of the partials,
-//                        then T_w = 2^(c w) S_w (the `result.double()` x c of
-//                        msm.rs:285-287) -- the dependency chain GLV halves
+//                        >= 64 K lanes work; the chunk weights (chunk index x
+//                        chunk sum) come from one suffix scan over the 64 lanes
+//                        of a block instead of a per-lane double-and-add; a
+//                        block leaves (weighted sum T, plain sum S)
+//   P8 k_shift_windows   one wavefront per window: the same suffix-scan fold
+//                        one level up (block index x S), then T_w = 2^(c w) S_w
+//                        (the `result.double()` x c of msm.rs:285-287) -- the
+//                        dependency chain GLV halves -- with the 7 products of
+//                        a Jacobian doubling spread over 3 lanes (depth 3)
 //   P9 k_final           sum of the shifted window sums + `to_affine`, or the
 //                        projective partial for the multi-GPU fold.
 //
@@ -502,104 +505,198 @@ __global__ void __launch_bounds__(256)
 }
 
 // --------------------------------------------------------------- P6
-// Lane (w, j) folds buckets [j*kChunk, (j+1)*kChunk) of window w:
-//   run = sum B_i ;  acc = sum (i - base + 1) B_i   (running-sum trick)
-//   partial = acc + base * run,   base = j*kChunk   (bucket i has weight i+1)
+// Lane (w, j) folds buckets [j*kChunk, (j+1)*kChunk) of window w with the
+// running-sum trick of msm.rs:298-302:
+//   run = sum B_i ;  acc = sum (i - base + 1) B_i ,  base = j*kChunk
+// (bucket i has weight i+1).  The lane's missing term base*run is NOT computed
+// by a per-lane double-and-add (15 doublings + divergent adds, 60 % of the old
+// kernel): lanes of a 64-lane block hold consecutive chunks, so
+//   sum_l (L l) run_l = L * sum_{l>=1} Sfx_l ,  Sfx_l = sum_{k>=l} run_k
+// -- one suffix scan (6 steps) instead; the block emits T = sum of weights
+// relative to ITS first bucket and S = its plain sum, and P8 applies the same
+// identity one level up (block index weights).
+// Code size matters here: these kernels run one wavefront per SIMD through long
+// straight-line adders (an inlined XYZZ add is ~3.5 k instructions), so every
+// extra inline site is instruction-cache misses on the critical path.  Each loop
+// below therefore has ONE adder site, operands picked by (uniform) selects.
+__device__ __forceinline__ G1Xyzz29 xyzz29_sel(bool c, const G1Xyzz29& a, const G1Xyzz29& b) {
+  G1Xyzz29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    r.x.v[i] = c ? a.x.v[i] : b.x.v[i];
+    r.y.v[i] = c ? a.y.v[i] : b.y.v[i];
+    r.zz.v[i] = c ? a.zz.v[i] : b.zz.v[i];
+    r.zzz.v[i] = c ? a.zzz.v[i] : b.zzz.v[i];
+  }
+  return r;
+}
+
 template <bool CAREFUL>
-__device__ __forceinline__ bool reduce_chunk(const G1Xyzz29* __restrict__ bw, uint32_t base, uint32_t top,
-                                             G1Xyzz29& out) {
-  G1Xyzz29 run = xyzz29_identity(), acc = xyzz29_identity();
+__device__ __forceinline__ bool chunk_sums(const G1Xyzz29* __restrict__ bw, uint32_t base, uint32_t top,
+                                           G1Xyzz29& run, G1Xyzz29& acc) {
+  run = xyzz29_identity();
+  acc = xyzz29_identity();
   bool bad = false;
-  for (uint32_t i = top; i-- > base;) {
-    if (CAREFUL) {
-      xyzz29_add_careful(run, bw[i]);
-      xyzz29_add_careful(acc, run);
-    } else {
-      xyzz29_add_skipid_fast(run, bw[i], bad);
-      xyzz29_add_skipid_fast(acc, run, bad);
-    }
+#pragma unroll 1
+  for (uint32_t op = 0; op < 2 * (top - base); ++op) {  // run += B_i ; acc += run   (i descending)
+    bool second = op & 1u;
+    G1Xyzz29 x = second ? acc : run;
+    G1Xyzz29 y = second ? run : bw[top - 1 - (op >> 1)];
+    if (CAREFUL) xyzz29_add_careful(x, y);
+    else xyzz29_add_skipid_fast(x, y, bad);
+    if (second) acc = x;
+    else run = x;
   }
-  // base * run by double-and-add over the bits of base
-  G1Xyzz29 m = xyzz29_identity();
-  if (!xyzz29_is_identity(run)) {
-    for (int bit = 31 - __clz((int)(base | 1u)); bit >= 0; --bit) {
-      if (!xyzz29_is_identity(m)) m = xyzz29_double(m);
-      if ((base >> bit) & 1u) {
-        if (CAREFUL) xyzz29_add_careful(m, run);
-        else xyzz29_add_skipid_fast(m, run, bad);
-      }
-    }
-  }
-  if (CAREFUL) xyzz29_add_careful(acc, m);
-  else xyzz29_add_skipid_fast(acc, m, bad);
-  out = acc;
   if (CAREFUL) return false;
   // any degenerate intermediate poisons everything downstream of it
   return bad || (!xyzz29_is_identity(run) && xyzz29_is_degenerate(run)) ||
-         (!xyzz29_is_identity(m) && xyzz29_is_degenerate(m)) ||
          (!xyzz29_is_identity(acc) && xyzz29_is_degenerate(acc));
 }
 
-// One 64-lane block = 64 consecutive chunks of one window; the block's 64
-// partials are folded by an LDS tree (careful adders: tiny, and a cooperative
-// redo would cost more) -> wave_parts[w][blockInWindow].
+// 64-lane workgroup fold.  Lane l brings (run_l, acc_l, extra_l); returns (to every lane)
+//   out   = sum_l [ extra_l + 2^log2_scale * ( acc_l + 2^log2_l * l * run_l ) ]
+//   total = sum_l run_l
+// as 14 steps of  x = 2^k x + y :  6 suffix-scan steps (y = the value d lanes up),
+// the two weighting steps, 6 more scan steps whose lane 0 ends with the sum.
+// Careful adders throughout: partial sums of neighbouring lanes can coincide or
+// cancel (duplicated points), and 14 adds per wave are not worth a redo path.
+__device__ __forceinline__ void wave_weighted_fold(G1Xyzz29* sh, const G1Xyzz29& run, const G1Xyzz29& acc,
+                                                   const G1Xyzz29& extra, int log2_l, int log2_scale,
+                                                   G1Xyzz29& out, G1Xyzz29& total) {
+  const uint32_t lane = threadIdx.x;
+  G1Xyzz29 x = run;
+#pragma unroll 1
+  for (int step = 0; step < 14; ++step) {
+    sh[lane] = x;
+    __syncthreads();
+    G1Xyzz29 y;
+    int ndbl = 0;
+    if (step == 6) {
+      total = sh[0];
+      x = xyzz29_sel(lane >= 1, x, xyzz29_identity());
+      y = acc;
+      ndbl = log2_l;
+    } else if (step == 7) {
+      y = extra;
+      ndbl = log2_scale;
+    } else {
+      uint32_t d = 1u << (step < 6 ? step : step - 8);
+      y = xyzz29_identity();
+      if (lane + d < 64) y = sh[lane + d];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < ndbl; ++k)
+      if (!xyzz29_is_identity(x)) x = xyzz29_double(x);
+    xyzz29_add_careful(x, y);
+  }
+  sh[lane] = x;
+  __syncthreads();
+  out = sh[0];
+}
+
+constexpr int ilog2_const(uint32_t v) { return v <= 1 ? 0 : 1 + ilog2_const(v >> 1); }
+static_assert((kChunk & (kChunk - 1)) == 0, "kChunk must be a power of two (chunk weights are applied by doublings)");
+constexpr int kLog2Chunk = ilog2_const(kChunk);
+constexpr int kLog2BlockBuckets = 6 + kLog2Chunk;  // a P6 block covers 64 * kChunk buckets
+
+// One 64-lane block = 64 consecutive chunks of one window ->
+//   block_parts[2 * blk]     = T = sum (i - first + 1) B_i over the block's buckets (first = its first bucket)
+//   block_parts[2 * blk + 1] = S = sum B_i
 __global__ void __launch_bounds__(64)
-    k_bucket_reduce(const G1Xyzz29* __restrict__ buckets, G1Xyzz29* __restrict__ wave_parts, PipParams p,
+    k_bucket_reduce(const G1Xyzz29* __restrict__ buckets, G1Xyzz29* __restrict__ block_parts, PipParams p,
                     uint32_t chunks_per_window, uint32_t blocks_per_window) {
   __shared__ G1Xyzz29 sh[64];
   uint32_t w = blockIdx.x / blocks_per_window, bj = blockIdx.x % blocks_per_window;
   uint32_t j = bj * 64 + threadIdx.x;
-  G1Xyzz29 out = xyzz29_identity();
+  G1Xyzz29 run = xyzz29_identity(), acc = xyzz29_identity();
   if (j < chunks_per_window) {
     uint32_t base = j * kChunk;
     uint32_t top = base + kChunk < p.B ? base + kChunk : p.B;
     const G1Xyzz29* bw = buckets + (size_t)w * p.B;
-    if (reduce_chunk<false>(bw, base, top, out)) reduce_chunk<true>(bw, base, top, out);
+    if (chunk_sums<false>(bw, base, top, run, acc)) chunk_sums<true>(bw, base, top, run, acc);
   }
-  sh[threadIdx.x] = out;
-  __syncthreads();
-  for (uint32_t s = 32; s >= 1; s >>= 1) {
-    if (threadIdx.x < s) {
-      G1Xyzz29 a = sh[threadIdx.x];
-      xyzz29_add_careful(a, sh[threadIdx.x + s]);
-      sh[threadIdx.x] = a;
-    }
-    __syncthreads();
+  G1Xyzz29 t, s;
+  wave_weighted_fold(sh, run, acc, xyzz29_identity(), kLog2Chunk, 0, t, s);
+  if (threadIdx.x == 0) {
+    block_parts[2 * (size_t)blockIdx.x] = t;
+    block_parts[2 * (size_t)blockIdx.x + 1] = s;
   }
-  if (threadIdx.x == 0) wave_parts[blockIdx.x] = sh[0];
 }
 
 // --------------------------------------------------------------- P8
-// One wavefront per window: S_w = sum of the window's wave partials (lane
-// stride + LDS tree), then shifted[w] = 2^(c w) S_w on lane 0.  The loop trip
-// count differs per block, never per lane, but the data is lane-private so the
-// arithmetic stays on the VALU (a uniform single-lane kernel gets scalarised
-// into SALU multiply emulation, 3x slower).
+// 2^n * P, P uniform over each aligned 4-lane group, with the 7 products of a
+// Jacobian doubling (dbl-2009-l, a = 0) spread over 3 lanes in 3 dependent
+// levels  { X^2, Y^2, Y Z } -> { B^2, (X+B)^2, (3A)^2 } -> { E (D - X3) }  and
+// exchanged by quad-broadcast DPP: the chain is one wavefront's critical path
+// (a lone wavefront issues one VALU instruction per ~4.6 cycles whatever its
+// ILP), so depth 3 instead of 7 products per doubling is what counts.  Same
+// dataflow and carry bounds as jac29_double (g1_29.cuh).
+template <int CTRL>
+__device__ __forceinline__ Fq29 fq29_dpp(const Fq29& a) {
+  Fq29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.v[i] = __builtin_amdgcn_update_dpp(0, a.v[i], CTRL, 0xF, 0xF, true);
+  return r;
+}
+__device__ __forceinline__ Fq29 fq29_sel(bool c, const Fq29& a, const Fq29& b) {
+  Fq29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+__device__ __forceinline__ G1Xyzz29 xyzz29_double_n_quad(const G1Xyzz29& p, int n) {
+  if (n <= 0) return p;
+  const uint32_t q = threadIdx.x & 3u;
+  Fq29 x = fq29_mul(p.x, p.zz);
+  Fq29 y = fq29_mul(fq29_norm(p.y), p.zzz);
+  Fq29 z = p.zz;
+  for (int k = 0; k < n; ++k) {
+    Fq29 p1 = fq29_mul(fq29_sel(q == 0, x, y), fq29_sel(q == 0, x, fq29_sel(q == 1, y, z)));
+    Fq29 a = fq29_dpp<0x00>(p1), b = fq29_dpp<0x55>(p1), yz = fq29_dpp<0xAA>(p1);  // quad_perm broadcasts of lane 0 / 1 / 2
+    Fq29 xb = fq29_norm(fq29_add(x, b));
+    Fq29 e = fq29_norm(fq29_add(fq29_dbl(a), a));  // E = 3A
+    Fq29 p2 = fq29_sqr(fq29_sel(q == 0, b, fq29_sel(q == 1, xb, e)));
+    Fq29 c = fq29_dpp<0x00>(p2), xb2 = fq29_dpp<0x55>(p2), f = fq29_dpp<0xAA>(p2);
+    Fq29 d = fq29_norm(fq29_dbl(fq29_sub(fq29_sub(xb2, a), c)));  // D = 2((X+B)^2 - A - C)
+    Fq29 x3 = fq29_norm(fq29_sub(f, fq29_dbl(d)));                // F - 2D
+    Fq29 c8 = fq29_dbl(fq29_norm(fq29_dbl(fq29_dbl(c))));         // 8C
+    y = fq29_norm(fq29_sub(fq29_mul(e, fq29_sub(d, x3)), c8));    // E(D - X3) - 8C
+    z = fq29_norm(fq29_dbl(yz));                                  // 2YZ
+    x = x3;
+  }
+  return jac29_to_xyzz(x, y, z);
+}
+
+// One wavefront per window.  Lane l owns `per` consecutive P6 blocks:
+//   window sum = sum_blk T_blk + 2^kLog2BlockBuckets * sum_blk blk * S_blk
+// with the block-index weights applied by the same suffix-scan fold as in P6,
+// then shifted[w] = 2^(c (w + w0)) * (window sum)  (the `result.double()` x c
+// of msm.rs:285-287) by the quad-cooperative doubling chain.
 __global__ void __launch_bounds__(64)
-    k_shift_windows(const G1Xyzz29* __restrict__ wave_parts, G1Xyzz29* __restrict__ shifted, PipParams p,
+    k_shift_windows(const G1Xyzz29* __restrict__ block_parts, G1Xyzz29* __restrict__ shifted, PipParams p,
                     uint32_t blocks_per_window) {
   __shared__ G1Xyzz29 sh[64];
   uint32_t w = blockIdx.x, lane = threadIdx.x;
-  const G1Xyzz29* src = wave_parts + (size_t)w * blocks_per_window;
-  G1Xyzz29 acc = xyzz29_identity();
-  for (uint32_t i = lane; i < blocks_per_window; i += 64) xyzz29_add_careful(acc, src[i]);
-  sh[lane] = acc;
-  __syncthreads();
-  for (uint32_t s = 32; s >= 1; s >>= 1) {
-    if (lane < s) {
-      G1Xyzz29 a = sh[lane];
-      xyzz29_add_careful(a, sh[lane + s]);
-      sh[lane] = a;
-    }
-    __syncthreads();
+  const G1Xyzz29* src = block_parts + 2 * (size_t)w * blocks_per_window;
+  uint32_t per = (blocks_per_window + 63) / 64;  // a power of two (B is), or 1
+  uint32_t lo = lane * per, hi = lo + per < blocks_per_window ? lo + per : blocks_per_window;
+  G1Xyzz29 run = xyzz29_identity(), acc_s = xyzz29_identity(), acc_t = xyzz29_identity();
+  uint32_t cnt = hi > lo ? hi - lo : 0;
+#pragma unroll 1
+  for (uint32_t op = 0; op < 3 * cnt; ++op) {  // per block i (descending): acc_s += run; run += S_i; acc_t += T_i
+    uint32_t i = hi - 1 - op / 3, k = op % 3;  // => acc_s = sum (i - lo) S_i
+    G1Xyzz29 x = xyzz29_sel(k == 0, acc_s, xyzz29_sel(k == 1, run, acc_t));
+    G1Xyzz29 y = run;
+    if (k != 0) y = src[2 * (size_t)i + (k == 1 ? 1 : 0)];
+    xyzz29_add_careful(x, y);
+    if (k == 0) acc_s = x;
+    else if (k == 1) run = x;
+    else acc_t = x;
   }
-  // every lane runs the chain on its own copy (lane-private registers)
-  G1Xyzz29 r = sh[0];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {  // pin the chain state to VGPRs (opaque to the uniformity analysis)
-    asm volatile("" : "+v"(r.x.v[i]), "+v"(r.y.v[i]), "+v"(r.zz.v[i]), "+v"(r.zzz.v[i]));
-  }
-  if (!xyzz29_is_identity(r)) r = xyzz29_double_n(r, p.c * (int)(w + p.w0));
+  G1Xyzz29 r, total;
+  wave_weighted_fold(sh, run, acc_s, acc_t, 31 - __clz((int)per), kLog2BlockBuckets, r, total);
+  if (!xyzz29_is_identity(r)) r = xyzz29_double_n_quad(r, p.c * (int)(w + p.w0));
   if (lane == 0) shifted[w] = r;
 }
 
@@ -705,7 +802,7 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SEG_IDS, (size_t)max_runs * 8, &d_seg_ids));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SEG_PARTIALS, (size_t)max_runs * 2 * sizeof(G1Xyzz29), &d_seg_parts));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_BUCKETS, (size_t)p.nb * sizeof(G1Xyzz29), &d_buckets));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_CHUNK_PARTIALS, (size_t)blocks_per_window * p.W * sizeof(G1Xyzz29), &d_wave));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_CHUNK_PARTIALS, 2 * (size_t)blocks_per_window * p.W * sizeof(G1Xyzz29), &d_wave));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SHIFTED, (size_t)p.W * sizeof(G1Xyzz29), &d_shift));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_MISC, 64, &d_misc));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_BIG_LIST, (size_t)kMaxBig * 4, &d_big));
@@ -825,7 +922,7 @@ int launch_buckets_reduce(snarkv_ctx* ctx, const void* d_buckets, uint32_t c, ui
   uint32_t chunks_per_window = (p.B + kChunk - 1) / kChunk;
   uint32_t blocks_per_window = (chunks_per_window + 63) / 64;
   void *d_wave, *d_shift;
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_CHUNK_PARTIALS, (size_t)blocks_per_window * wcount * sizeof(G1Xyzz29), &d_wave));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_CHUNK_PARTIALS, 2 * (size_t)blocks_per_window * wcount * sizeof(G1Xyzz29), &d_wave));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SHIFTED, (size_t)wcount * sizeof(G1Xyzz29), &d_shift));
   hipStream_t st = ctx->stream;
   hipLaunchKernelGGL(k_bucket_reduce, dim3(blocks_per_window * wcount), dim3(64), 0, st, (const G1Xyzz29*)d_buckets,
