@@ -708,10 +708,14 @@ __global__ void __launch_bounds__(64)
   __shared__ G1Xyzz29 sh[64];
   uint32_t lane = threadIdx.x;
   G1Xyzz29 acc = xyzz29_identity();
+#pragma unroll 1
   for (uint32_t i = lane; i < count; i += 64) xyzz29_add_careful(acc, parts[i]);
   sh[lane] = acc;
   __syncthreads();
-  for (uint32_t s = 32; s >= 1; s >>= 1) {
+  uint32_t s0 = 32;  // lanes >= count hold the identity: start the tree at the live width
+  while (s0 > 1 && s0 >= count) s0 >>= 1;
+#pragma unroll 1
+  for (uint32_t s = s0; s >= 1; s >>= 1) {
     if (lane < s) {
       G1Xyzz29 a = sh[lane];
       xyzz29_add_careful(a, sh[lane + s]);
