@@ -1,0 +1,271 @@
+// Mirror of the reference's inner-product-argument layer on the native loader:
+//   h_eval / h_coeffs                        snark-verifier/src/pcs/ipa.rs:391-421
+//   IpaSuccinctVerifyingKey                  snark-verifier/src/pcs/ipa.rs:251-276
+//   IpaProof::read, xi, xi_inv               snark-verifier/src/pcs/ipa.rs:278-374
+//   Ipa::succinct_verify                     snark-verifier/src/pcs/ipa.rs:139-180
+//   IpaAccumulator                           snark-verifier/src/pcs/ipa/accumulator.rs:3-25
+//   IpaAs::{read_proof, verify}, IpaAsProof  snark-verifier/src/pcs/ipa/accumulation.rs:21-146
+//   IpaDecidingKey, decide / decide_all      snark-verifier/src/pcs/ipa/decider.rs:3-68
+//
+// `IpaAs::decide` is the reference's second consumer of the large-MSM hot path:
+// U == `util::msm::multi_scalar_multiplication(h_coeffs(xi, 1), dk.g)` with 2^k
+// terms (decider.rs:51-52) -- here ONE device Pippenger
+// (`multi_scalar_multiplication` in msm.hpp -> bn254_g1_msm_pippenger); the two
+// `evaluate(None)` of the succinct check (ipa.rs:172,177) go to the device as one
+// segmented launch.  Scalars (h_eval, the 2^k h_coeffs products, one batch
+// inversion) stay on the host, as in the reference.
+//
+// The scheme is generic over `C: CurveAffine`; the reference's tests use pallas,
+// this mirror BN254 G1 -- the curve the device kernels are built for.  The prover
+// halves (`Ipa::create_proof`, `IpaAs::create_proof`) live in oracle/ipa.py only:
+// they make the test proofs and are not part of the verification path.
+#pragma once
+#include <optional>
+#include <vector>
+
+#include "pcs.hpp"
+
+namespace snarkv_host {
+
+// ipa.rs:391-403: prod_i (z^(2^i) xi_{k-1-i} + 1)
+inline Fr h_eval(const std::vector<Fr>& xi, const Fr& z) {
+  Fr out = Fr::one(), zp = z;
+  for (size_t i = xi.size(); i-- > 0;) {
+    out *= zp * xi[i] + Fr::one();
+    zp = zp * zp;
+  }
+  return out;
+}
+
+// ipa.rs:405-421
+inline std::vector<Fr> h_coeffs(const std::vector<Fr>& xi, const Fr& scalar) {
+  if (xi.empty()) throw Panic("h_coeffs of no challenges (reference: assert!, ipa.rs:406)");
+  std::vector<Fr> coeffs((size_t)1 << xi.size());
+  coeffs[0] = scalar;
+  size_t len = 1;
+  for (size_t i = xi.size(); i-- > 0; len <<= 1) {
+    const Fr& x = xi[i];
+    if (len >= 4096) {
+      parallel_for(len / 1024, 16, [&](size_t t) {
+        for (size_t j = t * 1024; j < (t + 1) * 1024; ++j) coeffs[len + j] = coeffs[j] * x;
+      }, 1);
+    } else {
+      for (size_t j = 0; j < len; ++j) coeffs[len + j] = coeffs[j] * x;
+    }
+  }
+  return coeffs;
+}
+
+// ipa.rs:251-276 (`domain` enters only through k)
+struct IpaSuccinctVerifyingKey {
+  size_t k = 0;
+  G1Affine g;  // G_0
+  G1Affine h;
+  std::optional<G1Affine> s;
+  bool zk() const { return s.has_value(); }
+};
+
+// accumulator.rs:3-25
+struct IpaAccumulator {
+  std::vector<Fr> xi;
+  G1Affine u;
+};
+
+// ipa.rs:278-389
+struct IpaProof {
+  struct Round {
+    G1Affine l, r;
+    Fr xi;
+  };
+  std::optional<std::pair<G1Affine, Fr>> c_bar_alpha;
+  std::optional<Fr> omega_prime;
+  Fr xi_0;
+  std::vector<Round> rounds;
+  G1Affine u;
+  Fr c;
+
+  // ipa.rs:320-356
+  static Result<IpaProof> read(const IpaSuccinctVerifyingKey& svk, Transcript& t) {
+    using Res = Result<IpaProof>;
+    IpaProof p;
+    if (svk.zk()) {
+      auto c_bar = t.read_ec_point();
+      if (!c_bar.ok()) return Res::Err(c_bar.err);
+      Fr alpha = t.squeeze_challenge();
+      p.c_bar_alpha = std::make_pair(*c_bar.value, alpha);
+      auto om = t.read_scalar();
+      if (!om.ok()) return Res::Err(om.err);
+      p.omega_prime = *om.value;
+    }
+    p.xi_0 = t.squeeze_challenge();
+    for (size_t i = 0; i < svk.k; ++i) {
+      auto l = t.read_ec_point();
+      if (!l.ok()) return Res::Err(l.err);
+      auto r = t.read_ec_point();
+      if (!r.ok()) return Res::Err(r.err);
+      p.rounds.push_back(Round{*l.value, *r.value, t.squeeze_challenge()});
+    }
+    auto u = t.read_ec_point();
+    if (!u.ok()) return Res::Err(u.err);
+    auto c = t.read_scalar();
+    if (!c.ok()) return Res::Err(c.err);
+    p.u = *u.value;
+    p.c = *c.value;
+    return Res::Ok(std::move(p));
+  }
+
+  // ipa.rs:358-361
+  std::vector<Fr> xi() const {
+    std::vector<Fr> v;
+    for (auto& r : rounds) v.push_back(r.xi);
+    return v;
+  }
+  // ipa.rs:363-373: `Fraction::one_over` + the loader's batch_invert (zeros stay zero)
+  std::vector<Fr> xi_inv() const {
+    std::vector<Fr> v = xi();
+    std::vector<Fr*> ptrs;
+    for (auto& x : v) ptrs.push_back(&x);
+    L::batch_invert(ptrs);
+    return v;
+  }
+};
+
+struct Ipa {
+  // ipa.rs:127-136
+  static Result<IpaProof> read_proof(const IpaSuccinctVerifyingKey& svk, Transcript& t) {
+    return IpaProof::read(svk, t);
+  }
+
+  // ipa.rs:139-180.  lhs = C' + eval [H'] + sum (xi_i^-1 [L_i] + xi_i [R_i]),  rhs = c [U] + v' [H'].
+  static Result<IpaAccumulator> succinct_verify(const IpaSuccinctVerifyingKey& svk, const MsmT& commitment, const Fr& z,
+                                                const Fr& eval, const IpaProof& proof) {
+    const G1Affine h = L::ec_point_load_const(svk.h);
+    MsmT h_prime = MsmT::base(&h) * proof.xi_0;
+    MsmT c_prime = commitment;
+    if (svk.zk() && proof.c_bar_alpha && proof.omega_prime) {
+      c_prime += MsmT::base(&proof.c_bar_alpha->first) * proof.c_bar_alpha->second;
+      c_prime -= MsmT::base(&*svk.s) * *proof.omega_prime;
+    } else if (svk.zk() || proof.c_bar_alpha || proof.omega_prime) {
+      throw Panic("IPA proof / key disagree on zero-knowledge (reference: unreachable!, ipa.rs:160)");
+    }
+    MsmT c_k = c_prime + h_prime * eval;
+    const std::vector<Fr> xi = proof.xi(), xi_inv = proof.xi_inv();
+    for (size_t i = 0; i < proof.rounds.size(); ++i) {
+      c_k += MsmT::base(&proof.rounds[i].l) * xi_inv[i];
+      c_k += MsmT::base(&proof.rounds[i].r) * xi[i];
+    }
+    Fr v_prime = h_eval(xi, z) * proof.c;
+    MsmT rhs = MsmT::base(&proof.u) * proof.c + h_prime * v_prime;
+    auto pts = L::multi_scalar_multiplication_batch({c_k.pairs(std::nullopt), rhs.pairs(std::nullopt)});
+    Error e = L::ec_point_assert_eq("C_k == c[U] + v'[H']", pts[0], pts[1]);
+    if (!e.ok()) return Result<IpaAccumulator>::Err(e);
+    return Result<IpaAccumulator>::Ok(IpaAccumulator{xi, proof.u});
+  }
+};
+
+// accumulation.rs:81-146
+struct IpaAsProof {
+  struct Abu {
+    Fr a, b;
+    G1Affine u;
+  };
+  std::optional<Abu> a_b_u;
+  std::optional<Fr> omega;
+  Fr alpha, z;
+  IpaProof ipa;
+
+  static Result<IpaAsProof> read(const IpaSuccinctVerifyingKey& vk, const std::vector<IpaAccumulator>& instances,
+                                 Transcript& t) {
+    using Res = Result<IpaAsProof>;
+    if (instances.size() <= 1) throw Panic("IpaAsProof::read needs > 1 instances (reference: assert!, accumulation.rs:107)");
+    IpaAsProof p;
+    if (vk.zk()) {
+      auto a = t.read_scalar();
+      if (!a.ok()) return Res::Err(a.err);
+      auto b = t.read_scalar();
+      if (!b.ok()) return Res::Err(b.err);
+      auto u = t.read_ec_point();
+      if (!u.ok()) return Res::Err(u.err);
+      p.a_b_u = Abu{*a.value, *b.value, *u.value};
+      auto om = t.read_scalar();
+      if (!om.ok()) return Res::Err(om.err);
+      p.omega = *om.value;
+    }
+    for (auto& acc : instances) {
+      for (auto& x : acc.xi) {
+        Error e = t.common_scalar(x);
+        if (!e.ok()) return Res::Err(e);
+      }
+      Error e = t.common_ec_point(acc.u);
+      if (!e.ok()) return Res::Err(e);
+    }
+    p.alpha = t.squeeze_challenge();
+    p.z = t.squeeze_challenge();
+    auto ipa = IpaProof::read(vk, t);
+    if (!ipa.ok()) return Res::Err(ipa.err);
+    p.ipa = std::move(*ipa.value);
+    return Res::Ok(std::move(p));
+  }
+};
+
+// decider.rs:3-22
+struct IpaDecidingKey {
+  IpaSuccinctVerifyingKey svk;
+  std::vector<G1Affine> g;
+};
+
+template <class MOS = std::monostate>
+struct IpaAs {
+  using Accumulator = IpaAccumulator;
+
+  // accumulation.rs:34-43
+  static Result<IpaAsProof> read_proof(const IpaSuccinctVerifyingKey& vk, const std::vector<IpaAccumulator>& instances,
+                                       Transcript& t) {
+    return IpaAsProof::read(vk, instances, t);
+  }
+
+  // accumulation.rs:45-79: C = sum alpha^i [U_i] (+ omega [S]),  v = sum alpha^i h_i(z)
+  static Result<IpaAccumulator> verify(const IpaSuccinctVerifyingKey& vk, const std::vector<IpaAccumulator>& instances,
+                                       const IpaAsProof& proof) {
+    std::vector<const G1Affine*> u;
+    std::vector<Fr> h;
+    for (auto& acc : instances) {
+      u.push_back(&acc.u);
+      h.push_back(h_eval(acc.xi, proof.z));
+    }
+    if (proof.a_b_u) {
+      u.push_back(&proof.a_b_u->u);
+      h.push_back(proof.a_b_u->a * proof.z + proof.a_b_u->b);
+    }
+    const std::vector<Fr> powers_of_alpha = proof.alpha.powers(u.size());
+    std::vector<MsmT> terms;
+    for (size_t i = 0; i < u.size(); ++i) terms.push_back(MsmT::base(u[i]) * powers_of_alpha[i]);
+    MsmT c = MsmT::sum(terms);
+    if (proof.omega) {
+      if (!vk.s) throw Panic("IpaAs proof carries omega but the key has no S (reference: unwrap, accumulation.rs:73)");
+      c += MsmT::base(&*vk.s) * *proof.omega;
+    }
+    std::vector<std::pair<Fr, Fr>> prods;
+    for (size_t i = 0; i < h.size(); ++i) prods.emplace_back(powers_of_alpha[i], h[i]);
+    Fr v = L::sum_products(prods);
+    return Ipa::succinct_verify(vk, c, proof.z, v, proof.ipa);
+  }
+
+  // decider.rs:47-55: U == commit(G, h) -- one 2^k-term MSM on the device
+  static Error decide(const IpaDecidingKey& dk, const IpaAccumulator& acc) {
+    std::vector<Fr> h = h_coeffs(acc.xi, Fr::one());
+    G1Affine c = multi_scalar_multiplication(h, dk.g);
+    return acc.u == c ? Error{} : Error::assertion("U == commit(G, h)");
+  }
+
+  // decider.rs:57-66: every accumulator must pass (the reference stops at the first failure)
+  static Error decide_all(const IpaDecidingKey& dk, const std::vector<IpaAccumulator>& accs) {
+    for (auto& a : accs) {
+      Error e = decide(dk, a);
+      if (!e.ok()) return e;
+    }
+    return Error{};
+  }
+};
+
+}  // namespace snarkv_host

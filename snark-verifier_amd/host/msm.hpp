@@ -1,6 +1,7 @@
 // Mirror of `util::msm::Msm` (reference snark-verifier/src/util/msm.rs:20-226):
 // the deferred linear combination  constant * G + sum scalar_i * base_i.
 #pragma once
+#include <algorithm>
 #include <cstring>
 #include <optional>
 #include <unordered_map>
@@ -159,5 +160,34 @@ class Msm {
   }
   static Msm sum(const std::vector<Msm>& v) { return sum(v.begin(), v.end()); }
 };
+
+// `util::msm::multi_scalar_multiplication(&[C::Scalar], &[C]) -> C::Curve`
+// (reference snark-verifier/src/util/msm.rs:308-343): the large-MSM free function
+// (IPA commit / decide) -> the device Pippenger.  Returns the affine point (the
+// reference's callers all `to_affine()` it).  Panics like the reference on a
+// length mismatch (`assert_eq!`, msm.rs:309) and on n = 0 (`scalars[0]`, msm.rs:265).
+inline G1Affine multi_scalar_multiplication(const std::vector<Fr>& scalars, const std::vector<G1Affine>& bases) {
+  if (scalars.size() != bases.size()) throw Panic("multi_scalar_multiplication: scalars.len() != bases.len() (msm.rs:309)");
+  if (scalars.empty()) throw Panic("multi_scalar_multiplication of no terms (reference: scalars[0], msm.rs:265)");
+  const size_t n = scalars.size();
+  std::vector<uint8_t> s(32 * n), p(64 * n);
+  auto pack = [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) {
+      scalars[i].to_bytes(&s[32 * i]);
+      memcpy(&p[64 * i], bases[i].b, 64);
+    }
+  };
+  if (n >= 8192) {
+    const size_t per = 2048, tasks = (n + per - 1) / per;
+    parallel_for(tasks, 16, [&](size_t t) { pack(t * per, std::min(n, (t + 1) * per)); }, 1);
+  } else {
+    pack(0, n);
+  }
+  G1Affine out;
+  std::lock_guard<std::mutex> lock(device_mutex());
+  int rc = bn254_g1_msm_pippenger(s.data(), p.data(), n, out.b);
+  if (rc != SNARKV_OK) throw std::runtime_error(std::string("bn254_g1_msm_pippenger: ") + snarkv_last_error());
+  return out;
+}
 
 }  // namespace snarkv_host

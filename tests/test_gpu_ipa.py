@@ -1,0 +1,148 @@
+"""GPU: the C++ mirror of the reference's IPA layer (snark-verifier_amd/host/ipa.hpp) against the
+oracle: `Ipa::succinct_verify` (two MSMs, one segmented launch), `IpaAs::verify`, and
+`IpaAs::decide` -- ONE device Pippenger of 2^k terms, the reference's second consumer of
+`util::msm::multi_scalar_multiplication` (pcs/ipa/decider.rs:51-52)."""
+import ctypes
+import os
+import random
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import bn254 as O  # noqa: E402
+import coracle as C  # noqa: E402
+import ipa as I  # noqa: E402
+import transcript as T  # noqa: E402
+from ipa_util import acc_from_json, case_key, load_cases, pack_acc, pack_svk  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TR = {"evm": (0, T.EvmTranscript), "poseidon": (1, T.PoseidonTranscript)}
+
+
+@pytest.fixture(scope="module")
+def H():
+    from hostfmt import load_host_lib
+
+    h = load_host_lib()
+    cp, u32, sz = ctypes.c_char_p, ctypes.c_uint32, ctypes.c_size_t
+    h.hd_ipa_succinct_verify.argtypes = [ctypes.c_int, cp, cp, cp, cp, cp, sz, cp]
+    h.hd_ipa_as_verify.argtypes = [ctypes.c_int, cp, cp, u32, cp, sz, cp]
+    h.hd_ipa_decide_all.argtypes = [u32, cp, sz, cp, u32]
+    h.hd_ipa_h.argtypes = [u32, cp, cp, cp]
+    return h
+
+
+def _buf(n):
+    return ctypes.create_string_buffer(n)
+
+
+def test_h_eval_and_h_coeffs(H):
+    rnd = random.Random(3)
+    for k in (1, 2, 6, 13):  # 13: the threaded path of h_coeffs
+        xi = [rnd.randrange(O.R) for _ in range(k)]
+        z = rnd.randrange(O.R)
+        out = _buf(32 + 32 * (1 << k))
+        assert H.hd_ipa_h(k, b"".join(O.fe_to_bytes(x) for x in xi), O.fe_to_bytes(z), out) == 0
+        assert out.raw[:32] == O.fe_to_bytes(I.h_eval(xi, z))
+        assert out.raw[32:] == b"".join(O.fe_to_bytes(c) for c in I.h_coeffs(xi, 1))
+    assert H.hd_ipa_h(0, b"", O.fe_to_bytes(1), _buf(64)) == -100  # ipa.rs:406 assert -> panic
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_golden_succinct_verify_accumulate_decide(H, idx):
+    c = load_cases()[idx]
+    g, h, s = case_key(c)
+    tk, _ = TR[c["transcript"]]
+    k = c["k"]
+    svk = pack_svk(k, g[0], h, s)
+    gb = b"".join(O.g1_to_bytes(p) for p in g)
+    stride = 32 * k + 64
+    accs = []
+    for o in c["openings"]:
+        proof = bytes.fromhex(o["proof"])
+        com, z, ev = (bytes.fromhex(o[n]) for n in ("commitment", "z", "eval"))
+        out = _buf(stride)
+        assert H.hd_ipa_succinct_verify(tk, svk, com, z, ev, proof, len(proof), out) == 1
+        assert out.raw == pack_acc(acc_from_json(o["accumulator"]))
+        accs.append(out.raw)
+        bad_ev = O.fe_to_bytes((O.fe_from_bytes(ev) + 1) % O.R)
+        assert H.hd_ipa_succinct_verify(tk, svk, com, z, bad_ev, proof, len(proof), out) == 0   # AssertionFailure
+        assert H.hd_ipa_succinct_verify(tk, svk, com, z, ev, proof[:-1], len(proof) - 1, out) == -10  # Transcript
+        flipped = bytearray(proof)
+        flipped[len(proof) // 2] ^= 1
+        assert H.hd_ipa_succinct_verify(tk, svk, com, z, ev, bytes(flipped), len(proof), out) in (0, -10)
+    assert H.hd_ipa_decide_all(k, gb, len(g), b"".join(accs), len(accs)) == 1
+    out = _buf(stride)
+    as_proof = bytes.fromhex(c["as_proof"])
+    assert H.hd_ipa_as_verify(tk, svk, b"".join(accs), len(accs), as_proof, len(as_proof), out) == 1
+    assert out.raw == pack_acc(acc_from_json(c["as_accumulator"]))
+    assert H.hd_ipa_decide_all(k, gb, len(g), out.raw, 1) == 1
+    # decide rejects a perturbed U / xi, wherever it sits in the list
+    xi, u = acc_from_json(c["as_accumulator"])
+    bad_u = pack_acc((xi, O.g1_add(u, h)))
+    bad_xi = pack_acc(([(xi[0] + 1) % O.R] + xi[1:], u))
+    assert H.hd_ipa_decide_all(k, gb, len(g), bad_u, 1) == 0
+    assert H.hd_ipa_decide_all(k, gb, len(g), bad_xi, 1) == 0
+    assert H.hd_ipa_decide_all(k, gb, len(g), b"".join(accs) + bad_u, len(accs) + 1) == 0
+    # one old accumulator replaced: the honest IpaAs proof no longer verifies
+    assert H.hd_ipa_as_verify(tk, svk, accs[0] + bad_u[:stride] + accs[2], 3, as_proof, len(as_proof), out) in (0, -10)
+    # a single instance: the reference asserts (accumulation.rs:107)
+    assert H.hd_ipa_as_verify(tk, svk, accs[0], 1, as_proof, len(as_proof), out) == -100
+    # committing key of the wrong length: `assert_eq!(scalars.len(), bases.len())` (msm.rs:309)
+    assert H.hd_ipa_decide_all(k, gb[:-64], len(g) - 1, accs[0], 1) == -100
+
+
+@pytest.mark.parametrize("k,zk", [(10, False), (10, True)])
+def test_reference_test_sizes(H, k, zk):
+    """`test_ipa` (pcs/ipa.rs:434-466: k = 10, zk in {false, true}) and `test_ipa_as`
+    (accumulation.rs:240-290) with a seeded RNG: oracle prover -> C++ verifier -> device decide."""
+    rnd = random.Random("ref-%d-%d" % (k, zk))
+    rng = lambda: rnd.randrange(O.R)  # noqa: E731
+    n = 1 << k
+    raw = C.sample_points(1000 + k + zk, n + 2)
+    pts = [O.g1_from_bytes(raw[64 * i:64 * i + 64]) for i in range(n + 2)]
+    pk = I.IpaProvingKey(k, pts[:n], pts[n], pts[n + 1] if zk else None)
+    svk, gb, stride = pack_svk(k, pk.g[0], pk.h, pk.s), raw[:64 * n], 32 * k + 64
+    accs, accs_py = [], []
+    for _ in range(3):
+        p = [rng() for _ in range(n)]
+        omega, z = (rng() if zk else None), rng()
+        com = pk.commit(p, omega)
+        t = T.EvmTranscript()
+        acc = I.ipa_create_proof(pk, p, z, omega, t, rng)
+        proof = t.finalize()
+        out = _buf(stride)
+        assert H.hd_ipa_succinct_verify(0, svk, O.g1_to_bytes(com), O.fe_to_bytes(z), O.fe_to_bytes(I.poly_eval(p, z)),
+                                        proof, len(proof), out) == 1
+        assert out.raw == pack_acc(acc)
+        accs.append(out.raw)
+        accs_py.append(acc)
+    assert H.hd_ipa_decide_all(k, gb, n, b"".join(accs), 3) == 1
+    t = T.EvmTranscript()
+    acc = I.ipa_as_create_proof(pk, accs_py, t, rng)
+    as_proof = t.finalize()
+    out = _buf(stride)
+    assert H.hd_ipa_as_verify(0, svk, b"".join(accs), 3, as_proof, len(as_proof), out) == 1
+    assert out.raw == pack_acc(acc)
+    assert H.hd_ipa_decide_all(k, gb, n, out.raw, 1) == 1
+    bad = bytearray(out.raw)
+    bad[5] ^= 4
+    assert H.hd_ipa_decide_all(k, gb, n, bytes(bad), 1) == 0
+
+
+def test_decide_is_one_large_msm_2p16(H):
+    """decide at k = 16: 65 536-term device Pippenger against the C oracle's MSM of the same h_coeffs."""
+    k, n = 16, 1 << 16
+    rnd = random.Random(9)
+    xi = [rnd.randrange(O.R) for _ in range(k)]
+    gb = C.sample_points(4242, n)
+    hb = b"".join(O.fe_to_bytes(c) for c in I.h_coeffs(xi, 1))
+    u = C.msm_pippenger(hb, gb, 8)
+    acc = b"".join(O.fe_to_bytes(x) for x in xi) + u
+    assert H.hd_ipa_decide_all(k, gb, n, acc, 1) == 1
+    other = C.g1_add(u, gb[:64])
+    assert H.hd_ipa_decide_all(k, gb, n, acc[:32 * k] + other, 1) == 0
