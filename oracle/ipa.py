@@ -257,3 +257,186 @@ def ipa_as_verify(h, s, instances, proof):
         c.append((proof["omega"], s))
     v = sum(p * x for p, x in zip(powers, hv)) % R
     return ipa_succinct_verify(h, s, c, z, v, proof["ipa"])
+
+
+# ---------------------------------------------------------------------------
+# Bgh19: the multi-open scheme of halo2's IPA backend
+#   bgh19_read_proof     <- snark-verifier/src/pcs/ipa/multiopen/bgh19.rs:113-153
+#   query sets / coeffs  <- bgh19.rs:155-250, 313-399  (same grouping as bdfg21.rs:121-171)
+#   bgh19_verify         <- bgh19.rs:48-96
+#   bgh19_create_proof   <- no reference code (the prover lives in halo2_proofs): written from the
+#                           verifier's equations, transcript order as `Bgh19Proof::read`
+# ---------------------------------------------------------------------------
+import kzg as K  # noqa: E402  (Msm, the shared query-set grouping)
+
+
+def bgh19_read_proof(k, queries, transcript):
+    x_1 = transcript.squeeze_challenge()
+    x_2 = transcript.squeeze_challenge()
+    f = transcript.read_ec_point()
+    x_3 = transcript.squeeze_challenge()
+    q_evals = [transcript.read_scalar() for _ in K.bdfg21_query_sets(queries)]
+    x_4 = transcript.squeeze_challenge()
+    s = transcript.read_ec_point()
+    xi = transcript.squeeze_challenge()
+    z = transcript.squeeze_challenge()
+    rounds = []
+    for _ in range(k):
+        l = transcript.read_ec_point()
+        r = transcript.read_ec_point()
+        rounds.append((l, r, transcript.squeeze_challenge()))
+    c = transcript.read_scalar()
+    blind = transcript.read_scalar()
+    g = transcript.read_ec_point()
+    ipa = dict(c_bar_alpha=(s, xi), omega_prime=blind, xi_0=z, rounds=rounds, u=g, c=c)  # bgh19.rs:150
+    return dict(x_1=x_1, x_2=x_2, f=f, x_3=x_3, q_evals=q_evals, x_4=x_4, ipa=ipa)
+
+
+def bgh19_query_set_coeffs(sets, x, x_3):
+    """bgh19.rs:217-250 + QuerySetCoeff (:313-399), after its two batch inversions."""
+    size = max([len(st["shifts"]) for st in sets] + [2])
+    px = K.powers(x, size)
+    out = []
+    for st in sets:
+        shifts = st["shifts"]
+        ell = []
+        for j, sj in enumerate(shifts):
+            acc = 1
+            for i, si in enumerate(shifts):
+                if i != j:
+                    acc = acc * (sj - si) % R
+            ell.append(acc)
+        xk1 = px[len(shifts) - 1]
+        bary = [_inv((e * xk1 * x_3 - e * s * xk1 * px[1]) % R) for s, e in zip(shifts, ell)]
+        den = 1
+        for s in shifts:
+            den = den * (x_3 - x * s) % R
+        out.append(dict(eval_coeffs=bary, r_eval_coeff=_inv(sum(bary) % R), f_eval_coeff=_inv(den)))
+    return out
+
+
+def bgh19_final_msm(g0, commitments, x, queries, proof):
+    """The `p` of bgh19.rs:61-93: the commitment whose opening at x_3 must be 0."""
+    sets = K.bdfg21_query_sets(queries)
+    coeffs = bgh19_query_set_coeffs(sets, x, proof["x_3"])
+    px1 = K.powers(proof["x_1"], max(len(st["polys"]) for st in sets))
+    f_evals = []
+    for st, co, q_eval in zip(sets, coeffs, proof["q_evals"]):
+        r_evals = [sum(c * e for c, e in zip(co["eval_coeffs"], evals)) % R * co["r_eval_coeff"] % R for evals in st["evals"]]
+        r_eval = sum(a * b for a, b in zip(reversed(r_evals), px1)) % R
+        f_evals.append((q_eval - r_eval) * co["f_eval_coeff"] % R)
+    px2 = K.powers(proof["x_2"], len(sets))
+    f_eval = sum(a * b for a, b in zip(px2, reversed(f_evals))) % R
+    terms = [K.Msm.base(proof["f"]) - K.Msm.const(f_eval)]
+    for st, q_eval in zip(sets, proof["q_evals"]):
+        m = K.Msm.sum([commitments[poly] * pw for poly, pw in zip(reversed(st["polys"]), px1)]) - K.Msm.const(q_eval)
+        terms.append(m)
+    px4 = K.powers(proof["x_4"], len(sets) + 1)
+    total = K.Msm.sum([m * pw for m, pw in zip(terms, reversed(px4))])
+    const, total.constant = total.constant, None  # `.split()`
+    if const is not None:
+        total = total + K.Msm.base(g0) * const
+    return total
+
+
+def bgh19_verify(g0, h, s, commitments, x, queries, proof):
+    p = bgh19_final_msm(g0, commitments, x, queries, proof)
+    return ipa_succinct_verify(h, s, list(zip(p.scalars, p.bases)), proof["x_3"], 0, proof["ipa"])
+
+
+# ---- prover (test fixtures only) -------------------------------------------------------------
+def _poly_add_scaled(a, b, f):
+    n = max(len(a), len(b))
+    a, b = a + [0] * (n - len(a)), b + [0] * (n - len(b))
+    return [(x + f * y) % R for x, y in zip(a, b)]
+
+
+def _poly_div_linear(p, a):
+    """p(X) / (X - a), exact."""
+    out, carry = [0] * (len(p) - 1), 0
+    for i in range(len(p) - 1, 0, -1):
+        carry = (p[i] + carry * a) % R
+        out[i - 1] = carry
+    assert (p[0] + carry * a) % R == 0, "not divisible"
+    return out
+
+
+def _interpolate(pts, vals):
+    res = [0]
+    for j, (pj, vj) in enumerate(zip(pts, vals)):
+        num, den = [1], 1
+        for i, pi in enumerate(pts):
+            if i != j:
+                num = [(a - pi * b) % R for a, b in zip([0] + num, num + [0])]
+                den = den * (pj - pi) % R
+        res = _poly_add_scaled(res, num, vj * _inv(den) % R)
+    return res
+
+
+def bgh19_create_proof(pk, polys, blinds, x, queries, transcript, rng):
+    """`queries` = [(poly, shift, eval)] with eval = polys[poly](x * shift); commitments are
+    pk.commit(polys[j], blinds[j]).  Writes what `Bgh19Proof::read` reads, in that order."""
+    assert pk.zk()
+    n = 1 << pk.k
+    sets = K.bdfg21_query_sets(queries)
+    x_1 = transcript.squeeze_challenge()
+    x_2 = transcript.squeeze_challenge()
+    px1 = K.powers(x_1, max(len(st["polys"]) for st in sets))
+    qs, q_blinds, fs = [], [], []
+    for st in sets:
+        q, qb = [0] * n, 0
+        for poly, pw in zip(reversed(st["polys"]), px1):  # QuerySet::msm order (bgh19.rs:268-273)
+            q = _poly_add_scaled(q, polys[poly], pw)
+            qb = (qb + pw * blinds[poly]) % R
+        pts = [x * sh % R for sh in st["shifts"]]
+        r = _interpolate(pts, [poly_eval(q, p) for p in pts])
+        fi = _poly_add_scaled(q, r, R - 1)
+        for p in pts:
+            fi = _poly_div_linear(fi, p)
+        qs.append(q)
+        q_blinds.append(qb)
+        fs.append(fi)
+    f = [0] * n
+    for fi, pw in zip(reversed(fs), K.powers(x_2, len(sets))):  # f_eval pairs x_2^j with f_evals.rev()
+        f = _poly_add_scaled(f, fi, pw)[:n]
+    f_blind = rng()
+    transcript.write_ec_point(pk.commit(f, f_blind))
+    x_3 = transcript.squeeze_challenge()
+    for q in qs:
+        transcript.write_scalar(poly_eval(q, x_3))
+    x_4 = transcript.squeeze_challenge()
+    px4 = list(reversed(K.powers(x_4, len(sets) + 1)))
+    p = [c * px4[0] % R for c in f]
+    omega = f_blind * px4[0] % R
+    p[0] = (p[0] - poly_eval(f, x_3) * px4[0]) % R
+    for q, qb, pw in zip(qs, q_blinds, px4[1:]):
+        p = _poly_add_scaled(p, q, pw)
+        p[0] = (p[0] - poly_eval(q, x_3) * pw) % R
+        omega = (omega + qb * pw) % R
+    assert poly_eval(p, x_3) == 0
+    # the IPA opening of p at x_3 (value 0), zero-knowledge form, in Bgh19's transcript order
+    p_bar = [rng() for _ in range(n)]
+    p_bar[0] = (p_bar[0] - poly_eval(p_bar, x_3)) % R
+    omega_bar = rng()
+    transcript.write_ec_point(pk.commit(p_bar, omega_bar))  # `s`
+    alpha = transcript.squeeze_challenge()                   # `xi`
+    xi_0 = transcript.squeeze_challenge()                    # `z`
+    coeffs = _poly_add_scaled(p, p_bar, alpha)
+    omega_prime = (omega + alpha * omega_bar) % R
+    h_prime = _mul(pk.h, xi_0)
+    bases = list(pk.g)
+    zs = [pow(x_3, i, R) for i in range(n)]
+    for i in range(pk.k):
+        half = 1 << (pk.k - i - 1)
+        l_i = O.g1_add(_msm(coeffs[half:], bases[:half]), _mul(h_prime, inner_product(coeffs[half:], zs[:half])))
+        r_i = O.g1_add(_msm(coeffs[:half], bases[half:]), _mul(h_prime, inner_product(coeffs[:half], zs[half:])))
+        transcript.write_ec_point(l_i)
+        transcript.write_ec_point(r_i)
+        xi_i = transcript.squeeze_challenge()
+        xi_i_inv = _inv(xi_i)
+        bases = [O.g1_add(bases[j], _mul(bases[half + j], xi_i)) for j in range(half)]
+        coeffs = [(coeffs[j] + xi_i_inv * coeffs[half + j]) % R for j in range(half)]
+        zs = [(zs[j] + xi_i * zs[half + j]) % R for j in range(half)]
+    transcript.write_scalar(coeffs[0])
+    transcript.write_scalar(omega_prime)
+    transcript.write_ec_point(bases[0])

@@ -6,6 +6,7 @@
 //   IpaAccumulator                           snark-verifier/src/pcs/ipa/accumulator.rs:3-25
 //   IpaAs::{read_proof, verify}, IpaAsProof  snark-verifier/src/pcs/ipa/accumulation.rs:21-146
 //   IpaDecidingKey, decide / decide_all      snark-verifier/src/pcs/ipa/decider.rs:3-68
+//   Bgh19 (halo2's IPA multi-open)           snark-verifier/src/pcs/ipa/multiopen/bgh19.rs:21-399
 //
 // `IpaAs::decide` is the reference's second consumer of the large-MSM hot path:
 // U == `util::msm::multi_scalar_multiplication(h_coeffs(xi, 1), dk.g)` with 2^k
@@ -265,6 +266,167 @@ struct IpaAs {
       if (!e.ok()) return e;
     }
     return Error{};
+  }
+};
+
+// ------------------------------------------------------------------ Bgh19
+// bgh19.rs:98-153.  The IPA part arrives in halo2's order (S, xi, z, rounds, c, blind, G) and
+// is stored as the `IpaProof` it maps to (bgh19.rs:150).
+struct Bgh19 {};
+struct Bgh19Proof {
+  Fr x_1, x_2;
+  G1Affine f;
+  Fr x_3;
+  std::vector<Fr> q_evals;
+  Fr x_4;
+  IpaProof ipa;
+
+  static Result<Bgh19Proof> read(const IpaSuccinctVerifyingKey& svk, const std::vector<Query<Fr>>& queries, Transcript& t) {
+    using Res = Result<Bgh19Proof>;
+    Bgh19Proof p;
+    p.x_1 = t.squeeze_challenge();
+    p.x_2 = t.squeeze_challenge();
+    auto f = t.read_ec_point();
+    if (!f.ok()) return Res::Err(f.err);
+    p.f = *f.value;
+    p.x_3 = t.squeeze_challenge();
+    const size_t n_sets = bdfg21::query_sets(queries).size();  // the same grouping as bdfg21.rs:121-171 (bgh19.rs:155-215)
+    for (size_t i = 0; i < n_sets; ++i) {
+      auto q = t.read_scalar();
+      if (!q.ok()) return Res::Err(q.err);
+      p.q_evals.push_back(*q.value);
+    }
+    p.x_4 = t.squeeze_challenge();
+    auto s = t.read_ec_point();
+    if (!s.ok()) return Res::Err(s.err);
+    Fr xi = t.squeeze_challenge();
+    Fr z = t.squeeze_challenge();
+    p.ipa.c_bar_alpha = std::make_pair(*s.value, xi);
+    p.ipa.xi_0 = z;
+    for (size_t i = 0; i < svk.k; ++i) {
+      auto l = t.read_ec_point();
+      if (!l.ok()) return Res::Err(l.err);
+      auto r = t.read_ec_point();
+      if (!r.ok()) return Res::Err(r.err);
+      p.ipa.rounds.push_back(IpaProof::Round{*l.value, *r.value, t.squeeze_challenge()});
+    }
+    auto c = t.read_scalar();
+    if (!c.ok()) return Res::Err(c.err);
+    auto blind = t.read_scalar();
+    if (!blind.ok()) return Res::Err(blind.err);
+    auto g = t.read_ec_point();
+    if (!g.ok()) return Res::Err(g.err);
+    p.ipa.c = *c.value;
+    p.ipa.omega_prime = *blind.value;
+    p.ipa.u = *g.value;
+    return Res::Ok(std::move(p));
+  }
+};
+
+namespace bgh19 {
+// bgh19.rs:313-399 after its two batch inversions (values, not Fractions)
+struct QuerySetCoeff {
+  std::vector<Fr> eval_coeffs;  // barycentric weights
+  Fr r_eval_coeff;              // 1 / sum of the weights
+  Fr f_eval_coeff;              // 1 / prod (x_3 - x shift)
+};
+
+// bgh19.rs:217-250
+inline std::vector<QuerySetCoeff> query_set_coeffs(const std::vector<bdfg21::QuerySet>& sets, const Fr& x, const Fr& x_3) {
+  size_t size = 2;
+  for (auto& s : sets) size = std::max(size, s.shifts.size());
+  const auto powers_of_x = x.powers(size);
+  std::vector<QuerySetCoeff> coeffs;
+  for (auto& set : sets) {
+    QuerySetCoeff c;
+    const auto& shifts = set.shifts;
+    const Fr& xk1 = powers_of_x[shifts.size() - 1];
+    for (size_t j = 0; j < shifts.size(); ++j) {
+      Fr ell = Fr::one();  // normalized_ell_prime, bgh19.rs:327-340
+      for (size_t i = 0; i < shifts.size(); ++i)
+        if (i != j) ell *= (shifts[j] - shifts[i]);
+      c.eval_coeffs.push_back(ell * xk1 * x_3 - ell * shifts[j] * xk1 * powers_of_x[1]);  // bgh19.rs:345-355
+    }
+    c.f_eval_coeff = Fr::one();
+    for (auto& sh : shifts) c.f_eval_coeff *= (x_3 - x * sh);  // bgh19.rs:357-364
+    coeffs.push_back(std::move(c));
+  }
+  {
+    std::vector<Fr*> denoms;  // first batch inversion (bgh19.rs:245)
+    for (auto& c : coeffs) {
+      for (auto& e : c.eval_coeffs) denoms.push_back(&e);
+      denoms.push_back(&c.f_eval_coeff);
+    }
+    L::batch_invert(denoms);
+  }
+  {
+    std::vector<Fr*> denoms;  // second: the barycentric-weight sums (bgh19.rs:246, :384-394)
+    for (auto& c : coeffs) {
+      Fr sum;
+      for (auto& e : c.eval_coeffs) sum += e;
+      c.r_eval_coeff = sum;
+      denoms.push_back(&c.r_eval_coeff);
+    }
+    L::batch_invert(denoms);
+  }
+  return coeffs;
+}
+
+// the `p` of bgh19.rs:61-93: the commitment whose opening at x_3 must be 0
+inline MsmT final_msm(const G1Affine* g0, const std::vector<MsmT>& commitments, const Fr& x,
+                      const std::vector<Query<Fr>>& queries, const Bgh19Proof& proof) {
+  const auto sets = bdfg21::query_sets(queries);
+  if (sets.size() != proof.q_evals.size()) throw Panic("Bgh19: queries changed between read_proof and verify");
+  const auto coeffs = bgh19::query_set_coeffs(sets, x, proof.x_3);
+  size_t maxp = 0;
+  for (auto& s : sets) maxp = std::max(maxp, s.polys.size());
+  const auto powers_of_x_1 = proof.x_1.powers(maxp);
+  const auto powers_of_x_2 = proof.x_2.powers(sets.size());
+  std::vector<Fr> f_evals;  // QuerySet::f_eval, bgh19.rs:276-300
+  for (size_t k = 0; k < sets.size(); ++k) {
+    const auto& set = sets[k];
+    const auto& co = coeffs[k];
+    Fr r_eval;
+    const size_t np = set.polys.size();
+    for (size_t i = 0; i < np; ++i) {
+      Fr r_i;
+      for (size_t j = 0; j < co.eval_coeffs.size(); ++j) r_i += co.eval_coeffs[j] * *set.evals[i][j];
+      r_eval += r_i * co.r_eval_coeff * powers_of_x_1[np - 1 - i];  // r_evals.rev() zip powers_of_x_1
+    }
+    f_evals.push_back((proof.q_evals[k] - r_eval) * co.f_eval_coeff);
+  }
+  Fr f_eval;
+  for (size_t j = 0; j < sets.size(); ++j) f_eval += powers_of_x_2[j] * f_evals[sets.size() - 1 - j];
+  const auto powers_of_x_4 = proof.x_4.powers(sets.size() + 1);
+  std::vector<MsmT> terms;
+  terms.push_back((MsmT::base(&proof.f) - MsmT::from_constant(f_eval)) * powers_of_x_4[sets.size()]);
+  for (size_t k = 0; k < sets.size(); ++k) {
+    const auto& set = sets[k];
+    std::vector<MsmT> polys;  // QuerySet::msm, bgh19.rs:262-274
+    for (size_t m = 0; m < set.polys.size(); ++m)
+      polys.push_back(commitments[set.polys[set.polys.size() - 1 - m]] * powers_of_x_1[m]);
+    terms.push_back((MsmT::sum(polys) - MsmT::from_constant(proof.q_evals[k])) * powers_of_x_4[sets.size() - 1 - k]);
+  }
+  auto [msm, constant] = MsmT::sum(terms).split();
+  if (constant) msm += MsmT::base(g0) * *constant;
+  return msm;
+}
+}  // namespace bgh19
+
+// `impl PolynomialCommitmentScheme for IpaAs<C, Bgh19>` (bgh19.rs:26-96)
+struct IpaBgh19 {
+  using VerifyingKey = IpaSuccinctVerifyingKey;
+  using Proof = Bgh19Proof;
+  using Output = IpaAccumulator;
+  static Result<Bgh19Proof> read_proof(const IpaSuccinctVerifyingKey& svk, const std::vector<Query<Fr>>& queries,
+                                       Transcript& t) {
+    return Bgh19Proof::read(svk, queries, t);
+  }
+  static Result<IpaAccumulator> verify(const IpaSuccinctVerifyingKey& svk, const std::vector<MsmT>& commitments,
+                                       const Fr& x, const std::vector<Query<Fr>>& queries, const Bgh19Proof& proof) {
+    const G1Affine g = L::ec_point_load_const(svk.g);
+    MsmT p = bgh19::final_msm(&g, commitments, x, queries, proof);
+    return Ipa::succinct_verify(svk, p, proof.x_3, L::load_zero(), proof.ipa);
   }
 };
 

@@ -887,3 +887,26 @@ extern "C" int hd_ipa_h(uint32_t k, const uint8_t* xi32, const uint8_t* z32, uin
     return 0;
   });
 }
+
+// `IpaAs<Bgh19>` as a PolynomialCommitmentScheme (bgh19.rs:26-96): read_proof + verify.
+//   commitments: pack_commitments format (the Msm list);  queries: pack_queries format
+extern "C" int hd_ipa_bgh19_verify(int tkind, const uint8_t* svk_bytes, const uint8_t* commitments, const uint8_t* x32,
+                                   const uint8_t* queries, const uint8_t* proof, size_t plen, uint8_t* acc_out) {
+  return guarded([&] {
+    IpaSuccinctVerifyingKey svk = parse_ipa_svk(svk_bytes);
+    Reader rc{commitments}, rq{queries};
+    std::vector<std::vector<G1Affine>> store;
+    std::vector<MsmT> cms;
+    read_commitments(rc, store, cms);
+    auto qs = read_queries(rq);
+    Fr x;
+    if (!Fr::from_bytes(x32, &x)) return -3;
+    auto t = make_transcript(tkind, proof, plen);
+    auto pr = IpaBgh19::read_proof(svk, qs, *t);
+    if (!pr.ok()) return error_code(pr.err);
+    auto acc = IpaBgh19::verify(svk, cms, x, qs, *pr.value);
+    if (!acc.ok()) return error_code(acc.err);
+    put_ipa_acc(*acc.value, acc_out);
+    return 1;
+  });
+}

@@ -8,9 +8,17 @@ import bn254 as O
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def load_cases():
+def load_cases(section="cases"):
     with open(os.path.join(ROOT, "tests", "golden", "ipa.json")) as f:
-        return json.load(f)["cases"]
+        return json.load(f)[section]
+
+
+def bgh19_case(c):
+    """-> (g, h, s, commitment points, x, queries [(poly, shift, eval)], proof bytes, accumulator)"""
+    g, h, s = case_key(c)
+    coms = [O.g1_from_bytes(bytes.fromhex(v)) for v in c["commitments"]]
+    queries = [(p, O.fe_from_bytes(bytes.fromhex(sh)), O.fe_from_bytes(bytes.fromhex(ev))) for p, sh, ev in c["queries"]]
+    return g, h, s, coms, O.fe_from_bytes(bytes.fromhex(c["x"])), queries, bytes.fromhex(c["proof"]), acc_from_json(c["accumulator"])
 
 
 def case_key(c):

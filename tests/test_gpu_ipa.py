@@ -17,7 +17,7 @@ import bn254 as O  # noqa: E402
 import coracle as C  # noqa: E402
 import ipa as I  # noqa: E402
 import transcript as T  # noqa: E402
-from ipa_util import acc_from_json, case_key, load_cases, pack_acc, pack_svk  # noqa: E402
+from ipa_util import acc_from_json, bgh19_case, case_key, load_cases, pack_acc, pack_svk  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 TR = {"evm": (0, T.EvmTranscript), "poseidon": (1, T.PoseidonTranscript)}
@@ -33,6 +33,7 @@ def H():
     h.hd_ipa_as_verify.argtypes = [ctypes.c_int, cp, cp, u32, cp, sz, cp]
     h.hd_ipa_decide_all.argtypes = [u32, cp, sz, cp, u32]
     h.hd_ipa_h.argtypes = [u32, cp, cp, cp]
+    h.hd_ipa_bgh19_verify.argtypes = [ctypes.c_int, cp, cp, cp, cp, cp, sz, cp]
     return h
 
 
@@ -146,3 +147,34 @@ def test_decide_is_one_large_msm_2p16(H):
     assert H.hd_ipa_decide_all(k, gb, n, acc, 1) == 1
     other = C.g1_add(u, gb[:64])
     assert H.hd_ipa_decide_all(k, gb, n, acc[:32 * k] + other, 1) == 0
+
+
+@pytest.mark.parametrize("idx", range(2))
+def test_golden_bgh19_multiopen(H, idx):
+    """`IpaAs<Bgh19>` read_proof + verify (multiopen/bgh19.rs:26-153) in the C++ mirror: same
+    accumulator bytes as the oracle, decide accepts; wrong evaluations / commitments reject."""
+    import kzg as K
+    from hostfmt import pack_commitments, pack_queries
+
+    c = load_cases("bgh19")[idx]
+    g, h, s, coms, x, queries, proof, exp = bgh19_case(c)
+    tk, k = TR[c["transcript"]][0], c["k"]
+    svk = pack_svk(k, g[0], h, s)
+    cm = pack_commitments([K.Msm.base(p) for p in coms])
+    out = _buf(32 * k + 64)
+    assert H.hd_ipa_bgh19_verify(tk, svk, cm, O.fe_to_bytes(x), pack_queries(queries), proof, len(proof), out) == 1
+    assert out.raw == pack_acc(exp)
+    gb = b"".join(O.g1_to_bytes(p) for p in g)
+    assert H.hd_ipa_decide_all(k, gb, len(g), out.raw, 1) == 1
+    for i in (0, 5, 8):
+        bad = list(queries)
+        bad[i] = (bad[i][0], bad[i][1], (bad[i][2] + 1) % O.R)
+        assert H.hd_ipa_bgh19_verify(tk, svk, cm, O.fe_to_bytes(x), pack_queries(bad), proof, len(proof), out) == 0
+    cm2 = pack_commitments([K.Msm.base(p) for p in [coms[1], coms[0]] + coms[2:]])
+    assert H.hd_ipa_bgh19_verify(tk, svk, cm2, O.fe_to_bytes(x), pack_queries(queries), proof, len(proof), out) == 0
+    assert H.hd_ipa_bgh19_verify(tk, svk, cm, O.fe_to_bytes(x), pack_queries(queries), proof[:-7], len(proof) - 7, out) == -10
+    # commitments given as linear combinations (what the PLONK verifier hands over): 2*C0 - C0 = C0
+    lin = [K.Msm.base(coms[0]) * 2 - K.Msm.base(coms[0])] + [K.Msm.base(p) for p in coms[1:]]
+    assert H.hd_ipa_bgh19_verify(tk, svk, pack_commitments(lin), O.fe_to_bytes(x), pack_queries(queries), proof,
+                                 len(proof), out) == 1
+    assert out.raw == pack_acc(exp)

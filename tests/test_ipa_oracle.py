@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bn254 as O  # noqa: E402
 import ipa as I  # noqa: E402
 import transcript as T  # noqa: E402
-from ipa_util import acc_from_json, case_key, load_cases  # noqa: E402
+from ipa_util import acc_from_json, bgh19_case, case_key, load_cases  # noqa: E402
 
 TR = {"evm": T.EvmTranscript, "poseidon": T.PoseidonTranscript}
 
@@ -93,3 +93,29 @@ def test_accumulation_of_ten_like_the_reference_test():
     I.ipa_as_create_proof(pk, accs, t, rng)
     acc = I.ipa_as_verify(pk.h, pk.s, accs, I.ipa_as_read_proof(True, k, accs, T.EvmTranscript(t.finalize())))
     assert I.ipa_decide(pk.g, acc)
+
+
+@pytest.mark.parametrize("idx", range(2))
+def test_golden_bgh19_multiopen(idx):
+    """`IpaAs<Bgh19>` as a PCS (multiopen/bgh19.rs:26-96) on an honest multi-open proof over six
+    polynomials with rotation sets {0}, {0,1}, {0,1,-1}, {1,0}, {-3} and a repeated query."""
+    import kzg as K
+
+    c = load_cases("bgh19")[idx]
+    g, h, s, coms, x, queries, proof, exp = bgh19_case(c)
+    Tr = TR[c["transcript"]]
+    sets = K.bdfg21_query_sets(queries)
+    assert [len(st["shifts"]) for st in sets] == [1, 2, 3, 1] and sets[1]["polys"] == [1, 3]
+    msms = [K.Msm.base(p) for p in coms]
+    acc = I.bgh19_verify(g[0], h, s, msms, x, queries, I.bgh19_read_proof(c["k"], queries, Tr(proof)))
+    assert (acc[0], acc[1]) == (exp[0], exp[1]) and I.ipa_decide(g, acc)
+    for i in (0, 5, 8):  # any wrong evaluation breaks the final opening
+        bad = list(queries)
+        bad[i] = (bad[i][0], bad[i][1], (bad[i][2] + 1) % O.R)
+        with pytest.raises(I.IpaError):
+            I.bgh19_verify(g[0], h, s, msms, x, bad, I.bgh19_read_proof(c["k"], bad, Tr(proof)))
+    swapped = [msms[1], msms[0]] + msms[2:]
+    with pytest.raises(I.IpaError):
+        I.bgh19_verify(g[0], h, s, swapped, x, queries, I.bgh19_read_proof(c["k"], queries, Tr(proof)))
+    with pytest.raises(T.TranscriptError):
+        I.bgh19_read_proof(c["k"], queries, Tr(proof[:-7]))
