@@ -173,6 +173,10 @@ def read_pcs_proof(pr, t, mos):
         ws = [t.read_ec_point() for _ in range(_query_set_count(pr, mos))]
         u = t.squeeze_challenge()
         return {"v": v, "ws": ws, "u": u}
+    if mos == "bgh19":  # pcs/ipa/multiopen/bgh19.rs:113-153 (svk.domain = the protocol's domain)
+        import ipa as I
+
+        return I.bgh19_read_proof(pr["domain"].k, [(poly, shift, 0) for poly, shift in empty_queries(pr)], t)
     mu = t.squeeze_challenge()  # bdfg21.rs:95-117
     gamma = t.squeeze_challenge()
     w = t.read_ec_point()
@@ -313,6 +317,18 @@ def succinct_verify(g, pr, instances, proof, mos):
     return [(lhs.evaluate(g), rhs.evaluate(g))] + list(proof["old_accumulators"])
 
 
+def succinct_verify_ipa(g0, h, s, pr, instances, proof):
+    """`PlonkSuccinctVerifier<IpaAs<Bgh19>>::verify` (plonk.rs:58-92 with the PCS of bgh19.rs:48-96):
+    -> [IpaAccumulator] (no old accumulators: the IPA side has no `AccumulatorEncoding`, pcs.rs:173-184)."""
+    import ipa as I
+
+    cpe = CommonPolyEval(pr["domain"], protocol_lagranges(pr), proof["z"])
+    evals = proof_evaluations(pr, instances, proof, cpe)
+    commitments = proof_commitments(pr, proof, cpe, evals)
+    queries = proof_queries(pr, evals)
+    return [I.bgh19_verify(g0, h, s, commitments, proof["z"], queries, proof["pcs"])]
+
+
 # ---------------------------------------------------------------- forger (toy SRS)
 class _Dlog:
     """Points with known discrete logs: mint(c) = [c]G, remembered."""
@@ -333,10 +349,9 @@ class _Dlog:
         return acc % R
 
 
-def forge_proof(pr, instances, secret, make_transcript, mos, rng, preprocessed_dlogs):
-    """Writes a proof that verifies under the toy SRS ([1]G, [s]G2).
-    `preprocessed_dlogs[i]` is the discrete log of pr["preprocessed"][i].
-    Returns the proof bytes."""
+def _forge_front(pr, instances, make_transcript, rng, preprocessed_dlogs):
+    """Everything up to the PCS opening: random commitments with known discrete logs, random
+    evaluations.  -> (transcript, dlog table, z, commitments, queries)"""
     d = _Dlog()
     for p, c in zip(pr["preprocessed"], preprocessed_dlogs):
         d.table[p] = c % R
@@ -385,6 +400,14 @@ def forge_proof(pr, instances, secret, make_transcript, mos, rng, preprocessed_d
     evals = proof_evaluations(pr, instances, proof, cpe)
     commitments = proof_commitments(pr, proof, cpe, evals)
     queries = proof_queries(pr, evals)
+    return t, d, z, commitments, queries
+
+
+def forge_proof(pr, instances, secret, make_transcript, mos, rng, preprocessed_dlogs):
+    """Writes a proof that verifies under the toy SRS ([1]G, [s]G2).
+    `preprocessed_dlogs[i]` is the discrete log of pr["preprocessed"][i].
+    Returns the proof bytes."""
+    t, d, z, commitments, queries = _forge_front(pr, instances, make_transcript, rng, preprocessed_dlogs)
     if mos == "gwc19":
         v = t.squeeze_challenge()
         sets = K.gwc19_query_sets(queries)
@@ -411,4 +434,50 @@ def forge_proof(pr, instances, secret, make_transcript, mos, rng, preprocessed_d
                 rest.push(s, b)
         wp = d.of_msm(rest) * pow((secret - coeff) % R, -1, R) % R
         t.write_ec_point(d.mint(wp))
+    return t.finalize()
+
+
+def forge_proof_ipa(pr, instances, key_dlogs, make_transcript, rng, preprocessed_dlogs):
+    """A PLONK proof over `IpaAs<Bgh19>` that verifies AND decides under a toy committing key whose
+    discrete logs are known: key_dlogs = {"g": [gamma_i] (2^k of them), "h": eta, "s": sigma}.
+    Commitments and evaluations are random; the multi-open part is random too, and the last scalar
+    `c` of the IPA opening is solved from  dlog(C_k) = c (dlog U + h_eval xi_0 eta)  with
+    U = <h_coeffs(xi), G> the honest value, so `decide` holds as well.  Returns the proof bytes."""
+    import ipa as I
+
+    k = pr["domain"].k
+    assert len(key_dlogs["g"]) == 1 << k
+    t, d, z, commitments, queries = _forge_front(pr, instances, make_transcript, rng, preprocessed_dlogs)
+    g = [d.mint(c) for c in key_dlogs["g"]]
+    s_pt = d.mint(key_dlogs["s"])
+    d.mint(key_dlogs["h"])
+    x_1 = t.squeeze_challenge()
+    x_2 = t.squeeze_challenge()
+    f = d.mint(rng.randrange(1, R))
+    t.write_ec_point(f)
+    x_3 = t.squeeze_challenge()
+    q_evals = [rng.randrange(R) for _ in K.bdfg21_query_sets(queries)]
+    for q in q_evals:
+        t.write_scalar(q)
+    x_4 = t.squeeze_challenge()
+    p = I.bgh19_final_msm(g[0], commitments, z, queries, dict(x_1=x_1, x_2=x_2, f=f, x_3=x_3, q_evals=q_evals, x_4=x_4))
+    c_bar = d.mint(rng.randrange(1, R))
+    t.write_ec_point(c_bar)
+    alpha = t.squeeze_challenge()
+    xi_0 = t.squeeze_challenge()
+    omega_prime = rng.randrange(R)
+    lhs = (d.of_msm(p) + alpha * d.table[c_bar] - omega_prime * d.table[s_pt]) % R
+    xi = []
+    for _ in range(k):
+        l, r = d.mint(rng.randrange(1, R)), d.mint(rng.randrange(1, R))
+        t.write_ec_point(l)
+        t.write_ec_point(r)
+        x = t.squeeze_challenge()
+        lhs = (lhs + pow(x, -1, R) * d.table[l] + x * d.table[r]) % R
+        xi.append(x)
+    u_dlog = sum(hc * gm for hc, gm in zip(I.h_coeffs(xi, 1), key_dlogs["g"])) % R
+    c = lhs * pow((u_dlog + I.h_eval(xi, x_3) * xi_0 % R * key_dlogs["h"]) % R, -1, R) % R
+    t.write_scalar(c)
+    t.write_scalar(omega_prime)
+    t.write_ec_point(d.mint(u_dlog))
     return t.finalize()

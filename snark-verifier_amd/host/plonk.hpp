@@ -22,9 +22,11 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <type_traits>
 #include <set>
 #include <thread>
 
+#include "ipa.hpp"
 #include "pcs.hpp"
 
 namespace snarkv_host {
@@ -222,6 +224,41 @@ template <>
 struct MosProof<Bdfg21> {
   using type = Bdfg21Proof;
 };
+template <>
+struct MosProof<Bgh19> {
+  using type = Bgh19Proof;
+};
+
+// The `AS: AccumulationScheme + PolynomialCommitmentScheme` a multi-open scheme belongs to
+// (plonk.rs:35-41): KzgAs<Gwc19 | Bdfg21> or IpaAs<Bgh19>.
+// `impl AccumulatorEncoding for PhantomData<PCS>` (pcs.rs:173-184): the default encoding of schemes
+// that define none (IPA) -- `from_repr` is `unimplemented!()`.
+template <class Acc>
+struct NoAccumulatorEncoding {
+  static Result<Acc> from_repr(const std::vector<const Fr*>&) {
+    throw Panic("AccumulatorEncoding::from_repr: unimplemented!() (reference pcs.rs:182)");
+  }
+};
+template <class MOS>
+struct PcsOf {
+  using Svk = KzgSuccinctVerifyingKey;
+  using Accumulator = KzgAccumulator;
+  using DecidingKey = KzgDecidingKey;
+  using DefaultAE = LimbsEncoding<4, 68>;
+  static Error decide_all(const DecidingKey& dk, const std::vector<Accumulator>& accs) {
+    return KzgAs<MOS>::decide_all(dk, accs);
+  }
+};
+template <>
+struct PcsOf<Bgh19> {
+  using Svk = IpaSuccinctVerifyingKey;
+  using Accumulator = IpaAccumulator;
+  using DecidingKey = IpaDecidingKey;
+  using DefaultAE = NoAccumulatorEncoding<IpaAccumulator>;
+  static Error decide_all(const DecidingKey& dk, const std::vector<Accumulator>& accs) {
+    return IpaAs<Bgh19>::decide_all(dk, accs);
+  }
+};
 
 // proof.rs:18-45
 template <class MOS>
@@ -234,7 +271,7 @@ struct PlonkProof {
   Fr z;
   std::vector<Fr> evaluations;
   PcsProof pcs;
-  std::vector<KzgAccumulator> old_accumulators;
+  std::vector<typename PcsOf<MOS>::Accumulator> old_accumulators;
 
   // proof.rs:170-181
   static std::vector<Query<std::monostate>> empty_queries(const PlonkProtocol& pr) {
@@ -243,11 +280,11 @@ struct PlonkProof {
     return out;
   }
 
-  static Result<PcsProof> read_pcs(const PlonkProtocol& pr, Transcript& t);
+  static Result<PcsProof> read_pcs(const typename PcsOf<MOS>::Svk& svk, const PlonkProtocol& pr, Transcript& t);
 
   // proof.rs:52-168; AE = LimbsEncoding<LIMBS, BITS>
-  template <class AE = LimbsEncoding<4, 68>>
-  static Result<PlonkProof> read(const KzgSuccinctVerifyingKey&, const PlonkProtocol& pr,
+  template <class AE = typename PcsOf<MOS>::DefaultAE>
+  static Result<PlonkProof> read(const typename PcsOf<MOS>::Svk& svk, const PlonkProtocol& pr,
                                  const std::vector<std::vector<Fr>>& instances, Transcript& t) {
     using R = Result<PlonkProof>;
     if (pr.transcript_initial_state) {
@@ -297,7 +334,7 @@ struct PlonkProof {
       if (!s.ok()) return R::Err(s.err);
       p.evaluations.push_back(*s.value);
     }
-    auto pcs = read_pcs(pr, t);
+    auto pcs = read_pcs(svk, pr, t);
     if (!pcs.ok()) return R::Err(pcs.err);
     p.pcs = *pcs.value;
     for (auto& idx : pr.accumulator_indices) {
@@ -450,12 +487,21 @@ struct PlonkProof {
 };
 
 template <>
-inline Result<Gwc19Proof> PlonkProof<Gwc19>::read_pcs(const PlonkProtocol& pr, Transcript& t) {
+inline Result<Gwc19Proof> PlonkProof<Gwc19>::read_pcs(const KzgSuccinctVerifyingKey&, const PlonkProtocol& pr,
+                                                      Transcript& t) {
   return gwc19::read(empty_queries(pr), t);
 }
 template <>
-inline Result<Bdfg21Proof> PlonkProof<Bdfg21>::read_pcs(const PlonkProtocol&, Transcript& t) {
+inline Result<Bdfg21Proof> PlonkProof<Bdfg21>::read_pcs(const KzgSuccinctVerifyingKey&, const PlonkProtocol&,
+                                                        Transcript& t) {
   return Bdfg21Proof::read(t);
+}
+template <>
+inline Result<Bgh19Proof> PlonkProof<Bgh19>::read_pcs(const IpaSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
+                                                      Transcript& t) {
+  std::vector<Query<Fr>> qs;  // only (poly, shift) matter to `Bgh19Proof::read` (the number of rotation sets)
+  for (auto& q : empty_queries(pr)) qs.push_back(Query<Fr>{q.poly, q.shift, Fr()});
+  return IpaBgh19::read_proof(svk, qs, t);
 }
 
 namespace plonk_detail {
@@ -502,9 +548,11 @@ template <class MOS>
 struct PlonkSuccinctVerifier {
   using Proof = PlonkProof<MOS>;
   using Pairs = std::vector<std::pair<Fr, G1Affine>>;
+  using Svk = typename PcsOf<MOS>::Svk;
+  using Accumulator = typename PcsOf<MOS>::Accumulator;
 
-  static Result<Proof> read_proof(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
-                                  const std::vector<std::vector<Fr>>& instances, Transcript& t) {
+  static Result<Proof> read_proof(const Svk& svk, const PlonkProtocol& pr, const std::vector<std::vector<Fr>>& instances,
+                                  Transcript& t) {
     return Proof::read(svk, pr, instances, t);
   }
 
@@ -525,13 +573,29 @@ struct PlonkSuccinctVerifier {
   }
 
   // plonk.rs:58-92: [new accumulator] ++ old accumulators
-  static Result<std::vector<KzgAccumulator>> verify(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
-                                                    const std::vector<std::vector<Fr>>& instances, const Proof& proof) {
-    using R = Result<std::vector<KzgAccumulator>>;
-    auto prs = msm_pairs(svk, pr, instances, proof);
-    if (!prs.ok()) return R::Err(prs.err);
-    auto pts = L::multi_scalar_multiplication_batch({prs.value->first, prs.value->second});
-    std::vector<KzgAccumulator> out{KzgAccumulator{pts[0], pts[1]}};
+  static Result<std::vector<Accumulator>> verify(const Svk& svk, const PlonkProtocol& pr,
+                                                 const std::vector<std::vector<Fr>>& instances, const Proof& proof) {
+    using R = Result<std::vector<Accumulator>>;
+    std::vector<Accumulator> out;
+    if constexpr (std::is_same_v<MOS, Bgh19>) {
+      // `AS::verify` of IpaAs<Bgh19> (bgh19.rs:48-96): the succinct check is part of it
+      try {
+        CommonPolyEval cpe(pr.domain, pr.langranges(), proof.z);
+        auto evals = proof.evaluations_map(pr, instances, cpe);
+        auto cm = proof.commitments(pr, cpe, evals);
+        auto queries = proof.queries(pr, evals);
+        auto acc = IpaBgh19::verify(svk, cm, proof.z, queries, proof.pcs);
+        if (!acc.ok()) return R::Err(acc.err);
+        out.push_back(std::move(*acc.value));
+      } catch (const InvalidProtocol& e) {
+        return R::Err(Error{Error::InvalidProtocol, e.what()});
+      }
+    } else {
+      auto prs = msm_pairs(svk, pr, instances, proof);
+      if (!prs.ok()) return R::Err(prs.err);
+      auto pts = L::multi_scalar_multiplication_batch({prs.value->first, prs.value->second});
+      out.push_back(KzgAccumulator{pts[0], pts[1]});
+    }
     out.insert(out.end(), proof.old_accumulators.begin(), proof.old_accumulators.end());
     return R::Ok(out);
   }
@@ -582,15 +646,16 @@ struct PlonkSuccinctVerifier {
 template <class MOS>
 struct PlonkVerifier {
   using Proof = PlonkProof<MOS>;
-  static Result<Proof> read_proof(const KzgDecidingKey& vk, const PlonkProtocol& pr,
+  using DecidingKey = typename PcsOf<MOS>::DecidingKey;
+  static Result<Proof> read_proof(const DecidingKey& vk, const PlonkProtocol& pr,
                                   const std::vector<std::vector<Fr>>& instances, Transcript& t) {
     return Proof::read(vk.svk, pr, instances, t);
   }
-  static Error verify(const KzgDecidingKey& vk, const PlonkProtocol& pr, const std::vector<std::vector<Fr>>& instances,
+  static Error verify(const DecidingKey& vk, const PlonkProtocol& pr, const std::vector<std::vector<Fr>>& instances,
                       const Proof& proof) {
     auto accs = PlonkSuccinctVerifier<MOS>::verify(vk.svk, pr, instances, proof);
     if (!accs.ok()) return accs.err;
-    return KzgAs<MOS>::decide_all(vk, *accs.value);
+    return PcsOf<MOS>::decide_all(vk, *accs.value);
   }
   // plonk.rs:178-188
   static Cost estimate_cost(const PlonkProtocol& pr) {

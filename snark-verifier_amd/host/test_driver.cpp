@@ -910,3 +910,28 @@ extern "C" int hd_ipa_bgh19_verify(int tkind, const uint8_t* svk_bytes, const ui
     return 1;
   });
 }
+
+// `PlonkVerifier<IpaAs<Bgh19>>::{read_proof, verify}` (verifier/plonk.rs:94-147; the reference's
+// system/halo2/test/ipa/native.rs flow): succinct verify -> IpaAccumulator -> `decide_all` (one device
+// Pippenger over the 2^k committing-key points).  acc_out (if non-null): k x xi | u.
+// Returns 1 accept, 0 reject (succinct check or decide failed), -10 Transcript, -11 InvalidInstances.
+extern "C" int hd_plonk_ipa_verify(int tkind, const uint8_t* protocol, size_t plen, const uint8_t* instances, size_t ilen,
+                                   const uint8_t* proof, size_t prlen, const uint8_t* svk_bytes, const uint8_t* g,
+                                   size_t n_g, uint8_t* acc_out, int decide) {
+  return guarded([&] {
+    PlonkProtocol pr = parse_protocol(protocol, plen);
+    IpaDecidingKey dk;
+    dk.svk = parse_ipa_svk(svk_bytes);
+    dk.g.resize(n_g);
+    for (size_t i = 0; i < n_g; ++i) dk.g[i] = G1Affine::from_bytes(g + 64 * i);
+    auto insts = parse_instances(instances, ilen);
+    auto t = make_transcript(tkind, proof, prlen);
+    auto pf = PlonkVerifier<Bgh19>::read_proof(dk, pr, insts, *t);
+    if (!pf.ok()) return error_code(pf.err);
+    auto accs = PlonkSuccinctVerifier<Bgh19>::verify(dk.svk, pr, insts, *pf.value);
+    if (!accs.ok()) return error_code(accs.err);
+    if (acc_out) put_ipa_acc((*accs.value)[0], acc_out);
+    if (!decide) return 1;
+    return PlonkVerifier<Bgh19>::verify(dk, pr, insts, *pf.value).ok() ? 1 : 0;
+  });
+}

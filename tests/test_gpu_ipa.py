@@ -178,3 +178,72 @@ def test_golden_bgh19_multiopen(H, idx):
     assert H.hd_ipa_bgh19_verify(tk, svk, pack_commitments(lin), O.fe_to_bytes(x), pack_queries(queries), proof,
                                  len(proof), out) == 1
     assert out.raw == pack_acc(exp)
+
+
+# ---- PLONK over IPA: `PlonkVerifier<IpaAs<Bgh19>>` (the reference's system/halo2/test/ipa/native.rs) ----
+def _plonk_ipa_setup(seed, k, **kw):
+    import plonk as P
+    import plonk_synth as S
+
+    rng = random.Random(seed)
+    pr, dl = S.standard_plonk_protocol(rng, k=k, **kw)
+    inst = [[rng.randrange(O.R) for _ in range(n)] for n in pr["num_instance"]]
+    kd = {"g": [rng.randrange(1, O.R) for _ in range(1 << k)], "h": rng.randrange(1, O.R), "s": rng.randrange(1, O.R)}
+    gb = b"".join(C.g1_mul(O.g1_to_bytes(O.G1_GEN), O.fe_to_bytes(c)) for c in kd["g"])
+    g = [O.g1_from_bytes(gb[64 * i:64 * i + 64]) for i in range(1 << k)]
+    h, s = O.g1_mul(O.G1_GEN, kd["h"]), O.g1_mul(O.G1_GEN, kd["s"])
+    return P, S, rng, pr, dl, inst, kd, g, gb, h, s
+
+
+def _plonk_ipa_run(H, tk, S, pr, inst, proof, svk, gb, k, decide=1):
+    H.hd_plonk_ipa_verify.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                      ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t,
+                                      ctypes.c_char_p, ctypes.c_int]
+    pb, ib = S.pack_protocol(pr), S.pack_instances(inst)
+    out = _buf(32 * k + 64)
+    rc = H.hd_plonk_ipa_verify(tk, pb, len(pb), ib, len(ib), proof, len(proof), svk, gb, len(gb) // 64, out, decide)
+    return rc, out.raw
+
+
+@pytest.mark.parametrize("kind", ["evm", "poseidon"])
+@pytest.mark.parametrize("lin", [None, "WithoutConstant", "MinusVanishingTimesQuotient"])
+def test_plonk_over_ipa_forged_proofs(H, kind, lin):
+    """Proofs forged under a committing key with known discrete logs (oracle/plonk.py
+    `forge_proof_ipa`): the C++ `PlonkSuccinctVerifier<Bgh19>` returns the oracle's accumulator bytes,
+    `PlonkVerifier<Bgh19>::verify` accepts (decide = one device MSM), any change rejects."""
+    k = 5
+    P, S, rng, pr, dl, inst, kd, g, gb, h, s = _plonk_ipa_setup("pipa-%s-%s" % (kind, lin), k, linearization=lin,
+                                                                num_instance=(2, 3))
+    tk, Tr = TR[kind]
+    proof = P.forge_proof_ipa(pr, inst, kd, Tr, rng, dl)
+    exp = P.succinct_verify_ipa(g[0], h, s, pr, inst, P.plonk_proof_read(pr, inst, Tr(proof), "bgh19"))
+    assert I.ipa_decide(g, exp[0])
+    svk = pack_svk(k, g[0], h, s)
+    rc, acc = _plonk_ipa_run(H, tk, S, pr, inst, proof, svk, gb, k)
+    assert rc == 1 and acc == pack_acc(exp[0])
+    for pos in (0, len(proof) // 2, len(proof) - 1):
+        bad = bytearray(proof)
+        bad[pos] ^= 1
+        assert _plonk_ipa_run(H, tk, S, pr, inst, bytes(bad), svk, gb, k)[0] in (0, -10)
+    inst2 = [list(x) for x in inst]
+    inst2[1][2] = (inst2[1][2] + 1) % O.R
+    assert _plonk_ipa_run(H, tk, S, pr, inst2, proof, svk, gb, k)[0] == 0
+    assert _plonk_ipa_run(H, tk, S, pr, [inst[0]], proof, svk, gb, k)[0] == -11  # InvalidInstances
+    # a committing key that differs in ONE point: the succinct check still passes (it never sees G_i, i > 0),
+    # `decide` is what catches it
+    gb2 = gb[:64 * 7] + gb[64 * 8:64 * 9] + gb[64 * 8:]
+    assert _plonk_ipa_run(H, tk, S, pr, inst, proof, svk, gb2, k, decide=0)[0] == 1
+    assert _plonk_ipa_run(H, tk, S, pr, inst, proof, svk, gb2, k, decide=1)[0] == 0
+
+
+def test_plonk_over_ipa_rejects_accumulator_indices(H):
+    """IPA has no `AccumulatorEncoding`: the reference's default (`PhantomData`, pcs.rs:173-184) is
+    `unimplemented!()`, so a protocol that declares old accumulators panics."""
+    k = 4
+    P, S, rng, pr, dl, inst, kd, g, gb, h, s = _plonk_ipa_setup(99, k, num_instance=(17,),
+                                                                accumulator_rows=[list(range(16))])
+    pr2 = dict(pr, accumulator_indices=[])
+    proof = P.forge_proof_ipa(pr2, inst, kd, T.EvmTranscript, rng, dl)
+    svk = pack_svk(k, g[0], h, s)
+    assert _plonk_ipa_run(H, 0, S, pr2, inst, proof, svk, gb, k)[0] == 1
+    assert _plonk_ipa_run(H, 0, S, pr, inst, proof, svk, gb, k)[0] == -100

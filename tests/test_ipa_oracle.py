@@ -119,3 +119,29 @@ def test_golden_bgh19_multiopen(idx):
         I.bgh19_verify(g[0], h, s, swapped, x, queries, I.bgh19_read_proof(c["k"], queries, Tr(proof)))
     with pytest.raises(T.TranscriptError):
         I.bgh19_read_proof(c["k"], queries, Tr(proof[:-7]))
+
+
+@pytest.mark.parametrize("kind", ["evm", "poseidon"])
+@pytest.mark.parametrize("lin", [None, "MinusVanishingTimesQuotient"])
+def test_plonk_over_ipa_forger_and_verifier(kind, lin):
+    """`PlonkVerifier<IpaAs<Bgh19>>` (the reference's system/halo2/test/ipa/native.rs) in the oracle:
+    a proof forged under a committing key with known discrete logs passes the succinct check AND
+    decide; a changed instance fails the succinct check."""
+    import plonk as P
+    import plonk_synth as S
+
+    rng = random.Random("%s-%s" % (kind, lin))
+    k = 4
+    pr, dl = S.standard_plonk_protocol(rng, k=k, linearization=lin, num_instance=(3,))
+    inst = [[rng.randrange(O.R) for _ in range(3)]]
+    kd = {"g": [rng.randrange(1, O.R) for _ in range(1 << k)], "h": rng.randrange(1, O.R), "s": rng.randrange(1, O.R)}
+    g = [O.g1_mul(O.G1_GEN, c) for c in kd["g"]]
+    h, s = O.g1_mul(O.G1_GEN, kd["h"]), O.g1_mul(O.G1_GEN, kd["s"])
+    proof = P.forge_proof_ipa(pr, inst, kd, TR[kind], rng, dl)
+    accs = P.succinct_verify_ipa(g[0], h, s, pr, inst, P.plonk_proof_read(pr, inst, TR[kind](proof), "bgh19"))
+    assert len(accs) == 1 and len(accs[0][0]) == k and I.ipa_decide(g, accs[0])
+    bad = [[inst[0][0], inst[0][1], (inst[0][2] + 1) % O.R]]
+    with pytest.raises(I.IpaError):
+        P.succinct_verify_ipa(g[0], h, s, pr, bad, P.plonk_proof_read(pr, bad, TR[kind](proof), "bgh19"))
+    with pytest.raises(T.TranscriptError):
+        P.plonk_proof_read(pr, inst, TR[kind](proof[:-1]), "bgh19")
