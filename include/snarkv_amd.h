@@ -179,6 +179,23 @@ int snarkv_g1_buckets_add_dev(snarkv_ctx* ctx, void* d_dst, const void* d_src, s
 int snarkv_g1_buckets_reduce_dev(snarkv_ctx* ctx, const void* d_buckets, uint32_t c, uint32_t w0, uint32_t wcount,
                                  void* d_partial);
 
+/* ---- IPA decider: `AccumulationDecider::{decide, decide_all}` for `IpaAs` --------------------
+ * reference snark-verifier/src/pcs/ipa/decider.rs:47-66:
+ *     U == multi_scalar_multiplication(h_coeffs(xi, 1), dk.g).to_affine()
+ * `snarkv_ipa_dk_create` uploads the committing key G (n = 2^k points, 64 B each: the `g` of
+ * `IpaDecidingKey`, decider.rs:5-9) once; `snarkv_ipa_decide_batch` takes m accumulators
+ * (`IpaAccumulator`, accumulator.rs:5-14: xi = k scalars of 32 B each, u = 64 B), builds h_coeffs
+ * (pcs/ipa.rs:405-421) on the device, runs one 2^k-term Pippenger per accumulator and writes
+ * ok[a] = 1 / 0 (0 is `Err(AssertionFailure("U == commit(G, h)"))`, not an error code).        */
+typedef struct snarkv_ipa_dk snarkv_ipa_dk;
+int snarkv_ipa_dk_create(snarkv_ctx* ctx, const uint8_t* g_points64, size_t n, snarkv_ipa_dk** out);
+void snarkv_ipa_dk_destroy(snarkv_ipa_dk* dk);
+uint32_t snarkv_ipa_dk_k(const snarkv_ipa_dk* dk);
+int snarkv_ipa_decide_batch(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const uint8_t* xi32, const uint8_t* u64, size_t m,
+                            uint8_t* ok);
+int bn254_ipa_dk_create(const uint8_t* g_points64, size_t n, snarkv_ipa_dk** out);
+int bn254_ipa_decide_batch(const snarkv_ipa_dk* dk, const uint8_t* xi32, const uint8_t* u64, size_t m, uint8_t* ok);
+
 /* ---- Poseidon transcripts, batched (SURVEY.md 8f row N2 on the device) ----
  * Replaces, for MANY proofs at once, the hashing of the reference's native
  * `PoseidonTranscript` (snark-verifier/src/system/halo2/transcript/halo2.rs:170-321

@@ -11,6 +11,7 @@ without the built library or without a HIP device raises.
 from ._lib import (  # noqa: F401
     Context,
     DecidingKey,
+    IpaDecidingKey,
     PoseidonSpec,
     SnarkvError,
     lib_path,
@@ -23,6 +24,7 @@ from ._lib import (  # noqa: F401
 __all__ = [
     "Context",
     "DecidingKey",
+    "IpaDecidingKey",
     "PoseidonSpec",
     "SnarkvError",
     "lib_path",

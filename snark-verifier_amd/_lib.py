@@ -78,6 +78,12 @@ _SIGNATURES = {
     "snarkv_g1_msm_fill_buckets_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "snarkv_g1_buckets_add_dev": (_int, [_vp, _vp, _vp, _sz]),
     "snarkv_g1_buckets_reduce_dev": (_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
+    "snarkv_ipa_dk_create": (_int, [_vp, _vp, _sz, ctypes.POINTER(_vp)]),
+    "snarkv_ipa_dk_destroy": (None, [_vp]),
+    "snarkv_ipa_dk_k": (_u32, [_vp]),
+    "snarkv_ipa_decide_batch": (_int, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "bn254_ipa_dk_create": (_int, [_vp, _sz, ctypes.POINTER(_vp)]),
+    "bn254_ipa_decide_batch": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "snarkv_poseidon_create": (_int, [_vp, _u32, _u32, _u32, _u32, _cp, _cp, _cp, _cp, _cp, _cp, _cp, _pp]),
     "snarkv_poseidon_destroy": (None, [_vp]),
     "snarkv_poseidon_transcript_batch": (_int, [_vp, _vp, _cp, _sz, _sz, _vp, _sz, _vp]),
@@ -155,6 +161,30 @@ class DecidingKey:
     def close(self):
         if self._h:
             self._lib.snarkv_dk_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class IpaDecidingKey:
+    """Device-resident committing key of `IpaDecidingKey` (reference pcs/ipa/decider.rs:5-9;
+    include/snarkv_amd.h `snarkv_ipa_dk_create`): `g` = 2^k points, 64 bytes each."""
+
+    def __init__(self, ctx, g):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        g = _as_bytes(g)
+        assert len(g) % 64 == 0
+        _check(self._lib.snarkv_ipa_dk_create(ctx._h, g if g else b"\x00", len(g) // 64, ctypes.byref(self._h)))
+        self.k = self._lib.snarkv_ipa_dk_k(self._h)
+
+    def close(self):
+        if self._h:
+            self._lib.snarkv_ipa_dk_destroy(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):
@@ -322,6 +352,16 @@ class Context:
 
     def buckets_reduce_dev(self, d_buckets, c, w0, wcount, d_partial):
         _check(self._lib.snarkv_g1_buckets_reduce_dev(self._h, d_buckets, c, w0, wcount, d_partial))
+
+    def ipa_decide_batch(self, dk, xi, u):
+        """`IpaAs::decide_all` semantics per accumulator (pcs/ipa/decider.rs:47-66): `xi` = m*k scalars
+        (32 bytes LE each), `u` = m points (64 bytes each) -> list of m booleans."""
+        xi, u = _as_bytes(xi), _as_bytes(u)
+        m = len(u) // 64
+        assert len(u) == 64 * m and len(xi) == 32 * dk.k * m
+        ok = ctypes.create_string_buffer(max(m, 1))
+        _check(self._lib.snarkv_ipa_decide_batch(self._h, dk._h, xi if xi else b"\x00", u if u else b"\x00", m, ok))
+        return [b != 0 for b in ok.raw[:m]]
 
     def poseidon_transcript_batch(self, spec, elems, n, seg_len):
         """n transcripts: `elems` = n*L canonical 32-byte Fr, absorbed in len(seg_len) segments with a

@@ -522,6 +522,20 @@ int bn254_poseidon_create(uint32_t t, uint32_t rate, uint32_t r_f, uint32_t r_p,
                                 sparse_col_hats, out);
 }
 
+int bn254_ipa_dk_create(const uint8_t* g_points64, size_t n, snarkv_ipa_dk** out) {
+  SNARKV_DEFAULT_CALL_LOCK();
+  snarkv_ctx* c;
+  SNARKV_TRY(default_ctx(&c));
+  return snarkv_ipa_dk_create(c, g_points64, n, out);
+}
+
+int bn254_ipa_decide_batch(const snarkv_ipa_dk* dk, const uint8_t* xi32, const uint8_t* u64, size_t m, uint8_t* ok) {
+  SNARKV_DEFAULT_CALL_LOCK();
+  snarkv_ctx* c;
+  SNARKV_TRY(default_ctx(&c));
+  return snarkv_ipa_decide_batch(c, dk, xi32, u64, m, ok);
+}
+
 int bn254_poseidon_transcript_batch(const snarkv_poseidon* ps, const uint8_t* elems, size_t n, size_t L,
                                     const uint32_t* seg_len, size_t S, uint8_t* out) {
   SNARKV_DEFAULT_CALL_LOCK();

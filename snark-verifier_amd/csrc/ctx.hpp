@@ -53,6 +53,9 @@ enum Slot {
   SLOT_TERM_CHAIN,
   SLOT_TERM_MAGS,
   SLOT_SPLIT_PARTIALS,
+  SLOT_IPA_XI,
+  SLOT_IPA_H,
+  SLOT_IPA_OUT,
   SLOT_COUNT
 };
 

@@ -1,0 +1,105 @@
+// `IpaAs::decide` on the device (reference snark-verifier/src/pcs/ipa/decider.rs:47-55):
+//     U == multi_scalar_multiplication(h_coeffs(xi, 1), dk.g).to_affine()
+// The committing key G (2^k points) is uploaded ONCE into a deciding-key object -- the
+// reference re-reads it from memory on every decide, a PCIe copy of 64 * 2^k bytes here --
+// and the 2^k coefficients of h(X) = prod_i (1 + xi_{k-1-i} X^(2^i)) (pcs/ipa.rs:405-421)
+// are produced by a kernel straight into the scalar buffer of the Pippenger, so a decide
+// moves k scalars in and 64 bytes out.
+#include <string.h>
+#include <vector>
+#include "ctx.hpp"
+#include "fr29.cuh"
+
+struct snarkv_ipa_dk {
+  int device;
+  uint32_t k;
+  void* d_points;  // 2^k x 64 B canonical affine, as the Pippenger entry point takes them
+};
+
+namespace snarkv {
+
+// coeff[j] = prod over the set bits i of j of xi[k-1-i]   (h_coeffs with scalar = 1: the
+// doubling loop `coeffs[len + j] = coeffs[j] * xi` unrolled per index).  One lane per
+// coefficient, <= k products; canonical little-endian out.
+__global__ void __launch_bounds__(256)
+    k_h_coeffs(const uint32_t* __restrict__ xi_canon, uint32_t k, uint32_t* __restrict__ out) {
+  __shared__ Fr29 sx[32];
+  if (threadIdx.x < k) sx[threadIdx.x] = fr29_from_canonical(xi_canon + 8 * (size_t)(k - 1 - threadIdx.x));
+  __syncthreads();
+  uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= (1u << k)) return;
+  Fr29 acc = fr29_one();
+#pragma unroll 1
+  for (uint32_t i = 0; i < k; ++i)
+    if ((j >> i) & 1u) acc = fr29_mul(acc, sx[i]);
+  uint32_t w[8];
+  fr29_to_canonical(acc, w);
+  uint4* o = reinterpret_cast<uint4*>(out + 8 * (size_t)j);
+  o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+}  // namespace snarkv
+
+using namespace snarkv;
+
+extern "C" {
+
+int snarkv_ipa_dk_create(snarkv_ctx* ctx, const uint8_t* g_points64, size_t n, snarkv_ipa_dk** out) {
+  if (!ctx || !g_points64 || !out) return SNARKV_ERR_ARG;
+  if (n == 0) return SNARKV_ERR_EMPTY;
+  uint32_t k = 0;
+  while (((size_t)1 << k) < n) ++k;
+  if (((size_t)1 << k) != n || k < 1 || k > 28) return SNARKV_ERR_LENGTH;  // committing keys have 2^k points
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  snarkv_ipa_dk* dk = new snarkv_ipa_dk();
+  dk->device = ctx->device;
+  dk->k = k;
+  dk->d_points = nullptr;
+  if (hipMalloc(&dk->d_points, n * 64) != hipSuccess) {
+    delete dk;
+    set_last_error("ipa_dk_create: hipMalloc of %zu bytes failed", n * 64);
+    return SNARKV_ERR_DEVICE;
+  }
+  SNARKV_HIP(hipMemcpyAsync(dk->d_points, g_points64, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  SNARKV_HIP(hipStreamSynchronize(ctx->stream));
+  *out = dk;
+  return SNARKV_OK;
+}
+
+void snarkv_ipa_dk_destroy(snarkv_ipa_dk* dk) {
+  if (!dk) return;
+  (void)hipSetDevice(dk->device);
+  if (dk->d_points) (void)hipFree(dk->d_points);
+  delete dk;
+}
+
+uint32_t snarkv_ipa_dk_k(const snarkv_ipa_dk* dk) { return dk ? dk->k : 0; }
+
+int snarkv_ipa_decide_batch(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const uint8_t* xi32, const uint8_t* u64, size_t m,
+                            uint8_t* ok) {
+  if (!ctx || !dk || !xi32 || !u64 || !ok) return SNARKV_ERR_ARG;
+  if (m == 0) return SNARKV_ERR_EMPTY;
+  if (dk->device != ctx->device) return SNARKV_ERR_ARG;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  const uint32_t k = dk->k;
+  const size_t n = (size_t)1 << k;
+  void *d_xi, *d_h, *d_out;
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_IPA_XI, m * k * 32, &d_xi));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_IPA_H, n * 32, &d_h));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_IPA_OUT, m * 64, &d_out));
+  SNARKV_HIP(hipMemcpyAsync(d_xi, xi32, m * k * 32, hipMemcpyHostToDevice, ctx->stream));
+  for (size_t a = 0; a < m; ++a) {
+    hipLaunchKernelGGL(k_h_coeffs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)d_xi + a * k * 8, k, (uint32_t*)d_h);
+    SNARKV_HIP(hipGetLastError());
+    SNARKV_TRY(launch_msm_pippenger(ctx, d_h, dk->d_points, n, 0, (uint8_t*)d_out + 64 * a, false));
+  }
+  std::vector<uint8_t> got(m * 64);
+  SNARKV_HIP(hipMemcpyAsync(got.data(), d_out, m * 64, hipMemcpyDeviceToHost, ctx->stream));
+  SNARKV_HIP(hipStreamSynchronize(ctx->stream));
+  for (size_t a = 0; a < m; ++a) ok[a] = memcmp(&got[64 * a], u64 + 64 * a, 64) == 0 ? 1 : 0;
+  return SNARKV_OK;
+}
+
+}  // extern "C"

@@ -11,16 +11,18 @@
 // `IpaAs::decide` is the reference's second consumer of the large-MSM hot path:
 // U == `util::msm::multi_scalar_multiplication(h_coeffs(xi, 1), dk.g)` with 2^k
 // terms (decider.rs:51-52) -- here ONE device Pippenger
-// (`multi_scalar_multiplication` in msm.hpp -> bn254_g1_msm_pippenger); the two
+// over the device-resident committing key (`bn254_ipa_decide_batch`: h_coeffs is
+// built by a kernel, so a decide moves k scalars in and 64 bytes out); the two
 // `evaluate(None)` of the succinct check (ipa.rs:172,177) go to the device as one
-// segmented launch.  Scalars (h_eval, the 2^k h_coeffs products, one batch
-// inversion) stay on the host, as in the reference.
+// segmented launch.  The other scalars (h_eval, one batch inversion) stay on the
+// host, as in the reference.
 //
 // The scheme is generic over `C: CurveAffine`; the reference's tests use pallas,
 // this mirror BN254 G1 -- the curve the device kernels are built for.  The prover
 // halves (`Ipa::create_proof`, `IpaAs::create_proof`) live in oracle/ipa.py only:
 // they make the test proofs and are not part of the verification path.
 #pragma once
+#include <memory>
 #include <optional>
 #include <vector>
 
@@ -209,10 +211,27 @@ struct IpaAsProof {
   }
 };
 
-// decider.rs:3-22
+// decider.rs:3-22.  The committing key is uploaded to the device once and cached (the
+// reference walks `dk.g` in host memory on every decide).
 struct IpaDecidingKey {
   IpaSuccinctVerifyingKey svk;
   std::vector<G1Affine> g;
+  snarkv_ipa_dk* handle() const {
+    if (!dk_) {
+      if (g.empty() || (g.size() & (g.size() - 1)) != 0 || g.size() != ((size_t)1 << svk.k))
+        throw Panic("IpaDecidingKey: g must hold 2^k points (reference: assert_eq!(scalars.len(), bases.len()), msm.rs:309)");
+      static_assert(sizeof(G1Affine) == 64, "G1Affine is the 64-byte wire form");
+      snarkv_ipa_dk* h = nullptr;
+      std::lock_guard<std::mutex> lock(device_mutex());
+      if (bn254_ipa_dk_create(g[0].b, g.size(), &h) != SNARKV_OK)
+        throw std::runtime_error(std::string("bn254_ipa_dk_create: ") + snarkv_last_error());
+      dk_ = std::shared_ptr<snarkv_ipa_dk>(h, [](snarkv_ipa_dk* p) { snarkv_ipa_dk_destroy(p); });
+    }
+    return dk_.get();
+  }
+
+ private:
+  mutable std::shared_ptr<snarkv_ipa_dk> dk_;
 };
 
 template <class MOS = std::monostate>
@@ -252,19 +271,28 @@ struct IpaAs {
     return Ipa::succinct_verify(vk, c, proof.z, v, proof.ipa);
   }
 
-  // decider.rs:47-55: U == commit(G, h) -- one 2^k-term MSM on the device
-  static Error decide(const IpaDecidingKey& dk, const IpaAccumulator& acc) {
-    std::vector<Fr> h = h_coeffs(acc.xi, Fr::one());
-    G1Affine c = multi_scalar_multiplication(h, dk.g);
-    return acc.u == c ? Error{} : Error::assertion("U == commit(G, h)");
-  }
+  // decider.rs:47-55: U == commit(G, h).  h_coeffs (ipa.rs:405-421) is built on the device straight
+  // into the scalar buffer of ONE 2^k-term Pippenger over the resident committing key.
+  static Error decide(const IpaDecidingKey& dk, const IpaAccumulator& acc) { return decide_all(dk, {acc}); }
 
-  // decider.rs:57-66: every accumulator must pass (the reference stops at the first failure)
+  // decider.rs:57-66: every accumulator must pass (same verdict as the reference's early exit)
   static Error decide_all(const IpaDecidingKey& dk, const std::vector<IpaAccumulator>& accs) {
-    for (auto& a : accs) {
-      Error e = decide(dk, a);
-      if (!e.ok()) return e;
+    if (accs.empty()) return Error{};
+    const size_t k = dk.svk.k;
+    std::vector<uint8_t> xi(accs.size() * k * 32), u(accs.size() * 64), ok(accs.size());
+    for (size_t a = 0; a < accs.size(); ++a) {
+      if (accs[a].xi.empty()) throw Panic("h_coeffs of no challenges (reference: assert!, ipa.rs:406)");
+      if (accs[a].xi.size() != k)
+        throw Panic("IpaAccumulator with xi.len() != k (reference: assert_eq!(scalars.len(), bases.len()), msm.rs:309)");
+      for (size_t j = 0; j < k; ++j) accs[a].xi[j].to_bytes(&xi[(a * k + j) * 32]);
+      memcpy(&u[64 * a], accs[a].u.b, 64);
     }
+    snarkv_ipa_dk* h = dk.handle();
+    std::lock_guard<std::mutex> lock(device_mutex());
+    int rc = bn254_ipa_decide_batch(h, xi.data(), u.data(), accs.size(), ok.data());
+    if (rc != SNARKV_OK) throw std::runtime_error(std::string("bn254_ipa_decide_batch: ") + snarkv_last_error());
+    for (uint8_t b : ok)
+      if (!b) return Error::assertion("U == commit(G, h)");
     return Error{};
   }
 };

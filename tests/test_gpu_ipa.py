@@ -247,3 +247,64 @@ def test_plonk_over_ipa_rejects_accumulator_indices(H):
     svk = pack_svk(k, g[0], h, s)
     assert _plonk_ipa_run(H, 0, S, pr2, inst, proof, svk, gb, k)[0] == 1
     assert _plonk_ipa_run(H, 0, S, pr, inst, proof, svk, gb, k)[0] == -100
+
+
+# ---- the C-ABI decider itself (include/snarkv_amd.h `snarkv_ipa_*`) -----------------------------
+def test_c_abi_ipa_decide_batch_against_the_oracle(gpu_ctx):
+    import snark_verifier_amd as sv
+
+    rnd = random.Random(21)
+    for k in (1, 2, 7, 12):
+        n = 1 << k
+        gb = C.sample_points(900 + k, n)
+        dk = sv.IpaDecidingKey(gpu_ctx, gb)
+        assert dk.k == k
+        xis, us, want = [], [], []
+        for a in range(5):
+            xi = [rnd.randrange(O.R) for _ in range(k)]
+            if a == 3:
+                xi[0] = 0  # a zero challenge: half of h_coeffs vanish (zero scalars in the MSM)
+            hb = b"".join(O.fe_to_bytes(c) for c in I.h_coeffs(xi, 1))
+            u = C.msm_pippenger(hb, gb, 4)
+            good = a != 1
+            if not good:
+                u = C.g1_add(u, gb[:64])
+            xis.append(b"".join(O.fe_to_bytes(x) for x in xi))
+            us.append(u)
+            want.append(good)
+        assert gpu_ctx.ipa_decide_batch(dk, b"".join(xis), b"".join(us)) == want
+        dk.close()
+
+
+def test_c_abi_ipa_error_codes(gpu_ctx):
+    import snark_verifier_amd as sv
+
+    gb = C.sample_points(5, 8)
+    with pytest.raises(sv.SnarkvError):
+        sv.IpaDecidingKey(gpu_ctx, gb[:64 * 6])  # not a power of two
+    with pytest.raises(sv.SnarkvError):
+        sv.IpaDecidingKey(gpu_ctx, b"")          # empty
+    dk = sv.IpaDecidingKey(gpu_ctx, gb)
+    with pytest.raises(sv.SnarkvError):
+        gpu_ctx.ipa_decide_batch(dk, b"", b"")   # m = 0
+
+
+def test_c_abi_ipa_decide_2p20_resident_key(gpu_ctx):
+    """k = 20: the committing key stays on the device, a decide uploads 20 scalars.  Checked through
+    the homomorphism instead of a CPU MSM of 2^20 terms: with G' = (G, G) (the key repeated),
+    commit_{G'}(h(xi_1..xi_k)) = (1 + xi_1) * commit_G(h(xi_2..xi_k))."""
+    import snark_verifier_amd as sv
+
+    k = 19
+    n = 1 << k
+    gb = C.sample_points(31337, n)
+    rnd = random.Random(4)
+    xi = [rnd.randrange(O.R) for _ in range(k)]
+    hb = b"".join(O.fe_to_bytes(c) for c in I.h_coeffs(xi, 1))
+    out = gpu_ctx.msm_pippenger(hb, gb)
+    x0 = rnd.randrange(O.R)
+    u2 = C.g1_mul(out, O.fe_to_bytes((1 + x0) % O.R))
+    dk2 = sv.IpaDecidingKey(gpu_ctx, gb + gb)
+    assert dk2.k == k + 1
+    xi2 = b"".join(O.fe_to_bytes(x) for x in [x0] + xi)
+    assert gpu_ctx.ipa_decide_batch(dk2, xi2 + xi2, u2 + out) == [True, False]
