@@ -135,6 +135,21 @@ def secondary_metrics(sv, torch, ctxs, cpu=True):
         out["decide_all_%d" % m] = {"ms": ms, "decides_per_s": m / ms * 1e3, "all_accept": bool(oks[:m].cpu().all())}
     for d in dks:
         d.close()
+    # `IpaAs::decide` (pcs/ipa/decider.rs:47-55) at k = 20: the other consumer of the 2^20-point MSM --
+    # committing key resident on the device, h_coeffs built by a kernel, 20 scalars in / 64 bytes out
+    k = 20
+    gpts = torch.empty(64 << k, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.sample_points_dev(0x5EED0005, 1 << k, gpts.data_ptr())
+    ctx.sync()
+    ipa_dk = sv.IpaDecidingKey(ctx, bytes(gpts.cpu().numpy()))
+    xi = b"".join((0x1234567 * (i + 3)).to_bytes(32, "little") for i in range(k))
+    u = bytes(64)
+    ms = t_ms(lambda: ctx.ipa_decide_batch(ipa_dk, xi, u), reps=5, warm=2)
+    out["ipa_decide_k20"] = {"ms": ms, "terms": 1 << k, "bytes_in": 32 * k + 64,
+                             "note": "h_coeffs kernel + one 2^20-term Pippenger over the resident committing key"}
+    ipa_dk.close()
+    del gpts
     return out
 
 

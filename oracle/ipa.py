@@ -26,6 +26,17 @@ h_eval(xi, z) must equal the evaluation at z of the polynomial h_coeffs(xi, 1).
 import bn254 as O
 
 R = O.R
+_FAST = True  # the C restatement (oracle/c) is BN254 only
+
+
+def use_curve(mod):
+    """Run the curve-generic part (everything above the Bgh19 section) on another curve module with
+    the interface of `oracle/bn254.py` -- `oracle/pallas.py`, the curve of the reference's own IPA
+    tests.  `use_curve(bn254)` switches back."""
+    global O, R, _FAST
+    O, R = mod, mod.R
+    _FAST = mod.__name__ == "bn254"
+
 
 
 def _inv(a):
@@ -67,6 +78,8 @@ def h_coeffs(xi, scalar=1):
 def _msm(scalars, points):
     """`util::msm::multi_scalar_multiplication`; the C restatement when it is built (much faster)."""
     assert len(scalars) == len(points) and len(scalars) > 0
+    if not _FAST:
+        return O.g1_msm_pippenger([s % R for s in scalars], points)
     try:
         import coracle as C
 
@@ -78,6 +91,8 @@ def _msm(scalars, points):
 
 
 def _mul(pt, k):
+    if not _FAST:
+        return O.g1_mul(pt, k % R)
     try:
         import coracle as C
 

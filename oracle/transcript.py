@@ -450,3 +450,71 @@ def poseidon_transcript_challenges(elems, seg_len, t=5, rate=4, r_f=8, r_p=60):
         pos += n
         out.append(p.squeeze())
     return out
+
+
+# ---------------------------------------------------------------------------
+# halo2's Blake2b transcript (`halo2_proofs::transcript::{Blake2bRead, Blake2bWrite}` with
+# `Challenge255`), the one the reference's IPA tests use on pallas (pcs/ipa.rs:438-440,
+# pcs/ipa/accumulation.rs:244-247, system/halo2/test/ipa/native.rs:11-12).  External crate, not in
+# /root/reference: restated from its published definition -- BLAKE2b-512 personalised
+# "Halo2-Transcript"; prefix byte 0 before a challenge, 1 before a point (x, y as 32-byte LE), 2 before
+# a scalar; a challenge is the 64-byte digest of a COPY of the state, read little-endian and reduced
+# mod r (`from_uniform_bytes`); points travel compressed (x with the parity of y in bit 255).
+# PARITY UNPINNED.  Curve-generic: `curve` is a module like oracle/bn254.py or oracle/pallas.py.
+# ---------------------------------------------------------------------------
+class Blake2bTranscript:
+    def __init__(self, curve, stream=b""):
+        import hashlib
+
+        self.c = curve
+        self.state = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")
+        self.stream = bytearray(stream)
+        self.pos = 0
+
+    def squeeze_challenge(self):
+        self.state.update(b"\x00")
+        return int.from_bytes(self.state.copy().digest(), "little") % self.c.R
+
+    def common_ec_point(self, pt):
+        if pt is None:
+            raise TranscriptError("cannot write points at infinity to the transcript")
+        self.state.update(b"\x01" + self.c.fe_to_bytes(pt[0]) + self.c.fe_to_bytes(pt[1]))
+
+    def common_scalar(self, s):
+        self.state.update(b"\x02" + self.c.fe_to_bytes(s % self.c.R))
+
+    def _read(self, n):
+        if self.pos + n > len(self.stream):
+            raise TranscriptError("failed to fill whole buffer")
+        b = bytes(self.stream[self.pos:self.pos + n])
+        self.pos += n
+        return b
+
+    def read_scalar(self):
+        v = int.from_bytes(self._read(32), "little")
+        if v >= self.c.R:
+            raise TranscriptError("invalid field element encoding in proof")
+        self.common_scalar(v)
+        return v
+
+    def read_ec_point(self):
+        raw = int.from_bytes(self._read(32), "little")
+        sign, x = raw >> 255, raw & ((1 << 255) - 1)
+        y = self.c.fq_sqrt(x * x * x + self.c.B1) if x < self.c.P else None
+        if y is None or (x == 0 and sign == 0):
+            raise TranscriptError("invalid point encoding in proof")
+        if y & 1 != sign:
+            y = self.c.P - y
+        self.common_ec_point((x, y))
+        return (x, y)
+
+    def write_ec_point(self, pt):
+        self.common_ec_point(pt)
+        self.stream += (pt[0] | ((pt[1] & 1) << 255)).to_bytes(32, "little")
+
+    def write_scalar(self, s):
+        self.common_scalar(s)
+        self.stream += self.c.fe_to_bytes(s % self.c.R)
+
+    def finalize(self):
+        return bytes(self.stream)

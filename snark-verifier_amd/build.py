@@ -20,22 +20,23 @@ FLAGS += os.environ.get("SNARKV_EXTRA_FLAGS", "").split()
 
 
 def _deps():
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".hpp", ".h"))]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".hpp", ".h", ".inc"))]
     hdrs.append(os.path.join(HERE, "..", "include", "snarkv_amd.h"))
+    hdrs.append(os.path.join(HERE, "..", "include", "snarkv_pallas.h"))
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def _compile(unit, verbose):
+def _compile(unit, verbose, extra=(), tag=""):
     src = os.path.join(CSRC, unit + ".hip")
-    obj = os.path.join(BUILD, unit + ".o")
+    obj = os.path.join(BUILD, unit + tag + ".o")
     newest = max(os.path.getmtime(src), _deps())
     if os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-c", src, "-o", obj]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)
-    with open(os.path.join(BUILD, unit + ".log"), "w") as f:
+    with open(os.path.join(BUILD, unit + tag + ".log"), "w") as f:
         f.write(r.stdout + r.stderr)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
@@ -54,8 +55,29 @@ def build(verbose=False):
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)
             raise RuntimeError("link failed")
+    build_pallas(verbose)
     build_host_driver()
     return LIB
+
+
+# The pasta build of the curve-generic units (csrc/pallas.hip explains the three flags).
+PALLAS_UNITS = ["pallas", "msm_pippenger", "ipa"]
+PALLAS_FLAGS = ["-DSNARKV_CURVE_PALLAS", "-DSNARKV_GLV=0", "-Dsnarkv=snarkv_pallas"]
+PALLAS_LIB = os.path.join(HERE, "libsnarkv_pallas.so")
+
+
+def build_pallas(verbose=False):
+    os.makedirs(BUILD, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=len(PALLAS_UNITS)) as ex:
+        res = list(ex.map(lambda u: _compile(u, verbose, PALLAS_FLAGS, "_pallas"), PALLAS_UNITS))
+    if any(ch for _, ch in res) or not os.path.exists(PALLAS_LIB):
+        # -Bsymbolic: the two libraries share extern-"C"-free internals by design, never by symbol lookup
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", PALLAS_LIB] + [o for o, _ in res]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("link failed (pallas)")
+    return PALLAS_LIB
 
 
 HOST = os.path.join(HERE, "host")

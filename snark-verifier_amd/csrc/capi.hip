@@ -8,34 +8,9 @@
 #include <stdlib.h>
 #include "ctx.hpp"
 
+#include "ctx_impl.inc"
+
 namespace snarkv {
-
-static thread_local char g_err[512] = "";
-
-void set_last_error(const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-}
-
-int ctx_reserve(snarkv_ctx* ctx, int slot, size_t bytes, void** out) {
-  if (bytes == 0) bytes = 16;
-  if (ctx->cap[slot] < bytes) {
-    if (ctx->buf[slot]) {
-      // earlier launches on the stream may still use the old buffer
-      SNARKV_HIP(hipStreamSynchronize(ctx->stream));
-      SNARKV_HIP(hipFree(ctx->buf[slot]));
-      ctx->buf[slot] = nullptr;
-      ctx->cap[slot] = 0;
-    }
-    size_t cap = bytes + bytes / 8 + 256;
-    SNARKV_HIP(hipMalloc(&ctx->buf[slot], cap));
-    ctx->cap[slot] = cap;
-  }
-  *out = ctx->buf[slot];
-  return SNARKV_OK;
-}
 
 static int stage_in(snarkv_ctx* ctx, int slot, const void* host, size_t bytes, void** d) {
   SNARKV_TRY(ctx_reserve(ctx, slot, bytes, d));
@@ -71,59 +46,6 @@ static int default_ctx(snarkv_ctx** out) {
 using namespace snarkv;
 
 extern "C" {
-
-const char* snarkv_last_error(void) { return g_err; }
-const char* snarkv_version(void) { return "snarkv_amd 0.1 (gfx950)"; }
-
-int snarkv_ctx_create(int device, void* hip_stream, snarkv_ctx** out) {
-  if (!out) return SNARKV_ERR_ARG;
-  int count = 0;
-  SNARKV_HIP(hipGetDeviceCount(&count));
-  if (count <= 0 || device < 0 || device >= count) {
-    set_last_error("no HIP device %d (count=%d): the MI355X path has no CPU fallback", device, count);
-    return SNARKV_ERR_DEVICE;
-  }
-  SNARKV_HIP(hipSetDevice(device));
-  snarkv_ctx* c = new snarkv_ctx();
-  memset(c, 0, sizeof(*c));
-  c->device = device;
-  if (hip_stream) {
-    c->stream = (hipStream_t)hip_stream;
-    c->own_stream = false;
-  } else {
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-      set_last_error("hipStreamCreate: %s", hipGetErrorString(e));
-      delete c;
-      return SNARKV_ERR_DEVICE;
-    }
-    c->own_stream = true;
-  }
-  *out = c;
-  return SNARKV_OK;
-}
-
-void snarkv_ctx_destroy(snarkv_ctx* ctx) {
-  if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
-  for (int i = 0; i < SLOT_COUNT; ++i)
-    if (ctx->buf[i]) (void)hipFree(ctx->buf[i]);
-  if (ctx->ev_ready)
-    for (int i = 0; i <= SNARKV_PIP_STAGES; ++i) (void)hipEventDestroy(ctx->ev[i]);
-  if (ctx->sub_ready) {
-    for (int i = 0; i < 3; ++i) snarkv_ctx_destroy(ctx->sub[i]);
-    for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ctx->sub_ev[i]);
-  }
-  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
-  delete ctx;
-}
-
-int snarkv_ctx_sync(snarkv_ctx* ctx) {
-  if (!ctx) return SNARKV_ERR_ARG;
-  SNARKV_HIP(hipStreamSynchronize(ctx->stream));
-  return SNARKV_OK;
-}
 
 int snarkv_set_stage_timing(snarkv_ctx* ctx, int enabled) {
   if (!ctx) return SNARKV_ERR_ARG;
@@ -300,7 +222,9 @@ int snarkv_g1_buckets_reduce_dev(snarkv_ctx* ctx, const void* d_buckets, uint32_
                                  void* d_partial) {
   if (!ctx || !d_buckets || !d_partial || c < 2 || c > 22) return SNARKV_ERR_ARG;
   if (wcount == 0) return SNARKV_ERR_EMPTY;
-  if ((uint64_t)w0 + wcount > (128 + c - 1) / c) return SNARKV_ERR_LENGTH;
+  uint32_t cc, windows, bpw;
+  SNARKV_TRY(pip_geometry(1, (int)c, &cc, &windows, &bpw));
+  if ((uint64_t)w0 + wcount > windows) return SNARKV_ERR_LENGTH;
   SNARKV_HIP(hipSetDevice(ctx->device));
   return launch_buckets_reduce(ctx, d_buckets, c, w0, wcount, d_partial);
 }

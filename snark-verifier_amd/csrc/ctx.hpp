@@ -5,6 +5,14 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/snarkv_amd.h"
+#include "curve_consts.h"
+
+// extern "C" names of the units shared between the BN254 library and the pasta build
+#if defined(SNARKV_CURVE_PALLAS)
+#define SNARKV_API(name) snarkv_pallas_##name
+#else
+#define SNARKV_API(name) snarkv_##name
+#endif
 
 namespace snarkv {
 

@@ -12,7 +12,7 @@
 // GPU).  Values are always fully reduced to [0, p).
 #pragma once
 #include <stdint.h>
-#include "bn254_consts.h"
+#include "curve_consts.h"
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -31,7 +31,7 @@ struct Fq {
 
 // Inline-constant tables (the compiler folds these into literals / s_mov).
 SNARKV_HD constexpr uint32_t fq_p(int i) {
-  constexpr uint32_t p[8] = BN254_P_LIMBS;
+  constexpr uint32_t p[8] = SNARKV_FQ_P_LIMBS;
   return p[i];
 }
 
@@ -43,7 +43,7 @@ SNARKV_HD Fq fq_zero() {
 }
 
 SNARKV_HD Fq fq_one() {
-  constexpr uint32_t c[8] = BN254_ONE_MONT;
+  constexpr uint32_t c[8] = SNARKV_FQ_ONE_MONT;
   Fq r;
 #pragma unroll
   for (int i = 0; i < 8; ++i) r.v[i] = c[i];
@@ -132,7 +132,7 @@ SNARKV_HD Fq fq_mul_portable(const Fq& a, const Fq& b) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     uint64_t A = (uint64_t)a.v[i] * b.v[0] + t[0];
-    uint32_t m = (uint32_t)A * BN254_P_INV32;
+    uint32_t m = (uint32_t)A * SNARKV_FQ_P_INV32;
     uint64_t C = (uint64_t)m * fq_p(0) + (uint32_t)A;
 #pragma unroll
     for (int j = 1; j < 8; ++j) {
@@ -174,7 +174,7 @@ SNARKV_HD Fq fq_sqr(const Fq& a) { return fq_mul(a, a); }
 
 // canonical 32-byte little-endian  <->  Montgomery
 SNARKV_HD Fq fq_from_canonical(const uint32_t w[8]) {
-  constexpr uint32_t r2[8] = BN254_R2_MONT;
+  constexpr uint32_t r2[8] = SNARKV_FQ_R2_MONT;
   Fq a, b;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -220,7 +220,7 @@ SNARKV_HD_NOINLINE Fq fq_pow(const Fq& a, const uint32_t* e) {
 // a^(p-2): Fermat inversion, fixed (lane-uniform) exponent.  inv(0) = 0.
 // Not inlined: one copy per kernel keeps code size in check.
 SNARKV_HD_NOINLINE Fq fq_inv(const Fq& a) {
-  constexpr uint32_t e[8] = BN254_P_MINUS_2_LIMBS;
+  constexpr uint32_t e[8] = SNARKV_FQ_P_MINUS_2_LIMBS;
   Fq res = fq_one();
   for (int i = 7; i >= 0; --i) {
     uint32_t w = e[i];

@@ -37,11 +37,11 @@ struct Fq29 {
 
 constexpr int32_t kMask29 = (1 << 29) - 1;
 
-// radix-2^29 constants (BN254_P29_LIMBS, BN254_P29_NINV, BN254_ONE29_LIMBS,
-// BN254_R2_29_LIMBS) come from bn254_consts.h (gen_consts.py).
+// radix-2^29 constants (SNARKV_FQ29_P_LIMBS, SNARKV_FQ29_NINV, SNARKV_FQ29_ONE_LIMBS,
+// SNARKV_FQ29_R2_LIMBS) come from bn254_consts.h (gen_consts.py).
 
 SNARKV_HD int32_t fq29_p(int i) {
-  constexpr int32_t p[9] = BN254_P29_LIMBS;
+  constexpr int32_t p[9] = SNARKV_FQ29_P_LIMBS;
   return p[i];
 }
 
@@ -53,7 +53,7 @@ SNARKV_HD Fq29 fq29_zero() {
 }
 
 SNARKV_HD Fq29 fq29_one() {
-  constexpr int32_t c[9] = BN254_ONE29_LIMBS;
+  constexpr int32_t c[9] = SNARKV_FQ29_ONE_LIMBS;
   Fq29 r;
 #pragma unroll
   for (int i = 0; i < 9; ++i) r.v[i] = c[i];
@@ -123,7 +123,7 @@ SNARKV_HD Fq29 fq29_mul(const Fq29& a, const Fq29& b) {
     for (int i = 0; i <= k; ++i) acc += (int64_t)a.v[i] * b.v[k - i];
 #pragma unroll
     for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * fq29_p(k - i);
-    m[k] = (int32_t)(((uint32_t)acc * (uint32_t)BN254_P29_NINV) & (uint32_t)kMask29);
+    m[k] = (int32_t)(((uint32_t)acc * (uint32_t)SNARKV_FQ29_NINV) & (uint32_t)kMask29);
     acc += (int64_t)m[k] * fq29_p(0);
     acc >>= 29;  // low 29 bits are zero
   }
@@ -156,7 +156,7 @@ SNARKV_HD Fq29 fq29_mul2(const Fq29& a, const Fq29& b, const Fq29& c, const Fq29
     for (int i = 0; i <= k; ++i) acc += (int64_t)c.v[i] * d.v[k - i];
 #pragma unroll
     for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * fq29_p(k - i);
-    m[k] = (int32_t)(((uint32_t)acc * (uint32_t)BN254_P29_NINV) & (uint32_t)kMask29);
+    m[k] = (int32_t)(((uint32_t)acc * (uint32_t)SNARKV_FQ29_NINV) & (uint32_t)kMask29);
     acc += (int64_t)m[k] * fq29_p(0);
     acc >>= 29;
   }
@@ -189,7 +189,7 @@ SNARKV_HD Fq29 fq29_sqr(const Fq29& a) {
     if ((k & 1) == 0) acc += (int64_t)a.v[k / 2] * a.v[k / 2];
 #pragma unroll
     for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * fq29_p(k - i);
-    m[k] = (int32_t)(((uint32_t)acc * (uint32_t)BN254_P29_NINV) & (uint32_t)kMask29);
+    m[k] = (int32_t)(((uint32_t)acc * (uint32_t)SNARKV_FQ29_NINV) & (uint32_t)kMask29);
     acc += (int64_t)m[k] * fq29_p(0);
     acc >>= 29;
   }
@@ -248,7 +248,7 @@ SNARKV_HD Fq29 fq29_from_canonical(const uint32_t w[8]) {
     if (word + 1 < 8) v |= (uint64_t)w[word + 1] << 32;
     a.v[i] = (int32_t)((uint32_t)(v >> sh) & (uint32_t)kMask29);
   }
-  constexpr int32_t r2[9] = BN254_R2_29_LIMBS;
+  constexpr int32_t r2[9] = SNARKV_FQ29_R2_LIMBS;
   Fq29 b;
 #pragma unroll
   for (int i = 0; i < 9; ++i) b.v[i] = r2[i];
@@ -294,7 +294,7 @@ SNARKV_HD void fq29_to_canonical(const Fq29& a, uint32_t w[8]) {
 // Result carry-normalised.  (Cheap modular squeeze after a lazy sum of many
 // products; one float multiply, nine 64-bit mads.)
 SNARKV_HD Fq29 fq29_reduce_small(const Fq29& x) {
-  const float inv_ptop = 1.0f / (float)(0x0030644e);  // p >> 232
+  const float inv_ptop = 1.0f / (float)fq29_p(8);  // p >> 232
   float qf = (float)x.v[8] * inv_ptop;
   int32_t q = (int32_t)(qf + (qf >= 0 ? 0.5f : -0.5f));
   Fq29 r;
@@ -326,7 +326,7 @@ SNARKV_HD Fq29 fq29_mul_small_norm(const Fq29& x, int32_t k) {
 // a^(p-2) (lane-uniform exponent); a must be carry-normalised, result too.
 // Kept as the independent cross-check of fq29_inv (tests/hosttest).
 SNARKV_HD_NOINLINE Fq29 fq29_inv_fermat(const Fq29& a) {
-  constexpr uint32_t e[8] = BN254_P_MINUS_2_LIMBS;
+  constexpr uint32_t e[8] = SNARKV_FQ_P_MINUS_2_LIMBS;
   Fq29 res = fq29_one();
   for (int i = 7; i >= 0; --i) {
     uint32_t w = e[i];
@@ -367,7 +367,7 @@ SNARKV_HD uint32_t u256_sub(U256w& a, const U256w& b) {
 
 // a += (p & mask)
 SNARKV_HD void u256_add_p_masked(U256w& a, uint32_t mask) {
-  constexpr uint32_t pl[8] = BN254_P_LIMBS;
+  constexpr uint32_t pl[8] = SNARKV_FQ_P_LIMBS;
   uint64_t c = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -398,7 +398,7 @@ SNARKV_HD void u256_sub_mod_p(U256w& x, const U256w& y) {
 
 // a^-1 mod p for a in [1, p); 0 for a = 0.  Plain integers in, plain integer out.
 SNARKV_HD_NOINLINE void fq_words_inv_binary(const uint32_t a[8], uint32_t out[8]) {
-  constexpr uint32_t pl[8] = BN254_P_LIMBS;
+  constexpr uint32_t pl[8] = SNARKV_FQ_P_LIMBS;
   U256w u, v, x1, x2;
   uint32_t nz = 0;
 #pragma unroll
@@ -451,7 +451,7 @@ struct S30 {
 constexpr int32_t kMask30 = (1 << 30) - 1;
 
 SNARKV_HD S30 s30_modulus() {
-  constexpr uint32_t pl[8] = BN254_P_LIMBS;
+  constexpr uint32_t pl[8] = SNARKV_FQ_P_LIMBS;
   S30 m;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
@@ -465,7 +465,7 @@ SNARKV_HD S30 s30_modulus() {
 
 // p^-1 mod 2^30 (Newton on the low word)
 SNARKV_HD uint32_t s30_modulus_inv30() {
-  constexpr uint32_t pl[8] = BN254_P_LIMBS;
+  constexpr uint32_t pl[8] = SNARKV_FQ_P_LIMBS;
   uint32_t x = pl[0];  // correct to 3 bits for odd p
 #pragma unroll
   for (int i = 0; i < 5; ++i) x *= 2u - pl[0] * x;

@@ -12,7 +12,7 @@ struct Fr29 {
 };
 
 SNARKV_HD int32_t fr29_r(int i) {
-  constexpr int32_t rl[9] = BN254_FR29_LIMBS;
+  constexpr int32_t rl[9] = SNARKV_FR29_P_LIMBS;
   return rl[i];
 }
 SNARKV_HD Fr29 fr29_zero() {
@@ -22,7 +22,7 @@ SNARKV_HD Fr29 fr29_zero() {
   return r;
 }
 SNARKV_HD Fr29 fr29_one() {
-  constexpr int32_t o[9] = BN254_FR29_ONE_LIMBS;
+  constexpr int32_t o[9] = SNARKV_FR29_ONE_LIMBS;
   Fr29 r;
 #pragma unroll
   for (int i = 0; i < 9; ++i) r.v[i] = o[i];
@@ -59,7 +59,7 @@ SNARKV_HD Fr29 fr29_mul(const Fr29& a, const Fr29& b) {
     for (int i = 0; i <= k; ++i) acc += (int64_t)a.v[i] * b.v[k - i];
 #pragma unroll
     for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * fr29_r(k - i);
-    m[k] = (int32_t)(((uint32_t)acc * (uint32_t)BN254_FR29_NINV) & (uint32_t)kMask29);
+    m[k] = (int32_t)(((uint32_t)acc * (uint32_t)SNARKV_FR29_NINV) & (uint32_t)kMask29);
     acc += (int64_t)m[k] * fr29_r(0);
     acc >>= 29;
   }
@@ -114,7 +114,7 @@ SNARKV_HD Fr29 fr29_from_canonical(const uint32_t w[8]) {
     if (word + 1 < 8) v |= (uint64_t)w[word + 1] << 32;
     a.v[i] = (int32_t)((uint32_t)(v >> sh) & (uint32_t)kMask29);
   }
-  constexpr int32_t r2[9] = BN254_FR29_R2_LIMBS;
+  constexpr int32_t r2[9] = SNARKV_FR29_R2_LIMBS;
   Fr29 b;
 #pragma unroll
   for (int i = 0; i < 9; ++i) b.v[i] = r2[i];

@@ -171,7 +171,7 @@ SNARKV_HD G1Affine xyzz_to_affine(const G1Xyzz& p) {
 // y^2 == x^3 + 3 (Montgomery domain); the identity (0,0) is accepted.
 SNARKV_HD bool g1a_is_on_curve(const G1Affine& p) {
   if (g1a_is_identity(p)) return true;
-  constexpr uint32_t three[8] = BN254_THREE_MONT;
+  constexpr uint32_t three[8] = SNARKV_G1_B_MONT;
   Fq b;
 #pragma unroll
   for (int i = 0; i < 8; ++i) b.v[i] = three[i];

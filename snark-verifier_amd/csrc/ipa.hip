@@ -45,7 +45,7 @@ using namespace snarkv;
 
 extern "C" {
 
-int snarkv_ipa_dk_create(snarkv_ctx* ctx, const uint8_t* g_points64, size_t n, snarkv_ipa_dk** out) {
+int SNARKV_API(ipa_dk_create)(snarkv_ctx* ctx, const uint8_t* g_points64, size_t n, snarkv_ipa_dk** out) {
   if (!ctx || !g_points64 || !out) return SNARKV_ERR_ARG;
   if (n == 0) return SNARKV_ERR_EMPTY;
   uint32_t k = 0;
@@ -67,16 +67,16 @@ int snarkv_ipa_dk_create(snarkv_ctx* ctx, const uint8_t* g_points64, size_t n, s
   return SNARKV_OK;
 }
 
-void snarkv_ipa_dk_destroy(snarkv_ipa_dk* dk) {
+void SNARKV_API(ipa_dk_destroy)(snarkv_ipa_dk* dk) {
   if (!dk) return;
   (void)hipSetDevice(dk->device);
   if (dk->d_points) (void)hipFree(dk->d_points);
   delete dk;
 }
 
-uint32_t snarkv_ipa_dk_k(const snarkv_ipa_dk* dk) { return dk ? dk->k : 0; }
+uint32_t SNARKV_API(ipa_dk_k)(const snarkv_ipa_dk* dk) { return dk ? dk->k : 0; }
 
-int snarkv_ipa_decide_batch(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const uint8_t* xi32, const uint8_t* u64, size_t m,
+int SNARKV_API(ipa_decide_batch)(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const uint8_t* xi32, const uint8_t* u64, size_t m,
                             uint8_t* ok) {
   if (!ctx || !dk || !xi32 || !u64 || !ok) return SNARKV_ERR_ARG;
   if (m == 0) return SNARKV_ERR_EMPTY;

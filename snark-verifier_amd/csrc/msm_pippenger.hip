@@ -50,7 +50,12 @@
 #include <mutex>
 #include "ctx.hpp"
 #include "g1_29.cuh"
+#ifndef SNARKV_GLV
+#define SNARKV_GLV 1  // 0: curves without the BN-shaped GLV lattice (the pasta build): one virtual point per point
+#endif
+#if SNARKV_GLV
 #include "glv.cuh"
+#endif
 
 namespace snarkv {
 
@@ -66,6 +71,9 @@ namespace snarkv {
 #ifndef SNARKV_ACC_WAVES
 #define SNARKV_ACC_WAVES 3
 #endif
+constexpr int kHalves = SNARKV_GLV ? 2 : 1;       // virtual points per input point: P and phi(P), or P alone
+constexpr int kDigitWords = SNARKV_GLV ? 4 : 8;   // words of a digit source: a 127-bit GLV half / the 255-bit scalar
+constexpr int kDigitBits = 32 * kDigitWords;      // W * c covers this: magnitude bits + the recoding carry
 constexpr int kRun = SNARKV_KRUN;      // P4: entries per lane
 constexpr int kChunk = SNARKV_KCHUNK;  // P6: buckets per lane
 constexpr uint32_t kSortCap = 7168;     // S4: items a workgroup sorts entirely in LDS (56 KiB of the 64 KiB dynamic limit)
@@ -90,12 +98,16 @@ struct PipParams {
   uint32_t w0;       // index of the first window held (bucket-sharded reduce of a window range; 0 otherwise)
 };
 
-// c bits at offset lo of a 128-bit magnitude held in 4 registers
-__device__ __forceinline__ uint32_t half_bits(const uint32_t k[4], int lo, int c) {
-  if (lo >= 128) return 0;
+// c bits at offset lo of a kDigitBits-bit magnitude held in registers (selects, no dynamic indexing)
+__device__ __forceinline__ uint32_t half_bits(const uint32_t (&k)[kDigitWords], int lo, int c) {
+  if (lo >= kDigitBits) return 0;
   int word = lo >> 5, sh = lo & 31;
-  uint32_t w0 = word == 0 ? k[0] : word == 1 ? k[1] : word == 2 ? k[2] : k[3];
-  uint32_t w1 = word == 0 ? k[1] : word == 1 ? k[2] : word == 2 ? k[3] : 0u;
+  uint32_t w0 = 0u, w1 = 0u;
+#pragma unroll
+  for (int i = 0; i < kDigitWords; ++i) {
+    w0 = word == i ? k[i] : w0;
+    if (i > 0) w1 = word == i - 1 ? k[i] : w1;
+  }
   uint64_t v = ((uint64_t)w1 << 32) | w0;
   return (uint32_t)(v >> sh) & ((1u << c) - 1u);
 }
@@ -106,9 +118,7 @@ __device__ __forceinline__ uint32_t half_bits(const uint32_t k[4], int lo, int c
 // With W*c >= 128 the top window never carries out.  A negative half (sign in
 // bit 127) flips every digit's sign.  `emit(key, bucket, neg)` per non-zero digit.
 template <class F>
-__device__ __forceinline__ void for_each_digit(const uint4 kv, const PipParams& p, F emit) {
-  uint32_t sgn = kv.w >> 31;
-  uint32_t k[4] = {kv.x, kv.y, kv.z, kv.w & 0x7FFFFFFFu};
+__device__ __forceinline__ void for_each_digit(const uint32_t (&k)[kDigitWords], uint32_t sgn, const PipParams& p, F emit) {
   uint32_t carry = 0;
   for (int w = 0; w < p.W; ++w) {
     uint32_t raw = half_bits(k, w * p.c, p.c) + carry;
@@ -117,6 +127,37 @@ __device__ __forceinline__ void for_each_digit(const uint4 kv, const PipParams& 
     carry = neg;
     if (d != 0) emit((uint32_t)w * p.SB + ((d - 1) >> p.low_bits), (uint32_t)w * p.B + d - 1, neg ^ sgn);
   }
+}
+// digit source held in registers (k_prepare): copy + sign split
+__device__ __forceinline__ uint32_t load_digit_words(const uint32_t* src, uint32_t (&k)[kDigitWords]) {
+#pragma unroll
+  for (int j = 0; j < kDigitWords; ++j) k[j] = src[j];
+#if SNARKV_GLV
+  uint32_t sgn = k[3] >> 31;
+  k[3] &= 0x7FFFFFFFu;
+  return sgn;
+#else
+  return 0u;
+#endif
+}
+// the stored digit source of virtual point v: kDigitWords words; with GLV bit 127 is the half's sign
+__device__ __forceinline__ uint32_t load_digit_source(const uint4* __restrict__ src, size_t v, uint32_t (&k)[kDigitWords]) {
+  const uint4* s = src + v * (kDigitWords / 4);
+#pragma unroll
+  for (int j = 0; j < kDigitWords / 4; ++j) {
+    uint4 q = s[j];
+    k[4 * j] = q.x;
+    k[4 * j + 1] = q.y;
+    k[4 * j + 2] = q.z;
+    k[4 * j + 3] = q.w;
+  }
+#if SNARKV_GLV
+  uint32_t sgn = k[3] >> 31;
+  k[3] &= 0x7FFFFFFFu;
+  return sgn;
+#else
+  return 0u;  // canonical scalars < r < 2^255: non-negative, bit 255 clear
+#endif
 }
 
 // One workgroup = one tile of p.tile scalars: GLV split k = k1 + k2*lambda,
@@ -145,26 +186,34 @@ __global__ void __launch_bounds__(SNARKV_TILE_THREADS)
     }
     G1Affine29 a = g1a29_from_canonical(w);
     bool ident = g1a29_is_identity(a);
-    pts[2 * (size_t)i] = a;
+    pts[kHalves * (size_t)i] = a;
+    const uint4* ks = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+    uint4 k0 = ks[0], k1 = ks[1];
+    uint32_t k[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w}, o[8];
+#if SNARKV_GLV
     constexpr int32_t bl[9] = BN254_GLV_BETA29_LIMBS;
     Fq29 beta;
 #pragma unroll
     for (int j = 0; j < 9; ++j) beta.v[j] = bl[j];
     a.x = fq29_canon_residue(fq29_mul(a.x, beta));  // phi(P) = (beta x, y)
     pts[2 * (size_t)i + 1] = a;
-    const uint4* ks = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
-    uint4 k0 = ks[0], k1 = ks[1];
-    uint32_t k[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w}, o[8];
     glv_decompose(k, o);
+#else
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = k[j];  // the canonical scalar is its own (only) digit source
+#endif
     if (ident) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = 0;
     }
-    uint4 h0 = make_uint4(o[0], o[1], o[2], o[3]), h1 = make_uint4(o[4], o[5], o[6], o[7]);
-    glv[2 * (size_t)i] = h0;
-    glv[2 * (size_t)i + 1] = h1;
-    for_each_digit(h0, p, [&](uint32_t key, uint32_t, uint32_t) { atomicAdd(&lds[key], 1u); });
-    for_each_digit(h1, p, [&](uint32_t key, uint32_t, uint32_t) { atomicAdd(&lds[key], 1u); });
+    glv[2 * (size_t)i] = make_uint4(o[0], o[1], o[2], o[3]);
+    glv[2 * (size_t)i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+#pragma unroll
+    for (int h = 0; h < kHalves; ++h) {
+      uint32_t d[kDigitWords];
+      uint32_t sgn = load_digit_words(o + h * kDigitWords, d);
+      for_each_digit(d, sgn, p, [&](uint32_t key, uint32_t, uint32_t) { atomicAdd(&lds[key], 1u); });
+    }
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) M[(size_t)k * p.mstride + blockIdx.x] = lds[k];
@@ -183,9 +232,12 @@ __global__ void __launch_bounds__(SNARKV_TILE_THREADS)
   uint32_t lo = blockIdx.x * p.tile;
   uint32_t hi = lo + p.tile < p.n ? lo + p.tile : p.n;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    for (uint32_t h = 0; h < 2; ++h) {
-      uint32_t v = 2 * i + h;  // virtual point: P (h=0) or phi(P) (h=1)
-      for_each_digit(glv[2 * (size_t)i + h], p, [&](uint32_t key, uint32_t bucket, uint32_t neg) {
+#pragma unroll
+    for (uint32_t h = 0; h < (uint32_t)kHalves; ++h) {
+      uint32_t v = kHalves * i + h;  // virtual point: P (h=0) or phi(P) (h=1)
+      uint32_t d[kDigitWords];
+      uint32_t sgn = load_digit_source(glv, v, d);
+      for_each_digit(d, sgn, p, [&](uint32_t key, uint32_t bucket, uint32_t neg) {
         uint32_t pos = atomicAdd(&lds[key], 1u);
         tmp[pos] = make_uint2(bucket, v | (neg << 31));
       });
@@ -752,11 +804,11 @@ static int default_window_bits(size_t n) {
 }
 
 // Smallest window size with the same number of windows: keeps the TOP window
-// populated (c = 18 would leave it one useful bit of a 127-bit half-scalar, i.e.
+// populated (with GLV c = 18 would leave it one useful bit of a 127-bit half-scalar, i.e.
 // one bucket holding half of all entries).
 static int balance_window_bits(int c) {
-  int W = (128 + c - 1) / c;
-  return (128 + W - 1) / W;
+  int W = (kDigitBits + c - 1) / c;
+  return (kDigitBits + W - 1) / W;
 }
 
 int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
@@ -767,22 +819,22 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   p.c = window_bits > 0 ? window_bits : balance_window_bits(default_window_bits(n));
   if (p.c < 2) p.c = 2;
   if (p.c > 22) p.c = 22;
-  p.W = (128 + p.c - 1) / p.c;
+  p.W = (kDigitBits + p.c - 1) / p.c;
   p.B = 1u << (p.c - 1);
   p.nb = (uint32_t)p.W * p.B;
   // level-1 keys: ~kSortTarget items each so that a level-2 workgroup sorts its
   // slice inside LDS; bounded by the LDS counters of a tile workgroup
   int high = p.c - 1 > 10 ? p.c - 1 - 10 : 0;  // at most 1024 level-2 bins (LDS)
-  while (high < p.c - 1 && ((2 * n) >> (high + 1)) >= kSortTarget && ((uint64_t)p.W << (high + 1)) <= kMaxKeys) ++high;
+  while (high < p.c - 1 && ((kHalves * n) >> (high + 1)) >= kSortTarget && ((uint64_t)p.W << (high + 1)) <= kMaxKeys) ++high;
   p.low_bits = (p.c - 1) - high;
   p.SB = p.B >> p.low_bits;
   p.nkeys = (uint32_t)p.W * p.SB;
   // tile: >= 16 items per (tile, key) stream so partition writes fill 128-byte lines
   p.tile = 4096;
-  while (p.tile < 65536 && (uint64_t)p.tile * 2 * p.W < 16ull * p.nkeys) p.tile *= 2;
+  while (p.tile < 65536 && (uint64_t)p.tile * kHalves * p.W < 16ull * p.nkeys) p.tile *= 2;
   p.nblk = (uint32_t)((n + p.tile - 1) / p.tile);
   p.mstride = p.nblk | 1u;
-  uint64_t max_entries = 2ull * (uint64_t)n * (uint64_t)p.W;
+  uint64_t max_entries = (uint64_t)kHalves * (uint64_t)n * (uint64_t)p.W;
   if (n == 0 || max_entries >= 0xFFFFFFFFull || n >= 0x40000000ull) {
     set_last_error("pippenger: n=%zu out of range", n);
     return SNARKV_ERR_LENGTH;
@@ -795,7 +847,7 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
 
   void *d_pts, *d_glv, *d_counts, *d_offsets, *d_M, *d_blocksum, *d_entries, *d_tmp, *d_seg_ids, *d_seg_parts,
       *d_buckets, *d_wave, *d_shift, *d_misc, *d_big;
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_POINTS_MONT, 2 * n * sizeof(G1Affine29), &d_pts));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_POINTS_MONT, kHalves * n * sizeof(G1Affine29), &d_pts));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_GLV, n * 32, &d_glv));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_COUNTS, (size_t)p.nb * 4, &d_counts));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_OFFSETS, (size_t)p.nb * 4, &d_offsets));
@@ -893,7 +945,7 @@ int pip_geometry(size_t n_total, int window_bits, uint32_t* c, uint32_t* windows
   if (cc < 2) cc = 2;
   if (cc > 22) cc = 22;
   *c = (uint32_t)cc;
-  *windows = (uint32_t)((128 + cc - 1) / cc);
+  *windows = (uint32_t)((kDigitBits + cc - 1) / cc);
   *buckets_per_window = 1u << (cc - 1);
   return SNARKV_OK;
 }

@@ -41,3 +41,30 @@ def test_no_cpu_fallback_without_device():
     with pytest.raises(sv.SnarkvError) as e:
         sv.Context(0)
     assert e.value.code == -4
+
+
+def test_pallas_library_exports_every_declared_symbol():
+    """The pasta build (include/snarkv_pallas.h -> libsnarkv_pallas.so) and, without a device, the same
+    loud failure as the BN254 library."""
+    import snark_verifier_amd as sv
+    from snark_verifier_amd import pallas as PL
+
+    txt = open(os.path.join(ROOT, "include", "snarkv_pallas.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(snarkv_pallas_[a-z0-9_]+)\s*\(", txt)))
+    assert len(declared) == 11
+    lib = PL.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"pallas" in lib.snarkv_pallas_version()
+    assert b"bn254" in sv.load_library().snarkv_version()
+    try:
+        import torch
+
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if not has_gpu:
+        with pytest.raises(sv.SnarkvError) as e:
+            PL.PallasContext(0)
+        assert e.value.code == -4

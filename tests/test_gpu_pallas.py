@@ -1,0 +1,141 @@
+"""GPU: the pasta build (libsnarkv_pallas.so) -- the same Pippenger and IPA-decider kernels compiled
+for pallas -- against the pallas oracle: MSM bytes, and the reference's `test_ipa` / `test_ipa_as`
+(pcs/ipa.rs:434-466, pcs/ipa/accumulation.rs:240-290) with the device doing `IpaAs::decide`."""
+import os
+import random
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import bn254 as BN  # noqa: E402
+import ipa as I  # noqa: E402
+import pallas as PA  # noqa: E402
+import transcript as T  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pctx():
+    from snark_verifier_amd import pallas as PL
+
+    c = PL.PallasContext(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture()
+def on_pallas():
+    I.use_curve(PA)
+    yield
+    I.use_curve(BN)
+
+
+def _pack(scalars, points):
+    return b"".join(PA.fe_to_bytes(s) for s in scalars), b"".join(PA.g1_to_bytes(p) for p in points)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 257, 1500])
+def test_msm_against_the_pallas_oracle(pctx, n):
+    rnd = random.Random(n)
+    pts = PA.sample_points(n, n)
+    sc = [rnd.randrange(PA.R) for _ in range(n)]
+    s, p = _pack(sc, pts)
+    assert pctx.msm_pippenger(s, p) == PA.g1_to_bytes(PA.g1_msm_pippenger(sc, pts))
+
+
+def test_msm_edge_cases(pctx):
+    import snark_verifier_amd as sv
+
+    rnd = random.Random(1)
+    base = PA.sample_points(5, 40)
+    # duplicates, P and -P, zero / r-1 / tiny scalars, identity points: the exceptional cases of the adders
+    pts = base[:10] + base[:10] + [PA.g1_neg(q) for q in base[:10]] + [None] * 3 + base[10:]
+    sc = [rnd.randrange(PA.R) for _ in pts]
+    for i, v in ((0, 0), (1, PA.R - 1), (2, 1), (3, 2), (11, sc[1]), (21, sc[1])):
+        sc[i] = v
+    s, p = _pack(sc, pts)
+    want = PA.g1_msm_pippenger([x for x, q in zip(sc, pts) if q is not None], [q for q in pts if q is not None])
+    assert pctx.msm_pippenger(s, p) == PA.g1_to_bytes(want)
+    # everything cancels -> the identity, 64 zero bytes
+    s2, p2 = _pack([7, 7], [base[0], PA.g1_neg(base[0])])
+    assert pctx.msm_pippenger(s2, p2) == bytes(64)
+    # all scalars equal (one bucket per window holds everything)
+    s3, p3 = _pack([12345] * 300, base[:30] * 10)
+    assert pctx.msm_pippenger(s3, p3) == PA.g1_to_bytes(PA.g1_mul(PA.g1_msm_pippenger([10] * 30, base[:30]), 12345))
+    with pytest.raises(sv.SnarkvError):
+        pctx.msm_pippenger(b"", b"")
+    with pytest.raises(sv.SnarkvError):
+        pctx.msm_pippenger(s2, p2[:64])
+
+
+def test_msm_2p16_linearity_and_prefix(pctx):
+    """2^16 terms (1 024 distinct points, each 64 times): the pure-Python oracle is too slow for that
+    many, so size-independent properties -- MSM(s, P) + MSM(t, P) = MSM(s + t, P) -- and the same sum
+    folded on the host to a 1 024-term oracle MSM."""
+    n = 1 << 16
+    rnd = random.Random(3)
+    base = PA.sample_points(11, 1 << 10)
+    sa = [rnd.randrange(PA.R) for _ in range(n)]
+    sb = [rnd.randrange(PA.R) for _ in range(n)]
+    pb = b"".join(PA.g1_to_bytes(p) for p in base) * (n >> 10)
+    enc = lambda v: b"".join(PA.fe_to_bytes(x) for x in v)  # noqa: E731
+    a = PA.g1_from_bytes(pctx.msm_pippenger(enc(sa), pb))
+    b = PA.g1_from_bytes(pctx.msm_pippenger(enc(sb), pb))
+    ab = PA.g1_from_bytes(pctx.msm_pippenger(enc([(x + y) % PA.R for x, y in zip(sa, sb)]), pb))
+    assert PA.g1_add(a, b) == ab and ab is not None
+    # collapse the repeats on the host: sum_j s_{i + 1024 j} per base point, 1024-term oracle MSM
+    folded = [sum(sa[i::1 << 10]) % PA.R for i in range(1 << 10)]
+    assert a == PA.g1_msm_pippenger(folded, base)
+
+
+@pytest.mark.parametrize("k,zk", [(6, False), (6, True), (10, True)])
+def test_ipa_decide_on_pallas(pctx, on_pallas, k, zk):
+    rnd = random.Random("gpu-pallas-%d-%d" % (k, zk))
+    rng = lambda: rnd.randrange(PA.R)  # noqa: E731
+    n = 1 << k
+    pts = PA.sample_points(100 + k + zk, n + 2)
+    pk = I.IpaProvingKey(k, pts[:n], pts[n], pts[n + 1] if zk else None)
+    dk = pctx.ipa_dk_create(b"".join(PA.g1_to_bytes(p) for p in pk.g))
+    assert dk.k == k
+    accs = []
+    for _ in range(2 if k == 10 else 3):
+        p = [rng() for _ in range(n)]
+        omega, z = (rng() if zk else None), rng()
+        c = pk.commit(p, omega)
+        t = T.Blake2bTranscript(PA)
+        I.ipa_create_proof(pk, p, z, omega, t, rng)
+        accs.append(I.ipa_succinct_verify(pk.h, pk.s, [(1, c)], z, I.poly_eval(p, z),
+                                          I.ipa_read_proof(zk, k, T.Blake2bTranscript(PA, t.finalize()))))
+    t = T.Blake2bTranscript(PA)
+    I.ipa_as_create_proof(pk, accs, t, rng)
+    new = I.ipa_as_verify(pk.h, pk.s, accs, I.ipa_as_read_proof(zk, k, accs, T.Blake2bTranscript(PA, t.finalize())))
+    everything = accs + [new]
+    xi = b"".join(PA.fe_to_bytes(x) for a in everything for x in a[0])
+    u = b"".join(PA.g1_to_bytes(a[1]) for a in everything)
+    assert pctx.ipa_decide_batch(dk, xi, u) == [True] * len(everything)
+    bad_u = PA.g1_to_bytes(PA.g1_add(new[1], pk.h))
+    bad_xi = b"".join(PA.fe_to_bytes(x) for x in [(new[0][0] + 1) % PA.R] + new[0][1:])
+    good_xi = b"".join(PA.fe_to_bytes(x) for x in new[0])
+    assert pctx.ipa_decide_batch(dk, good_xi + bad_xi + good_xi, bad_u + PA.g1_to_bytes(new[1]) * 2) == [False, False, True]
+    dk.close()
+
+
+def test_both_libraries_in_one_process(pctx, gpu_ctx):
+    """The BN254 library and the pasta build side by side: same kernels, different constants and
+    namespaces (-Dsnarkv=snarkv_pallas, -Bsymbolic) -- each answers for its own curve."""
+    import coracle as C
+
+    rnd = random.Random(8)
+    n = 200
+    s = b"".join(rnd.randrange(BN.R).to_bytes(32, "little") for _ in range(n))
+    pb = C.sample_points(3, n)
+    assert gpu_ctx.msm_pippenger(s, pb) == C.msm_pippenger(s, pb, 1)
+    pts = PA.sample_points(4, n)
+    sc = [rnd.randrange(PA.R) for _ in range(n)]
+    s2, p2 = _pack(sc, pts)
+    assert pctx.msm_pippenger(s2, p2) == PA.g1_to_bytes(PA.g1_msm_pippenger(sc, pts))
+    assert gpu_ctx.msm_pippenger(s, pb) == C.msm_pippenger(s, pb, 1)
