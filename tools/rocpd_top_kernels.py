@@ -22,7 +22,6 @@ with open(sys.argv[2], "w", newline="") as f:
     w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
     f.write("Name,Calls,TotalDurationUs,AverageUs,Percentage\n")
     for r in rows:
-        tot = col(r, "total_duration", "total_duration (nsec)", "totaldurationns")
-        w.writerow([col(r, "name"), int(col(r, "total_calls", "calls")), round(tot / 1e3, 3),
-                    round(col(r, "average", "average (nsec)", "averagens") / 1e3, 3),
-                    round(col(r, "percentage", "percent"), 4)])
+        # the view reports microseconds (rocprofv3 7.x: `total_duration`, `average`)
+        w.writerow([col(r, "name"), int(col(r, "total_calls", "calls")), round(col(r, "total_duration"), 3),
+                    round(col(r, "average"), 3), round(col(r, "percentage", "percent"), 4)])
