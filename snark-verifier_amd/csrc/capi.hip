@@ -128,31 +128,19 @@ static int pippenger_maybe_split(snarkv_ctx* ctx, const void* d_s, const void* d
   bool allow = env && env[0] == '1';
   if (!allow || n < 4 * kChunk || window_bits != 0 || ctx->stage_timing)
     return launch_msm_pippenger(ctx, d_s, d_p, n, window_bits, d_out, partial_out);
-  // Four lanes: the caller's own stream + three private ones.  (Not four private
-  // ones: HIP multiplexes streams onto 4 hardware queues by default, and a fifth
-  // busy stream would share a queue with one of the lanes.)
-  if (!ctx->sub_ready) {
-    for (int i = 0; i < 3; ++i) SNARKV_TRY(snarkv_ctx_create(ctx->device, nullptr, &ctx->sub[i]));
-    ctx->sub[3] = nullptr;
-    for (int i = 0; i < 5; ++i) SNARKV_HIP(hipEventCreateWithFlags(&ctx->sub_ev[i], hipEventDisableTiming));
-    ctx->sub_ready = true;
-  }
+  SNARKV_TRY(ctx_lanes(ctx));
   const size_t chunks = (n + kChunk - 1) / kChunk;
   void* d_parts;
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SPLIT_PARTIALS, chunks * (size_t)SNARKV_G1_PARTIAL_BYTES, &d_parts));
   // inputs (and the partials buffer) may still be in flight on the caller's stream
-  SNARKV_HIP(hipEventRecord(ctx->sub_ev[4], ctx->stream));
-  for (int i = 0; i < 3; ++i) SNARKV_HIP(hipStreamWaitEvent(ctx->sub[i]->stream, ctx->sub_ev[4], 0));
+  SNARKV_TRY(ctx_lanes_fork(ctx));
   for (size_t c = 0; c < chunks; ++c) {
     size_t lo = c * kChunk, len = std::min(kChunk, n - lo);
-    snarkv_ctx* lane = (c % 4 == 3) ? ctx : ctx->sub[c % 4];
+    snarkv_ctx* lane = ctx_lane(ctx, c);
     SNARKV_TRY(launch_msm_pippenger(lane, (const char*)d_s + 32 * lo, (const char*)d_p + 64 * lo, len, 0,
                                     (char*)d_parts + c * (size_t)SNARKV_G1_PARTIAL_BYTES, true));
   }
-  for (int i = 0; i < 3; ++i) {
-    SNARKV_HIP(hipEventRecord(ctx->sub_ev[i], ctx->sub[i]->stream));
-    SNARKV_HIP(hipStreamWaitEvent(ctx->stream, ctx->sub_ev[i], 0));
-  }
+  SNARKV_TRY(ctx_lanes_join(ctx));
   return launch_fold_partials(ctx, d_parts, chunks, d_out, partial_out);
 }
 

@@ -97,6 +97,11 @@ namespace snarkv {
 
 // Ensure slot capacity; returns device pointer through *out.
 int ctx_reserve(snarkv_ctx* ctx, int slot, size_t bytes, void** out);
+// four lanes (the context's stream + three private sub-contexts) for independent launches: ctx_impl.inc
+int ctx_lanes(snarkv_ctx* ctx);
+int ctx_lanes_fork(snarkv_ctx* ctx);
+int ctx_lanes_join(snarkv_ctx* ctx);
+inline snarkv_ctx* ctx_lane(snarkv_ctx* ctx, size_t i) { return (i % 4 == 3) ? ctx : ctx->sub[i % 4]; }
 
 // kernels' host-side launchers (each enqueues on ctx->stream)
 int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, const void* d_offsets,

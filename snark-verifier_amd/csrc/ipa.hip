@@ -84,17 +84,27 @@ int SNARKV_API(ipa_decide_batch)(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const
   SNARKV_HIP(hipSetDevice(ctx->device));
   const uint32_t k = dk->k;
   const size_t n = (size_t)1 << k;
-  void *d_xi, *d_h, *d_out;
+  void *d_xi, *d_out;
   SNARKV_TRY(ctx_reserve(ctx, SLOT_IPA_XI, m * k * 32, &d_xi));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_IPA_H, n * 32, &d_h));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_IPA_OUT, m * 64, &d_out));
   SNARKV_HIP(hipMemcpyAsync(d_xi, xi32, m * k * 32, hipMemcpyHostToDevice, ctx->stream));
+  // accumulators are independent: up to four in flight (the tail of one Pippenger -- bucket reduce,
+  // shift chains -- overlaps the accumulation of the next), each lane with its own h buffer
+  const bool lanes = m >= 2;
+  if (lanes) {
+    SNARKV_TRY(ctx_lanes(ctx));
+    SNARKV_TRY(ctx_lanes_fork(ctx));
+  }
   for (size_t a = 0; a < m; ++a) {
-    hipLaunchKernelGGL(k_h_coeffs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+    snarkv_ctx* lane = lanes ? ctx_lane(ctx, a) : ctx;
+    void* d_h;
+    SNARKV_TRY(ctx_reserve(lane, SLOT_IPA_H, n * 32, &d_h));
+    hipLaunchKernelGGL(k_h_coeffs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, lane->stream,
                        (const uint32_t*)d_xi + a * k * 8, k, (uint32_t*)d_h);
     SNARKV_HIP(hipGetLastError());
-    SNARKV_TRY(launch_msm_pippenger(ctx, d_h, dk->d_points, n, 0, (uint8_t*)d_out + 64 * a, false));
+    SNARKV_TRY(launch_msm_pippenger(lane, d_h, dk->d_points, n, 0, (uint8_t*)d_out + 64 * a, false));
   }
+  if (lanes) SNARKV_TRY(ctx_lanes_join(ctx));
   std::vector<uint8_t> got(m * 64);
   SNARKV_HIP(hipMemcpyAsync(got.data(), d_out, m * 64, hipMemcpyDeviceToHost, ctx->stream));
   SNARKV_HIP(hipStreamSynchronize(ctx->stream));

@@ -34,9 +34,11 @@ for k in (16, 18, 20, 22):
     for _ in range(reps):
         ctx.ipa_decide_batch(dk, xi, u)
     t_dec = (time.perf_counter() - t0) * 1e3 / reps
+    ctx.ipa_decide_batch(dk, xi * 8, u * 8)  # first call creates the lanes and their scratch
     t0 = time.perf_counter()
-    ctx.ipa_decide_batch(dk, xi * 8, u * 8)
-    t_dec8 = (time.perf_counter() - t0) * 1e3 / 8
+    for _ in range(3):
+        ctx.ipa_decide_batch(dk, xi * 8, u * 8)
+    t_dec8 = (time.perf_counter() - t0) * 1e3 / 24
     # the host route: scalars + points cross PCIe every time (h_coeffs itself not even counted)
     hs = os.urandom(31 * n)
     hb = b"".join(hs[31 * i:31 * i + 31] + b"\x00" for i in range(0, n, max(1, n // 4096)))  # cheap filler
