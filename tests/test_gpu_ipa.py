@@ -308,3 +308,72 @@ def test_c_abi_ipa_decide_2p20_resident_key(gpu_ctx):
     assert dk2.k == k + 1
     xi2 = b"".join(O.fe_to_bytes(x) for x in [x0] + xi)
     assert gpu_ctx.ipa_decide_batch(dk2, xi2 + xi2, u2 + out) == [True, False]
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_protocol_shapes_over_ipa(H, seed):
+    """Fuzzing `PlonkVerifier<IpaAs<Bgh19>>` in the C++ mirror against the oracle: random polynomial
+    counts, phases, rotations (so random Bgh19 rotation sets), expression trees, quotient chunking,
+    linearization modes, both transcripts; k = 3..7."""
+    import plonk as P
+    import plonk_synth as S
+
+    rng = random.Random(9000 + seed)
+    lin = rng.choice([None, None, "WithoutConstant", "MinusVanishingTimesQuotient"])
+    kind = rng.choice(["evm", "poseidon"])
+    pr, dl = S.random_protocol(rng, lin)
+    k = pr["domain"].k
+    inst = [[rng.randrange(O.R) for _ in range(n)] for n in pr["num_instance"]]
+    kd = {"g": [rng.randrange(1, O.R) for _ in range(1 << k)], "h": rng.randrange(1, O.R), "s": rng.randrange(1, O.R)}
+    gb = b"".join(C.g1_mul(O.g1_to_bytes(O.G1_GEN), O.fe_to_bytes(c)) for c in kd["g"])
+    g = [O.g1_from_bytes(gb[64 * i:64 * i + 64]) for i in range(1 << k)]
+    h, s = O.g1_mul(O.G1_GEN, kd["h"]), O.g1_mul(O.G1_GEN, kd["s"])
+    tk, Tr = TR[kind]
+    proof = P.forge_proof_ipa(pr, inst, kd, Tr, rng, dl)
+    exp = P.succinct_verify_ipa(g[0], h, s, pr, inst, P.plonk_proof_read(pr, inst, Tr(proof), "bgh19"))
+    rc, acc = _plonk_ipa_run(H, tk, S, pr, inst, proof, pack_svk(k, g[0], h, s), gb, k)
+    assert rc == 1, (seed, lin, kind, k)
+    assert acc == pack_acc(exp[0])
+    bad = bytearray(proof)
+    bad[rng.randrange(len(proof))] ^= 1 << rng.randrange(8)
+    assert _plonk_ipa_run(H, tk, S, pr, inst, bytes(bad), pack_svk(k, g[0], h, s), gb, k)[0] in (0, -10)
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_random_bgh19_query_patterns_with_the_polynomial_prover(H, seed):
+    """Honest Bgh19 openings (oracle prover over real polynomials) of random query patterns: random
+    numbers of polynomials, rotations drawn from {0, 1, -1, 2, -3}, duplicated queries."""
+    import kzg as K
+    from hostfmt import pack_commitments, pack_queries
+
+    rng = random.Random(7000 + seed)
+    rnd = lambda: rng.randrange(O.R)  # noqa: E731
+    k = rng.randrange(2, 6)
+    n = 1 << k
+    raw = C.sample_points(7000 + seed, n + 2)
+    pts = [O.g1_from_bytes(raw[64 * i:64 * i + 64]) for i in range(n + 2)]
+    pk = I.IpaProvingKey(k, pts[:n], pts[n], pts[n + 1])
+    npoly = rng.randrange(1, 7)
+    polys = [[rnd() for _ in range(n)] for _ in range(npoly)]
+    blinds = [rnd() for _ in polys]
+    coms = [pk.commit(p, b) for p, b in zip(polys, blinds)]
+    w = pow(5, (O.R - 1) // n, O.R)
+    shifts = [pow(w, e % n, O.R) for e in (0, 1, -1, 2, -3)][: min(5, n)]
+    x = rnd()
+    spec = [(rng.randrange(npoly), rng.randrange(len(shifts))) for _ in range(rng.randrange(1, 12))]
+    spec += [(p, 0) for p in range(npoly) if all(q != p for q, _ in spec)][:2]
+    queries = [(p, shifts[s], I.poly_eval(polys[p], x * shifts[s] % O.R)) for p, s in spec]
+    kind = rng.choice(["evm", "poseidon"])
+    tk, Tr = TR[kind]
+    t = Tr()
+    I.bgh19_create_proof(pk, polys, blinds, x, queries, t, rnd)
+    proof = t.finalize()
+    exp = I.bgh19_verify(pk.g[0], pk.h, pk.s, [K.Msm.base(c) for c in coms], x, queries,
+                         I.bgh19_read_proof(k, queries, Tr(proof)))
+    assert I.ipa_decide(pk.g, exp)
+    out = _buf(32 * k + 64)
+    cm = pack_commitments([K.Msm.base(p) for p in coms])
+    assert H.hd_ipa_bgh19_verify(tk, pack_svk(k, pk.g[0], pk.h, pk.s), cm, O.fe_to_bytes(x), pack_queries(queries), proof,
+                                 len(proof), out) == 1
+    assert out.raw == pack_acc(exp)
+    assert H.hd_ipa_decide_all(k, raw[:64 * n], n, out.raw, 1) == 1
