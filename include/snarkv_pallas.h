@@ -33,6 +33,16 @@ int snarkv_pallas_g1_msm_pippenger(snarkv_ctx* ctx, const uint8_t* scalars32, co
 int snarkv_pallas_g1_msm_pippenger_dev(snarkv_ctx* ctx, const void* d_scalars32, const void* d_points64, size_t n,
                                        int window_bits, void* d_out64);
 
+/* `NativeLoader::multi_scalar_multiplication(&[(&Scalar, &C)]) -> C` for C = pallas::Affine (reference
+ * snark-verifier/src/loader/native.rs:61-71; trait loader.rs:108-112) -- one MSM, or n_msm of them as
+ * segments of one launch (segment k = terms offsets[k] .. offsets[k+1], offsets[0] = 0).  An empty
+ * MSM -> SNARKV_ERR_EMPTY (reference: `reduce().unwrap()` panic, native.rs:69).  flags:
+ * SNARKV_FLAG_VALIDATE checks canonical encodings and curve membership on the device.        */
+int snarkv_pallas_g1_msm_naive(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8_t* points64, size_t n,
+                               uint32_t flags, uint8_t out64[64]);
+int snarkv_pallas_g1_msm_batched(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8_t* points64,
+                                 const uint32_t* offsets, size_t n_msm, uint32_t flags, uint8_t* out);
+
 /* `AccumulationDecider::{decide, decide_all}` for `IpaAs<pallas::Affine, _>` (reference
  * snark-verifier/src/pcs/ipa/decider.rs:47-66); semantics as snarkv_ipa_* in snarkv_amd.h.     */
 int snarkv_pallas_ipa_dk_create(snarkv_ctx* ctx, const uint8_t* g_points64, size_t n, snarkv_ipa_dk** out);

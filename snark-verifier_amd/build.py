@@ -60,9 +60,9 @@ def build(verbose=False):
     return LIB
 
 
-# The pasta build of the curve-generic units (csrc/pallas.hip explains the three flags).
-PALLAS_UNITS = ["pallas", "msm_pippenger", "ipa"]
-PALLAS_FLAGS = ["-DSNARKV_CURVE_PALLAS", "-DSNARKV_GLV=0", "-Dsnarkv=snarkv_pallas"]
+# The pasta build of the curve-generic units (csrc/pallas.hip explains the flags).
+PALLAS_UNITS = ["pallas", "msm_pippenger", "msm_naive", "ipa"]
+PALLAS_FLAGS = ["-DSNARKV_CURVE_PALLAS", "-Dsnarkv=snarkv_pallas"]
 PALLAS_LIB = os.path.join(HERE, "libsnarkv_pallas.so")
 
 

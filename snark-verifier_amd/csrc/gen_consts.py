@@ -45,6 +45,85 @@ def generic_section(p, r, b, name):
     print("#define SNARKV_FR29_R2_LIMBS { %s }  // 2^522 mod r" % lim29(r29 * r29 % r))
 
 
+def _cube_roots(m):
+    for g_ in range(2, 50):
+        w = pow(g_, (m - 1) // 3, m)
+        if w != 1:
+            return w, w * w % m
+
+
+def _affine_mul(pt, k, p):
+    def add(a, b):
+        if a is None:
+            return b
+        if b is None:
+            return a
+        if a[0] == b[0]:
+            if (a[1] + b[1]) % p == 0:
+                return None
+            l = 3 * a[0] * a[0] * pow(2 * a[1], -1, p) % p
+        else:
+            l = (b[1] - a[1]) * pow(b[0] - a[0], -1, p) % p
+        x = (l * l - a[0] - b[0]) % p
+        return (x, (l * (a[0] - x) - a[1]) % p)
+
+    acc = None
+    for bit in bin(k)[2:]:
+        acc = add(acc, acc)
+        if bit == "1":
+            acc = add(acc, pt)
+    return acc
+
+
+def _glv_lattice(n, lam):
+    import math
+
+    rs, ts = [n, lam], [0, 1]
+    sq = math.isqrt(n)
+    while rs[-1] >= sq:
+        q = rs[-2] // rs[-1]
+        rs.append(rs[-2] - q * rs[-1])
+        ts.append(ts[-2] - q * ts[-1])
+    q = rs[-2] // rs[-1]
+    cand = [(rs[-2], -ts[-2]), (rs[-2] - q * rs[-1], -(ts[-2] - q * ts[-1]))]
+    a2, b2 = min(cand, key=lambda v: v[0] * v[0] + v[1] * v[1])
+    return rs[-1], -ts[-1], a2, b2
+
+
+def glv_section(p, r, gen):
+    """GLV endomorphism phi(x, y) = (beta x, y) = lambda (x, y) of a j = 0 curve (glv.cuh): beta, the
+    reduced lattice (a1, b1), (a2, b2) of {(a, b): a + b lambda = 0 mod r} with b1 < 0 < a1, a2, b2, and
+    g_i = floor(2^288 |b_j| / r).  Uniform widths: lattice entries 4 words (<= 128 bits), g_i 6 words.
+    The 288-bit shift keeps the rounding error of c_i = round(k b / r) below 2^-34, so the remainder is
+    (alpha, beta) in (-1/2 - 2^-34, 1/2 + 2^-34)^2 of the lattice basis and |k_i| <= (1/2 + 2^-34) (|x1| + |x2|)."""
+    def words(v, n):
+        assert 0 <= v < 1 << (32 * n)
+        return ", ".join("0x%08xu" % ((v >> (32 * i)) & 0xFFFFFFFF) for i in range(n))
+
+    def lim29(v):
+        return ", ".join("0x%08x" % ((v >> (29 * i)) & ((1 << 29) - 1)) for i in range(9))
+
+    lam = _cube_roots(r)[0]
+    lg = _affine_mul(gen, lam, p)
+    beta = [b for b in _cube_roots(p) if (b * gen[0] % p, gen[1]) == lg][0]
+    a1, b1, a2, b2 = _glv_lattice(r, lam)
+    assert a1 * b2 - a2 * b1 == r and b1 < 0 < a1 and a2 > 0 and b2 > 0
+    assert (a1 + b1 * lam) % r == 0 and (a2 + b2 * lam) % r == 0
+    # |k1| <= (1/2 + 2^-34)(a1 + a2), |k2| <= (1/2 + 2^-34)(|b1| + b2): both must stay below 2^127 (bit 127 = sign)
+    assert a1 + a2 < (1 << 128) - (1 << 120) and -b1 + b2 < (1 << 128) - (1 << 120)
+    g1, g2 = (b2 << 288) // r, ((-b1) << 288) // r
+    print("// GLV: lambda^2 + lambda + 1 = 0 mod r, phi(x, y) = (beta x, y) = lambda (x, y);")
+    print("// lattice (a1, b1), (a2, b2) with a + b lambda = 0 mod r, b1 < 0; g_i = floor(2^288 |b_j| / r)")
+    print("// lambda = 0x%x" % lam)
+    print("#define SNARKV_GLV_BETA29_LIMBS { %s }  // beta * 2^261 mod p" % lim29(beta * (1 << 261) % p))
+    print("#define SNARKV_GLV_A1 { %s }  // %d bits" % (words(a1, 4), a1.bit_length()))
+    print("#define SNARKV_GLV_NEG_B1 { %s }  // |b1|, %d bits" % (words(-b1, 4), (-b1).bit_length()))
+    print("#define SNARKV_GLV_A2 { %s }  // %d bits" % (words(a2, 4), a2.bit_length()))
+    print("#define SNARKV_GLV_B2 { %s }  // %d bits" % (words(b2, 4), b2.bit_length()))
+    print("#define SNARKV_GLV_G1 { %s }  // floor(2^288 b2 / r), %d bits" % (words(g1, 6), g1.bit_length()))
+    print("#define SNARKV_GLV_G2 { %s }  // floor(2^288 |b1| / r), %d bits" % (words(g2, 6), g2.bit_length()))
+
+
 if len(sys.argv) > 1 and sys.argv[1] == "pallas":
     # pallas (pasta): y^2 = x^3 + 5 over Fp, group order q (= the base field of vesta); generator (-1, 2).
     PP = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001
@@ -53,10 +132,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "pallas":
     assert PQ == (1 << 254) + 45560315531506369815346746415080538113
     assert (2 * 2 - ((-1) ** 3 + 5)) % PP == 0  # the generator is on the curve
     print("// GENERATED by gen_consts.py pallas -- do not edit.  8x32-bit limbs little-endian; *_MONT in Montgomery")
-    print("// form (R = 2^256); *29* in 9x29-bit limbs (R = 2^261).  No GLV / pairing constants: the pasta build of the")
-    print("// kernels is compiled with SNARKV_GLV=0 and has no decider.")
+    print("// form (R = 2^256); *29* in 9x29-bit limbs (R = 2^261).  No pairing constants: the pasta build has no KZG decider.")
     print("#pragma once")
     generic_section(PP, PQ, 5, "pallas")
+    glv_section(PP, PQ, (PP - 1, 2))
     sys.exit(0)
 
 
@@ -92,6 +171,7 @@ print("// GENERATED by gen_consts.py -- do not edit.  BN254 constants, 8x32-bit 
 print("// little-endian limb order; *_MONT values are in Montgomery form (R = 2^256).")
 print("#pragma once")
 generic_section(P, R, 3, "bn254")
+glv_section(P, R, (1, 2))
 print("// ---- BN254 only")
 print("#define BN254_P_LIMBS { %s }" % limbs(P))
 print("#define BN254_R_LIMBS { %s }" % limbs(R))
@@ -126,77 +206,6 @@ print("#define BN254_FR29_LIMBS { %s }  // r" % limbs29(R))
 print("#define BN254_FR29_NINV 0x%08x  // -r^-1 mod 2^29" % ((-pow(R, -1, 1 << 29)) % (1 << 29)))
 print("#define BN254_FR29_ONE_LIMBS { %s }  // 2^261 mod r" % limbs29(R29 % R))
 print("#define BN254_FR29_R2_LIMBS { %s }  // 2^522 mod r" % limbs29(R29 * R29 % R))
-# GLV endomorphism (glv.cuh): phi(x, y) = (beta x, y) = lambda (x, y)
-def cube_roots(m):
-    for g_ in range(2, 50):
-        w = pow(g_, (m - 1) // 3, m)
-        if w != 1:
-            return w, w * w % m
-
-
-def g1_mul_affine(pt, k):
-    def add(a, b):
-        if a is None:
-            return b
-        if b is None:
-            return a
-        if a[0] == b[0]:
-            if (a[1] + b[1]) % P == 0:
-                return None
-            l = 3 * a[0] * a[0] * pow(2 * a[1], -1, P) % P
-        else:
-            l = (b[1] - a[1]) * pow(b[0] - a[0], -1, P) % P
-        x = (l * l - a[0] - b[0]) % P
-        return (x, (l * (a[0] - x) - a[1]) % P)
-
-    acc = None
-    for bit in bin(k)[2:]:
-        acc = add(acc, acc)
-        if bit == "1":
-            acc = add(acc, pt)
-    return acc
-
-
-LAM = cube_roots(R)[0]
-_lg = g1_mul_affine((1, 2), LAM)
-BETA = [b for b in cube_roots(P) if (b * 1 % P, 2) == _lg][0]
-
-
-def glv_lattice(n, lam):
-    import math
-
-    rs, ts = [n, lam], [0, 1]
-    sq = math.isqrt(n)
-    while rs[-1] >= sq:
-        q = rs[-2] // rs[-1]
-        rs.append(rs[-2] - q * rs[-1])
-        ts.append(ts[-2] - q * ts[-1])
-    q = rs[-2] // rs[-1]
-    cand = [(rs[-2], -ts[-2]), (rs[-2] - q * rs[-1], -(ts[-2] - q * ts[-1]))]
-    a2, b2 = min(cand, key=lambda v: v[0] * v[0] + v[1] * v[1])
-    return rs[-1], -ts[-1], a2, b2
-
-
-GA1, GB1, GA2, GB2 = glv_lattice(R, LAM)
-assert GA1 * GB2 - GA2 * GB1 == R and GB1 < 0 < GA1 and GA2 > 0 and GB2 > 0
-GG1 = (GB2 << 256) // R
-GG2 = ((-GB1) << 256) // R
-
-
-def words(v, n):
-    return ", ".join("0x%08xu" % ((v >> (32 * i)) & 0xFFFFFFFF) for i in range(n))
-
-
-print("// GLV: lambda^2+lambda+1 = 0 mod r, phi(x,y) = (beta x, y) = lambda (x,y);")
-print("// lattice (a1,b1),(a2,b2) with a + b lambda = 0 mod r, b1 < 0; g_i = floor(2^256 |b_j| / r)")
-print("#define BN254_GLV_BETA29_LIMBS { %s }  // beta * 2^261 mod p" % limbs29(BETA * R29 % P))
-print("#define BN254_GLV_A1 { %s }  // 64 bits" % words(GA1, 2))
-print("#define BN254_GLV_NEG_B1 { %s }  // |b1|, 127 bits" % words(-GB1, 4))
-print("#define BN254_GLV_A2 { %s }  // 127 bits" % words(GA2, 4))
-print("#define BN254_GLV_B2 { %s }  // 64 bits" % words(GB2, 2))
-print("#define BN254_GLV_G1 { %s }  // floor(2^256 b2 / r), 66 bits" % words(GG1, 3))
-print("#define BN254_GLV_G2 { %s }  // floor(2^256 |b1| / r), 130 bits" % words(GG2, 5))
-print("// lambda = 0x%x" % LAM)
 # Frobenius coefficients gamma_{k,i} = xi^(i (p^k - 1)/6), k=1..3, i=1..5
 for k in (1, 2, 3):
     print("// gamma_%d,i = xi^(i*(p^%d-1)/6), i = 1..5 : {c0, c1} Montgomery" % (k, k))

@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(64) k_term_scalar_mul(const uint32_t* __restri
     return;
   }
   if (h) {
-    constexpr int32_t bl[9] = BN254_GLV_BETA29_LIMBS;
+    constexpr int32_t bl[9] = SNARKV_GLV_BETA29_LIMBS;
     Fq29 beta;
 #pragma unroll
     for (int j = 0; j < 9; ++j) beta.v[j] = bl[j];
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(64) k_term_chain(const uint32_t* __restrict__ 
   if (g1a29_is_identity(q)) mag = make_uint4(0, 0, 0, 0);  // all digits zero -> identity partial
   mags[g] = mag;
   if (h) {
-    constexpr int32_t bl[9] = BN254_GLV_BETA29_LIMBS;
+    constexpr int32_t bl[9] = SNARKV_GLV_BETA29_LIMBS;
     Fq29 beta;
 #pragma unroll
     for (int j = 0; j < 9; ++j) beta.v[j] = bl[j];
@@ -254,7 +254,7 @@ __global__ void k_validate(const uint32_t* __restrict__ scalars, const uint32_t*
   if (i >= n) return;
   bool ok = true;
   if (scalars) {
-    constexpr uint32_t r[8] = BN254_R_LIMBS;
+    constexpr uint32_t r[8] = SNARKV_FR_R_LIMBS;
     uint32_t k[8];
     load_words16(scalars + (size_t)i * 8, k, 2);
     uint64_t borrow = 0;

@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(SNARKV_TILE_THREADS)
     uint4 k0 = ks[0], k1 = ks[1];
     uint32_t k[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w}, o[8];
 #if SNARKV_GLV
-    constexpr int32_t bl[9] = BN254_GLV_BETA29_LIMBS;
+    constexpr int32_t bl[9] = SNARKV_GLV_BETA29_LIMBS;
     Fq29 beta;
 #pragma unroll
     for (int j = 0; j < 9; ++j) beta.v[j] = bl[j];

@@ -5,13 +5,13 @@
 // `util::msm::multi_scalar_multiplication` (msm.rs:308-343: `IpaProvingKey::commit`,
 // pcs/ipa.rs:220-229, and `IpaAs::decide`, pcs/ipa/decider.rs:47-55).
 //
-// Same sources as the BN254 library -- fq29.cuh / fr29.cuh / g1_29.cuh / msm_pippenger.hip /
-// ipa.hip -- compiled with
+// Same sources as the BN254 library -- fq29.cuh / fr29.cuh / g1_29.cuh / glv.cuh / msm_pippenger.hip /
+// msm_naive.hip / ipa.hip -- compiled with
 //   -DSNARKV_CURVE_PALLAS   pallas_consts.h: p, r, b = 5 (curve_consts.h)
-//   -DSNARKV_GLV=0          one virtual point per point, 255-bit digit source, 16 windows of 16
-//                           bits (the GLV split in glv.cuh is BN-shaped and stays with BN254)
 //   -Dsnarkv=snarkv_pallas  the C++ namespace, so both libraries can live in one process
-// There is no pairing, no decider and no transcript here.
+// msm_naive.hip (the segmented small-MSM kernels behind `NativeLoader::multi_scalar_multiplication`,
+// loader/native.rs:61-71) comes along; pallas has the same kind of endomorphism as BN254 (j = 0), so
+// the GLV split stays on, with pallas' lattice.  There is no pairing, no KZG decider and no transcript.
 #include <stdarg.h>
 #include <string.h>
 #include "ctx.hpp"
@@ -46,6 +46,49 @@ int snarkv_pallas_g1_msm_pippenger(snarkv_ctx* ctx, const uint8_t* scalars32, co
   SNARKV_HIP(hipMemcpyAsync(out64, d_o, 64, hipMemcpyDeviceToHost, ctx->stream));
   SNARKV_HIP(hipStreamSynchronize(ctx->stream));
   return SNARKV_OK;
+}
+
+// `NativeLoader::multi_scalar_multiplication` (loader/native.rs:61-71) for C = pallas::Affine, n_msm
+// independent MSMs in one launch (segment k = terms offsets[k] .. offsets[k+1])
+int snarkv_pallas_g1_msm_batched(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8_t* points64,
+                                 const uint32_t* offsets, size_t n_msm, uint32_t flags, uint8_t* out) {
+  if (!ctx || !scalars32 || !points64 || !offsets || !out) return SNARKV_ERR_ARG;
+  if (n_msm == 0) return SNARKV_ERR_EMPTY;
+  if (offsets[0] != 0) return SNARKV_ERR_LENGTH;
+  for (size_t k = 0; k < n_msm; ++k) {
+    if (offsets[k + 1] < offsets[k]) return SNARKV_ERR_LENGTH;
+    if (offsets[k + 1] == offsets[k]) return SNARKV_ERR_EMPTY;  // reference panics: native.rs:69
+  }
+  const size_t n = offsets[n_msm];
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  void *d_s, *d_p, *d_o, *d_out;
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_IN_SCALARS, n * 32, &d_s));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_IN_POINTS, n * 64, &d_p));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_IN_OFFSETS, (n_msm + 1) * 4, &d_o));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_OUT, n_msm * 64, &d_out));
+  SNARKV_HIP(hipMemcpyAsync(d_s, scalars32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  SNARKV_HIP(hipMemcpyAsync(d_p, points64, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  SNARKV_HIP(hipMemcpyAsync(d_o, offsets, (n_msm + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (flags & SNARKV_FLAG_VALIDATE) {
+    int bad = 0;
+    SNARKV_TRY(launch_validate(ctx, d_s, d_p, n, &bad));
+    if (bad) {
+      set_last_error("%d of %zu inputs are non-canonical or off-curve", bad, n);
+      return SNARKV_ERR_ENCODING;
+    }
+  }
+  SNARKV_TRY(launch_msm_batched(ctx, d_s, d_p, d_o, n_msm, n, d_out));
+  SNARKV_HIP(hipMemcpyAsync(out, d_out, n_msm * 64, hipMemcpyDeviceToHost, ctx->stream));
+  SNARKV_HIP(hipStreamSynchronize(ctx->stream));
+  return SNARKV_OK;
+}
+
+int snarkv_pallas_g1_msm_naive(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8_t* points64, size_t n,
+                               uint32_t flags, uint8_t out64[64]) {
+  if (n == 0) return SNARKV_ERR_EMPTY;
+  if (n > 0xFFFFFFFFull) return SNARKV_ERR_LENGTH;
+  uint32_t offsets[2] = {0, (uint32_t)n};
+  return snarkv_pallas_g1_msm_batched(ctx, scalars32, points64, offsets, 1, flags, out64);
 }
 
 }  // extern "C"

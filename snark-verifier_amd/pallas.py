@@ -29,6 +29,8 @@ def load_library():
             "snarkv_pallas_version": (ctypes.c_char_p, []),
             "snarkv_pallas_g1_msm_pippenger": (ctypes.c_int, [vp, vp, vp, sz, vp]),
             "snarkv_pallas_g1_msm_pippenger_dev": (ctypes.c_int, [vp, vp, vp, sz, ctypes.c_int, vp]),
+            "snarkv_pallas_g1_msm_naive": (ctypes.c_int, [vp, vp, vp, sz, u32, vp]),
+            "snarkv_pallas_g1_msm_batched": (ctypes.c_int, [vp, vp, vp, vp, sz, u32, vp]),
             "snarkv_pallas_ipa_dk_create": (ctypes.c_int, [vp, vp, sz, ctypes.POINTER(vp)]),
             "snarkv_pallas_ipa_dk_destroy": (None, [vp]),
             "snarkv_pallas_ipa_dk_k": (u32, [vp]),
@@ -75,6 +77,28 @@ class PallasContext:
             raise SnarkvError(-2, "scalars/points length mismatch (reference: assert_eq!, msm.rs:309)")
         out = ctypes.create_string_buffer(64)
         _check(self._lib.snarkv_pallas_g1_msm_pippenger(self._h, s if s else b"\x00", p if p else b"\x00", len(s) // 32, out))
+        return out.raw
+
+    def msm_batched(self, scalars, points, offsets, flags=0):
+        """`NativeLoader::multi_scalar_multiplication` on pallas (loader/native.rs:61-71), len(offsets)-1
+        MSMs as segments of one launch -> concatenated affine bytes."""
+        import array
+
+        s, p = _as_bytes(scalars), _as_bytes(points)
+        off = array.array("I", offsets)
+        addr, _ = off.buffer_info()
+        n_msm = len(offsets) - 1
+        out = ctypes.create_string_buffer(64 * max(n_msm, 1))
+        _check(self._lib.snarkv_pallas_g1_msm_batched(self._h, s if s else b"\x00", p if p else b"\x00",
+                                                      ctypes.c_void_p(addr), n_msm, flags, out))
+        return out.raw[:64 * n_msm]
+
+    def msm_naive(self, scalars, points, flags=0):
+        s, p = _as_bytes(scalars), _as_bytes(points)
+        if len(s) % 32 or len(p) % 64 or len(s) // 32 != len(p) // 64:
+            raise SnarkvError(-2, "scalars/points length mismatch")
+        out = ctypes.create_string_buffer(64)
+        _check(self._lib.snarkv_pallas_g1_msm_naive(self._h, s if s else b"\x00", p if p else b"\x00", len(s) // 32, flags, out))
         return out.raw
 
     def msm_pippenger_dev(self, d_scalars, d_points, n, d_out, window_bits=0):

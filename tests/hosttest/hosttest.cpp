@@ -207,7 +207,7 @@ void ht_glv_decompose(const uint8_t* k, uint8_t* out32) {
 // phi(P) = (beta x, y) through the 29-bit field
 void ht29_glv_phi(const uint8_t* p, uint8_t* out) {
   G1Affine29 a = load_g1_29(p);
-  constexpr int32_t b[9] = BN254_GLV_BETA29_LIMBS;
+  constexpr int32_t b[9] = SNARKV_GLV_BETA29_LIMBS;
   Fq29 beta;
   for (int i = 0; i < 9; ++i) beta.v[i] = b[i];
   a.x = fq29_mul(a.x, beta);

@@ -139,3 +139,80 @@ def test_both_libraries_in_one_process(pctx, gpu_ctx):
     s2, p2 = _pack(sc, pts)
     assert pctx.msm_pippenger(s2, p2) == PA.g1_to_bytes(PA.g1_msm_pippenger(sc, pts))
     assert gpu_ctx.msm_pippenger(s, pb) == C.msm_pippenger(s, pb, 1)
+
+
+def test_native_loader_msm_on_pallas(pctx):
+    """`NativeLoader::multi_scalar_multiplication` semantics on pallas (loader/native.rs:61-71): single
+    and segmented small MSMs (every chunking the kernels pick by batch size) against the oracle's naive
+    sum; empty segment / validation errors."""
+    import snark_verifier_amd as sv
+
+    rnd = random.Random(12)
+    pts = PA.sample_points(6, 64)
+    for n in (1, 2, 3, 24, 64):
+        sc = [rnd.randrange(PA.R) for _ in range(n)]
+        sc[0] = rnd.choice([0, 1, PA.R - 1, sc[0]])
+        s, p = _pack(sc, pts[:n])
+        assert pctx.msm_naive(s, p) == PA.g1_to_bytes(PA.g1_msm_naive(sc, pts[:n]))
+    # 40 segments of ragged sizes, duplicates and opposite points inside a segment
+    offs, sc_all, pt_all, want = [0], [], [], []
+    for j in range(40):
+        n = rnd.randrange(1, 30)
+        q = [rnd.choice(pts) for _ in range(n)]
+        if n > 2:
+            q[1] = q[0]
+            q[2] = PA.g1_neg(q[0])
+        sc = [rnd.randrange(PA.R) for _ in range(n)]
+        want.append(PA.g1_msm_naive(sc, q))
+        sc_all += sc
+        pt_all += q
+        offs.append(offs[-1] + n)
+    s, p = _pack(sc_all, pt_all)
+    assert pctx.msm_batched(s, p, offs) == b"".join(PA.g1_to_bytes(w) for w in want)
+    # a big batch: > 16 k terms takes the one-lane-per-(term, half) kernels
+    big_pts = (pts * 300)[:18000]
+    big_sc = [rnd.randrange(PA.R) for _ in big_pts]
+    offs2 = list(range(0, 18001, 1500))
+    s, p = _pack(big_sc, big_pts)
+    got = pctx.msm_batched(s, p, offs2)
+    for j in (0, 5, 11):
+        assert got[64 * j:64 * j + 64] == PA.g1_to_bytes(PA.g1_msm_pippenger(big_sc[offs2[j]:offs2[j + 1]], big_pts[offs2[j]:offs2[j + 1]]))
+    with pytest.raises(sv.SnarkvError):
+        pctx.msm_batched(s[:64], p[:128], [0, 1, 1, 2])  # empty segment: the reference panics (native.rs:69)
+    off_curve = PA.fe_to_bytes(5) + PA.fe_to_bytes(7)
+    with pytest.raises(sv.SnarkvError):
+        pctx.msm_naive(PA.fe_to_bytes(3), off_curve, flags=sv.SNARKV_FLAG_VALIDATE)
+    with pytest.raises(sv.SnarkvError):
+        pctx.msm_naive(PA.fe_to_bytes(PA.R), PA.g1_to_bytes(pts[0]), flags=sv.SNARKV_FLAG_VALIDATE)  # scalar >= r
+
+
+def test_ipa_succinct_check_msms_on_the_device(pctx, on_pallas):
+    """The two `Msm::evaluate(None)` of `Ipa::succinct_verify` (pcs/ipa.rs:172,177) as ONE segmented device
+    launch on pallas, fed by the oracle's transcript + scalar algebra: C_k == c[U] + v'[H']."""
+    rnd = random.Random(44)
+    rng = lambda: rnd.randrange(PA.R)  # noqa: E731
+    k = 5
+    pts = PA.sample_points(303, (1 << k) + 2)
+    pk = I.IpaProvingKey(k, pts[:1 << k], pts[1 << k], pts[(1 << k) + 1])
+    p = [rng() for _ in range(1 << k)]
+    omega, z = rng(), rng()
+    c = pk.commit(p, omega)
+    t = T.Blake2bTranscript(PA)
+    I.ipa_create_proof(pk, p, z, omega, t, rng)
+    pr = I.ipa_read_proof(True, k, T.Blake2bTranscript(PA, t.finalize()))
+    xi = [r[2] for r in pr["rounds"]]
+    c_bar, alpha = pr["c_bar_alpha"]
+    ev = I.poly_eval(p, z)
+    lhs = [(1, c), (alpha, c_bar), ((-pr["omega_prime"]) % PA.R, pk.s), (pr["xi_0"] * ev % PA.R, pk.h)]
+    for (l, r, x) in pr["rounds"]:
+        lhs += [(pow(x, -1, PA.R), l), (x, r)]
+    v_prime = I.h_eval(xi, z) * pr["c"] % PA.R
+    rhs = [(pr["c"], pr["u"]), (pr["xi_0"] * v_prime % PA.R, pk.h)]
+    s, pp = _pack([a for a, _ in lhs + rhs], [b for _, b in lhs + rhs])
+    out = pctx.msm_batched(s, pp, [0, len(lhs), len(lhs) + len(rhs)])
+    assert out[:64] == out[64:] != bytes(64)
+    # a wrong evaluation breaks the equality
+    lhs[3] = (pr["xi_0"] * (ev + 1) % PA.R, pk.h)
+    s, pp = _pack([a for a, _ in lhs + rhs], [b for _, b in lhs + rhs])
+    out = pctx.msm_batched(s, pp, [0, len(lhs), len(lhs) + len(rhs)])
+    assert out[:64] != out[64:]
