@@ -1,11 +1,11 @@
 """Dev tool: throughput of the pasta build's MSM at 2^20 distinct pallas points (P_i = P_0 + i*Q,
 made on the host: the library has no pallas sampler) -- one MSM at a time and 4 in flight, next to the
-BN254 library on the same box.  Run on the GPU box: python tools/bench_pallas_msm.py [log2n]"""
+BN254 library on the same box.  Run on the GPU box: python tests/tools/bench_pallas_msm.py [log2n]"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import torch

@@ -1,6 +1,6 @@
 """Dev tool: latency of the batched Poseidon transcript kernel (host buffers in/out) for a proof-shaped schedule."""
 import os, random, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import bn254 as O, transcript as T
 import snark_verifier_amd as sv

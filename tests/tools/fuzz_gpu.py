@@ -1,7 +1,7 @@
 """Dev tool: randomized differential run of the C-ABI MSM entry points against the C oracle
 (random sizes, special scalars, identity / repeated / opposite bases, random segmentations)."""
 import os, random, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import bn254 as O
 import coracle as C
