@@ -403,10 +403,10 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 # rocprofv3 PMC, separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this same command at 2^20
-                # (profiles/r01_rocprofv3_pmc_hbm_traffic.txt): k_accumulate, bytes per launch, FETCH_SIZE + WRITE_SIZE
+                # (profiles/r01_rocprofv3_pmc_hbm_traffic_final3.txt): k_accumulate, bytes per launch, FETCH_SIZE + WRITE_SIZE
                 # as counted (Infinity-Cache hits included; the guide's x2 correction for wide coalesced reads would
-                # give 4.47e9).  Only valid for the default 2^20 workload; null otherwise.
-                "traffic": 2.307e9 if (args.log2n == 20 and dom == "bucket_accumulate") else None,
+                # give 4.34e9).  Only valid for the default 2^20 workload; null otherwise.
+                "traffic": 2.235e9 if (args.log2n == 20 and dom == "bucket_accumulate") else None,
                 "traffic_note": "k_accumulate gathers each 72-byte Montgomery point once per window (8 windows x 2^21 "
                                 "half-scalars x 72 B = 1.2e9 B algorithmic gather, 128-byte requests; served mostly by the "
                                 "256 MiB Infinity Cache: the 151 MB table fits) -- inherent "
