@@ -51,6 +51,15 @@ uint32_t snarkv_pallas_ipa_dk_k(const snarkv_ipa_dk* dk);
 int snarkv_pallas_ipa_decide_batch(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const uint8_t* xi32, const uint8_t* u64,
                                    size_t m, uint8_t* ok);
 
+/* Context-free forms over a lazily created process-global context (device 0), as the bn254_* entry
+ * points of snarkv_amd.h: `multi_scalar_multiplication` has no `&self` in the reference (loader.rs:108). */
+int pallas_g1_msm_naive(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]);
+int pallas_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, const uint32_t* offsets, size_t n_msm,
+                          uint8_t* out);
+int pallas_g1_msm_pippenger(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]);
+int pallas_ipa_dk_create(const uint8_t* g_points64, size_t n, snarkv_ipa_dk** out);
+int pallas_ipa_decide_batch(const snarkv_ipa_dk* dk, const uint8_t* xi32, const uint8_t* u64, size_t m, uint8_t* ok);
+
 #ifdef __cplusplus
 }
 #endif

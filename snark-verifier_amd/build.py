@@ -98,7 +98,33 @@ def build_host_driver():
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
         raise RuntimeError("host driver build failed")
+    build_host_driver_pallas()
     return HOST_LIB
+
+
+HOST_PALLAS_LIB = os.path.join(HERE, "libsnarkv_host_pallas.so")
+
+
+def build_host_driver_pallas():
+    """The pasta flavour of the host mirror (host/test_driver_pallas.cpp, -DSNARKV_HOST_PALLAS): Fr = pallas::Scalar,
+    loader bound to libsnarkv_pallas.so."""
+    if not os.path.exists(PALLAS_LIB):
+        return None
+    srcs = [os.path.join(HOST, f) for f in os.listdir(HOST)]
+    newest = max([os.path.getmtime(f) for f in srcs] + [os.path.getmtime(PALLAS_LIB)])
+    if os.path.exists(HOST_PALLAS_LIB) and os.path.getmtime(HOST_PALLAS_LIB) >= newest:
+        return HOST_PALLAS_LIB
+    # -Dsnarkv_host=...: its own C++ namespace -- the two flavours define the same inline functions and
+    # `static constexpr` members with different constants, and C++17 inline variables are STB_GNU_UNIQUE
+    # (bound process-wide even under RTLD_LOCAL) when both libraries sit in one process
+    cmd = ["g++", "-O3", "-mbmi2", "-madx", "-std=c++17", "-shared", "-fPIC", "-DSNARKV_HOST_PALLAS",
+           "-Dsnarkv_host=snarkv_host_pallas", "-fno-gnu-unique", "-o", HOST_PALLAS_LIB,
+           os.path.join(HOST, "test_driver_pallas.cpp"), "-L" + HERE, "-lsnarkv_pallas", "-pthread", "-Wl,-rpath,$ORIGIN"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("host driver (pallas) build failed")
+    return HOST_PALLAS_LIB
 
 
 if __name__ == "__main__":

@@ -14,6 +14,7 @@
 // the GLV split stays on, with pallas' lattice.  There is no pairing, no KZG decider and no transcript.
 #include <stdarg.h>
 #include <string.h>
+#include <mutex>
 #include "ctx.hpp"
 #include "../../include/snarkv_pallas.h"
 
@@ -89,6 +90,46 @@ int snarkv_pallas_g1_msm_naive(snarkv_ctx* ctx, const uint8_t* scalars32, const 
   if (n > 0xFFFFFFFFull) return SNARKV_ERR_LENGTH;
   uint32_t offsets[2] = {0, (uint32_t)n};
   return snarkv_pallas_g1_msm_batched(ctx, scalars32, points64, offsets, 1, flags, out64);
+}
+
+// ---- context-free forms (what a `NativeLoader`-style unit struct binds: loader.rs:108 has no &self) ----
+static std::mutex g_default_mu;
+static snarkv_ctx* g_default_ctx = nullptr;
+static std::recursive_mutex g_default_call_mu;  // one shared context: calls from different host threads take turns
+static int default_ctx(snarkv_ctx** out) {
+  std::lock_guard<std::mutex> lk(g_default_mu);
+  if (!g_default_ctx) {
+    int rc = snarkv_pallas_ctx_create(0, nullptr, &g_default_ctx);
+    if (rc < 0) return rc;
+  }
+  *out = g_default_ctx;
+  return SNARKV_OK;
+}
+#define PALLAS_DEFAULT_CTX()                                             \
+  std::lock_guard<std::recursive_mutex> _call_lock(g_default_call_mu);   \
+  snarkv_ctx* c;                                                         \
+  SNARKV_TRY(default_ctx(&c))
+
+int pallas_g1_msm_naive(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]) {
+  PALLAS_DEFAULT_CTX();
+  return snarkv_pallas_g1_msm_naive(c, scalars32, points64, n, 0, out64);
+}
+int pallas_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, const uint32_t* offsets, size_t n_msm,
+                          uint8_t* out) {
+  PALLAS_DEFAULT_CTX();
+  return snarkv_pallas_g1_msm_batched(c, scalars32, points64, offsets, n_msm, 0, out);
+}
+int pallas_g1_msm_pippenger(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]) {
+  PALLAS_DEFAULT_CTX();
+  return snarkv_pallas_g1_msm_pippenger(c, scalars32, points64, n, out64);
+}
+int pallas_ipa_dk_create(const uint8_t* g_points64, size_t n, snarkv_ipa_dk** out) {
+  PALLAS_DEFAULT_CTX();
+  return snarkv_pallas_ipa_dk_create(c, g_points64, n, out);
+}
+int pallas_ipa_decide_batch(const snarkv_ipa_dk* dk, const uint8_t* xi32, const uint8_t* u64, size_t m, uint8_t* ok) {
+  PALLAS_DEFAULT_CTX();
+  return snarkv_pallas_ipa_decide_batch(c, dk, xi32, u64, m, ok);
 }
 
 }  // extern "C"

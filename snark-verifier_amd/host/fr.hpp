@@ -18,6 +18,17 @@ class Fr {
  public:
   uint64_t v[4];  // Montgomery form
 
+#if defined(SNARKV_HOST_PALLAS)
+  // the pasta flavour of the host mirror (host/test_driver_pallas.cpp): `pallas::Scalar`,
+  // q = 2^254 + 45560315531506369815346746415080538113
+  static constexpr uint64_t MOD[4] = {0x8c46eb2100000001ull, 0x224698fc0994a8ddull, 0x0000000000000000ull,
+                                      0x4000000000000000ull};
+  static constexpr uint64_t INV = 0x8c46eb20ffffffffull;  // -q^-1 mod 2^64
+  static constexpr uint64_t ONE_M[4] = {0x5b2b3e9cfffffffdull, 0x992c350be3420567ull, 0xffffffffffffffffull,
+                                        0x3fffffffffffffffull};
+  static constexpr uint64_t R2[4] = {0xfc9678ff0000000full, 0x67bb433d891a16e3ull, 0x7fae231004ccf590ull,
+                                     0x096d41af7ccfdaa9ull};
+#else
   static constexpr uint64_t MOD[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull,
                                       0x30644e72e131a029ull};
   static constexpr uint64_t INV = 0xc2e1f593efffffffull;  // -r^-1 mod 2^64
@@ -25,6 +36,8 @@ class Fr {
                                         0x0e0a77c19a07df2full};
   static constexpr uint64_t R2[4] = {0x1bb8e645ae216da7ull, 0x53fe3ab1e35c59e3ull, 0x8c49833d53bb8085ull,
                                      0x0216d0b17f4e44a5ull};
+
+#endif
 
   Fr() : v{0, 0, 0, 0} {}
   static Fr zero() { return Fr(); }

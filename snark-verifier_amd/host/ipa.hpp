@@ -223,9 +223,9 @@ struct IpaDecidingKey {
       static_assert(sizeof(G1Affine) == 64, "G1Affine is the 64-byte wire form");
       snarkv_ipa_dk* h = nullptr;
       std::lock_guard<std::mutex> lock(device_mutex());
-      if (bn254_ipa_dk_create(g[0].b, g.size(), &h) != SNARKV_OK)
-        throw std::runtime_error(std::string("bn254_ipa_dk_create: ") + snarkv_last_error());
-      dk_ = std::shared_ptr<snarkv_ipa_dk>(h, [](snarkv_ipa_dk* p) { snarkv_ipa_dk_destroy(p); });
+      if (SNARKV_DEV(ipa_dk_create)(g[0].b, g.size(), &h) != SNARKV_OK)
+        throw std::runtime_error(std::string("ipa_dk_create: ") + SNARKV_DEV_LAST_ERROR());
+      dk_ = std::shared_ptr<snarkv_ipa_dk>(h, [](snarkv_ipa_dk* p) { SNARKV_DEV_IPA_DK_DESTROY(p); });
     }
     return dk_.get();
   }
@@ -289,8 +289,8 @@ struct IpaAs {
     }
     snarkv_ipa_dk* h = dk.handle();
     std::lock_guard<std::mutex> lock(device_mutex());
-    int rc = bn254_ipa_decide_batch(h, xi.data(), u.data(), accs.size(), ok.data());
-    if (rc != SNARKV_OK) throw std::runtime_error(std::string("bn254_ipa_decide_batch: ") + snarkv_last_error());
+    int rc = SNARKV_DEV(ipa_decide_batch)(h, xi.data(), u.data(), accs.size(), ok.data());
+    if (rc != SNARKV_OK) throw std::runtime_error(std::string("ipa_decide_batch: ") + SNARKV_DEV_LAST_ERROR());
     for (uint8_t b : ok)
       if (!b) return Error::assertion("U == commit(G, h)");
     return Error{};

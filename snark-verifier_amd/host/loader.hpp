@@ -28,6 +28,19 @@
 #include "../../include/snarkv_amd.h"
 #include "fr.hpp"
 
+// The context-free device entry points the loader binds: libsnarkv_amd.so (bn254_*) or, for the pasta
+// flavour of the mirror (-DSNARKV_HOST_PALLAS: host/test_driver_pallas.cpp), libsnarkv_pallas.so (pallas_*).
+#if defined(SNARKV_HOST_PALLAS)
+#include "../../include/snarkv_pallas.h"
+#define SNARKV_DEV(name) pallas_##name
+#define SNARKV_DEV_LAST_ERROR snarkv_pallas_last_error
+#define SNARKV_DEV_IPA_DK_DESTROY snarkv_pallas_ipa_dk_destroy
+#else
+#define SNARKV_DEV(name) bn254_##name
+#define SNARKV_DEV_LAST_ERROR snarkv_last_error
+#define SNARKV_DEV_IPA_DK_DESTROY snarkv_ipa_dk_destroy
+#endif
+
 namespace snarkv_host {
 
 // `snark_verifier::Error` (reference snark-verifier/src/lib.rs:18-28)
@@ -52,12 +65,14 @@ struct G1Affine {
     memcpy(r.b, p, 64);
     return r;
   }
-  static G1Affine generator() {
+#if !defined(SNARKV_HOST_PALLAS)
+  static G1Affine generator() {  // bn256 G1: (1, 2)
     G1Affine r;
     r.b[0] = 1;
     r.b[32] = 2;
     return r;
   }
+#endif
   static G1Affine identity() { return G1Affine(); }
   bool is_identity() const {
     for (int i = 0; i < 64; ++i)
@@ -235,8 +250,8 @@ struct GpuNativeLoader {
     }
     G1Affine out;
     std::lock_guard<std::mutex> lock(device_mutex());
-    int rc = bn254_g1_msm_naive(s.data(), p.data(), pairs.size(), out.b);
-    if (rc != SNARKV_OK) throw std::runtime_error(std::string("bn254_g1_msm_naive: ") + snarkv_last_error());
+    int rc = SNARKV_DEV(g1_msm_naive)(s.data(), p.data(), pairs.size(), out.b);
+    if (rc != SNARKV_OK) throw std::runtime_error(std::string("g1_msm_naive: ") + SNARKV_DEV_LAST_ERROR());
     return out;
   }
 
@@ -270,8 +285,8 @@ struct GpuNativeLoader {
     }
     std::vector<G1Affine> out(msms.size());
     std::lock_guard<std::mutex> lock(device_mutex());
-    int rc = bn254_g1_msm_batched(s.data(), p.data(), offs.data(), msms.size(), out.empty() ? nullptr : out[0].b);
-    if (rc != SNARKV_OK) throw std::runtime_error(std::string("bn254_g1_msm_batched: ") + snarkv_last_error());
+    int rc = SNARKV_DEV(g1_msm_batched)(s.data(), p.data(), offs.data(), msms.size(), out.empty() ? nullptr : out[0].b);
+    if (rc != SNARKV_OK) throw std::runtime_error(std::string("g1_msm_batched: ") + SNARKV_DEV_LAST_ERROR());
     return out;
   }
 };

@@ -185,8 +185,8 @@ inline G1Affine multi_scalar_multiplication(const std::vector<Fr>& scalars, cons
   }
   G1Affine out;
   std::lock_guard<std::mutex> lock(device_mutex());
-  int rc = bn254_g1_msm_pippenger(s.data(), p.data(), n, out.b);
-  if (rc != SNARKV_OK) throw std::runtime_error(std::string("bn254_g1_msm_pippenger: ") + snarkv_last_error());
+  int rc = SNARKV_DEV(g1_msm_pippenger)(s.data(), p.data(), n, out.b);
+  if (rc != SNARKV_OK) throw std::runtime_error(std::string("g1_msm_pippenger: ") + SNARKV_DEV_LAST_ERROR());
   return out;
 }
 

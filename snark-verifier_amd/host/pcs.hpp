@@ -81,6 +81,7 @@ struct Transcript {
   }
 };
 
+#if !defined(SNARKV_HOST_PALLAS)  // ---- KZG: BN254 only (pairing decider) ----
 // kzg.rs:19-35
 struct KzgSuccinctVerifyingKey {
   G1Affine g;
@@ -323,6 +324,8 @@ inline Result<KzgAccumulator> KzgAs<Gwc19>::pcs_verify<Gwc19Proof>(const KzgSucc
   return Result<KzgAccumulator>::Ok(KzgAccumulator{pts[0], pts[1]});
 }
 
+#endif  // KZG
+
 // ------------------------------------------------------------------ Bdfg21
 // bdfg21.rs:85-120
 struct Bdfg21Proof {
@@ -484,6 +487,7 @@ inline std::pair<MsmT, MsmT> msms(const std::vector<MsmT>& commitments, const Fr
 }
 }  // namespace bdfg21
 
+#if !defined(SNARKV_HOST_PALLAS)
 template <>
 template <>
 inline Result<KzgAccumulator> KzgAs<Bdfg21>::pcs_verify<Bdfg21Proof>(const KzgSuccinctVerifyingKey& svk,
@@ -566,5 +570,7 @@ struct LimbsEncoding {
     return out;
   }
 };
+
+#endif  // KZG
 
 }  // namespace snarkv_host

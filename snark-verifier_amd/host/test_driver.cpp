@@ -784,109 +784,17 @@ extern "C" int hd_plonk_verify(int mos, int tkind, const uint8_t* protocol, size
 }
 
 
-// ---- IPA (pcs/ipa.rs, pcs/ipa/{accumulation,decider}.rs) ----------------------------------------
-//   svk        : k(u32) | zk(u32) | g0(64) | h(64) | s(64, only when zk)
-//   accumulator: k x xi(32 LE) | u(64)
-// Returns 1 = the check passed, 0 = `Error::AssertionFailure`, -10 Transcript, -100 panic.
+// ---- IPA (pcs/ipa.rs, pcs/ipa/{accumulation,decider}.rs): entry points in ipa_driver.inc -------------
 #include "ipa.hpp"
 namespace {
-IpaSuccinctVerifyingKey parse_ipa_svk(const uint8_t* b) {
-  IpaSuccinctVerifyingKey svk;
-  uint32_t k, zk;
-  memcpy(&k, b, 4);
-  memcpy(&zk, b + 4, 4);
-  svk.k = k;
-  svk.g = G1Affine::from_bytes(b + 8);
-  svk.h = G1Affine::from_bytes(b + 72);
-  if (zk) svk.s = G1Affine::from_bytes(b + 136);
-  return svk;
-}
-bool parse_ipa_accs(const uint8_t* b, size_t k, uint32_t m, std::vector<IpaAccumulator>* out) {
-  const size_t stride = 32 * k + 64;
-  for (uint32_t i = 0; i < m; ++i) {
-    IpaAccumulator a;
-    a.xi.resize(k);
-    for (size_t j = 0; j < k; ++j)
-      if (!Fr::from_bytes(b + i * stride + 32 * j, &a.xi[j])) return false;
-    a.u = G1Affine::from_bytes(b + i * stride + 32 * k);
-    out->push_back(std::move(a));
-  }
-  return true;
-}
-void put_ipa_acc(const IpaAccumulator& a, uint8_t* out) {
-  for (size_t j = 0; j < a.xi.size(); ++j) a.xi[j].to_bytes(out + 32 * j);
-  memcpy(out + 32 * a.xi.size(), a.u.b, 64);
-}
 std::unique_ptr<Transcript> make_transcript(int tkind, const uint8_t* proof, size_t plen) {
   std::vector<uint8_t> bytes(proof, proof + plen);
   if (tkind == 0) return std::make_unique<EvmTranscript>(std::move(bytes));
   return std::make_unique<PoseidonTranscript>(std::move(bytes));
 }
 }  // namespace
-
-// `Ipa::read_proof` + `Ipa::succinct_verify` of ONE opening of `commitment` at z with value `eval`
-extern "C" int hd_ipa_succinct_verify(int tkind, const uint8_t* svk_bytes, const uint8_t* commitment64,
-                                      const uint8_t* z32, const uint8_t* eval32, const uint8_t* proof, size_t plen,
-                                      uint8_t* acc_out) {
-  return guarded([&] {
-    IpaSuccinctVerifyingKey svk = parse_ipa_svk(svk_bytes);
-    Fr z, ev;
-    if (!Fr::from_bytes(z32, &z) || !Fr::from_bytes(eval32, &ev)) return -3;
-    G1Affine c = G1Affine::from_bytes(commitment64);
-    auto t = make_transcript(tkind, proof, plen);
-    auto pr = Ipa::read_proof(svk, *t);
-    if (!pr.ok()) return error_code(pr.err);
-    auto acc = Ipa::succinct_verify(svk, MsmT::base(&c), z, ev, *pr.value);
-    if (!acc.ok()) return error_code(acc.err);
-    put_ipa_acc(*acc.value, acc_out);
-    return 1;
-  });
-}
-
-// `IpaAs::read_proof` + `IpaAs::verify` over m old accumulators
-extern "C" int hd_ipa_as_verify(int tkind, const uint8_t* svk_bytes, const uint8_t* accs, uint32_t m,
-                                const uint8_t* proof, size_t plen, uint8_t* acc_out) {
-  return guarded([&] {
-    IpaSuccinctVerifyingKey svk = parse_ipa_svk(svk_bytes);
-    std::vector<IpaAccumulator> instances;
-    if (!parse_ipa_accs(accs, svk.k, m, &instances)) return -3;
-    auto t = make_transcript(tkind, proof, plen);
-    auto pr = IpaAs<>::read_proof(svk, instances, *t);
-    if (!pr.ok()) return error_code(pr.err);
-    auto acc = IpaAs<>::verify(svk, instances, *pr.value);
-    if (!acc.ok()) return error_code(acc.err);
-    put_ipa_acc(*acc.value, acc_out);
-    return 1;
-  });
-}
-
-// `IpaAs::decide_all`: g = 2^k committing-key points (64 B each)
-extern "C" int hd_ipa_decide_all(uint32_t k, const uint8_t* g, size_t n_g, const uint8_t* accs, uint32_t m) {
-  return guarded([&] {
-    IpaDecidingKey dk;
-    dk.svk.k = k;
-    dk.g.resize(n_g);
-    for (size_t i = 0; i < n_g; ++i) dk.g[i] = G1Affine::from_bytes(g + 64 * i);
-    std::vector<IpaAccumulator> instances;
-    if (!parse_ipa_accs(accs, k, m, &instances)) return -3;
-    return IpaAs<>::decide_all(dk, instances).ok() ? 1 : 0;
-  });
-}
-
-// h_eval / h_coeffs hooks: out = h_eval(xi, z) (32) || h_coeffs(xi, 1) (2^k x 32)
-extern "C" int hd_ipa_h(uint32_t k, const uint8_t* xi32, const uint8_t* z32, uint8_t* out) {
-  return guarded([&] {
-    std::vector<Fr> xi(k);
-    Fr z;
-    for (uint32_t i = 0; i < k; ++i)
-      if (!Fr::from_bytes(xi32 + 32 * i, &xi[i])) return -3;
-    if (!Fr::from_bytes(z32, &z)) return -3;
-    h_eval(xi, z).to_bytes(out);
-    auto h = h_coeffs(xi, Fr::one());
-    for (size_t i = 0; i < h.size(); ++i) h[i].to_bytes(out + 32 + 32 * i);
-    return 0;
-  });
-}
+#define SNARKV_DRV(name) hd_##name
+#include "ipa_driver.inc"
 
 // `IpaAs<Bgh19>` as a PolynomialCommitmentScheme (bgh19.rs:26-96): read_proof + verify.
 //   commitments: pack_commitments format (the Msm list);  queries: pack_queries format

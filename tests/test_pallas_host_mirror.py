@@ -1,0 +1,168 @@
+"""The pasta flavour of the C++ host mirror (libsnarkv_host_pallas.so: Fr = pallas::Scalar, halo2's Blake2b
+transcript, the IPA layer bound to libsnarkv_pallas.so) against the oracle.
+CPU part: field, BLAKE2b (vs hashlib), transcript framing and point decompression.
+GPU part: the reference's `test_ipa` / `test_ipa_as` (pcs/ipa.rs:434-466, pcs/ipa/accumulation.rs:240-290)
+on their own curve and transcript: oracle prover -> C++ `Ipa::succinct_verify` / `IpaAs::verify` (MSMs on
+the device) -> `IpaAs::decide` (device)."""
+import ctypes
+import hashlib
+import os
+import random
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import bn254 as BN  # noqa: E402
+import ipa as I  # noqa: E402
+import pallas as PA  # noqa: E402
+import transcript as T  # noqa: E402
+from ipa_util import pack_acc, pack_svk  # noqa: E402  (curve-agnostic byte packing: 32-byte LE, x || y)
+
+
+@pytest.fixture(scope="module")
+def HP():
+    import importlib.util
+
+    from snark_verifier_amd import pallas as PL
+
+    PL.load_library()  # HIP runtime + libsnarkv_pallas.so first
+    spec = importlib.util.spec_from_file_location("_snarkv_build", os.path.join(ROOT, "snark-verifier_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build_host_driver_pallas()
+    h = ctypes.CDLL(os.path.join(ROOT, "snark-verifier_amd", "libsnarkv_host_pallas.so"))
+    cp, u32, sz = ctypes.c_char_p, ctypes.c_uint32, ctypes.c_size_t
+    h.hp_blake2b.argtypes = [cp, cp, sz, sz, cp]
+    h.hp_transcript_script.argtypes = [cp, sz, cp, sz, cp]
+    h.hp_ipa_succinct_verify.argtypes = [ctypes.c_int, cp, cp, cp, cp, cp, sz, cp]
+    h.hp_ipa_as_verify.argtypes = [ctypes.c_int, cp, cp, u32, cp, sz, cp]
+    h.hp_ipa_decide_all.argtypes = [u32, cp, sz, cp, u32]
+    h.hp_ipa_h.argtypes = [u32, cp, cp, cp]
+    return h
+
+
+@pytest.fixture()
+def on_pallas():
+    I.use_curve(PA)
+    yield
+    I.use_curve(BN)
+
+
+def _buf(n):
+    return ctypes.create_string_buffer(n)
+
+
+def test_pallas_scalar_field(HP):
+    rnd = random.Random(1)
+    R = PA.R
+    vals = [0, 1, 2, R - 1, R - 2, (R - 1) // 2, 1 << 254] + [rnd.randrange(R) for _ in range(60)]
+    o = _buf(32)
+    for a in vals:
+        for b in vals[:9]:
+            HP.hp_fr_mul(PA.fe_to_bytes(a % R), PA.fe_to_bytes(b % R), o)
+            assert o.raw == PA.fe_to_bytes(a * b % R)
+        if a % R:
+            assert HP.hp_fr_inv(PA.fe_to_bytes(a % R), o) == 1 and o.raw == PA.fe_to_bytes(pow(a, -1, R))
+    assert HP.hp_fr_inv(bytes(32), o) == 0
+
+
+def test_blake2b_against_hashlib(HP):
+    rnd = random.Random(2)
+    out = _buf(64)
+    for person in (b"Halo2-Transcript", b"x", b"0123456789abcdef"):
+        for n in (0, 1, 63, 64, 127, 128, 129, 255, 256, 257, 1000, 4096):
+            data = bytes(rnd.randrange(256) for _ in range(n))
+            for chunk in (1, 7, 128, 100000):
+                if chunk == 1 and n > 300:
+                    continue
+                HP.hp_blake2b(person.ljust(16, b"\x00"), data if data else b"\x00", n, chunk, out)
+                assert out.raw == hashlib.blake2b(data, digest_size=64, person=person).digest(), (person, n, chunk)
+
+
+def test_blake2b_transcript_script_matches_the_oracle(HP):
+    rnd = random.Random(3)
+    pts = PA.sample_points(21, 6)
+    w = T.Blake2bTranscript(PA)
+    ops, want = "", b""
+    for i in range(6):
+        p = pts[i] if i % 2 == 0 else (pts[i][0], PA.P - pts[i][1])  # both parities of y
+        w.write_ec_point(p)
+        ops += "P"
+        want += PA.g1_to_bytes(p)
+        if i % 3 == 0:
+            ops += "C"
+            want += PA.fe_to_bytes(w.squeeze_challenge())
+        s = rnd.choice([0, 1, PA.R - 1, rnd.randrange(PA.R)])
+        w.write_scalar(s)
+        ops += "SC"
+        want += PA.fe_to_bytes(s) + PA.fe_to_bytes(w.squeeze_challenge())
+    proof = w.finalize()
+    out = _buf(len(want))
+    assert HP.hp_transcript_script(proof, len(proof), ops.encode(), len(ops), out) == len(ops)
+    assert out.raw == want
+    # errors: truncated stream, non-canonical scalar, x not on the curve, x >= p, the identity's encoding
+    assert HP.hp_transcript_script(proof[:31], 31, b"P", 1, out) == -10
+    assert HP.hp_transcript_script(PA.fe_to_bytes(PA.R), 32, b"S", 1, out) == -10
+    x = next(x for x in range(2, 50) if PA.fq_sqrt(x ** 3 + 5) is None)
+    assert HP.hp_transcript_script(PA.fe_to_bytes(x), 32, b"P", 1, out) == -10
+    assert HP.hp_transcript_script(PA.fe_to_bytes(PA.P), 32, b"P", 1, out) == -10
+    assert HP.hp_transcript_script(bytes(32), 32, b"P", 1, out) == -10
+
+
+@pytest.mark.gpu
+def test_h_eval_and_h_coeffs_on_pallas(HP, on_pallas):
+    rnd = random.Random(4)
+    for k in (1, 5, 12):
+        xi = [rnd.randrange(PA.R) for _ in range(k)]
+        z = rnd.randrange(PA.R)
+        out = _buf(32 + 32 * (1 << k))
+        assert HP.hp_ipa_h(k, b"".join(PA.fe_to_bytes(x) for x in xi), PA.fe_to_bytes(z), out) == 0
+        assert out.raw[:32] == PA.fe_to_bytes(I.h_eval(xi, z))
+        assert out.raw[32:] == b"".join(PA.fe_to_bytes(c) for c in I.h_coeffs(xi, 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,zk", [(5, False), (5, True), (10, True)])
+def test_ipa_on_pallas_cpp_verifier_device_msms(HP, on_pallas, k, zk):
+    rnd = random.Random("hp-%d-%d" % (k, zk))
+    rng = lambda: rnd.randrange(PA.R)  # noqa: E731
+    n = 1 << k
+    pts = PA.sample_points(500 + k + zk, n + 2)
+    pk = I.IpaProvingKey(k, pts[:n], pts[n], pts[n + 1] if zk else None)
+    svk = pack_svk(k, pk.g[0], pk.h, pk.s)
+    gb = b"".join(PA.g1_to_bytes(p) for p in pk.g)
+    stride = 32 * k + 64
+    accs, accs_py = [], []
+    for _ in range(2 if k == 10 else 3):
+        p = [rng() for _ in range(n)]
+        omega, z = (rng() if zk else None), rng()
+        c = pk.commit(p, omega)
+        ev = I.poly_eval(p, z)
+        t = T.Blake2bTranscript(PA)
+        acc = I.ipa_create_proof(pk, p, z, omega, t, rng)
+        proof = t.finalize()
+        out = _buf(stride)
+        assert HP.hp_ipa_succinct_verify(2, svk, PA.g1_to_bytes(c), PA.fe_to_bytes(z), PA.fe_to_bytes(ev), proof, len(proof), out) == 1
+        assert out.raw == pack_acc(acc)
+        assert HP.hp_ipa_succinct_verify(2, svk, PA.g1_to_bytes(c), PA.fe_to_bytes(z), PA.fe_to_bytes((ev + 1) % PA.R), proof,
+                                         len(proof), out) == 0
+        assert HP.hp_ipa_succinct_verify(2, svk, PA.g1_to_bytes(c), PA.fe_to_bytes(z), PA.fe_to_bytes(ev), proof[:-1],
+                                         len(proof) - 1, out) == -10
+        accs.append(pack_acc(acc))
+        accs_py.append(acc)
+    assert HP.hp_ipa_decide_all(k, gb, n, b"".join(accs), len(accs)) == 1
+    t = T.Blake2bTranscript(PA)
+    new = I.ipa_as_create_proof(pk, accs_py, t, rng)
+    as_proof = t.finalize()
+    out = _buf(stride)
+    assert HP.hp_ipa_as_verify(2, svk, b"".join(accs), len(accs), as_proof, len(as_proof), out) == 1
+    assert out.raw == pack_acc(new)
+    assert HP.hp_ipa_decide_all(k, gb, n, out.raw, 1) == 1
+    bad = pack_acc((new[0], PA.g1_add(new[1], pk.h)))
+    assert HP.hp_ipa_decide_all(k, gb, n, bad, 1) == 0
+    assert HP.hp_ipa_decide_all(k, gb, n, b"".join(accs) + bad, len(accs) + 1) == 0
+    assert HP.hp_ipa_as_verify(2, svk, accs[0], 1, as_proof, len(as_proof), out) == -100  # accumulation.rs:107
