@@ -28,6 +28,7 @@ R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 BN_X = 4965661367192848881  # 0x44e992b44a6909f1
 ATE_LOOP = 6 * BN_X + 2
 B1 = 3
+TWO_ADICITY, MULT_GEN = 28, 7  # of the scalar field r: Fr::S, Fr::MULTIPLICATIVE_GENERATOR (halo2curves bn256)
 
 assert P == 36 * BN_X**4 + 36 * BN_X**3 + 24 * BN_X**2 + 6 * BN_X + 1
 assert R == 36 * BN_X**4 + 36 * BN_X**3 + 18 * BN_X**2 + 6 * BN_X + 1

@@ -21,6 +21,13 @@ import bn254 as O
 R = O.R
 
 
+def use_curve(mod):
+    """Run the curve-generic parts (Msm, powers, the query-set grouping) over another curve module with
+    the interface of oracle/bn254.py (oracle/pallas.py); the KZG schemes themselves stay BN254."""
+    global O, R
+    O, R = mod, mod.R
+
+
 def fr_inv(a):
     return pow(a % R, -1, R)
 

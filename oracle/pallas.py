@@ -14,6 +14,7 @@ law checks in tests/test_pallas_oracle.py and by the halo2 convention G = (-1, 2
 P = (1 << 254) + 45560315531419706090280762371685220353
 R = (1 << 254) + 45560315531506369815346746415080538113
 B1 = 5
+TWO_ADICITY, MULT_GEN = 32, 5  # of the scalar field r (halo2curves pasta Fq: S = 32, generator 5)
 G1_GEN = (P - 1, 2)
 
 assert P == 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001

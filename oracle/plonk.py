@@ -31,12 +31,25 @@ R = O.R
 Msm = K.Msm
 
 
+def use_curve(mod):
+    """Everything here is generic over the curve (`C: CurveAffine` in the reference); switch the whole
+    oracle stack -- this module, kzg.py's Msm / query sets, ipa.py -- to `mod` (oracle/pallas.py), or back."""
+    global O, R
+    import ipa as I
+
+    O, R = mod, mod.R
+    K.use_curve(mod)
+    I.use_curve(mod)
+
+
 # ---------------------------------------------------------------- domain
 def root_of_unity(k):
-    """`root_of_unity` (arithmetic.rs:85-94): Fr::ROOT_OF_UNITY = 7^((r-1)/2^28), squared 28-k times."""
-    assert k <= 28
-    w = pow(7, (R - 1) >> 28, R)
-    for _ in range(28 - k):
+    """`root_of_unity` (arithmetic.rs:85-94): F::ROOT_OF_UNITY = g^((r-1)/2^S), squared S-k times
+    (bn256 Fr: g = 7, S = 28; pasta: g = 5, S = 32)."""
+    s_, g_ = O.TWO_ADICITY, O.MULT_GEN
+    assert k <= s_
+    w = pow(g_, (R - 1) >> s_, R)
+    for _ in range(s_ - k):
         w = w * w % R
     return w
 

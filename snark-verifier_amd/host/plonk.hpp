@@ -216,6 +216,7 @@ struct CommonPolyEval {
 
 template <class MOS>
 struct MosProof;
+#if !defined(SNARKV_HOST_PALLAS)  // KZG: BN254 only
 template <>
 struct MosProof<Gwc19> {
   using type = Gwc19Proof;
@@ -224,6 +225,7 @@ template <>
 struct MosProof<Bdfg21> {
   using type = Bdfg21Proof;
 };
+#endif
 template <>
 struct MosProof<Bgh19> {
   using type = Bgh19Proof;
@@ -239,6 +241,7 @@ struct NoAccumulatorEncoding {
     throw Panic("AccumulatorEncoding::from_repr: unimplemented!() (reference pcs.rs:182)");
   }
 };
+#if !defined(SNARKV_HOST_PALLAS)  // KZG: BN254 only
 template <class MOS>
 struct PcsOf {
   using Svk = KzgSuccinctVerifyingKey;
@@ -249,6 +252,10 @@ struct PcsOf {
     return KzgAs<MOS>::decide_all(dk, accs);
   }
 };
+#else
+template <class MOS>
+struct PcsOf;
+#endif
 template <>
 struct PcsOf<Bgh19> {
   using Svk = IpaSuccinctVerifyingKey;
@@ -486,6 +493,7 @@ struct PlonkProof {
   }
 };
 
+#if !defined(SNARKV_HOST_PALLAS)  // KZG: BN254 only
 template <>
 inline Result<Gwc19Proof> PlonkProof<Gwc19>::read_pcs(const KzgSuccinctVerifyingKey&, const PlonkProtocol& pr,
                                                       Transcript& t) {
@@ -496,6 +504,7 @@ inline Result<Bdfg21Proof> PlonkProof<Bdfg21>::read_pcs(const KzgSuccinctVerifyi
                                                         Transcript& t) {
   return Bdfg21Proof::read(t);
 }
+#endif
 template <>
 inline Result<Bgh19Proof> PlonkProof<Bgh19>::read_pcs(const IpaSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
                                                       Transcript& t) {
@@ -504,6 +513,7 @@ inline Result<Bgh19Proof> PlonkProof<Bgh19>::read_pcs(const IpaSuccinctVerifying
   return IpaBgh19::read_proof(svk, qs, t);
 }
 
+#if !defined(SNARKV_HOST_PALLAS)  // KZG: BN254 only
 namespace plonk_detail {
 inline std::pair<MsmT, MsmT> pcs_msms(const std::vector<MsmT>& cm, const Fr& z, const std::vector<Query<Fr>>& q,
                                       const Gwc19Proof& p) {
@@ -514,6 +524,7 @@ inline std::pair<MsmT, MsmT> pcs_msms(const std::vector<MsmT>& cm, const Fr& z, 
   return bdfg21::msms(cm, z, q, p);
 }
 }  // namespace plonk_detail
+#endif
 
 // cost.rs:5-33 + the `CostEstimation` impls (gwc19.rs:168-175, bdfg21.rs:379-385, plonk.rs:149-188)
 struct Cost {
@@ -527,6 +538,7 @@ struct Cost {
            num_msm == o.num_msm && num_pairing == o.num_pairing;
   }
 };
+#if !defined(SNARKV_HOST_PALLAS)  // KZG: BN254 only
 inline Cost pcs_estimate_cost(Gwc19, const std::vector<Query<std::monostate>>& queries) {
   std::vector<Query<Fr>> qs;
   for (auto& q : queries) qs.push_back(Query<Fr>{q.poly, q.shift, Fr()});
@@ -542,6 +554,7 @@ inline Cost pcs_estimate_cost(Bdfg21, const std::vector<Query<std::monostate>>&)
   c.num_msm = 2;
   return c;
 }
+#endif
 
 // verifier/plonk.rs:32-92
 template <class MOS>
@@ -556,6 +569,7 @@ struct PlonkSuccinctVerifier {
     return Proof::read(svk, pr, instances, t);
   }
 
+#if !defined(SNARKV_HOST_PALLAS)  // KZG: BN254 only
   // the host part of `verify`: the (lhs, rhs) pair lists of the PCS accumulator
   static Result<std::pair<Pairs, Pairs>> msm_pairs(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
                                                    const std::vector<std::vector<Fr>>& instances, const Proof& proof) {
@@ -572,6 +586,7 @@ struct PlonkSuccinctVerifier {
     }
   }
 
+#endif
   // plonk.rs:58-92: [new accumulator] ++ old accumulators
   static Result<std::vector<Accumulator>> verify(const Svk& svk, const PlonkProtocol& pr,
                                                  const std::vector<std::vector<Fr>>& instances, const Proof& proof) {
@@ -590,16 +605,20 @@ struct PlonkSuccinctVerifier {
       } catch (const InvalidProtocol& e) {
         return R::Err(Error{Error::InvalidProtocol, e.what()});
       }
-    } else {
+    }
+#if !defined(SNARKV_HOST_PALLAS)
+    else {
       auto prs = msm_pairs(svk, pr, instances, proof);
       if (!prs.ok()) return R::Err(prs.err);
       auto pts = L::multi_scalar_multiplication_batch({prs.value->first, prs.value->second});
       out.push_back(KzgAccumulator{pts[0], pts[1]});
     }
+#endif
     out.insert(out.end(), proof.old_accumulators.begin(), proof.old_accumulators.end());
     return R::Ok(out);
   }
 
+#if !defined(SNARKV_HOST_PALLAS)  // KZG: BN254 only
   // plonk.rs:149-176
   static Cost estimate_cost(const PlonkProtocol& pr) {
     Cost c;
@@ -640,6 +659,7 @@ struct PlonkSuccinctVerifier {
     }
     return R::Ok(out);
   }
+#endif
 };
 
 // verifier/plonk.rs:94-147: succinct verify, then `decide_all`
@@ -657,12 +677,14 @@ struct PlonkVerifier {
     if (!accs.ok()) return accs.err;
     return PcsOf<MOS>::decide_all(vk, *accs.value);
   }
+#if !defined(SNARKV_HOST_PALLAS)  // KZG: BN254 only
   // plonk.rs:178-188
   static Cost estimate_cost(const PlonkProtocol& pr) {
     Cost c = PlonkSuccinctVerifier<MOS>::estimate_cost(pr);
     c.num_pairing += 2;
     return c;
   }
+#endif
 };
 
 }  // namespace snarkv_host

@@ -16,26 +16,7 @@ using namespace snarkv_host;
 
 namespace {
 
-struct Reader {
-  const uint8_t* p;
-  Fr fr() {
-    Fr x;
-    if (!Fr::from_bytes(p, &x)) throw Panic("non-canonical Fr in test input");
-    p += 32;
-    return x;
-  }
-  G1Affine g1() {
-    G1Affine x = G1Affine::from_bytes(p);
-    p += 64;
-    return x;
-  }
-  uint32_t u32() {
-    uint32_t v;
-    memcpy(&v, p, 4);
-    p += 4;
-    return v;
-  }
-};
+#include "driver_parse.inc"
 
 // Deterministic stand-in for the hash transcripts (out of the hot path): the
 // test supplies the challenges / points it wants "read".
@@ -61,153 +42,6 @@ struct ScriptedTranscript : Transcript {
   }
   Error write_scalar(const Fr&) override { return {}; }
 };
-
-// commitments: n, then per commitment: has_const(u32) [const] k(u32) {scalar, point} x k
-void read_commitments(Reader& rd, std::vector<std::vector<G1Affine>>& store, std::vector<MsmT>& out) {
-  uint32_t n = rd.u32();
-  store.resize(n);
-  std::vector<std::pair<std::optional<Fr>, std::vector<Fr>>> tmp(n);
-  for (uint32_t i = 0; i < n; ++i) {
-    if (rd.u32()) tmp[i].first = rd.fr();
-    uint32_t k = rd.u32();
-    for (uint32_t j = 0; j < k; ++j) {
-      tmp[i].second.push_back(rd.fr());
-      store[i].push_back(rd.g1());
-    }
-  }
-  for (uint32_t i = 0; i < n; ++i) {
-    MsmT m;
-    if (tmp[i].first) m = MsmT::from_constant(*tmp[i].first);
-    for (size_t j = 0; j < store[i].size(); ++j) m += MsmT::base(&store[i][j]) * tmp[i].second[j];
-    out.push_back(m);
-  }
-}
-
-std::vector<Query<Fr>> read_queries(Reader& rd) {
-  uint32_t n = rd.u32();
-  std::vector<Query<Fr>> q;
-  for (uint32_t i = 0; i < n; ++i) {
-    uint32_t poly = rd.u32();
-    Fr shift = rd.fr();
-    Fr ev = rd.fr();
-    q.push_back(Query<Fr>{poly, shift, ev});
-  }
-  return q;
-}
-
-// ---- PLONK protocol / instances wire format of the tests (tests/plonk_synth.py)
-struct PReader {
-  const uint8_t* p;
-  const uint8_t* end;
-  void need(size_t n) {
-    if ((size_t)(end - p) < n) throw Panic("truncated protocol bytes");
-  }
-  uint8_t u8() {
-    need(1);
-    return *p++;
-  }
-  uint32_t u32() {
-    need(4);
-    uint32_t v;
-    memcpy(&v, p, 4);
-    p += 4;
-    return v;
-  }
-  int32_t i32() {
-    need(4);
-    int32_t v;
-    memcpy(&v, p, 4);
-    p += 4;
-    return v;
-  }
-  Fr fr() {
-    need(32);
-    Fr x;
-    if (!Fr::from_bytes(p, &x)) throw Panic("non-canonical Fr in protocol bytes");
-    p += 32;
-    return x;
-  }
-  G1Affine g1() {
-    need(64);
-    G1Affine x = G1Affine::from_bytes(p);
-    p += 64;
-    return x;
-  }
-};
-
-ExprPtr parse_expr(PReader& rd) {
-  auto e = std::make_shared<Expression>();
-  switch (rd.u8()) {
-    case 0: e->kind = Expression::Constant; e->scalar = rd.fr(); break;
-    case 1: e->kind = Expression::Identity; break;
-    case 2: e->kind = Expression::Lagrange; e->lagrange = rd.i32(); break;
-    case 3: e->kind = Expression::Polynomial; e->query.poly = rd.u32(); e->query.rotation = rd.i32(); break;
-    case 4: e->kind = Expression::Challenge; e->index = rd.u32(); break;
-    case 5: e->kind = Expression::Negated; e->ch.push_back(parse_expr(rd)); break;
-    case 6: e->kind = Expression::Sum; e->ch.push_back(parse_expr(rd)); e->ch.push_back(parse_expr(rd)); break;
-    case 7: e->kind = Expression::Product; e->ch.push_back(parse_expr(rd)); e->ch.push_back(parse_expr(rd)); break;
-    case 8: e->kind = Expression::Scaled; e->ch.push_back(parse_expr(rd)); e->scalar = rd.fr(); break;
-    case 9: {
-      e->kind = Expression::DistributePowers;
-      uint32_t n = rd.u32();
-      for (uint32_t i = 0; i < n; ++i) e->ch.push_back(parse_expr(rd));
-      e->ch.push_back(parse_expr(rd));
-      break;
-    }
-    default: throw Panic("bad expression tag");
-  }
-  return e;
-}
-
-PlonkProtocol parse_protocol(const uint8_t* b, size_t len) {
-  PReader rd{b, b + len};
-  PlonkProtocol pr;
-  uint32_t k = rd.u32();
-  pr.domain = Domain::make(k, rd.fr());
-  for (uint32_t n = rd.u32(), i = 0; i < n; ++i) pr.preprocessed.push_back(rd.g1());
-  for (auto* v : {&pr.num_instance, &pr.num_witness, &pr.num_challenge})
-    for (uint32_t n = rd.u32(), i = 0; i < n; ++i) v->push_back(rd.u32());
-  for (auto* v : {&pr.evaluations, &pr.queries})
-    for (uint32_t n = rd.u32(), i = 0; i < n; ++i) {
-      PQuery q;
-      q.poly = rd.u32();
-      q.rotation = rd.i32();
-      v->push_back(q);
-    }
-  pr.quotient.chunk_degree = rd.u32();
-  pr.quotient.num_chunk = rd.u32();
-  pr.quotient.numerator = parse_expr(rd);
-  if (rd.u8()) pr.transcript_initial_state = rd.fr();
-  if (rd.u8()) {
-    InstanceCommittingKey ick;
-    for (uint32_t n = rd.u32(), i = 0; i < n; ++i) ick.bases.push_back(rd.g1());
-    if (rd.u8()) ick.constant = rd.g1();
-    pr.instance_committing_key = ick;
-  }
-  uint8_t lin = rd.u8();
-  pr.linearization = lin == 0 ? Linearization::None : lin == 1 ? Linearization::WithoutConstant : Linearization::MinusVanishingTimesQuotient;
-  for (uint32_t n = rd.u32(), i = 0; i < n; ++i) {
-    std::vector<std::pair<size_t, size_t>> idx;
-    for (uint32_t m = rd.u32(), j = 0; j < m; ++j) {
-      uint32_t a = rd.u32(), c = rd.u32();
-      idx.emplace_back(a, c);
-    }
-    pr.accumulator_indices.push_back(idx);
-  }
-  if (rd.p != rd.end) throw Panic("trailing protocol bytes");
-  return pr;
-}
-
-std::vector<std::vector<Fr>> parse_instances(const uint8_t* b, size_t len) {
-  PReader rd{b, b + len};
-  std::vector<std::vector<Fr>> out;
-  for (uint32_t n = rd.u32(), i = 0; i < n; ++i) {
-    std::vector<Fr> v;
-    for (uint32_t m = rd.u32(), j = 0; j < m; ++j) v.push_back(rd.fr());
-    out.push_back(v);
-  }
-  return out;
-}
 
 int error_code(const Error& e) {
   switch (e.kind) {
@@ -795,51 +629,3 @@ std::unique_ptr<Transcript> make_transcript(int tkind, const uint8_t* proof, siz
 }  // namespace
 #define SNARKV_DRV(name) hd_##name
 #include "ipa_driver.inc"
-
-// `IpaAs<Bgh19>` as a PolynomialCommitmentScheme (bgh19.rs:26-96): read_proof + verify.
-//   commitments: pack_commitments format (the Msm list);  queries: pack_queries format
-extern "C" int hd_ipa_bgh19_verify(int tkind, const uint8_t* svk_bytes, const uint8_t* commitments, const uint8_t* x32,
-                                   const uint8_t* queries, const uint8_t* proof, size_t plen, uint8_t* acc_out) {
-  return guarded([&] {
-    IpaSuccinctVerifyingKey svk = parse_ipa_svk(svk_bytes);
-    Reader rc{commitments}, rq{queries};
-    std::vector<std::vector<G1Affine>> store;
-    std::vector<MsmT> cms;
-    read_commitments(rc, store, cms);
-    auto qs = read_queries(rq);
-    Fr x;
-    if (!Fr::from_bytes(x32, &x)) return -3;
-    auto t = make_transcript(tkind, proof, plen);
-    auto pr = IpaBgh19::read_proof(svk, qs, *t);
-    if (!pr.ok()) return error_code(pr.err);
-    auto acc = IpaBgh19::verify(svk, cms, x, qs, *pr.value);
-    if (!acc.ok()) return error_code(acc.err);
-    put_ipa_acc(*acc.value, acc_out);
-    return 1;
-  });
-}
-
-// `PlonkVerifier<IpaAs<Bgh19>>::{read_proof, verify}` (verifier/plonk.rs:94-147; the reference's
-// system/halo2/test/ipa/native.rs flow): succinct verify -> IpaAccumulator -> `decide_all` (one device
-// Pippenger over the 2^k committing-key points).  acc_out (if non-null): k x xi | u.
-// Returns 1 accept, 0 reject (succinct check or decide failed), -10 Transcript, -11 InvalidInstances.
-extern "C" int hd_plonk_ipa_verify(int tkind, const uint8_t* protocol, size_t plen, const uint8_t* instances, size_t ilen,
-                                   const uint8_t* proof, size_t prlen, const uint8_t* svk_bytes, const uint8_t* g,
-                                   size_t n_g, uint8_t* acc_out, int decide) {
-  return guarded([&] {
-    PlonkProtocol pr = parse_protocol(protocol, plen);
-    IpaDecidingKey dk;
-    dk.svk = parse_ipa_svk(svk_bytes);
-    dk.g.resize(n_g);
-    for (size_t i = 0; i < n_g; ++i) dk.g[i] = G1Affine::from_bytes(g + 64 * i);
-    auto insts = parse_instances(instances, ilen);
-    auto t = make_transcript(tkind, proof, prlen);
-    auto pf = PlonkVerifier<Bgh19>::read_proof(dk, pr, insts, *t);
-    if (!pf.ok()) return error_code(pf.err);
-    auto accs = PlonkSuccinctVerifier<Bgh19>::verify(dk.svk, pr, insts, *pf.value);
-    if (!accs.ok()) return error_code(accs.err);
-    if (acc_out) put_ipa_acc((*accs.value)[0], acc_out);
-    if (!decide) return 1;
-    return PlonkVerifier<Bgh19>::verify(dk, pr, insts, *pf.value).ok() ? 1 : 0;
-  });
-}

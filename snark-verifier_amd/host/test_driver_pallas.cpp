@@ -1,8 +1,10 @@
 // Test driver of the PASTA flavour of the host mirror -> libsnarkv_host_pallas.so (compiled with
 // -DSNARKV_HOST_PALLAS: `Fr` = pallas::Scalar, the loader bound to libsnarkv_pallas.so).  It carries the
-// curve-generic part of the mirror -- Msm, the native loader, the IPA layer (host/ipa.hpp) -- with halo2's
+// curve-generic part of the mirror -- Msm, the native loader, the IPA layer (host/ipa.hpp), the PLONK
+// verifier over `IpaAs<Bgh19>` (host/plonk.hpp) -- with halo2's
 // Blake2b transcript: the reference's own `test_ipa` / `test_ipa_as` setting (pcs/ipa.rs:434-466,
-// pcs/ipa/accumulation.rs:240-290).  KZG (pairing) and the EVM / Poseidon transcripts stay BN254.
+// pcs/ipa/accumulation.rs:240-290, system/halo2/test/ipa/native.rs).  KZG (pairing) and the EVM / Poseidon
+// transcripts stay BN254.
 #ifndef SNARKV_HOST_PALLAS
 #error "compile with -DSNARKV_HOST_PALLAS"
 #endif
@@ -13,10 +15,13 @@
 
 #include "blake2b_transcript.hpp"
 #include "ipa.hpp"
+#include "plonk.hpp"
 
 using namespace snarkv_host;
 
 namespace {
+#include "driver_parse.inc"
+
 int error_code(const Error& e) {
   switch (e.kind) {
     case Error::Transcript: return -10;

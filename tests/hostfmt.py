@@ -8,6 +8,12 @@ import bn254 as O
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def use_curve(mod):
+    """Pack scenario inputs for another curve module (oracle/pallas.py): scalars reduce mod ITS r."""
+    global O
+    O = mod
+
+
 def load_host_lib():
     import snark_verifier_amd as sv
 

@@ -13,6 +13,13 @@ import plonk as P
 R = O.R
 
 
+def use_curve(mod):
+    """Synthesise protocols over another curve module (oracle/pallas.py); switches plonk.py / kzg.py / ipa.py too."""
+    global O, R
+    O, R = mod, mod.R
+    P.use_curve(mod)
+
+
 def const(v):
     return ("const", v % R)
 

@@ -42,14 +42,21 @@ def HP():
     h.hp_ipa_as_verify.argtypes = [ctypes.c_int, cp, cp, u32, cp, sz, cp]
     h.hp_ipa_decide_all.argtypes = [u32, cp, sz, cp, u32]
     h.hp_ipa_h.argtypes = [u32, cp, cp, cp]
+    h.hp_ipa_bgh19_verify.argtypes = [ctypes.c_int, cp, cp, cp, cp, cp, sz, cp]
+    h.hp_plonk_ipa_verify.argtypes = [ctypes.c_int, cp, sz, cp, sz, cp, sz, cp, cp, sz, cp, ctypes.c_int]
     return h
 
 
 @pytest.fixture()
 def on_pallas():
-    I.use_curve(PA)
+    import hostfmt
+    import plonk_synth as S
+
+    S.use_curve(PA)  # plonk_synth -> plonk -> kzg, ipa
+    hostfmt.use_curve(PA)
     yield
-    I.use_curve(BN)
+    S.use_curve(BN)
+    hostfmt.use_curve(BN)
 
 
 def _buf(n):
@@ -166,3 +173,85 @@ def test_ipa_on_pallas_cpp_verifier_device_msms(HP, on_pallas, k, zk):
     assert HP.hp_ipa_decide_all(k, gb, n, bad, 1) == 0
     assert HP.hp_ipa_decide_all(k, gb, n, b"".join(accs) + bad, len(accs) + 1) == 0
     assert HP.hp_ipa_as_verify(2, svk, accs[0], 1, as_proof, len(as_proof), out) == -100  # accumulation.rs:107
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(4))
+def test_bgh19_multiopen_on_pallas(HP, on_pallas, seed):
+    """`IpaAs<pallas, Bgh19>` as a PCS (multiopen/bgh19.rs:26-153): honest openings from the oracle's
+    polynomial prover, random query patterns, through the C++ reader + verifier + device decide."""
+    import kzg as K
+    from hostfmt import pack_commitments, pack_queries
+
+    rng = random.Random(300 + seed)
+    rnd = lambda: rng.randrange(PA.R)  # noqa: E731
+    k = rng.randrange(3, 6)
+    n = 1 << k
+    pts = PA.sample_points(300 + seed, n + 2)
+    pk = I.IpaProvingKey(k, pts[:n], pts[n], pts[n + 1])
+    npoly = rng.randrange(2, 6)
+    polys = [[rnd() for _ in range(n)] for _ in range(npoly)]
+    blinds = [rnd() for _ in polys]
+    coms = [pk.commit(p, b) for p, b in zip(polys, blinds)]
+    w = pow(PA.MULT_GEN, (PA.R - 1) // n, PA.R)
+    shifts = [pow(w, e % n, PA.R) for e in (0, 1, -1, 2)]
+    x = rnd()
+    spec = [(p, 0) for p in range(npoly)] + [(rng.randrange(npoly), rng.randrange(4)) for _ in range(rng.randrange(1, 8))]
+    queries = [(p, shifts[s], I.poly_eval(polys[p], x * shifts[s] % PA.R)) for p, s in spec]
+    t = T.Blake2bTranscript(PA)
+    I.bgh19_create_proof(pk, polys, blinds, x, queries, t, rnd)
+    proof = t.finalize()
+    exp = I.bgh19_verify(pk.g[0], pk.h, pk.s, [K.Msm.base(c) for c in coms], x, queries,
+                         I.bgh19_read_proof(k, queries, T.Blake2bTranscript(PA, proof)))
+    assert I.ipa_decide(pk.g, exp)
+    out = _buf(32 * k + 64)
+    svk = pack_svk(k, pk.g[0], pk.h, pk.s)
+    cm = pack_commitments([K.Msm.base(p) for p in coms])
+    assert HP.hp_ipa_bgh19_verify(2, svk, cm, PA.fe_to_bytes(x), pack_queries(queries), proof, len(proof), out) == 1
+    assert out.raw == pack_acc(exp)
+    gb = b"".join(PA.g1_to_bytes(p) for p in pk.g)
+    assert HP.hp_ipa_decide_all(k, gb, n, out.raw, 1) == 1
+    bad = list(queries)
+    bad[0] = (bad[0][0], bad[0][1], (bad[0][2] + 1) % PA.R)
+    assert HP.hp_ipa_bgh19_verify(2, svk, cm, PA.fe_to_bytes(x), pack_queries(bad), proof, len(proof), out) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lin", [None, "WithoutConstant", "MinusVanishingTimesQuotient"])
+def test_plonk_verifier_over_ipa_on_pallas(HP, on_pallas, lin):
+    """`PlonkVerifier<IpaAs<pallas::Affine, Bgh19>>` with halo2's Blake2b transcript -- the configuration of
+    the reference's system/halo2/test/ipa/native.rs (zk StandardPlonk) -- on proofs forged under a
+    committing key with known discrete logs: C++ accumulator bytes == oracle, decide on the device."""
+    import plonk as P
+    import plonk_synth as S
+
+    rng = random.Random("pallas-plonk-%s" % lin)
+    k = 5
+    pr, dl = S.standard_plonk_protocol(rng, k=k, linearization=lin, num_instance=(2, 3))
+    inst = [[rng.randrange(PA.R) for _ in range(m)] for m in pr["num_instance"]]
+    kd = {"g": [rng.randrange(1, PA.R) for _ in range(1 << k)], "h": rng.randrange(1, PA.R), "s": rng.randrange(1, PA.R)}
+    g = [PA.g1_mul(PA.G1_GEN, c) for c in kd["g"]]
+    h, s = PA.g1_mul(PA.G1_GEN, kd["h"]), PA.g1_mul(PA.G1_GEN, kd["s"])
+    mk = lambda stream=b"": T.Blake2bTranscript(PA, stream)  # noqa: E731
+    proof = P.forge_proof_ipa(pr, inst, kd, mk, rng, dl)
+    exp = P.succinct_verify_ipa(g[0], h, s, pr, inst, P.plonk_proof_read(pr, inst, mk(proof), "bgh19"))
+    assert I.ipa_decide(g, exp[0])
+    pb, ib = S.pack_protocol(pr), S.pack_instances(inst)
+    gb = b"".join(PA.g1_to_bytes(p) for p in g)
+    svk = pack_svk(k, g[0], h, s)
+    out = _buf(32 * k + 64)
+
+    def run(proof_bytes, instances=ib, key=gb, decide=1):
+        return HP.hp_plonk_ipa_verify(2, pb, len(pb), instances, len(instances), proof_bytes, len(proof_bytes), svk, key,
+                                      len(key) // 64, out, decide)
+
+    assert run(proof) == 1 and out.raw == pack_acc(exp[0])
+    for pos in (0, len(proof) // 2, len(proof) - 1):
+        bad = bytearray(proof)
+        bad[pos] ^= 1
+        assert run(bytes(bad)) in (0, -10)
+    inst2 = [list(v) for v in inst]
+    inst2[0][0] = (inst2[0][0] + 1) % PA.R
+    assert run(proof, instances=S.pack_instances(inst2)) == 0
+    gb2 = gb[:64 * 3] + gb[64 * 4:64 * 5] + gb[64 * 4:]
+    assert run(proof, key=gb2, decide=0) == 1 and run(proof, key=gb2, decide=1) == 0  # only `decide` sees G_i, i > 0
