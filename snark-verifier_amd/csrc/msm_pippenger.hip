@@ -68,6 +68,9 @@ namespace snarkv {
 #ifndef SNARKV_TILE_THREADS
 #define SNARKV_TILE_THREADS 512  // tile workgroups of k_prepare / k_sort_scatter (256 left the chip at 1 wave/SIMD)
 #endif
+#ifndef SNARKV_TILE_BASE
+#define SNARKV_TILE_BASE 4096  // smallest tile (scalars per k_prepare / k_sort_scatter workgroup)
+#endif
 #ifndef SNARKV_ACC_WAVES
 #define SNARKV_ACC_WAVES 3
 #endif
@@ -830,7 +833,7 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   p.SB = p.B >> p.low_bits;
   p.nkeys = (uint32_t)p.W * p.SB;
   // tile: >= 16 items per (tile, key) stream so partition writes fill 128-byte lines
-  p.tile = 4096;
+  p.tile = SNARKV_TILE_BASE;
   while (p.tile < 65536 && (uint64_t)p.tile * kHalves * p.W < 16ull * p.nkeys) p.tile *= 2;
   p.nblk = (uint32_t)((n + p.tile - 1) / p.tile);
   p.mstride = p.nblk | 1u;
