@@ -110,6 +110,23 @@ SNARKV_HD Fq29 fq29_norm(const Fq29& a) {
   return r;
 }
 
+// acc + a*b for signed 32-bit a, b: ONE `v_mad_i64_i32`.  Written as an instruction on the device
+// because the compiler, knowing that masked limbs are non-negative, turns a mixed-sign product into
+// `v_mad_u64_u32` plus a sign fix-up (shift, move, subtract): ~1.5 instructions per product where the
+// hardware needs one, and on this machine every VOP3 instruction costs the same issue slot
+// (profiles/r01_ubench_isa_rates.txt).  The carry-out goes to VCC, dead.  Only the OPERAND products go
+// through it: the reduction products m_i * p_j (both non-negative, p_j an SGPR constant) already compile to
+// one `v_mad_u64_u32` each, and keeping them a separate accumulator chain measured faster than one chain
+// (the compiler pads consecutive VCC-writing asm statements with s_nop: 2.51 vs 2.42 ms per 2^20 MSM).
+SNARKV_HD int64_t fq29_smad(int32_t a, int32_t b, int64_t acc) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNARKV_NO_SMAD_ASM)
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+  return acc;
+#else
+  return acc + (int64_t)a * b;
+#endif
+}
+
 // Montgomery product a*b*2^-261 (mod p), column-wise (product scanning) with a
 // single 64-bit accumulator: 81 + 81 `v_mad_i64_i32`, 17 64-bit shifts, 9
 // `v_mul_lo_u32`.
@@ -120,7 +137,7 @@ SNARKV_HD Fq29 fq29_mul(const Fq29& a, const Fq29& b) {
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
 #pragma unroll
-    for (int i = 0; i <= k; ++i) acc += (int64_t)a.v[i] * b.v[k - i];
+    for (int i = 0; i <= k; ++i) acc = fq29_smad(a.v[i], b.v[k - i], acc);
 #pragma unroll
     for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * fq29_p(k - i);
     m[k] = (int32_t)(((uint32_t)acc * (uint32_t)SNARKV_FQ29_NINV) & (uint32_t)kMask29);
@@ -130,7 +147,7 @@ SNARKV_HD Fq29 fq29_mul(const Fq29& a, const Fq29& b) {
 #pragma unroll
   for (int k = 9; k < 17; ++k) {
 #pragma unroll
-    for (int i = k - 8; i < 9; ++i) acc += (int64_t)a.v[i] * b.v[k - i];
+    for (int i = k - 8; i < 9; ++i) acc = fq29_smad(a.v[i], b.v[k - i], acc);
 #pragma unroll
     for (int i = k - 8; i < 9; ++i) acc += (int64_t)m[i] * fq29_p(k - i);
     r.v[k - 9] = (int32_t)acc & kMask29;
@@ -151,9 +168,9 @@ SNARKV_HD Fq29 fq29_mul2(const Fq29& a, const Fq29& b, const Fq29& c, const Fq29
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
 #pragma unroll
-    for (int i = 0; i <= k; ++i) acc += (int64_t)a.v[i] * b.v[k - i];
+    for (int i = 0; i <= k; ++i) acc = fq29_smad(a.v[i], b.v[k - i], acc);
 #pragma unroll
-    for (int i = 0; i <= k; ++i) acc += (int64_t)c.v[i] * d.v[k - i];
+    for (int i = 0; i <= k; ++i) acc = fq29_smad(c.v[i], d.v[k - i], acc);
 #pragma unroll
     for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * fq29_p(k - i);
     m[k] = (int32_t)(((uint32_t)acc * (uint32_t)SNARKV_FQ29_NINV) & (uint32_t)kMask29);
@@ -163,9 +180,9 @@ SNARKV_HD Fq29 fq29_mul2(const Fq29& a, const Fq29& b, const Fq29& c, const Fq29
 #pragma unroll
   for (int k = 9; k < 17; ++k) {
 #pragma unroll
-    for (int i = k - 8; i < 9; ++i) acc += (int64_t)a.v[i] * b.v[k - i];
+    for (int i = k - 8; i < 9; ++i) acc = fq29_smad(a.v[i], b.v[k - i], acc);
 #pragma unroll
-    for (int i = k - 8; i < 9; ++i) acc += (int64_t)c.v[i] * d.v[k - i];
+    for (int i = k - 8; i < 9; ++i) acc = fq29_smad(c.v[i], d.v[k - i], acc);
 #pragma unroll
     for (int i = k - 8; i < 9; ++i) acc += (int64_t)m[i] * fq29_p(k - i);
     r.v[k - 9] = (int32_t)acc & kMask29;
@@ -185,8 +202,8 @@ SNARKV_HD Fq29 fq29_sqr(const Fq29& a) {
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
 #pragma unroll
-    for (int i = 0; 2 * i < k; ++i) acc += (int64_t)a2[i] * a.v[k - i];
-    if ((k & 1) == 0) acc += (int64_t)a.v[k / 2] * a.v[k / 2];
+    for (int i = 0; 2 * i < k; ++i) acc = fq29_smad(a2[i], a.v[k - i], acc);
+    if ((k & 1) == 0) acc = fq29_smad(a.v[k / 2], a.v[k / 2], acc);
 #pragma unroll
     for (int i = 0; i < k; ++i) acc += (int64_t)m[i] * fq29_p(k - i);
     m[k] = (int32_t)(((uint32_t)acc * (uint32_t)SNARKV_FQ29_NINV) & (uint32_t)kMask29);
@@ -196,8 +213,8 @@ SNARKV_HD Fq29 fq29_sqr(const Fq29& a) {
 #pragma unroll
   for (int k = 9; k < 17; ++k) {
 #pragma unroll
-    for (int i = k - 8; 2 * i < k; ++i) acc += (int64_t)a2[i] * a.v[k - i];
-    if ((k & 1) == 0) acc += (int64_t)a.v[k / 2] * a.v[k / 2];
+    for (int i = k - 8; 2 * i < k; ++i) acc = fq29_smad(a2[i], a.v[k - i], acc);
+    if ((k & 1) == 0) acc = fq29_smad(a.v[k / 2], a.v[k / 2], acc);
 #pragma unroll
     for (int i = k - 8; i < 9; ++i) acc += (int64_t)m[i] * fq29_p(k - i);
     r.v[k - 9] = (int32_t)acc & kMask29;

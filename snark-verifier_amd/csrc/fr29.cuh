@@ -47,7 +47,9 @@ SNARKV_HD Fr29 fr29_norm(const Fr29& a) {
   r.v[8] = a.v[8] + c;
   return r;
 }
-// Montgomery product a*b*2^-261 (mod r); |limb| < 2^30 on both sides.  Result carry-normalised,
+// Montgomery product a*b*2^-261 (mod r); |limb| < 2^30 on both sides.  (Plain C products on purpose: the
+// explicit `fq29_smad` form that pays off in the throughput-bound G1 kernels slows the latency-bound
+// Poseidon kernel down -- one wavefront per SIMD, where the compiler's two interleaved chains hide latency.)  Result carry-normalised,
 // value in (-r/8, 9r/8) for |a|, |b| < 8r.
 SNARKV_HD Fr29 fr29_mul(const Fr29& a, const Fr29& b) {
   int32_t m[9];
