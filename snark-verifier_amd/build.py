@@ -46,18 +46,23 @@ def _compile(unit, verbose, extra=(), tag=""):
 
 def build(verbose=False):
     os.makedirs(BUILD, exist_ok=True)
-    with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
-        res = list(ex.map(lambda u: _compile(u, verbose), UNITS))
-    objs = [o for o, _ in res]
-    if any(ch for _, ch in res) or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    # every unit of both libraries in one pool (hipcc is single-threaded per unit)
+    jobs = [(u, (), "") for u in UNITS] + [(u, tuple(PALLAS_FLAGS), "_pallas") for u in PALLAS_UNITS]
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+        res = list(ex.map(lambda j: _compile(j[0], verbose, j[1], j[2]), jobs))
+    _link(LIB, res[:len(UNITS)], [])
+    _link(PALLAS_LIB, res[len(UNITS):], ["-Wl,-Bsymbolic"])  # its internals never bind by symbol lookup across libraries
+    build_host_driver()
+    return LIB
+
+
+def _link(lib, res, extra):
+    if any(ch for _, ch in res) or not os.path.exists(lib):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + extra + ["-o", lib] + [o for o, _ in res]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)
-            raise RuntimeError("link failed")
-    build_pallas(verbose)
-    build_host_driver()
-    return LIB
+            raise RuntimeError("link failed: %s" % os.path.basename(lib))
 
 
 # The pasta build of the curve-generic units (csrc/pallas.hip explains the flags).
@@ -70,13 +75,7 @@ def build_pallas(verbose=False):
     os.makedirs(BUILD, exist_ok=True)
     with ThreadPoolExecutor(max_workers=len(PALLAS_UNITS)) as ex:
         res = list(ex.map(lambda u: _compile(u, verbose, PALLAS_FLAGS, "_pallas"), PALLAS_UNITS))
-    if any(ch for _, ch in res) or not os.path.exists(PALLAS_LIB):
-        # -Bsymbolic: the two libraries share extern-"C"-free internals by design, never by symbol lookup
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", PALLAS_LIB] + [o for o, _ in res]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            sys.stderr.write(r.stdout + r.stderr)
-            raise RuntimeError("link failed (pallas)")
+    _link(PALLAS_LIB, res, ["-Wl,-Bsymbolic"])
     return PALLAS_LIB
 
 
