@@ -63,7 +63,7 @@ namespace snarkv {
 #define SNARKV_KRUN 32
 #endif
 #ifndef SNARKV_KCHUNK
-#define SNARKV_KCHUNK 4
+#define SNARKV_KCHUNK 8
 #endif
 #ifndef SNARKV_TILE_THREADS
 #define SNARKV_TILE_THREADS 512  // tile workgroups of k_prepare / k_sort_scatter (256 left the chip at 1 wave/SIMD)
