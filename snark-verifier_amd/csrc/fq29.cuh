@@ -40,7 +40,7 @@ constexpr int32_t kMask29 = (1 << 29) - 1;
 // radix-2^29 constants (SNARKV_FQ29_P_LIMBS, SNARKV_FQ29_NINV, SNARKV_FQ29_ONE_LIMBS,
 // SNARKV_FQ29_R2_LIMBS) come from bn254_consts.h (gen_consts.py).
 
-SNARKV_HD int32_t fq29_p(int i) {
+SNARKV_HD constexpr int32_t fq29_p(int i) {
   constexpr int32_t p[9] = SNARKV_FQ29_P_LIMBS;
   return p[i];
 }
@@ -131,6 +131,9 @@ SNARKV_HD int64_t fq29_smad(int32_t a, int32_t b, int64_t acc) {
 // single 64-bit accumulator: 81 + 81 `v_mad_i64_i32`, 17 64-bit shifts, 9
 // `v_mul_lo_u32`.
 SNARKV_HD Fq29 fq29_mul(const Fq29& a, const Fq29& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNARKV_NO_SMAD_ASM)
+#include "fq29_mul_asm.inc"  // every column one chain of v_mad_i64_i32 (gen_fq29_mul_asm.py)
+#else
   int32_t m[9];
   Fq29 r;
   int64_t acc = 0;
@@ -155,6 +158,7 @@ SNARKV_HD Fq29 fq29_mul(const Fq29& a, const Fq29& b) {
   }
   r.v[8] = (int32_t)acc;
   return r;
+#endif
 }
 
 // a*b + c*d with ONE Montgomery reduction (the two halves of an Fq2 product
@@ -162,6 +166,9 @@ SNARKV_HD Fq29 fq29_mul(const Fq29& a, const Fq29& b) {
 // a carry-normalised value (|limb| < 2^29): a column then holds at most
 // 18 + 9 products of magnitude < 2^58, below 2^63.  243 mads instead of 326.
 SNARKV_HD Fq29 fq29_mul2(const Fq29& a, const Fq29& b, const Fq29& c, const Fq29& d) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNARKV_NO_SMAD_ASM)
+#include "fq29_mul2_asm.inc"
+#else
   int32_t m[9];
   Fq29 r;
   int64_t acc = 0;
@@ -190,10 +197,14 @@ SNARKV_HD Fq29 fq29_mul2(const Fq29& a, const Fq29& b, const Fq29& c, const Fq29
   }
   r.v[8] = (int32_t)acc;
   return r;
+#endif
 }
 
 // a^2; a must be carry-normalised (|limb| < 2^29): doubled limbs stay < 2^30.
 SNARKV_HD Fq29 fq29_sqr(const Fq29& a) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNARKV_NO_SMAD_ASM)
+#include "fq29_sqr_asm.inc"
+#else
   int32_t m[9], a2[9];
   Fq29 r;
 #pragma unroll
@@ -222,6 +233,7 @@ SNARKV_HD Fq29 fq29_sqr(const Fq29& a) {
   }
   r.v[8] = (int32_t)acc;
   return r;
+#endif
 }
 
 // Unique representative in [0, p), carry-normalised.  x must be within
