@@ -110,14 +110,18 @@ SNARKV_HD Fq29 fq29_norm(const Fq29& a) {
   return r;
 }
 
-// acc + a*b for signed 32-bit a, b: ONE `v_mad_i64_i32`.  Written as an instruction on the device
-// because the compiler, knowing that masked limbs are non-negative, turns a mixed-sign product into
-// `v_mad_u64_u32` plus a sign fix-up (shift, move, subtract): ~1.5 instructions per product where the
-// hardware needs one, and on this machine every VOP3 instruction costs the same issue slot
-// (profiles/r01_ubench_isa_rates.txt).  The carry-out goes to VCC, dead.  Only the OPERAND products go
-// through it: the reduction products m_i * p_j (both non-negative, p_j an SGPR constant) already compile to
-// one `v_mad_u64_u32` each, and keeping them a separate accumulator chain measured faster than one chain
-// (the compiler pads consecutive VCC-writing asm statements with s_nop: 2.51 vs 2.42 ms per 2^20 MSM).
+// How the products are issued on the device.  The compiler, knowing that masked limbs are non-negative,
+// turns a mixed-sign 32x32+64 product into `v_mad_u64_u32` plus a sign fix-up (shift, move, subtract) and
+// keeps the operand products and the reduction products in two chains joined by a 64-bit add per column:
+// 2 642 instructions per mixed G1 addition where 1 475 are multiply-adds -- and on this machine every VOP3
+// instruction costs the same issue slot (profiles/r01_ubench_isa_rates.txt).  So fq29_mul / fq29_mul2 /
+// fq29_sqr take their device bodies from gen_fq29_mul_asm.py: every column of the product scanning loop is
+// ONE chain of `v_mad_i64_i32` on the column accumulator (carry-out to VCC, dead), 2 276 instructions per
+// entry of k_accumulate.  Stepping stones, kept in DESIGN.md section 4: one asm statement per operand product
+// (-12 %), one statement per product of either kind (slower again: the compiler pads consecutive
+// VCC-writing asm statements with s_nop), one statement per column (this form).
+// -DSNARKV_NO_SMAD_ASM keeps the plain C below -- the latency-bound pairing (decider.hip) measures 3 % faster
+// with the compiler's two interleaved chains; host builds always use it.
 SNARKV_HD int64_t fq29_smad(int32_t a, int32_t b, int64_t acc) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SNARKV_NO_SMAD_ASM)
   asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
@@ -129,7 +133,7 @@ SNARKV_HD int64_t fq29_smad(int32_t a, int32_t b, int64_t acc) {
 
 // Montgomery product a*b*2^-261 (mod p), column-wise (product scanning) with a
 // single 64-bit accumulator: 81 + 81 `v_mad_i64_i32`, 17 64-bit shifts, 9
-// `v_mul_lo_u32`.
+// `v_mul_lo_u32`, 18 masks.
 SNARKV_HD Fq29 fq29_mul(const Fq29& a, const Fq29& b) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SNARKV_NO_SMAD_ASM)
 #include "fq29_mul_asm.inc"  // every column one chain of v_mad_i64_i32 (gen_fq29_mul_asm.py)
