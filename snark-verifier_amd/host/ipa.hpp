@@ -139,9 +139,15 @@ struct Ipa {
     return IpaProof::read(svk, t);
   }
 
-  // ipa.rs:139-180.  lhs = C' + eval [H'] + sum (xi_i^-1 [L_i] + xi_i [R_i]),  rhs = c [U] + v' [H'].
-  static Result<IpaAccumulator> succinct_verify(const IpaSuccinctVerifyingKey& svk, const MsmT& commitment, const Fr& z,
-                                                const Fr& eval, const IpaProof& proof) {
+  // The host half of `succinct_verify` (ipa.rs:139-180): the pair lists of
+  //   lhs = C' + eval [H'] + sum (xi_i^-1 [L_i] + xi_i [R_i])   and   rhs = c [U] + v' [H'],
+  // plus the accumulator that results if they turn out equal.  No device work.
+  struct Pending {
+    std::vector<std::pair<Fr, G1Affine>> lhs, rhs;
+    IpaAccumulator acc;
+  };
+  static Pending succinct_verify_pairs(const IpaSuccinctVerifyingKey& svk, const MsmT& commitment, const Fr& z,
+                                       const Fr& eval, const IpaProof& proof) {
     const G1Affine h = L::ec_point_load_const(svk.h);
     MsmT h_prime = MsmT::base(&h) * proof.xi_0;
     MsmT c_prime = commitment;
@@ -159,10 +165,35 @@ struct Ipa {
     }
     Fr v_prime = h_eval(xi, z) * proof.c;
     MsmT rhs = MsmT::base(&proof.u) * proof.c + h_prime * v_prime;
-    auto pts = L::multi_scalar_multiplication_batch({c_k.pairs(std::nullopt), rhs.pairs(std::nullopt)});
+    return Pending{c_k.pairs(std::nullopt), rhs.pairs(std::nullopt), IpaAccumulator{xi, proof.u}};  // pairs hold copies
+  }
+
+  // ipa.rs:139-180: the two `evaluate(None)` as one segmented launch, then `ec_point_assert_eq`
+  static Result<IpaAccumulator> succinct_verify(const IpaSuccinctVerifyingKey& svk, const MsmT& commitment, const Fr& z,
+                                                const Fr& eval, const IpaProof& proof) {
+    Pending p = succinct_verify_pairs(svk, commitment, z, eval, proof);
+    auto pts = L::multi_scalar_multiplication_batch({p.lhs, p.rhs});
     Error e = L::ec_point_assert_eq("C_k == c[U] + v'[H']", pts[0], pts[1]);
     if (!e.ok()) return Result<IpaAccumulator>::Err(e);
-    return Result<IpaAccumulator>::Ok(IpaAccumulator{xi, proof.u});
+    return Result<IpaAccumulator>::Ok(std::move(p.acc));
+  }
+
+  // Many openings at once: every (lhs, rhs) of every opening in ONE segmented launch.
+  static Result<std::vector<IpaAccumulator>> finish_batch(std::vector<Pending>& pending) {
+    using R = Result<std::vector<IpaAccumulator>>;
+    std::vector<std::vector<std::pair<Fr, G1Affine>>> jobs;
+    for (auto& p : pending) {
+      jobs.push_back(std::move(p.lhs));
+      jobs.push_back(std::move(p.rhs));
+    }
+    auto pts = jobs.empty() ? std::vector<G1Affine>() : L::multi_scalar_multiplication_batch(jobs);
+    std::vector<IpaAccumulator> out;
+    for (size_t i = 0; i < pending.size(); ++i) {
+      Error e = L::ec_point_assert_eq("C_k == c[U] + v'[H']", pts[2 * i], pts[2 * i + 1]);
+      if (!e.ok()) return R::Err(e);
+      out.push_back(std::move(pending[i].acc));
+    }
+    return R::Ok(std::move(out));
   }
 };
 
@@ -455,6 +486,13 @@ struct IpaBgh19 {
     const G1Affine g = L::ec_point_load_const(svk.g);
     MsmT p = bgh19::final_msm(&g, commitments, x, queries, proof);
     return Ipa::succinct_verify(svk, p, proof.x_3, L::load_zero(), proof.ipa);
+  }
+  // the host half only (for batches: Ipa::finish_batch launches all of them together)
+  static Ipa::Pending verify_pairs(const IpaSuccinctVerifyingKey& svk, const std::vector<MsmT>& commitments, const Fr& x,
+                                   const std::vector<Query<Fr>>& queries, const Bgh19Proof& proof) {
+    const G1Affine g = L::ec_point_load_const(svk.g);
+    MsmT p = bgh19::final_msm(&g, commitments, x, queries, proof);
+    return Ipa::succinct_verify_pairs(svk, p, proof.x_3, L::load_zero(), proof.ipa);
   }
 };
 

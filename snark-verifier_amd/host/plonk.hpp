@@ -662,6 +662,33 @@ struct PlonkSuccinctVerifier {
 #endif
 };
 
+// Many PLONK-over-IPA proofs (possibly of different protocols): the host halves in parallel, then all
+// 2 x N MSMs of the succinct checks in ONE segmented launch -- the IPA counterpart of
+// PlonkSuccinctVerifier<Gwc19 | Bdfg21>::verify_batch.  One accumulator per proof, in order.
+inline Result<std::vector<IpaAccumulator>> plonk_ipa_verify_batch(
+    const IpaSuccinctVerifyingKey& svk, const std::vector<const PlonkProtocol*>& protocols,
+    const std::vector<std::vector<std::vector<Fr>>>& instances, const std::vector<PlonkProof<Bgh19>>& proofs,
+    unsigned threads = 1) {
+  using R = Result<std::vector<IpaAccumulator>>;
+  std::vector<Ipa::Pending> pending(proofs.size());
+  std::vector<Error> errs(proofs.size());
+  parallel_for(proofs.size(), threads, [&](size_t i) {
+    try {
+      const PlonkProtocol& pr = *protocols[i];
+      CommonPolyEval cpe(pr.domain, pr.langranges(), proofs[i].z);
+      auto evals = proofs[i].evaluations_map(pr, instances[i], cpe);
+      auto cm = proofs[i].commitments(pr, cpe, evals);
+      auto queries = proofs[i].queries(pr, evals);
+      pending[i] = IpaBgh19::verify_pairs(svk, cm, proofs[i].z, queries, proofs[i].pcs);
+    } catch (const InvalidProtocol& e) {
+      errs[i] = Error{Error::InvalidProtocol, e.what()};
+    }
+  });
+  for (auto& e : errs)
+    if (!e.ok()) return R::Err(e);
+  return Ipa::finish_batch(pending);
+}
+
 // verifier/plonk.rs:94-147: succinct verify, then `decide_all`
 template <class MOS>
 struct PlonkVerifier {

@@ -377,3 +377,45 @@ def test_random_bgh19_query_patterns_with_the_polynomial_prover(H, seed):
                                  len(proof), out) == 1
     assert out.raw == pack_acc(exp)
     assert H.hd_ipa_decide_all(k, raw[:64 * n], n, out.raw, 1) == 1
+
+
+def _batch_args(H_fn):
+    H_fn.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
+                     ctypes.c_size_t, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint,
+                     ctypes.c_char_p, ctypes.c_int]
+
+
+@pytest.mark.parametrize("kind", ["evm", "poseidon"])
+def test_plonk_over_ipa_batch_is_one_launch_and_matches_single(H, kind):
+    """N proofs of one protocol: `plonk_ipa_verify_batch` (all 2N succinct-check MSMs in one segmented
+    launch, then `decide_all` with four accumulators in flight) returns, proof by proof, the accumulators
+    of the one-at-a-time path = the oracle's; one bad proof anywhere fails the batch."""
+    import struct
+
+    import plonk as P
+    import plonk_synth as S
+
+    k, n = 5, 12
+    P_, S_, rng, pr, dl, inst0, kd, g, gb, h, s = _plonk_ipa_setup("batch-%s" % kind, k, num_instance=(2,))
+    tk, Tr = TR[kind]
+    insts = [[[rng.randrange(O.R) for _ in range(2)]] for _ in range(n)]
+    proofs = [P.forge_proof_ipa(pr, insts[i], kd, Tr, rng, dl) for i in range(n)]
+    want = b"".join(pack_acc(P.succinct_verify_ipa(g[0], h, s, pr, insts[i], P.plonk_proof_read(pr, insts[i], Tr(proofs[i]), "bgh19"))[0])
+                    for i in range(n))
+    _batch_args(H.hd_plonk_ipa_verify_batch)
+    pb = S.pack_protocol(pr)
+    ib = b"".join(S.pack_instances(x) for x in insts)
+    prb = b"".join(struct.pack("<I", len(p)) + p for p in proofs)
+    svk = pack_svk(k, g[0], h, s)
+    out = _buf((32 * k + 64) * n)
+    for threads in (1, 4):
+        assert H.hd_plonk_ipa_verify_batch(tk, pb, len(pb), ib, len(ib), prb, len(prb), n, svk, gb, len(gb) // 64, threads, out, 1) == 1
+        assert out.raw == want
+    bad = list(proofs)
+    bad[7] = bad[7][:40] + bytes([bad[7][40] ^ 1]) + bad[7][41:]
+    prb2 = b"".join(struct.pack("<I", len(p)) + p for p in bad)
+    assert H.hd_plonk_ipa_verify_batch(tk, pb, len(pb), ib, len(ib), prb2, len(prb2), n, svk, gb, len(gb) // 64, 2, out, 1) in (0, -10)
+    # a wrong committing key: every succinct check passes, decide_all rejects
+    gb2 = gb[:64] + gb[128:192] + gb[128:]
+    assert H.hd_plonk_ipa_verify_batch(tk, pb, len(pb), ib, len(ib), prb, len(prb), n, svk, gb2, len(gb2) // 64, 2, out, 0) == 1
+    assert H.hd_plonk_ipa_verify_batch(tk, pb, len(pb), ib, len(ib), prb, len(prb), n, svk, gb2, len(gb2) // 64, 2, out, 1) == 0

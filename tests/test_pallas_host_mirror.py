@@ -255,3 +255,38 @@ def test_plonk_verifier_over_ipa_on_pallas(HP, on_pallas, lin):
     assert run(proof, instances=S.pack_instances(inst2)) == 0
     gb2 = gb[:64 * 3] + gb[64 * 4:64 * 5] + gb[64 * 4:]
     assert run(proof, key=gb2, decide=0) == 1 and run(proof, key=gb2, decide=1) == 0  # only `decide` sees G_i, i > 0
+
+
+@pytest.mark.gpu
+def test_plonk_over_ipa_batch_on_pallas(HP, on_pallas):
+    """The batched form (one segmented launch for the succinct checks of N proofs, then `decide_all`) on pallas."""
+    import struct
+
+    import plonk as P
+    import plonk_synth as S
+
+    rng = random.Random("pallas-batch")
+    k, n = 4, 9
+    pr, dl = S.standard_plonk_protocol(rng, k=k, num_instance=(3,))
+    kd = {"g": [rng.randrange(1, PA.R) for _ in range(1 << k)], "h": rng.randrange(1, PA.R), "s": rng.randrange(1, PA.R)}
+    g = [PA.g1_mul(PA.G1_GEN, c) for c in kd["g"]]
+    h, s = PA.g1_mul(PA.G1_GEN, kd["h"]), PA.g1_mul(PA.G1_GEN, kd["s"])
+    mk = lambda stream=b"": T.Blake2bTranscript(PA, stream)  # noqa: E731
+    insts = [[[rng.randrange(PA.R) for _ in range(3)]] for _ in range(n)]
+    proofs = [P.forge_proof_ipa(pr, insts[i], kd, mk, rng, dl) for i in range(n)]
+    want = b"".join(pack_acc(P.succinct_verify_ipa(g[0], h, s, pr, insts[i], P.plonk_proof_read(pr, insts[i], mk(proofs[i]), "bgh19"))[0])
+                    for i in range(n))
+    fn = HP.hp_plonk_ipa_verify_batch
+    fn.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
+                   ctypes.c_size_t, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint,
+                   ctypes.c_char_p, ctypes.c_int]
+    pb = S.pack_protocol(pr)
+    ib = b"".join(S.pack_instances(x) for x in insts)
+    prb = b"".join(struct.pack("<I", len(p)) + p for p in proofs)
+    gb = b"".join(PA.g1_to_bytes(p) for p in g)
+    out = _buf((32 * k + 64) * n)
+    assert fn(2, pb, len(pb), ib, len(ib), prb, len(prb), n, pack_svk(k, g[0], h, s), gb, len(g), 3, out, 1) == 1
+    assert out.raw == want
+    insts[4][0][1] = (insts[4][0][1] + 1) % PA.R
+    ib2 = b"".join(S.pack_instances(x) for x in insts)
+    assert fn(2, pb, len(pb), ib2, len(ib2), prb, len(prb), n, pack_svk(k, g[0], h, s), gb, len(g), 3, out, 1) == 0
