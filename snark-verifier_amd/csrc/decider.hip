@@ -18,9 +18,6 @@
 //                     reduction stages: 1.64 ms.)
 // Batches of independent accumulators (decide_all) are the second parallel axis
 // (SURVEY.md 8e).
-// The pairing runs a few latency-bound wavefronts: the explicit `fq29_smad` form of the field products
-// (fq29.cuh), which wins 10 % in the throughput-bound MSM kernels, measures 3 % slower here.
-#define SNARKV_NO_SMAD_ASM
 #include "ctx.hpp"
 #include "g1.cuh"
 #include "pairing.cuh"

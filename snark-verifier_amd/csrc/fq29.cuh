@@ -120,8 +120,9 @@ SNARKV_HD Fq29 fq29_norm(const Fq29& a) {
 // entry of k_accumulate.  Stepping stones, kept in DESIGN.md section 4: one asm statement per operand product
 // (-12 %), one statement per product of either kind (slower again: the compiler pads consecutive
 // VCC-writing asm statements with s_nop), one statement per column (this form).
-// -DSNARKV_NO_SMAD_ASM keeps the plain C below -- the latency-bound pairing (decider.hip) measures 3 % faster
-// with the compiler's two interleaved chains; host builds always use it.
+// -DSNARKV_NO_SMAD_ASM keeps the plain C below (host builds always use it).  The pairing (decider.hip), a few
+// latency-bound wavefronts, lost 3 % to the one-statement-per-product form but gains 2-3 % from the column
+// chains (decide 0.887 -> 0.866 ms, 1 024 accumulators 1.51 -> 1.46 ms); Poseidon's Fr products stay plain C.
 SNARKV_HD int64_t fq29_smad(int32_t a, int32_t b, int64_t acc) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SNARKV_NO_SMAD_ASM)
   asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
