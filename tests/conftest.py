@@ -14,6 +14,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The C-ABI libraries are build artefacts (git-ignored): in a tree where `__graft_entry__.build()` has not
+    run yet, build them once (hipcc cross-compiles gfx950 without a GPU) instead of failing the symbol tests."""
+    pkg = os.path.join(ROOT, "snark-verifier_amd")
+    need = ["libsnarkv_amd.so", "libsnarkv_pallas.so", "libsnarkv_host.so", "libsnarkv_host_pallas.so"]
+    if all(os.path.exists(os.path.join(pkg, n)) for n in need):
+        return
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_snarkv_build", os.path.join(pkg, "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build()
+
+
 @pytest.fixture(scope="session")
 def golden_msm():
     with open(os.path.join(ROOT, "tests", "golden", "g1_msm.json")) as f:
