@@ -193,6 +193,13 @@ void snarkv_ipa_dk_destroy(snarkv_ipa_dk* dk);
 uint32_t snarkv_ipa_dk_k(const snarkv_ipa_dk* dk);
 int snarkv_ipa_decide_batch(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const uint8_t* xi32, const uint8_t* u64, size_t m,
                             uint8_t* ok);
+/* Multi-GPU decide (the MSM is linear in the points, as util/msm.rs:322-335 chunks it): rank r keeps points
+ * [first, first + count) of the key (`..._create_shard`), `snarkv_ipa_commit_partial_dev` leaves its share of
+ * commit(G, h(xi)) as a SNARKV_G1_PARTIAL_BYTES projective partial in device memory; all-gather the partials,
+ * fold them with snarkv_g1_fold_partials_dev and compare with U.  A shard key is refused by ..._decide_batch. */
+int snarkv_ipa_dk_create_shard(snarkv_ctx* ctx, const uint8_t* g_shard64, size_t count, uint32_t k, size_t first,
+                               snarkv_ipa_dk** out);
+int snarkv_ipa_commit_partial_dev(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const uint8_t* xi32, void* d_partial);
 int bn254_ipa_dk_create(const uint8_t* g_points64, size_t n, snarkv_ipa_dk** out);
 int bn254_ipa_decide_batch(const snarkv_ipa_dk* dk, const uint8_t* xi32, const uint8_t* u64, size_t m, uint8_t* ok);
 

@@ -48,6 +48,9 @@ int snarkv_pallas_g1_msm_batched(snarkv_ctx* ctx, const uint8_t* scalars32, cons
 int snarkv_pallas_ipa_dk_create(snarkv_ctx* ctx, const uint8_t* g_points64, size_t n, snarkv_ipa_dk** out);
 void snarkv_pallas_ipa_dk_destroy(snarkv_ipa_dk* dk);
 uint32_t snarkv_pallas_ipa_dk_k(const snarkv_ipa_dk* dk);
+int snarkv_pallas_ipa_dk_create_shard(snarkv_ctx* ctx, const uint8_t* g_shard64, size_t count, uint32_t k, size_t first,
+                                      snarkv_ipa_dk** out);
+int snarkv_pallas_ipa_commit_partial_dev(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const uint8_t* xi32, void* d_partial);
 int snarkv_pallas_ipa_decide_batch(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const uint8_t* xi32, const uint8_t* u64,
                                    size_t m, uint8_t* ok);
 

@@ -79,6 +79,8 @@ _SIGNATURES = {
     "snarkv_g1_buckets_add_dev": (_int, [_vp, _vp, _vp, _sz]),
     "snarkv_g1_buckets_reduce_dev": (_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
     "snarkv_ipa_dk_create": (_int, [_vp, _vp, _sz, ctypes.POINTER(_vp)]),
+    "snarkv_ipa_dk_create_shard": (_int, [_vp, _vp, _sz, _u32, _sz, ctypes.POINTER(_vp)]),
+    "snarkv_ipa_commit_partial_dev": (_int, [_vp, _vp, _vp, _vp]),
     "snarkv_ipa_dk_destroy": (None, [_vp]),
     "snarkv_ipa_dk_k": (_u32, [_vp]),
     "snarkv_ipa_decide_batch": (_int, [_vp, _vp, _vp, _vp, _sz, _vp]),
@@ -174,12 +176,17 @@ class IpaDecidingKey:
     """Device-resident committing key of `IpaDecidingKey` (reference pcs/ipa/decider.rs:5-9;
     include/snarkv_amd.h `snarkv_ipa_dk_create`): `g` = 2^k points, 64 bytes each."""
 
-    def __init__(self, ctx, g):
+    def __init__(self, ctx, g, k=None, first=0):
+        """All 2^k points, or -- with `k` and `first` -- the shard [first, first + len(g)/64) of a 2^k-point key."""
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         g = _as_bytes(g)
         assert len(g) % 64 == 0
-        _check(self._lib.snarkv_ipa_dk_create(ctx._h, g if g else b"\x00", len(g) // 64, ctypes.byref(self._h)))
+        if k is None:
+            _check(self._lib.snarkv_ipa_dk_create(ctx._h, g if g else b"\x00", len(g) // 64, ctypes.byref(self._h)))
+        else:
+            _check(self._lib.snarkv_ipa_dk_create_shard(ctx._h, g if g else b"\x00", len(g) // 64, k, first,
+                                                        ctypes.byref(self._h)))
         self.k = self._lib.snarkv_ipa_dk_k(self._h)
 
     def close(self):
@@ -362,6 +369,12 @@ class Context:
         ok = ctypes.create_string_buffer(max(m, 1))
         _check(self._lib.snarkv_ipa_decide_batch(self._h, dk._h, xi if xi else b"\x00", u if u else b"\x00", m, ok))
         return [b != 0 for b in ok.raw[:m]]
+
+    def ipa_commit_partial_dev(self, dk, xi, d_partial):
+        """This shard's part of commit(G, h(xi)) as a projective partial at device address `d_partial`."""
+        xi = _as_bytes(xi)
+        assert len(xi) == 32 * dk.k
+        _check(self._lib.snarkv_ipa_commit_partial_dev(self._h, dk._h, xi, d_partial))
 
     def poseidon_transcript_batch(self, spec, elems, n, seg_len):
         """n transcripts: `elems` = n*L canonical 32-byte Fr, absorbed in len(seg_len) segments with a

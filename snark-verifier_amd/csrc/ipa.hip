@@ -13,7 +13,9 @@
 struct snarkv_ipa_dk {
   int device;
   uint32_t k;
-  void* d_points;  // 2^k x 64 B canonical affine, as the Pippenger entry point takes them
+  void* d_points;  // the points held: 64 B canonical affine each, as the Pippenger entry point takes them
+  size_t first;    // index of the first point held in the 2^k-point key (0 unless a multi-GPU shard)
+  size_t count;    // points held (2^k unless a shard)
 };
 
 namespace snarkv {
@@ -22,19 +24,21 @@ namespace snarkv {
 // doubling loop `coeffs[len + j] = coeffs[j] * xi` unrolled per index).  One lane per
 // coefficient, <= k products; canonical little-endian out.
 __global__ void __launch_bounds__(256)
-    k_h_coeffs(const uint32_t* __restrict__ xi_canon, uint32_t k, uint32_t* __restrict__ out) {
+    k_h_coeffs(const uint32_t* __restrict__ xi_canon, uint32_t k, uint32_t first, uint32_t count,
+               uint32_t* __restrict__ out) {
   __shared__ Fr29 sx[32];
   if (threadIdx.x < k) sx[threadIdx.x] = fr29_from_canonical(xi_canon + 8 * (size_t)(k - 1 - threadIdx.x));
   __syncthreads();
-  uint32_t j = blockIdx.x * 256u + threadIdx.x;
-  if (j >= (1u << k)) return;
+  uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= count) return;
+  const uint32_t j = first + t;  // coefficient index in the full 2^k vector; out[] is shard-local
   Fr29 acc = fr29_one();
 #pragma unroll 1
   for (uint32_t i = 0; i < k; ++i)
     if ((j >> i) & 1u) acc = fr29_mul(acc, sx[i]);
   uint32_t w[8];
   fr29_to_canonical(acc, w);
-  uint4* o = reinterpret_cast<uint4*>(out + 8 * (size_t)j);
+  uint4* o = reinterpret_cast<uint4*>(out + 8 * (size_t)t);
   o[0] = make_uint4(w[0], w[1], w[2], w[3]);
   o[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
@@ -45,26 +49,59 @@ using namespace snarkv;
 
 extern "C" {
 
+static int ipa_dk_make(snarkv_ctx* ctx, const uint8_t* g_points64, uint32_t k, size_t first, size_t count,
+                       snarkv_ipa_dk** out) {
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  snarkv_ipa_dk* dk = new snarkv_ipa_dk();
+  dk->device = ctx->device;
+  dk->k = k;
+  dk->first = first;
+  dk->count = count;
+  dk->d_points = nullptr;
+  if (hipMalloc(&dk->d_points, count * 64) != hipSuccess) {
+    delete dk;
+    set_last_error("ipa_dk_create: hipMalloc of %zu bytes failed", count * 64);
+    return SNARKV_ERR_DEVICE;
+  }
+  SNARKV_HIP(hipMemcpyAsync(dk->d_points, g_points64, count * 64, hipMemcpyHostToDevice, ctx->stream));
+  SNARKV_HIP(hipStreamSynchronize(ctx->stream));
+  *out = dk;
+  return SNARKV_OK;
+}
+
 int SNARKV_API(ipa_dk_create)(snarkv_ctx* ctx, const uint8_t* g_points64, size_t n, snarkv_ipa_dk** out) {
   if (!ctx || !g_points64 || !out) return SNARKV_ERR_ARG;
   if (n == 0) return SNARKV_ERR_EMPTY;
   uint32_t k = 0;
   while (((size_t)1 << k) < n) ++k;
   if (((size_t)1 << k) != n || k < 1 || k > 28) return SNARKV_ERR_LENGTH;  // committing keys have 2^k points
+  return ipa_dk_make(ctx, g_points64, k, 0, n, out);
+}
+
+// Multi-GPU: this rank holds points [first, first + count) of the 2^k-point key.
+int SNARKV_API(ipa_dk_create_shard)(snarkv_ctx* ctx, const uint8_t* g_shard64, size_t count, uint32_t k, size_t first,
+                                    snarkv_ipa_dk** out) {
+  if (!ctx || !g_shard64 || !out) return SNARKV_ERR_ARG;
+  if (count == 0) return SNARKV_ERR_EMPTY;
+  if (k < 1 || k > 28 || first + count > ((size_t)1 << k)) return SNARKV_ERR_LENGTH;
+  return ipa_dk_make(ctx, g_shard64, k, first, count, out);
+}
+
+// The shard's part of commit(G, h(xi)) as a projective partial (SNARKV_G1_PARTIAL_BYTES), device to device:
+// all-gather the partials and fold them (snarkv_g1_fold_partials_dev) to get the point `decide` compares with U.
+int SNARKV_API(ipa_commit_partial_dev)(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const uint8_t* xi32, void* d_partial) {
+  if (!ctx || !dk || !xi32 || !d_partial) return SNARKV_ERR_ARG;
+  if (dk->device != ctx->device) return SNARKV_ERR_ARG;
   SNARKV_HIP(hipSetDevice(ctx->device));
-  snarkv_ipa_dk* dk = new snarkv_ipa_dk();
-  dk->device = ctx->device;
-  dk->k = k;
-  dk->d_points = nullptr;
-  if (hipMalloc(&dk->d_points, n * 64) != hipSuccess) {
-    delete dk;
-    set_last_error("ipa_dk_create: hipMalloc of %zu bytes failed", n * 64);
-    return SNARKV_ERR_DEVICE;
-  }
-  SNARKV_HIP(hipMemcpyAsync(dk->d_points, g_points64, n * 64, hipMemcpyHostToDevice, ctx->stream));
-  SNARKV_HIP(hipStreamSynchronize(ctx->stream));
-  *out = dk;
-  return SNARKV_OK;
+  const uint32_t k = dk->k;
+  void *d_xi, *d_h;
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_IPA_XI, (size_t)k * 32, &d_xi));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_IPA_H, dk->count * 32, &d_h));
+  SNARKV_HIP(hipMemcpyAsync(d_xi, xi32, (size_t)k * 32, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_h_coeffs, dim3((uint32_t)((dk->count + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const uint32_t*)d_xi, k, (uint32_t)dk->first, (uint32_t)dk->count, (uint32_t*)d_h);
+  SNARKV_HIP(hipGetLastError());
+  return launch_msm_pippenger(ctx, d_h, dk->d_points, dk->count, 0, d_partial, true);
 }
 
 void SNARKV_API(ipa_dk_destroy)(snarkv_ipa_dk* dk) {
@@ -81,6 +118,7 @@ int SNARKV_API(ipa_decide_batch)(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const
   if (!ctx || !dk || !xi32 || !u64 || !ok) return SNARKV_ERR_ARG;
   if (m == 0) return SNARKV_ERR_EMPTY;
   if (dk->device != ctx->device) return SNARKV_ERR_ARG;
+  if (dk->first != 0 || dk->count != ((size_t)1 << dk->k)) return SNARKV_ERR_LENGTH;  // a shard cannot decide alone
   SNARKV_HIP(hipSetDevice(ctx->device));
   const uint32_t k = dk->k;
   const size_t n = (size_t)1 << k;
@@ -100,7 +138,7 @@ int SNARKV_API(ipa_decide_batch)(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const
     void* d_h;
     SNARKV_TRY(ctx_reserve(lane, SLOT_IPA_H, n * 32, &d_h));
     hipLaunchKernelGGL(k_h_coeffs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, lane->stream,
-                       (const uint32_t*)d_xi + a * k * 8, k, (uint32_t*)d_h);
+                       (const uint32_t*)d_xi + a * k * 8, k, 0u, (uint32_t)n, (uint32_t*)d_h);
     SNARKV_HIP(hipGetLastError());
     SNARKV_TRY(launch_msm_pippenger(lane, d_h, dk->d_points, n, 0, (uint8_t*)d_out + 64 * a, false));
   }

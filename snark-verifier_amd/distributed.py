@@ -187,6 +187,64 @@ def gpu_bucket_sharded_msm(ctx, d_scalars, d_points, n_total, window_bits=0):
 
 
 @dataclass
+class ShardedIpaDecide:
+    """`IpaAs::decide` (reference pcs/ipa/decider.rs:47-55) with the 2^k-point committing key sharded over
+    the ranks: the check U == <h(xi), G> is one MSM, linear in the points, so rank g commits to its slice
+    G[lo:hi] with the matching slice of h_coeffs (`partial_fn(lo, hi, xi) -> uint8[partial_bytes]`), the
+    projective partials are all-gathered (144 B per rank, latency-bound) and every rank folds them
+    (`fold_fn(gathered, world) -> uint8[64]`) and compares with U -- all ranks hold the same verdict."""
+
+    k: int
+    partial_fn: Callable
+    fold_fn: Callable
+    partial_bytes: int = 144
+
+    def run(self, xi, u) -> bool:
+        import torch
+        import torch.distributed as dist
+
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        lo, hi = shard_range(1 << self.k, rank, world)
+        if hi > lo:
+            part = self.partial_fn(lo, hi, xi)
+        else:  # more ranks than points: the identity
+            part = torch.zeros(self.partial_bytes, dtype=torch.uint8, device="cuda" if world > 1 and dist.get_backend() == "nccl" else "cpu")
+        assert part.numel() == self.partial_bytes and part.dtype == torch.uint8
+        if world == 1:
+            gathered = part
+        else:
+            gathered = torch.empty(world * self.partial_bytes, dtype=torch.uint8, device=part.device)
+            dist.all_gather_into_tensor(gathered, part)
+        got = self.fold_fn(gathered, world)
+        return bytes(got.cpu().numpy()) == bytes(u)
+
+
+def gpu_sharded_ipa_decide(ctx, dk_shard, xi, u):
+    """Product wiring: `dk_shard` = IpaDecidingKey(ctx, g[lo:hi], k, lo) of THIS rank (shard_range(2^k, rank, world));
+    xi = k scalars (32 bytes each), u = 64 bytes.  -> bool, identical on every rank."""
+    import torch
+
+    from . import G1_PARTIAL_BYTES
+
+    part = torch.zeros(G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+
+    def partial_fn(lo, hi, xi_):
+        ctx.ipa_commit_partial_dev(dk_shard, xi_, part.data_ptr())
+        ctx.sync()  # the partial is in memory before the all-gather reads it
+        return part
+
+    def fold_fn(gathered, world):
+        torch.cuda.current_stream().synchronize()
+        ctx.fold_partials_dev(gathered.data_ptr(), world, out.data_ptr())
+        ctx.sync()
+        return out
+
+    return ShardedIpaDecide(dk_shard.k, partial_fn, fold_fn, G1_PARTIAL_BYTES).run(xi, u)
+
+
+@dataclass
 class ShardedAggregation:
     """Proof-sharded aggregation: proofs are independent,
     so rank g succinct-verifies ITS contiguous shard of the proofs

@@ -32,6 +32,8 @@ def load_library():
             "snarkv_pallas_g1_msm_naive": (ctypes.c_int, [vp, vp, vp, sz, u32, vp]),
             "snarkv_pallas_g1_msm_batched": (ctypes.c_int, [vp, vp, vp, vp, sz, u32, vp]),
             "snarkv_pallas_ipa_dk_create": (ctypes.c_int, [vp, vp, sz, ctypes.POINTER(vp)]),
+            "snarkv_pallas_ipa_dk_create_shard": (ctypes.c_int, [vp, vp, sz, u32, sz, ctypes.POINTER(vp)]),
+            "snarkv_pallas_ipa_commit_partial_dev": (ctypes.c_int, [vp, vp, vp, vp]),
             "snarkv_pallas_ipa_dk_destroy": (None, [vp]),
             "snarkv_pallas_ipa_dk_k": (u32, [vp]),
             "snarkv_pallas_ipa_decide_batch": (ctypes.c_int, [vp, vp, vp, vp, sz, vp]),

@@ -242,3 +242,60 @@ def test_bucket_sharded_msm_ranks_agree_with_single_process(n, world):
     expected = C.msm_pippenger(C.sample_scalars(7, n), C.sample_points(8, n), 1)
     for _, out in res:
         assert out == expected
+
+
+# ---- sharded IPA decide ------------------------------------------------------------------------
+def _ipa_worker(rank, world, port, k, good, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import random
+
+    import torch
+    import torch.distributed as dist
+
+    import bn254 as O
+    import coracle as C
+    import ipa as I
+    from snark_verifier_amd.distributed import ShardedIpaDecide
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rnd = random.Random(31)
+    xi = [rnd.randrange(O.R) for _ in range(k)]
+    g = C.sample_points(5, 1 << k)
+    h = I.h_coeffs(xi, 1)
+    u = C.msm_pippenger(b"".join(O.fe_to_bytes(c) for c in h), g, 1)
+    if not good:
+        u = C.g1_add(u, g[:64])
+
+    def partial_fn(lo, hi, xi_):  # oracle double of the device partial: affine bytes padded to 144
+        pt = C.msm_pippenger(b"".join(O.fe_to_bytes(c) for c in h[lo:hi]), g[64 * lo:64 * hi], 1)
+        return torch.frombuffer(bytearray(pt + bytes(80)), dtype=torch.uint8)
+
+    def fold_fn(gathered, w):
+        acc, raw = bytes(64), bytes(gathered.numpy())
+        for j in range(w):
+            acc = C.g1_add(acc, raw[144 * j:144 * j + 64])
+        return torch.frombuffer(bytearray(acc), dtype=torch.uint8)
+
+    q.put((rank, ShardedIpaDecide(k, partial_fn, fold_fn).run(xi, u)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,world,good", [(5, 2, True), (5, 2, False), (3, 3, True), (1, 3, True)])
+def test_sharded_ipa_decide_ranks_agree(k, world, good):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() + 13 * k + world + good) % 2000
+    procs = [ctx.Process(target=_ipa_worker, args=(r, world, port, k, good, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert [v for _, v in res] == [good] * world

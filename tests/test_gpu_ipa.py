@@ -419,3 +419,40 @@ def test_plonk_over_ipa_batch_is_one_launch_and_matches_single(H, kind):
     gb2 = gb[:64] + gb[128:192] + gb[128:]
     assert H.hd_plonk_ipa_verify_batch(tk, pb, len(pb), ib, len(ib), prb, len(prb), n, svk, gb2, len(gb2) // 64, 2, out, 0) == 1
     assert H.hd_plonk_ipa_verify_batch(tk, pb, len(pb), ib, len(ib), prb, len(prb), n, svk, gb2, len(gb2) // 64, 2, out, 1) == 0
+
+
+@pytest.mark.parametrize("k,world", [(1, 2), (6, 3), (12, 8), (16, 5)])
+def test_sharded_ipa_commit_emulated_ranks(gpu_ctx, k, world):
+    """Multi-GPU `IpaAs::decide` emulated on one device: `world` shards of the committing key
+    (`snarkv_ipa_dk_create_shard`) each commit to their slice (`snarkv_ipa_commit_partial_dev`), the folded
+    partials equal the point the un-sharded decider accepts; a shard key cannot decide on its own."""
+    import torch
+
+    import snark_verifier_amd as sv
+    from snark_verifier_amd.distributed import shard_range
+
+    rnd = random.Random(k * 10 + world)
+    n = 1 << k
+    gb = C.sample_points(2000 + k, n)
+    xi = [rnd.randrange(O.R) for _ in range(k)]
+    xb = b"".join(O.fe_to_bytes(x) for x in xi)
+    parts = torch.zeros(world, sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    keys = []
+    for r in range(world):
+        lo, hi = shard_range(n, r, world)
+        if hi > lo:
+            dk = sv.IpaDecidingKey(gpu_ctx, gb[64 * lo:64 * hi], k, lo)
+            keys.append(dk)
+            gpu_ctx.ipa_commit_partial_dev(dk, xb, parts[r].data_ptr())
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    gpu_ctx.fold_partials_dev(parts.data_ptr(), world, out.data_ptr())
+    gpu_ctx.sync()
+    u = bytes(out.cpu().numpy())
+    full = sv.IpaDecidingKey(gpu_ctx, gb)
+    assert gpu_ctx.ipa_decide_batch(full, xb, u) == [True]
+    assert u == C.msm_pippenger(b"".join(O.fe_to_bytes(c) for c in I.h_coeffs(xi, 1)), gb, 2)
+    with pytest.raises(sv.SnarkvError):
+        gpu_ctx.ipa_decide_batch(keys[0], xb, u)
+    with pytest.raises(sv.SnarkvError):
+        sv.IpaDecidingKey(gpu_ctx, gb, k, 1)  # shard past the end of the key
