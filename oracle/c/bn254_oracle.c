@@ -500,3 +500,6 @@ void oracle_sample_points(uint64_t seed, size_t first, size_t n, uint8_t* out) {
     memcpy(out + 64 * i + 32, yb, 32);
   }
 }
+
+/* ------------------------------------------- pairing side (KzgAs::decide, decider.rs:70-93) */
+#include "bn254_pairing.inc"

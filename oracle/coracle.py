@@ -31,6 +31,10 @@ def lib():
         L.oracle_sample_scalars.restype = None
         L.oracle_sample_points.argtypes = [ctypes.c_uint64, z, z, vp]
         L.oracle_sample_points.restype = None
+        L.oracle_kzg_decide.argtypes = [c, c, c]
+        L.oracle_kzg_pairing_value.argtypes = [c, c, c, vp]
+        L.oracle_kzg_decide_all.argtypes = [c, c, c, z, ctypes.c_int, vp]
+        L.oracle_selftest_cyclotomic.argtypes = [c, c]
         _lib = L
     return _lib
 
@@ -89,3 +93,23 @@ def sample_points(seed, n, first=0):
     out = ctypes.create_string_buffer(64 * n)
     lib().oracle_sample_points(seed, first, n, out)
     return out.raw
+
+
+def kzg_decide(g2, s_g2, acc):
+    """`KzgAs::decide` (decider.rs:70-82): e(lhs, g2) e(rhs, -s_g2) == 1.  g2 / s_g2: 128 B, acc = lhs|rhs: 128 B."""
+    return bool(lib().oracle_kzg_decide(g2, s_g2, acc))
+
+
+def kzg_pairing_value(g2, s_g2, acc):
+    """The Gt element itself: 12 x 32 B in tower order (= oracle/bn254.py Fq12.to_bytes)."""
+    out = ctypes.create_string_buffer(384)
+    lib().oracle_kzg_pairing_value(g2, s_g2, acc, out)
+    return out.raw
+
+
+def kzg_decide_all(g2, s_g2, accs, threads=1):
+    """`decide_all` (decider.rs:84-93): (all accepted, [per-accumulator verdicts])."""
+    m = len(accs) // 128
+    ok = ctypes.create_string_buffer(max(m, 1))
+    allok = lib().oracle_kzg_decide_all(g2, s_g2, accs, m, threads, ok)
+    return bool(allok), [b != 0 for b in ok.raw[:m]]

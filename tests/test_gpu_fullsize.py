@@ -1,0 +1,72 @@
+"""GPU parity AT BASELINE.json's sizes, bit for bit against the CPU oracle.
+
+Config 2 ("BN254 G1 Pippenger MSM, 2^20 random points/scalars ... bit-exact"): the HIP
+Pippenger (`util::msm::multi_scalar_multiplication`, reference snark-verifier/src/util/msm.rs:308-343)
+on the bench seeds 0x5EED0001 / 0x5EED0002 at 2^20 and 2^22 points, every default (window size,
+tile size, key count, kBigSpan path all depend on n), against the threaded C restatement of the
+reference algorithm (oracle/c/bn254_oracle.c <- msm.rs:259-343) on ALL host cores.  Different n
+=> different c / tile / key geometry, so sizes in between are covered too."""
+import os
+
+import pytest
+
+import coracle as C
+
+pytestmark = pytest.mark.gpu
+
+SEED_S, SEED_P = 0x5EED0001, 0x5EED0002  # bench.py's seeds
+
+
+def _device_inputs(gpu_ctx, n):
+    import torch
+
+    ds = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+    dp = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.sample_scalars_dev(SEED_S, n, ds.data_ptr())
+    gpu_ctx.sample_points_dev(SEED_P, n, dp.data_ptr())
+    gpu_ctx.sync()
+    return ds, dp
+
+
+def _gpu_msm(gpu_ctx, ds, dp, n, window_bits=0):
+    import torch
+
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.msm_pippenger_dev(ds.data_ptr(), dp.data_ptr(), n, out.data_ptr(), window_bits)
+    gpu_ctx.sync()
+    return bytes(out.cpu().numpy())
+
+
+@pytest.mark.parametrize("log2n", [20, 22])
+def test_pippenger_full_size_bit_exact_vs_c_oracle(gpu_ctx, log2n):
+    n = 1 << log2n
+    ds, dp = _device_inputs(gpu_ctx, n)
+    s, p = bytes(ds.cpu().numpy()), bytes(dp.cpu().numpy())
+    # the device sampler is the oracle's sampler (spot check both ends of the arrays)
+    assert s[:32 * 64] == C.sample_scalars(SEED_S, 64) and p[-64 * 64:] == C.sample_points(SEED_P, 64, first=n - 64)
+    exp = C.msm_pippenger(s, p, os.cpu_count() or 1)
+    assert exp != bytes(64) and C.g1_is_on_curve(exp)
+    assert _gpu_msm(gpu_ctx, ds, dp, n) == exp
+    # the host-buffer entry point (H2D staging included) gives the same bytes
+    if log2n == 20:
+        assert gpu_ctx.msm_pippenger(s, p) == exp
+
+
+@pytest.mark.parametrize("n", [(1 << 17) + 1, 3 * (1 << 18) - 7, (1 << 21) + 4099])
+def test_pippenger_in_between_sizes_bit_exact(gpu_ctx, n):
+    """Ragged sizes between the powers of two: last tile partial, key geometry of the next size down."""
+    ds, dp = _device_inputs(gpu_ctx, n)
+    s, p = bytes(ds.cpu().numpy()), bytes(dp.cpu().numpy())
+    assert _gpu_msm(gpu_ctx, ds, dp, n) == C.msm_pippenger(s, p, os.cpu_count() or 1)
+
+
+def test_pippenger_2p20_every_supported_window_size_same_bytes(gpu_ctx):
+    """At the headline size the result is the same group element for every window size the launcher accepts
+    around the default (c = 13..17): different bucket counts, level-1/level-2 splits and tile sizes."""
+    n = 1 << 20
+    ds, dp = _device_inputs(gpu_ctx, n)
+    ref = _gpu_msm(gpu_ctx, ds, dp, n)
+    for c in (13, 14, 15, 16, 17):
+        assert _gpu_msm(gpu_ctx, ds, dp, n, window_bits=c) == ref, c

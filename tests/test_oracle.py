@@ -110,3 +110,43 @@ def test_golden_kzg_layer_oracle_reproduces():
     limbs = [O.fe_from_bytes(lim[32 * i:32 * i + 32]) for i in range(16)]
     back = K.limbs_from_repr(limbs)
     assert (O.g1_to_bytes(back[0]) + O.g1_to_bytes(back[1])).hex() == g["limbs"]["accumulator"]
+
+
+def test_golden_decider_c_oracle_gt_bytes(golden_decider):
+    """The C restatement of the pairing decider (oracle/c/bn254_pairing.inc <- pcs/kzg/decider.rs:70-93: prepared
+    G2 lines, signed-digit Miller loop, cyclotomic final exponentiation) produces the SAME Gt element, byte for
+    byte, as the independent big-integer oracle (affine lines, plain f^((p^12-1)/r)) on every golden case."""
+    g2, s_g2 = bytes.fromhex(golden_decider["g2"]), bytes.fromhex(golden_decider["s_g2"])
+    accs = b""
+    for case in golden_decider["cases"]:
+        acc = bytes.fromhex(case["acc"])
+        accs += acc
+        assert C.kzg_decide(g2, s_g2, acc) == case["accept"], case["name"]
+        if case.get("gt"):
+            assert C.kzg_pairing_value(g2, s_g2, acc).hex() == case["gt"], case["name"]
+    exp = [c["accept"] for c in golden_decider["cases"]]
+    for threads in (1, 3):
+        allok, oks = C.kzg_decide_all(g2, s_g2, accs, threads)
+        assert oks == exp and allok == all(exp)
+    assert C.kzg_decide_all(g2, s_g2, b"", 1) == (True, [])
+
+
+def test_c_pairing_random_vs_python_and_bilinear():
+    import random
+
+    rng = random.Random(0xDEC1DE)
+    assert C.lib().oracle_selftest_cyclotomic(O.g2_to_bytes(O.G2_GEN), O.g1_to_bytes(O.G1_GEN)) == 1
+    for _ in range(3):
+        a, b, s = (rng.randrange(1, O.R) for _ in range(3))
+        g2, s_g2 = O.g2_mul(O.G2_GEN, b), O.g2_mul(O.G2_GEN, b * s % O.R)
+        lhs, rhs = O.g1_mul(O.G1_GEN, a), O.g1_mul(O.G1_GEN, rng.randrange(1, O.R))
+        f = O.final_exponentiation(O.miller_loop([(lhs, g2), (rhs, O.g2_neg(s_g2))]))
+        acc = O.g1_to_bytes(lhs) + O.g1_to_bytes(rhs)
+        assert C.kzg_pairing_value(O.g2_to_bytes(g2), O.g2_to_bytes(s_g2), acc) == f.to_bytes()
+        # bilinearity through the decider: e(s a G, b G2) e(a G, -(s b) G2) = 1
+        good = O.g1_to_bytes(O.g1_mul(O.G1_GEN, a * s % O.R)) + O.g1_to_bytes(lhs)
+        assert C.kzg_decide(O.g2_to_bytes(g2), O.g2_to_bytes(s_g2), good)
+    # identity members contribute 1 (multi_miller_loop skips them)
+    z = bytes(64)
+    assert C.kzg_decide(O.g2_to_bytes(O.G2_GEN), O.g2_to_bytes(O.G2_GEN), z + z)
+    assert not C.kzg_decide(O.g2_to_bytes(O.G2_GEN), O.g2_to_bytes(O.G2_GEN), O.g1_to_bytes(O.G1_GEN) + z)

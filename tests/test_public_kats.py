@@ -1,0 +1,130 @@
+"""Public known-answer vectors (tests/golden/public_kats.json: EIP-196 ecAdd / ecMul, EIP-197
+pairing check, Keccak-256, circomlib Poseidon) through BOTH oracles (Python big-int, C 4x64
+Montgomery), the C++ host mirror (Keccak, Poseidon) and -- under `-m gpu` -- the device path.
+
+These are the only vectors here that were not produced by code in this repository: they pin the
+oracle (and through it every parity test) to the published arithmetic of alt_bn128 / BN254, the
+curve halo2curves' `bn256` implements (reference Cargo.toml:14)."""
+import ctypes
+import json
+import os
+
+import pytest
+
+import bn254 as O
+import coracle as C
+import transcript as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def kats():
+    with open(os.path.join(ROOT, "tests", "golden", "public_kats.json")) as f:
+        return json.load(f)
+
+
+def _pt(xy):
+    return (int(xy[0], 16), int(xy[1], 16))
+
+
+def _pairs(words):
+    v = [int(w, 16) for w in words]
+    out = []
+    for i in range(0, len(v), 6):  # EIP-197 encodes Fq2 as (imaginary, real)
+        out.append(((v[i], v[i + 1]), (O.Fq2(v[i + 3], v[i + 2]), O.Fq2(v[i + 5], v[i + 4]))))
+    return out
+
+
+def test_eip196_python_and_c_oracles(kats):
+    for c in kats["eip196_ecadd"]:
+        p, q, s = _pt(c["p"]), _pt(c["q"]), _pt(c["sum"])
+        assert O.g1_is_on_curve(p) and O.g1_is_on_curve(q)
+        assert O.g1_add(p, q) == s
+        assert C.g1_add(O.g1_to_bytes(p), O.g1_to_bytes(q)) == O.g1_to_bytes(s)
+        one = O.fe_to_bytes(1)
+        assert C.msm_naive(one + one, O.g1_to_bytes(p) + O.g1_to_bytes(q)) == O.g1_to_bytes(s)
+        assert C.msm_pippenger(one + one, O.g1_to_bytes(p) + O.g1_to_bytes(q), 1) == O.g1_to_bytes(s)
+    for c in kats["eip196_ecmul"]:
+        p, k, e = _pt(c["p"]), int(c["k"], 16), _pt(c["product"])
+        assert O.g1_mul(p, k) == e
+        assert C.g1_mul(O.g1_to_bytes(p), O.fe_to_bytes(k)) == O.g1_to_bytes(e)
+        assert C.msm_naive(O.fe_to_bytes(k), O.g1_to_bytes(p)) == O.g1_to_bytes(e)
+        assert C.msm_pippenger(O.fe_to_bytes(k), O.g1_to_bytes(p), 1) == O.g1_to_bytes(e)
+
+
+def test_eip197_pairing_check_python_oracle(kats):
+    for c in kats["eip197_pairing_check"]:
+        pairs = _pairs(c["words"])
+        for p, q in pairs:
+            assert O.g1_is_on_curve(p) and O.g2_is_on_curve(q)
+        assert (O.final_exponentiation(O.miller_loop(pairs)) == O.FQ12_ONE) == bool(c["result"])
+        assert pairs[1][1] == O.G2_GEN  # the EIP-197 generator the deciding keys of the tests are built on
+        # the decider form e(lhs, g2) e(rhs, -s_g2) = 1 (pcs/kzg/decider.rs:70-82) of the same check
+        (p1, q1), (p2, q2) = pairs
+        assert O.kzg_decide(p2, p1, q2, O.g2_neg(q1))
+
+
+def test_eip197_pairing_check_c_oracle(kats):
+    for c in kats["eip197_pairing_check"]:
+        (p1, q1), (p2, q2) = _pairs(c["words"])
+        acc = O.g1_to_bytes(p2) + O.g1_to_bytes(p1)
+        assert C.kzg_decide(O.g2_to_bytes(q2), O.g2_to_bytes(O.g2_neg(q1)), acc) is True
+        bad = O.g1_to_bytes(O.g1_double(p2)) + O.g1_to_bytes(p1)
+        assert C.kzg_decide(O.g2_to_bytes(q2), O.g2_to_bytes(O.g2_neg(q1)), bad) is False
+
+
+def test_keccak_and_poseidon_public_values(kats):
+    H = ctypes.CDLL(os.path.join(ROOT, "snark-verifier_amd", "libsnarkv_host.so"))
+    H.hd_keccak256.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+    H.hd_poseidon_permute.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    for c in kats["keccak256"]:
+        msg = bytes.fromhex(c["msg_hex"])
+        assert T.keccak256(msg).hex() == c["digest"]
+        out = ctypes.create_string_buffer(32)
+        H.hd_keccak256(msg, len(msg), out)
+        assert out.raw.hex() == c["digest"]
+    for c in kats["poseidon_circomlib"]:
+        st = [0] + c["inputs"]
+        assert len(st) == c["t"]
+        exp = int(c["hash_dec"])
+        assert T.poseidon_permute(list(st), c["r_f"], c["r_p"])[0] == exp
+        assert T.poseidon_permute_opt(list(st), c["t"], c["r_f"], c["r_p"])[0] == exp
+        buf = ctypes.create_string_buffer(b"".join(O.fe_to_bytes(x) for x in st), 32 * c["t"])
+        assert H.hd_poseidon_permute(c["t"], c["r_f"], c["r_p"], buf) == 0
+        assert int.from_bytes(buf.raw[:32], "little") == exp
+
+
+# ------------------------------------------------------------------ device
+@pytest.mark.gpu
+def test_eip196_on_device(gpu_ctx, kats):
+    one = O.fe_to_bytes(1)
+    for c in kats["eip196_ecadd"]:
+        p, q, s = (O.g1_to_bytes(_pt(c[k])) for k in ("p", "q", "sum"))
+        assert gpu_ctx.msm_naive(one + one, p + q) == s
+        assert gpu_ctx.msm_pippenger(one + one, p + q) == s
+        assert gpu_ctx.msm_batched(one + one, p + q, [0, 1, 2]) == p + q
+    for c in kats["eip196_ecmul"]:
+        p, k, e = O.g1_to_bytes(_pt(c["p"])), O.fe_to_bytes(int(c["k"], 16)), O.g1_to_bytes(_pt(c["product"]))
+        assert gpu_ctx.msm_naive(k, p) == e
+        assert gpu_ctx.msm_pippenger(k, p) == e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("teams", ["1", "2"])
+def test_eip197_pairing_check_on_device(gpu_ctx, kats, teams, monkeypatch):
+    """e(P1,Q1) e(P2,Q2) = 1 fed to the HIP decider as e(lhs, g2) e(rhs, -s_g2) with g2 := Q2,
+    s_g2 := -Q1, lhs := P2, rhs := P1, for both kernel forms."""
+    import snark_verifier_amd as sv
+
+    monkeypatch.setenv("SNARKV_DECIDE_TEAMS", teams)
+    for c in kats["eip197_pairing_check"]:
+        (p1, q1), (p2, q2) = _pairs(c["words"])
+        dk = sv.DecidingKey(gpu_ctx, O.g1_to_bytes(O.G1_GEN), O.g2_to_bytes(q2), O.g2_to_bytes(O.g2_neg(q1)))
+        acc = O.g1_to_bytes(p2) + O.g1_to_bytes(p1)
+        bad = O.g1_to_bytes(O.g1_double(p2)) + O.g1_to_bytes(p1)
+        assert gpu_ctx.decide(dk, acc) is True
+        assert gpu_ctx.decide(dk, bad) is False
+        allok, oks = gpu_ctx.decide_batch(dk, acc + bad + acc)
+        assert not allok and oks == [True, False, True]
+        dk.close()
