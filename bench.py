@@ -161,51 +161,54 @@ def end_to_end_metrics():
     tests/golden/bench_plonk_gwc19_evm_64.bin (64 StandardPlonk-shaped proofs forged under
     a toy SRS by tests/golden/gen_bench_proofs.py; data only, no oracle code runs here).
     Host work (transcript, Fr algebra) is INCLUDED in these timings."""
-    import ctypes
-    import struct
+    from snark_verifier_amd import host_api as H
 
-    lib = os.path.join(ROOT, "snark-verifier_amd", "libsnarkv_host.so")
-    if not os.path.exists(lib):
-        return None
-    H = ctypes.CDLL(lib)
-    H.hd_aggregate_end_to_end.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
-                                          ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32,
-                                          ctypes.c_char_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p]
     threads = max(1, min(64, os.cpu_count() or 1))
     out = {}
     for tkind, tname in ((0, "evm"), (1, "poseidon"), (2, "poseidon")):
         path = os.path.join(ROOT, "tests", "golden", "bench_plonk_gwc19_%s_64.bin" % tname)
         if not os.path.exists(path):
             continue
-        b = open(path, "rb").read()
-        n, = struct.unpack_from("<I", b, 4)
-        off, parts = 8, []
-        for _ in range(3):
-            ln, = struct.unpack_from("<I", b, off)
-            parts.append(b[off + 4:off + 4 + ln])
-            off += 4 + ln
-        pb, ib, prb = parts
-        dk, exp = b[off:off + 320], b[off + 320:off + 448]
-        tm = (ctypes.c_double * 6)()
-        acc = ctypes.create_string_buffer(128)
+        fx = H.read_fixture(path)
+        n = fx["n"]
+        hp, hdk = H.Protocol(fx["protocol"]), H.DecidingKey(fx["dk"])
         for rep in (1, 16):
             best = None
             for _ in range(5):
-                rc = H.hd_aggregate_end_to_end(0, tkind, pb, len(pb), ib * rep, len(ib) * rep, prb * rep, len(prb) * rep,
-                                               n * rep, dk, threads, tm, acc)
-                if rc != 1:
-                    return {"error": "verifier returned %d" % rc}
-                if best is None or tm[5] < best[5]:
-                    best = list(tm)
+                ok, acc, tm = H.aggregate(hp, hdk, fx["instances"] * rep, fx["proofs"] * rep, n * rep, H.MOS_GWC19, tkind,
+                                          threads, timings=True)
+                if not ok:
+                    return {"error": "verifier rejected"}
+                if best is None or tm["total"] < best["total"]:
+                    best = tm
             key = "end_to_end_aggregate_%d_proofs" % (n * rep) + (
                 "", "_poseidon_transcript_host_hashed", "_poseidon_transcript_device_hashed")[tkind]
             out[key] = {
-                "ms": best[5], "proofs_per_s": n * rep / best[5] * 1e3, "host_threads": threads,
-                ("ms_read_proofs_incl_device_hashing" if tkind == 2 else "ms_read_proofs_host"): best[0],
-                "ms_fr_algebra_host": best[1], "ms_msm_device_incl_h2d": best[2],
-                "ms_kzg_accumulate": best[3], "ms_decide": best[4],
-                "accepted": True, "matches_fixture_accumulator": (acc.raw == exp) if rep == 1 else None,
+                "ms": best["total"], "proofs_per_s": n * rep / best["total"] * 1e3, "host_threads": threads,
+                ("ms_read_proofs_incl_device_hashing" if tkind == 2 else "ms_read_proofs_host"): best["read_proofs"],
+                "ms_fr_algebra_host": best["fr_algebra"], "ms_msm_device_incl_h2d": best["msm_device"],
+                "ms_kzg_accumulate": best["accumulate"], "ms_decide": best["decide"],
+                "accepted": True, "matches_fixture_accumulator": (acc == fx["expected_acc"]) if rep == 1 else None,
                 "input": os.path.basename(path) + (" x%d" % rep if rep > 1 else "")}
+        hp.close()
+        hdk.close()
+    # config 5 on its own input: 1 024 DISTINCT proofs (tests/golden/bench_plonk_gwc19_evm_1024.bin)
+    path = os.path.join(ROOT, "tests", "golden", "bench_plonk_gwc19_evm_1024.bin")
+    if os.path.exists(path):
+        fx = H.read_fixture(path)
+        hp, hdk = H.Protocol(fx["protocol"]), H.DecidingKey(fx["dk"])
+        best = None
+        for _ in range(5):
+            ok, acc, tm = H.aggregate(hp, hdk, fx["instances"], fx["proofs"], fx["n"], H.MOS_GWC19, 0, threads, timings=True)
+            if best is None or tm["total"] < best["total"]:
+                best = tm
+        out["end_to_end_aggregate_1024_distinct_proofs"] = {
+            "ms": best["total"], "proofs_per_s": fx["n"] / best["total"] * 1e3, "host_threads": threads,
+            "ms_read_proofs_host": best["read_proofs"], "ms_fr_algebra_host": best["fr_algebra"],
+            "ms_msm_device_incl_h2d": best["msm_device"], "ms_kzg_accumulate": best["accumulate"], "ms_decide": best["decide"],
+            "accepted": bool(ok), "matches_fixture_accumulator": acc == fx["expected_acc"], "input": os.path.basename(path)}
+        hp.close()
+        hdk.close()
     return out
 
 

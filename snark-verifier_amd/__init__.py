@@ -21,7 +21,10 @@ from ._lib import (  # noqa: F401
     G1_PARTIAL_BYTES,
 )
 
+from . import host_api  # noqa: F401,E402  (C API of the C++ host mirror: include/snarkv_host.h)
+
 __all__ = [
+    "host_api",
     "Context",
     "DecidingKey",
     "IpaDecidingKey",

@@ -80,49 +80,51 @@ def build_pallas(verbose=False):
 
 
 HOST = os.path.join(HERE, "host")
-HOST_LIB = os.path.join(HERE, "libsnarkv_host.so")
+HOST_LIB = os.path.join(HERE, "libsnarkv_host.so")                 # product: C API of the host mirror (host/capi.cpp)
+HOSTTEST_LIB = os.path.join(HERE, "libsnarkv_hosttest.so")         # test hooks only (host/test_driver.cpp)
+HOST_PALLAS_LIB = os.path.join(HERE, "libsnarkv_hosttest_pallas.so")  # pasta flavour of the mirror, test hooks
+
+
+def _host_stale(out, dev_lib):
+    srcs = [os.path.join(HOST, f) for f in os.listdir(HOST)] + [os.path.join(os.path.dirname(HERE), "include", "snarkv_host.h")]
+    newest = max([os.path.getmtime(f) for f in srcs] + [os.path.getmtime(dev_lib)])
+    return not os.path.exists(out) or os.path.getmtime(out) < newest
+
+
+def _gxx(out, src, extra, dev):
+    # -mbmi2 -madx: mulx/adcx for the 4x64 Montgomery products (every x86-64 server CPU since 2015)
+    cmd = ["g++", "-O3", "-mbmi2", "-madx", "-std=c++17", "-shared", "-fPIC"] + extra + ["-o", out, os.path.join(HOST, src),
+           "-L" + HERE, "-l" + dev, "-pthread", "-Wl,-rpath,$ORIGIN"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("host build failed: %s" % src)
+    return out
 
 
 def build_host_driver():
-    """C++ host mirror (host/*.hpp) + its test driver -> libsnarkv_host.so,
-    linked against libsnarkv_amd.so next to it (rpath $ORIGIN)."""
-    srcs = [os.path.join(HOST, f) for f in os.listdir(HOST)]
-    newest = max([os.path.getmtime(f) for f in srcs] + [os.path.getmtime(LIB)])
-    if os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) >= newest:
-        return HOST_LIB
-    # -mbmi2 -madx: mulx/adcx for the 4x64 Montgomery products (every x86-64 server CPU since 2015)
-    cmd = ["g++", "-O3", "-mbmi2", "-madx", "-std=c++17", "-shared", "-fPIC", "-o", HOST_LIB, os.path.join(HOST, "test_driver.cpp"),
-           "-L" + HERE, "-lsnarkv_amd", "-pthread", "-Wl,-rpath,$ORIGIN"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("host driver build failed")
-    build_host_driver_pallas()
+    """C++ host mirror (host/*.hpp): its C API (host/capi.cpp -> libsnarkv_host.so, include/snarkv_host.h), the test
+    hooks (host/test_driver.cpp -> libsnarkv_hosttest.so) and the pasta flavour's test hooks, each linked against the
+    device library next to it (rpath $ORIGIN).  Every target has its own staleness check."""
+    jobs = []
+    if _host_stale(HOST_LIB, LIB):
+        jobs.append((HOST_LIB, "capi.cpp", [], "snarkv_amd"))
+    if _host_stale(HOSTTEST_LIB, LIB):
+        jobs.append((HOSTTEST_LIB, "test_driver.cpp", [], "snarkv_amd"))
+    if os.path.exists(PALLAS_LIB) and _host_stale(HOST_PALLAS_LIB, PALLAS_LIB):
+        # -Dsnarkv_host=...: its own C++ namespace -- the two flavours define the same inline functions and
+        # `static constexpr` members with different constants, and C++17 inline variables are STB_GNU_UNIQUE
+        # (bound process-wide even under RTLD_LOCAL) when both libraries sit in one process
+        jobs.append((HOST_PALLAS_LIB, "test_driver_pallas.cpp",
+                     ["-DSNARKV_HOST_PALLAS", "-Dsnarkv_host=snarkv_host_pallas", "-fno-gnu-unique"], "snarkv_pallas"))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            list(ex.map(lambda j: _gxx(*j), jobs))
     return HOST_LIB
 
 
-HOST_PALLAS_LIB = os.path.join(HERE, "libsnarkv_host_pallas.so")
-
-
 def build_host_driver_pallas():
-    """The pasta flavour of the host mirror (host/test_driver_pallas.cpp, -DSNARKV_HOST_PALLAS): Fr = pallas::Scalar,
-    loader bound to libsnarkv_pallas.so."""
-    if not os.path.exists(PALLAS_LIB):
-        return None
-    srcs = [os.path.join(HOST, f) for f in os.listdir(HOST)]
-    newest = max([os.path.getmtime(f) for f in srcs] + [os.path.getmtime(PALLAS_LIB)])
-    if os.path.exists(HOST_PALLAS_LIB) and os.path.getmtime(HOST_PALLAS_LIB) >= newest:
-        return HOST_PALLAS_LIB
-    # -Dsnarkv_host=...: its own C++ namespace -- the two flavours define the same inline functions and
-    # `static constexpr` members with different constants, and C++17 inline variables are STB_GNU_UNIQUE
-    # (bound process-wide even under RTLD_LOCAL) when both libraries sit in one process
-    cmd = ["g++", "-O3", "-mbmi2", "-madx", "-std=c++17", "-shared", "-fPIC", "-DSNARKV_HOST_PALLAS",
-           "-Dsnarkv_host=snarkv_host_pallas", "-fno-gnu-unique", "-o", HOST_PALLAS_LIB,
-           os.path.join(HOST, "test_driver_pallas.cpp"), "-L" + HERE, "-lsnarkv_pallas", "-pthread", "-Wl,-rpath,$ORIGIN"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("host driver (pallas) build failed")
+    build_host_driver()
     return HOST_PALLAS_LIB
 
 

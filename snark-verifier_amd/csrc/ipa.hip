@@ -133,16 +133,27 @@ int SNARKV_API(ipa_decide_batch)(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const
     SNARKV_TRY(ctx_lanes(ctx));
     SNARKV_TRY(ctx_lanes_fork(ctx));
   }
-  for (size_t a = 0; a < m; ++a) {
+  // an error between fork and join must not leave the sub-streams unjoined: remember it, join, then return it
+  int rc = SNARKV_OK;
+  for (size_t a = 0; a < m && rc == SNARKV_OK; ++a) {
     snarkv_ctx* lane = lanes ? ctx_lane(ctx, a) : ctx;
     void* d_h;
-    SNARKV_TRY(ctx_reserve(lane, SLOT_IPA_H, n * 32, &d_h));
+    rc = ctx_reserve(lane, SLOT_IPA_H, n * 32, &d_h);
+    if (rc != SNARKV_OK) break;
     hipLaunchKernelGGL(k_h_coeffs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, lane->stream,
                        (const uint32_t*)d_xi + a * k * 8, k, 0u, (uint32_t)n, (uint32_t*)d_h);
-    SNARKV_HIP(hipGetLastError());
-    SNARKV_TRY(launch_msm_pippenger(lane, d_h, dk->d_points, n, 0, (uint8_t*)d_out + 64 * a, false));
+    if (hipGetLastError() != hipSuccess) {
+      set_last_error("ipa_decide_batch: k_h_coeffs launch failed");
+      rc = SNARKV_ERR_DEVICE;
+      break;
+    }
+    rc = launch_msm_pippenger(lane, d_h, dk->d_points, n, 0, (uint8_t*)d_out + 64 * a, false);
   }
-  if (lanes) SNARKV_TRY(ctx_lanes_join(ctx));
+  if (lanes) {
+    int jrc = ctx_lanes_join(ctx);
+    if (rc == SNARKV_OK) rc = jrc;
+  }
+  if (rc != SNARKV_OK) return rc;
   std::vector<uint8_t> got(m * 64);
   SNARKV_HIP(hipMemcpyAsync(got.data(), d_out, m * 64, hipMemcpyDeviceToHost, ctx->stream));
   SNARKV_HIP(hipStreamSynchronize(ctx->stream));

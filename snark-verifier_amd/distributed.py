@@ -68,6 +68,13 @@ def gpu_sharded_msm(ctx, d_scalars, d_points, n_total, window_bits=0):
     # created without a stream owns a private one), and the collective is ordered
     # against torch's current stream only -- so order the three steps explicitly.
     def partial_fn(lo, hi):
+        if hi == lo:
+            # ceil chunking leaves trailing ranks empty when n is small against the world size (n = 9, world = 8:
+            # ranks 5-7).  The device call would return SNARKV_ERR_EMPTY on this rank only and the peers would
+            # hang in the all-gather: contribute the identity instead (all-zero partial: ZZ = 0).
+            part.zero_()
+            torch.cuda.current_stream().synchronize()
+            return part
         ctx.msm_pippenger_partial_dev(d_scalars.data_ptr(), d_points.data_ptr(), hi - lo, part.data_ptr(), window_bits)
         ctx.sync()  # the partial is in memory before the all-gather reads it
         return part
@@ -251,7 +258,11 @@ class ShardedAggregation:
     (`verify_fn(lo, hi) -> bytes`, 128 bytes per accumulator), the accumulators are
     all-gathered (a few KiB: latency-bound) and every rank folds them and decides
     (`combine_fn(all_accumulator_bytes) -> (acc128, ok)`), so all ranks hold the same
-    verdict.  No other exchange: the per-proof MSMs never leave their GPU."""
+    verdict.  No other exchange: the per-proof MSMs never leave their GPU.
+
+    A shard that fails to verify (an invalid proof is a NORMAL outcome: `verify_fn` raises or returns None)
+    must not leave its rank outside the collectives while the peers block in them: the failure travels as
+    length -1 in the size exchange and EVERY rank returns `(None, False)` after it."""
 
     verify_fn: Callable
     combine_fn: Callable
@@ -263,14 +274,26 @@ class ShardedAggregation:
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
         lo, hi = shard_range(n_proofs, rank, world)
-        local = bytes(self.verify_fn(lo, hi)) if hi > lo else b""
+        failed, self.last_error = False, None
+        local = b""
+        if hi > lo:
+            try:
+                got = self.verify_fn(lo, hi)
+                if got is None:
+                    failed = True
+                else:
+                    local = bytes(got)
+            except Exception as e:  # reject on this shard: reported to every rank below
+                failed, self.last_error = True, e
         assert len(local) % 128 == 0
         if world == 1:
-            return self.combine_fn(local)
+            return (None, False) if failed else self.combine_fn(local)
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
         sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-        mine = torch.tensor([len(local)], dtype=torch.int64, device=dev)
+        mine = torch.tensor([-1 if failed else len(local)], dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(sizes, mine)
+        if int(sizes.min().item()) < 0:  # some shard rejected: same answer on every rank, no further collective
+            return None, False
         cap = int(sizes.max().item())
         buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
         if local:
@@ -282,27 +305,18 @@ class ShardedAggregation:
         return self.combine_fn(allb)
 
 
-def gpu_sharded_aggregation(host_lib, mos, tkind, protocol_bytes, instances_packed, proofs, dk320):
-    """Product wiring over the host mirror (libsnarkv_host.so): `instances_packed[i]` and
-    `proofs[i]` are the i-th proof's packed instances / proof bytes; returns (acc128, ok)."""
-    import ctypes
+def gpu_sharded_aggregation(protocol, dk, instances_packed, proofs, mos=0, transcript=0):
+    """Product wiring over the host mirror's C API (libsnarkv_host.so, include/snarkv_host.h; `host_api.Protocol` /
+    `host_api.DecidingKey` handles): `instances_packed[i]` and `proofs[i]` are the i-th proof's packed instances /
+    proof bytes; returns (acc128, ok) -- `(None, False)` on every rank when any shard fails to verify."""
+    from . import host_api as H
 
     def verify_fn(lo, hi):
         ib = b"".join(instances_packed[lo:hi])
-        prb = b"".join(len(p).to_bytes(4, "little") + p for p in proofs[lo:hi])
-        out = ctypes.create_string_buffer(128 * 8 * (hi - lo))
-        n = ctypes.c_uint32(0)
-        rc = host_lib.hd_plonk_succinct_verify(mos, tkind, protocol_bytes, len(protocol_bytes), ib, len(ib), prb, len(prb),
-                                               hi - lo, dk320, out, len(out), ctypes.byref(n))
-        if rc != 1:
-            raise RuntimeError("succinct verification failed on this shard: %d" % rc)
-        return out.raw[: 128 * n.value]
+        return H.plonk_succinct_verify_batch(protocol, dk, ib, H.pack_proofs(proofs[lo:hi]), hi - lo, mos, transcript)
 
     def combine_fn(allb):
-        acc = ctypes.create_string_buffer(128)
-        rc = host_lib.hd_kzg_as_accumulate_and_decide(allb, len(allb) // 128, dk320, acc)
-        if rc < 0:
-            raise RuntimeError("accumulation failed: %d" % rc)
-        return acc.raw, rc == 1
+        acc, _ = H.kzg_as_accumulate(allb)
+        return acc, H.kzg_decide(dk, acc)
 
     return ShardedAggregation(verify_fn, combine_fn).run(len(proofs))

@@ -248,6 +248,8 @@ struct IpaDecidingKey {
   IpaSuccinctVerifyingKey svk;
   std::vector<G1Affine> g;
   snarkv_ipa_dk* handle() const {
+    static std::mutex init_mu;  // lazy, once per key, under a lock (the host mirror is multi-threaded)
+    std::lock_guard<std::mutex> init(init_mu);
     if (!dk_) {
       if (g.empty() || (g.size() & (g.size() - 1)) != 0 || g.size() != ((size_t)1 << svk.k))
         throw Panic("IpaDecidingKey: g must hold 2^k points (reference: assert_eq!(scalars.len(), bases.len()), msm.rs:309)");

@@ -103,6 +103,9 @@ struct KzgDecidingKey {
   G2Affine g2, s_g2;
   KzgDecidingKey(const G1Affine& g1, const G2Affine& g2_, const G2Affine& s_g2_) : svk{g1}, g2(g2_), s_g2(s_g2_) {}
   snarkv_dk* handle() const {
+    // lazy, once per key; the host mirror is multi-threaded (HostPool), so the check sits under a lock
+    static std::mutex init_mu;
+    std::lock_guard<std::mutex> init(init_mu);
     if (!dk_) {
       snarkv_dk* h = nullptr;
       std::lock_guard<std::mutex> lock(device_mutex());
@@ -557,6 +560,11 @@ struct LimbsEncoding {
       for (size_t i = 0; i < LIMBS; ++i) tmp[i] = *limbs[c * LIMBS + i];
       if (!fe_from_limbs(tmp, pts + 32 * c)) throw Panic("limbs overflow the base field (reference: from_repr().unwrap())");
     }
+    // (0, 0) is this library's encoding of the identity and passes the device's on-curve check, but it is NOT
+    // a curve point for `C::from_xy` (0 != 0 + 3): the reference's unwrap() panics on it
+    static const uint8_t zero64[64] = {0};
+    if (!memcmp(pts, zero64, 64) || !memcmp(pts + 64, zero64, 64))
+      throw Panic("accumulator point (0, 0) is not on the curve (reference: from_xy().unwrap())");
     std::lock_guard<std::mutex> lock(device_mutex());
     if (bn254_g1_validate(pts, 2) != SNARKV_OK)
       throw Panic("accumulator point is non-canonical or off-curve (reference: from_xy().unwrap())");

@@ -1,4 +1,5 @@
-// Test driver for the C++ host mirror: exposes scenario functions with plain
+// Test driver for the C++ host mirror -> libsnarkv_hosttest.so (TEST HOOKS ONLY: the product API of the mirror is
+// host/capi.cpp -> libsnarkv_host.so, include/snarkv_host.h): exposes scenario functions with plain
 // byte buffers so the pytest suite can drive `Msm`, `KzgAs<Gwc19|Bdfg21>`,
 // `LimbsEncoding` and the decider exactly as the reference's callers do
 // (snark-verifier/examples/evm-verifier-with-accumulator.rs:357-380) and compare
@@ -10,6 +11,7 @@
 #include "aggregation.hpp"
 #include "pcs.hpp"
 #include "plonk.hpp"
+#include "wire.hpp"
 #include "transcript.hpp"
 
 using namespace snarkv_host;

@@ -1,4 +1,4 @@
-// Test driver of the PASTA flavour of the host mirror -> libsnarkv_host_pallas.so (compiled with
+// Test driver of the PASTA flavour of the host mirror -> libsnarkv_hosttest_pallas.so (compiled with
 // -DSNARKV_HOST_PALLAS: `Fr` = pallas::Scalar, the loader bound to libsnarkv_pallas.so).  It carries the
 // curve-generic part of the mirror -- Msm, the native loader, the IPA layer (host/ipa.hpp), the PLONK
 // verifier over `IpaAs<Bgh19>` (host/plonk.hpp) -- with halo2's
@@ -16,6 +16,7 @@
 #include "blake2b_transcript.hpp"
 #include "ipa.hpp"
 #include "plonk.hpp"
+#include "wire.hpp"
 
 using namespace snarkv_host;
 

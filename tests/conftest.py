@@ -18,7 +18,7 @@ def pytest_sessionstart(session):
     """The C-ABI libraries are build artefacts (git-ignored): in a tree where `__graft_entry__.build()` has not
     run yet, build them once (hipcc cross-compiles gfx950 without a GPU) instead of failing the symbol tests."""
     pkg = os.path.join(ROOT, "snark-verifier_amd")
-    need = ["libsnarkv_amd.so", "libsnarkv_pallas.so", "libsnarkv_host.so", "libsnarkv_host_pallas.so"]
+    need = ["libsnarkv_amd.so", "libsnarkv_pallas.so", "libsnarkv_host.so", "libsnarkv_hosttest.so", "libsnarkv_hosttest_pallas.so"]
     if all(os.path.exists(os.path.join(pkg, n)) for n in need):
         return
     import importlib.util

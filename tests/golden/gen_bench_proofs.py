@@ -5,7 +5,13 @@ or Poseidon transcript for the proofs, GWC19 multi-open -- so that bench.py can 
 end (proof bytes in, accept out) without importing the oracle.
 Layout: magic 'SVB1' | u32 n | u32 plen | protocol | u32 ilen | instances | u32 prlen | proofs (u32 len || bytes each)
         | dk (64 + 128 + 128) | expected aggregated accumulator (128)
-Run from the repo root:  python tests/golden/gen_bench_proofs.py"""
+Run from the repo root:  python tests/golden/gen_bench_proofs.py
+
+`python tests/golden/gen_bench_proofs.py 1024` writes the C5 workload (BASELINE.json configs[4],
+reference call pattern snark-verifier/examples/evm-verifier-with-accumulator.rs:357-385 x1024):
+bench_plonk_gwc19_evm_1024.bin, 1024 DISTINCT instance sets and proofs (per-proof seeded generators, forged in
+a process pool), same layout plus a trailer  u32 n | n x 128 B  = every proof's own accumulator as the
+oracle's PlonkSuccinctVerifier computed it (decide_all over 1024 distinct accumulators, per-proof parity)."""
 import os
 import random
 import struct
@@ -55,6 +61,51 @@ def main(n=64, kind="evm"):
     print("wrote", path, len(blob), "bytes")
 
 
+def _forge_one(args):
+    seed, i, kind = args
+    rng = random.Random(seed)
+    pr, dl = S.standard_plonk_protocol(rng)          # the same protocol in every worker (same seed)
+    rng = random.Random((seed << 20) ^ (i + 1))      # per-proof stream: distinct instances, blinds, evaluations
+    TR = T.EvmTranscript if kind == "evm" else T.PoseidonTranscript
+    inst = [[rng.randrange(O.R) for _ in range(m)] for m in pr["num_instance"]]
+    proof = P.forge_proof(pr, inst, SECRET, lambda: TR(), "gwc19", rng, dl)
+    pf = P.plonk_proof_read(pr, inst, TR(proof), "gwc19")
+    accs = P.succinct_verify(O.G1_GEN, pr, inst, pf, "gwc19")
+    assert len(accs) == 1
+    return inst, proof, accs[0]
+
+
+def main_distinct(n=1024, kind="evm", seed=0xC5C5):
+    import multiprocessing as mp
+
+    pr, _ = S.standard_plonk_protocol(random.Random(seed))
+    with mp.Pool() as pool:
+        res = pool.map(_forge_one, [(seed, i, kind) for i in range(n)], chunksize=8)
+    insts, proofs, accs = [r[0] for r in res], [r[1] for r in res], [r[2] for r in res]
+    assert len(set(proofs)) == n
+    t = T.EvmTranscript()
+    for lhs, rhs in accs:
+        t.common_ec_point(lhs)
+        t.common_ec_point(rhs)
+    r = t.squeeze_challenge()
+    agg = K.kzg_as_verify(accs, r)
+    assert agg[0] == O.g1_mul(agg[1], SECRET)
+    pb = S.pack_protocol(pr)
+    ib = b"".join(S.pack_instances(i) for i in insts)
+    prb = b"".join(struct.pack("<I", len(p)) + p for p in proofs)
+    dk = O.g1_to_bytes(O.G1_GEN) + O.g2_to_bytes(O.G2_GEN) + O.g2_to_bytes(O.g2_mul(O.G2_GEN, SECRET))
+    blob = (b"SVB1" + struct.pack("<I", n) + struct.pack("<I", len(pb)) + pb + struct.pack("<I", len(ib)) + ib
+            + struct.pack("<I", len(prb)) + prb + dk + O.g1_to_bytes(agg[0]) + O.g1_to_bytes(agg[1])
+            + struct.pack("<I", n) + b"".join(O.g1_to_bytes(l) + O.g1_to_bytes(rh) for l, rh in accs))
+    path = os.path.join(ROOT, "tests", "golden", "bench_plonk_gwc19_%s_%d.bin" % (kind, n))
+    with open(path, "wb") as f:
+        f.write(blob)
+    print("wrote", path, len(blob), "bytes")
+
+
 if __name__ == "__main__":
-    main(kind="evm")
-    main(kind="poseidon")
+    if len(sys.argv) > 1:
+        main_distinct(int(sys.argv[1]))
+    else:
+        main(kind="evm")
+        main(kind="poseidon")

@@ -24,7 +24,7 @@ def load_host_lib():
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     b.build_host_driver()  # g++ only; no-op unless a host header is newer than the library
-    return ctypes.CDLL(os.path.join(ROOT, "snark-verifier_amd", "libsnarkv_host.so"))
+    return ctypes.CDLL(os.path.join(ROOT, "snark-verifier_amd", "libsnarkv_hosttest.so"))
 
 
 def fr(x):

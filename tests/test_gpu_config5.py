@@ -1,0 +1,155 @@
+"""BASELINE.json configs[4] at size under `-m gpu`: 1 024 DISTINCT proofs through the whole native pipeline
+(the call pattern of snark-verifier/examples/evm-verifier-with-accumulator.rs:357-385, x1024) and the pairing
+decider over 1 024 distinct accumulators (`decide_all`, pcs/kzg/decider.rs:84-93), against what the oracle
+computed for the committed fixture tests/golden/bench_plonk_gwc19_evm_1024.bin (gen_bench_proofs.py 1024)
+and against the C oracle's pairing on the box's host cores.  Everything goes through the C APIs
+(include/snarkv_host.h over include/snarkv_amd.h)."""
+import os
+
+import pytest
+
+import bn254 as O
+import coracle as C
+from snark_verifier_amd import host_api as H
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return H.read_fixture(os.path.join(ROOT, "tests", "golden", "bench_plonk_gwc19_evm_1024.bin"))
+
+
+@pytest.fixture(scope="module")
+def handles(fx):
+    hp, hdk = H.Protocol(fx["protocol"]), H.DecidingKey(fx["dk"])
+    yield hp, hdk
+    hp.close()
+    hdk.close()
+
+
+def test_1024_distinct_proofs_per_proof_accumulators_equal_oracle(fx, handles):
+    hp, hdk = handles
+    assert fx["n"] == 1024 and len(fx["accs"]) == 128 * 1024
+    accs = H.plonk_succinct_verify_batch(hp, hdk, fx["instances"], fx["proofs"], fx["n"], strict=True)
+    assert accs == fx["accs"]  # 1 024 x (lhs, rhs), byte for byte what oracle/plonk.py's succinct verifier computed
+    assert len({accs[128 * i:128 * i + 128] for i in range(1024)}) == 1024
+
+
+def test_1024_distinct_proofs_aggregate_and_decide(fx, handles):
+    hp, hdk = handles
+    ok, acc = H.aggregate(hp, hdk, fx["instances"], fx["proofs"], fx["n"])
+    assert ok and acc == fx["expected_acc"]  # KzgAs over 1 024 accumulators == oracle/kzg.py's, then the pairing accepts
+    # the two halves separately: accumulate the fixture's accumulators, decide the result
+    acc2, r = H.kzg_as_accumulate(fx["accs"])
+    assert acc2 == fx["expected_acc"] and H.kzg_decide(hdk, acc2)
+    # the CPU restatement of the decider agrees on that accumulator (C oracle pairing, decider.rs:70-82)
+    assert C.kzg_decide(fx["dk"][64:192], fx["dk"][192:320], acc2)
+    # PlonkVerifier::verify on all 1 024: succinct verify + ONE decide_all over 1 024 accumulators
+    assert H.plonk_verify(hp, hdk, fx["instances"], fx["proofs"], fx["n"])
+
+
+def test_1024_proofs_with_a_corrupted_one_reject(fx, handles):
+    hp, hdk = handles
+    prb = bytearray(fx["proofs"])
+    # flip one bit inside the 700th proof's evaluation section: still parses, no longer verifies
+    off = 0
+    for _ in range(700):
+        off += 4 + int.from_bytes(prb[off:off + 4], "little")
+    ln = int.from_bytes(prb[off:off + 4], "little")
+    prb[off + 4 + ln - 200] ^= 4
+    try:
+        ok, _ = H.aggregate(hp, hdk, fx["instances"], bytes(prb), fx["n"])
+        assert not ok
+    except H.HostError as e:  # or the flipped byte made a non-canonical scalar: Error::Transcript
+        assert e.code == H.ERR_TRANSCRIPT
+
+
+@pytest.mark.parametrize("teams", ["1", "2"])
+def test_decide_all_1024_distinct_accumulators_with_invalid_ones_at_known_indices(gpu_ctx, fx, teams, monkeypatch):
+    """`decide_all` over 1 024 DISTINCT valid accumulators, k of them replaced by invalid ones at known indices:
+    per-accumulator verdicts exactly as expected, for both forms of the decide kernel, through the context API and
+    the host mirror; a sample cross-checked with the C oracle's pairing."""
+    import snark_verifier_amd as sv
+
+    monkeypatch.setenv("SNARKV_DECIDE_TEAMS", teams)
+    dkb = fx["dk"]
+    accs = bytearray(fx["accs"])
+    bad_idx = [0, 1, 63, 64, 511, 777, 1000, 1023]
+    g = O.g1_to_bytes(O.G1_GEN)
+    for k, i in enumerate(bad_idx):
+        a = bytes(accs[128 * i:128 * i + 128])
+        if k % 3 == 0:      # lhs + G
+            a = C.g1_add(a[:64], g) + a[64:]
+        elif k % 3 == 1:    # lhs and rhs swapped
+            a = a[64:] + a[:64]
+        else:               # rhs doubled
+            a = a[:64] + C.g1_add(a[64:], a[64:])
+        accs[128 * i:128 * i + 128] = a
+    accs = bytes(accs)
+    expected = [i not in bad_idx for i in range(1024)]
+    dk = sv.DecidingKey(gpu_ctx, dkb[:64], dkb[64:192], dkb[192:320])
+    allok, oks = gpu_ctx.decide_batch(dk, accs)
+    assert not allok and oks == expected
+    allok, oks = gpu_ctx.decide_batch(dk, fx["accs"])
+    assert allok and all(oks)
+    for m in (1, 2, 3, 64, 65, 512, 513):  # ragged batch sizes around the kernel-form switch (<= 512 accumulators)
+        allok, oks = gpu_ctx.decide_batch(dk, accs[:128 * m])
+        assert oks == expected[:m] and allok == all(expected[:m])
+    dk.close()
+    hdk = H.DecidingKey(dkb)
+    allok, oks = H.kzg_decide_all(hdk, accs)
+    assert not allok and oks == expected
+    hdk.close()
+    # C oracle on a sample including every bad index (a CPU decide costs ~2 ms)
+    sample = sorted(set(bad_idx + list(range(0, 1024, 37))))
+    sub = b"".join(accs[128 * i:128 * i + 128] for i in sample)
+    _, coks = C.kzg_decide_all(dkb[64:192], dkb[192:320], sub, os.cpu_count() or 1)
+    assert coks == [expected[i] for i in sample]
+
+
+def test_snark_in_the_reference_serialisation_end_to_end(fx, handles):
+    """N3: a (protocol, instances, proof) triple written as the SDK's bincode `Snark` (snark-verifier-sdk/src/lib.rs:47-53,
+    both field encodings) -> snarkv_host_snark_parse -> PlonkVerifier::verify on the device: accept; one flipped
+    proof byte: reject."""
+    import random
+    import struct
+
+    import interchange_fmt as X
+    import plonk_synth as S
+
+    rng = random.Random(0xC5C5)  # gen_bench_proofs.main_distinct's protocol
+    pr, _ = S.standard_plonk_protocol(rng)
+    assert S.pack_protocol(pr) == fx["protocol"]
+    # proof 5 and its instances out of the packed streams
+    ib, off = fx["instances"], 0
+    for _ in range(5):
+        cols, = struct.unpack_from("<I", ib, off)
+        off += 4
+        for _ in range(cols):
+            m, = struct.unpack_from("<I", ib, off)
+            off += 4 + 32 * m
+    cols, = struct.unpack_from("<I", ib, off)
+    o2, inst = off + 4, []
+    for _ in range(cols):
+        m, = struct.unpack_from("<I", ib, o2)
+        inst.append([int.from_bytes(ib[o2 + 4 + 32 * j:o2 + 36 + 32 * j], "little") for j in range(m)])
+        o2 += 4 + 32 * m
+    prb, off = fx["proofs"], 0
+    for _ in range(5):
+        off += 4 + int.from_bytes(prb[off:off + 4], "little")
+    proof = prb[off + 4:off + 4 + int.from_bytes(prb[off:off + 4], "little")]
+    hdk = handles[1]
+    for mode in ("canonical", "montgomery"):
+        s = H.Snark(X.snark_to_bincode(pr, inst, proof, mode), H.PROTOCOL_BINCODE)
+        assert H.plonk_verify(s.protocol, hdk, s.instances, H.pack_proofs([s.proof]), 1)
+        accs = H.plonk_succinct_verify_batch(s.protocol, hdk, s.instances, H.pack_proofs([s.proof]), 1)
+        assert accs == fx["accs"][128 * 5:128 * 6]
+        badp = bytearray(s.proof)
+        badp[-100] ^= 1
+        try:
+            assert not H.plonk_verify(s.protocol, hdk, s.instances, H.pack_proofs([bytes(badp)]), 1)
+        except H.HostError as e:
+            assert e.code == H.ERR_TRANSCRIPT
+        s.close()

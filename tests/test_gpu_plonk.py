@@ -259,8 +259,8 @@ def test_proof_sharded_aggregation_wiring(H):
 
     from snark_verifier_amd import distributed as D
 
-    H.hd_plonk_succinct_verify.argtypes = H.hd_plonk_verify.argtypes
-    H.hd_kzg_as_accumulate_and_decide.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p]
+    from snark_verifier_amd import host_api as HA
+
     n, pb, ib, prb, dk, exp = load_bench_blob()
     insts, proofs, off = [], [], 0
     for _ in range(n):  # split the packed streams per proof
@@ -276,8 +276,15 @@ def test_proof_sharded_aggregation_wiring(H):
         ln, = struct.unpack_from("<I", prb, off)
         proofs.append(prb[off + 4:off + 4 + ln])
         off += 4 + ln
-    acc, ok = D.gpu_sharded_aggregation(H, 0, 0, pb, insts, proofs, dk)
+    hp, hdk = HA.Protocol(pb), HA.DecidingKey(dk)
+    acc, ok = D.gpu_sharded_aggregation(hp, hdk, insts, proofs)
     assert ok and acc == exp
+    # a shard that fails to verify is a reject on every rank, not an exception that would leave the peers in a collective
+    bad = list(proofs)
+    bad[3] = bad[3][:100]
+    assert D.gpu_sharded_aggregation(hp, hdk, insts, bad) == (None, False)
+    hp.close()
+    hdk.close()
 
 
 @pytest.mark.parametrize("seed", list(range(24)))

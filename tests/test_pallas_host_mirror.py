@@ -1,4 +1,4 @@
-"""The pasta flavour of the C++ host mirror (libsnarkv_host_pallas.so: Fr = pallas::Scalar, halo2's Blake2b
+"""The pasta flavour of the C++ host mirror (libsnarkv_hosttest_pallas.so: Fr = pallas::Scalar, halo2's Blake2b
 transcript, the IPA layer bound to libsnarkv_pallas.so) against the oracle.
 CPU part: field, BLAKE2b (vs hashlib), transcript framing and point decompression.
 GPU part: the reference's `test_ipa` / `test_ipa_as` (pcs/ipa.rs:434-466, pcs/ipa/accumulation.rs:240-290)
@@ -34,7 +34,7 @@ def HP():
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     b.build_host_driver_pallas()
-    h = ctypes.CDLL(os.path.join(ROOT, "snark-verifier_amd", "libsnarkv_host_pallas.so"))
+    h = ctypes.CDLL(os.path.join(ROOT, "snark-verifier_amd", "libsnarkv_hosttest_pallas.so"))
     cp, u32, sz = ctypes.c_char_p, ctypes.c_uint32, ctypes.c_size_t
     h.hp_blake2b.argtypes = [cp, cp, sz, sz, cp]
     h.hp_transcript_script.argtypes = [cp, sz, cp, sz, cp]

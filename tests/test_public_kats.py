@@ -75,7 +75,7 @@ def test_eip197_pairing_check_c_oracle(kats):
 
 
 def test_keccak_and_poseidon_public_values(kats):
-    H = ctypes.CDLL(os.path.join(ROOT, "snark-verifier_amd", "libsnarkv_host.so"))
+    H = ctypes.CDLL(os.path.join(ROOT, "snark-verifier_amd", "libsnarkv_hosttest.so"))
     H.hd_keccak256.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
     H.hd_poseidon_permute.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
     for c in kats["keccak256"]:
