@@ -64,6 +64,11 @@ def load_library():
         path = lib_path()
         if not os.path.exists(path):
             raise HostError(ERR_DEVICE, "%s not built (run `python __graft_entry__.py`)" % path)
+        # the device library first, through its own loader: it brings torch's HIP runtime in before anything binds
+        # to /opt/rocm's copy (one HIP runtime per process; see _lib.load_library)
+        from ._lib import load_library as _load_device_library
+
+        _load_device_library()
         L = ctypes.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
