@@ -30,6 +30,33 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 BYTES_PER_POINT = 96    # 64 B affine point + 32 B scalar, read once
 
 
+def _kernel_source_hash():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_srchash", os.path.join(ROOT, "snark-verifier_amd", "_srchash.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.kernel_source_hash()
+
+
+def _profile_record(pattern):
+    """The newest profiles/<pattern> JSON whose recorded kernel-source hash equals the tree's, else (None, why)."""
+    import glob
+
+    cur = _kernel_source_hash()
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=os.path.getmtime, reverse=True):
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        if rec.get("kernel_source_hash") == cur:
+            return rec, os.path.relpath(path, ROOT)
+        stale = stale or os.path.relpath(path, ROOT)
+    return None, ("no record for kernel sources %s (newest: %s, taken on other kernels)" % (cur, stale)) if stale else \
+        "no record under profiles/%s" % pattern
+
+
 def cpu_baseline(ctx, d_scalars, d_points, sample_log2):
     """Reference algorithm restated in C (oracle/c/bn254_oracle.c <- util/msm.rs:259-343),
     timed on the host cores over a bounded sample of the SAME inputs.
@@ -133,6 +160,8 @@ def secondary_metrics(sv, torch, ctxs, cpu=True):
     for m in (1, 1024):
         ms = t_ms(lambda: ctx.decide_batch_dev(dk, one.data_ptr(), m, oks.data_ptr()), reps=3, warm=1)
         out["decide_all_%d" % m] = {"ms": ms, "decides_per_s": m / ms * 1e3, "all_accept": bool(oks[:m].cpu().all())}
+    if cpu:
+        out["decide_all_1"]["cpu_baseline"], out["decide_all_1024"]["cpu_baseline"] = cpu_baseline_decide(g2, g1 + g1)
     for d in dks:
         d.close()
     # `IpaAs::decide` (pcs/ipa/decider.rs:47-55) at k = 20: the other consumer of the 2^20-point MSM --
@@ -212,10 +241,39 @@ def end_to_end_metrics():
     return out
 
 
+def cpu_baseline_decide(g2, acc):
+    """CPU leg of `decide` / `decide_all(1024)` (pcs/kzg/decider.rs:70-93): the pairing
+    decider restated in C (oracle/c/bn254_pairing.inc: G2Prepared x2 per call as the reference, multi Miller loop, final
+    exponentiation), one thread as the reference runs it, and spread over all host threads (beyond-reference)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import coracle  # cpu_baseline leg only
+
+    reps = 16
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ok1 = coracle.kzg_decide(g2, g2, acc)
+    dt1 = (time.perf_counter() - t0) / reps
+    cores = os.cpu_count() or 1
+    m = 1024
+    t0 = time.perf_counter()
+    allok, _ = coracle.kzg_decide_all(g2, g2, acc * m, cores)
+    dtm = time.perf_counter() - t0
+    one = {"value": 1.0 / dt1, "unit": "decides/s", "cores": 1, "kind": "port", "accepted": bool(ok1),
+           "sample": "one KzgAs::decide (2 x G2Prepared::from + 2-pair Miller loop + final exponentiation) restated in C, "
+                     "1 thread, mean of %d calls = %.3f ms; not a halo2curves measurement" % (reps, dt1 * 1e3)}
+    many = {"value": m / dtm, "unit": "decides/s", "cores": cores, "kind": "port", "accepted": bool(allok),
+            "single_thread": {"value": 1.0 / dt1, "unit": "decides/s", "cores": 1,
+                              "sample": "decide_all is a loop of decide in the reference (decider.rs:84-93): 1 024 x %.3f ms = %.2f s on one thread"
+                                        % (dt1 * 1e3, m * dt1)},
+            "sample": "decide_all over 1 024 accumulators, the same C restatement spread over %d host threads (beyond-reference "
+                      "threading), %.3f s; not a halo2curves measurement" % (cores, dtm)}
+    return one, many
+
+
 def cpu_baseline_aggregate(ds, dp, offs, n1, nproofs, n2):
-    """CPU leg of the aggregate metric (SURVEY.md 8d): the reference's naive
-    NativeLoader loop (native.rs:61-71) restated in C, ONE thread (the reference
-    has no threading on this path), MSM part only (the C restatement has no pairing)."""
+    """CPU leg of the aggregate metric (SURVEY.md 8d; BASELINE.md section 3 row B2): the reference's naive
+    NativeLoader loop (native.rs:61-71) restated in C, ONE thread (the reference has no threading on this
+    path), followed by ONE pairing decide of the C restatement (decider.rs:70-82) -- the same job the device runs."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import coracle  # cpu_baseline leg only
 
@@ -223,11 +281,17 @@ def cpu_baseline_aggregate(ds, dp, offs, n1, nproofs, n2):
     p = bytes(dp[: 64 * max(n1, n2)].cpu().numpy())
     t0 = time.perf_counter()
     coracle.msm_batched(s[: 32 * n1], p[: 64 * n1], offs)
-    coracle.msm_batched(s[: 32 * n2], p[: 64 * n2], [0, nproofs + 1, n2])
+    acc = coracle.msm_batched(s[: 32 * n2], p[: 64 * n2], [0, nproofs + 1, n2])
+    g2 = bytes.fromhex(
+        "edf692d95cbdde46ddda5ef7d422436779445c5e66006a42761e1f12efde0018c212f3aeb785e49712e7a9353349aaf1255dfb31b7bf60723a480d9293938e19"
+        "aa7dfa6601cce64c7bd3430c69e7d1e38f40cb8d8071ab4aeb6d8cdba55ec8125b9722d1dcdaac55f38eb37033314bbc95330c69ad999eec75f05f58d0890609")
+    t1 = time.perf_counter()
+    coracle.kzg_decide(g2, g2, acc)
+    dt_dec = time.perf_counter() - t1
     dt = time.perf_counter() - t0
-    return {"value": nproofs / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
-            "sample": "the 64-proof job's %d MSM terms, naive double-and-add loop of native.rs:61-71 restated in C, "
-                      "1 thread, %.2f s; decide not included; not a halo2curves measurement" % (n1 + n2, dt)}
+    return {"value": nproofs / dt, "unit": "proofs/s", "cores": 1, "kind": "port", "includes_decide": True,
+            "sample": "the 64-proof job's %d MSM terms, naive double-and-add loop of native.rs:61-71 restated in C, then one "
+                      "pairing decide (%.1f ms), 1 thread, %.2f s in all; not a halo2curves measurement" % (n1 + n2, dt_dec * 1e3, dt)}
 
 
 def main():
@@ -237,7 +301,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=20, help="points per GPU = 2^log2n")
     ap.add_argument("--window-bits", type=int, default=0)
-    ap.add_argument("--cpu-sample-log2", type=int, default=18)
+    ap.add_argument("--cpu-sample-log2", type=int, default=20,
+                    help="CPU baseline sample = the first 2^k points of the same inputs (default: the whole 2^20 workload)")
+    ap.add_argument("--total-log2n", type=int, default=0,
+                    help="STRONG scaling: 2^k points in total, split evenly over the ranks (BASELINE config 4: --gpus 8 "
+                         "--total-log2n 24); overrides --log2n")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path even at world size 1 (testing)")
@@ -265,7 +333,14 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    n = 1 << args.log2n
+    strong = args.total_log2n > 0
+    if strong:
+        if (1 << args.total_log2n) % world:
+            raise SystemExit("--total-log2n: the world size must divide 2^k")
+        n = (1 << args.total_log2n) // world
+        args.log2n = n.bit_length() - 1
+    else:
+        n = 1 << args.log2n
     # One context per in-flight MSM, each on its own HIP stream: the latency-bound
     # tail of one MSM (bucket reduce, 2^(cw) doubling chains, to_affine: a few
     # wavefronts) overlaps the VALU-bound bucket accumulation of the next.
@@ -376,7 +451,7 @@ def main():
         dom_ms = stages[dom]
         achieved = BYTES_PER_POINT * n / (dom_ms * 1e-3) / 1e9
         line = {
-            "metric": "BN254 G1 MSM points/sec at 2^%d" % args.log2n,
+            "metric": "BN254 G1 MSM points/sec at 2^%d" % (args.total_log2n if strong else args.log2n),
             "value": world * n * args.steps / dt,
             "unit": "points/s",
             "n_gpus": world,
@@ -384,13 +459,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "i32x9 (254-bit Montgomery Fq as 9 x 29-bit signed lazy limbs on the integer VALU, 64-bit column accumulators)",
             "data": "synthetic",
             "config": {
-                "workload": "BN254 G1 Pippenger MSM, 2^%d random points/scalars per GPU, inputs resident in HBM, "
-                            "affine result (configs[1])" % args.log2n,
+                "workload": ("BN254 G1 Pippenger MSM, 2^%d random points/scalars IN TOTAL sharded over %d GPU(s) (2^%d each), "
+                             "inputs resident in HBM, affine result (configs[3])" % (args.total_log2n, world, args.log2n)) if strong
+                            else "BN254 G1 Pippenger MSM, 2^%d random points/scalars per GPU, inputs resident in HBM, "
+                                 "affine result (configs[1])" % args.log2n,
                 "points_per_gpu": n,
                 "window_bits": args.window_bits or "default",
                 "parallelism": "point-sharded x%d, all-gather of 144 B partials + local fold" % world,
@@ -409,17 +486,42 @@ def main():
                 # (profiles/r01_rocprofv3_pmc_hbm_traffic_final3.txt): k_accumulate, bytes per launch, FETCH_SIZE + WRITE_SIZE
                 # as counted (Infinity-Cache hits included; the guide's x2 correction for wide coalesced reads would
                 # give 4.34e9).  Only valid for the default 2^20 workload; null otherwise.
-                "traffic": 2.235e9 if (args.log2n == 20 and dom == "bucket_accumulate") else None,
-                "traffic_note": "k_accumulate gathers each 72-byte Montgomery point once per window (8 windows x 2^21 "
-                                "half-scalars x 72 B = 1.2e9 B algorithmic gather, 128-byte requests; served mostly by the "
-                                "256 MiB Infinity Cache: the 151 MB table fits) -- inherent "
-                                "to bucket accumulation, not re-reads of the 96 B/point input",
+                "traffic": None,  # filled below from the PMC record of THESE kernels, or left null
+
                 "note": "algorithmic 96 B/point x 2^%d points / avg HIP-event duration of the dominant stage in the "
                         "timed region (where %d MSMs overlap, so one launch shares the GPU); the path is "
                         "integer-VALU-bound (~160 Fq products per point), see DESIGN.md" % (args.log2n, inflight),
             },
             "stages_ms": stages,
         }
+        # HBM-side traffic of the dominant kernel: rocprofv3 PMC (tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE
+        # passes, gfx950 correction 2 x FETCH + WRITE), quoted only from a record taken on the kernels of this tree
+        pmc, where = _profile_record("r*_pmc_hbm_traffic%s.json" % ("" if args.log2n == 20 else "_2p%d" % args.log2n))
+        kname = {"bucket_accumulate": "k_accumulate"}.get(dom)
+        if pmc and kname in pmc["kernels"]:
+            k = pmc["kernels"][kname]
+            line["roofline"]["traffic"] = k["bytes_corrected"]
+            line["roofline"]["traffic_as_counted"] = k["bytes_as_counted"]
+            line["roofline"]["traffic_source"] = where + " (kernel_source_hash %s)" % pmc["kernel_source_hash"]
+            line["roofline"]["traffic_note"] = (
+                "per launch of k_accumulate; it gathers every Montgomery point once per window (8 windows x 2^21 half-scalar "
+                "entries), mostly out of the 256 MiB Infinity Cache (the counter sits on the fabric side of L2 and includes "
+                "those hits) -- inherent to bucket accumulation, not re-reads of the 96 B/point input")
+        else:
+            line["roofline"]["traffic_source"] = where if not pmc else "record has no %s" % kname
+        # issue roofline of the dominant kernel from its ISA (tools/isa_stats.py), same hash rule
+        isa, iwhere = _profile_record("r*_isa_k_accumulate.json")
+        if isa:
+            line["issue_roofline"] = {
+                "kernel": "k_accumulate", "mads_per_entry": isa["mads_per_entry"], "instr_per_entry": isa["instr_per_entry"],
+                "frac": isa["useful_issue_fraction"], "source": iwhere,
+                "note": "static ISA census of the accumulate loop: v_mad_i64_i32 (the 29 x 29-bit partial products) per issued "
+                        "instruction; on gfx950 every instruction of this mix costs one ~4.2-cycle issue slot "
+                        "(profiles/r02_ubench_issue.txt), so this is the fraction of issue slots doing arithmetic that the "
+                        "algorithm needs",
+            }
+        else:
+            line["issue_roofline"] = {"kernel": "k_accumulate", "frac": None, "source": iwhere}
         if not use_dist:
             # Integer-VALU roofline (the binding constraint): the same
             # mixed addition as k_accumulate in isolation, 4 waves/SIMD on every CU.
@@ -443,7 +545,7 @@ def main():
             if dseq > 0:
                 line["roofline"]["achieved_unshared"] = BYTES_PER_POINT * n / (dseq * 1e-3) / 1e9
                 line["roofline"]["frac_unshared"] = line["roofline"]["achieved_unshared"] / HBM_PEAK_GBPS
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             cb, cpu_out, (s, p) = cpu_baseline(ctx, d_scalars, d_points, min(args.cpu_sample_log2, args.log2n))
             # the GPU must agree with the CPU restatement on that same sample
             m = len(s) // 32
@@ -452,6 +554,7 @@ def main():
             ctx.msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), m, chk.data_ptr(), 0)
             ctx.sync()
             cb["gpu_matches_on_sample"] = bytes(chk.cpu().numpy()) == cpu_out
+            cb["sample_is_the_whole_workload"] = m == n
             line["cpu_baseline"] = cb
         if not use_dist and not args.no_secondary:
             extra_streams = [torch.cuda.Stream() for _ in range(max(0, 8 - len(ctxs)))]  # kept alive

@@ -235,6 +235,35 @@ int bn254_poseidon_create(uint32_t t, uint32_t rate, uint32_t r_f, uint32_t r_p,
 int bn254_poseidon_transcript_batch(const snarkv_poseidon* ps, const uint8_t* elems, size_t n, size_t L,
                                     const uint32_t* seg_len, size_t S, uint8_t* out);
 
+/* ---- multi-GPU in ONE process (SURVEY.md 8b `*_multi_gpu`, 8e) -----------------
+ * For a caller without torchrun -- the reference's `NativeLoader` is a unit struct
+ * with static dispatch (loader.rs:108, native.rs:11-19).  A `snarkv_mgpu` owns one
+ * context + HIP stream per entry of `devices`; a device may be listed several times
+ * (each entry is a rank of its own: a 1-GPU box runs the 8-rank code path that way).
+ * Sharding follows the reference's own chunking, `chunk = ceil(n / ranks)`
+ * (util/msm.rs:311-336, GPUs in place of rayon threads); partial results travel as
+ * point-to-point peer copies over xGMI (144 bytes per rank) to rank 0's device and
+ * are folded there.  variant: 0 = point-sharded (every rank a full Pippenger of its
+ * shard), 1 = bucket-sharded (the "bucket-sum allreduce" of BASELINE config 4: all
+ * ranks fill the GLOBAL bucket grid, exchange it by window range, reduce the windows
+ * they own).  Same group element, same bytes, for any rank count and either variant.
+ * (One process per GPU keeps using RCCL: snark-verifier_amd/distributed.py.)      */
+typedef struct snarkv_mgpu snarkv_mgpu;
+int snarkv_mgpu_create(const int* devices, int n, snarkv_mgpu** out);
+void snarkv_mgpu_destroy(snarkv_mgpu* mg);
+int snarkv_mgpu_size(const snarkv_mgpu* mg);
+snarkv_ctx* snarkv_mgpu_ctx(snarkv_mgpu* mg, int rank);              /* rank's context (to allocate / fill its shard) */
+int snarkv_mgpu_shard(const snarkv_mgpu* mg, size_t n_total, int rank, size_t* lo, size_t* hi);
+/* host buffers of the WHOLE MSM (sharded, staged and reduced inside); n >= 1 */
+int snarkv_g1_msm_pippenger_mgpu(snarkv_mgpu* mg, const uint8_t* scalars32, const uint8_t* points64, size_t n,
+                                 int variant, uint8_t out64[64]);
+/* shards already resident: d_scalars32[g] / d_points64[g] on rank g's device, counts[g] points (0 allowed) */
+int snarkv_g1_msm_pippenger_mgpu_dev(snarkv_mgpu* mg, const void* const* d_scalars32, const void* const* d_points64,
+                                     const size_t* counts, int window_bits, int variant, uint8_t out64[64]);
+/* decide_all with the accumulators sharded over the ranks; returns 1 iff all accepted, ok[i] per accumulator */
+int snarkv_kzg_decide_batch_mgpu(snarkv_mgpu* mg, const uint8_t g1_64[64], const uint8_t g2_128[128],
+                                 const uint8_t s_g2_128[128], const uint8_t* accs128, size_t m, uint8_t* ok);
+
 int snarkv_set_stage_timing(snarkv_ctx* ctx, int enabled);
 int snarkv_get_stage_timing(snarkv_ctx* ctx, float ms[SNARKV_PIP_STAGES]);
 

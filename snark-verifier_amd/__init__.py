@@ -12,6 +12,7 @@ from ._lib import (  # noqa: F401
     Context,
     DecidingKey,
     IpaDecidingKey,
+    MultiGpu,
     PoseidonSpec,
     SnarkvError,
     lib_path,
@@ -28,6 +29,7 @@ __all__ = [
     "Context",
     "DecidingKey",
     "IpaDecidingKey",
+    "MultiGpu",
     "PoseidonSpec",
     "SnarkvError",
     "lib_path",

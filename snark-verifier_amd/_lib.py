@@ -74,6 +74,14 @@ _SIGNATURES = {
     "snarkv_sample_scalars_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
     "snarkv_sample_points_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
     "snarkv_ubench_valu": (_int, [_vp, _int, _int, ctypes.POINTER(ctypes.c_double)]),
+    "snarkv_mgpu_create": (_int, [ctypes.POINTER(_int), _int, _pp]),
+    "snarkv_mgpu_destroy": (None, [_vp]),
+    "snarkv_mgpu_size": (_int, [_vp]),
+    "snarkv_mgpu_ctx": (_vp, [_vp, _int]),
+    "snarkv_mgpu_shard": (_int, [_vp, _sz, _int, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "snarkv_g1_msm_pippenger_mgpu": (_int, [_vp, _cp, _cp, _sz, _int, _vp]),
+    "snarkv_g1_msm_pippenger_mgpu_dev": (_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_sz), _int, _int, _vp]),
+    "snarkv_kzg_decide_batch_mgpu": (_int, [_vp, _cp, _cp, _cp, _cp, _sz, _vp]),
     "snarkv_g1_msm_bucket_geometry": (_int, [_sz, _int, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
     "snarkv_g1_msm_fill_buckets_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "snarkv_g1_buckets_add_dev": (_int, [_vp, _vp, _vp, _sz]),
@@ -146,6 +154,70 @@ def _as_bytes(x):
     if tb is not None:
         return tb()
     raise TypeError("expected bytes-like, got %r" % type(x))
+
+
+class MultiGpu:
+    """Single-process multi-GPU handle (include/snarkv_amd.h "multi-GPU in ONE process"): one rank per entry of
+    `devices` (a device may repeat).  `msm_pippenger(scalars, points, variant)` and `decide_batch(...)` shard, run
+    and combine inside the library."""
+
+    POINT_SHARDED, BUCKET_SHARDED = 0, 1
+
+    def __init__(self, devices):
+        self._lib = load_library()
+        arr = (ctypes.c_int * len(devices))(*devices)
+        self._h = ctypes.c_void_p()
+        _check(self._lib.snarkv_mgpu_create(arr, len(devices), ctypes.byref(self._h)))
+        self.world = len(devices)
+
+    def close(self):
+        if self._h:
+            self._lib.snarkv_mgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shard(self, n_total, rank):
+        lo, hi = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        _check(self._lib.snarkv_mgpu_shard(self._h, n_total, rank, ctypes.byref(lo), ctypes.byref(hi)))
+        return lo.value, hi.value
+
+    def rank_context(self, rank):
+        """Borrowed `Context` of a rank (owned by the handle): to sample / stage that rank's shard on its device."""
+        c = Context.__new__(Context)
+        c._lib = self._lib
+        c._h = ctypes.c_void_p(self._lib.snarkv_mgpu_ctx(self._h, rank))
+        c._borrowed = True
+        return c
+
+    def msm_pippenger(self, scalars, points, variant=0):
+        scalars, points = _as_bytes(scalars), _as_bytes(points)
+        n = len(scalars) // 32
+        if len(points) != 64 * n:
+            raise SnarkvError(SNARKV_ERR_LENGTH, "scalars / points length mismatch (reference: assert_eq!, msm.rs:309)")
+        out = ctypes.create_string_buffer(64)
+        _check(self._lib.snarkv_g1_msm_pippenger_mgpu(self._h, scalars, points, n, variant, out))
+        return out.raw
+
+    def msm_pippenger_dev(self, d_scalars, d_points, counts, window_bits=0, variant=0):
+        w = self.world
+        ds = (ctypes.c_void_p * w)(*[int(x) if x else None for x in d_scalars])
+        dp = (ctypes.c_void_p * w)(*[int(x) if x else None for x in d_points])
+        cn = (ctypes.c_size_t * w)(*counts)
+        out = ctypes.create_string_buffer(64)
+        _check(self._lib.snarkv_g1_msm_pippenger_mgpu_dev(self._h, ds, dp, cn, window_bits, variant, out))
+        return out.raw
+
+    def decide_batch(self, g1, g2, s_g2, accs):
+        accs = _as_bytes(accs)
+        m = len(accs) // 128
+        ok = ctypes.create_string_buffer(max(m, 1))
+        allok = _check(self._lib.snarkv_kzg_decide_batch_mgpu(self._h, _as_bytes(g1), _as_bytes(g2), _as_bytes(s_g2), accs, m, ok))
+        return bool(allok), [b != 0 for b in ok.raw[:m]]
 
 
 class DecidingKey:
@@ -255,9 +327,9 @@ class Context:
         self.device = int(device)
 
     def close(self):
-        if self._h:
+        if self._h and not getattr(self, "_borrowed", False):
             self._lib.snarkv_ctx_destroy(self._h)
-            self._h = ctypes.c_void_p()
+        self._h = ctypes.c_void_p()
 
     def __del__(self):
         try:

@@ -58,6 +58,9 @@ int snarkv_get_stage_timing(snarkv_ctx* ctx, float ms[SNARKV_PIP_STAGES]) {
   SNARKV_HIP(hipStreamSynchronize(ctx->stream));
   SNARKV_HIP(hipEventElapsedTime(&ms[0], ctx->ev[0], ctx->ev[SNARKV_PIP_STAGES - 1]));
   for (int i = 1; i < SNARKV_PIP_STAGES; ++i) SNARKV_HIP(hipEventElapsedTime(&ms[i], ctx->ev[i - 1], ctx->ev[i]));
+  // pipelined mode: the accumulate stage as the KERNEL's own duration on the shared stream (ev[3] -> ev[4] would
+  // include the wait for other contexts' accumulations queued ahead of it)
+  if (ctx->acc_ev_ready && ctx->acc_timed) SNARKV_HIP(hipEventElapsedTime(&ms[4], ctx->acc_ev[1], ctx->acc_ev[2]));
   return SNARKV_OK;
 }
 

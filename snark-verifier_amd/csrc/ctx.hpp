@@ -64,6 +64,8 @@ enum Slot {
   SLOT_IPA_XI,
   SLOT_IPA_H,
   SLOT_IPA_OUT,
+  SLOT_MGPU_GRID,
+  SLOT_MGPU_RECV,
   SLOT_COUNT
 };
 
@@ -85,6 +87,11 @@ struct snarkv_ctx {
   snarkv_ctx* sub[4];
   hipEvent_t sub_ev[5];
   bool sub_ready;
+  // software pipeline across contexts: every k_accumulate of a device goes through ONE shared stream
+  // (msm_pippenger.hip, acc_lane); acc_ev = {inputs ready, kernel begins, kernel done}
+  hipEvent_t acc_ev[3];
+  bool acc_ev_ready;
+  bool acc_timed;  // the last Pippenger of this context ran its accumulation on the shared stream
 };
 
 struct snarkv_dk {

@@ -1,0 +1,308 @@
+// Single-process multi-GPU entry points of the C ABI (include/snarkv_amd.h, "multi-GPU"): what SURVEY.md 8(b) lists as
+// `*_multi_gpu` -- for a caller that is ONE process without torchrun (the reference's `NativeLoader` is a unit struct with
+// static dispatch, loader.rs:108 / native.rs:11-19: a Rust or C caller cannot be handed a torch.distributed world).
+//
+// A `snarkv_mgpu` owns one context + HIP stream per listed device.  The same device may be listed several times: each
+// entry is a "rank" with its own context, which is how the 1-GPU test box exercises every code path of an 8-rank run.
+//
+//   snarkv_g1_msm_pippenger_mgpu[_dev]   the reference's own chunking (`chunk = ceil(n / threads)`, every chunk a full
+//                                        Pippenger, results added: util/msm.rs:311-336) with GPUs in place of rayon
+//                                        threads.  variant 0 = point-sharded (default): rank g reduces its shard to a
+//                                        144-byte projective partial; the partials travel to rank 0's device by
+//                                        hipMemcpyPeerAsync (xGMI point-to-point; 144 B per rank: latency-bound) and are
+//                                        folded there.  variant 1 = bucket-sharded ("bucket-sum allreduce", SURVEY 8e /
+//                                        BASELINE config 4): every rank fills the GLOBAL bucket grid from its points, the
+//                                        grid is exchanged by window range (peer copies: a reduce-scatter whose reduction
+//                                        is EC addition, done on the receiving device), every rank reduces the windows it
+//                                        owns, partials gathered and folded as above.
+//   snarkv_kzg_decide_batch_mgpu         `decide_all` (pcs/kzg/decider.rs:84-93) with the accumulators sharded over the
+//                                        ranks; no exchange (independent pairings), m verdict bytes gathered by the host.
+//
+// No collective library is needed for either: the only inter-GPU traffic is point-to-point copies, which is what RCCL's
+// all-gather of 144 B per rank would degenerate to (one process per GPU keeps using RCCL: snark-verifier_amd/distributed.py).
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "ctx.hpp"
+
+struct snarkv_mgpu {
+  std::vector<snarkv_ctx*> ctx;     // one per rank
+  std::vector<hipEvent_t> done;     // rank's work so far finished (recorded on its stream when a peer needs it)
+  std::vector<hipEvent_t> filled;   // bucket-sharded: rank's grid is complete
+  std::vector<void*> d_gather;      // on rank 0's device: world x 144 B
+  std::vector<void*> d_part;        // per rank: its 144-byte partial
+  std::vector<snarkv_dk*> dk;       // decide: one prepared key per rank (lazily, keyed by the last key bytes)
+  uint8_t dk_bytes[320];
+  bool dk_valid = false;
+};
+
+namespace snarkv {
+
+static void shard(size_t n, int g, int world, size_t* lo, size_t* hi) {  // msm.rs:322: chunk = ceil(n / threads)
+  size_t chunk = (n + (size_t)world - 1) / (size_t)world;
+  *lo = std::min((size_t)g * chunk, n);
+  *hi = std::min(*lo + chunk, n);
+}
+
+// rank g's stream waits for everything rank src has enqueued so far
+static int wait_for(snarkv_mgpu* mg, int g, int src) {
+  SNARKV_HIP(hipSetDevice(mg->ctx[src]->device));
+  SNARKV_HIP(hipEventRecord(mg->done[src], mg->ctx[src]->stream));
+  SNARKV_HIP(hipSetDevice(mg->ctx[g]->device));
+  SNARKV_HIP(hipStreamWaitEvent(mg->ctx[g]->stream, mg->done[src], 0));
+  return SNARKV_OK;
+}
+
+// partials of all ranks -> rank 0's device -> fold -> 64 host bytes
+static int gather_fold(snarkv_mgpu* mg, uint8_t out64[64]) {
+  const int world = (int)mg->ctx.size();
+  snarkv_ctx* c0 = mg->ctx[0];
+  for (int g = 0; g < world; ++g) {
+    snarkv_ctx* c = mg->ctx[g];
+    SNARKV_HIP(hipSetDevice(c->device));
+    // the copy is enqueued on the PRODUCING rank's stream (ordered after its kernels), then rank 0 waits for it
+    SNARKV_HIP(hipMemcpyPeerAsync((char*)mg->d_gather[0] + (size_t)g * SNARKV_G1_PARTIAL_BYTES, c0->device, mg->d_part[g],
+                                  c->device, SNARKV_G1_PARTIAL_BYTES, c->stream));
+    if (g != 0) SNARKV_TRY(wait_for(mg, 0, g));
+  }
+  SNARKV_HIP(hipSetDevice(c0->device));
+  void* d_out;
+  SNARKV_TRY(ctx_reserve(c0, SLOT_OUT, 64, &d_out));
+  SNARKV_TRY(launch_fold_partials(c0, mg->d_gather[0], (size_t)world, d_out));
+  SNARKV_HIP(hipMemcpyAsync(out64, d_out, 64, hipMemcpyDeviceToHost, c0->stream));
+  SNARKV_HIP(hipStreamSynchronize(c0->stream));
+  return SNARKV_OK;
+}
+
+static int msm_point_sharded(snarkv_mgpu* mg, const void* const* d_s, const void* const* d_p, const size_t* counts,
+                             int window_bits, uint8_t out64[64]) {
+  const int world = (int)mg->ctx.size();
+  for (int g = 0; g < world; ++g) {
+    snarkv_ctx* c = mg->ctx[g];
+    SNARKV_HIP(hipSetDevice(c->device));
+    if (counts[g] == 0) {  // ceil chunking leaves trailing ranks empty when n is small: the identity (ZZ = 0)
+      SNARKV_HIP(hipMemsetAsync(mg->d_part[g], 0, SNARKV_G1_PARTIAL_BYTES, c->stream));
+      continue;
+    }
+    SNARKV_TRY(launch_msm_pippenger(c, d_s[g], d_p[g], counts[g], window_bits, mg->d_part[g], true));
+  }
+  return gather_fold(mg, out64);
+}
+
+static int msm_bucket_sharded(snarkv_mgpu* mg, const void* const* d_s, const void* const* d_p, const size_t* counts,
+                              size_t n_total, int window_bits, uint8_t out64[64]) {
+  const int world = (int)mg->ctx.size();
+  uint32_t c = 0, windows = 0, bpw = 0;
+  SNARKV_TRY(pip_geometry(n_total, window_bits, &c, &windows, &bpw));  // ONE geometry for all ranks: that of the total
+  const size_t wbytes = (size_t)bpw * SNARKV_G1_PARTIAL_BYTES, grid_bytes = wbytes * windows;
+  std::vector<void*> grid(world), recv(world);
+  std::vector<size_t> w0(world), w1(world);
+  for (int g = 0; g < world; ++g) {
+    shard(windows, g, world, &w0[g], &w1[g]);
+    snarkv_ctx* cx = mg->ctx[g];
+    SNARKV_HIP(hipSetDevice(cx->device));
+    SNARKV_TRY(ctx_reserve(cx, SLOT_MGPU_GRID, grid_bytes, &grid[g]));
+    SNARKV_TRY(ctx_reserve(cx, SLOT_MGPU_RECV, std::max<size_t>(16, (w1[g] - w0[g]) * wbytes), &recv[g]));
+    if (counts[g] == 0) SNARKV_HIP(hipMemsetAsync(grid[g], 0, grid_bytes, cx->stream));
+    else SNARKV_TRY(launch_msm_pippenger(cx, d_s[g], d_p[g], counts[g], (int)c, nullptr, false, grid[g]));
+    SNARKV_HIP(hipEventRecord(mg->filled[g], cx->stream));
+  }
+  // exchange by window range: owner g receives every other rank's copy of windows [w0, w1) and adds it to its own
+  for (int g = 0; g < world; ++g) {
+    if (w1[g] == w0[g]) continue;
+    snarkv_ctx* cx = mg->ctx[g];
+    const size_t own = (w1[g] - w0[g]) * wbytes;
+    for (int src = 0; src < world; ++src) {
+      if (src == g) continue;
+      snarkv_ctx* cs = mg->ctx[src];
+      SNARKV_HIP(hipSetDevice(cx->device));
+      SNARKV_HIP(hipStreamWaitEvent(cx->stream, mg->filled[src], 0));  // src's grid is complete
+      SNARKV_HIP(hipMemcpyPeerAsync(recv[g], cx->device, (const char*)grid[src] + w0[g] * wbytes, cs->device, own, cx->stream));
+      SNARKV_TRY(launch_buckets_add(cx, (char*)grid[g] + w0[g] * wbytes, recv[g], own / SNARKV_G1_PARTIAL_BYTES));
+    }
+  }
+  for (int g = 0; g < world; ++g) {
+    snarkv_ctx* cx = mg->ctx[g];
+    SNARKV_HIP(hipSetDevice(cx->device));
+    if (w1[g] == w0[g]) {  // more ranks than windows: the identity
+      SNARKV_HIP(hipMemsetAsync(mg->d_part[g], 0, SNARKV_G1_PARTIAL_BYTES, cx->stream));
+      continue;
+    }
+    SNARKV_TRY(launch_buckets_reduce(cx, (const char*)grid[g] + w0[g] * wbytes, c, (uint32_t)w0[g], (uint32_t)(w1[g] - w0[g]),
+                                     mg->d_part[g]));
+  }
+  // a grid must not be overwritten by this rank's NEXT call while a peer still copies from it: all ranks drain here
+  int rc = gather_fold(mg, out64);
+  for (int g = 0; g < world; ++g) {
+    (void)hipSetDevice(mg->ctx[g]->device);
+    (void)hipStreamSynchronize(mg->ctx[g]->stream);
+  }
+  return rc;
+}
+
+}  // namespace snarkv
+
+using namespace snarkv;
+
+extern "C" {
+
+int snarkv_mgpu_create(const int* devices, int n, snarkv_mgpu** out) {
+  if (!devices || !out || n <= 0 || n > 64) return SNARKV_ERR_ARG;
+  *out = nullptr;
+  snarkv_mgpu* mg = new snarkv_mgpu();
+  auto fail = [&](int rc) {
+    snarkv_mgpu_destroy(mg);
+    return rc;
+  };
+  for (int g = 0; g < n; ++g) {
+    snarkv_ctx* c = nullptr;
+    int rc = snarkv_ctx_create(devices[g], nullptr, &c);
+    if (rc < 0) return fail(rc);
+    mg->ctx.push_back(c);
+    hipEvent_t ev;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(SNARKV_ERR_DEVICE);
+    mg->done.push_back(ev);
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(SNARKV_ERR_DEVICE);
+    mg->filled.push_back(ev);
+    void* p = nullptr;
+    if (hipMalloc(&p, SNARKV_G1_PARTIAL_BYTES) != hipSuccess) return fail(SNARKV_ERR_DEVICE);
+    mg->d_part.push_back(p);
+  }
+  (void)hipSetDevice(devices[0]);
+  void* gbuf = nullptr;
+  if (hipMalloc(&gbuf, (size_t)n * SNARKV_G1_PARTIAL_BYTES) != hipSuccess) return fail(SNARKV_ERR_DEVICE);
+  mg->d_gather.push_back(gbuf);
+  // direct xGMI access between distinct devices where the platform allows it (peer copies work either way)
+  for (int a = 0; a < n; ++a)
+    for (int b = 0; b < n; ++b) {
+      int can = 0;
+      if (devices[a] != devices[b] && hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
+        (void)hipSetDevice(devices[a]);
+        hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+      }
+    }
+  (void)hipGetLastError();
+  *out = mg;
+  return SNARKV_OK;
+}
+
+void snarkv_mgpu_destroy(snarkv_mgpu* mg) {
+  if (!mg) return;
+  for (size_t g = 0; g < mg->ctx.size(); ++g) {
+    (void)hipSetDevice(mg->ctx[g]->device);
+    (void)hipStreamSynchronize(mg->ctx[g]->stream);
+  }
+  for (auto* d : mg->dk) snarkv_dk_destroy(d);
+  for (size_t g = 0; g < mg->d_part.size(); ++g) {
+    (void)hipSetDevice(mg->ctx[g]->device);
+    (void)hipFree(mg->d_part[g]);
+  }
+  if (!mg->d_gather.empty()) {
+    (void)hipSetDevice(mg->ctx[0]->device);
+    (void)hipFree(mg->d_gather[0]);
+  }
+  for (auto ev : mg->done) (void)hipEventDestroy(ev);
+  for (auto ev : mg->filled) (void)hipEventDestroy(ev);
+  for (auto* c : mg->ctx) snarkv_ctx_destroy(c);
+  delete mg;
+}
+
+int snarkv_mgpu_size(const snarkv_mgpu* mg) { return mg ? (int)mg->ctx.size() : SNARKV_ERR_ARG; }
+
+snarkv_ctx* snarkv_mgpu_ctx(snarkv_mgpu* mg, int rank) {
+  return (mg && rank >= 0 && rank < (int)mg->ctx.size()) ? mg->ctx[rank] : nullptr;
+}
+
+int snarkv_mgpu_shard(const snarkv_mgpu* mg, size_t n_total, int rank, size_t* lo, size_t* hi) {
+  if (!mg || !lo || !hi || rank < 0 || rank >= (int)mg->ctx.size()) return SNARKV_ERR_ARG;
+  shard(n_total, rank, (int)mg->ctx.size(), lo, hi);
+  return SNARKV_OK;
+}
+
+int snarkv_g1_msm_pippenger_mgpu_dev(snarkv_mgpu* mg, const void* const* d_scalars32, const void* const* d_points64,
+                                     const size_t* counts, int window_bits, int variant, uint8_t out64[64]) {
+  if (!mg || !d_scalars32 || !d_points64 || !counts || !out64 || variant < 0 || variant > 1) return SNARKV_ERR_ARG;
+  const int world = (int)mg->ctx.size();
+  size_t total = 0;
+  for (int g = 0; g < world; ++g) {
+    if (counts[g] && (!d_scalars32[g] || !d_points64[g])) return SNARKV_ERR_ARG;
+    total += counts[g];
+  }
+  if (total == 0) return SNARKV_ERR_EMPTY;  // reference panics: msm.rs:265
+  return variant == 0 ? msm_point_sharded(mg, d_scalars32, d_points64, counts, window_bits, out64)
+                      : msm_bucket_sharded(mg, d_scalars32, d_points64, counts, total, window_bits, out64);
+}
+
+int snarkv_g1_msm_pippenger_mgpu(snarkv_mgpu* mg, const uint8_t* scalars32, const uint8_t* points64, size_t n, int variant,
+                                 uint8_t out64[64]) {
+  if (!mg || !scalars32 || !points64 || !out64) return SNARKV_ERR_ARG;
+  if (n == 0) return SNARKV_ERR_EMPTY;
+  const int world = (int)mg->ctx.size();
+  std::vector<const void*> ds(world, nullptr), dp(world, nullptr);
+  std::vector<size_t> counts(world, 0);
+  for (int g = 0; g < world; ++g) {
+    size_t lo, hi;
+    shard(n, g, world, &lo, &hi);
+    counts[g] = hi - lo;
+    if (hi == lo) continue;
+    snarkv_ctx* c = mg->ctx[g];
+    SNARKV_HIP(hipSetDevice(c->device));
+    void *s, *p;
+    SNARKV_TRY(ctx_reserve(c, SLOT_IN_SCALARS, (hi - lo) * 32, &s));
+    SNARKV_TRY(ctx_reserve(c, SLOT_IN_POINTS, (hi - lo) * 64, &p));
+    SNARKV_HIP(hipMemcpyAsync(s, scalars32 + 32 * lo, (hi - lo) * 32, hipMemcpyHostToDevice, c->stream));
+    SNARKV_HIP(hipMemcpyAsync(p, points64 + 64 * lo, (hi - lo) * 64, hipMemcpyHostToDevice, c->stream));
+    ds[g] = s;
+    dp[g] = p;
+  }
+  return snarkv_g1_msm_pippenger_mgpu_dev(mg, ds.data(), dp.data(), counts.data(), 0, variant, out64);
+}
+
+int snarkv_kzg_decide_batch_mgpu(snarkv_mgpu* mg, const uint8_t g1_64[64], const uint8_t g2_128[128],
+                                 const uint8_t s_g2_128[128], const uint8_t* accs128, size_t m, uint8_t* ok) {
+  if (!mg || !g1_64 || !g2_128 || !s_g2_128 || (m && (!accs128 || !ok))) return SNARKV_ERR_ARG;
+  if (m == 0) return 1;  // decide_all over an empty list is Ok(()) (decider.rs:84-93)
+  const int world = (int)mg->ctx.size();
+  uint8_t key[320];
+  memcpy(key, g1_64, 64);
+  memcpy(key + 64, g2_128, 128);
+  memcpy(key + 192, s_g2_128, 128);
+  if (!mg->dk_valid || memcmp(key, mg->dk_bytes, 320) != 0) {  // G2 line tables: once per key per rank
+    for (auto* d : mg->dk) snarkv_dk_destroy(d);
+    mg->dk.clear();
+    mg->dk_valid = false;
+    for (int g = 0; g < world; ++g) {
+      snarkv_dk* d = nullptr;
+      SNARKV_TRY(snarkv_dk_create(mg->ctx[g], g1_64, g2_128, s_g2_128, 0, &d));
+      mg->dk.push_back(d);
+    }
+    memcpy(mg->dk_bytes, key, 320);
+    mg->dk_valid = true;
+  }
+  std::vector<void*> d_ok(world, nullptr);
+  std::vector<size_t> lo(world), hi(world);
+  for (int g = 0; g < world; ++g) {
+    shard(m, g, world, &lo[g], &hi[g]);
+    if (hi[g] == lo[g]) continue;
+    snarkv_ctx* c = mg->ctx[g];
+    SNARKV_HIP(hipSetDevice(c->device));
+    void* d_a;
+    SNARKV_TRY(ctx_reserve(c, SLOT_IN_POINTS, (hi[g] - lo[g]) * 128, &d_a));
+    SNARKV_TRY(ctx_reserve(c, SLOT_OUT, hi[g] - lo[g], &d_ok[g]));
+    SNARKV_HIP(hipMemcpyAsync(d_a, accs128 + 128 * lo[g], (hi[g] - lo[g]) * 128, hipMemcpyHostToDevice, c->stream));
+    SNARKV_TRY(launch_decide(c, mg->dk[g]->d_prep, d_a, hi[g] - lo[g], d_ok[g], nullptr));
+    SNARKV_HIP(hipMemcpyAsync(ok + lo[g], d_ok[g], hi[g] - lo[g], hipMemcpyDeviceToHost, c->stream));
+  }
+  int all = 1;
+  for (int g = 0; g < world; ++g) {
+    if (hi[g] == lo[g]) continue;
+    SNARKV_HIP(hipSetDevice(mg->ctx[g]->device));
+    SNARKV_HIP(hipStreamSynchronize(mg->ctx[g]->stream));
+  }
+  for (size_t i = 0; i < m; ++i) all &= ok[i] ? 1 : 0;
+  return all;
+}
+
+}  // extern "C"

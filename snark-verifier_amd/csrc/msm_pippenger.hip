@@ -74,6 +74,20 @@ namespace snarkv {
 #ifndef SNARKV_ACC_WAVES
 #define SNARKV_ACC_WAVES 3
 #endif
+// Wave priority of every Pippenger kernel EXCEPT k_accumulate (s_setprio, 0..3).  With several MSMs in flight the
+// latency-bound stages (one wavefront per SIMD or per window: bucket reduce, shift chains, to_affine) share their
+// SIMDs with three resident k_accumulate wavefronts of a neighbouring MSM; at equal priority the issue arbiter
+// gives them a quarter of the slots and they run ~3x longer than alone (rocprofv3 trace: k_shift_windows
+// 0.35 -> 0.57-0.71 ms, k_sort_level2 0.08 -> 0.8 ms), which is what the in-flight plateau is made of.  At
+// priority 3 they issue whenever they are ready -- a dependency chain cannot use more than its own latency allows --
+// and k_accumulate fills every other slot.
+#ifndef SNARKV_BPRIO
+#define SNARKV_BPRIO 3
+#endif
+#define SNARKV_RAISE_PRIO() __builtin_amdgcn_s_setprio(SNARKV_BPRIO)
+#ifndef SNARKV_ACC_STREAM_DEFAULT
+#define SNARKV_ACC_STREAM_DEFAULT 0  // see acc_lane()
+#endif
 constexpr int kHalves = SNARKV_GLV ? 2 : 1;       // virtual points per input point: P and phi(P), or P alone
 constexpr int kDigitWords = SNARKV_GLV ? 4 : 8;   // words of a digit source: a 127-bit GLV half / the 255-bit scalar
 constexpr int kDigitBits = 32 * kDigitWords;      // W * c covers this: magnitude bits + the recoding carry
@@ -171,6 +185,7 @@ __device__ __forceinline__ uint32_t load_digit_source(const uint4* __restrict__ 
 __global__ void __launch_bounds__(SNARKV_TILE_THREADS)
     k_prepare(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points,
               G1Affine29* __restrict__ pts, uint4* __restrict__ glv, PipParams p, uint32_t* __restrict__ M) {
+  SNARKV_RAISE_PRIO();
   extern __shared__ uint32_t lds[];  // nkeys counters
   for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) lds[k] = 0u;
   __syncthreads();
@@ -229,6 +244,7 @@ __global__ void __launch_bounds__(SNARKV_TILE_THREADS)
 __global__ void __launch_bounds__(SNARKV_TILE_THREADS)
     k_sort_scatter(const uint4* __restrict__ glv, PipParams p, const uint32_t* __restrict__ M,
                    uint2* __restrict__ tmp) {
+  SNARKV_RAISE_PRIO();
   extern __shared__ uint32_t lds[];  // nkeys cursors
   for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) lds[k] = M[(size_t)k * p.mstride + blockIdx.x];
   __syncthreads();
@@ -253,6 +269,7 @@ __global__ void __launch_bounds__(SNARKV_TILE_THREADS)
 // block sums scanned by one block, then added back.
 __global__ void __launch_bounds__(256) k_scan_local(uint32_t* __restrict__ data, uint32_t* __restrict__ blocksum,
                                                     uint32_t nb) {
+  SNARKV_RAISE_PRIO();
   __shared__ uint32_t sh[256];
   uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
   uint32_t v[4], s = 0;
@@ -280,6 +297,7 @@ __global__ void __launch_bounds__(256) k_scan_local(uint32_t* __restrict__ data,
 
 __global__ void __launch_bounds__(1024) k_scan_blocksums(uint32_t* __restrict__ blocksum, uint32_t nblocks,
                                                          uint32_t* __restrict__ total_out) {
+  SNARKV_RAISE_PRIO();
   __shared__ uint32_t sh[1024];
   __shared__ uint32_t running;
   if (threadIdx.x == 0) running = 0;
@@ -306,6 +324,7 @@ __global__ void __launch_bounds__(1024) k_scan_blocksums(uint32_t* __restrict__ 
 
 __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ data, const uint32_t* __restrict__ blocksum,
                                                   uint32_t nb) {
+  SNARKV_RAISE_PRIO();
   uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
   uint32_t add = blocksum[blockIdx.x];
 #pragma unroll
@@ -325,6 +344,7 @@ __global__ void __launch_bounds__(512)
     k_sort_level2(const uint2* __restrict__ tmp, const uint32_t* __restrict__ M, const uint32_t* __restrict__ total_ptr,
                   PipParams p, uint2* __restrict__ entries, uint32_t* __restrict__ counts,
                   uint32_t* __restrict__ offsets) {
+  SNARKV_RAISE_PRIO();
   extern __shared__ uint32_t lds[];  // nbins counters | 512 scan words | kSortCap items (uint2)
   const uint32_t nbins = 1u << p.low_bits;
   uint32_t* hist = lds;
@@ -494,6 +514,7 @@ __global__ void __launch_bounds__(64)
               const uint2* __restrict__ entries, const G1Affine29* __restrict__ pts,
               const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
               G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list) {
+  SNARKV_RAISE_PRIO();
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= p.nb) return;
   uint32_t cnt = counts[b];
@@ -535,6 +556,7 @@ __global__ void __launch_bounds__(256)
                   const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
                   G1Xyzz29* __restrict__ buckets, const uint32_t* __restrict__ big_count,
                   const uint32_t* __restrict__ big_list) {
+  SNARKV_RAISE_PRIO();
   __shared__ G1Xyzz29 sh[256];
   __shared__ int any_bad;
   uint32_t nbig = *big_count < kMaxBig ? *big_count : kMaxBig;
@@ -671,6 +693,7 @@ constexpr int kLog2BlockBuckets = 6 + kLog2Chunk;  // a P6 block covers 64 * kCh
 __global__ void __launch_bounds__(64)
     k_bucket_reduce(const G1Xyzz29* __restrict__ buckets, G1Xyzz29* __restrict__ block_parts, PipParams p,
                     uint32_t chunks_per_window, uint32_t blocks_per_window) {
+  SNARKV_RAISE_PRIO();
   __shared__ G1Xyzz29 sh[64];
   uint32_t w = blockIdx.x / blocks_per_window, bj = blockIdx.x % blocks_per_window;
   uint32_t j = bj * 64 + threadIdx.x;
@@ -741,6 +764,7 @@ __device__ __forceinline__ G1Xyzz29 xyzz29_double_n_quad(const G1Xyzz29& p, int 
 __global__ void __launch_bounds__(64)
     k_shift_windows(const G1Xyzz29* __restrict__ block_parts, G1Xyzz29* __restrict__ shifted, PipParams p,
                     uint32_t blocks_per_window) {
+  SNARKV_RAISE_PRIO();
   __shared__ G1Xyzz29 sh[64];
   uint32_t w = blockIdx.x, lane = threadIdx.x;
   const G1Xyzz29* src = block_parts + 2 * (size_t)w * blocks_per_window;
@@ -770,6 +794,7 @@ __global__ void __launch_bounds__(64)
 // projective partial for the multi-GPU fold).  Also used for the fold itself.
 __global__ void __launch_bounds__(64)
     k_final(const G1Xyzz29* __restrict__ parts, uint32_t count, uint32_t* __restrict__ out, int partial_out) {
+  SNARKV_RAISE_PRIO();
   __shared__ G1Xyzz29 sh[64];
   uint32_t lane = threadIdx.x;
   G1Xyzz29 acc = xyzz29_identity();
@@ -798,6 +823,47 @@ __global__ void __launch_bounds__(64)
       for (int i = 0; i < 16; ++i) out[i] = w[i];
     }
   }
+}
+
+// ---- the accumulate lane ----------------------------------------------------------------------------
+// With several MSMs in flight (one context + stream each) the kernels of different MSMs share the GPU as the
+// hardware queues happen to interleave them: rocprofv3 traces show all four queues inside their latency-/
+// memory-bound stages at once for a quarter of the wall time (no k_accumulate resident, the integer VALU idle)
+// and then three k_accumulate on top of each other.  Mode 1/2 turns that into a software pipeline: EVERY
+// k_accumulate of a device is enqueued on one shared stream (in launch order, back to back), the context's own
+// stream carries the stages before and after it and meets the shared stream through two events -- so the
+// VALU-bound kernel of MSM i overlaps the partition / bucket-reduce / shift chains of its neighbours by design.
+//   SNARKV_ACC_STREAM = 0  off (every kernel on the context's stream)
+//                       1  shared stream, default priority      2  shared stream, lowest priority
+static std::mutex g_acc_mu;
+static hipStream_t g_acc_stream[64];
+static int g_acc_mode = -1;
+static int acc_lane_mode() {
+  if (g_acc_mode < 0) {
+    const char* e = getenv("SNARKV_ACC_STREAM");
+    g_acc_mode = e ? atoi(e) : SNARKV_ACC_STREAM_DEFAULT;
+    if (g_acc_mode < 0 || g_acc_mode > 2) g_acc_mode = 0;
+  }
+  return g_acc_mode;
+}
+static int acc_lane(snarkv_ctx* ctx, hipStream_t* out) {
+  std::lock_guard<std::mutex> lock(g_acc_mu);
+  int mode = acc_lane_mode();
+  *out = nullptr;
+  if (mode == 0 || ctx->device >= 64) return SNARKV_OK;
+  if (!g_acc_stream[ctx->device]) {
+    int lo = 0, hi = 0;
+    SNARKV_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = numerically greatest = lowest priority
+    SNARKV_HIP(hipStreamCreateWithPriority(&g_acc_stream[ctx->device], hipStreamNonBlocking, mode == 2 ? lo : 0));
+  }
+  if (!ctx->acc_ev_ready) {
+    SNARKV_HIP(hipEventCreateWithFlags(&ctx->acc_ev[0], hipEventDisableTiming));
+    SNARKV_HIP(hipEventCreate(&ctx->acc_ev[1]));
+    SNARKV_HIP(hipEventCreate(&ctx->acc_ev[2]));
+    ctx->acc_ev_ready = true;
+  }
+  *out = g_acc_stream[ctx->device];
+  return SNARKV_OK;
 }
 
 int launch_fold_partials(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64, bool partial_out) {
@@ -913,9 +979,21 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   // (Tried: one shared low-priority HIP stream for every k_accumulate of a device, so that the small
   // kernels of other in-flight MSMs never queue behind it -- no gain, 2.0-2.1 ms/MSM either way; the
   // in-flight plateau is total VALU + HBM work)
-  hipLaunchKernelGGL(k_accumulate, dim3((max_runs + 63) / 64), dim3(64), 0, st, (const uint2*)d_entries,
+  hipStream_t acc_st = nullptr;
+  SNARKV_TRY(acc_lane(ctx, &acc_st));
+  ctx->acc_timed = acc_st != nullptr && tm;
+  if (acc_st) {  // inputs ready -> the shared accumulate stream -> done
+    SNARKV_HIP(hipEventRecord(ctx->acc_ev[0], st));
+    SNARKV_HIP(hipStreamWaitEvent(acc_st, ctx->acc_ev[0], 0));
+    if (tm) SNARKV_HIP(hipEventRecord(ctx->acc_ev[1], acc_st));
+  }
+  hipLaunchKernelGGL(k_accumulate, dim3((max_runs + 63) / 64), dim3(64), 0, acc_st ? acc_st : st, (const uint2*)d_entries,
                      (const uint32_t*)d_total, (const G1Affine29*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
                      (G1Xyzz29*)d_seg_parts);
+  if (acc_st) {
+    SNARKV_HIP(hipEventRecord(ctx->acc_ev[2], acc_st));
+    SNARKV_HIP(hipStreamWaitEvent(st, ctx->acc_ev[2], 0));
+  }
   STAGE_MARK();  // 4: bucket accumulate
   uint32_t* d_big_count = d_total + 4;
   SNARKV_HIP(hipMemsetAsync(d_big_count, 0, 4, st));
@@ -964,6 +1042,7 @@ int pip_geometry(size_t n_total, int window_bits, uint32_t* c, uint32_t* windows
 }
 
 __global__ void __launch_bounds__(256) k_buckets_add(G1Xyzz29* __restrict__ dst, const G1Xyzz29* __restrict__ src, uint32_t count) {
+  SNARKV_RAISE_PRIO();
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   G1Xyzz29 a = dst[i];

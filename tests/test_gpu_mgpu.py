@@ -1,0 +1,118 @@
+"""GPU: the single-process multi-GPU C ABI (include/snarkv_amd.h `snarkv_mgpu_*`, csrc/mgpu.hip; SURVEY.md 8b
+`*_multi_gpu`, 8e) on a 1-GPU box: every rank is a context of its own on device 0, so the sharding (the reference's
+`chunk = ceil(n / ranks)`, util/msm.rs:311-336), both combine variants (point-sharded / bucket-sharded "bucket-sum
+allreduce"), the peer copies, events and folds of an 8-rank run are all executed -- against the C oracle, bit for bit.
+BASELINE configs 4 and 5 in their single-process form."""
+import os
+
+import pytest
+
+import bn254 as O
+import coracle as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_mgpu_msm_host_buffers_vs_oracle(world, variant):
+    import snark_verifier_amd as sv
+
+    mg = sv.MultiGpu([0] * world)
+    assert mg.world == world
+    for n in (1, 5, 9, 777, 5000, (1 << 16) + 3):  # n < world: trailing ranks hold the identity
+        s, p = C.sample_scalars(0x40 + n, n), C.sample_points(0x41 + n, n)
+        assert mg.msm_pippenger(s, p, variant) == C.msm_pippenger(s, p, 8), (world, variant, n)
+    # duplicate / opposite / identity bases that end up in DIFFERENT shards and meet again in the exchange / fold
+    n = 4096
+    base = C.sample_points(0x77, n // 4)
+    p = bytearray(base * 4)
+    neg = O.g1_to_bytes(O.g1_neg(O.g1_from_bytes(bytes(p[:64]))))
+    p[64 * 2048:64 * 2049] = neg
+    p[64 * 7:64 * 8] = bytes(64)
+    s = bytearray(C.sample_scalars(0x78, n))
+    s[32 * 2048:32 * 2049] = s[:32]  # s_0 * P + s_0 * (-P) cancels across shards
+    assert mg.msm_pippenger(bytes(s), bytes(p), variant) == C.msm_pippenger(bytes(s), bytes(p), 8)
+    mg.close()
+
+
+def test_mgpu_shard_rule_and_errors():
+    import snark_verifier_amd as sv
+    from snark_verifier_amd.distributed import shard_range
+
+    mg = sv.MultiGpu([0, 0, 0])
+    for n in (1, 2, 3, 10, 1000):
+        assert [mg.shard(n, r) for r in range(3)] == [shard_range(n, r, 3) for r in range(3)]
+    with pytest.raises(sv.SnarkvError) as e:
+        mg.msm_pippenger(b"", b"")
+    assert e.value.code == -1  # empty MSM: the reference panics (msm.rs:265)
+    with pytest.raises(sv.SnarkvError) as e:
+        mg.msm_pippenger(bytes(64), bytes(64))
+    assert e.value.code == -2
+    with pytest.raises(sv.SnarkvError):
+        sv.MultiGpu([])
+    with pytest.raises(sv.SnarkvError):
+        sv.MultiGpu([99])  # no such device: loud failure, no fallback
+    mg.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_mgpu_config4_shape_device_resident_shards(variant):
+    """BASELINE config 4 in shape: 8 ranks, shards generated in place on each rank's device (disjoint index ranges of
+    the bench's seeded streams), 2^21 points in total here (2^18 per rank) so the threaded C oracle checks the bytes;
+    the 2^24 total of the config is the same code with bigger shards (bench.py --total-log2n 24)."""
+    import torch
+
+    import snark_verifier_amd as sv
+
+    world, per = 8, 1 << 18
+    mg = sv.MultiGpu([0] * world)
+    ds, dp = [], []
+    for r in range(world):
+        c = mg.rank_context(r)
+        s = torch.empty(32 * per, dtype=torch.uint8, device="cuda")
+        p = torch.empty(64 * per, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        c.sample_scalars_dev(0x5EED0001, per, s.data_ptr(), first=r * per)
+        c.sample_points_dev(0x5EED0002, per, p.data_ptr(), first=r * per)
+        c.sync()
+        ds.append(s)
+        dp.append(p)
+    got = mg.msm_pippenger_dev([t.data_ptr() for t in ds], [t.data_ptr() for t in dp], [per] * world, 0, variant)
+    s = b"".join(bytes(t.cpu().numpy()) for t in ds)
+    p = b"".join(bytes(t.cpu().numpy()) for t in dp)
+    assert s[:32 * 16] == C.sample_scalars(0x5EED0001, 16)
+    assert got == C.msm_pippenger(s, p, os.cpu_count() or 1)
+    # uneven shards incl. an empty one
+    counts = [per, 0, 1000, per, 7, per // 2, 1, per]
+    s2 = b"".join(bytes(ds[r][:32 * counts[r]].cpu().numpy()) for r in range(world))
+    p2 = b"".join(bytes(dp[r][:64 * counts[r]].cpu().numpy()) for r in range(world))
+    got = mg.msm_pippenger_dev([t.data_ptr() for t in ds], [t.data_ptr() for t in dp], counts, 0, variant)
+    assert got == C.msm_pippenger(s2, p2, os.cpu_count() or 1)
+    mg.close()
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_mgpu_decide_all_1024_sharded(world):
+    """BASELINE config 5's decider in its single-process multi-GPU form: 1 024 distinct accumulators of the committed
+    fixture, k invalid ones at known indices, sharded over `world` ranks: verdicts in order, identical for any rank count."""
+    import snark_verifier_amd as sv
+    from snark_verifier_amd import host_api as H
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fx = H.read_fixture(os.path.join(root, "tests", "golden", "bench_plonk_gwc19_evm_1024.bin"))
+    dk, accs = fx["dk"], bytearray(fx["accs"])
+    bad = [0, 127, 128, 341, 342, 682, 683, 1023]  # around the shard boundaries of 3 and 8 ranks
+    g = O.g1_to_bytes(O.G1_GEN)
+    for i in bad:
+        accs[128 * i:128 * i + 64] = C.g1_add(bytes(accs[128 * i:128 * i + 64]), g)
+    mg = sv.MultiGpu([0] * world)
+    allok, oks = mg.decide_batch(dk[:64], dk[64:192], dk[192:320], bytes(accs))
+    assert not allok and oks == [i not in bad for i in range(1024)]
+    allok, oks = mg.decide_batch(dk[:64], dk[64:192], dk[192:320], fx["accs"])
+    assert allok and all(oks)
+    for m in (1, 2, 5):  # fewer accumulators than ranks
+        allok, oks = mg.decide_batch(dk[:64], dk[64:192], dk[192:320], bytes(accs[:128 * m]))
+        assert oks == [i not in bad for i in range(m)]
+    assert mg.decide_batch(dk[:64], dk[64:192], dk[192:320], b"") == (True, [])
+    mg.close()

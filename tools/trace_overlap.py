@@ -21,6 +21,8 @@ def main():
     ap.add_argument("path")
     ap.add_argument("--tail", type=float, default=0.6)
     ap.add_argument("--focus", default="k_accumulate")
+    ap.add_argument("--first", type=int, default=-1, help="window = from the start of the N-th k_prepare (0-based) ...")
+    ap.add_argument("--count", type=int, default=20, help="... to the end of the (N+count)-th k_final")
     a = ap.parse_args()
     files = [a.path] if os.path.isfile(a.path) else glob.glob(os.path.join(a.path, "**", "*kernel_trace.csv"), recursive=True)
     ev = []
@@ -29,8 +31,14 @@ def main():
             ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
     ev.sort()
     t0, t1 = ev[0][0], max(e[1] for e in ev)
-    lo = t1 - (t1 - t0) * a.tail
-    ev = [e for e in ev if e[0] >= lo]
+    if a.first >= 0:
+        preps = [e for e in ev if e[2] == "k_prepare"]
+        fins = sorted(e[1] for e in ev if e[2] == "k_final")
+        lo, hi = preps[a.first][0], fins[a.first + a.count - 1]
+        ev = [e for e in ev if e[0] >= lo and e[1] <= hi]
+    else:
+        lo = t1 - (t1 - t0) * a.tail
+        ev = [e for e in ev if e[0] >= lo]
     t0, t1 = ev[0][0], max(e[1] for e in ev)
     pts = []
     for s, e, n in ev:
