@@ -31,6 +31,53 @@ struct G1Xyzz29 {
   Fq29 x, y, zz, zzz;
 };
 
+// Memory form of the Montgomery points the Pippenger gathers: each coordinate's canonical residue (< p < 2^256) as a
+// 256-bit little-endian integer, 64 bytes per point, 64-byte aligned -- ONE 64-byte sector per gather where the
+// 72-byte limb form straddled two (and, 7 times out of 8, two 128-byte lines): rocprofv3 FETCH_SIZE of k_accumulate
+// halves.  The 9 x 29-bit limbs are cut out of the words in registers (a v_alignbit + v_and per limb).
+struct alignas(64) G1Packed {
+  uint32_t w[16];
+};
+
+SNARKV_HD void fq29_pack256(const Fq29& a, uint32_t w[8]) {  // a: canonical residue, limbs in [0, 2^29)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int bit = 32 * j;
+    int i = bit / 29, sh = bit % 29;
+    uint64_t v = (uint64_t)(uint32_t)a.v[i];
+    if (i + 1 < 9) v |= (uint64_t)(uint32_t)a.v[i + 1] << 29;
+    if (i + 2 < 9 && sh + 32 > 58) v |= (uint64_t)(uint32_t)a.v[i + 2] << 58;
+    w[j] = (uint32_t)(v >> sh);
+  }
+}
+
+SNARKV_HD Fq29 fq29_unpack256(const uint32_t w[8]) {
+  Fq29 a;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    int bit = 29 * i;
+    int word = bit >> 5, sh = bit & 31;
+    uint64_t v = w[word];
+    if (word + 1 < 8) v |= (uint64_t)w[word + 1] << 32;
+    a.v[i] = (int32_t)((uint32_t)(v >> sh) & (uint32_t)kMask29);
+  }
+  return a;
+}
+
+SNARKV_HD G1Packed g1a29_pack(const G1Affine29& p) {
+  G1Packed r;
+  fq29_pack256(p.x, r.w);
+  fq29_pack256(p.y, r.w + 8);
+  return r;
+}
+
+SNARKV_HD G1Affine29 g1a29_unpack(const G1Packed& k) {
+  G1Affine29 r;
+  r.x = fq29_unpack256(k.w);
+  r.y = fq29_unpack256(k.w + 8);
+  return r;
+}
+
 SNARKV_HD bool g1a29_is_identity(const G1Affine29& p) { return fq29_limbs_all_zero(p.x) && fq29_limbs_all_zero(p.y); }
 
 SNARKV_HD G1Xyzz29 xyzz29_identity() {

@@ -60,7 +60,7 @@
 namespace snarkv {
 
 #ifndef SNARKV_KRUN
-#define SNARKV_KRUN 32
+#define SNARKV_KRUN 64
 #endif
 #ifndef SNARKV_KCHUNK
 #define SNARKV_KCHUNK 8
@@ -184,7 +184,7 @@ __device__ __forceinline__ uint32_t load_digit_source(const uint4* __restrict__ 
 // stored as zero, so the sort never has to look at the points again.
 __global__ void __launch_bounds__(SNARKV_TILE_THREADS)
     k_prepare(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points,
-              G1Affine29* __restrict__ pts, uint4* __restrict__ glv, PipParams p, uint32_t* __restrict__ M) {
+              G1Packed* __restrict__ pts, uint4* __restrict__ glv, PipParams p, uint32_t* __restrict__ M) {
   SNARKV_RAISE_PRIO();
   extern __shared__ uint32_t lds[];  // nkeys counters
   for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) lds[k] = 0u;
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(SNARKV_TILE_THREADS)
     }
     G1Affine29 a = g1a29_from_canonical(w);
     bool ident = g1a29_is_identity(a);
-    pts[kHalves * (size_t)i] = a;
+    pts[kHalves * (size_t)i] = g1a29_pack(a);
     const uint4* ks = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
     uint4 k0 = ks[0], k1 = ks[1];
     uint32_t k[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w}, o[8];
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(SNARKV_TILE_THREADS)
 #pragma unroll
     for (int j = 0; j < 9; ++j) beta.v[j] = bl[j];
     a.x = fq29_canon_residue(fq29_mul(a.x, beta));  // phi(P) = (beta x, y)
-    pts[2 * (size_t)i + 1] = a;
+    pts[2 * (size_t)i + 1] = g1a29_pack(a);
     glv_decompose(k, o);
 #else
 #pragma unroll
@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(512)
 // checks.  P5 tests every bucket once and redoes the rare bad one carefully.
 __global__ void __launch_bounds__(64, SNARKV_ACC_WAVES)
     k_accumulate(const uint2* __restrict__ entries, const uint32_t* __restrict__ total_ptr,
-                 const G1Affine29* __restrict__ pts, G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ seg_ids,
+                 const G1Packed* __restrict__ pts, G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ seg_ids,
                  G1Xyzz29* __restrict__ seg_parts) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t stop = *total_ptr;
@@ -438,7 +438,8 @@ __global__ void __launch_bounds__(64, SNARKV_ACC_WAVES)
   // software pipeline: the (entry -> point) gather of step e+1 is issued before the ~2 200-instruction
   // mixed addition of step e; two steps per trip with ping-pong registers, so the prefetched point is
   // consumed where it was loaded instead of being copied (18 moves per entry)
-  auto step = [&](const uint2& ent, G1Affine29& p) {
+  auto step = [&](const uint2& ent, const G1Packed& pk) {
+    G1Affine29 p = g1a29_unpack(pk);  // 256-bit words -> 9 x 29-bit limbs, in registers
     if (ent.x != cur) {
       if (first) {
         seg_ids[2 * slot] = cur;
@@ -462,7 +463,7 @@ __global__ void __launch_bounds__(64, SNARKV_ACC_WAVES)
     }
   };
   uint2 ent0 = entries[begin], ent1 = ent0;
-  G1Affine29 p0 = pts[ent0.y & 0x7FFFFFFFu], p1 = p0;
+  G1Packed p0 = pts[ent0.y & 0x7FFFFFFFu], p1 = p0;
 #pragma unroll 1
   for (uint32_t e = begin; e < end; e += 2) {
     if (e + 1 < end) {
@@ -492,12 +493,12 @@ __global__ void __launch_bounds__(64, SNARKV_ACC_WAVES)
 // Careful recomputation of one bucket straight from its sorted entries (the
 // rare bucket in which a fast addition met P = +-Q: duplicate / opposite bases).
 __device__ __noinline__ G1Xyzz29 bucket_from_entries_careful(const uint2* __restrict__ entries,
-                                                             const G1Affine29* __restrict__ pts, uint32_t o,
+                                                             const G1Packed* __restrict__ pts, uint32_t o,
                                                              uint32_t cnt, uint32_t first, uint32_t stride) {
   G1Xyzz29 acc = xyzz29_identity();
   for (uint32_t e = o + first; e < o + cnt; e += stride) {
     uint2 ent = entries[e];
-    G1Affine29 p = pts[ent.y & 0x7FFFFFFFu];
+    G1Affine29 p = g1a29_unpack(pts[ent.y & 0x7FFFFFFFu]);
     if (ent.y >> 31) p.y = fq29_neg(p.y);
     xyzz29_madd_careful(acc, p);
   }
@@ -511,7 +512,7 @@ __device__ __noinline__ G1Xyzz29 bucket_from_entries_careful(const uint2* __rest
 // signal, a run never legitimately produces the identity).
 __global__ void __launch_bounds__(64)
     k_combine(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, PipParams p,
-              const uint2* __restrict__ entries, const G1Affine29* __restrict__ pts,
+              const uint2* __restrict__ entries, const G1Packed* __restrict__ pts,
               const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
               G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list) {
   SNARKV_RAISE_PRIO();
@@ -552,7 +553,7 @@ __global__ void __launch_bounds__(64)
 // the whole bucket is recomputed carefully from its entries.
 __global__ void __launch_bounds__(256)
     k_combine_big(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                  const uint2* __restrict__ entries, const G1Affine29* __restrict__ pts,
+                  const uint2* __restrict__ entries, const G1Packed* __restrict__ pts,
                   const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
                   G1Xyzz29* __restrict__ buckets, const uint32_t* __restrict__ big_count,
                   const uint32_t* __restrict__ big_list) {
@@ -926,7 +927,7 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
 
   void *d_pts, *d_glv, *d_counts, *d_offsets, *d_M, *d_blocksum, *d_entries, *d_tmp, *d_seg_ids, *d_seg_parts,
       *d_buckets, *d_wave, *d_shift, *d_misc, *d_big;
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_POINTS_MONT, kHalves * n * sizeof(G1Affine29), &d_pts));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_POINTS_MONT, kHalves * n * sizeof(G1Packed), &d_pts));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_GLV, n * 32, &d_glv));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_COUNTS, (size_t)p.nb * 4, &d_counts));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_OFFSETS, (size_t)p.nb * 4, &d_offsets));
@@ -962,7 +963,7 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   size_t lds1 = (size_t)p.nkeys * 4;
   SNARKV_HIP(hipMemsetAsync(d_M, 0, (size_t)mcount * 4, st));  // padding columns must read as zero
   hipLaunchKernelGGL(k_prepare, dim3(p.nblk), dim3(SNARKV_TILE_THREADS), lds1, st, (const uint32_t*)d_scalars,
-                     (const uint32_t*)d_points, (G1Affine29*)d_pts, (uint4*)d_glv, p, (uint32_t*)d_M);
+                     (const uint32_t*)d_points, (G1Packed*)d_pts, (uint4*)d_glv, p, (uint32_t*)d_M);
   STAGE_MARK();  // 1: prepare (GLV split, phi(P), to Montgomery) + digit histogram
   hipLaunchKernelGGL(k_scan_local, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (uint32_t*)d_blocksum, mcount);
   hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, st, (uint32_t*)d_blocksum, scan_blocks, d_total);
@@ -988,7 +989,7 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
     if (tm) SNARKV_HIP(hipEventRecord(ctx->acc_ev[1], acc_st));
   }
   hipLaunchKernelGGL(k_accumulate, dim3((max_runs + 63) / 64), dim3(64), 0, acc_st ? acc_st : st, (const uint2*)d_entries,
-                     (const uint32_t*)d_total, (const G1Affine29*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
+                     (const uint32_t*)d_total, (const G1Packed*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
                      (G1Xyzz29*)d_seg_parts);
   if (acc_st) {
     SNARKV_HIP(hipEventRecord(ctx->acc_ev[2], acc_st));
@@ -998,14 +999,14 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   uint32_t* d_big_count = d_total + 4;
   SNARKV_HIP(hipMemsetAsync(d_big_count, 0, 4, st));
   hipLaunchKernelGGL(k_combine, dim3((p.nb + 63) / 64), dim3(64), 0, st, (const uint32_t*)d_counts,
-                     (const uint32_t*)d_offsets, p, (const uint2*)d_entries, (const G1Affine29*)d_pts,
+                     (const uint32_t*)d_offsets, p, (const uint2*)d_entries, (const G1Packed*)d_pts,
                      (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets, d_big_count,
                      (uint32_t*)d_big);
   // one workgroup per oversized bucket; idle workgroups exit at once
   uint32_t big_grid = (uint32_t)(max_runs / kBigSpan + 1);
   if (big_grid > kMaxBig) big_grid = kMaxBig;
   hipLaunchKernelGGL(k_combine_big, dim3(big_grid), dim3(256), 0, st, (const uint32_t*)d_counts,
-                     (const uint32_t*)d_offsets, (const uint2*)d_entries, (const G1Affine29*)d_pts,
+                     (const uint32_t*)d_offsets, (const uint2*)d_entries, (const G1Packed*)d_pts,
                      (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets,
                      (const uint32_t*)d_big_count, (const uint32_t*)d_big);
   STAGE_MARK();  // 5: bucket combine

@@ -299,3 +299,24 @@ void ht_fr29_roundtrip(const uint8_t* a, uint8_t* out) {
   memcpy(out, w, 32);
 }
 }
+
+// packed 64-byte memory form of the Pippenger's Montgomery points (g1_29.cuh G1Packed): canonical x | y -> Montgomery
+// canonical residues -> pack -> unpack -> back to canonical; also reports the packed words and whether every unpacked
+// limb is in [0, 2^29)
+extern "C" int ht_g1_pack_roundtrip(const uint8_t* p64, uint8_t* out64, uint8_t* packed64) {
+  uint32_t w[16];
+  memcpy(w, p64, 64);
+  G1Affine29 a = g1a29_from_canonical(w);
+  G1Packed k = g1a29_pack(a);
+  memcpy(packed64, k.w, 64);
+  G1Affine29 b = g1a29_unpack(k);
+  int ok = 1;
+  for (int i = 0; i < 9; ++i) {
+    ok &= b.x.v[i] == a.x.v[i] && b.y.v[i] == a.y.v[i];
+    ok &= b.x.v[i] >= 0 && b.x.v[i] <= kMask29 && b.y.v[i] >= 0 && b.y.v[i] <= kMask29;
+  }
+  uint32_t o[16];
+  g1a29_to_canonical(b, o);
+  memcpy(out64, o, 64);
+  return ok;
+}

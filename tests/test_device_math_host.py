@@ -296,3 +296,30 @@ def test_fr29_scalar_field(hosttest_lib):
         b, c = rng.choice(vals), rng.choice(vals)
         hosttest_lib.ht_fr29_expr(fb(a), fb(b), fb(c), o)
         assert int.from_bytes(o.raw, "little") == pow((a * b + c) % O.R, 5, O.R)
+
+
+def test_packed_point_memory_form_roundtrip(hosttest_lib):
+    """G1Packed (g1_29.cuh): the 64-byte memory form of the Montgomery points k_accumulate gathers -- each coordinate's
+    canonical Montgomery residue x * 2^261 mod p as a 256-bit LE integer -- unpacks to exactly the 9 x 29-bit limbs it
+    was packed from, for random points, the identity and coordinates near 0 and p."""
+    import random
+
+    H = hosttest_lib
+    H.ht_g1_pack_roundtrip.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    rng = random.Random(64)
+    R261 = pow(2, 261, O.P)
+    pts = [O.g1_mul(O.G1_GEN, rng.randrange(1, O.R)) for _ in range(40)]
+    raw = [O.g1_to_bytes(p) for p in pts] + [bytes(64)]
+    # field values that are not curve points exercise the codec alone: 0 / 1 / p-1 / all 29-bit-limb boundaries
+    for x in (1, 2, O.P - 1, O.P - 2, (1 << 253) + 12345, (1 << 29) - 1, 1 << 29, (1 << 232) - 1, 1 << 232):
+        raw.append(O.fe_to_bytes(x % O.P) + O.fe_to_bytes((O.P - x) % O.P))
+    for b in raw:
+        out, packed = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+        assert H.ht_g1_pack_roundtrip(b, out, packed) == 1
+        assert out.raw == b
+        if b != bytes(64):
+            x, y = int.from_bytes(b[:32], "little"), int.from_bytes(b[32:], "little")
+            assert int.from_bytes(packed.raw[:32], "little") == x * R261 % O.P
+            assert int.from_bytes(packed.raw[32:], "little") == y * R261 % O.P
+        else:
+            assert packed.raw == bytes(64)

@@ -49,6 +49,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", default="r02")
     ap.add_argument("--log2n", type=int, default=20)
+    ap.add_argument("--out-dir", default=os.path.join(ROOT, "profiles"),
+                    help="gpurun only merges gpurun_out/ back: use --out-dir gpurun_out there and copy the files into profiles/")
     a = ap.parse_args()
     spec = importlib.util.spec_from_file_location("_h", os.path.join(ROOT, "snark-verifier_amd", "_srchash.py"))
     h = importlib.util.module_from_spec(spec)
@@ -71,7 +73,7 @@ def main():
                 "(gfx950: FETCH_SIZE counts 128-byte requests as 64 B; Infinity-Cache hits included)",
         "kernels": kernels,
     }
-    base = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic%s" % (a.tag, "" if a.log2n == 20 else "_2p%d" % a.log2n))
+    base = os.path.join(a.out_dir, "%s_pmc_hbm_traffic%s" % (a.tag, "" if a.log2n == 20 else "_2p%d" % a.log2n))
     with open(base + ".json", "w") as f:
         json.dump(rec, f, indent=1)
     with open(base + ".txt", "w") as f:

@@ -1,19 +1,10 @@
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_sq -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --inflight 1 > /dev/null 2>$R/gpurun_out/pmc_sq.err
-cd $R; ls gpurun_out/pmc_sq/*/ | head; python - <<'PY'
-import csv,glob,re,collections
-f=glob.glob('gpurun_out/pmc_sq/**/*counter_collection.csv',recursive=True)[0]
-rows=list(csv.DictReader(open(f)))
-print(rows[0].keys())
-agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
-seen=set()
-for r in rows:
-    m=re.search(r"(k_[a-z0-9_]+)",r["Kernel_Name"]); n=m.group(1) if m else r["Kernel_Name"][:24]
-    agg[n][r["Counter_Name"]]+=float(r["Counter_Value"])
-    key=(n,r["Dispatch_Id"])
-    if key not in seen: seen.add(key); cnt[n]+=1
-names=sorted({c for v in agg.values() for c in v})
-print("%-24s %5s "%("kernel","calls")+" ".join("%16s"%c for c in names))
-for n,v in sorted(agg.items(), key=lambda kv:-kv[1].get("SQ_INSTS_VALU",0)):
-    print("%-24s %5d "%(n,cnt[n])+" ".join("%16.4g"%(v.get(c,0)/cnt[n]) for c in names))
-PY
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_msm.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -3
+for rep in 1 2 3; do
+  python bench.py --steps 24 --warmup 4 --no-cpu-baseline --no-secondary --inflight 4 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read())
+sq=d['stages_ms_sequential']
+print('packed64 value=%.3e ms=%.3f lat=%.3f seq: acc=%.3f comb=%.3f red=%.3f prep=%.3f sort=%.3f shift=%.3f' % (d['value'], d['ms_per_step'], d['config']['single_msm_latency_ms'], sq['bucket_accumulate'], sq['bucket_combine'], sq['bucket_reduce'], sq['prepare_glv_montgomery_histogram'], sq['partition_sort'], sq['window_shift_chain']))"
+done
+python tools/pmc_traffic.py --tag r02 --out-dir gpurun_out | head -8
