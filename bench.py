@@ -428,14 +428,23 @@ def main():
     lat_ms, seq_stages = None, None
     if not use_dist:
         torch.cuda.synchronize()
+        # one caller, one MSM at a time
+        for _ in range(2):
+            ctx.msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, out.data_ptr(), args.window_bits)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(8):
+            ctx.msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, out.data_ptr(), args.window_bits)
+            ctx.sync()
+        lat_ms = (time.perf_counter() - t1) / 8 * 1e3
+        assert bytes(out.cpu().numpy()) == bytes(outs[written[-1]].cpu().numpy())
+        # unshared per-stage durations, for the roofline of the dominant kernel
         ctx.set_stage_timing(True)
         seq_sum = {}
-        t1 = time.perf_counter()
         for _ in range(5):
             ctx.msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, out.data_ptr(), args.window_bits)
             for k, v in ctx.get_stage_timing().items():  # syncs
                 seq_sum[k] = seq_sum.get(k, 0.0) + v
-        lat_ms = (time.perf_counter() - t1) / 5 * 1e3
         ctx.set_stage_timing(False)
         seq_stages = {k: v / 5 for k, v in seq_sum.items()}
 

@@ -58,9 +58,6 @@ int snarkv_get_stage_timing(snarkv_ctx* ctx, float ms[SNARKV_PIP_STAGES]) {
   SNARKV_HIP(hipStreamSynchronize(ctx->stream));
   SNARKV_HIP(hipEventElapsedTime(&ms[0], ctx->ev[0], ctx->ev[SNARKV_PIP_STAGES - 1]));
   for (int i = 1; i < SNARKV_PIP_STAGES; ++i) SNARKV_HIP(hipEventElapsedTime(&ms[i], ctx->ev[i - 1], ctx->ev[i]));
-  // pipelined mode: the accumulate stage as the KERNEL's own duration on the shared stream (ev[3] -> ev[4] would
-  // include the wait for other contexts' accumulations queued ahead of it)
-  if (ctx->acc_ev_ready && ctx->acc_timed) SNARKV_HIP(hipEventElapsedTime(&ms[4], ctx->acc_ev[1], ctx->acc_ev[2]));
   return SNARKV_OK;
 }
 
@@ -114,37 +111,61 @@ int snarkv_g1_msm_batched_dev(snarkv_ctx* ctx, const void* d_scalars32, const vo
 
 }  // extern "C"
 
-// A Pippenger MSM of 2^20 points leaves the machine half idle during its
-// latency-bound tail (bucket reduce, 2^(cw) doubling chains, to_affine); several
-// MSMs in flight fill it.  A LARGE MSM gets the same benefit
-// from itself: MSM is linear (the reference's own chunking, msm.rs:311-336), so
-// n >= 2^22 points run as 2^20-point chunks round-robin on four lanes (the
-// caller's stream and three private sub-contexts, one HIP stream + scratch
-// each), and the 144-byte projective partials are folded on the caller's stream.  Same group element, same bytes.
+// LARGE MSMs as a chunk pipeline over ONE bucket grid.
+//
+// Beyond ~2^21 points the single-launch Pippenger degrades: the Montgomery point table (64 B x 2n) outgrows the
+// 256 MiB Infinity Cache, so every bucket-accumulate gather goes to HBM (k_accumulate +11 % per point at 2^24), the
+// level-1 partition scatters 8-byte entries into thousands of streams (k_sort_scatter: 3.5x write amplification), and
+// level-2 slices no longer fit LDS.  MSM is linear (the reference's own chunking, util/msm.rs:311-336), so n points are
+// cut into 2^20-point chunks that all use the window size of a 2^20-point MSM; every chunk runs the efficient small-n
+// stages (prepare, partition, sort, bucket accumulate, combine) on one of three worker lanes (private sub-contexts: one
+// HIP stream + scratch each) and ADDS its bucket sums into its worker's grid (windows x 2^(c-1) XYZZ points, 36 MiB).
+// Chunks on different lanes overlap -- the memory-bound partition of one under the VALU-bound accumulation of another --
+// and the latency-bound tail (bucket reduce, 2^(cw) shift chains, to_affine: 0.65 ms) is paid ONCE on the sum of the
+// three grids instead of once per chunk.  Same group element, same bytes as the single launch.
+// Measured (MI355X, one MSM at a time): 2^22 / 2^24 points, see DESIGN.md section 4.
 static int pippenger_maybe_split(snarkv_ctx* ctx, const void* d_s, const void* d_p, size_t n, int window_bits,
                                  void* d_out, bool partial_out) {
-  constexpr size_t kChunk = (size_t)1 << 20;
-  // OPT-IN (SNARKV_PIP_SPLIT=1).  Measured on MI355X: with HIP's default 4 hardware queues the lanes
-  // collide and the split form LOSES (2^24: 39.0 vs 36.5 ms); with GPU_MAX_HW_QUEUES=8 it wins 7 %
-  // at 2^24 (34.1 ms, 4.9e8 points/s) and is level at 2^22.  The single-launch form stays the default.
-  const char* env = getenv("SNARKV_PIP_SPLIT");
-  bool allow = env && env[0] == '1';
-  if (!allow || n < 4 * kChunk || window_bits != 0 || ctx->stage_timing)
+  size_t kChunk = (size_t)1 << 20;
+  if (const char* cl = getenv("SNARKV_SPLIT_LOG2")) kChunk = (size_t)1 << std::max(16, std::min(23, atoi(cl)));  // tuning knob
+  const char* e = getenv("SNARKV_PIP_SPLIT");  // 0 = never, 1 = default threshold (3 chunks), 2 = from 2 chunks on
+  const int mode = e ? atoi(e) : 1;
+  const size_t min_chunks = mode == 2 ? 2 : 3;
+  const size_t chunks = (n + kChunk - 1) / kChunk;
+  if (mode == 0 || chunks < min_chunks || window_bits != 0 || ctx->stage_timing || ctx->throughput_mode)
     return launch_msm_pippenger(ctx, d_s, d_p, n, window_bits, d_out, partial_out);
   SNARKV_TRY(ctx_lanes(ctx));
-  const size_t chunks = (n + kChunk - 1) / kChunk;
-  void* d_parts;
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_SPLIT_PARTIALS, chunks * (size_t)SNARKV_G1_PARTIAL_BYTES, &d_parts));
-  // inputs (and the partials buffer) may still be in flight on the caller's stream
+  uint32_t c = 0, windows = 0, bpw = 0;
+  SNARKV_TRY(pip_geometry(kChunk, 0, &c, &windows, &bpw));
+  const size_t nb = (size_t)windows * bpw, grid_bytes = nb * SNARKV_G1_PARTIAL_BYTES;
+  int kWorkers = 2;  // 2 vs 3 measured level (2^24: 24.7 vs 25.3 ms); two keep the footprint at ~2 GiB
+  if (const char* wl = getenv("SNARKV_SPLIT_WORKERS")) kWorkers = std::max(1, std::min(3, atoi(wl)));  // tuning knob
+  void *grid[3], *tmp[3];
+  bool started[3] = {false, false, false};
+  for (int w = 0; w < kWorkers; ++w) {
+    SNARKV_TRY(ctx_reserve(ctx->sub[w], SLOT_MGPU_GRID, grid_bytes, &grid[w]));
+    SNARKV_TRY(ctx_reserve(ctx->sub[w], SLOT_MGPU_RECV, grid_bytes, &tmp[w]));
+  }
+  // inputs may still be in flight on the caller's stream
   SNARKV_TRY(ctx_lanes_fork(ctx));
-  for (size_t c = 0; c < chunks; ++c) {
-    size_t lo = c * kChunk, len = std::min(kChunk, n - lo);
-    snarkv_ctx* lane = ctx_lane(ctx, c);
-    SNARKV_TRY(launch_msm_pippenger(lane, (const char*)d_s + 32 * lo, (const char*)d_p + 64 * lo, len, 0,
-                                    (char*)d_parts + c * (size_t)SNARKV_G1_PARTIAL_BYTES, true));
+  for (size_t k = 0; k < chunks; ++k) {
+    size_t lo = k * kChunk, len = std::min(kChunk, n - lo);
+    int w = (int)(k % kWorkers);
+    snarkv_ctx* lane = ctx->sub[w];
+    // the chunk's bucket sums (sanitised XYZZ, zero = identity): straight into the worker's grid the first time, added to it after
+    SNARKV_TRY(launch_msm_pippenger(lane, (const char*)d_s + 32 * lo, (const char*)d_p + 64 * lo, len, (int)c, nullptr, false,
+                                    started[w] ? tmp[w] : grid[w]));
+    if (started[w]) SNARKV_TRY(launch_buckets_add(lane, grid[w], tmp[w], nb));
+    started[w] = true;
   }
   SNARKV_TRY(ctx_lanes_join(ctx));
-  return launch_fold_partials(ctx, d_parts, chunks, d_out, partial_out);
+  for (int w = 1; w < kWorkers; ++w)
+    if (started[w]) SNARKV_TRY(launch_buckets_add(ctx, grid[0], grid[w], nb));
+  void* d_part;
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_SPLIT_PARTIALS, SNARKV_G1_PARTIAL_BYTES, &d_part));
+  if (partial_out) return launch_buckets_reduce(ctx, grid[0], c, 0, windows, d_out);
+  SNARKV_TRY(launch_buckets_reduce(ctx, grid[0], c, 0, windows, d_part));
+  return launch_fold_partials(ctx, d_part, 1, d_out, false);
 }
 
 extern "C" {

@@ -87,11 +87,10 @@ struct snarkv_ctx {
   snarkv_ctx* sub[4];
   hipEvent_t sub_ev[5];
   bool sub_ready;
-  // software pipeline across contexts: every k_accumulate of a device goes through ONE shared stream
-  // (msm_pippenger.hip, acc_lane); acc_ev = {inputs ready, kernel begins, kernel done}
-  hipEvent_t acc_ev[3];
-  bool acc_ev_ready;
-  bool acc_timed;  // the last Pippenger of this context ran its accumulation on the shared stream
+  // window-group pipeline of one Pippenger (msm_pippenger.hip): [j] group j accumulated, [8 + j] group j's tail done
+  hipEvent_t grp_ev[16];
+  bool grp_ev_ready;
+  bool throughput_mode;  // this context is one of several lanes in flight (set on sub-contexts; informational)
 };
 
 struct snarkv_dk {

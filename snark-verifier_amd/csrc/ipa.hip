@@ -135,6 +135,8 @@ int SNARKV_API(ipa_decide_batch)(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const
   }
   // an error between fork and join must not leave the sub-streams unjoined: remember it, join, then return it
   int rc = SNARKV_OK;
+  const bool was_throughput = ctx->throughput_mode;
+  if (lanes) ctx->throughput_mode = true;  // four accumulators in flight: the caller's lane runs like the others
   for (size_t a = 0; a < m && rc == SNARKV_OK; ++a) {
     snarkv_ctx* lane = lanes ? ctx_lane(ctx, a) : ctx;
     void* d_h;
@@ -149,6 +151,7 @@ int SNARKV_API(ipa_decide_batch)(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const
     }
     rc = launch_msm_pippenger(lane, d_h, dk->d_points, n, 0, (uint8_t*)d_out + 64 * a, false);
   }
+  ctx->throughput_mode = was_throughput;
   if (lanes) {
     int jrc = ctx_lanes_join(ctx);
     if (rc == SNARKV_OK) rc = jrc;

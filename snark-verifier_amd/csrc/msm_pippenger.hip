@@ -47,6 +47,7 @@
 // 254-bit modular multiplication on the integer VALU (v_mad_i64_i32).
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <mutex>
 #include "ctx.hpp"
 #include "g1_29.cuh"
@@ -85,9 +86,7 @@ namespace snarkv {
 #define SNARKV_BPRIO 3
 #endif
 #define SNARKV_RAISE_PRIO() __builtin_amdgcn_s_setprio(SNARKV_BPRIO)
-#ifndef SNARKV_ACC_STREAM_DEFAULT
-#define SNARKV_ACC_STREAM_DEFAULT 0  // see acc_lane()
-#endif
+
 constexpr int kHalves = SNARKV_GLV ? 2 : 1;       // virtual points per input point: P and phi(P), or P alone
 constexpr int kDigitWords = SNARKV_GLV ? 4 : 8;   // words of a digit source: a 127-bit GLV half / the 255-bit scalar
 constexpr int kDigitBits = 32 * kDigitWords;      // W * c covers this: magnitude bits + the recoding carry
@@ -113,6 +112,11 @@ struct PipParams {
   uint32_t tile;   // scalars per tile workgroup
   uint32_t mstride;  // row stride of the key x tile matrix (odd: no power-of-two channel aliasing)
   uint32_t w0;       // index of the first window held (bucket-sharded reduce of a window range; 0 otherwise)
+  // window groups (single-MSM latency pipeline, launch_msm_pippenger): the sorted stream is accumulated group by
+  // group, top windows first, and a group's combine / bucket reduce / shift chain runs on a side stream under the
+  // accumulation of the next groups.  Runs are cut relative to the START of their group's part of the stream.
+  uint32_t gsz;      // windows per group (W = one group: the whole stream, runs cut from offset 0)
+  uint32_t rpw;      // run slots reserved per window: ceil(max entries of a window / kRun) + 1
 };
 
 // c bits at offset lo of a kDigitBits-bit magnitude held in registers (selects, no dynamic indexing)
@@ -424,14 +428,17 @@ __global__ void __launch_bounds__(512)
 __global__ void __launch_bounds__(64, SNARKV_ACC_WAVES)
     k_accumulate(const uint2* __restrict__ entries, const uint32_t* __restrict__ total_ptr,
                  const G1Packed* __restrict__ pts, G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ seg_ids,
-                 G1Xyzz29* __restrict__ seg_parts) {
+                 G1Xyzz29* __restrict__ seg_parts, const uint32_t* __restrict__ M, uint32_t mstride, uint32_t key_lo,
+                 uint32_t key_hi, uint32_t nkeys, uint32_t run_base) {
+  // the part of the sorted stream that belongs to level-1 keys [key_lo, key_hi): a group of windows
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t stop = *total_ptr;
-  uint64_t begin64 = (uint64_t)t * kRun;
+  uint32_t gfirst = M[(size_t)key_lo * mstride];
+  uint32_t stop = key_hi < nkeys ? M[(size_t)key_hi * mstride] : *total_ptr;
+  uint64_t begin64 = (uint64_t)gfirst + (uint64_t)t * kRun;
   if (begin64 >= stop) return;
   uint32_t begin = (uint32_t)begin64;
   uint32_t end = (stop - begin > (uint32_t)kRun) ? begin + kRun : stop;
-  size_t slot = t;
+  size_t slot = (size_t)run_base + t;
   uint32_t cur = entries[begin].x;
   bool first = true, fresh = true;
   G1Xyzz29 acc = xyzz29_identity();
@@ -510,18 +517,31 @@ __device__ __noinline__ G1Xyzz29 bucket_from_entries_careful(const uint2* __rest
 // bucket: a fast addition that met an exceptional case left ZZ = 0 (mod p)
 // (sticky through every later addition; an exact-zero ZZ partial is the same
 // signal, a run never legitimately produces the identity).
+// the run slots [s0, s1] that hold partials of bucket b (its entries are entries[o, o + cnt)): runs are cut every kRun
+// entries counted from the start of the bucket's WINDOW GROUP in the sorted stream, slots are reserved per window
+__device__ __forceinline__ void run_span(const PipParams& p, const uint32_t* __restrict__ M, uint32_t b, uint32_t o,
+                                         uint32_t cnt, size_t& s0, size_t& s1) {
+  uint32_t w0 = ((b / p.B) / p.gsz) * p.gsz;  // first window of the group
+  uint32_t first = M[(size_t)(w0 * p.SB) * p.mstride];
+  size_t base = (size_t)w0 * p.rpw;
+  s0 = base + (o - first) / kRun;
+  s1 = base + (o + cnt - 1 - first) / kRun;
+}
+
 __global__ void __launch_bounds__(64)
     k_combine(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, PipParams p,
               const uint2* __restrict__ entries, const G1Packed* __restrict__ pts,
               const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
-              G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list) {
+              G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list,
+              const uint32_t* __restrict__ M, uint32_t b_lo, uint32_t b_hi) {
   SNARKV_RAISE_PRIO();
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= p.nb) return;
+  uint32_t b = b_lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= b_hi) return;
   uint32_t cnt = counts[b];
   if (cnt == 0) return;  // bucket array was zero-filled = identity
   uint32_t o = offsets[b];
-  size_t s0 = o / kRun, s1 = (o + cnt - 1) / kRun;
+  size_t s0, s1;
+  run_span(p, M, b, o, cnt, s0, s1);
   if (s1 - s0 >= kBigSpan) {  // skewed scalars: hand the bucket to k_combine_big
     uint32_t slot = atomicAdd(big_count, 1u);
     if (slot < kMaxBig) {
@@ -556,7 +576,7 @@ __global__ void __launch_bounds__(256)
                   const uint2* __restrict__ entries, const G1Packed* __restrict__ pts,
                   const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
                   G1Xyzz29* __restrict__ buckets, const uint32_t* __restrict__ big_count,
-                  const uint32_t* __restrict__ big_list) {
+                  const uint32_t* __restrict__ big_list, PipParams p, const uint32_t* __restrict__ M) {
   SNARKV_RAISE_PRIO();
   __shared__ G1Xyzz29 sh[256];
   __shared__ int any_bad;
@@ -564,7 +584,8 @@ __global__ void __launch_bounds__(256)
   if (blockIdx.x >= nbig) return;
   uint32_t b = big_list[blockIdx.x];
   uint32_t o = offsets[b], cnt = counts[b];
-  size_t s0 = o / kRun, s1 = (o + cnt - 1) / kRun;
+  size_t s0, s1;
+  run_span(p, M, b, o, cnt, s0, s1);
   if (threadIdx.x == 0) any_bad = 0;
   __syncthreads();
   G1Xyzz29 acc = xyzz29_identity();
@@ -826,47 +847,6 @@ __global__ void __launch_bounds__(64)
   }
 }
 
-// ---- the accumulate lane ----------------------------------------------------------------------------
-// With several MSMs in flight (one context + stream each) the kernels of different MSMs share the GPU as the
-// hardware queues happen to interleave them: rocprofv3 traces show all four queues inside their latency-/
-// memory-bound stages at once for a quarter of the wall time (no k_accumulate resident, the integer VALU idle)
-// and then three k_accumulate on top of each other.  Mode 1/2 turns that into a software pipeline: EVERY
-// k_accumulate of a device is enqueued on one shared stream (in launch order, back to back), the context's own
-// stream carries the stages before and after it and meets the shared stream through two events -- so the
-// VALU-bound kernel of MSM i overlaps the partition / bucket-reduce / shift chains of its neighbours by design.
-//   SNARKV_ACC_STREAM = 0  off (every kernel on the context's stream)
-//                       1  shared stream, default priority      2  shared stream, lowest priority
-static std::mutex g_acc_mu;
-static hipStream_t g_acc_stream[64];
-static int g_acc_mode = -1;
-static int acc_lane_mode() {
-  if (g_acc_mode < 0) {
-    const char* e = getenv("SNARKV_ACC_STREAM");
-    g_acc_mode = e ? atoi(e) : SNARKV_ACC_STREAM_DEFAULT;
-    if (g_acc_mode < 0 || g_acc_mode > 2) g_acc_mode = 0;
-  }
-  return g_acc_mode;
-}
-static int acc_lane(snarkv_ctx* ctx, hipStream_t* out) {
-  std::lock_guard<std::mutex> lock(g_acc_mu);
-  int mode = acc_lane_mode();
-  *out = nullptr;
-  if (mode == 0 || ctx->device >= 64) return SNARKV_OK;
-  if (!g_acc_stream[ctx->device]) {
-    int lo = 0, hi = 0;
-    SNARKV_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = numerically greatest = lowest priority
-    SNARKV_HIP(hipStreamCreateWithPriority(&g_acc_stream[ctx->device], hipStreamNonBlocking, mode == 2 ? lo : 0));
-  }
-  if (!ctx->acc_ev_ready) {
-    SNARKV_HIP(hipEventCreateWithFlags(&ctx->acc_ev[0], hipEventDisableTiming));
-    SNARKV_HIP(hipEventCreate(&ctx->acc_ev[1]));
-    SNARKV_HIP(hipEventCreate(&ctx->acc_ev[2]));
-    ctx->acc_ev_ready = true;
-  }
-  *out = g_acc_stream[ctx->device];
-  return SNARKV_OK;
-}
-
 int launch_fold_partials(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64, bool partial_out) {
   hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_partials, (uint32_t)count,
                      (uint32_t*)d_out64, partial_out ? 1 : 0);
@@ -919,7 +899,20 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
     set_last_error("pippenger: n=%zu out of range", n);
     return SNARKV_ERR_LENGTH;
   }
-  uint32_t max_runs = (uint32_t)((max_entries + kRun - 1) / kRun);
+  // window groups: OFF by default (one group = the whole stream).  Measured on MI355X at 2^20 points (VERDICT r1 item 7,
+  // profiles/r02_sweep_gsz.txt): 1 / 2 / 4 / 8 groups -> single-MSM latency 2.23 / 2.55 / 2.90 / 4.51 ms.  A group's
+  // k_accumulate holds a third (or less) of the wave slots for a full wave lifetime (64 entries ~ 0.33 ms), so the
+  // accumulation stretches by more than the tail it hides, and the LAST group's tail -- bucket reduce and the two
+  // 14-step folds, latency-bound whatever the window count -- stays on the critical path.  SNARKV_PIP_GSZ=<windows per
+  // group> switches it on for experiments; results are the same bytes.
+  p.gsz = (uint32_t)p.W;
+  if (const char* e = getenv("SNARKV_PIP_GSZ")) {
+    int v = atoi(e);
+    if (v >= 1) p.gsz = (uint32_t)std::min(v, p.W);
+  }
+  if (((uint32_t)p.W + p.gsz - 1) / p.gsz > 8) p.gsz = ((uint32_t)p.W + 7) / 8;  // at most 8 groups (events, counters)
+  p.rpw = (uint32_t)(((uint64_t)kHalves * n + kRun - 1) / kRun) + 1;
+  uint32_t max_runs = (uint32_t)p.W * p.rpw;
   uint32_t mcount = p.nkeys * p.mstride;
   uint32_t scan_blocks = (mcount + 1023) / 1024;
   uint32_t chunks_per_window = (p.B + kChunk - 1) / kChunk;
@@ -941,7 +934,7 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   SNARKV_TRY(ctx_reserve(ctx, SLOT_CHUNK_PARTIALS, 2 * (size_t)blocks_per_window * p.W * sizeof(G1Xyzz29), &d_wave));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SHIFTED, (size_t)p.W * sizeof(G1Xyzz29), &d_shift));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_MISC, 64, &d_misc));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_BIG_LIST, (size_t)kMaxBig * 4, &d_big));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_BIG_LIST, (size_t)kMaxBig * 4 * 8, &d_big));
   uint32_t* d_total = (uint32_t*)d_misc;
   if ((size_t)p.nkeys * 4 > 65536) {
     set_last_error("pippenger: key table too large (nkeys=%u)", p.nkeys);
@@ -977,50 +970,72 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
                      (const uint32_t*)d_total, p, (uint2*)d_entries, (uint32_t*)d_counts, (uint32_t*)d_offsets);
   STAGE_MARK();  // 3: partition + level-2 sort
   SNARKV_HIP(hipMemsetAsync(d_buckets, 0, (size_t)p.nb * sizeof(G1Xyzz29), st));
-  // (Tried: one shared low-priority HIP stream for every k_accumulate of a device, so that the small
-  // kernels of other in-flight MSMs never queue behind it -- no gain, 2.0-2.1 ms/MSM either way; the
-  // in-flight plateau is total VALU + HBM work)
-  hipStream_t acc_st = nullptr;
-  SNARKV_TRY(acc_lane(ctx, &acc_st));
-  ctx->acc_timed = acc_st != nullptr && tm;
-  if (acc_st) {  // inputs ready -> the shared accumulate stream -> done
-    SNARKV_HIP(hipEventRecord(ctx->acc_ev[0], st));
-    SNARKV_HIP(hipStreamWaitEvent(acc_st, ctx->acc_ev[0], 0));
-    if (tm) SNARKV_HIP(hipEventRecord(ctx->acc_ev[1], acc_st));
+  // (Tried, both measured on MI355X and dropped: one shared stream for every k_accumulate of a device -- a software
+  // pipeline across the in-flight MSMs -- and s_setprio on / off for the other kernels: the in-flight plateau moved by
+  // less than the run-to-run spread either way.  SQ counters show why: k_accumulate keeps every SIMD's VALU busy
+  // (3.7 cycles per instruction at 3 waves) at the ~1.8 GHz the power budget allows, and the other kernels add 25 %
+  // more VALU instructions: the plateau is total issued work, not scheduling.  DESIGN.md section 4.)
+  uint32_t* d_big_count = d_total + 4;  // one counter per window group
+  SNARKV_HIP(hipMemsetAsync(d_big_count, 0, 4 * 8, st));
+  // Window groups (opt-in, see p.gsz above), top first: group j = windows [j gsz, (j+1) gsz).  Its accumulation runs on the context's stream;
+  // its tail -- combine, bucket reduce, the 2^(c w) shift chain (the longest for the TOP windows: c w doublings, a
+  // dependency chain no lane count shortens) -- runs on a side stream under the accumulation of the groups below it.
+  // Only the bottom group's tail (the shortest chains) is left exposed.
+  const uint32_t ngroups = ((uint32_t)p.W + p.gsz - 1) / p.gsz;
+  if (ngroups > 1) {
+    SNARKV_TRY(ctx_lanes(ctx));
+    if (!ctx->grp_ev_ready) {
+      for (int i = 0; i < 16; ++i) SNARKV_HIP(hipEventCreateWithFlags(&ctx->grp_ev[i], hipEventDisableTiming));
+      ctx->grp_ev_ready = true;
+    }
   }
-  hipLaunchKernelGGL(k_accumulate, dim3((max_runs + 63) / 64), dim3(64), 0, acc_st ? acc_st : st, (const uint2*)d_entries,
-                     (const uint32_t*)d_total, (const G1Packed*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
-                     (G1Xyzz29*)d_seg_parts);
-  if (acc_st) {
-    SNARKV_HIP(hipEventRecord(ctx->acc_ev[2], acc_st));
-    SNARKV_HIP(hipStreamWaitEvent(st, ctx->acc_ev[2], 0));
+  for (int j = (int)ngroups - 1; j >= 0; --j) {
+    const uint32_t w0 = (uint32_t)j * p.gsz, w1 = std::min<uint32_t>((uint32_t)p.W, w0 + p.gsz), wcount = w1 - w0;
+    const uint32_t lanes = wcount * p.rpw;
+    hipLaunchKernelGGL(k_accumulate, dim3((lanes + 63) / 64), dim3(64), 0, st, (const uint2*)d_entries,
+                       (const uint32_t*)d_total, (const G1Packed*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
+                       (G1Xyzz29*)d_seg_parts, (const uint32_t*)d_M, p.mstride, w0 * p.SB, w1 * p.SB, p.nkeys, w0 * p.rpw);
+    hipStream_t ts = st;
+    if (j > 0) {
+      ts = ctx->sub[j & 1]->stream;
+      SNARKV_HIP(hipEventRecord(ctx->grp_ev[j], st));
+      SNARKV_HIP(hipStreamWaitEvent(ts, ctx->grp_ev[j], 0));
+    } else {
+      STAGE_MARK();  // 4: bucket accumulate (all groups)
+    }
+    hipLaunchKernelGGL(k_combine, dim3((wcount * p.B + 63) / 64), dim3(64), 0, ts, (const uint32_t*)d_counts,
+                       (const uint32_t*)d_offsets, p, (const uint2*)d_entries, (const G1Packed*)d_pts,
+                       (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets, d_big_count + j,
+                       (uint32_t*)d_big + (size_t)j * kMaxBig, (const uint32_t*)d_M, w0 * p.B, w1 * p.B);
+    // one workgroup per oversized bucket; idle workgroups exit at once
+    uint32_t big_grid = (uint32_t)(lanes / kBigSpan + 1);
+    if (big_grid > kMaxBig) big_grid = kMaxBig;
+    hipLaunchKernelGGL(k_combine_big, dim3(big_grid), dim3(256), 0, ts, (const uint32_t*)d_counts,
+                       (const uint32_t*)d_offsets, (const uint2*)d_entries, (const G1Packed*)d_pts,
+                       (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets,
+                       (const uint32_t*)(d_big_count + j), (const uint32_t*)d_big + (size_t)j * kMaxBig, p,
+                       (const uint32_t*)d_M);
+    if (j == 0) STAGE_MARK();  // 5: bucket combine (the bottom group's: the exposed one)
+    if (!d_buckets_out) {
+      PipParams pg = p;
+      pg.W = (int)wcount;
+      pg.w0 = p.w0 + w0;
+      G1Xyzz29* gw = (G1Xyzz29*)d_wave + 2 * (size_t)blocks_per_window * w0;
+      hipLaunchKernelGGL(k_bucket_reduce, dim3(blocks_per_window * wcount), dim3(64), 0, ts,
+                         (const G1Xyzz29*)d_buckets + (size_t)w0 * p.B, gw, pg, chunks_per_window, blocks_per_window);
+      if (j == 0) STAGE_MARK();  // 6: bucket reduce
+      hipLaunchKernelGGL(k_shift_windows, dim3(wcount), dim3(64), 0, ts, (const G1Xyzz29*)gw, (G1Xyzz29*)d_shift + w0, pg,
+                         blocks_per_window);
+    }
+    if (j > 0) SNARKV_HIP(hipEventRecord(ctx->grp_ev[8 + j], ts));
   }
-  STAGE_MARK();  // 4: bucket accumulate
-  uint32_t* d_big_count = d_total + 4;
-  SNARKV_HIP(hipMemsetAsync(d_big_count, 0, 4, st));
-  hipLaunchKernelGGL(k_combine, dim3((p.nb + 63) / 64), dim3(64), 0, st, (const uint32_t*)d_counts,
-                     (const uint32_t*)d_offsets, p, (const uint2*)d_entries, (const G1Packed*)d_pts,
-                     (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets, d_big_count,
-                     (uint32_t*)d_big);
-  // one workgroup per oversized bucket; idle workgroups exit at once
-  uint32_t big_grid = (uint32_t)(max_runs / kBigSpan + 1);
-  if (big_grid > kMaxBig) big_grid = kMaxBig;
-  hipLaunchKernelGGL(k_combine_big, dim3(big_grid), dim3(256), 0, st, (const uint32_t*)d_counts,
-                     (const uint32_t*)d_offsets, (const uint2*)d_entries, (const G1Packed*)d_pts,
-                     (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets,
-                     (const uint32_t*)d_big_count, (const uint32_t*)d_big);
-  STAGE_MARK();  // 5: bucket combine
+  for (uint32_t j = 1; j < ngroups; ++j) SNARKV_HIP(hipStreamWaitEvent(st, ctx->grp_ev[8 + j], 0));
   if (d_buckets_out) {  // bucket-sharded variant: hand the (sanitised) bucket sums out and stop here
     SNARKV_HIP(hipMemcpyAsync(d_buckets_out, d_buckets, (size_t)p.nb * sizeof(G1Xyzz29), hipMemcpyDeviceToDevice, st));
     SNARKV_HIP(hipGetLastError());
     return SNARKV_OK;
   }
-  hipLaunchKernelGGL(k_bucket_reduce, dim3(blocks_per_window * p.W), dim3(64), 0, st, (const G1Xyzz29*)d_buckets,
-                     (G1Xyzz29*)d_wave, p, chunks_per_window, blocks_per_window);
-  STAGE_MARK();  // 6: bucket reduce
-  hipLaunchKernelGGL(k_shift_windows, dim3(p.W), dim3(64), 0, st, (const G1Xyzz29*)d_wave, (G1Xyzz29*)d_shift, p,
-                     blocks_per_window);
-  STAGE_MARK();  // 7: window sums + 2^(cw) shift chains
+  STAGE_MARK();  // 7: window sums + 2^(cw) shift chains (all groups joined)
   hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, st, (const G1Xyzz29*)d_shift, (uint32_t)p.W, (uint32_t*)d_out,
                      partial_out ? 1 : 0);
   STAGE_MARK();  // 8: final sum + to_affine

@@ -219,9 +219,9 @@ def test_batched_chunked_scalar_mul_all_chunkings(gpu_ctx, golden_msm, chunks, m
 
 
 def test_large_msm_chunk_pipelined_form_matches_unsplit(gpu_ctx, monkeypatch):
-    """n >= 2^22 runs as pipelined 2^20-point chunks on sub-contexts (capi.hip
-    pippenger_maybe_split): same bytes as the single-launch form, for an exact
-    multiple and a ragged size, affine result and projective partial."""
+    """n > 2^21 runs as 2^20-point chunks on worker lanes that add their bucket sums into shared grids, with ONE
+    bucket reduce / shift / to_affine at the end (capi.hip pippenger_maybe_split): same bytes as the single-launch
+    form, for an exact multiple and a ragged size, affine result and projective partial."""
     import torch
 
     import snark_verifier_amd as sv
@@ -241,6 +241,16 @@ def test_large_msm_chunk_pipelined_form_matches_unsplit(gpu_ctx, monkeypatch):
             res[(split, m)] = bytes(out.cpu().numpy())
     for m in (1 << 22, n):
         assert res[("0", m)] == res[("1", m)] != bytes(64)
+    # two chunks (the second one ragged) through the shared bucket grid: opt-in below the default threshold of three
+    monkeypatch.setenv("SNARKV_PIP_SPLIT", "2")
+    m2 = (1 << 20) + 4099
+    gpu_ctx.msm_pippenger_dev(ds.data_ptr(), dp.data_ptr(), m2, out.data_ptr(), 0)
+    gpu_ctx.sync()
+    two = bytes(out.cpu().numpy())
+    monkeypatch.setenv("SNARKV_PIP_SPLIT", "0")
+    gpu_ctx.msm_pippenger_dev(ds.data_ptr(), dp.data_ptr(), m2, out.data_ptr(), 0)
+    gpu_ctx.sync()
+    assert two == bytes(out.cpu().numpy()) != bytes(64)
     # partial + fold (the multi-GPU building blocks) through the split path
     monkeypatch.setenv("SNARKV_PIP_SPLIT", "1")
     part = torch.zeros(sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")

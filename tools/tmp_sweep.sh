@@ -1,10 +1,16 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_msm.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -3
-for rep in 1 2 3; do
-  python bench.py --steps 24 --warmup 4 --no-cpu-baseline --no-secondary --inflight 4 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.read())
-sq=d['stages_ms_sequential']
-print('packed64 value=%.3e ms=%.3f lat=%.3f seq: acc=%.3f comb=%.3f red=%.3f prep=%.3f sort=%.3f shift=%.3f' % (d['value'], d['ms_per_step'], d['config']['single_msm_latency_ms'], sq['bucket_accumulate'], sq['bucket_combine'], sq['bucket_reduce'], sq['prepare_glv_montgomery_histogram'], sq['partition_sort'], sq['window_shift_chain']))"
-done
-python tools/pmc_traffic.py --tag r02 --out-dir gpurun_out | head -8
+cat > /tmp/b.py <<'PY'
+import os, sys, time
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+import torch, snark_verifier_amd as sv
+k=int(sys.argv[1]); n=1<<k
+ctx=sv.Context(0)
+ds=torch.empty(32*n,dtype=torch.uint8,device="cuda"); dp=torch.empty(64*n,dtype=torch.uint8,device="cuda"); out=torch.zeros(64,dtype=torch.uint8,device="cuda")
+torch.cuda.synchronize(); ctx.sample_scalars_dev(1,n,ds.data_ptr()); ctx.sample_points_dev(2,n,dp.data_ptr()); ctx.sync()
+def f():
+    ctx.msm_pippenger_dev(ds.data_ptr(),dp.data_ptr(),n,out.data_ptr(),0); ctx.sync()
+f(); f(); t=time.perf_counter()
+for _ in range(5): f()
+print("2^%d workers=%s chunk=2^%s: %.2f ms"%(k,os.environ.get("SNARKV_SPLIT_WORKERS","3"),os.environ.get("SNARKV_SPLIT_LOG2","20"),(time.perf_counter()-t)/5*1e3))
+PY
+for k in 22 24; do for w in 2 3; do for cl in 19 20 21; do SNARKV_PIP_SPLIT=2 SNARKV_SPLIT_WORKERS=$w SNARKV_SPLIT_LOG2=$cl python /tmp/b.py $k; done; done; done
