@@ -241,13 +241,10 @@ SNARKV_HD Fq29 fq29_sqr(const Fq29& a) {
 #endif
 }
 
-// Unique representative in [0, p), carry-normalised.  x must be within
-// (-8p, 8p); one Montgomery product by 2^261 (i.e. by `one`) squeezes the
-// value into (-p/8, 9p/8) without changing the residue, then at most one +p and
-// one -p.
-SNARKV_HD Fq29 fq29_canon_residue(const Fq29& x) {
-  Fq29 y = fq29_mul(fq29_norm(x), fq29_one());  // same residue: x * R * R^-1
-  // y limbs 0..7 in [0,2^29); y.v[8] small signed
+// Unique representative in [0, p), carry-normalised.
+// canonical limbs of a value y in (-p, 2p) whose limbs 0..7 are already in [0, 2^29) -- in particular any OUTPUT of
+// fq29_mul / fq29_mul2 / fq29_sqr (value in (-p/8, p + p/8)): one conditional +p, one conditional -p, no product
+SNARKV_HD Fq29 fq29_canon_of_product(const Fq29& y) {
   Fq29 t;
   int32_t neg = y.v[8] >> 31;  // all ones if negative
 #pragma unroll
@@ -268,6 +265,10 @@ SNARKV_HD Fq29 fq29_canon_residue(const Fq29& x) {
   for (int i = 0; i < 9; ++i) t.v[i] = (t.v[i] & keep) | (d.v[i] & ~keep);
   return t;
 }
+
+// canonical limbs of ANY lazy value (the contract's (-8p, 8p)): one Montgomery product by 2^261 (i.e. by `one`) squeezes
+// the value into (-p/8, 9p/8) without changing the residue (x * R * R^-1), then at most one +p and one -p
+SNARKV_HD Fq29 fq29_canon_residue(const Fq29& x) { return fq29_canon_of_product(fq29_mul(fq29_norm(x), fq29_one())); }
 
 SNARKV_HD bool fq29_is_zero_mod_p(const Fq29& x) { return fq29_limbs_all_zero(fq29_canon_residue(x)); }
 

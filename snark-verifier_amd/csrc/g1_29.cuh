@@ -321,8 +321,8 @@ SNARKV_HD G1Affine29 g1a29_from_canonical(const uint32_t w[16]) {
     return r;
   }
   // canonical residues so that the stored affine point has limbs in [0, 2^29)
-  r.x = fq29_canon_residue(fq29_from_canonical(w));
-  r.y = fq29_canon_residue(fq29_from_canonical(w + 8));
+  r.x = fq29_canon_of_product(fq29_from_canonical(w));  // fq29_from_canonical ends in a product (by R^2)
+  r.y = fq29_canon_of_product(fq29_from_canonical(w + 8));
   return r;
 }
 

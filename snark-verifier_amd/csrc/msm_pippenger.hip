@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(SNARKV_TILE_THREADS)
     Fq29 beta;
 #pragma unroll
     for (int j = 0; j < 9; ++j) beta.v[j] = bl[j];
-    a.x = fq29_canon_residue(fq29_mul(a.x, beta));  // phi(P) = (beta x, y)
+    a.x = fq29_canon_of_product(fq29_mul(a.x, beta));  // phi(P) = (beta x, y)
     pts[2 * (size_t)i + 1] = g1a29_pack(a);
     glv_decompose(k, o);
 #else
