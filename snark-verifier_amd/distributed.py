@@ -54,6 +54,22 @@ class ShardedMsm:
         return self.fold_fn(gathered, world)
 
 
+def gpu_msm_partial(ctx, part, d_scalars, d_points, count, window_bits=0):
+    """This rank's 144-byte projective partial of its shard (`count` points at the head of d_scalars / d_points) into
+    `part`.  An EMPTY shard contributes the identity: ceil chunking leaves trailing ranks empty when n is small against
+    the world size (n = 9, world = 8: ranks 5-7); the device call would return SNARKV_ERR_EMPTY on that rank only and
+    the peers would hang in the all-gather."""
+    import torch
+
+    if count == 0:
+        part.zero_()  # all-zero partial: ZZ = 0 is the identity
+        torch.cuda.current_stream().synchronize()
+        return part
+    ctx.msm_pippenger_partial_dev(d_scalars.data_ptr(), d_points.data_ptr(), count, part.data_ptr(), window_bits)
+    ctx.sync()  # the partial is in memory before the all-gather reads it
+    return part
+
+
 def gpu_sharded_msm(ctx, d_scalars, d_points, n_total, window_bits=0):
     """Product wiring: shard -> HIP Pippenger partial -> all_gather -> HIP fold.
     `d_scalars` / `d_points` hold THIS rank's shard only (weak scaling)."""
@@ -68,16 +84,7 @@ def gpu_sharded_msm(ctx, d_scalars, d_points, n_total, window_bits=0):
     # created without a stream owns a private one), and the collective is ordered
     # against torch's current stream only -- so order the three steps explicitly.
     def partial_fn(lo, hi):
-        if hi == lo:
-            # ceil chunking leaves trailing ranks empty when n is small against the world size (n = 9, world = 8:
-            # ranks 5-7).  The device call would return SNARKV_ERR_EMPTY on this rank only and the peers would
-            # hang in the all-gather: contribute the identity instead (all-zero partial: ZZ = 0).
-            part.zero_()
-            torch.cuda.current_stream().synchronize()
-            return part
-        ctx.msm_pippenger_partial_dev(d_scalars.data_ptr(), d_points.data_ptr(), hi - lo, part.data_ptr(), window_bits)
-        ctx.sync()  # the partial is in memory before the all-gather reads it
-        return part
+        return gpu_msm_partial(ctx, part, d_scalars, d_points, hi - lo, window_bits)
 
     def fold_fn(gathered, world):
         torch.cuda.current_stream().synchronize()  # the all-gather has landed before the fold reads it

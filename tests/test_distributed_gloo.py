@@ -120,7 +120,20 @@ def _agg_worker(rank, world, port, n_proofs, q):
         return O.g1_to_bytes(lhs) + O.g1_to_bytes(rhs), lhs == O.g1_mul(rhs, secret)
 
     acc, ok = ShardedAggregation(verify_fn, combine_fn).run(n_proofs)
-    q.put((rank, acc, ok, shard_range(n_proofs, rank, world)))
+    # a shard that REJECTS (an invalid proof: the normal failure) on ONE rank must come back as a reject on every
+    # rank, after the collective -- not as an exception that leaves the peers blocked in the all-gather
+    failing = n_proofs - 1  # the last proof: owned by the last non-empty rank
+
+    def verify_fail(lo, hi):
+        if lo <= failing < hi:
+            raise RuntimeError("succinct verification failed on this shard")
+        return verify_fn(lo, hi)
+
+    def verify_none(lo, hi):
+        return None if lo <= 0 < hi else verify_fn(lo, hi)
+
+    rejected = [ShardedAggregation(verify_fail, combine_fn).run(n_proofs), ShardedAggregation(verify_none, combine_fn).run(n_proofs)]
+    q.put((rank, acc, ok, shard_range(n_proofs, rank, world), rejected))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -142,6 +155,8 @@ def test_sharded_aggregation_two_ranks_agree(n_proofs):
         pr.join(timeout=60)
     assert res[0][1] == res[1][1] and res[0][2] is True and res[1][2] is True
     assert res[0][3][1] == res[1][3][0]  # contiguous shards
+    for r in res:  # the failing shard (raised / returned None) is a reject everywhere
+        assert r[4] == [(None, False), (None, False)]
     # single-process reference: same fold over all accumulators in proof order
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import random

@@ -236,3 +236,33 @@ def test_bucket_sharded_msm_world1_rccl_wiring():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_empty_shard_contributes_the_identity(gpu_ctx):
+    """n < world: a rank whose shard is empty must hand the all-gather the identity partial instead of
+    raising on its own while the peers block.  Emulated here: 5 points over 8 ranks -- ranks 5..7 are empty -- through
+    `distributed.gpu_msm_partial` (the per-rank step of `gpu_sharded_msm`) and the device fold."""
+    import torch
+
+    import coracle as C
+    import snark_verifier_amd as sv
+    from snark_verifier_amd.distributed import gpu_msm_partial, shard_range
+
+    n, world = 5, 8
+    s, p = C.sample_scalars(0x91, n), C.sample_points(0x92, n)
+    ds = torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda()
+    dp = torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda()
+    gathered = torch.zeros(world, sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+    empties = 0
+    for r in range(world):
+        lo, hi = shard_range(n, r, world)
+        empties += hi == lo
+        part = torch.full((sv.G1_PARTIAL_BYTES,), 0xAB, dtype=torch.uint8, device="cuda")  # stale bytes must not survive
+        gpu_msm_partial(gpu_ctx, part, ds[32 * lo:], dp[64 * lo:], hi - lo)
+        gathered[r] = part
+    assert empties == 3
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.fold_partials_dev(gathered.data_ptr(), world, out.data_ptr())
+    gpu_ctx.sync()
+    assert bytes(out.cpu().numpy()) == C.msm_pippenger(s, p, 1)
