@@ -458,7 +458,8 @@ def main():
         stages = {k: v / stage_cnt for k, v in stage_sum.items()}
         dom = max((k for k in stages if k != "total"), key=lambda k: stages[k])
         dom_ms = stages[dom]
-        achieved = BYTES_PER_POINT * n / (dom_ms * 1e-3) / 1e9
+        launch_n = sv.Context.launch_points(n)  # n, or the 2^20-point chunk large MSMs are pipelined in
+        achieved = BYTES_PER_POINT * launch_n / (dom_ms * 1e-3) / 1e9
         line = {
             "metric": "BN254 G1 MSM points/sec at 2^%d" % (args.total_log2n if strong else args.log2n),
             "value": world * n * args.steps / dt,
@@ -478,6 +479,7 @@ def main():
                             else "BN254 G1 Pippenger MSM, 2^%d random points/scalars per GPU, inputs resident in HBM, "
                                  "affine result (configs[1])" % args.log2n,
                 "points_per_gpu": n,
+                "points_per_kernel_launch": launch_n,
                 "window_bits": args.window_bits or "default",
                 "parallelism": "point-sharded x%d, all-gather of 144 B partials + local fold" % world,
                 "msms_in_flight": inflight,
@@ -497,9 +499,9 @@ def main():
                 # give 4.34e9).  Only valid for the default 2^20 workload; null otherwise.
                 "traffic": None,  # filled below from the PMC record of THESE kernels, or left null
 
-                "note": "algorithmic 96 B/point x 2^%d points / avg HIP-event duration of the dominant stage in the "
+                "note": "algorithmic 96 B/point x %d points per launch / avg HIP-event duration of the dominant stage in the "
                         "timed region (where %d MSMs overlap, so one launch shares the GPU); the path is "
-                        "integer-VALU-bound (~160 Fq products per point), see DESIGN.md" % (args.log2n, inflight),
+                        "integer-VALU-bound (~160 Fq products per point), see DESIGN.md" % (launch_n, inflight),
             },
             "stages_ms": stages,
         }
@@ -535,7 +537,7 @@ def main():
             # Integer-VALU roofline (the binding constraint): the same
             # mixed addition as k_accumulate in isolation, 4 waves/SIMD on every CU.
             W = -(-128 // 16) if not args.window_bits else -(-128 // args.window_bits)
-            adds = 2.0 * n * W  # one bucket addition per (half-scalar, window)
+            adds = 2.0 * launch_n * W  # one bucket addition per (half-scalar, window) of the points one launch covers
             peak_madd = ctx.ubench_valu(1, 300)
             peak_mul = ctx.ubench_valu(0, 2000)
             acc_ms = (seq_stages or stages).get("bucket_accumulate", 0.0)
@@ -552,7 +554,7 @@ def main():
             dseq = seq_stages.get(dom, 0.0)
             line["stages_ms_sequential"] = seq_stages
             if dseq > 0:
-                line["roofline"]["achieved_unshared"] = BYTES_PER_POINT * n / (dseq * 1e-3) / 1e9
+                line["roofline"]["achieved_unshared"] = BYTES_PER_POINT * launch_n / (dseq * 1e-3) / 1e9
                 line["roofline"]["frac_unshared"] = line["roofline"]["achieved_unshared"] / HBM_PEAK_GBPS
         if not args.no_cpu_baseline and world == 1:
             cb, cpu_out, (s, p) = cpu_baseline(ctx, d_scalars, d_points, min(args.cpu_sample_log2, args.log2n))

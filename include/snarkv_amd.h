@@ -264,6 +264,9 @@ int snarkv_g1_msm_pippenger_mgpu_dev(snarkv_mgpu* mg, const void* const* d_scala
 int snarkv_kzg_decide_batch_mgpu(snarkv_mgpu* mg, const uint8_t g1_64[64], const uint8_t g2_128[128],
                                  const uint8_t s_g2_128[128], const uint8_t* accs128, size_t m, uint8_t* ok);
 
+/* points ONE launch of the Pippenger kernels processes for an n-point MSM: n itself, or the 2^20-point chunk of the
+ * chunk pipeline large MSMs run as (csrc/capi.hip pippenger_maybe_split) -- what a per-launch roofline divides by */
+int snarkv_g1_msm_launch_points(size_t n, size_t* per_launch);
 int snarkv_set_stage_timing(snarkv_ctx* ctx, int enabled);
 int snarkv_get_stage_timing(snarkv_ctx* ctx, float ms[SNARKV_PIP_STAGES]);
 

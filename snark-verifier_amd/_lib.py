@@ -74,6 +74,7 @@ _SIGNATURES = {
     "snarkv_sample_scalars_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
     "snarkv_sample_points_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
     "snarkv_ubench_valu": (_int, [_vp, _int, _int, ctypes.POINTER(ctypes.c_double)]),
+    "snarkv_g1_msm_launch_points": (_int, [_sz, ctypes.POINTER(_sz)]),
     "snarkv_mgpu_create": (_int, [ctypes.POINTER(_int), _int, _pp]),
     "snarkv_mgpu_destroy": (None, [_vp]),
     "snarkv_mgpu_size": (_int, [_vp]),
@@ -414,6 +415,13 @@ class Context:
 
     def sample_points_dev(self, seed, n, d_out, first=0):
         _check(self._lib.snarkv_sample_points_dev(self._h, seed, first, n, d_out))
+
+    @staticmethod
+    def launch_points(n):
+        """points one launch of the Pippenger kernels processes for an n-point MSM (n, or the chunk of the chunk pipeline)"""
+        v = ctypes.c_size_t(0)
+        _check(load_library().snarkv_g1_msm_launch_points(n, ctypes.byref(v)))
+        return v.value
 
     @staticmethod
     def bucket_geometry(n_total, window_bits=0):

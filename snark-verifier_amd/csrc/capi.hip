@@ -53,9 +53,38 @@ int snarkv_set_stage_timing(snarkv_ctx* ctx, int enabled) {
   return SNARKV_OK;
 }
 
+int snarkv_g1_msm_launch_points(size_t n, size_t* per_launch) {
+  if (!per_launch) return SNARKV_ERR_ARG;
+  const char* e = getenv("SNARKV_PIP_SPLIT");
+  const int mode = e ? atoi(e) : 1;
+  const size_t chunk = (size_t)1 << 20, chunks = (n + chunk - 1) / chunk;
+  *per_launch = (mode == 0 || chunks < (mode == 2 ? 2u : 3u)) ? n : chunk;
+  return SNARKV_OK;
+}
+
 int snarkv_get_stage_timing(snarkv_ctx* ctx, float ms[SNARKV_PIP_STAGES]) {
   if (!ctx || !ctx->ev_ready) return SNARKV_ERR_ARG;
   SNARKV_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->last_split_workers > 0) {
+    // chunk pipeline: total = the whole MSM on this stream; stages 1..5 = ONE 2^20-point chunk (the last one of every
+    // worker lane, averaged): what a single launch of each kernel took; the shared tail is not broken down
+    SNARKV_HIP(hipEventElapsedTime(&ms[0], ctx->ev[0], ctx->ev[SNARKV_PIP_STAGES - 1]));
+    for (int i = 1; i < SNARKV_PIP_STAGES; ++i) ms[i] = 0.f;
+    int used = 0;
+    for (int w = 0; w < ctx->last_split_workers; ++w) {
+      snarkv_ctx* lane = ctx->sub[w];
+      if (!lane || !lane->ev_ready) continue;
+      SNARKV_HIP(hipStreamSynchronize(lane->stream));
+      for (int i = 1; i <= 5; ++i) {
+        float t = 0.f;
+        SNARKV_HIP(hipEventElapsedTime(&t, lane->ev[i - 1], lane->ev[i]));
+        ms[i] += t;
+      }
+      ++used;
+    }
+    for (int i = 1; i <= 5 && used; ++i) ms[i] /= (float)used;
+    return SNARKV_OK;
+  }
   SNARKV_HIP(hipEventElapsedTime(&ms[0], ctx->ev[0], ctx->ev[SNARKV_PIP_STAGES - 1]));
   for (int i = 1; i < SNARKV_PIP_STAGES; ++i) SNARKV_HIP(hipEventElapsedTime(&ms[i], ctx->ev[i - 1], ctx->ev[i]));
   return SNARKV_OK;
@@ -132,9 +161,16 @@ static int pippenger_maybe_split(snarkv_ctx* ctx, const void* d_s, const void* d
   const int mode = e ? atoi(e) : 1;
   const size_t min_chunks = mode == 2 ? 2 : 3;
   const size_t chunks = (n + kChunk - 1) / kChunk;
-  if (mode == 0 || chunks < min_chunks || window_bits != 0 || ctx->stage_timing || ctx->throughput_mode)
+  ctx->last_split_workers = 0;
+  if (mode == 0 || chunks < min_chunks || window_bits != 0 || ctx->throughput_mode)
     return launch_msm_pippenger(ctx, d_s, d_p, n, window_bits, d_out, partial_out);
   SNARKV_TRY(ctx_lanes(ctx));
+  const bool tm = ctx->stage_timing;  // per-stage events: on the worker lanes (their LAST chunk); total on this stream
+  if (tm && !ctx->ev_ready) {
+    for (int i = 0; i <= SNARKV_PIP_STAGES; ++i) SNARKV_HIP(hipEventCreate(&ctx->ev[i]));
+    ctx->ev_ready = true;
+  }
+  if (tm) SNARKV_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
   uint32_t c = 0, windows = 0, bpw = 0;
   SNARKV_TRY(pip_geometry(kChunk, 0, &c, &windows, &bpw));
   const size_t nb = (size_t)windows * bpw, grid_bytes = nb * SNARKV_G1_PARTIAL_BYTES;
@@ -152,6 +188,7 @@ static int pippenger_maybe_split(snarkv_ctx* ctx, const void* d_s, const void* d
     size_t lo = k * kChunk, len = std::min(kChunk, n - lo);
     int w = (int)(k % kWorkers);
     snarkv_ctx* lane = ctx->sub[w];
+    lane->stage_timing = tm;
     // the chunk's bucket sums (sanitised XYZZ, zero = identity): straight into the worker's grid the first time, added to it after
     SNARKV_TRY(launch_msm_pippenger(lane, (const char*)d_s + 32 * lo, (const char*)d_p + 64 * lo, len, (int)c, nullptr, false,
                                     started[w] ? tmp[w] : grid[w]));
@@ -163,9 +200,16 @@ static int pippenger_maybe_split(snarkv_ctx* ctx, const void* d_s, const void* d
     if (started[w]) SNARKV_TRY(launch_buckets_add(ctx, grid[0], grid[w], nb));
   void* d_part;
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SPLIT_PARTIALS, SNARKV_G1_PARTIAL_BYTES, &d_part));
-  if (partial_out) return launch_buckets_reduce(ctx, grid[0], c, 0, windows, d_out);
-  SNARKV_TRY(launch_buckets_reduce(ctx, grid[0], c, 0, windows, d_part));
-  return launch_fold_partials(ctx, d_part, 1, d_out, false);
+  ctx->last_split_workers = kWorkers;
+  int rc = SNARKV_OK;
+  if (partial_out) {
+    rc = launch_buckets_reduce(ctx, grid[0], c, 0, windows, d_out);
+  } else {
+    rc = launch_buckets_reduce(ctx, grid[0], c, 0, windows, d_part);
+    if (rc == SNARKV_OK) rc = launch_fold_partials(ctx, d_part, 1, d_out, false);
+  }
+  if (tm && rc == SNARKV_OK) SNARKV_HIP(hipEventRecord(ctx->ev[SNARKV_PIP_STAGES - 1], ctx->stream));
+  return rc;
 }
 
 extern "C" {

@@ -90,6 +90,7 @@ struct snarkv_ctx {
   // window-group pipeline of one Pippenger (msm_pippenger.hip): [j] group j accumulated, [8 + j] group j's tail done
   hipEvent_t grp_ev[16];
   bool grp_ev_ready;
+  int last_split_workers;  // > 0: the last Pippenger ran as a chunk pipeline on that many worker lanes (stage timing)
   bool throughput_mode;  // this context is one of several lanes in flight (set on sub-contexts; informational)
 };
 

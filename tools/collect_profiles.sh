@@ -1,0 +1,30 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): every record the round's profiles/ directory keeps, written under gpurun_out/<tag>_*
+# (gpurun merges only gpurun_out/ back; copy what you want judged into profiles/).
+#   tools/collect_profiles.sh r02
+set -u
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+python bench.py --log2n 22 --inflight 1 --steps 10 --warmup 2 --no-secondary --cpu-sample-log2 18 > $O/${TAG}_bench_2p22.json 2>/dev/null
+python bench.py --log2n 24 --inflight 1 --steps 6 --warmup 2 --no-secondary --cpu-sample-log2 18 > $O/${TAG}_bench_2p24.json 2>/dev/null
+python tools/pmc_traffic.py --tag $TAG --out-dir $O > /dev/null
+python tools/pmc_traffic.py --tag $TAG --out-dir $O --log2n 24 > /dev/null
+cd /tmp
+stats() {  # name, bench args...
+  name=$1; shift
+  rm -rf /tmp/prof_$name
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -- python $R/bench.py "$@" > /dev/null 2>&1
+  db=$(find /tmp/prof_$name -name "*.db" | head -1)
+  if [ -n "$db" ]; then python $R/tools/rocpd_top_kernels.py $db $O/${TAG}_rocprofv3_kernel_stats_$name.csv; else
+    f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_rocprofv3_kernel_stats_$name.csv; fi
+}
+stats 4inflight --steps 20 --warmup 3 --no-cpu-baseline --no-secondary
+stats sequential --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --inflight 1
+stats with_secondary --steps 4 --warmup 1 --no-cpu-baseline
+stats 2p24_single --log2n 24 --inflight 1 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary
+cd $R
+timeout 120 tools/ubench_issue > $O/${TAG}_ubench_issue.txt 2>&1
+ls -la $O | grep $TAG

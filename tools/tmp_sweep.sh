@@ -1,16 +1,9 @@
 cd $GRAFT_REPO_ROOT
-cat > /tmp/b.py <<'PY'
-import os, sys, time
-sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
-import torch, snark_verifier_amd as sv
-k=int(sys.argv[1]); n=1<<k
-ctx=sv.Context(0)
-ds=torch.empty(32*n,dtype=torch.uint8,device="cuda"); dp=torch.empty(64*n,dtype=torch.uint8,device="cuda"); out=torch.zeros(64,dtype=torch.uint8,device="cuda")
-torch.cuda.synchronize(); ctx.sample_scalars_dev(1,n,ds.data_ptr()); ctx.sample_points_dev(2,n,dp.data_ptr()); ctx.sync()
-def f():
-    ctx.msm_pippenger_dev(ds.data_ptr(),dp.data_ptr(),n,out.data_ptr(),0); ctx.sync()
-f(); f(); t=time.perf_counter()
-for _ in range(5): f()
-print("2^%d workers=%s chunk=2^%s: %.2f ms"%(k,os.environ.get("SNARKV_SPLIT_WORKERS","3"),os.environ.get("SNARKV_SPLIT_LOG2","20"),(time.perf_counter()-t)/5*1e3))
-PY
-for k in 22 24; do for w in 2 3; do for cl in 19 20 21; do SNARKV_PIP_SPLIT=2 SNARKV_SPLIT_WORKERS=$w SNARKV_SPLIT_LOG2=$cl python /tmp/b.py $k; done; done; done
+python -m pytest tests/test_gpu_msm.py -x -q -k "chunk or 2p24 or golden" 2>&1 | tail -2
+for L in 22 24; do
+  python bench.py --log2n $L --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --inflight 1 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); sq=d.get('stages_ms_sequential') or {}
+print('log2n=$L value=%.3e ms=%.3f lat=%.3f launch_n=%d' % (d['value'], d['ms_per_step'], d['config']['single_msm_latency_ms'], d['config']['points_per_kernel_launch']))
+print('   stages', {k: round(v,3) for k,v in d['stages_ms'].items()}); print('   roofline', d['roofline']['achieved'], d['roofline']['frac'], d['valu_roofline']['frac'])"
+done
