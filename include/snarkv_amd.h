@@ -264,6 +264,10 @@ int snarkv_g1_msm_pippenger_mgpu_dev(snarkv_mgpu* mg, const void* const* d_scala
 int snarkv_kzg_decide_batch_mgpu(snarkv_mgpu* mg, const uint8_t g1_64[64], const uint8_t g2_128[128],
                                  const uint8_t s_g2_128[128], const uint8_t* accs128, size_t m, uint8_t* ok);
 
+/* Hint: the caller keeps SEVERAL large MSMs in flight on several contexts (one context + stream each).  The Pippenger then cuts
+ * the sorted stream into longer runs per lane -- less total work per MSM (-3.5 % at 2^20 with 4 in flight) at the price of a
+ * longer single-MSM latency (+4 %), because one MSM alone no longer fills every wave slot.  Same bytes either way. */
+int snarkv_ctx_set_throughput_hint(snarkv_ctx* ctx, int enabled);
 /* points ONE launch of the Pippenger kernels processes for an n-point MSM: n itself, or the 2^20-point chunk of the
  * chunk pipeline large MSMs run as (csrc/capi.hip pippenger_maybe_split) -- what a per-launch roofline divides by */
 int snarkv_g1_msm_launch_points(size_t n, size_t* per_launch);

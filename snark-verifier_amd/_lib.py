@@ -74,6 +74,7 @@ _SIGNATURES = {
     "snarkv_sample_scalars_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
     "snarkv_sample_points_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
     "snarkv_ubench_valu": (_int, [_vp, _int, _int, ctypes.POINTER(ctypes.c_double)]),
+    "snarkv_ctx_set_throughput_hint": (_int, [_vp, _int]),
     "snarkv_g1_msm_launch_points": (_int, [_sz, ctypes.POINTER(_sz)]),
     "snarkv_mgpu_create": (_int, [ctypes.POINTER(_int), _int, _pp]),
     "snarkv_mgpu_destroy": (None, [_vp]),
@@ -340,6 +341,10 @@ class Context:
 
     def sync(self):
         _check(self._lib.snarkv_ctx_sync(self._h))
+
+    def set_throughput_hint(self, enabled=True):
+        """Several MSMs in flight on several contexts: longer runs per lane (less work per MSM, longer single-MSM latency)."""
+        _check(self._lib.snarkv_ctx_set_throughput_hint(self._h, 1 if enabled else 0))
 
     # ---- host-buffer entry points ------------------------------------
     def msm_naive(self, scalars, points, flags=0):

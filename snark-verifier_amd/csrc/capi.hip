@@ -53,6 +53,12 @@ int snarkv_set_stage_timing(snarkv_ctx* ctx, int enabled) {
   return SNARKV_OK;
 }
 
+int snarkv_ctx_set_throughput_hint(snarkv_ctx* ctx, int enabled) {
+  if (!ctx) return SNARKV_ERR_ARG;
+  ctx->throughput_mode = enabled != 0;
+  return SNARKV_OK;
+}
+
 int snarkv_g1_msm_launch_points(size_t n, size_t* per_launch) {
   if (!per_launch) return SNARKV_ERR_ARG;
   const char* e = getenv("SNARKV_PIP_SPLIT");
@@ -162,7 +168,7 @@ static int pippenger_maybe_split(snarkv_ctx* ctx, const void* d_s, const void* d
   const size_t min_chunks = mode == 2 ? 2 : 3;
   const size_t chunks = (n + kChunk - 1) / kChunk;
   ctx->last_split_workers = 0;
-  if (mode == 0 || chunks < min_chunks || window_bits != 0 || ctx->throughput_mode)
+  if (mode == 0 || chunks < min_chunks || window_bits != 0 || ctx->is_lane)
     return launch_msm_pippenger(ctx, d_s, d_p, n, window_bits, d_out, partial_out);
   SNARKV_TRY(ctx_lanes(ctx));
   const bool tm = ctx->stage_timing;  // per-stage events: on the worker lanes (their LAST chunk); total on this stream

@@ -91,7 +91,8 @@ struct snarkv_ctx {
   hipEvent_t grp_ev[16];
   bool grp_ev_ready;
   int last_split_workers;  // > 0: the last Pippenger ran as a chunk pipeline on that many worker lanes (stage timing)
-  bool throughput_mode;  // this context is one of several lanes in flight (set on sub-contexts; informational)
+  bool throughput_mode;  // several MSMs are kept in flight next to this context's (snarkv_ctx_set_throughput_hint; always on lanes)
+  bool is_lane;          // a private sub-context of another context (never starts lanes of its own)
 };
 
 struct snarkv_dk {

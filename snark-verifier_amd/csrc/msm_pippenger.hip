@@ -90,7 +90,15 @@ namespace snarkv {
 constexpr int kHalves = SNARKV_GLV ? 2 : 1;       // virtual points per input point: P and phi(P), or P alone
 constexpr int kDigitWords = SNARKV_GLV ? 4 : 8;   // words of a digit source: a 127-bit GLV half / the 255-bit scalar
 constexpr int kDigitBits = 32 * kDigitWords;      // W * c covers this: magnitude bits + the recoding carry
-constexpr int kRun = SNARKV_KRUN;      // P4: entries per lane
+constexpr int kRun = SNARKV_KRUN;      // P4: entries per lane (a context with the throughput hint uses kRunThroughput)
+#ifndef SNARKV_KRUN_THROUGHPUT
+#define SNARKV_KRUN_THROUGHPUT 96
+#endif
+// Longer runs = fewer head/tail partials for k_combine and fewer bucket-head entries that occupy an addition slot without
+// adding (interleaved A/B, profiles/r02_ab_krun*.txt: 64 -> 96 entries = -3.5 % per MSM with several MSMs in flight),
+// but 2^24 entries / 96 / 64 = 2 731 wavefronts no longer fill the 3 072 slots of the machine: one MSM alone runs
+// k_accumulate 1.11 -> 1.26 ms.  So the run length follows the context's hint (snarkv_ctx_set_throughput_hint).
+constexpr int kRunThroughput = SNARKV_KRUN_THROUGHPUT;
 constexpr int kChunk = SNARKV_KCHUNK;  // P6: buckets per lane
 constexpr uint32_t kSortCap = 7168;     // S4: items a workgroup sorts entirely in LDS (56 KiB of the 64 KiB dynamic limit)
 constexpr uint32_t kSortTarget = 3072;  // S1: average items per (window, high bits) key
@@ -116,7 +124,8 @@ struct PipParams {
   // group, top windows first, and a group's combine / bucket reduce / shift chain runs on a side stream under the
   // accumulation of the next groups.  Runs are cut relative to the START of their group's part of the stream.
   uint32_t gsz;      // windows per group (W = one group: the whole stream, runs cut from offset 0)
-  uint32_t rpw;      // run slots reserved per window: ceil(max entries of a window / kRun) + 1
+  uint32_t krun;     // entries per run (kRun, or kRunThroughput on a context with the throughput hint)
+  uint32_t rpw;      // run slots reserved per window: ceil(max entries of a window / krun) + 1
 };
 
 // c bits at offset lo of a kDigitBits-bit magnitude held in registers (selects, no dynamic indexing)
@@ -425,6 +434,7 @@ __global__ void __launch_bounds__(512)
 // and NO degeneracy test here: a flush is a plain store, so the lanes of a wave
 // (which change bucket at different iterations) never wait for each other's
 // checks.  P5 tests every bucket once and redoes the rare bad one carefully.
+template <int RUN>
 __global__ void __launch_bounds__(64, SNARKV_ACC_WAVES)
     k_accumulate(const uint2* __restrict__ entries, const uint32_t* __restrict__ total_ptr,
                  const G1Packed* __restrict__ pts, G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ seg_ids,
@@ -434,10 +444,10 @@ __global__ void __launch_bounds__(64, SNARKV_ACC_WAVES)
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t gfirst = M[(size_t)key_lo * mstride];
   uint32_t stop = key_hi < nkeys ? M[(size_t)key_hi * mstride] : *total_ptr;
-  uint64_t begin64 = (uint64_t)gfirst + (uint64_t)t * kRun;
+  uint64_t begin64 = (uint64_t)gfirst + (uint64_t)t * RUN;
   if (begin64 >= stop) return;
   uint32_t begin = (uint32_t)begin64;
-  uint32_t end = (stop - begin > (uint32_t)kRun) ? begin + kRun : stop;
+  uint32_t end = (stop - begin > (uint32_t)RUN) ? begin + RUN : stop;
   size_t slot = (size_t)run_base + t;
   uint32_t cur = entries[begin].x;
   bool first = true, fresh = true;
@@ -524,8 +534,8 @@ __device__ __forceinline__ void run_span(const PipParams& p, const uint32_t* __r
   uint32_t w0 = ((b / p.B) / p.gsz) * p.gsz;  // first window of the group
   uint32_t first = M[(size_t)(w0 * p.SB) * p.mstride];
   size_t base = (size_t)w0 * p.rpw;
-  s0 = base + (o - first) / kRun;
-  s1 = base + (o + cnt - 1 - first) / kRun;
+  s0 = base + (o - first) / p.krun;
+  s1 = base + (o + cnt - 1 - first) / p.krun;
 }
 
 __global__ void __launch_bounds__(64)
@@ -911,7 +921,8 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
     if (v >= 1) p.gsz = (uint32_t)std::min(v, p.W);
   }
   if (((uint32_t)p.W + p.gsz - 1) / p.gsz > 8) p.gsz = ((uint32_t)p.W + 7) / 8;  // at most 8 groups (events, counters)
-  p.rpw = (uint32_t)(((uint64_t)kHalves * n + kRun - 1) / kRun) + 1;
+  p.krun = ctx->throughput_mode ? (uint32_t)kRunThroughput : (uint32_t)kRun;
+  p.rpw = (uint32_t)(((uint64_t)kHalves * n + p.krun - 1) / p.krun) + 1;
   uint32_t max_runs = (uint32_t)p.W * p.rpw;
   uint32_t mcount = p.nkeys * p.mstride;
   uint32_t scan_blocks = (mcount + 1023) / 1024;
@@ -992,7 +1003,8 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   for (int j = (int)ngroups - 1; j >= 0; --j) {
     const uint32_t w0 = (uint32_t)j * p.gsz, w1 = std::min<uint32_t>((uint32_t)p.W, w0 + p.gsz), wcount = w1 - w0;
     const uint32_t lanes = wcount * p.rpw;
-    hipLaunchKernelGGL(k_accumulate, dim3((lanes + 63) / 64), dim3(64), 0, st, (const uint2*)d_entries,
+    auto acc_kernel = p.krun == (uint32_t)kRun ? k_accumulate<kRun> : k_accumulate<kRunThroughput>;
+    hipLaunchKernelGGL(acc_kernel, dim3((lanes + 63) / 64), dim3(64), 0, st, (const uint2*)d_entries,
                        (const uint32_t*)d_total, (const G1Packed*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
                        (G1Xyzz29*)d_seg_parts, (const uint32_t*)d_M, p.mstride, w0 * p.SB, w1 * p.SB, p.nkeys, w0 * p.rpw);
     hipStream_t ts = st;

@@ -344,3 +344,40 @@ def test_bucket_sharded_error_paths(gpu_ctx):
         gpu_ctx.buckets_reduce_dev(d.data_ptr(), 8, 15, 2, d.data_ptr())  # window range past the top window
     with pytest.raises(sv.SnarkvError):
         gpu_ctx.buckets_add_dev(d.data_ptr(), d.data_ptr(), 0)
+
+
+def test_throughput_hint_gives_the_same_bytes():
+    """`snarkv_ctx_set_throughput_hint` changes how the sorted stream is cut into per-lane runs (96 instead of 64 entries)
+    -- never the result: sizes around the run / tile boundaries, skewed scalars (one bucket spanning many runs), and the
+    2^20 workload against the C oracle."""
+    import os
+
+    import torch
+
+    import snark_verifier_amd as sv
+
+    ctx = sv.Context(0)
+    ctx.set_throughput_hint(True)
+    for n in (1, 95, 96, 97, 4097, 50_000):
+        s, p = C.sample_scalars(0x700 + n, n), C.sample_points(0x701 + n, n)
+        assert ctx.msm_pippenger(s, p) == C.msm_pippenger(s, p, 8), n
+    n = 5000
+    p = C.sample_points(77, n)
+    s = b"".join(O.fe_to_bytes(x) for x in [0x1234567] * n)
+    assert ctx.msm_pippenger(s, p) == C.msm_pippenger(s, p, 4)
+    n = 1 << 20
+    ds = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+    dp = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.sample_scalars_dev(0x5EED0001, n, ds.data_ptr())
+    ctx.sample_points_dev(0x5EED0002, n, dp.data_ptr())
+    ctx.msm_pippenger_dev(ds.data_ptr(), dp.data_ptr(), n, out.data_ptr())
+    ctx.sync()
+    hinted = bytes(out.cpu().numpy())
+    ctx.set_throughput_hint(False)
+    ctx.msm_pippenger_dev(ds.data_ptr(), dp.data_ptr(), n, out.data_ptr())
+    ctx.sync()
+    assert hinted == bytes(out.cpu().numpy())
+    assert hinted == C.msm_pippenger(bytes(ds.cpu().numpy()), bytes(dp.cpu().numpy()), os.cpu_count() or 1)
+    ctx.close()
