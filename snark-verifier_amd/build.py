@@ -20,7 +20,7 @@ FLAGS += os.environ.get("SNARKV_EXTRA_FLAGS", "").split()
 
 
 def _deps():
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".hpp", ".h", ".inc"))]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".inc"))]
     hdrs.append(os.path.join(HERE, "..", "include", "snarkv_amd.h"))
     hdrs.append(os.path.join(HERE, "..", "include", "snarkv_pallas.h"))
     return max(os.path.getmtime(h) for h in hdrs)

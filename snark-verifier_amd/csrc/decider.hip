@@ -7,7 +7,7 @@
 //   D0 k_g2_prepare : once per deciding key -- line tables of g2 and -s_g2
 //                     (the reference's `G2Prepared::from`, redone there on
 //                     every call, decider.rs:74)
-//   D1 k_decide     : ONE 128-lane WORKGROUP per accumulator (pairing_coop29.cuh):
+//   D1 k_decide     : ONE 128-lane WORKGROUP per accumulator (pairing_coop29.h):
 //                     2-pair Miller loop with shared squarings + exact final
 //                     exponentiation + `is_identity`; every Fq12 product is one
 //                     parallel round of 72 fused two-product Montgomery steps,
@@ -19,10 +19,10 @@
 // Batches of independent accumulators (decide_all) are the second parallel axis
 // (SURVEY.md 8e).
 #include "ctx.hpp"
-#include "g1.cuh"
-#include "pairing.cuh"
-#include "pairing_coop.cuh"
-#include "pairing_coop29.cuh"
+#include "g1.h"
+#include "pairing.h"
+#include "pairing_coop.h"
+#include "pairing_coop29.h"
 
 namespace snarkv {
 
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) k_g2_to29(const G2Prepared* __restrict__ 
 }
 
 // ------------------------------------------------------------------ D1
-constexpr int kDecideThreads = 128;  // 96 lanes carry the round (pairing_coop29.cuh coop3), 2 wavefronts
+constexpr int kDecideThreads = 128;  // 96 lanes carry the round (pairing_coop29.h coop3), 2 wavefronts
 
 struct CoopReg {  // an Fq12 in the flat basis (c = 2i+e <-> u^e w^i)
   Fq29 v[12];
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(kDecideThreads * TEAMS)
   }
 
   DECIDE_STAMP(2);
-  // ---- final exponentiation, exact exponent (p^12-1)/r (see pairing.cuh)
+  // ---- final exponentiation, exact exponent (p^12-1)/r (see pairing.h)
   coop_inv(RINV, RF);
   DECIDE_STAMP(3);
   coop_conj(RT, RF);

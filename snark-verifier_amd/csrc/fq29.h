@@ -1,7 +1,7 @@
 // BN254 Fq for the MSM hot loops: 9 x 29-bit SIGNED limbs, lazy carries,
 // Montgomery with R = 2^261.
 //
-// Why not the 8 x 32 form of fq.cuh: measured on MI355X (tools/ubench_fq.hip,
+// Why not the 8 x 32 form of fq.h: measured on MI355X (tools/ubench_fq.hip,
 // profiles/r01_ubench.txt) `v_mad_u64_u32` issues at the SAME rate as any other
 // VOP3 instruction (~4.5 cycles per wave-instruction at >= 2 waves/SIMD), so a
 // saturated 32-bit limb pays as much for carry handling (a 64-bit add plus
@@ -19,7 +19,7 @@
 //     max|a_i| * max|b_j| < 2^59.6 (one operand carry-normalised (< 2^29), the
 //     other up to 2^30.6; or both < 2^29.8).  Its result has limbs 0..7 in
 //     [0, 2^29) and value in (-p/8, p + p/8) for operands within (-8p, 8p)... see
-//     the bound notes at each call site in g1_29.cuh.
+//     the bound notes at each call site in g1_29.h.
 //   * add/sub/neg are limb-wise and never carry; `fq29_norm` re-normalises the
 //     limbs (value unchanged) when the next product needs it.
 //   * zero/equality tests mod p need `fq29_is_zero_mod_p` (canonicalising).
@@ -27,7 +27,7 @@
 // (tests/hosttest).
 #pragma once
 #include <stdint.h>
-#include "fq.cuh"
+#include "fq.h"
 
 namespace snarkv {
 

@@ -1,9 +1,9 @@
 // BN254 SCALAR field Fr on the lazy 9x29-bit signed-limb form (Montgomery, R = 2^261):
 // the arithmetic of the Poseidon transcript kernel (poseidon.hip).  Same
-// algorithms as fq29.cuh (one 64-bit column accumulator, one mad per partial
+// algorithms as fq29.h (one 64-bit column accumulator, one mad per partial
 // product, limb-wise add/sub with lazy carries); only what Poseidon needs.
 #pragma once
-#include "fq29.cuh"
+#include "fq29.h"
 
 namespace snarkv {
 

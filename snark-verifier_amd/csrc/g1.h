@@ -10,7 +10,7 @@
 // (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2): mixed add 8M+2S, add 12M+2S, no
 // inversion; identity <=> ZZ == 0.
 #pragma once
-#include "fq.cuh"
+#include "fq.h"
 
 namespace snarkv {
 

@@ -1,4 +1,4 @@
-// G1 group law over the lazy 9x29-bit field (fq29.cuh) -- the MSM hot loops.
+// G1 group law over the lazy 9x29-bit field (fq29.h) -- the MSM hot loops.
 //
 // Two flavours of every adder:
 //   *_fast     branch-free formulas, NO exceptional-case tests.  If an addition
@@ -19,7 +19,7 @@
 // Every product below has one carry-normalised operand (< 2^29) and one with
 // |limb| < 2^30, inside the 2^59.6 budget of fq29_mul.
 #pragma once
-#include "fq29.cuh"
+#include "fq29.h"
 
 namespace snarkv {
 

@@ -6,7 +6,7 @@ Run:  python gen_consts.py > bn254_consts.h ; python gen_consts.py pallas > pall
 
 Two layers of names:
   SNARKV_FQ_* / SNARKV_FQ29_* / SNARKV_FR29_* / SNARKV_G1_B_MONT  -- what the field and group layers
-      (fq.cuh, fq29.cuh, fr29.cuh, g1.cuh) read: base field p, scalar field r, curve constant b of
+      (fq.h, fq29.h, fr29.h, g1.h) read: base field p, scalar field r, curve constant b of
       y^2 = x^3 + b.  Emitted for every curve.
   BN254_*  -- everything only BN254 has: the GLV lattice, the tower, the pairing (bn254_consts.h only).
 """
@@ -91,7 +91,7 @@ def _glv_lattice(n, lam):
 
 
 def glv_section(p, r, gen):
-    """GLV endomorphism phi(x, y) = (beta x, y) = lambda (x, y) of a j = 0 curve (glv.cuh): beta, the
+    """GLV endomorphism phi(x, y) = (beta x, y) = lambda (x, y) of a j = 0 curve (glv.h): beta, the
     reduced lattice (a1, b1), (a2, b2) of {(a, b): a + b lambda = 0 mod r} with b1 < 0 < a1, a2, b2, and
     g_i = floor(2^288 |b_j| / r).  Uniform widths: lattice entries 4 words (<= 128 bits), g_i 6 words.
     The 288-bit shift keeps the rounding error of c_i = round(k b / r) below 2^-34, so the remainder is
@@ -190,7 +190,7 @@ print("#define BN254_P_PLUS_1_DIV_4_LIMBS { %s }" % limbs((P + 1) // 4))
 print("#define BN254_X_U64 0x%016xull" % X)
 print("#define BN254_ATE_LOOP_LO 0x%016xull  // (6x+2) low 64 bits" % ((6 * X + 2) & (2**64 - 1)))
 print("#define BN254_ATE_LOOP_HI 0x%xull  // (6x+2) >> 64" % ((6 * X + 2) >> 64))
-# radix-2^29 signed-limb form (fq29.cuh), Montgomery R = 2^261
+# radix-2^29 signed-limb form (fq29.h), Montgomery R = 2^261
 def limbs29(v):
     return ", ".join("0x%08x" % ((v >> (29 * i)) & ((1 << 29) - 1)) for i in range(9))
 
@@ -201,7 +201,7 @@ print("#define BN254_P29_NINV 0x%08x  // -p^-1 mod 2^29" % ((-pow(P, -1, 1 << 29
 print("#define BN254_ONE29_LIMBS { %s }  // 2^261 mod p" % limbs29(R29 % P))
 print("#define BN254_R2_29_LIMBS { %s }  // 2^522 mod p" % limbs29(R29 * R29 % P))
 print("#define BN254_THREE29_LIMBS { %s }  // 3 * 2^261 mod p" % limbs29(3 * R29 % P))
-# the scalar field in the same form (fr29.cuh: Poseidon transcripts on the device)
+# the scalar field in the same form (fr29.h: Poseidon transcripts on the device)
 print("#define BN254_FR29_LIMBS { %s }  // r" % limbs29(R))
 print("#define BN254_FR29_NINV 0x%08x  // -r^-1 mod 2^29" % ((-pow(R, -1, 1 << 29)) % (1 << 29)))
 print("#define BN254_FR29_ONE_LIMBS { %s }  // 2^261 mod r" % limbs29(R29 % R))

@@ -15,7 +15,7 @@
 // rounding only bounds the size: |k1| <= (1/2 + 2^-34)(a1 + a2), |k2| <= (1/2 + 2^-34)(|b1| + b2), both
 // < 2^127 for BN254 and pallas (asserted by gen_consts.py).
 #pragma once
-#include "fq.cuh"
+#include "fq.h"
 
 namespace snarkv {
 

@@ -8,7 +8,7 @@
 #include <string.h>
 #include <vector>
 #include "ctx.hpp"
-#include "fr29.cuh"
+#include "fr29.h"
 
 struct snarkv_ipa_dk {
   int device;

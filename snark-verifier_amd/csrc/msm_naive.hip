@@ -16,9 +16,9 @@
 // A single small MSM is latency-bound by construction (one dependency chain);
 // the segmented launch is what fills the machine.
 #include "ctx.hpp"
-#include "g1.cuh"
-#include "g1_29.cuh"
-#include "glv.cuh"
+#include "g1.h"
+#include "g1_29.h"
+#include "glv.h"
 
 namespace snarkv {
 
@@ -63,7 +63,7 @@ __device__ __forceinline__ G1Xyzz29 half_scalar_mul(const G1Affine29& q, const u
 }
 
 // K1: one lane per (term, GLV half).  k = k1 + k2*lambda with |k_i| < 2^127
-// (glv.cuh) turns `*base * scalar` (reference native.rs:67), a 254-step chain,
+// (glv.h) turns `*base * scalar` (reference native.rs:67), a 254-step chain,
 // into two independent 127-step chains on P and phi(P) = (beta x, y).
 __global__ void __launch_bounds__(64) k_term_scalar_mul(const uint32_t* __restrict__ scalars,
                                                          const uint32_t* __restrict__ points,

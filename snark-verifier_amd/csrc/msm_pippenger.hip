@@ -8,7 +8,7 @@
 // shape has no parallelism, so the device algorithm is different while
 // producing the same group element (canonical after `to_affine`):
 //
-//   P0 k_prepare        GLV split k = k1 + k2*lambda (|k_i| < 2^127, glv.cuh) and
+//   P0 k_prepare        GLV split k = k1 + k2*lambda (|k_i| < 2^127, glv.h) and
 //                        points P, phi(P) = (beta x, y): canonical LE -> 9x29-bit
 //                        Montgomery, once.  2n half-width terms: the same number
 //                        of bucket additions, half the windows.  Fused with S1:
@@ -39,7 +39,7 @@
 //   P9 k_final           sum of the shifted window sums + `to_affine`, or the
 //                        projective partial for the multi-GPU fold.
 //
-// Field arithmetic is the lazy 9x29-bit form (fq29.cuh, g1_29.cuh): branch-free
+// Field arithmetic is the lazy 9x29-bit form (fq29.h, g1_29.h): branch-free
 // "fast" adders, one degenerate-ZZ check per run and a careful redo only when an
 // exceptional case (P = +-Q, identity) was met.
 //
@@ -50,12 +50,12 @@
 #include <algorithm>
 #include <mutex>
 #include "ctx.hpp"
-#include "g1_29.cuh"
+#include "g1_29.h"
 #ifndef SNARKV_GLV
 #define SNARKV_GLV 1  // 0: curves without the BN-shaped GLV lattice (the pasta build): one virtual point per point
 #endif
 #if SNARKV_GLV
-#include "glv.cuh"
+#include "glv.h"
 #endif
 
 namespace snarkv {
@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(64)
 // exchanged by quad-broadcast DPP: the chain is one wavefront's critical path
 // (a lone wavefront issues one VALU instruction per ~4.6 cycles whatever its
 // ILP), so depth 3 instead of 7 products per doubling is what counts.  Same
-// dataflow and carry bounds as jac29_double (g1_29.cuh).
+// dataflow and carry bounds as jac29_double (g1_29.h).
 template <int CTRL>
 __device__ __forceinline__ Fq29 fq29_dpp(const Fq29& a) {
   Fq29 r;

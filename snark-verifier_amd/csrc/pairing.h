@@ -9,7 +9,7 @@
 // inversion-free) and kept in HBM; the Miller loop proper then contains no G2
 // arithmetic at all -- only Fq12 squarings and sparse line products.
 #pragma once
-#include "tower.cuh"
+#include "tower.h"
 
 namespace snarkv {
 

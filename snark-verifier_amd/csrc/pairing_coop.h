@@ -1,8 +1,8 @@
 // Flat basis of the workgroup-cooperative pairing: coefficient index
-// c = 2 i + e  <->  u^e w^i  (the rounds themselves: pairing_coop29.cuh, decider.hip).
+// c = 2 i + e  <->  u^e w^i  (the rounds themselves: pairing_coop29.h, decider.hip).
 // Host-compilable so tests/hosttest can emulate the lanes against the tower arithmetic.
 #pragma once
-#include "pairing.cuh"
+#include "pairing.h"
 
 namespace snarkv {
 

@@ -12,7 +12,7 @@
 // operands of a product stay inside the multiplier budget (|limb| < 2^29) and every
 // fused two-product value inside (-p/16, 17p/16).
 #pragma once
-#include "fq29.cuh"
+#include "fq29.h"
 
 namespace snarkv {
 

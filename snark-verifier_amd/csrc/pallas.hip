@@ -5,7 +5,7 @@
 // `util::msm::multi_scalar_multiplication` (msm.rs:308-343: `IpaProvingKey::commit`,
 // pcs/ipa.rs:220-229, and `IpaAs::decide`, pcs/ipa/decider.rs:47-55).
 //
-// Same sources as the BN254 library -- fq29.cuh / fr29.cuh / g1_29.cuh / glv.cuh / msm_pippenger.hip /
+// Same sources as the BN254 library -- fq29.h / fr29.h / g1_29.h / glv.h / msm_pippenger.hip /
 // msm_naive.hip / ipa.hip -- compiled with
 //   -DSNARKV_CURVE_PALLAS   pallas_consts.h: p, r, b = 5 (curve_consts.h)
 //   -Dsnarkv=snarkv_pallas  the C++ namespace, so both libraries can live in one process

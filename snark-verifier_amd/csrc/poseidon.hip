@@ -10,7 +10,7 @@
 //
 //   P0 k_poseidon_tables     : the optimised schedule's tables (exactly what the
 //                              reference's `poseidon::Spec` holds) -> Montgomery
-//                              form on the 9x29-bit scalar field (fr29.cuh)
+//                              form on the 9x29-bit scalar field (fr29.h)
 //   P1 k_poseidon_transcript : 8 lanes per transcript, lane j = state word j;
 //                              full round: x^5 + k in every lane, dense MDS row
 //                              per lane (words exchanged by 8-lane shuffles);
@@ -23,7 +23,7 @@
 #include <vector>
 
 #include "ctx.hpp"
-#include "fr29.cuh"
+#include "fr29.h"
 
 struct snarkv_poseidon {
   int device;

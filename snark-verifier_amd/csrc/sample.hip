@@ -5,8 +5,8 @@
 // snark-verifier/src/system/halo2/test.rs:191).  `oracle/c/bn254_oracle.c`
 // restates the same streams so tests can check device inputs byte for byte.
 #include "ctx.hpp"
-#include "g1.cuh"
-#include "g1_29.cuh"
+#include "g1.h"
+#include "g1_29.h"
 
 namespace snarkv {
 

@@ -5,7 +5,7 @@
 // `final_exponentiation` at `snark-verifier/src/pcs/kzg/decider.rs:74-78`).
 // Written from the field definitions; Karatsuba at every level.
 #pragma once
-#include "fq.cuh"
+#include "fq.h"
 
 #if defined(__HIPCC__)
 #define SNARKV_TW static __host__ __device__ __noinline__

@@ -43,7 +43,7 @@ def golden_decider():
 
 @pytest.fixture(scope="session")
 def hosttest_lib():
-    """Device math headers (csrc/*.cuh) compiled for the HOST: unit tests of
+    """Device math headers (csrc/*.h) compiled for the HOST: unit tests of
     the exact device functions without a GPU.  Test infrastructure only."""
     import ctypes
 
@@ -51,7 +51,7 @@ def hosttest_lib():
     so = os.path.join(d, "libhosttest.so")
     src = os.path.join(d, "hosttest.cpp")
     csrc = os.path.join(ROOT, "snark-verifier_amd", "csrc")
-    newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith((".cuh", ".h"))])
+    newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith((".h", ".inc"))])
     if not os.path.exists(so) or os.path.getmtime(so) < newest:
         subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src], check=True)
     return ctypes.CDLL(so)

@@ -1,14 +1,14 @@
-// TEST INFRASTRUCTURE: compiles the device math headers (csrc/*.cuh) for the
+// TEST INFRASTRUCTURE: compiles the device math headers (csrc/*.h) for the
 // HOST with g++ so tests/ can unit-test the exact device functions without a
 // GPU.  Never linked into the product library.
 #include <cstring>
-#include "../../snark-verifier_amd/csrc/g1.cuh"
-#include "../../snark-verifier_amd/csrc/pairing.cuh"
-#include "../../snark-verifier_amd/csrc/g1_29.cuh"
-#include "../../snark-verifier_amd/csrc/glv.cuh"
-#include "../../snark-verifier_amd/csrc/pairing_coop.cuh"
-#include "../../snark-verifier_amd/csrc/pairing_coop29.cuh"
-#include "../../snark-verifier_amd/csrc/fr29.cuh"
+#include "../../snark-verifier_amd/csrc/g1.h"
+#include "../../snark-verifier_amd/csrc/pairing.h"
+#include "../../snark-verifier_amd/csrc/g1_29.h"
+#include "../../snark-verifier_amd/csrc/glv.h"
+#include "../../snark-verifier_amd/csrc/pairing_coop.h"
+#include "../../snark-verifier_amd/csrc/pairing_coop29.h"
+#include "../../snark-verifier_amd/csrc/fr29.h"
 
 using namespace snarkv;
 
@@ -106,7 +106,7 @@ void ht_pairing_product(const uint8_t* p, const uint8_t* q, int npairs, uint8_t*
   delete[] prep;
 }
 
-// ---------------- 9x29-bit lazy field / group (fq29.cuh, g1_29.cuh) ----------
+// ---------------- 9x29-bit lazy field / group (fq29.h, g1_29.h) ----------
 static Fq29 load29(const uint8_t* b) {
   uint32_t w[8];
   memcpy(w, b, 32);
@@ -220,7 +220,7 @@ void ht29_double_n(const uint8_t* p, int n, uint8_t* out) {
   a = xyzz29_double(a);
   store_g1_29(xyzz29_to_affine(xyzz29_double_n(a, n)), out);
 }
-// the round k_decide runs (pairing_coop29.cuh "coop3"): 96 lanes emulated one by
+// the round k_decide runs (pairing_coop29.h "coop3"): 96 lanes emulated one by
 // one, butterflies replaced by explicit sums.  mode 0: f <- f*b each round;
 // mode 1: f <- f*f, then f <- f*b (the Miller-loop pattern, both operands lazy).
 static void coop3_round(const Fq29* fa, const Fq29* fb, Fq29* fc) {
@@ -278,7 +278,7 @@ void ht29_fq_mul2(const uint8_t* a, const uint8_t* b, const uint8_t* c, const ui
   if (neg_c) cc = fq29_neg(cc);
   store29(fq29_mul2(load29(a), load29(b), cc, load29(d)), out);
 }
-// scalar field on the 29-bit form (fr29.cuh): ((a * b) + c)^5, canonical in / out
+// scalar field on the 29-bit form (fr29.h): ((a * b) + c)^5, canonical in / out
 void ht_fr29_expr(const uint8_t* a, const uint8_t* b, const uint8_t* c, uint8_t* out) {
   uint32_t w[8];
   memcpy(w, a, 32);
@@ -300,7 +300,7 @@ void ht_fr29_roundtrip(const uint8_t* a, uint8_t* out) {
 }
 }
 
-// packed 64-byte memory form of the Pippenger's Montgomery points (g1_29.cuh G1Packed): canonical x | y -> Montgomery
+// packed 64-byte memory form of the Pippenger's Montgomery points (g1_29.h G1Packed): canonical x | y -> Montgomery
 // canonical residues -> pack -> unpack -> back to canonical; also reports the packed words and whether every unpacked
 // limb is in [0, 2^29)
 extern "C" int ht_g1_pack_roundtrip(const uint8_t* p64, uint8_t* out64, uint8_t* packed64) {

@@ -1,9 +1,9 @@
-// Host build of the CURVE-GENERIC device headers (fq29.cuh, fr29.cuh, g1_29.cuh, glv.cuh), compiled twice
+// Host build of the CURVE-GENERIC device headers (fq29.h, fr29.h, g1_29.h, glv.h), compiled twice
 // by tests/conftest.py: default (BN254) and -DSNARKV_CURVE_PALLAS.  Test infrastructure only.
 #include <string.h>
-#include "../../snark-verifier_amd/csrc/fr29.cuh"
-#include "../../snark-verifier_amd/csrc/g1_29.cuh"
-#include "../../snark-verifier_amd/csrc/glv.cuh"
+#include "../../snark-verifier_amd/csrc/fr29.h"
+#include "../../snark-verifier_amd/csrc/g1_29.h"
+#include "../../snark-verifier_amd/csrc/glv.h"
 
 using namespace snarkv;
 

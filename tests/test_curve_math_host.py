@@ -1,4 +1,4 @@
-"""CPU: the curve-generic device headers (fq29.cuh, fr29.cuh, g1_29.cuh, glv.cuh) compiled for the HOST
+"""CPU: the curve-generic device headers (fq29.h, fr29.h, g1_29.h, glv.h) compiled for the HOST
 with the BN254 and with the pallas constants (csrc/curve_consts.h) against the big-integer oracles: lazy
 9x29-bit field products at the edges of the range, the XYZZ adders, the Jacobian doubling chain, and the
 GLV split k = k1 + k2 lambda with |k_i| < 2^127 -- the packing the Pippenger relies on."""
@@ -23,7 +23,7 @@ def _lib(curve):
     src = os.path.join(d, "hosttest_curve.cpp")
     csrc = os.path.join(ROOT, "snark-verifier_amd", "csrc")
     newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc)
-                                            if f.endswith((".cuh", ".h"))])
+                                            if f.endswith((".h", ".h"))])
     if not os.path.exists(so) or os.path.getmtime(so) < newest:
         flags = ["-DSNARKV_CURVE_PALLAS"] if curve == "pallas" else []
         subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC"] + flags + ["-o", so, src], check=True)

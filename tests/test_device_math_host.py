@@ -1,4 +1,4 @@
-"""CPU: the DEVICE math headers (csrc/fq.cuh, g1.cuh, tower.cuh, pairing.cuh)
+"""CPU: the DEVICE math headers (csrc/fq.h, g1.h, tower.h, pairing.h)
 compiled for the host and checked against the big-integer oracle -- catches
 formula bugs before any GPU minute is spent."""
 import ctypes
@@ -95,7 +95,7 @@ def test_pairing_matches_oracle_value(hosttest_lib, golden_decider):
 
 
 # ---------------------------------------------------------------------------
-# 9x29-bit lazy field + group law (csrc/fq29.cuh, g1_29.cuh): the MSM hot path
+# 9x29-bit lazy field + group law (csrc/fq29.h, g1_29.h): the MSM hot path
 # ---------------------------------------------------------------------------
 def _rand_point(rng):
     while True:
@@ -245,7 +245,7 @@ def test_fq29_fused_two_product(hosttest_lib):
 
 
 def test_cooperative_fq12_coop3_rounds(hosttest_lib):
-    """The round the shipped k_decide runs (pairing_coop29.cuh coop3: 72 fused
+    """The round the shipped k_decide runs (pairing_coop29.h coop3: 72 fused
     two-product lanes, low/high sums, xi fix-up in the finalize step), emulated
     lane by lane: exact over long chains of products and squarings, including
     all-(p-1) coefficients (worst-case magnitudes)."""
@@ -285,7 +285,7 @@ def test_cooperative_fq12_coop3_rounds(hosttest_lib):
 
 
 def test_fr29_scalar_field(hosttest_lib):
-    """fr29.cuh (the Poseidon kernel's field): Montgomery product, lazy add, x^5, codecs, vs Python mod r."""
+    """fr29.h (the Poseidon kernel's field): Montgomery product, lazy add, x^5, codecs, vs Python mod r."""
     rng = random.Random(31)
     o = _buf(32)
     fb = lambda x: (x % O.R).to_bytes(32, "little")
@@ -299,7 +299,7 @@ def test_fr29_scalar_field(hosttest_lib):
 
 
 def test_packed_point_memory_form_roundtrip(hosttest_lib):
-    """G1Packed (g1_29.cuh): the 64-byte memory form of the Montgomery points k_accumulate gathers -- each coordinate's
+    """G1Packed (g1_29.h): the 64-byte memory form of the Montgomery points k_accumulate gathers -- each coordinate's
     canonical Montgomery residue x * 2^261 mod p as a 256-bit LE integer -- unpacks to exactly the 9 x 29-bit limbs it
     was packed from, for random points, the identity and coordinates near 0 and p."""
     import random

@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
-#include "../snark-verifier_amd/csrc/g1.cuh"
+#include "../snark-verifier_amd/csrc/g1.h"
 
 using namespace snarkv;
 

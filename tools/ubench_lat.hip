@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
-#include "../snark-verifier_amd/csrc/fq29.cuh"
+#include "../snark-verifier_amd/csrc/fq29.h"
 
 using namespace snarkv;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
