@@ -159,8 +159,16 @@ int snarkv_g1_msm_batched_dev(snarkv_ctx* ctx, const void* d_scalars32, const vo
 // and the latency-bound tail (bucket reduce, 2^(cw) shift chains, to_affine: 0.65 ms) is paid ONCE on the sum of the
 // three grids instead of once per chunk.  Same group element, same bytes as the single launch.
 // Measured (MI355X, one MSM at a time): 2^22 / 2^24 points, see DESIGN.md section 4.
+namespace snarkv {
+int launch_msm_pippenger_auto(snarkv_ctx* ctx, const void* d_s, const void* d_p, size_t n, int window_bits, void* d_out,
+                              bool partial_out);
+}
 static int pippenger_maybe_split(snarkv_ctx* ctx, const void* d_s, const void* d_p, size_t n, int window_bits,
                                  void* d_out, bool partial_out) {
+  return launch_msm_pippenger_auto(ctx, d_s, d_p, n, window_bits, d_out, partial_out);
+}
+int snarkv::launch_msm_pippenger_auto(snarkv_ctx* ctx, const void* d_s, const void* d_p, size_t n, int window_bits,
+                                      void* d_out, bool partial_out) {
   size_t kChunk = (size_t)1 << 20;
   if (const char* cl = getenv("SNARKV_SPLIT_LOG2")) kChunk = (size_t)1 << std::max(16, std::min(23, atoi(cl)));  // tuning knob
   const char* e = getenv("SNARKV_PIP_SPLIT");  // 0 = never, 1 = default threshold (3 chunks), 2 = from 2 chunks on

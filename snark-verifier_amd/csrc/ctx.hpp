@@ -116,6 +116,9 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
                        size_t n_msm, size_t n_terms, void* d_out);
 int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
                          void* d_out, bool partial_out, void* d_buckets_out = nullptr);
+// the product path of a large MSM: single launch, or the chunk pipeline over shared bucket grids (capi.hip)
+int launch_msm_pippenger_auto(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
+                              void* d_out, bool partial_out);
 int pip_geometry(size_t n_total, int window_bits, uint32_t* c, uint32_t* windows, uint32_t* buckets_per_window);
 int launch_buckets_add(snarkv_ctx* ctx, void* d_dst, const void* d_src, size_t count);
 int launch_buckets_reduce(snarkv_ctx* ctx, const void* d_buckets, uint32_t c, uint32_t w0, uint32_t wcount, void* d_partial);

@@ -85,7 +85,7 @@ static int msm_point_sharded(snarkv_mgpu* mg, const void* const* d_s, const void
       SNARKV_HIP(hipMemsetAsync(mg->d_part[g], 0, SNARKV_G1_PARTIAL_BYTES, c->stream));
       continue;
     }
-    SNARKV_TRY(launch_msm_pippenger(c, d_s[g], d_p[g], counts[g], window_bits, mg->d_part[g], true));
+    SNARKV_TRY(launch_msm_pippenger_auto(c, d_s[g], d_p[g], counts[g], window_bits, mg->d_part[g], true));
   }
   return gather_fold(mg, out64);
 }

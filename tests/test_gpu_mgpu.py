@@ -116,3 +116,29 @@ def test_mgpu_decide_all_1024_sharded(world):
         assert oks == [i not in bad for i in range(m)]
     assert mg.decide_batch(dk[:64], dk[64:192], dk[192:320], b"") == (True, [])
     mg.close()
+
+
+def test_mgpu_large_shards_take_the_chunk_pipeline(gpu_ctx, monkeypatch):
+    """Shards of more than 3 x 2^20 points run as the chunk pipeline over shared bucket grids INSIDE each rank
+    (capi.hip launch_msm_pippenger_auto): two ranks x (3 x 2^20 + 5) points == one single-launch MSM over all of them."""
+    import torch
+
+    import snark_verifier_amd as sv
+
+    per = 3 * (1 << 20) + 5
+    n = 2 * per
+    ds = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+    dp = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.sample_scalars_dev(0x6A, n, ds.data_ptr())
+    gpu_ctx.sample_points_dev(0x6B, n, dp.data_ptr())
+    monkeypatch.setenv("SNARKV_PIP_SPLIT", "0")
+    gpu_ctx.msm_pippenger_dev(ds.data_ptr(), dp.data_ptr(), n, out.data_ptr())
+    gpu_ctx.sync()
+    single = bytes(out.cpu().numpy())
+    monkeypatch.setenv("SNARKV_PIP_SPLIT", "1")
+    mg = sv.MultiGpu([0, 0])
+    got = mg.msm_pippenger_dev([ds.data_ptr(), ds.data_ptr() + 32 * per], [dp.data_ptr(), dp.data_ptr() + 64 * per], [per, per])
+    assert got == single != bytes(64)
+    mg.close()
