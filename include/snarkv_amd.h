@@ -247,7 +247,9 @@ int bn254_poseidon_transcript_batch(const snarkv_poseidon* ps, const uint8_t* el
  * shard), 1 = bucket-sharded (the "bucket-sum allreduce" of BASELINE config 4: all
  * ranks fill the GLOBAL bucket grid, exchange it by window range, reduce the windows
  * they own).  Same group element, same bytes, for any rank count and either variant.
- * (One process per GPU keeps using RCCL: snark-verifier_amd/distributed.py.)      */
+ * (One process per GPU keeps using RCCL: snark-verifier_amd/distributed.py.)
+ * Threading: one call at a time per handle (its ranks' streams are driven by the
+ * calling thread); different handles are independent.                            */
 typedef struct snarkv_mgpu snarkv_mgpu;
 int snarkv_mgpu_create(const int* devices, int n, snarkv_mgpu** out);
 void snarkv_mgpu_destroy(snarkv_mgpu* mg);

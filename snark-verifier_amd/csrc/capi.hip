@@ -209,6 +209,7 @@ int snarkv::launch_msm_pippenger_auto(snarkv_ctx* ctx, const void* d_s, const vo
     if (started[w]) SNARKV_TRY(launch_buckets_add(lane, grid[w], tmp[w], nb));
     started[w] = true;
   }
+  for (int w = 0; w < kWorkers; ++w) ctx->sub[w]->stage_timing = false;
   SNARKV_TRY(ctx_lanes_join(ctx));
   for (int w = 1; w < kWorkers; ++w)
     if (started[w]) SNARKV_TRY(launch_buckets_add(ctx, grid[0], grid[w], nb));

@@ -287,7 +287,11 @@ inline void json_field_raw(const JValue& v, uint8_t out[32]) {
     return;
   }
   if (a.size() == 32) {  // [u8; 32]
-    for (int i = 0; i < 32; ++i) out[i] = (uint8_t)a[i].u64();
+    for (int i = 0; i < 32; ++i) {
+      uint64_t b = a[i].u64();
+      if (b > 255) throw Panic("json: byte out of range");
+      out[i] = (uint8_t)b;
+    }
     return;
   }
   throw Panic("json: field element must be a hex string, 4 limbs or 32 bytes");
@@ -446,7 +450,11 @@ inline SnarkData snark_from_json(const JValue& v) {
     for (auto& x : col.arr()) c.push_back(cx.fr(x));
     s.instances.push_back(c);
   }
-  for (auto& b : v.at("proof").arr()) s.proof.push_back((uint8_t)b.u64());
+  for (auto& b : v.at("proof").arr()) {
+    uint64_t x = b.u64();
+    if (x > 255) throw Panic("json: proof byte out of range");
+    s.proof.push_back((uint8_t)x);
+  }
   return s;
 }
 
