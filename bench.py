@@ -354,11 +354,18 @@ def main():
         for c in ctxs:  # several MSMs in flight: the library's throughput hint (longer runs per lane; same bytes)
             c.set_throughput_hint(True)
 
-    d_scalars = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
-    d_points = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
-    # disjoint index ranges of one global stream per rank: rank r owns [r*n, (r+1)*n)
-    ctx.sample_scalars_dev(0x5EED0001, n, d_scalars.data_ptr(), first=rank * n)
-    ctx.sample_points_dev(0x5EED0002, n, d_points.data_ptr(), first=rank * n)
+    # Every in-flight slot works on ITS OWN input arrays (disjoint index ranges of the two seeded streams): slot 0 of
+    # rank r owns [r*n, (r+1)*n) -- so an N-rank job is the MSM over [0, N*n) -- and the other slots ranges beyond N*n.
+    # (Round 1 pointed all slots at the same arrays; distinct inputs keep the headline free of any cache sharing.)
+    slot_first = [rank * n] + [(world + rank * (inflight - 1) + k) * n for k in range(inflight - 1)]
+    d_scalars_k = [torch.empty(32 * n, dtype=torch.uint8, device="cuda") for _ in range(inflight)]
+    d_points_k = [torch.empty(64 * n, dtype=torch.uint8, device="cuda") for _ in range(inflight)]
+    torch.cuda.synchronize()
+    for k in range(inflight):
+        ctx.sample_scalars_dev(0x5EED0001, n, d_scalars_k[k].data_ptr(), first=slot_first[k])
+        ctx.sample_points_dev(0x5EED0002, n, d_points_k[k].data_ptr(), first=slot_first[k])
+    ctx.sync()
+    d_scalars, d_points = d_scalars_k[0], d_points_k[0]
     partials = [torch.zeros(sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda") for _ in range(inflight)]
     gathereds = [torch.zeros(world * sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda") for _ in range(inflight)]
     out = torch.zeros(64, dtype=torch.uint8, device="cuda")
@@ -370,12 +377,12 @@ def main():
         k = step_no[0] % inflight
         step_no[0] += 1
         if not use_dist:
-            ctxs[k].msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, outs[k].data_ptr(), args.window_bits)
+            ctxs[k].msm_pippenger_dev(d_scalars_k[k].data_ptr(), d_points_k[k].data_ptr(), n, outs[k].data_ptr(), args.window_bits)
         else:
             # snark-verifier_amd/distributed.py: shard -> HIP partial -> RCCL all-gather (144 B/rank) -> HIP fold,
             # all three enqueued on slot k's stream (every rank issues the collectives in the same order)
             with torch.cuda.stream(streams[k]):
-                ctxs[k].msm_pippenger_partial_dev(d_scalars.data_ptr(), d_points.data_ptr(), n,
+                ctxs[k].msm_pippenger_partial_dev(d_scalars_k[k].data_ptr(), d_points_k[k].data_ptr(), n,
                                                   partials[k].data_ptr(), args.window_bits)
                 dist.all_gather_into_tensor(gathereds[k], partials[k])
                 ctxs[k].fold_partials_dev(gathereds[k].data_ptr(), world, outs[k].data_ptr())
@@ -424,8 +431,8 @@ def main():
         c.set_stage_timing(False)
     written = list(range(inflight))  # every slot ran at least once (initialisation pass)
     out = outs[written[0]]
-    for k in written[1:]:
-        assert bytes(outs[k].cpu().numpy()) == bytes(out.cpu().numpy())
+    slot_results = [bytes(o.cpu().numpy()) for o in outs]
+    assert all(r != bytes(64) for r in slot_results) and len(set(slot_results)) == inflight  # distinct inputs, distinct sums
 
     # single-MSM latency (strictly sequential), outside the timed region, for the record
     lat_ms, seq_stages = None, None
@@ -441,7 +448,7 @@ def main():
             ctx.msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, out.data_ptr(), args.window_bits)
             ctx.sync()
         lat_ms = (time.perf_counter() - t1) / 8 * 1e3
-        assert bytes(out.cpu().numpy()) == bytes(outs[written[-1]].cpu().numpy())
+        assert bytes(out.cpu().numpy()) == slot_results[0]  # the latency mode gives the same bytes as the hinted in-flight run
         # unshared per-stage durations, for the roofline of the dominant kernel
         ctx.set_stage_timing(True)
         seq_sum = {}
@@ -487,6 +494,7 @@ def main():
                 "window_bits": args.window_bits or "default",
                 "parallelism": "point-sharded x%d, all-gather of 144 B partials + local fold" % world,
                 "msms_in_flight": inflight,
+                "inputs": "every in-flight slot has its own scalar / point arrays (disjoint ranges of the seeded streams)",
                 "throughput_hint": inflight > 1,  # snarkv_ctx_set_throughput_hint on the in-flight contexts (runs of 96 entries per lane
                                                   # instead of 64); the single-MSM latency and the sequential stage times are taken without it
                 "single_msm_latency_ms": lat_ms,
