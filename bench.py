@@ -564,6 +564,15 @@ def main():
                     "note": "peak = xyzz29_madd_fast chains with no memory traffic, measured live "
                             "(snarkv_ubench_valu); achieved uses the unshared (sequential) launch duration",
                 }
+        if inflight > 1 and dom_ms > 0:
+            # launches of the dominant kernel overlap in the timed region (that overlap is what the in-flight mode is for), so a
+            # launch's duration stretches with the number of its kind resident at once: sum of launch durations / wall time
+            conc = dom_ms * args.steps / (dt * 1e3)
+            line["roofline"]["launches_resident_on_average"] = conc
+            line["roofline"]["frac_per_resident_launch"] = line["roofline"]["frac"] * max(conc, 1.0)
+            line["roofline"]["overlap_note"] = (
+                "`frac` is per launch as prescribed; with %d MSMs in flight %.2f launches of this kernel share the GPU on average, "
+                "so its duration (%.2f ms) is not the kernel's own speed -- `frac_unshared` (one MSM at a time) is" % (inflight, conc, dom_ms))
         if seq_stages:
             dseq = seq_stages.get(dom, 0.0)
             line["stages_ms_sequential"] = seq_stages

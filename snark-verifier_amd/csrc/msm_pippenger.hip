@@ -985,7 +985,10 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   // pipeline across the in-flight MSMs -- and s_setprio on / off for the other kernels: the in-flight plateau moved by
   // less than the run-to-run spread either way.  SQ counters show why: k_accumulate keeps every SIMD's VALU busy
   // (3.7 cycles per instruction at 3 waves) at the ~1.8 GHz the power budget allows, and the other kernels add 25 %
-  // more VALU instructions: the plateau is total issued work, not scheduling.  DESIGN.md section 4.)
+  // more VALU instructions: the plateau is total issued work, not scheduling.  DESIGN.md section 4.
+  // Re-measured with the throughput hint's 96-entry runs (profiles/r02_sweep_accstream2.txt): serialising the
+  // accumulations on one stream now LOSES 15-25 % (1.50 -> 1.75-1.89 ms per MSM): 2 731 wavefronts leave a ninth of the
+  // slots and the whole drain of every launch empty unless another MSM's accumulation overlaps it.)
   uint32_t* d_big_count = d_total + 4;  // one counter per window group
   SNARKV_HIP(hipMemsetAsync(d_big_count, 0, 4 * 8, st));
   // Window groups (opt-in, see p.gsz above), top first: group j = windows [j gsz, (j+1) gsz).  Its accumulation runs on the context's stream;

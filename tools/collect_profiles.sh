@@ -7,11 +7,14 @@ TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-python bench.py --log2n 22 --inflight 1 --steps 10 --warmup 2 --no-secondary --cpu-sample-log2 18 > $O/${TAG}_bench_2p22.json 2>/dev/null
-python bench.py --log2n 24 --inflight 1 --steps 6 --warmup 2 --no-secondary --cpu-sample-log2 18 > $O/${TAG}_bench_2p24.json 2>/dev/null
+# PMC records first (and into profiles/ of THIS tree) so that the bench lines below quote the traffic of these very kernels
 python tools/pmc_traffic.py --tag $TAG --out-dir $O > /dev/null
 python tools/pmc_traffic.py --tag $TAG --out-dir $O --log2n 24 > /dev/null
+cp $O/${TAG}_pmc_hbm_traffic*.json profiles/
+python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+python bench.py --steps 40 --warmup 4 --no-secondary --no-cpu-baseline > $O/${TAG}_bench_40steps.json 2>/dev/null
+python bench.py --log2n 22 --inflight 1 --steps 10 --warmup 2 --no-secondary --cpu-sample-log2 18 > $O/${TAG}_bench_2p22.json 2>/dev/null
+python bench.py --log2n 24 --inflight 1 --steps 6 --warmup 2 --no-secondary --cpu-sample-log2 18 > $O/${TAG}_bench_2p24.json 2>/dev/null
 cd /tmp
 stats() {  # name, bench args...
   name=$1; shift
