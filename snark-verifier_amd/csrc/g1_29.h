@@ -122,6 +122,33 @@ SNARKV_HD void xyzz29_finish(G1Xyzz29& acc, const Fq29& u1, const Fq29& s1, cons
 }
 
 // acc += P (affine, non-identity), acc non-identity.  madd-2008-s, 8M + 2S.
+// Interleaved product pairs: OFF.  Measured on MI355X (interleaved A/B medians, two sessions): the pairs take the issued
+// instructions of k_accumulate from 2 404 to 2 278 per entry (s_nop 203 -> 78) and one MSM alone gains 1.4 % on the kernel,
+// but with four MSMs in flight -- the headline mode -- the paired form is 1-5 % SLOWER: there the chip is at its power
+// budget, an s_nop costs no energy, and a denser instruction stream comes back as a lower clock.
+#ifndef SNARKV_MADD_PAIRS
+#define SNARKV_MADD_PAIRS 0
+#endif
+#if SNARKV_MADD_PAIRS
+// The ten products as four interleaved pairs and two singles (fq29.h: pairs) -- the dependency graph allows
+//   (U2, S2) -> (PP, RR) -> (PPP, Q) -> X3 -> (Y3 [two products, one reduction], ZZ3) -> ZZZ3
+// Same values in the same lazy bounds as the sequential form below.
+SNARKV_HD void xyzz29_madd_fast(G1Xyzz29& acc, const G1Affine29& p) {
+  Fq29 u2, s2, pp, rr, ppp, q, y3, zz3;
+  fq29_mul_mul(p.x, acc.zz, p.y, acc.zzz, u2, s2);
+  Fq29 pn = fq29_norm(fq29_sub(u2, acc.x));  // limbs (-2^29, 2^30) -> norm
+  Fq29 rn = fq29_norm(fq29_sub(s2, acc.y));
+  fq29_sqr_sqr(pn, rn, pp, rr);
+  fq29_mul_mul(pn, pp, acc.x, pp, ppp, q);
+  Fq29 x3 = fq29_norm(fq29_sub(fq29_sub(rr, ppp), fq29_dbl(q)));  // limbs before norm in (-3*2^29, 2^29)
+  Fq29 t = fq29_sub(q, x3);                                         // |limb| < 2^29
+  fq29_mul2_mul(rn, t, fq29_neg(acc.y), ppp, acc.zz, pp, y3, zz3);
+  acc.zzz = fq29_mul(acc.zzz, ppp);
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = zz3;
+}
+#else
 SNARKV_HD void xyzz29_madd_fast(G1Xyzz29& acc, const G1Affine29& p) {
   Fq29 u2 = fq29_mul(p.x, acc.zz);
   Fq29 s2 = fq29_mul(p.y, acc.zzz);
@@ -133,6 +160,7 @@ SNARKV_HD void xyzz29_madd_fast(G1Xyzz29& acc, const G1Affine29& p) {
   acc.zz = fq29_mul(acc.zz, pp);
   acc.zzz = fq29_mul(acc.zzz, ppp);
 }
+#endif
 
 // acc += b, both non-identity.  add-2008-s, 12M + 2S.
 SNARKV_HD void xyzz29_add_fast(G1Xyzz29& acc, const G1Xyzz29& b) {

@@ -65,7 +65,83 @@ def body(kind, zero_limbs=()):
     print("  return r;")
 
 
+class Prod:
+    """One Montgomery product of a PAIR: kind 'mul' / 'mul2' / 'sqr', operand names, a suffix for its locals."""
+
+    def __init__(self, kind, ops, sfx, out):
+        self.kind, self.ops, self.sfx, self.out = kind, ops, sfx, out
+
+    def decls(self):
+        s = self.sfx
+        print("  int32_t m%s[9];" % s)
+        if self.kind == "sqr":
+            print("  int32_t dbl%s[9];" % s)
+            print("#pragma unroll")
+            print("  for (int i = 0; i < 9; ++i) dbl%s[i] = %s.v[i] * 2;" % (s, self.ops[0]))
+        print("  int64_t acc%s = 0;" % s)
+
+    def prods(self, k, zero_limbs):
+        lo, hi = max(0, k - 8), min(k, 8)
+        o, s = self.ops, self.sfx
+        if self.kind == "sqr":
+            pr = [("dbl%s[%d]" % (s, i), "%s.v[%d]" % (o[0], k - i), False) for i in range(lo, hi + 1) if 2 * i < k]
+            if k % 2 == 0:
+                pr.append(("%s.v[%d]" % (o[0], k // 2), "%s.v[%d]" % (o[0], k // 2), False))
+        else:
+            pr = [("%s.v[%d]" % (o[0], i), "%s.v[%d]" % (o[1], k - i), False) for i in range(lo, hi + 1)]
+            if self.kind == "mul2":
+                pr += [("%s.v[%d]" % (o[2], i), "%s.v[%d]" % (o[3], k - i), False) for i in range(lo, hi + 1)]
+        pr += [("m%s[%d]" % (s, i), "fq29_p(%d)" % (k - i), True) for i in range(lo, hi + 1)
+               if i < k and 1 <= k - i <= 8 and (k - i) not in zero_limbs]
+        return pr
+
+
+def emit_chain_named(prods, acc):
+    return emit_chain(prods).replace('"+v"(acc)', '"+v"(%s)' % acc)
+
+
+def pair_body(pa, pb, zero_limbs=()):
+    """Two INDEPENDENT products column by column: A's chain, B's chain, A's tail, B's tail.  The compiler pads an asm
+    statement whose VGPR result is read by the very next instruction with `s_nop` (it must assume the asm wrote with
+    dst_sel); with a second, independent product in between that next instruction is never the dependent one."""
+    pa.decls()
+    pb.decls()
+    for k in range(17):
+        print("  {  // column %d" % k)
+        for pr in (pa, pb):
+            print(emit_chain_named(pr.prods(k, zero_limbs), "acc" + pr.sfx))
+        if k < 9:
+            for pr in (pa, pb):
+                print("    m%s[%d] = (int32_t)(((uint32_t)acc%s * (uint32_t)SNARKV_FQ29_NINV) & (uint32_t)kMask29);" % (pr.sfx, k, pr.sfx))
+            for pr in (pa, pb):
+                print(emit_chain_named([("m%s[%d]" % (pr.sfx, k), "fq29_p(0)", True)], "acc" + pr.sfx))
+        else:
+            for pr in (pa, pb):
+                print("    %s.v[%d] = (int32_t)acc%s & kMask29;" % (pr.out, k - 9, pr.sfx))
+        for pr in (pa, pb):
+            print("    acc%s >>= 29;" % pr.sfx)
+        print("  }")
+    for pr in (pa, pb):
+        print("  %s.v[8] = (int32_t)acc%s;" % (pr.out, pr.sfx))
+
+
+PAIRS = {
+    # name: (kind A, operands A, kind B, operands B); results r1, r2
+    "mul_mul": (("mul", ("a", "b")), ("mul", ("c", "d"))),
+    "sqr_sqr": (("sqr", ("a",)), ("sqr", ("c",))),
+    "mul2_mul": (("mul2", ("a", "b", "c", "d")), ("mul", ("e", "f"))),
+}
+
 kind = sys.argv[1] if len(sys.argv) > 1 else "mul"
+if kind in PAIRS:
+    (ka, oa), (kb, ob) = PAIRS[kind]
+    print("// GENERATED by gen_fq29_mul_asm.py %s -- do not edit." % kind)
+    print("#if defined(SNARKV_CURVE_PALLAS)")
+    pair_body(Prod(ka, oa, "_a", "r1"), Prod(kb, ob, "_b", "r2"), zero_limbs=(5, 6, 7))
+    print("#else")
+    pair_body(Prod(ka, oa, "_a", "r1"), Prod(kb, ob, "_b", "r2"))
+    print("#endif")
+    sys.exit(0)
 print("// GENERATED by gen_fq29_mul_asm.py %s -- do not edit." % kind)
 # pallas: p = 2^254 + (a 125-bit number): limbs 5, 6, 7 of its 9 x 29-bit form are zero (pallas_consts.h)
 print("#if defined(SNARKV_CURVE_PALLAS)")
