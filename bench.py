@@ -298,7 +298,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log2n", type=int, default=20, help="points per GPU = 2^log2n")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--cpu-sample-log2", type=int, default=20,

@@ -85,6 +85,58 @@ def test_malformed_inputs_are_errors_not_crashes():
             H.Protocol(text, H.PROTOCOL_SERDE_JSON)
 
 
+def _mutations(rng, data, count):
+    """byte flips, 0xFF / 0x00 overwrites of a length-sized window, truncations, splices"""
+    for _ in range(count):
+        b = bytearray(data)
+        kind = rng.randrange(5)
+        if kind == 0:
+            for _ in range(rng.randrange(1, 4)):
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+        elif kind == 1:
+            at = rng.randrange(len(b))
+            b[at:at + 8] = b"\xff" * min(8, len(b) - at)
+        elif kind == 2:
+            at = rng.randrange(len(b))
+            b[at:at + 8] = b"\x00" * min(8, len(b) - at)
+        elif kind == 3:
+            b = b[:rng.randrange(len(b))]
+        else:
+            at, ln = rng.randrange(len(b)), rng.randrange(1, 64)
+            b[at:at + ln] = bytes(rng.randrange(256) for _ in range(rng.randrange(0, 64)))
+        yield bytes(b)
+
+
+def _as_bytes(x):
+    return x.encode() if isinstance(x, str) else bytes(x)
+
+
+def test_mutated_inputs_never_crash_the_readers():
+    """Seeded mutation fuzz of the four readers (protocol / snark x bincode / JSON): every input either parses (and
+    then packs without error) or is refused with an error code -- no crash, no hang, no runaway allocation from a
+    corrupted length prefix."""
+    rng = random.Random(0xF022)
+    pr = _protocols()[0]
+    inst = [[rng.randrange(O.R) for _ in range(m)] for m in pr["num_instance"]]
+    proof = bytes(rng.randrange(256) for _ in range(320))
+    seeds = ((H.Protocol, H.PROTOCOL_BINCODE, X.protocol_to_bincode(pr)),
+             (H.Protocol, H.PROTOCOL_SERDE_JSON, _as_bytes(X.protocol_to_json(pr))),
+             (H.Snark, H.PROTOCOL_BINCODE, X.snark_to_bincode(pr, inst, proof)),
+             (H.Snark, H.PROTOCOL_SERDE_JSON, _as_bytes(X.snark_to_json(pr, inst, proof))))
+    parsed = refused = 0
+    for cls, fmt, data in seeds:
+        for bad in _mutations(rng, data, 250):
+            try:
+                obj = cls(bad, fmt)
+            except H.HostError:
+                refused += 1
+                continue
+            parsed += 1
+            (obj.protocol if cls is H.Snark else obj).pack()
+            obj.close()
+    assert refused > 500 and parsed + refused == 1000
+
+
 def test_reference_generated_snark_if_present():
     """tools/refgen (Rust; needs cargo + network, neither here) writes ref_snark.bin / ref_snark.json with the
     reference's own serde: when a maintainer has dropped them into tests/golden/, both must load and agree."""
