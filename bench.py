@@ -309,8 +309,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path even at world size 1 (testing)")
-    ap.add_argument("--inflight", type=int, default=4,
-                    help="independent MSMs kept in flight (one context + HIP stream each); 1 = strictly sequential")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="0 (default): the K timed steps are ONE batch call (snarkv_g1_msm_pippenger_many_dev: the library "
+                         "pipelines them).  N >= 1: N independent single-MSM calls kept in flight instead (one context + HIP "
+                         "stream each; 1 = strictly sequential) -- the round-1 / early round-2 way, kept for comparison")
     args = ap.parse_args()
 
     import torch
@@ -344,7 +346,8 @@ def main():
     # One context per in-flight MSM, each on its own HIP stream: the latency-bound
     # tail of one MSM (bucket reduce, 2^(cw) doubling chains, to_affine: a few
     # wavefronts) overlaps the VALU-bound bucket accumulation of the next.
-    inflight = max(1, args.inflight)
+    batch = args.inflight <= 0  # the K steps as one batch call
+    inflight = 4 if batch else max(1, args.inflight)
     # explicit side streams only: a context given the NULL stream handle (torch's legacy default
     # stream) would create its own stream, invisible to the stream ordering torch.distributed relies on
     streams = [torch.cuda.Stream() for _ in range(inflight)]
@@ -373,6 +376,38 @@ def main():
     torch.cuda.synchronize()
     step_no = [0]
 
+    # ---- batch submission: job i of a K-step batch works on input set i (disjoint ranges again; at most 32 sets, reused
+    # cyclically beyond -- 96 MiB each at 2^20); the first `inflight` sets are the slots above
+    if batch:
+        nsets = min(args.steps, 32)
+        for k in range(inflight, nsets):
+            first = (world * (1 + (inflight - 1)) + rank * (nsets - inflight) + (k - inflight)) * n
+            d_scalars_k.append(torch.empty(32 * n, dtype=torch.uint8, device="cuda"))
+            d_points_k.append(torch.empty(64 * n, dtype=torch.uint8, device="cuda"))
+            ctx.sample_scalars_dev(0x5EED0001, n, d_scalars_k[k].data_ptr(), first=first)
+            ctx.sample_points_dev(0x5EED0002, n, d_points_k[k].data_ptr(), first=first)
+        ctx.sync()
+        nsets = min(nsets, len(d_scalars_k))
+        b_out = torch.zeros(64 * args.steps, dtype=torch.uint8, device="cuda")
+        b_part = torch.zeros(sv.G1_PARTIAL_BYTES * args.steps, dtype=torch.uint8, device="cuda")
+        b_gath = torch.zeros(world * sv.G1_PARTIAL_BYTES * args.steps, dtype=torch.uint8, device="cuda")
+        job_s = [d_scalars_k[i % nsets].data_ptr() for i in range(args.steps)]
+        job_p = [d_points_k[i % nsets].data_ptr() for i in range(args.steps)]
+
+    def run_batch():
+        """the K steps: one call; multi-GPU: K partials -> ONE all-gather (K x 144 B per rank) -> K folds"""
+        if not use_dist:
+            ctx.msm_pippenger_many_dev(job_s, job_p, [n] * args.steps, b_out.data_ptr(), args.window_bits)
+        else:
+            with torch.cuda.stream(streams[0]):
+                ctx.msm_pippenger_many_partial_dev(job_s, job_p, [n] * args.steps, b_part.data_ptr(), args.window_bits)
+                dist.all_gather_into_tensor(b_gath, b_part)
+                pb = sv.G1_PARTIAL_BYTES
+                g = b_gath.view(world, args.steps, pb).transpose(0, 1).contiguous()  # [job][rank][144]
+                for i in range(args.steps):
+                    ctx.fold_partials_dev(g.data_ptr() + i * world * pb, world, b_out.data_ptr() + 64 * i)
+                run_batch.keep = g
+
     def step():
         k = step_no[0] % inflight
         step_no[0] += 1
@@ -399,8 +434,14 @@ def main():
         step()
     barrier()
     step_no[0] = 0
-    for _ in range(args.warmup):
-        step()
+    if batch:
+        run_batch()  # initialisation again: the batch's job contexts allocate their scratch
+        barrier()
+        for _ in range(-(-args.warmup // args.steps)):  # W warm-up steps, rounded up to whole batches
+            run_batch()
+    else:
+        for _ in range(args.warmup):
+            step()
     barrier()
 
     # timed region: exactly K steps.  Per-stage HIP events are recorded on the
@@ -410,7 +451,9 @@ def main():
     stage_sum, stage_cnt = {}, 0
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    if batch:
+        run_batch()
+    for i in range(0 if batch else args.steps):
         step()
         if inflight == 1:
             st = ctx.get_stage_timing()  # sequential mode: consume each step before the next
@@ -419,6 +462,8 @@ def main():
                 stage_sum[k] = stage_sum.get(k, 0.0) + v
     barrier()
     dt = time.perf_counter() - t0
+    if batch:  # [total of the call, mean k_accumulate / combine launch over the jobs' own events]
+        stage_sum, stage_cnt = dict(ctx.get_stage_timing()), 1
     if stage_cnt == 0:  # pipelined mode: the events of the last step of every context that ran a timed step
         first = step_no[0] - args.steps
         used = sorted({i % inflight for i in range(first, step_no[0])})
@@ -433,6 +478,11 @@ def main():
     out = outs[written[0]]
     slot_results = [bytes(o.cpu().numpy()) for o in outs]
     assert all(r != bytes(64) for r in slot_results) and len(set(slot_results)) == inflight  # distinct inputs, distinct sums
+    if batch:  # job i of the batch = input set i: the first sets are the slots, whose single-call results are above
+        got = bytes(b_out.cpu().numpy())
+        jobs = [got[64 * i:64 * i + 64] for i in range(args.steps)]
+        assert all(jobs[i] == slot_results[i % nsets] for i in range(args.steps) if i % nsets < inflight)
+        assert len(set(jobs)) == nsets and bytes(64) not in jobs
 
     # single-MSM latency (strictly sequential), outside the timed region, for the record
     lat_ms, seq_stages = None, None
@@ -493,10 +543,16 @@ def main():
                 "points_per_kernel_launch": launch_n,
                 "window_bits": args.window_bits or "default",
                 "parallelism": "point-sharded x%d, all-gather of 144 B partials + local fold" % world,
-                "msms_in_flight": inflight,
-                "inputs": "every in-flight slot has its own scalar / point arrays (disjoint ranges of the seeded streams)",
-                "throughput_hint": inflight > 1,  # snarkv_ctx_set_throughput_hint on the in-flight contexts (runs of 96 entries per lane
-                                                  # instead of 64); the single-MSM latency and the sequential stage times are taken without it
+                "submission": ("the %d timed steps are ONE snarkv_g1_msm_pippenger_many_dev call (the library pipelines the "
+                               "MSMs: sorts on high-priority streams, accumulations back to back, one batched tail)" % args.steps)
+                              if batch else "%d single-MSM calls kept in flight, one context + stream each" % inflight,
+                "msms_in_flight": args.steps if batch else inflight,
+                "inputs": ("job i works on input set i mod %d, every set its own scalar / point arrays (disjoint ranges of the "
+                           "seeded streams)" % nsets) if batch else
+                          "every in-flight slot has its own scalar / point arrays (disjoint ranges of the seeded streams)",
+                "throughput_hint": batch or inflight > 1,  # runs of 96 entries per lane instead of 64 (snarkv_ctx_set_throughput_hint on
+                                                           # in-flight contexts; always on a batch's jobs); the single-MSM latency and
+                                                           # the sequential stage times are taken without it
                 "single_msm_latency_ms": lat_ms,
                 "result": result_hex,
             },
@@ -515,7 +571,7 @@ def main():
 
                 "note": "algorithmic 96 B/point x %d points per launch / avg HIP-event duration of the dominant stage in the "
                         "timed region (where %d MSMs overlap, so one launch shares the GPU); the path is "
-                        "integer-VALU-bound (~160 Fq products per point), see DESIGN.md" % (launch_n, inflight),
+                        "integer-VALU-bound (~160 Fq products per point), see DESIGN.md" % (launch_n, 3 if batch else inflight),
             },
             "stages_ms": stages,
         }
@@ -571,8 +627,9 @@ def main():
             line["roofline"]["launches_resident_on_average"] = conc
             line["roofline"]["frac_per_resident_launch"] = line["roofline"]["frac"] * max(conc, 1.0)
             line["roofline"]["overlap_note"] = (
-                "`frac` is per launch as prescribed; with %d MSMs in flight %.2f launches of this kernel share the GPU on average, "
-                "so its duration (%.2f ms) is not the kernel's own speed -- `frac_unshared` (one MSM at a time) is" % (inflight, conc, dom_ms))
+                "`frac` is per launch as prescribed; with %s %.2f launches of this kernel share the GPU on average, "
+                "so its duration (%.2f ms) is not the kernel's own speed -- `frac_unshared` (one MSM at a time) is"
+                % ("a batch's accumulations on three streams" if batch else "%d MSMs in flight" % inflight, conc, dom_ms))
         if seq_stages:
             dseq = seq_stages.get(dom, 0.0)
             line["stages_ms_sequential"] = seq_stages

@@ -96,6 +96,23 @@ int snarkv_g1_msm_pippenger_dev(snarkv_ctx* ctx, const void* d_scalars32, const 
 int snarkv_g1_msm_batched_dev(snarkv_ctx* ctx, const void* d_scalars32, const void* d_points64,
                               const void* d_offsets, size_t n_msm, size_t n_terms, void* d_out);
 
+/* MANY independent large MSMs in one call (what a batch of `util::msm::multi_scalar_multiplication` calls,
+ * msm.rs:308, is to the reference: the accumulation path issues one per `Msm::evaluate`): d_out64s[64 i ..] =
+ * sum_j scalars_i[j] * points_i[j], the same bytes `snarkv_g1_msm_pippenger_dev` gives for each.  One call, one
+ * context: the library pipelines the MSMs itself (sorts on high-priority streams, accumulations back to back, ONE
+ * batched tail per round; csrc/capi.hip) -- 4-5 % faster than four single calls kept in flight for 8-20 MSMs of 2^20
+ * points, level beyond.  Scratch: ~0.5 KiB per point and job; more than SNARKV_MANY_MAX_JOBS MSMs (or 48 GiB of
+ * scratch) run as successive rounds; an MSM large enough for the chunk pipeline (3 * 2^20 points) makes the call
+ * fall back to one MSM after the other.  Asynchronous on the context stream; n[i] = 0 is SNARKV_ERR_EMPTY. */
+#define SNARKV_MANY_MAX_JOBS 64
+int snarkv_g1_msm_pippenger_many_dev(snarkv_ctx* ctx, size_t count, const void* const* d_scalars32,
+                                     const void* const* d_points64, const size_t* n, int window_bits, void* d_out64s);
+/* the same with projective partials out (count x SNARKV_G1_PARTIAL_BYTES): a rank's shard of `count` multi-GPU MSMs --
+ * ONE all-gather of all the partials, then snarkv_g1_fold_partials_dev per MSM                                        */
+int snarkv_g1_msm_pippenger_many_partial_dev(snarkv_ctx* ctx, size_t count, const void* const* d_scalars32,
+                                             const void* const* d_points64, const size_t* n, int window_bits,
+                                             void* d_partials);
+
 /* Multi-GPU building blocks: each rank reduces ITS shard of
  * the points to one projective partial (SNARKV_G1_PARTIAL_BYTES, internal XYZZ
  * 9x29-bit Montgomery form, opaque), the partials are all-gathered (RCCL), and every rank folds

@@ -53,6 +53,8 @@ _SIGNATURES = {
     "snarkv_g1_msm_batched": (_int, [_vp, _cp, _cp, _vp, _sz, _u32, _vp]),
     "snarkv_g1_msm_pippenger": (_int, [_vp, _cp, _cp, _sz, _u32, _vp]),
     "snarkv_g1_msm_pippenger_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
+    "snarkv_g1_msm_pippenger_many_dev": (_int, [_vp, _sz, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_sz), _int, _vp]),
+    "snarkv_g1_msm_pippenger_many_partial_dev": (_int, [_vp, _sz, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_sz), _int, _vp]),
     "snarkv_g1_msm_batched_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "snarkv_g1_msm_pippenger_partial_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "snarkv_g1_fold_partials_dev": (_int, [_vp, _vp, _sz, _vp]),
@@ -402,6 +404,22 @@ class Context:
     # ---- device-pointer entry points (ints from tensor.data_ptr()) ----
     def msm_pippenger_dev(self, d_scalars, d_points, n, d_out, window_bits=0):
         _check(self._lib.snarkv_g1_msm_pippenger_dev(self._h, d_scalars, d_points, n, window_bits, d_out))
+
+    def msm_pippenger_many_dev(self, d_scalars, d_points, counts, d_out, window_bits=0):
+        """`len(counts)` independent MSMs in one phase-ordered call: d_out[64 i ..] = MSM i (device pointers as ints)."""
+        k = len(counts)
+        ds = (ctypes.c_void_p * k)(*[int(x) for x in d_scalars])
+        dp = (ctypes.c_void_p * k)(*[int(x) for x in d_points])
+        cn = (ctypes.c_size_t * k)(*counts)
+        _check(self._lib.snarkv_g1_msm_pippenger_many_dev(self._h, k, ds, dp, cn, window_bits, d_out))
+
+    def msm_pippenger_many_partial_dev(self, d_scalars, d_points, counts, d_partials, window_bits=0):
+        """the same with projective partials out (G1_PARTIAL_BYTES each): this rank's shard of `len(counts)` multi-GPU MSMs"""
+        k = len(counts)
+        ds = (ctypes.c_void_p * k)(*[int(x) for x in d_scalars])
+        dp = (ctypes.c_void_p * k)(*[int(x) for x in d_points])
+        cn = (ctypes.c_size_t * k)(*counts)
+        _check(self._lib.snarkv_g1_msm_pippenger_many_partial_dev(self._h, k, ds, dp, cn, window_bits, d_partials))
 
     def msm_pippenger_partial_dev(self, d_scalars, d_points, n, d_partial, window_bits=0):
         _check(self._lib.snarkv_g1_msm_pippenger_partial_dev(self._h, d_scalars, d_points, n, window_bits, d_partial))

@@ -71,6 +71,23 @@ int snarkv_g1_msm_launch_points(size_t n, size_t* per_launch) {
 int snarkv_get_stage_timing(snarkv_ctx* ctx, float ms[SNARKV_PIP_STAGES]) {
   if (!ctx || !ctx->ev_ready) return SNARKV_ERR_ARG;
   SNARKV_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->last_many_jobs > 0) {
+    // batch (snarkv_g1_msm_pippenger_many_dev): [0] the whole call; [4] / [5] ONE k_accumulate / combine launch of its
+    // last round, averaged over the jobs' own events (launches of up to three jobs overlap); the rest is not broken down
+    for (int i = 0; i < SNARKV_PIP_STAGES; ++i) ms[i] = 0.f;
+    SNARKV_HIP(hipEventElapsedTime(&ms[0], ctx->ev[0], ctx->ev[SNARKV_PIP_STAGES - 1]));
+    const float jobs = (float)ctx->last_many_jobs;
+    for (int j = 0; j < ctx->last_many_jobs; ++j) {
+      snarkv_ctx* job = ctx->jobs[j];
+      if (!job->ev_ready) continue;
+      float t = 0.f;
+      SNARKV_HIP(hipEventElapsedTime(&t, job->ev[3], job->ev[4]));
+      ms[4] += t / jobs;
+      SNARKV_HIP(hipEventElapsedTime(&t, job->ev[4], job->ev[5]));
+      ms[5] += t / jobs;
+    }
+    return SNARKV_OK;
+  }
   if (ctx->last_split_workers > 0) {
     // chunk pipeline: total = the whole MSM on this stream; stages 1..5 = ONE 2^20-point chunk (the last one of every
     // worker lane, averaged): what a single launch of each kernel took; the shared tail is not broken down
@@ -176,6 +193,7 @@ int snarkv::launch_msm_pippenger_auto(snarkv_ctx* ctx, const void* d_s, const vo
   const size_t min_chunks = mode == 2 ? 2 : 3;
   const size_t chunks = (n + kChunk - 1) / kChunk;
   ctx->last_split_workers = 0;
+  ctx->last_many_jobs = 0;
   if (mode == 0 || chunks < min_chunks || window_bits != 0 || ctx->is_lane)
     return launch_msm_pippenger(ctx, d_s, d_p, n, window_bits, d_out, partial_out);
   SNARKV_TRY(ctx_lanes(ctx));
@@ -227,7 +245,153 @@ int snarkv::launch_msm_pippenger_auto(snarkv_ctx* ctx, const void* d_s, const vo
   return rc;
 }
 
+// ---- many MSMs in one call --------------------------------------------------------------------------------------
+// Several MSMs kept in flight on their own streams time-share the GPU kernel by kernel: a resident k_accumulate owns
+// nearly every VGPR (3 waves x 168 registers per SIMD), so the kernels of the other MSMs (prepare, the sorts, the
+// tails) wait for wave slots 5-20x longer than they run alone (rocprofv3 trace of 4 in flight at 2^20: k_prepare
+// 0.1 -> 2 ms), and every stream's next MSM waits for its own tail.  A batch knows all its MSMs up front:
+//   * every prepare + sort goes to two HIGH-PRIORITY streams (memory-bound kernels: they take the wave slots first as
+//     accumulation wavefronts retire, and give the VALU back while they wait for memory);
+//   * the accumulations (+ combine) run on three normal-priority streams, each waiting only for its own sort -- the
+//     next accumulation's wavefronts fill the slots the previous one drains;
+//   * ONE tail per round for all jobs (their bucket grids lie end to end): three launches, and no stream waits for it.
+// Measured (MI355X, 2^20 points each): 8 / 20 MSMs 1.67 / 1.53 ms per MSM against 1.74 / 1.60 with four single calls
+// in flight; level from 40 on (the machine is issue-bound on the total work either way).  Strict
+// phase order (all sorts, then all accumulations) measured 6 % slower than this pipeline, tails in groups of 2-10 under
+// the later accumulations level, an occupancy cap on k_accumulate (LDS allocation) 3-9 % slower.
+// Job j's scratch is a private context (ctx->jobs[j]); results are the bytes of the single-MSM entry point.
+int snarkv::launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void* const* d_s, const void* const* d_p,
+                                      const size_t* n, int window_bits, void* d_out, bool partial_out) {
+  const size_t ostride = partial_out ? SNARKV_G1_PARTIAL_BYTES : 64;
+  ctx->last_many_jobs = 0;
+  ctx->last_split_workers = 0;
+  if (count == 0) return SNARKV_OK;
+  const size_t kLarge = (size_t)3 << 20;  // the chunk pipeline's threshold (launch_msm_pippenger_auto)
+  uint32_t c0 = 0, w0 = 0, b0 = 0;
+  bool uniform = true, large = false;
+  size_t nmax = 0, sig = count * 1000003u;
+  for (size_t i = 0; i < count; ++i) {
+    if (n[i] == 0) return SNARKV_ERR_EMPTY;
+    uint32_t c, w, b;
+    SNARKV_TRY(pip_geometry(n[i], window_bits, &c, &w, &b));
+    if (i == 0) c0 = c, w0 = w, b0 = b;
+    uniform = uniform && c == c0;
+    large = large || (n[i] >= kLarge && window_bits == 0);
+    nmax = std::max(nmax, n[i]);
+    sig = sig * 31 + n[i];
+  }
+  const char* em = getenv("SNARKV_MANY_MODE");  // 0: one MSM after the other through the single-call path (A/B knob)
+  if (count == 1 || large || (em && atoi(em) == 0) || ctx->is_lane) {
+    for (size_t i = 0; i < count; ++i)
+      SNARKV_TRY(launch_msm_pippenger_auto(ctx, d_s[i], d_p[i], n[i], window_bits, (uint8_t*)d_out + ostride * i, partial_out));
+    return SNARKV_OK;
+  }
+  // jobs per round: bounded by the scratch footprint (~560 B per point + two bucket grids)
+  const size_t per_job = nmax * 560 + (size_t)w0 * b0 * SNARKV_G1_PARTIAL_BYTES * 2 + (1u << 20);
+  size_t G = std::min<size_t>(count, SNARKV_MANY_MAX_JOBS);
+  G = std::max<size_t>(1, std::min<size_t>(G, ((size_t)48 << 30) / per_job));
+  if (const char* eg = getenv("SNARKV_MANY_JOBS")) G = std::max<size_t>(1, std::min<size_t>(G, (size_t)atoi(eg)));
+  const size_t rounds = (count + G - 1) / G;
+  G = (count + rounds - 1) / rounds;  // even rounds
+  SNARKV_TRY(ctx_lanes(ctx));
+  while ((size_t)ctx->njobs < G) {
+    snarkv_ctx* j = nullptr;
+    SNARKV_TRY(snarkv_ctx_create(ctx->device, nullptr, &j));
+    j->is_lane = true;
+    j->throughput_mode = true;  // long runs: other accumulations are always resident next to a job's
+    for (int e = 0; e < 16; ++e) SNARKV_HIP(hipEventCreateWithFlags(&j->grp_ev[e], hipEventDisableTiming));
+    j->grp_ev_ready = true;
+    ctx->jobs[ctx->njobs++] = j;
+  }
+  if (!ctx->hi_ready) {
+    int least = 0, greatest = 0;
+    SNARKV_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    for (int i = 0; i < 2; ++i) SNARKV_HIP(hipStreamCreateWithPriority(&ctx->hi_stream[i], hipStreamNonBlocking, greatest));
+    for (int i = 0; i < 2; ++i) SNARKV_HIP(hipEventCreateWithFlags(&ctx->many_ev[i], hipEventDisableTiming));
+    ctx->hi_ready = true;
+  }
+  const bool tm = ctx->stage_timing;
+  if (tm && !ctx->ev_ready) {
+    for (int i = 0; i <= SNARKV_PIP_STAGES; ++i) SNARKV_HIP(hipEventCreate(&ctx->ev[i]));
+    ctx->ev_ready = true;
+  }
+  if (sig != ctx->many_sig) {  // a new shape may grow (free + reallocate) scratch that queued work still uses
+    SNARKV_HIP(hipDeviceSynchronize());
+    ctx->many_sig = sig;
+  }
+  hipStream_t S[3] = {ctx->stream, ctx->sub[0]->stream, ctx->sub[1]->stream};  // the accumulation streams
+  // the context's stream waits for everything queued on the other four streams, then they wait for it
+  auto join_and_fork = [&]() -> int {
+    for (int k = 0; k < 2; ++k) {
+      SNARKV_HIP(hipEventRecord(ctx->many_ev[k], ctx->hi_stream[k]));
+      SNARKV_HIP(hipStreamWaitEvent(ctx->stream, ctx->many_ev[k], 0));
+      SNARKV_HIP(hipEventRecord(ctx->sub_ev[k], S[k + 1]));
+      SNARKV_HIP(hipStreamWaitEvent(ctx->stream, ctx->sub_ev[k], 0));
+    }
+    SNARKV_HIP(hipEventRecord(ctx->sub_ev[4], ctx->stream));
+    for (int k = 0; k < 2; ++k) {
+      SNARKV_HIP(hipStreamWaitEvent(ctx->hi_stream[k], ctx->sub_ev[4], 0));
+      SNARKV_HIP(hipStreamWaitEvent(S[k + 1], ctx->sub_ev[4], 0));
+    }
+    return SNARKV_OK;
+  };
+  void* d_grids = nullptr;
+  const size_t grid_bytes = (size_t)w0 * b0 * SNARKV_G1_PARTIAL_BYTES;
+  if (uniform) SNARKV_TRY(ctx_reserve(ctx, SLOT_MGPU_GRID, grid_bytes * G, &d_grids));
+  if (tm) SNARKV_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+  SNARKV_TRY(join_and_fork());  // inputs may still be in flight on the caller's stream
+  for (size_t lo = 0; lo < count; lo += G) {
+    const size_t hi = std::min(count, lo + G);
+    const bool last = hi == count;
+    for (size_t i = lo; i < hi; ++i) {
+      snarkv_ctx* job = ctx->jobs[i - lo];
+      job->stage_timing = tm && last;
+      void* grid = uniform ? (uint8_t*)d_grids + grid_bytes * (i - lo) : nullptr;
+      hipStream_t sa = ctx->hi_stream[(i - lo) % 2], sb = S[(i - lo) % 3];
+      SNARKV_TRY(launch_msm_pippenger_phases(job, sa, PIP_PHASE_SORT, d_s[i], d_p[i], n[i], window_bits, nullptr, false,
+                                             nullptr, grid));
+      SNARKV_HIP(hipEventRecord(job->grp_ev[0], sa));
+      SNARKV_HIP(hipStreamWaitEvent(sb, job->grp_ev[0], 0));
+      SNARKV_TRY(launch_msm_pippenger_phases(job, sb, PIP_PHASE_ACC, d_s[i], d_p[i], n[i], window_bits, nullptr, false,
+                                             nullptr, grid));
+      // a ragged batch (different window sizes) cannot share one tail: each job's own, behind its accumulation
+      if (!uniform)
+        SNARKV_TRY(launch_msm_pippenger_phases(job, sb, PIP_PHASE_TAIL, d_s[i], d_p[i], n[i], window_bits,
+                                               (uint8_t*)d_out + ostride * i, partial_out, nullptr, nullptr));
+      job->stage_timing = false;
+    }
+    SNARKV_TRY(join_and_fork());
+    if (uniform) {
+      SNARKV_TRY(launch_buckets_reduce_many(ctx, ctx->stream, d_grids, c0, w0, (uint32_t)(hi - lo),
+                                            (uint8_t*)d_out + ostride * lo, partial_out));
+      if (!last) SNARKV_TRY(join_and_fork());  // the next round overwrites the grids
+    }
+    if (last) ctx->last_many_jobs = (int)(hi - lo);
+  }
+  if (tm) SNARKV_HIP(hipEventRecord(ctx->ev[SNARKV_PIP_STAGES - 1], ctx->stream));
+  return SNARKV_OK;
+}
+
 extern "C" {
+
+int snarkv_g1_msm_pippenger_many_dev(snarkv_ctx* ctx, size_t count, const void* const* d_scalars32,
+                                     const void* const* d_points64, const size_t* n, int window_bits, void* d_out64s) {
+  if (!ctx || (count && (!d_scalars32 || !d_points64 || !n || !d_out64s))) return SNARKV_ERR_ARG;
+  for (size_t i = 0; i < count; ++i)
+    if (!d_scalars32[i] || !d_points64[i]) return SNARKV_ERR_ARG;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  return launch_msm_pippenger_many(ctx, count, d_scalars32, d_points64, n, window_bits, d_out64s, false);
+}
+
+int snarkv_g1_msm_pippenger_many_partial_dev(snarkv_ctx* ctx, size_t count, const void* const* d_scalars32,
+                                             const void* const* d_points64, const size_t* n, int window_bits,
+                                             void* d_partials) {
+  if (!ctx || (count && (!d_scalars32 || !d_points64 || !n || !d_partials))) return SNARKV_ERR_ARG;
+  for (size_t i = 0; i < count; ++i)
+    if (!d_scalars32[i] || !d_points64[i]) return SNARKV_ERR_ARG;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  return launch_msm_pippenger_many(ctx, count, d_scalars32, d_points64, n, window_bits, d_partials, true);
+}
 
 int snarkv_g1_msm_pippenger(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8_t* points64, size_t n,
                             uint32_t flags, uint8_t out64[64]) {

@@ -93,6 +93,14 @@ struct snarkv_ctx {
   int last_split_workers;  // > 0: the last Pippenger ran as a chunk pipeline on that many worker lanes (stage timing)
   bool throughput_mode;  // several MSMs are kept in flight next to this context's (snarkv_ctx_set_throughput_hint; always on lanes)
   bool is_lane;          // a private sub-context of another context (never starts lanes of its own)
+  // job contexts of the batch entry point (snarkv_g1_msm_pippenger_many_dev): scratch of one MSM each
+  snarkv_ctx* jobs[SNARKV_MANY_MAX_JOBS];
+  int njobs;
+  int last_many_jobs;    // > 0: the last call was a batch of that many jobs per round (stage timing reads the jobs' events)
+  size_t many_sig;       // shape of the last batch (a new shape may grow scratch: synchronise first)
+  hipEvent_t many_ev[2];
+  hipStream_t hi_stream[2];  // high-priority streams of the batch pipeline (the sorts) + their join events (many_ev)
+  bool hi_ready;
 };
 
 struct snarkv_dk {
@@ -116,6 +124,16 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
                        size_t n_msm, size_t n_terms, void* d_out);
 int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
                          void* d_out, bool partial_out, void* d_buckets_out = nullptr);
+// one Pippenger cut into phases, each on a stream of the caller's choice (msm_pippenger.hip); `ctx` owns the scratch
+enum { PIP_PHASE_SORT = 1, PIP_PHASE_ACC = 2, PIP_PHASE_TAIL = 4, PIP_PHASE_ALL = 7 };
+int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, const void* d_scalars, const void* d_points,
+                                size_t n, int window_bits, void* d_out, bool partial_out, void* d_buckets_out,
+                                void* d_grid);
+int launch_buckets_reduce_many(snarkv_ctx* ctx, hipStream_t st, const void* d_grids, uint32_t c, uint32_t windows,
+                               uint32_t jobs, void* d_out, bool partial_out);
+// `count` independent MSMs, phase-ordered over private job contexts (capi.hip)
+int launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void* const* d_scalars, const void* const* d_points,
+                              const size_t* n, int window_bits, void* d_out, bool partial_out);
 // the product path of a large MSM: single launch, or the chunk pipeline over shared bucket grids (capi.hip)
 int launch_msm_pippenger_auto(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
                               void* d_out, bool partial_out);

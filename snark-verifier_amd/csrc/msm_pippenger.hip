@@ -49,6 +49,7 @@
 #include <string.h>
 #include <algorithm>
 #include <mutex>
+#include <atomic>
 #include "ctx.hpp"
 #include "g1_29.h"
 #ifndef SNARKV_GLV
@@ -68,6 +69,15 @@ namespace snarkv {
 #endif
 #ifndef SNARKV_TILE_THREADS
 #define SNARKV_TILE_THREADS 512  // tile workgroups of k_prepare / k_sort_scatter (256 left the chip at 1 wave/SIMD)
+#endif
+#ifndef SNARKV_SCATTER_WINDOW_MAJOR
+#define SNARKV_SCATTER_WINDOW_MAJOR 1  // k_sort_scatter walks its tile window by window (see there)
+#endif
+#ifndef SNARKV_SCATTER_STAGED
+#define SNARKV_SCATTER_STAGED 1  // k_sort_scatter_staged (LDS-staged, coalesced write-out) instead of k_sort_scatter
+#endif
+#ifndef SNARKV_XCD_TILES
+#define SNARKV_XCD_TILES 1  // tiles -> workgroups so that an XCD owns a contiguous tile range (xcd_tile)
 #endif
 #ifndef SNARKV_TILE_BASE
 #define SNARKV_TILE_BASE 4096  // smallest tile (scalars per k_prepare / k_sort_scatter workgroup)
@@ -126,6 +136,7 @@ struct PipParams {
   uint32_t gsz;      // windows per group (W = one group: the whole stream, runs cut from offset 0)
   uint32_t krun;     // entries per run (kRun, or kRunThroughput on a context with the throughput hint)
   uint32_t rpw;      // run slots reserved per window: ceil(max entries of a window / krun) + 1
+  uint32_t wper;     // batched tail over several MSMs' grids laid end to end: windows per MSM (0: one MSM)
 };
 
 // c bits at offset lo of a kDigitBits-bit magnitude held in registers (selects, no dynamic indexing)
@@ -157,6 +168,25 @@ __device__ __forceinline__ void for_each_digit(const uint32_t (&k)[kDigitWords],
     carry = neg;
     if (d != 0) emit((uint32_t)w * p.SB + ((d - 1) >> p.low_bits), (uint32_t)w * p.B + d - 1, neg ^ sgn);
   }
+}
+// One window's digit of the same recoding, without walking the windows below it: the carry into window w is 1 iff the
+// low w*c bits exceed the constant with B in every window, i.e. the first window below w (from the top) whose bits
+// differ from B decides (expected: one step).
+template <class F>
+__device__ __forceinline__ void digit_of_window(const uint32_t (&k)[kDigitWords], uint32_t sgn, const PipParams& p, int w,
+                                                F emit) {
+  uint32_t carry = 0;
+  for (int j = w - 1; j >= 0; --j) {
+    uint32_t b = half_bits(k, j * p.c, p.c);
+    if (b != p.B) {
+      carry = b > p.B ? 1u : 0u;
+      break;
+    }
+  }
+  uint32_t raw = half_bits(k, w * p.c, p.c) + carry;
+  uint32_t neg = raw > p.B ? 1u : 0u;
+  uint32_t d = neg ? ((1u << p.c) - raw) : raw;
+  if (d != 0) emit((uint32_t)w * p.SB + ((d - 1) >> p.low_bits), (uint32_t)w * p.B + d - 1, neg ^ sgn);
 }
 // digit source held in registers (k_prepare): copy + sign split
 __device__ __forceinline__ uint32_t load_digit_words(const uint32_t* src, uint32_t (&k)[kDigitWords]) {
@@ -190,6 +220,16 @@ __device__ __forceinline__ uint32_t load_digit_source(const uint4* __restrict__ 
 #endif
 }
 
+// Workgroup b runs on XCD b % 8 (observed placement, MI355X_MICROARCH.md): give every XCD a CONTIGUOUS range of tiles, so
+// that the sorted stream's lines shared by neighbouring tiles' runs of one key collect both halves in ONE L2.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nblk) {
+#if SNARKV_XCD_TILES
+  return (nblk & 7u) == 0 ? (b & 7u) * (nblk >> 3) + (b >> 3) : b;
+#else
+  return b;
+#endif
+}
+
 // One workgroup = one tile of p.tile scalars: GLV split k = k1 + k2*lambda,
 // P and phi(P) = (beta x, y) to 9x29-bit Montgomery, and the LDS histogram of
 // the (window, high digit bits) keys -> column `blockIdx` of the matrix M.
@@ -202,7 +242,8 @@ __global__ void __launch_bounds__(SNARKV_TILE_THREADS)
   extern __shared__ uint32_t lds[];  // nkeys counters
   for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) lds[k] = 0u;
   __syncthreads();
-  uint32_t lo = blockIdx.x * p.tile;
+  const uint32_t tile = xcd_tile(blockIdx.x, p.nblk);
+  uint32_t lo = tile * p.tile;
   uint32_t hi = lo + p.tile < p.n ? lo + p.tile : p.n;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     const uint4* s = reinterpret_cast<const uint4*>(points + (size_t)i * 16);
@@ -247,7 +288,7 @@ __global__ void __launch_bounds__(SNARKV_TILE_THREADS)
     }
   }
   __syncthreads();
-  for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) M[(size_t)k * p.mstride + blockIdx.x] = lds[k];
+  for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) M[(size_t)k * p.mstride + tile] = lds[k];
 }
 
 // --------------------------------------------------------------- S3
@@ -259,10 +300,33 @@ __global__ void __launch_bounds__(SNARKV_TILE_THREADS)
                    uint2* __restrict__ tmp) {
   SNARKV_RAISE_PRIO();
   extern __shared__ uint32_t lds[];  // nkeys cursors
-  for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) lds[k] = M[(size_t)k * p.mstride + blockIdx.x];
+  const uint32_t tile = xcd_tile(blockIdx.x, p.nblk);
+  for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) lds[k] = M[(size_t)k * p.mstride + tile];
   __syncthreads();
-  uint32_t lo = blockIdx.x * p.tile;
+  uint32_t lo = tile * p.tile;
   uint32_t hi = lo + p.tile < p.n ? lo + p.tile : p.n;
+#if SNARKV_SCATTER_WINDOW_MAJOR
+  // WINDOW-major: the workgroup walks its tile once per window, so that only that window's SB key streams are open at
+  // a time (SB lines of 128 B per workgroup: 2 MiB per XCD at 2^20 points, inside the 4 MiB L2, where a line collects
+  // its 16 entries before it is written back).  Scalar-major order keeps W*SB lines open per workgroup -- 16 MiB per XCD
+  // -- and the L2 evicts them half-written: WRITE_SIZE was 3.5x the payload (profiles/r02_pmc_hbm_traffic.txt).  The
+  // digit source (16 B per half-scalar) is re-read per window, out of L2 / the Infinity Cache.
+  for (int w = 0; w < p.W; ++w) {
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+#pragma unroll
+      for (uint32_t h = 0; h < (uint32_t)kHalves; ++h) {
+        uint32_t v = kHalves * i + h;  // virtual point: P (h=0) or phi(P) (h=1)
+        uint32_t d[kDigitWords];
+        uint32_t sgn = load_digit_source(glv, v, d);
+        digit_of_window(d, sgn, p, w, [&](uint32_t key, uint32_t bucket, uint32_t neg) {
+          uint32_t pos = atomicAdd(&lds[key], 1u);
+          tmp[pos] = make_uint2(bucket, v | (neg << 31));
+        });
+      }
+    }
+    __syncthreads();  // the whole workgroup moves on to the next window together
+  }
+#else
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
 #pragma unroll
     for (uint32_t h = 0; h < (uint32_t)kHalves; ++h) {
@@ -274,6 +338,97 @@ __global__ void __launch_bounds__(SNARKV_TILE_THREADS)
         tmp[pos] = make_uint2(bucket, v | (neg << 31));
       });
     }
+  }
+#endif
+}
+
+// The same partition with its writes STAGED through LDS (the default; k_sort_scatter above is the direct form: the
+// fall-back for geometries whose counters do not fit, and the comparison).  A workgroup owns ONE tile of kStageScalars
+// scalars, keeps their digit sources in registers, and per window counts its entries per key, scans the counts, places
+// the entries in LDS in key order and writes them out with consecutive lanes on consecutive addresses: a (tile, key)
+// run leaves as whole 64-128-byte segments instead of 8-byte stores issued at unrelated times.  The L2 does not merge
+// those: WRITE_SIZE was 3.5x the payload with the direct form (2.8x walking the tile window by window), 1.0x staged
+// (profiles/r02_pmc_hbm_traffic.txt); partition + sort 0.28 -> 0.19 ms at 2^20 points.
+constexpr uint32_t kStageScalars = SNARKV_TILE_BASE;                    // scalars per staged workgroup = the tile
+constexpr uint32_t kStageItems = kStageScalars / SNARKV_TILE_THREADS;   // ... per lane
+static_assert(kStageScalars % SNARKV_TILE_THREADS == 0, "a staged tile gives every lane the same number of scalars");
+__global__ void __launch_bounds__(SNARKV_TILE_THREADS)
+    k_sort_scatter_staged(const uint4* __restrict__ glv, PipParams p, const uint32_t* __restrict__ M,
+                          uint2* __restrict__ tmp) {
+  SNARKV_RAISE_PRIO();
+  extern __shared__ uint32_t lds[];  // gbase[SB] | cnt[SB] | off[SB] | wsum[16] | stage[kStageScalars * kHalves] (uint2)
+  uint32_t* gbase = lds;
+  uint32_t* cnt = lds + p.SB;
+  uint32_t* off = lds + 2 * p.SB;
+  uint32_t* wsum = lds + 3 * p.SB;
+  uint2* stage = reinterpret_cast<uint2*>(lds + 3 * p.SB + 16);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t tile = xcd_tile(blockIdx.x, p.nblk);
+  const uint32_t lo = tile * kStageScalars;
+  const uint32_t hi = lo + kStageScalars < p.n ? lo + kStageScalars : p.n;
+  const uint32_t per = (p.SB + SNARKV_TILE_THREADS - 1) / SNARKV_TILE_THREADS;  // keys a lane scans
+  // (Keeping the lane's 16 digit sources in registers across the windows instead of re-reading them -- FETCH 270 -> 40 MB
+  // -- made the kernel 12 % faster alone and the batch 5 % SLOWER: 196 VGPRs, and a 512-lane workgroup of those finds no
+  // room next to a resident k_accumulate.  The re-reads come out of L2 / the Infinity Cache.)
+  for (int w = 0; w < p.W; ++w) {
+    for (uint32_t k = tid; k < p.SB; k += blockDim.x) {
+      gbase[k] = M[((size_t)w * p.SB + k) * p.mstride + tile];
+      cnt[k] = 0u;
+    }
+    __syncthreads();
+    // this lane's entries of window w: bucket inside the window (0xFFFFFFFF: none), rank inside its key, sign
+    uint32_t ebkt[kStageItems * kHalves], erank[kStageItems * kHalves], eneg = 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < kStageItems; ++j) {
+      const uint32_t i = lo + tid + j * SNARKV_TILE_THREADS;
+#pragma unroll
+      for (uint32_t h = 0; h < (uint32_t)kHalves; ++h) {
+        const uint32_t e = j * kHalves + h;
+        ebkt[e] = 0xFFFFFFFFu;
+        if (i < hi) {
+          uint32_t d[kDigitWords];
+          uint32_t sgn = load_digit_source(glv, (size_t)kHalves * i + h, d);
+          digit_of_window(d, sgn, p, w, [&](uint32_t key, uint32_t bucket, uint32_t neg) {
+            ebkt[e] = bucket - (uint32_t)w * p.B;
+            eneg |= neg << e;
+            erank[e] = atomicAdd(&cnt[key - (uint32_t)w * p.SB], 1u);
+          });
+        }
+      }
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0 .. SB) -> off
+    uint32_t mine = 0;
+    for (uint32_t k = tid * per; k < (tid + 1) * per && k < p.SB; ++k) mine += cnt[k];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t up = __shfl_up(incl, d, 64);
+      if ((int)lane >= d) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+    for (uint32_t q = 0; q < wave; ++q) run += wsum[q];
+    for (uint32_t k = tid * per; k < (tid + 1) * per && k < p.SB; ++k) {
+      off[k] = run;
+      run += cnt[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < kStageItems * kHalves; ++e)
+      if (ebkt[e] != 0xFFFFFFFFu) {
+        const uint32_t v = kHalves * (lo + tid + (e / kHalves) * SNARKV_TILE_THREADS) + (e % kHalves);
+        stage[off[ebkt[e] >> p.low_bits] + erank[e]] = make_uint2(ebkt[e] + (uint32_t)w * p.B, v | (((eneg >> e) & 1u) << 31));
+      }
+    __syncthreads();
+    const uint32_t total = off[p.SB - 1] + cnt[p.SB - 1];
+    for (uint32_t idx = tid; idx < total; idx += blockDim.x) {
+      const uint2 e = stage[idx];
+      const uint32_t key = (e.x - (uint32_t)w * p.B) >> p.low_bits;
+      tmp[gbase[key] + (idx - off[key])] = e;
+    }
+    __syncthreads();  // the next window overwrites gbase / cnt / stage
   }
 }
 
@@ -817,7 +972,8 @@ __global__ void __launch_bounds__(64)
   }
   G1Xyzz29 r, total;
   wave_weighted_fold(sh, run, acc_s, acc_t, 31 - __clz((int)per), kLog2BlockBuckets, r, total);
-  if (!xyzz29_is_identity(r)) r = xyzz29_double_n_quad(r, p.c * (int)(w + p.w0));
+  const uint32_t wl = p.wper ? w % p.wper : w;  // window index inside its own MSM
+  if (!xyzz29_is_identity(r)) r = xyzz29_double_n_quad(r, p.c * (int)(wl + p.w0));
   if (lane == 0) shifted[w] = r;
 }
 
@@ -829,6 +985,9 @@ __global__ void __launch_bounds__(64)
   SNARKV_RAISE_PRIO();
   __shared__ G1Xyzz29 sh[64];
   uint32_t lane = threadIdx.x;
+  // batched form: workgroup b folds parts[b * count ..) into out[b]  (a single MSM launches one workgroup)
+  parts += (size_t)blockIdx.x * count;
+  out += (size_t)blockIdx.x * (partial_out ? sizeof(G1Xyzz29) / 4 : 16);
   G1Xyzz29 acc = xyzz29_identity();
 #pragma unroll 1
   for (uint32_t i = lane; i < count; i += 64) xyzz29_add_careful(acc, parts[i]);
@@ -883,8 +1042,24 @@ static int balance_window_bits(int c) {
 
 int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
                          void* d_out, bool partial_out, void* d_buckets_out) {
+  return launch_msm_pippenger_phases(ctx, ctx->stream, PIP_PHASE_ALL, d_scalars, d_points, n, window_bits, d_out,
+                                     partial_out, d_buckets_out, nullptr);
+}
+
+// The same launch cut into its three phases, each enqueued on a stream of the caller's choice (the batch scheduler of
+// capi.hip runs the phases of MANY MSMs in phase order):
+//   PIP_PHASE_SORT  P0-P4  prepare, scan, partition + sort               (reads the inputs, fills ctx's scratch)
+//   PIP_PHASE_ACC   P5     bucket accumulation + combine                 (scratch -> bucket grid)
+//   PIP_PHASE_TAIL  P6-P9  bucket reduce, shift chains, final            (bucket grid -> d_out)
+// `ctx` owns the scratch (its own stream is not used unless passed as `st`); `d_grid`, when given, is the bucket grid
+// to fill in place of the context's own (a batch lays its MSMs' grids end to end for one batched tail).  Every call
+// of one MSM must pass the same n / window_bits; window groups and stage marks exist only for PIP_PHASE_ALL.
+int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, const void* d_scalars, const void* d_points,
+                                size_t n, int window_bits, void* d_out, bool partial_out, void* d_buckets_out,
+                                void* d_grid) {
   PipParams p;
   p.w0 = 0;
+  p.wper = 0;
   p.n = (uint32_t)n;
   p.c = window_bits > 0 ? window_bits : balance_window_bits(default_window_bits(n));
   if (p.c < 2) p.c = 2;
@@ -901,7 +1076,11 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   p.nkeys = (uint32_t)p.W * p.SB;
   // tile: >= 16 items per (tile, key) stream so partition writes fill 128-byte lines
   p.tile = SNARKV_TILE_BASE;
-  while (p.tile < 65536 && (uint64_t)p.tile * kHalves * p.W < 16ull * p.nkeys) p.tile *= 2;
+  // the staged partition (k_sort_scatter_staged) owns one tile of exactly SNARKV_TILE_BASE scalars per workgroup; the
+  // direct form needs >= 16 items per (tile, key) stream for its writes to fill lines
+  const size_t lds_staged = ((size_t)3 * p.SB + 16) * 4 + (size_t)kStageScalars * kHalves * 8;
+  const bool staged = SNARKV_SCATTER_STAGED && lds_staged <= 96 * 1024 && kStageItems * kHalves <= 32;
+  while (!staged && p.tile < 65536 && (uint64_t)p.tile * kHalves * p.W < 16ull * p.nkeys) p.tile *= 2;
   p.nblk = (uint32_t)((n + p.tile - 1) / p.tile);
   p.mstride = p.nblk | 1u;
   uint64_t max_entries = (uint64_t)kHalves * (uint64_t)n * (uint64_t)p.W;
@@ -921,6 +1100,7 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
     if (v >= 1) p.gsz = (uint32_t)std::min(v, p.W);
   }
   if (((uint32_t)p.W + p.gsz - 1) / p.gsz > 8) p.gsz = ((uint32_t)p.W + 7) / 8;  // at most 8 groups (events, counters)
+  if (phases != PIP_PHASE_ALL) p.gsz = (uint32_t)p.W;
   p.krun = ctx->throughput_mode ? (uint32_t)kRunThroughput : (uint32_t)kRun;
   p.rpw = (uint32_t)(((uint64_t)kHalves * n + p.krun - 1) / p.krun) + 1;
   uint32_t max_runs = (uint32_t)p.W * p.rpw;
@@ -941,7 +1121,8 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SORT_TMP, max_entries * 8, &d_tmp));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SEG_IDS, (size_t)max_runs * 8, &d_seg_ids));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SEG_PARTIALS, (size_t)max_runs * 2 * sizeof(G1Xyzz29), &d_seg_parts));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_BUCKETS, (size_t)p.nb * sizeof(G1Xyzz29), &d_buckets));
+  if (d_grid) d_buckets = d_grid;
+  else SNARKV_TRY(ctx_reserve(ctx, SLOT_BUCKETS, (size_t)p.nb * sizeof(G1Xyzz29), &d_buckets));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_CHUNK_PARTIALS, 2 * (size_t)blocks_per_window * p.W * sizeof(G1Xyzz29), &d_wave));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SHIFTED, (size_t)p.W * sizeof(G1Xyzz29), &d_shift));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_MISC, 64, &d_misc));
@@ -952,35 +1133,49 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
     return SNARKV_ERR_LENGTH;
   }
 
-  hipStream_t st = ctx->stream;
-  bool tm = ctx->stage_timing;
+  const bool tm = ctx->stage_timing && phases == PIP_PHASE_ALL;
+  const bool tm_acc = ctx->stage_timing && phases == PIP_PHASE_ACC;  // a batch times its accumulations: ev[3] .. ev[4] .. ev[5]
   int evi = 0;
 #define STAGE_MARK()                                         \
   do {                                                       \
     if (tm) SNARKV_HIP(hipEventRecord(ctx->ev[evi++], st));  \
   } while (0)
-  if (tm && !ctx->ev_ready) {
+  if ((tm || tm_acc) && !ctx->ev_ready) {
     for (int i = 0; i <= SNARKV_PIP_STAGES; ++i) SNARKV_HIP(hipEventCreate(&ctx->ev[i]));
     ctx->ev_ready = true;
   }
   STAGE_MARK();  // 0
   size_t lds1 = (size_t)p.nkeys * 4;
-  SNARKV_HIP(hipMemsetAsync(d_M, 0, (size_t)mcount * 4, st));  // padding columns must read as zero
-  hipLaunchKernelGGL(k_prepare, dim3(p.nblk), dim3(SNARKV_TILE_THREADS), lds1, st, (const uint32_t*)d_scalars,
-                     (const uint32_t*)d_points, (G1Packed*)d_pts, (uint4*)d_glv, p, (uint32_t*)d_M);
-  STAGE_MARK();  // 1: prepare (GLV split, phi(P), to Montgomery) + digit histogram
-  hipLaunchKernelGGL(k_scan_local, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (uint32_t*)d_blocksum, mcount);
-  hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, st, (uint32_t*)d_blocksum, scan_blocks, d_total);
-  hipLaunchKernelGGL(k_scan_add, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (const uint32_t*)d_blocksum,
-                     mcount);
-  STAGE_MARK();  // 2: scan
-  hipLaunchKernelGGL(k_sort_scatter, dim3(p.nblk), dim3(SNARKV_TILE_THREADS), lds1, st, (const uint4*)d_glv, p,
-                     (const uint32_t*)d_M, (uint2*)d_tmp);
-  size_t lds2 = ((size_t)(1u << p.low_bits) + 512) * 4 + (size_t)kSortCap * 8;
-  hipLaunchKernelGGL(k_sort_level2, dim3(p.nkeys), dim3(512), lds2, st, (const uint2*)d_tmp, (const uint32_t*)d_M,
-                     (const uint32_t*)d_total, p, (uint2*)d_entries, (uint32_t*)d_counts, (uint32_t*)d_offsets);
+  if (phases & PIP_PHASE_SORT) {
+    SNARKV_HIP(hipMemsetAsync(d_M, 0, (size_t)mcount * 4, st));  // padding columns must read as zero
+    hipLaunchKernelGGL(k_prepare, dim3(p.nblk), dim3(SNARKV_TILE_THREADS), lds1, st, (const uint32_t*)d_scalars,
+                       (const uint32_t*)d_points, (G1Packed*)d_pts, (uint4*)d_glv, p, (uint32_t*)d_M);
+    STAGE_MARK();  // 1: prepare (GLV split, phi(P), to Montgomery) + digit histogram
+    hipLaunchKernelGGL(k_scan_local, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (uint32_t*)d_blocksum, mcount);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(1024), 0, st, (uint32_t*)d_blocksum, scan_blocks, d_total);
+    hipLaunchKernelGGL(k_scan_add, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (const uint32_t*)d_blocksum,
+                       mcount);
+    STAGE_MARK();  // 2: scan
+    if (staged) {
+      static std::atomic<uint64_t> attr_set{0};  // per device: more dynamic LDS than the 64 KiB default
+      const uint64_t bit = 1ull << (ctx->device & 63);
+      if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
+        SNARKV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_scatter_staged),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_set.fetch_or(bit, std::memory_order_relaxed);
+      }
+      hipLaunchKernelGGL(k_sort_scatter_staged, dim3(p.nblk), dim3(SNARKV_TILE_THREADS), lds_staged, st, (const uint4*)d_glv,
+                         p, (const uint32_t*)d_M, (uint2*)d_tmp);
+    } else {
+      hipLaunchKernelGGL(k_sort_scatter, dim3(p.nblk), dim3(SNARKV_TILE_THREADS), lds1, st, (const uint4*)d_glv, p,
+                         (const uint32_t*)d_M, (uint2*)d_tmp);
+    }
+    size_t lds2 = ((size_t)(1u << p.low_bits) + 512) * 4 + (size_t)kSortCap * 8;
+    hipLaunchKernelGGL(k_sort_level2, dim3(p.nkeys), dim3(512), lds2, st, (const uint2*)d_tmp, (const uint32_t*)d_M,
+                       (const uint32_t*)d_total, p, (uint2*)d_entries, (uint32_t*)d_counts, (uint32_t*)d_offsets);
+  }
   STAGE_MARK();  // 3: partition + level-2 sort
-  SNARKV_HIP(hipMemsetAsync(d_buckets, 0, (size_t)p.nb * sizeof(G1Xyzz29), st));
+  if (phases & PIP_PHASE_ACC) SNARKV_HIP(hipMemsetAsync(d_buckets, 0, (size_t)p.nb * sizeof(G1Xyzz29), st));
   // (Tried, both measured on MI355X and dropped: one shared stream for every k_accumulate of a device -- a software
   // pipeline across the in-flight MSMs -- and s_setprio on / off for the other kernels: the in-flight plateau moved by
   // less than the run-to-run spread either way.  SQ counters show why: k_accumulate keeps every SIMD's VALU busy
@@ -990,12 +1185,16 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   // accumulations on one stream now LOSES 15-25 % (1.50 -> 1.75-1.89 ms per MSM): 2 731 wavefronts leave a ninth of the
   // slots and the whole drain of every launch empty unless another MSM's accumulation overlaps it.)
   uint32_t* d_big_count = d_total + 4;  // one counter per window group
-  SNARKV_HIP(hipMemsetAsync(d_big_count, 0, 4 * 8, st));
+  if (phases & PIP_PHASE_ACC) SNARKV_HIP(hipMemsetAsync(d_big_count, 0, 4 * 8, st));
+  if (tm_acc) SNARKV_HIP(hipEventRecord(ctx->ev[3], st));
   // Window groups (opt-in, see p.gsz above), top first: group j = windows [j gsz, (j+1) gsz).  Its accumulation runs on the context's stream;
   // its tail -- combine, bucket reduce, the 2^(c w) shift chain (the longest for the TOP windows: c w doublings, a
   // dependency chain no lane count shortens) -- runs on a side stream under the accumulation of the groups below it.
   // Only the bottom group's tail (the shortest chains) is left exposed.
   const uint32_t ngroups = ((uint32_t)p.W + p.gsz - 1) / p.gsz;
+  // (Measured and dropped: capping k_accumulate at 12 / 10 / 9 / 8 wavefronts per CU with an unused LDS allocation, so that
+  // the other kernels of in-flight MSMs always find wave slots: 3-9 % slower the tighter the cap -- the accumulation
+  // needs its three wavefronts per SIMD more than the others need the room.)
   if (ngroups > 1) {
     SNARKV_TRY(ctx_lanes(ctx));
     if (!ctx->grp_ev_ready) {
@@ -1007,9 +1206,10 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
     const uint32_t w0 = (uint32_t)j * p.gsz, w1 = std::min<uint32_t>((uint32_t)p.W, w0 + p.gsz), wcount = w1 - w0;
     const uint32_t lanes = wcount * p.rpw;
     auto acc_kernel = p.krun == (uint32_t)kRun ? k_accumulate<kRun> : k_accumulate<kRunThroughput>;
-    hipLaunchKernelGGL(acc_kernel, dim3((lanes + 63) / 64), dim3(64), 0, st, (const uint2*)d_entries,
-                       (const uint32_t*)d_total, (const G1Packed*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
-                       (G1Xyzz29*)d_seg_parts, (const uint32_t*)d_M, p.mstride, w0 * p.SB, w1 * p.SB, p.nkeys, w0 * p.rpw);
+    if (phases & PIP_PHASE_ACC)
+      hipLaunchKernelGGL(acc_kernel, dim3((lanes + 63) / 64), dim3(64), 0, st, (const uint2*)d_entries,
+                         (const uint32_t*)d_total, (const G1Packed*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
+                         (G1Xyzz29*)d_seg_parts, (const uint32_t*)d_M, p.mstride, w0 * p.SB, w1 * p.SB, p.nkeys, w0 * p.rpw);
     hipStream_t ts = st;
     if (j > 0) {
       ts = ctx->sub[j & 1]->stream;
@@ -1017,21 +1217,25 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
       SNARKV_HIP(hipStreamWaitEvent(ts, ctx->grp_ev[j], 0));
     } else {
       STAGE_MARK();  // 4: bucket accumulate (all groups)
+      if (tm_acc) SNARKV_HIP(hipEventRecord(ctx->ev[4], st));
     }
-    hipLaunchKernelGGL(k_combine, dim3((wcount * p.B + 63) / 64), dim3(64), 0, ts, (const uint32_t*)d_counts,
-                       (const uint32_t*)d_offsets, p, (const uint2*)d_entries, (const G1Packed*)d_pts,
-                       (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets, d_big_count + j,
-                       (uint32_t*)d_big + (size_t)j * kMaxBig, (const uint32_t*)d_M, w0 * p.B, w1 * p.B);
-    // one workgroup per oversized bucket; idle workgroups exit at once
-    uint32_t big_grid = (uint32_t)(lanes / kBigSpan + 1);
-    if (big_grid > kMaxBig) big_grid = kMaxBig;
-    hipLaunchKernelGGL(k_combine_big, dim3(big_grid), dim3(256), 0, ts, (const uint32_t*)d_counts,
-                       (const uint32_t*)d_offsets, (const uint2*)d_entries, (const G1Packed*)d_pts,
-                       (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets,
-                       (const uint32_t*)(d_big_count + j), (const uint32_t*)d_big + (size_t)j * kMaxBig, p,
-                       (const uint32_t*)d_M);
+    if (phases & PIP_PHASE_ACC) {
+      hipLaunchKernelGGL(k_combine, dim3((wcount * p.B + 63) / 64), dim3(64), 0, ts, (const uint32_t*)d_counts,
+                         (const uint32_t*)d_offsets, p, (const uint2*)d_entries, (const G1Packed*)d_pts,
+                         (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets, d_big_count + j,
+                         (uint32_t*)d_big + (size_t)j * kMaxBig, (const uint32_t*)d_M, w0 * p.B, w1 * p.B);
+      // one workgroup per oversized bucket; idle workgroups exit at once
+      uint32_t big_grid = (uint32_t)(lanes / kBigSpan + 1);
+      if (big_grid > kMaxBig) big_grid = kMaxBig;
+      hipLaunchKernelGGL(k_combine_big, dim3(big_grid), dim3(256), 0, ts, (const uint32_t*)d_counts,
+                         (const uint32_t*)d_offsets, (const uint2*)d_entries, (const G1Packed*)d_pts,
+                         (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets,
+                         (const uint32_t*)(d_big_count + j), (const uint32_t*)d_big + (size_t)j * kMaxBig, p,
+                         (const uint32_t*)d_M);
+      if (tm_acc) SNARKV_HIP(hipEventRecord(ctx->ev[5], st));
+    }
     if (j == 0) STAGE_MARK();  // 5: bucket combine (the bottom group's: the exposed one)
-    if (!d_buckets_out) {
+    if (!d_buckets_out && (phases & PIP_PHASE_TAIL)) {
       PipParams pg = p;
       pg.W = (int)wcount;
       pg.w0 = p.w0 + w0;
@@ -1046,13 +1250,15 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
   }
   for (uint32_t j = 1; j < ngroups; ++j) SNARKV_HIP(hipStreamWaitEvent(st, ctx->grp_ev[8 + j], 0));
   if (d_buckets_out) {  // bucket-sharded variant: hand the (sanitised) bucket sums out and stop here
-    SNARKV_HIP(hipMemcpyAsync(d_buckets_out, d_buckets, (size_t)p.nb * sizeof(G1Xyzz29), hipMemcpyDeviceToDevice, st));
+    if (phases & PIP_PHASE_ACC)
+      SNARKV_HIP(hipMemcpyAsync(d_buckets_out, d_buckets, (size_t)p.nb * sizeof(G1Xyzz29), hipMemcpyDeviceToDevice, st));
     SNARKV_HIP(hipGetLastError());
     return SNARKV_OK;
   }
   STAGE_MARK();  // 7: window sums + 2^(cw) shift chains (all groups joined)
-  hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, st, (const G1Xyzz29*)d_shift, (uint32_t)p.W, (uint32_t*)d_out,
-                     partial_out ? 1 : 0);
+  if (phases & PIP_PHASE_TAIL)
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, st, (const G1Xyzz29*)d_shift, (uint32_t)p.W, (uint32_t*)d_out,
+                       partial_out ? 1 : 0);
   STAGE_MARK();  // 8: final sum + to_affine
 #undef STAGE_MARK
   SNARKV_HIP(hipGetLastError());
@@ -1109,6 +1315,35 @@ int launch_buckets_reduce(snarkv_ctx* ctx, const void* d_buckets, uint32_t c, ui
   hipLaunchKernelGGL(k_shift_windows, dim3(wcount), dim3(64), 0, st, (const G1Xyzz29*)d_wave, (G1Xyzz29*)d_shift, p,
                      blocks_per_window);
   hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, st, (const G1Xyzz29*)d_shift, wcount, (uint32_t*)d_partial, 1);
+  SNARKV_HIP(hipGetLastError());
+  return SNARKV_OK;
+}
+
+// The tail of `jobs` MSMs of the same geometry whose bucket grids lie end to end ([job][window][bucket]): three
+// launches for all of them (a tail is latency-bound -- 14-step folds and the 2^(c w) doubling chains -- so `jobs` of
+// them cost what one does), out[job] = the affine sum (64 B) or the projective partial.
+int launch_buckets_reduce_many(snarkv_ctx* ctx, hipStream_t st, const void* d_grids, uint32_t c, uint32_t windows,
+                               uint32_t jobs, void* d_out, bool partial_out) {
+  PipParams p;
+  memset(&p, 0, sizeof p);
+  p.c = (int)c;
+  p.W = (int)(windows * jobs);
+  p.B = 1u << (c - 1);
+  p.nb = windows * jobs * p.B;
+  p.w0 = 0;
+  p.wper = windows;
+  const uint32_t wtotal = windows * jobs;
+  uint32_t chunks_per_window = (p.B + kChunk - 1) / kChunk;
+  uint32_t blocks_per_window = (chunks_per_window + 63) / 64;
+  void *d_wave, *d_shift;
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_CHUNK_PARTIALS, 2 * (size_t)blocks_per_window * wtotal * sizeof(G1Xyzz29), &d_wave));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_SHIFTED, (size_t)wtotal * sizeof(G1Xyzz29), &d_shift));
+  hipLaunchKernelGGL(k_bucket_reduce, dim3(blocks_per_window * wtotal), dim3(64), 0, st, (const G1Xyzz29*)d_grids,
+                     (G1Xyzz29*)d_wave, p, chunks_per_window, blocks_per_window);
+  hipLaunchKernelGGL(k_shift_windows, dim3(wtotal), dim3(64), 0, st, (const G1Xyzz29*)d_wave, (G1Xyzz29*)d_shift, p,
+                     blocks_per_window);
+  hipLaunchKernelGGL(k_final, dim3(jobs), dim3(64), 0, st, (const G1Xyzz29*)d_shift, windows, (uint32_t*)d_out,
+                     partial_out ? 1 : 0);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }

@@ -13,6 +13,7 @@ python tools/pmc_traffic.py --tag $TAG --out-dir $O --log2n 24 > /dev/null
 cp $O/${TAG}_pmc_hbm_traffic*.json profiles/
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python bench.py --steps 40 --warmup 4 --no-secondary --no-cpu-baseline > $O/${TAG}_bench_40steps.json 2>/dev/null
+python bench.py --inflight 4 --no-secondary --no-cpu-baseline > $O/${TAG}_bench_4inflight.json 2>/dev/null   # four single calls in flight (the earlier submission)
 python bench.py --log2n 22 --inflight 1 --steps 10 --warmup 2 --no-secondary --cpu-sample-log2 18 > $O/${TAG}_bench_2p22.json 2>/dev/null
 python bench.py --log2n 24 --inflight 1 --steps 6 --warmup 2 --no-secondary --cpu-sample-log2 18 > $O/${TAG}_bench_2p24.json 2>/dev/null
 cd /tmp
@@ -24,8 +25,9 @@ stats() {  # name, bench args...
   if [ -n "$db" ]; then python $R/tools/rocpd_top_kernels.py $db $O/${TAG}_rocprofv3_kernel_stats_$name.csv; else
     f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_rocprofv3_kernel_stats_$name.csv; fi
 }
-stats 4inflight --steps 20 --warmup 3 --no-cpu-baseline --no-secondary
-stats sequential --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --inflight 1
+stats batch --steps 20 --warmup 5 --no-cpu-baseline --no-secondary
+stats 4inflight --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --inflight 4
+stats sequential --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --inflight 1
 stats with_secondary --steps 4 --warmup 1 --no-cpu-baseline
 stats 2p24_single --log2n 24 --inflight 1 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary
 cd $R
