@@ -68,10 +68,27 @@ namespace snarkv {
 #define SNARKV_KCHUNK 8
 #endif
 #ifndef SNARKV_TILE_THREADS
-#define SNARKV_TILE_THREADS 512  // tile workgroups of k_prepare / k_sort_scatter (256 left the chip at 1 wave/SIMD)
+// Tile workgroups of k_prepare / k_sort_scatter*: 256 lanes on 2 048 scalars, i.e. ONE wavefront per SIMD, and registers
+// capped so that one fits beside three resident k_accumulate wavefronts (3 x 136 VGPRs leave 104 per SIMD): with several
+// MSMs in flight the sorts of the next MSM then run UNDER the accumulation instead of waiting for its wavefronts to
+// retire.  Measured against 512 lanes on 4 096 scalars (two wavefronts per SIMD, 120 VGPRs): batch of 40 MSMs -1.5 to
+// -3.4 %, one MSM alone level (profiles/r02_ab_coresidency.txt).
+#define SNARKV_TILE_THREADS 256
 #endif
 #ifndef SNARKV_SCATTER_WINDOW_MAJOR
 #define SNARKV_SCATTER_WINDOW_MAJOR 1  // k_sort_scatter walks its tile window by window (see there)
+#endif
+#ifndef SNARKV_SCATTER_ATTR
+#define SNARKV_SCATTER_ATTR __attribute__((amdgpu_waves_per_eu(5)))  // k_sort_scatter_staged: 96 VGPRs (120 uncapped, no spills either way)
+#endif
+#ifndef SNARKV_L2_THREADS
+#define SNARKV_L2_THREADS 512  // lanes of a k_sort_level2 workgroup
+#endif
+#ifndef SNARKV_LEVEL2_ATTR
+#define SNARKV_LEVEL2_ATTR
+#endif
+#ifndef SNARKV_PREP_THREADS
+#define SNARKV_PREP_THREADS SNARKV_TILE_THREADS  // lanes of a k_prepare workgroup (one tile)
 #endif
 #ifndef SNARKV_SCATTER_STAGED
 #define SNARKV_SCATTER_STAGED 1  // k_sort_scatter_staged (LDS-staged, coalesced write-out) instead of k_sort_scatter
@@ -80,7 +97,7 @@ namespace snarkv {
 #define SNARKV_XCD_TILES 1  // tiles -> workgroups so that an XCD owns a contiguous tile range (xcd_tile)
 #endif
 #ifndef SNARKV_TILE_BASE
-#define SNARKV_TILE_BASE 4096  // smallest tile (scalars per k_prepare / k_sort_scatter workgroup)
+#define SNARKV_TILE_BASE 2048  // smallest tile (scalars per k_prepare / k_sort_scatter workgroup)
 #endif
 #ifndef SNARKV_ACC_WAVES
 #define SNARKV_ACC_WAVES 3
@@ -235,7 +252,7 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nblk) {
 // the (window, high digit bits) keys -> column `blockIdx` of the matrix M.
 // The identity (64 zero bytes) contributes nothing: its half-scalars are
 // stored as zero, so the sort never has to look at the points again.
-__global__ void __launch_bounds__(SNARKV_TILE_THREADS)
+__global__ void __launch_bounds__(SNARKV_PREP_THREADS)
     k_prepare(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points,
               G1Packed* __restrict__ pts, uint4* __restrict__ glv, PipParams p, uint32_t* __restrict__ M) {
   SNARKV_RAISE_PRIO();
@@ -352,7 +369,7 @@ __global__ void __launch_bounds__(SNARKV_TILE_THREADS)
 constexpr uint32_t kStageScalars = SNARKV_TILE_BASE;                    // scalars per staged workgroup = the tile
 constexpr uint32_t kStageItems = kStageScalars / SNARKV_TILE_THREADS;   // ... per lane
 static_assert(kStageScalars % SNARKV_TILE_THREADS == 0, "a staged tile gives every lane the same number of scalars");
-__global__ void __launch_bounds__(SNARKV_TILE_THREADS)
+__global__ void __launch_bounds__(SNARKV_TILE_THREADS) SNARKV_SCATTER_ATTR
     k_sort_scatter_staged(const uint4* __restrict__ glv, PipParams p, const uint32_t* __restrict__ M,
                           uint2* __restrict__ tmp) {
   SNARKV_RAISE_PRIO();
@@ -508,16 +525,16 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ data, c
 // scatter to HBM costs a 128-byte read-modify-write once the working set
 // outgrows L2/Infinity Cache.  Larger slices (skewed scalars) take the
 // two-pass global path.
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(SNARKV_L2_THREADS) SNARKV_LEVEL2_ATTR
     k_sort_level2(const uint2* __restrict__ tmp, const uint32_t* __restrict__ M, const uint32_t* __restrict__ total_ptr,
                   PipParams p, uint2* __restrict__ entries, uint32_t* __restrict__ counts,
                   uint32_t* __restrict__ offsets) {
   SNARKV_RAISE_PRIO();
-  extern __shared__ uint32_t lds[];  // nbins counters | 512 scan words | kSortCap items (uint2)
+  extern __shared__ uint32_t lds[];  // nbins counters | one scan word per lane | kSortCap items (uint2)
   const uint32_t nbins = 1u << p.low_bits;
   uint32_t* hist = lds;
   uint32_t* scan = lds + nbins;
-  uint2* stage = reinterpret_cast<uint2*>(lds + nbins + 512);
+  uint2* stage = reinterpret_cast<uint2*>(lds + nbins + SNARKV_L2_THREADS);
   const uint32_t T = blockDim.x;
   uint32_t key = blockIdx.x;
   uint32_t begin = M[(size_t)key * p.mstride];
@@ -527,7 +544,8 @@ __global__ void __launch_bounds__(512)
   for (uint32_t k = threadIdx.x; k < nbins; k += T) hist[k] = 0;
   __syncthreads();
   const uint32_t low_mask = nbins - 1;
-  constexpr int kPer = kSortCap / 512;  // items a lane keeps in registers on the fast path
+  constexpr int kPer = kSortCap / SNARKV_L2_THREADS;  // items a lane keeps in registers on the fast path
+  static_assert(kSortCap % SNARKV_L2_THREADS == 0, "kSortCap items spread evenly over the lanes");
   uint2 mine[kPer];
   if (fast) {
 #pragma unroll
@@ -1148,7 +1166,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   size_t lds1 = (size_t)p.nkeys * 4;
   if (phases & PIP_PHASE_SORT) {
     SNARKV_HIP(hipMemsetAsync(d_M, 0, (size_t)mcount * 4, st));  // padding columns must read as zero
-    hipLaunchKernelGGL(k_prepare, dim3(p.nblk), dim3(SNARKV_TILE_THREADS), lds1, st, (const uint32_t*)d_scalars,
+    hipLaunchKernelGGL(k_prepare, dim3(p.nblk), dim3(SNARKV_PREP_THREADS), lds1, st, (const uint32_t*)d_scalars,
                        (const uint32_t*)d_points, (G1Packed*)d_pts, (uint4*)d_glv, p, (uint32_t*)d_M);
     STAGE_MARK();  // 1: prepare (GLV split, phi(P), to Montgomery) + digit histogram
     hipLaunchKernelGGL(k_scan_local, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (uint32_t*)d_blocksum, mcount);
@@ -1170,8 +1188,8 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
       hipLaunchKernelGGL(k_sort_scatter, dim3(p.nblk), dim3(SNARKV_TILE_THREADS), lds1, st, (const uint4*)d_glv, p,
                          (const uint32_t*)d_M, (uint2*)d_tmp);
     }
-    size_t lds2 = ((size_t)(1u << p.low_bits) + 512) * 4 + (size_t)kSortCap * 8;
-    hipLaunchKernelGGL(k_sort_level2, dim3(p.nkeys), dim3(512), lds2, st, (const uint2*)d_tmp, (const uint32_t*)d_M,
+    size_t lds2 = ((size_t)(1u << p.low_bits) + SNARKV_L2_THREADS) * 4 + (size_t)kSortCap * 8;
+    hipLaunchKernelGGL(k_sort_level2, dim3(p.nkeys), dim3(SNARKV_L2_THREADS), lds2, st, (const uint2*)d_tmp, (const uint32_t*)d_M,
                        (const uint32_t*)d_total, p, (uint2*)d_entries, (uint32_t*)d_counts, (uint32_t*)d_offsets);
   }
   STAGE_MARK();  // 3: partition + level-2 sort
