@@ -404,8 +404,7 @@ def main():
                 dist.all_gather_into_tensor(b_gath, b_part)
                 pb = sv.G1_PARTIAL_BYTES
                 g = b_gath.view(world, args.steps, pb).transpose(0, 1).contiguous()  # [job][rank][144]
-                for i in range(args.steps):
-                    ctx.fold_partials_dev(g.data_ptr() + i * world * pb, world, b_out.data_ptr() + 64 * i)
+                ctx.fold_partials_many_dev(g.data_ptr(), world, args.steps, b_out.data_ptr())  # K folds, one launch
                 run_batch.keep = g
 
     def step():
@@ -542,7 +541,9 @@ def main():
                 "points_per_gpu": n,
                 "points_per_kernel_launch": launch_n,
                 "window_bits": args.window_bits or "default",
-                "parallelism": "point-sharded x%d, all-gather of 144 B partials + local fold" % world,
+                "parallelism": ("point-sharded x%d: per batch ONE all-gather of %d x 144 B partials per rank, then the %d folds in one "
+                                "launch" % (world, args.steps, args.steps)) if batch else
+                               "point-sharded x%d, all-gather of 144 B partials + local fold" % world,
                 "submission": ("the %d timed steps are ONE snarkv_g1_msm_pippenger_many_dev call (the library pipelines the "
                                "MSMs: sorts on high-priority streams, accumulations back to back, one batched tail)" % args.steps)
                               if batch else "%d single-MSM calls kept in flight, one context + stream each" % inflight,

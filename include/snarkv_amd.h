@@ -121,6 +121,9 @@ int snarkv_g1_msm_pippenger_many_partial_dev(snarkv_ctx* ctx, size_t count, cons
 int snarkv_g1_msm_pippenger_partial_dev(snarkv_ctx* ctx, const void* d_scalars32, const void* d_points64,
                                         size_t n, int window_bits, void* d_partial);
 int snarkv_g1_fold_partials_dev(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64);
+/* `jobs` folds in one launch (the multi-GPU form of the batch entry point): d_partials = [job][count] partials --
+ * the all-gathered [rank][job] array transposed --, d_out64s = [job] affine points                                   */
+int snarkv_g1_fold_partials_many_dev(snarkv_ctx* ctx, const void* d_partials, size_t count, size_t jobs, void* d_out64s);
 
 /* ---- A8: KzgAs::decide / decide_all ------------------------------------ *
  * replaces snark-verifier/src/pcs/kzg/decider.rs:70-93.  The deciding key

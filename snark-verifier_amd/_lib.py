@@ -58,6 +58,7 @@ _SIGNATURES = {
     "snarkv_g1_msm_batched_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "snarkv_g1_msm_pippenger_partial_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "snarkv_g1_fold_partials_dev": (_int, [_vp, _vp, _sz, _vp]),
+    "snarkv_g1_fold_partials_many_dev": (_int, [_vp, _vp, _sz, _sz, _vp]),
     "snarkv_dk_create": (_int, [_vp, _cp, _cp, _cp, _u32, _pp]),
     "snarkv_dk_destroy": (None, [_vp]),
     "snarkv_kzg_decide": (_int, [_vp, _vp, _cp, _u32]),
@@ -426,6 +427,10 @@ class Context:
 
     def fold_partials_dev(self, d_partials, count, d_out):
         _check(self._lib.snarkv_g1_fold_partials_dev(self._h, d_partials, count, d_out))
+
+    def fold_partials_many_dev(self, d_partials, count, jobs, d_out):
+        """`jobs` folds of `count` partials each ([job][count] layout) in one launch"""
+        _check(self._lib.snarkv_g1_fold_partials_many_dev(self._h, d_partials, count, jobs, d_out))
 
     def msm_batched_dev(self, d_scalars, d_points, d_offsets, n_msm, n_terms, d_out):
         _check(self._lib.snarkv_g1_msm_batched_dev(self._h, d_scalars, d_points, d_offsets, n_msm, n_terms, d_out))

@@ -430,6 +430,13 @@ int snarkv_g1_fold_partials_dev(snarkv_ctx* ctx, const void* d_partials, size_t 
   return launch_fold_partials(ctx, d_partials, count, d_out64);
 }
 
+int snarkv_g1_fold_partials_many_dev(snarkv_ctx* ctx, const void* d_partials, size_t count, size_t jobs, void* d_out64s) {
+  if (!ctx || !d_partials || !d_out64s) return SNARKV_ERR_ARG;
+  if (count == 0 || jobs == 0) return SNARKV_ERR_EMPTY;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  return launch_fold_partials_many(ctx, d_partials, count, jobs, d_out64s);
+}
+
 int snarkv_g1_msm_bucket_geometry(size_t n_total, int window_bits, uint32_t* c, uint32_t* windows,
                                   uint32_t* buckets_per_window) {
   if (!c || !windows || !buckets_per_window) return SNARKV_ERR_ARG;

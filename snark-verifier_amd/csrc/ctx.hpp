@@ -141,6 +141,7 @@ int pip_geometry(size_t n_total, int window_bits, uint32_t* c, uint32_t* windows
 int launch_buckets_add(snarkv_ctx* ctx, void* d_dst, const void* d_src, size_t count);
 int launch_buckets_reduce(snarkv_ctx* ctx, const void* d_buckets, uint32_t c, uint32_t w0, uint32_t wcount, void* d_partial);
 int launch_fold_partials(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64, bool partial_out = false);
+int launch_fold_partials_many(snarkv_ctx* ctx, const void* d_partials, size_t count, size_t jobs, void* d_out64s);
 int launch_validate(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int* bad_host);
 int launch_g2_prepare(snarkv_ctx* ctx, const void* d_g2x2_256, void* d_prep);
 int launch_decide(snarkv_ctx* ctx, const void* d_prep, const void* d_accs, size_t m, void* d_ok, void* d_gt);

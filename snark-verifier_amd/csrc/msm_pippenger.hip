@@ -1034,6 +1034,14 @@ __global__ void __launch_bounds__(64)
   }
 }
 
+// `jobs` folds in one launch: d_partials = [job][count] partials, d_out64s = [job] affine points
+int launch_fold_partials_many(snarkv_ctx* ctx, const void* d_partials, size_t count, size_t jobs, void* d_out64s) {
+  hipLaunchKernelGGL(k_final, dim3((uint32_t)jobs), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_partials, (uint32_t)count,
+                     (uint32_t*)d_out64s, 0);
+  SNARKV_HIP(hipGetLastError());
+  return SNARKV_OK;
+}
+
 int launch_fold_partials(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64, bool partial_out) {
   hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_partials, (uint32_t)count,
                      (uint32_t*)d_out64, partial_out ? 1 : 0);

@@ -98,6 +98,14 @@ def test_partial_form_folds_to_the_same_point(gpu_ctx):
         gpu_ctx.sync()
         assert bytes(out.cpu().numpy()) == C.msm_pippenger(s, p, 8)
     assert len(parts[0][0]) == sv.G1_PARTIAL_BYTES
+    # all the folds in one launch: [job][rank] layout
+    buf = torch.frombuffer(bytearray(b"".join(parts[0][i] + parts[1][i] for i in range(3))), dtype=torch.uint8).cuda()
+    out = torch.zeros(64 * 3, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.fold_partials_many_dev(buf.data_ptr(), 2, 3, out.data_ptr())
+    gpu_ctx.sync()
+    got = bytes(out.cpu().numpy())
+    assert [got[64 * i:64 * i + 64] for i in range(3)] == [C.msm_pippenger(s, p, 8) for s, p in whole]
 
 
 def test_window_bits_and_fallbacks(gpu_ctx, monkeypatch):
