@@ -1049,13 +1049,25 @@ int launch_fold_partials(snarkv_ctx* ctx, const void* d_partials, size_t count, 
   return SNARKV_OK;
 }
 
+// Window size of an n-point MSM: the c that minimises  entries + buckets  in field products -- kHalves n W(c) mixed
+// additions of ~10 products, W(c) 2^(c-1) buckets at ~30 (two full additions each in the reduce, whose chains are
+// latency- rather than throughput-bound) -- among the sizes whose TOP window is populated: with magnitudes of
+// kDigitBits - 1 bits the top window holds t = kDigitBits - 1 - (W - 1) c of them, and a narrow one (t < c - 3) piles
+// its whole window's entries into a handful of level-1 keys, each sorted by ONE workgroup (2^19 points at c = 15: t = 7,
+// partition + sort 1.4 ms instead of 0.12).  For GLV's 127-bit halves that leaves c = 8, 10, 13, 16.  Measured single-MSM
+// latency, 2^16 .. 2^19 points, round-1 rule (c = log2 n - 4, windows balanced) against this: 1.29 / 1.19 / 1.49 / 3.11 ms
+// -> 1.15 / 1.19 / 1.36 / 1.67 ms (profiles/r02_sweep_window_bits.txt).
 static int default_window_bits(size_t n) {
-  int lg = 0;
-  while (((size_t)1 << (lg + 1)) <= n) ++lg;
-  int c = lg - 4;
-  if (c < 2) c = 2;
-  if (c > 16) c = 16;  // beyond 2^20 points the bucket count, not n, sets the reduce cost
-  return c;
+  int best = 2;
+  double best_cost = 0;
+  for (int c = 2; c <= 22; ++c) {
+    const int W = (kDigitBits + c - 1) / c;
+    const int top = kDigitBits - 1 - (W - 1) * c;
+    double cost = (double)kHalves * (double)n * W * 10.0 + (double)W * (double)(1u << (c - 1)) * 30.0;
+    if (top < c - 3) cost *= 1.6;
+    if (c == 2 || cost < best_cost) best = c, best_cost = cost;
+  }
+  return best;
 }
 
 // Smallest window size with the same number of windows: keeps the TOP window
@@ -1064,6 +1076,20 @@ static int default_window_bits(size_t n) {
 static int balance_window_bits(int c) {
   int W = (kDigitBits + c - 1) / c;
   return (kDigitBits + W - 1) / W;
+}
+
+// Entries per k_accumulate lane for ONE MSM at a time.  A lane is a serial chain (~5 us per entry when the SIMD is shared
+// three ways), so below ~2^20 points 64-entry runs leave the machine to a few hundred wavefronts that each run for
+// 0.33 ms whatever n is (measured: k_accumulate 0.33 ms at 2^16 AND 2^17 points).  Shorter runs = more lanes, at the price
+// of more head / tail partials for k_combine: the shortest of 16 / 32 / 64 that keeps the launch within ~1.5 rounds of
+// the 3 072 wave slots, and 32 rather than 16 when even 16 would not fill two thirds of them.  Measured single-MSM
+// latency at 2^16 / 2^17 / 2^18 / 2^19 points: 1.15 / 1.19 / 1.35 / 1.66 -> 1.03 / 1.13 / 1.14 / 1.46 ms
+// (profiles/r02_sweep_run_length.txt).  With several MSMs in flight (hint, batch) the long runs stay.
+static uint32_t latency_run_length(uint64_t entries) {
+  auto waves = [&](uint64_t run) { return (entries + 64 * run - 1) / (64 * run); };
+  if (waves(16) <= 4608) return waves(16) >= 2048 ? 16u : 32u;
+  if (waves(32) <= 4608) return 32u;
+  return (uint32_t)kRun;
 }
 
 int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
@@ -1127,7 +1153,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   }
   if (((uint32_t)p.W + p.gsz - 1) / p.gsz > 8) p.gsz = ((uint32_t)p.W + 7) / 8;  // at most 8 groups (events, counters)
   if (phases != PIP_PHASE_ALL) p.gsz = (uint32_t)p.W;
-  p.krun = ctx->throughput_mode ? (uint32_t)kRunThroughput : (uint32_t)kRun;
+  p.krun = ctx->throughput_mode ? (uint32_t)kRunThroughput : latency_run_length((uint64_t)kHalves * n * (uint64_t)p.W);
   p.rpw = (uint32_t)(((uint64_t)kHalves * n + p.krun - 1) / p.krun) + 1;
   uint32_t max_runs = (uint32_t)p.W * p.rpw;
   uint32_t mcount = p.nkeys * p.mstride;
@@ -1231,7 +1257,8 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   for (int j = (int)ngroups - 1; j >= 0; --j) {
     const uint32_t w0 = (uint32_t)j * p.gsz, w1 = std::min<uint32_t>((uint32_t)p.W, w0 + p.gsz), wcount = w1 - w0;
     const uint32_t lanes = wcount * p.rpw;
-    auto acc_kernel = p.krun == (uint32_t)kRun ? k_accumulate<kRun> : k_accumulate<kRunThroughput>;
+    auto acc_kernel = p.krun == 16u ? k_accumulate<16> : p.krun == 32u ? k_accumulate<32>
+                      : p.krun == (uint32_t)kRun ? k_accumulate<kRun> : k_accumulate<kRunThroughput>;
     if (phases & PIP_PHASE_ACC)
       hipLaunchKernelGGL(acc_kernel, dim3((lanes + 63) / 64), dim3(64), 0, st, (const uint2*)d_entries,
                          (const uint32_t*)d_total, (const G1Packed*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,

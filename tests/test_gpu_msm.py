@@ -95,6 +95,23 @@ def test_pippenger_2p16_vs_c_oracle(gpu_ctx):
     assert gpu_ctx.msm_pippenger(s, p) == exp
 
 
+@pytest.mark.parametrize("n", [(1 << 17) + 3, 1 << 18, (1 << 19) - 5])
+def test_pippenger_mid_sizes_vs_c_oracle(gpu_ctx, n):
+    """the sizes where the default window size (13 -> 16) and the single-MSM run length (32 / 16 / 16 / 32 / 64 entries per
+    lane at 2^16 .. 2^20 points) change: bytes ≡ C oracle, with and without the throughput hint (96-entry runs)"""
+    import os
+
+    import snark_verifier_amd as sv
+
+    s, p = C.sample_scalars(0x5EED0001 + n, n), C.sample_points(0x5EED0002 + n, n)
+    exp = C.msm_pippenger(s, p, os.cpu_count() or 1)
+    assert gpu_ctx.msm_pippenger(s, p) == exp
+    ctx = sv.Context(0)
+    ctx.set_throughput_hint(True)
+    assert ctx.msm_pippenger(s, p) == exp
+    ctx.close()
+
+
 def test_pippenger_skewed_scalars(gpu_ctx):
     """Non-uniform scalar distributions: the fixed-run accumulate must stay
     correct when single buckets span many runs."""
