@@ -1131,7 +1131,8 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   // the staged partition (k_sort_scatter_staged) owns one tile of exactly SNARKV_TILE_BASE scalars per workgroup; the
   // direct form needs >= 16 items per (tile, key) stream for its writes to fill lines
   const size_t lds_staged = ((size_t)3 * p.SB + 16) * 4 + (size_t)kStageScalars * kHalves * 8;
-  const bool staged = SNARKV_SCATTER_STAGED && lds_staged <= 96 * 1024 && kStageItems * kHalves <= 32;
+  const char* direct = getenv("SNARKV_SCATTER_DIRECT");  // test / comparison knob: the direct partition kernel
+  const bool staged = SNARKV_SCATTER_STAGED && lds_staged <= 96 * 1024 && kStageItems * kHalves <= 32 && !(direct && atoi(direct));
   while (!staged && p.tile < 65536 && (uint64_t)p.tile * kHalves * p.W < 16ull * p.nkeys) p.tile *= 2;
   p.nblk = (uint32_t)((n + p.tile - 1) / p.tile);
   p.mstride = p.nblk | 1u;
