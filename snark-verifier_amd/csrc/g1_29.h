@@ -228,6 +228,42 @@ SNARKV_HD G1Xyzz29 jac29_to_xyzz(const Fq29& x, const Fq29& y, const Fq29& z) {
   return r;
 }
 
+#if defined(__HIPCC__)
+// One Jacobian doubling (dbl-2009-l, a = 0) of a point held UNIFORMLY by the four lanes of an aligned quad (q = lane & 3),
+// its 7 products spread over 3 lanes in 3 dependent levels  { X^2, Y^2, Y Z } -> { B^2, (X+B)^2, (3A)^2 } ->
+// { E (D - X3) }  and exchanged by quad-broadcast DPP.  A doubling chain is one wavefront's critical path (a lone
+// wavefront issues one VALU instruction per ~4.6 cycles whatever its ILP), so depth 3 instead of 7 products per doubling
+// is what counts: the 2^(c w) shift chains of the Pippenger tail and the chunk-base chains of the segmented small MSMs.
+// Same dataflow and carry bounds as jac29_double.
+template <int CTRL>
+__device__ __forceinline__ Fq29 fq29_dpp(const Fq29& a) {
+  Fq29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.v[i] = __builtin_amdgcn_update_dpp(0, a.v[i], CTRL, 0xF, 0xF, true);
+  return r;
+}
+__device__ __forceinline__ Fq29 fq29_sel(bool c, const Fq29& a, const Fq29& b) {
+  Fq29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+__device__ __forceinline__ void jac29_double_quad(Fq29& x, Fq29& y, Fq29& z, uint32_t q) {
+  Fq29 p1 = fq29_mul(fq29_sel(q == 0, x, y), fq29_sel(q == 0, x, fq29_sel(q == 1, y, z)));
+  Fq29 a = fq29_dpp<0x00>(p1), b = fq29_dpp<0x55>(p1), yz = fq29_dpp<0xAA>(p1);  // quad_perm broadcasts of lane 0 / 1 / 2
+  Fq29 xb = fq29_norm(fq29_add(x, b));
+  Fq29 e = fq29_norm(fq29_add(fq29_dbl(a), a));  // E = 3A
+  Fq29 p2 = fq29_sqr(fq29_sel(q == 0, b, fq29_sel(q == 1, xb, e)));
+  Fq29 c = fq29_dpp<0x00>(p2), xb2 = fq29_dpp<0x55>(p2), f = fq29_dpp<0xAA>(p2);
+  Fq29 d = fq29_norm(fq29_dbl(fq29_sub(fq29_sub(xb2, a), c)));  // D = 2((X+B)^2 - A - C)
+  Fq29 x3 = fq29_norm(fq29_sub(f, fq29_dbl(d)));                // F - 2D
+  Fq29 c8 = fq29_dbl(fq29_norm(fq29_dbl(fq29_dbl(c))));         // 8C
+  y = fq29_norm(fq29_sub(fq29_mul(e, fq29_sub(d, x3)), c8));    // E(D - X3) - 8C
+  z = fq29_norm(fq29_dbl(yz));                                  // 2YZ
+  x = x3;
+}
+#endif
+
 SNARKV_HD G1Xyzz29 xyzz29_double_n(const G1Xyzz29& p, int n) {
   if (n <= 0) return p;
   Fq29 x = fq29_mul(p.x, p.zz);

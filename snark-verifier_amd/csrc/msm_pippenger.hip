@@ -918,46 +918,14 @@ __global__ void __launch_bounds__(64)
 }
 
 // --------------------------------------------------------------- P8
-// 2^n * P, P uniform over each aligned 4-lane group, with the 7 products of a
-// Jacobian doubling (dbl-2009-l, a = 0) spread over 3 lanes in 3 dependent
-// levels  { X^2, Y^2, Y Z } -> { B^2, (X+B)^2, (3A)^2 } -> { E (D - X3) }  and
-// exchanged by quad-broadcast DPP: the chain is one wavefront's critical path
-// (a lone wavefront issues one VALU instruction per ~4.6 cycles whatever its
-// ILP), so depth 3 instead of 7 products per doubling is what counts.  Same
-// dataflow and carry bounds as jac29_double (g1_29.h).
-template <int CTRL>
-__device__ __forceinline__ Fq29 fq29_dpp(const Fq29& a) {
-  Fq29 r;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) r.v[i] = __builtin_amdgcn_update_dpp(0, a.v[i], CTRL, 0xF, 0xF, true);
-  return r;
-}
-__device__ __forceinline__ Fq29 fq29_sel(bool c, const Fq29& a, const Fq29& b) {
-  Fq29 r;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) r.v[i] = c ? a.v[i] : b.v[i];
-  return r;
-}
+// 2^n * P, P uniform over each aligned 4-lane group: the quad-cooperative Jacobian doubling of g1_29.h
 __device__ __forceinline__ G1Xyzz29 xyzz29_double_n_quad(const G1Xyzz29& p, int n) {
   if (n <= 0) return p;
   const uint32_t q = threadIdx.x & 3u;
   Fq29 x = fq29_mul(p.x, p.zz);
   Fq29 y = fq29_mul(fq29_norm(p.y), p.zzz);
   Fq29 z = p.zz;
-  for (int k = 0; k < n; ++k) {
-    Fq29 p1 = fq29_mul(fq29_sel(q == 0, x, y), fq29_sel(q == 0, x, fq29_sel(q == 1, y, z)));
-    Fq29 a = fq29_dpp<0x00>(p1), b = fq29_dpp<0x55>(p1), yz = fq29_dpp<0xAA>(p1);  // quad_perm broadcasts of lane 0 / 1 / 2
-    Fq29 xb = fq29_norm(fq29_add(x, b));
-    Fq29 e = fq29_norm(fq29_add(fq29_dbl(a), a));  // E = 3A
-    Fq29 p2 = fq29_sqr(fq29_sel(q == 0, b, fq29_sel(q == 1, xb, e)));
-    Fq29 c = fq29_dpp<0x00>(p2), xb2 = fq29_dpp<0x55>(p2), f = fq29_dpp<0xAA>(p2);
-    Fq29 d = fq29_norm(fq29_dbl(fq29_sub(fq29_sub(xb2, a), c)));  // D = 2((X+B)^2 - A - C)
-    Fq29 x3 = fq29_norm(fq29_sub(f, fq29_dbl(d)));                // F - 2D
-    Fq29 c8 = fq29_dbl(fq29_norm(fq29_dbl(fq29_dbl(c))));         // 8C
-    y = fq29_norm(fq29_sub(fq29_mul(e, fq29_sub(d, x3)), c8));    // E(D - X3) - 8C
-    z = fq29_norm(fq29_dbl(yz));                                  // 2YZ
-    x = x3;
-  }
+  for (int k = 0; k < n; ++k) jac29_double_quad(x, y, z, q);
   return jac29_to_xyzz(x, y, z);
 }
 

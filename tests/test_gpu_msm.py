@@ -145,6 +145,25 @@ def test_pippenger_window_sizes(gpu_ctx):
         assert bytes(out.cpu().numpy()) == exp, c
 
 
+@pytest.mark.parametrize("quad", ["0", "1"])
+def test_chunk_base_chain_one_lane_and_four_lanes(gpu_ctx, golden_msm, quad, monkeypatch):
+    """the chunk-base doubling chain of the segmented kernel, one lane per (term, half) or a quad of lanes
+    (jac29_double_quad): same bytes, every chunking, identity / zero-scalar / repeated-point terms included"""
+    monkeypatch.setenv("SNARKV_NAIVE_QUAD", quad)
+    n = 300
+    s, p = bytearray(C.sample_scalars(51, n)), bytearray(C.sample_points(52, n))
+    p[64 * 7:64 * 8] = bytes(64)            # an identity base
+    s[32 * 9:32 * 10] = bytes(32)           # a zero scalar
+    p[64 * 11:64 * 12] = p[64 * 10:64 * 11]  # a repeated base
+    s, p = bytes(s), bytes(p)
+    offs = [0, 1, 22, 25, 150, n]
+    exp = C.msm_batched(s, p, offs)
+    for chunks in ("2", "4", "8", "16"):
+        monkeypatch.setenv("SNARKV_NAIVE_CHUNKS", chunks)
+        assert gpu_ctx.msm_batched(s, p, offs) == exp, chunks
+        assert gpu_ctx.msm_naive(s, p) == C.msm_pippenger(s, p, 2), chunks
+
+
 def test_direct_partition_kernel_gives_the_same_bytes(gpu_ctx, monkeypatch):
     """`k_sort_scatter` (8-byte stores straight to HBM, tiles grown until a (tile, key) run fills a line) is the fall-back
     of the LDS-staged partition for geometries whose counters do not fit; SNARKV_SCATTER_DIRECT=1 forces it."""
