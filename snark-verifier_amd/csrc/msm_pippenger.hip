@@ -373,12 +373,12 @@ __global__ void __launch_bounds__(SNARKV_TILE_THREADS) SNARKV_SCATTER_ATTR
     k_sort_scatter_staged(const uint4* __restrict__ glv, PipParams p, const uint32_t* __restrict__ M,
                           uint2* __restrict__ tmp) {
   SNARKV_RAISE_PRIO();
-  extern __shared__ uint32_t lds[];  // gbase[SB] | cnt[SB] | off[SB] | wsum[16] | stage[kStageScalars * kHalves] (uint2)
+  extern __shared__ uint32_t lds[];  // gbase[SB] | cnt[SB] | off[SB] | wsum[16] | (pad) | stage[kStageScalars * kHalves] (uint2)
   uint32_t* gbase = lds;
   uint32_t* cnt = lds + p.SB;
   uint32_t* off = lds + 2 * p.SB;
   uint32_t* wsum = lds + 3 * p.SB;
-  uint2* stage = reinterpret_cast<uint2*>(lds + 3 * p.SB + 16);
+  uint2* stage = reinterpret_cast<uint2*>(lds + 3 * p.SB + 16 + (p.SB & 1u));  // 8-byte aligned (SB = 1 for tiny MSMs)
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t tile = xcd_tile(blockIdx.x, p.nblk);
   const uint32_t lo = tile * kStageScalars;
@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(SNARKV_L2_THREADS) SNARKV_LEVEL2_ATTR
   const uint32_t nbins = 1u << p.low_bits;
   uint32_t* hist = lds;
   uint32_t* scan = lds + nbins;
-  uint2* stage = reinterpret_cast<uint2*>(lds + nbins + SNARKV_L2_THREADS);
+  uint2* stage = reinterpret_cast<uint2*>(lds + nbins + SNARKV_L2_THREADS + (nbins & 1u));  // 8-byte aligned (one bin for tiny windows)
   const uint32_t T = blockDim.x;
   uint32_t key = blockIdx.x;
   uint32_t begin = M[(size_t)key * p.mstride];
@@ -1098,7 +1098,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   p.tile = SNARKV_TILE_BASE;
   // the staged partition (k_sort_scatter_staged) owns one tile of exactly SNARKV_TILE_BASE scalars per workgroup; the
   // direct form needs >= 16 items per (tile, key) stream for its writes to fill lines
-  const size_t lds_staged = ((size_t)3 * p.SB + 16) * 4 + (size_t)kStageScalars * kHalves * 8;
+  const size_t lds_staged = ((size_t)3 * p.SB + 16 + (p.SB & 1u)) * 4 + (size_t)kStageScalars * kHalves * 8;
   const char* direct = getenv("SNARKV_SCATTER_DIRECT");  // test / comparison knob: the direct partition kernel
   const bool staged = SNARKV_SCATTER_STAGED && lds_staged <= 96 * 1024 && kStageItems * kHalves <= 32 && !(direct && atoi(direct));
   while (!staged && p.tile < 65536 && (uint64_t)p.tile * kHalves * p.W < 16ull * p.nkeys) p.tile *= 2;
@@ -1191,7 +1191,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
       hipLaunchKernelGGL(k_sort_scatter, dim3(p.nblk), dim3(SNARKV_TILE_THREADS), lds1, st, (const uint4*)d_glv, p,
                          (const uint32_t*)d_M, (uint2*)d_tmp);
     }
-    size_t lds2 = ((size_t)(1u << p.low_bits) + SNARKV_L2_THREADS) * 4 + (size_t)kSortCap * 8;
+    size_t lds2 = ((size_t)(1u << p.low_bits) + SNARKV_L2_THREADS + 1) * 4 + (size_t)kSortCap * 8;
     hipLaunchKernelGGL(k_sort_level2, dim3(p.nkeys), dim3(SNARKV_L2_THREADS), lds2, st, (const uint2*)d_tmp, (const uint32_t*)d_M,
                        (const uint32_t*)d_total, p, (uint2*)d_entries, (uint32_t*)d_counts, (uint32_t*)d_offsets);
   }
