@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--focus", default="k_accumulate")
     ap.add_argument("--first", type=int, default=-1, help="window = from the start of the N-th k_prepare (0-based) ...")
     ap.add_argument("--count", type=int, default=20, help="... to the end of the (N+count)-th k_final")
+    ap.add_argument("--until-prepare", type=int, default=-1,
+                    help="... or (batch mode: one k_final per batch) to the end of the last kernel started before the M-th k_prepare")
     a = ap.parse_args()
     files = [a.path] if os.path.isfile(a.path) else glob.glob(os.path.join(a.path, "**", "*kernel_trace.csv"), recursive=True)
     ev = []
@@ -34,7 +36,11 @@ def main():
     if a.first >= 0:
         preps = [e for e in ev if e[2] == "k_prepare"]
         fins = sorted(e[1] for e in ev if e[2] == "k_final")
-        lo, hi = preps[a.first][0], fins[a.first + a.count - 1]
+        if a.until_prepare >= 0:
+            stop = preps[a.until_prepare][0] if a.until_prepare < len(preps) else max(e[1] for e in ev) + 1
+            lo, hi = preps[a.first][0], max(e[1] for e in ev if e[0] < stop)
+        else:
+            lo, hi = preps[a.first][0], fins[a.first + a.count - 1]
         ev = [e for e in ev if e[0] >= lo and e[1] <= hi]
     else:
         lo = t1 - (t1 - t0) * a.tail
