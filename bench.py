@@ -389,8 +389,6 @@ def main():
         ctx.sync()
         nsets = min(nsets, len(d_scalars_k))
         b_out = torch.zeros(64 * args.steps, dtype=torch.uint8, device="cuda")
-        b_part = torch.zeros(sv.G1_PARTIAL_BYTES * args.steps, dtype=torch.uint8, device="cuda")
-        b_gath = torch.zeros(world * sv.G1_PARTIAL_BYTES * args.steps, dtype=torch.uint8, device="cuda")
         job_s = [d_scalars_k[i % nsets].data_ptr() for i in range(args.steps)]
         job_p = [d_points_k[i % nsets].data_ptr() for i in range(args.steps)]
 
@@ -399,13 +397,12 @@ def main():
         if not use_dist:
             ctx.msm_pippenger_many_dev(job_s, job_p, [n] * args.steps, b_out.data_ptr(), args.window_bits)
         else:
-            with torch.cuda.stream(streams[0]):
-                ctx.msm_pippenger_many_partial_dev(job_s, job_p, [n] * args.steps, b_part.data_ptr(), args.window_bits)
-                dist.all_gather_into_tensor(b_gath, b_part)
-                pb = sv.G1_PARTIAL_BYTES
-                g = b_gath.view(world, args.steps, pb).transpose(0, 1).contiguous()  # [job][rank][144]
-                ctx.fold_partials_many_dev(g.data_ptr(), world, args.steps, b_out.data_ptr())  # K folds, one launch
-                run_batch.keep = g
+            # snark-verifier_amd/distributed.py: K partials -> ONE all-gather -> K folds in one launch, on slot 0's stream
+            from snark_verifier_amd.distributed import gpu_sharded_msm_batch
+            res = gpu_sharded_msm_batch(ctx, [d_scalars_k[i % nsets] for i in range(args.steps)],
+                                        [d_points_k[i % nsets] for i in range(args.steps)], [n] * args.steps,
+                                        args.window_bits, stream=streams[0])
+            run_batch.last = res
 
     def step():
         k = step_no[0] % inflight
@@ -478,7 +475,7 @@ def main():
     slot_results = [bytes(o.cpu().numpy()) for o in outs]
     assert all(r != bytes(64) for r in slot_results) and len(set(slot_results)) == inflight  # distinct inputs, distinct sums
     if batch:  # job i of the batch = input set i: the first sets are the slots, whose single-call results are above
-        got = bytes(b_out.cpu().numpy())
+        got = bytes((run_batch.last if use_dist else b_out).cpu().numpy())
         jobs = [got[64 * i:64 * i + 64] for i in range(args.steps)]
         assert all(jobs[i] == slot_results[i % nsets] for i in range(args.steps) if i % nsets < inflight)
         assert len(set(jobs)) == nsets and bytes(64) not in jobs

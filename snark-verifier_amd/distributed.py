@@ -95,6 +95,71 @@ def gpu_sharded_msm(ctx, d_scalars, d_points, n_total, window_bits=0):
 
 
 @dataclass
+class ShardedMsmBatch:
+    """K independent MSMs, every one sharded by points over the ranks, with ONE collective for the whole batch:
+    `partials_fn(ranges) -> tensor[K * partial_bytes]` reduces this rank's shard of every MSM (`ranges[i]` = its
+    (lo, hi) of MSM i), the ranks all-gather K x partial_bytes each, and `fold_fn(tensor[K][world][partial_bytes], world,
+    K) -> tensor[K * 64]` folds per MSM.  On a GPU box these are `Context.msm_pippenger_many_partial_dev` and
+    `Context.fold_partials_many_dev` (`gpu_sharded_msm_batch`, what `bench.py --gpus N` times); the gloo CPU tests inject
+    oracle-backed doubles."""
+
+    partials_fn: Callable
+    fold_fn: Callable
+    partial_bytes: int = 144
+
+    def run(self, n_totals):
+        import torch
+        import torch.distributed as dist
+
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        k = len(n_totals)
+        parts = self.partials_fn([shard_range(n, rank, world) for n in n_totals])
+        assert parts.numel() == k * self.partial_bytes and parts.dtype == torch.uint8
+        if world == 1:
+            gathered = parts
+        else:
+            gathered = torch.empty(world * k * self.partial_bytes, dtype=torch.uint8, device=parts.device)
+            dist.all_gather_into_tensor(gathered, parts)  # [rank][job][partial]
+        by_job = gathered.view(world, k, self.partial_bytes).transpose(0, 1).contiguous()  # [job][rank][partial]
+        return self.fold_fn(by_job, world, k)
+
+
+def gpu_sharded_msm_batch(ctx, d_scalars, d_points, counts, window_bits=0, stream=None):
+    """Product wiring of ShardedMsmBatch: `d_scalars[i]` / `d_points[i]` hold THIS rank's shard of MSM i (`counts[i]`
+    points, > 0).  Everything is enqueued on the context's stream, which must be torch's current stream for the
+    collective to be ordered after the partials (create the context with `stream=torch_stream.cuda_stream` and pass that
+    torch stream here); returns the device tensor of the K affine results (64 B each), valid after that stream."""
+    import contextlib
+
+    import torch
+
+    from . import G1_PARTIAL_BYTES
+
+    k = len(counts)
+    keep = []
+
+    def partials_fn(_ranges):
+        parts = torch.zeros(G1_PARTIAL_BYTES * k, dtype=torch.uint8, device=d_scalars[0].device)
+        keep.append(parts)
+        ctx.msm_pippenger_many_partial_dev([t.data_ptr() for t in d_scalars], [t.data_ptr() for t in d_points], list(counts),
+                                           parts.data_ptr(), window_bits)
+        return parts
+
+    def fold_fn(by_job, world, k_):
+        out = torch.zeros(64 * k_, dtype=torch.uint8, device=by_job.device)
+        keep.append(by_job)
+        ctx.fold_partials_many_dev(by_job.data_ptr(), world, k_, out.data_ptr())
+        return out
+
+    with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+        res = ShardedMsmBatch(partials_fn, fold_fn, G1_PARTIAL_BYTES).run(list(counts))
+    res._keep_alive = keep  # the partials and the transposed gather buffer outlive the asynchronous launches that read them
+                            # (all allocated while `stream` is current: the caching allocator ties them to it)
+    return res
+
+
+@dataclass
 class BucketShardedMsm:
     """The "bucket-sum allreduce" alternative of SURVEY.md 8(e): ranks still hold disjoint
     POINT shards, but instead of finishing their own Pippenger they all fill the same

@@ -69,6 +69,71 @@ def test_sharded_msm_two_ranks_agree_with_single_process(n):
         assert out == expected  # all ranks hold the same (all-reduce semantics)
 
 
+def _batch_worker(rank, world, port, sizes, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+
+    import coracle as C
+    from snark_verifier_amd.distributed import ShardedMsmBatch
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    jobs = [(C.sample_scalars(70 + i, n), C.sample_points(80 + i, n)) for i, n in enumerate(sizes)]
+
+    def partials_fn(ranges):  # oracle double: every shard's MSM as affine bytes, zero-padded to 144
+        buf = bytearray()
+        for (s, p), (lo, hi) in zip(jobs, ranges):
+            pt = C.msm_pippenger(s[32 * lo:32 * hi], p[64 * lo:64 * hi], 1) if hi > lo else b"\x00" * 64
+            buf += pt + b"\x00" * 80
+        return torch.frombuffer(buf, dtype=torch.uint8)
+
+    def fold_fn(by_job, w, k):  # [job][rank][144]
+        assert tuple(by_job.shape) == (k, w, 144)
+        raw = bytes(by_job.numpy())
+        out = bytearray()
+        for i in range(k):
+            acc = b"\x00" * 64
+            for r in range(w):
+                o = 144 * (i * w + r)
+                acc = C.g1_add(acc, raw[o:o + 64])
+            out += acc
+        return torch.frombuffer(out, dtype=torch.uint8)
+
+    out = ShardedMsmBatch(partials_fn, fold_fn).run(list(sizes))
+    q.put((rank, bytes(out.numpy())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_msm_batch_one_collective_for_the_whole_batch(world):
+    """K MSMs of different sizes (some smaller than the world: empty trailing shards), every one point-sharded, ONE
+    all-gather of K x 144 bytes per rank, the gathered [rank][job] array transposed to [job][rank] before the folds: every
+    rank ends with the K single-process results.  (The wiring `bench.py --gpus N` times: gpu_sharded_msm_batch.)"""
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import coracle as C
+
+    sizes = (1, 2, 37, 500, 3)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + world) % 2000
+    procs = [ctx.Process(target=_batch_worker, args=(r, world, port, sizes, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+    exp = b"".join(C.msm_pippenger(C.sample_scalars(70 + i, n), C.sample_points(80 + i, n), 1) for i, n in enumerate(sizes))
+    assert sorted(r for r, _ in got) == list(range(world))
+    for _, out in got:
+        assert out == exp
+
+
 def test_shard_range_is_reference_chunking():
     from snark_verifier_amd.distributed import shard_range
 
