@@ -174,6 +174,43 @@ def test_sharded_msm_over_rccl_world_of_one_is_ordered():
         dist.destroy_process_group()
 
 
+def test_sharded_msm_batch_wiring_on_a_one_rank_rccl_group():
+    """`gpu_sharded_msm_batch` (K partials -> ONE RCCL all-gather -> K folds in one launch; what `bench.py --gpus N`
+    times) on a 1-rank NCCL group, context on a torch side stream, inputs that change every call: every job must equal
+    the single-call result of the same inputs."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    import snark_verifier_amd as sv
+    from snark_verifier_amd import distributed as D
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29619"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        side = torch.cuda.Stream()
+        ctx = sv.Context(0, stream=side.cuda_stream)
+        ref = sv.Context(0)
+        sizes = [1 << 13, 5000, 1 << 13, 777]
+        ds = [torch.empty(32 * n, dtype=torch.uint8, device="cuda") for n in sizes]
+        dp = [torch.empty(64 * n, dtype=torch.uint8, device="cuda") for n in sizes]
+        exp = torch.zeros(64 * len(sizes), dtype=torch.uint8, device="cuda")
+        for it in range(4):
+            for i, n in enumerate(sizes):
+                ref.sample_scalars_dev(3000 + 10 * it + i, n, ds[i].data_ptr())
+                ref.sample_points_dev(4000 + 10 * it + i, n, dp[i].data_ptr())
+                ref.msm_pippenger_dev(ds[i].data_ptr(), dp[i].data_ptr(), n, exp.data_ptr() + 64 * i, 0)
+            ref.sync()
+            torch.cuda.synchronize()
+            got = D.gpu_sharded_msm_batch(ctx, ds, dp, sizes, stream=side)
+            side.synchronize()
+            assert bytes(got.cpu().numpy()) == bytes(exp.cpu().numpy()), it
+    finally:
+        dist.destroy_process_group()
+
+
 def test_context_free_entry_points_from_many_threads(golden_msm):
     """`bn254_*` share one process-global context; concurrent callers must take turns, not race."""
     import ctypes
