@@ -3,15 +3,16 @@
 
 A "step" is ONE pass of the hot path over one batch of synthetic input: every
 rank reduces its own 2^20-point shard (inputs resident in HBM, generated there
-by the seeded SplitMix64 sampler of SURVEY.md 8d) to a projective partial with
-the HIP Pippenger; for N > 1 the partials (144 B per rank) are all-gathered
-over RCCL/xGMI and every rank folds them to the same affine point (SURVEY.md
-8e).  value = N * 2^20 * steps / wall time (max over ranks) -> weak scaling.
-Several independent MSMs are kept in flight (one context + HIP stream each,
-default 4): bucket accumulation is VALU-bound while the bucket reduce, the
-2^(cw) doubling chains and to_affine are dependency chains on a few wavefronts,
-so consecutive steps overlap.  `config.single_msm_latency_ms` gives the strictly
-sequential figure.
+by the seeded SplitMix64 sampler of SURVEY.md 8d) with the HIP Pippenger.  The K
+timed steps are submitted as ONE batch call (`snarkv_g1_msm_pippenger_many_dev`:
+the library pipelines the K MSMs -- sorts on high-priority streams, bucket
+accumulations back to back on three streams, one batched tail -- every job on
+its own input arrays); for N > 1 every rank computes K projective partials, ONE
+all-gather moves K x 144 B per rank over RCCL/xGMI and every rank folds them to
+the same K affine points.  value = N * 2^20 * steps / wall time
+(max over ranks) -> weak scaling.  `--inflight N` keeps N single-MSM calls in
+flight instead (the round-1 way, for comparison); `config.single_msm_latency_ms`
+gives the strictly sequential figure.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -301,8 +302,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log2n", type=int, default=20, help="points per GPU = 2^log2n")
     ap.add_argument("--window-bits", type=int, default=0)
-    ap.add_argument("--cpu-sample-log2", type=int, default=20,
-                    help="CPU baseline sample = the first 2^k points of the same inputs (default: the whole 2^20 workload)")
+    ap.add_argument("--cpu-sample-log2", type=int, default=0,
+                    help="CPU baseline sample = the first 2^k points of the same inputs (default 0: the WHOLE workload, so the "
+                         "GPU result is compared with the CPU restatement on every point -- at 2^24 through the chunk pipeline)")
     ap.add_argument("--total-log2n", type=int, default=0,
                     help="STRONG scaling: 2^k points in total, split evenly over the ranks (BASELINE config 4: --gpus 8 "
                          "--total-log2n 24); overrides --log2n")
@@ -515,7 +517,7 @@ def main():
         stages = {k: v / stage_cnt for k, v in stage_sum.items()}
         dom = max((k for k in stages if k != "total"), key=lambda k: stages[k])
         dom_ms = stages[dom]
-        launch_n = sv.Context.launch_points(n)  # n, or the 2^20-point chunk large MSMs are pipelined in
+        launch_n = sv.Context.launch_points(n, args.window_bits)  # n, or the 2^20-point chunk large MSMs are pipelined in
         achieved = BYTES_PER_POINT * launch_n / (dom_ms * 1e-3) / 1e9
         line = {
             "metric": "BN254 G1 MSM points/sec at 2^%d" % (args.total_log2n if strong else args.log2n),
@@ -561,10 +563,9 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                # rocprofv3 PMC, separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this same command at 2^20
-                # (profiles/r01_rocprofv3_pmc_hbm_traffic_final3.txt): k_accumulate, bytes per launch, FETCH_SIZE + WRITE_SIZE
-                # as counted (Infinity-Cache hits included; the guide's x2 correction for wide coalesced reads would
-                # give 4.34e9).  Only valid for the default 2^20 workload; null otherwise.
+                # HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC record of THIS tree's kernels
+                # (tools/pmc_traffic.py -> profiles/r*_pmc_hbm_traffic*.json, keyed by the kernel-source hash); null when
+                # no record matches the sources.
                 "traffic": None,  # filled below from the PMC record of THESE kernels, or left null
 
                 "note": "algorithmic 96 B/point x %d points per launch / avg HIP-event duration of the dominant stage in the "
@@ -635,7 +636,7 @@ def main():
                 line["roofline"]["achieved_unshared"] = BYTES_PER_POINT * launch_n / (dseq * 1e-3) / 1e9
                 line["roofline"]["frac_unshared"] = line["roofline"]["achieved_unshared"] / HBM_PEAK_GBPS
         if not args.no_cpu_baseline and world == 1:
-            cb, cpu_out, (s, p) = cpu_baseline(ctx, d_scalars, d_points, min(args.cpu_sample_log2, args.log2n))
+            cb, cpu_out, (s, p) = cpu_baseline(ctx, d_scalars, d_points, min(args.cpu_sample_log2 or args.log2n, args.log2n))
             # the GPU must agree with the CPU restatement on that same sample
             m = len(s) // 32
             chk = torch.zeros(64, dtype=torch.uint8, device="cuda")

@@ -293,6 +293,8 @@ int snarkv_ctx_set_throughput_hint(snarkv_ctx* ctx, int enabled);
 /* points ONE launch of the Pippenger kernels processes for an n-point MSM: n itself, or the 2^20-point chunk of the
  * chunk pipeline large MSMs run as (csrc/capi.hip pippenger_maybe_split) -- what a per-launch roofline divides by */
 int snarkv_g1_msm_launch_points(size_t n, size_t* per_launch);
+/* ... for a call that passes `window_bits` (an explicit window size keeps the single launch whatever n is) */
+int snarkv_g1_msm_launch_points_ex(size_t n, int window_bits, size_t* per_launch);
 int snarkv_set_stage_timing(snarkv_ctx* ctx, int enabled);
 int snarkv_get_stage_timing(snarkv_ctx* ctx, float ms[SNARKV_PIP_STAGES]);
 

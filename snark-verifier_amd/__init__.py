@@ -18,6 +18,11 @@ from ._lib import (  # noqa: F401
     lib_path,
     load_library,
     SNARKV_FLAG_VALIDATE,
+    SNARKV_ERR_EMPTY,
+    SNARKV_ERR_LENGTH,
+    SNARKV_ERR_ENCODING,
+    SNARKV_ERR_DEVICE,
+    SNARKV_ERR_ARG,
     PIP_STAGE_NAMES,
     G1_PARTIAL_BYTES,
 )
@@ -35,6 +40,11 @@ __all__ = [
     "lib_path",
     "load_library",
     "SNARKV_FLAG_VALIDATE",
+    "SNARKV_ERR_EMPTY",
+    "SNARKV_ERR_LENGTH",
+    "SNARKV_ERR_ENCODING",
+    "SNARKV_ERR_DEVICE",
+    "SNARKV_ERR_ARG",
     "PIP_STAGE_NAMES",
     "G1_PARTIAL_BYTES",
 ]

@@ -79,6 +79,7 @@ _SIGNATURES = {
     "snarkv_ubench_valu": (_int, [_vp, _int, _int, ctypes.POINTER(ctypes.c_double)]),
     "snarkv_ctx_set_throughput_hint": (_int, [_vp, _int]),
     "snarkv_g1_msm_launch_points": (_int, [_sz, ctypes.POINTER(_sz)]),
+    "snarkv_g1_msm_launch_points_ex": (_int, [_sz, _int, ctypes.POINTER(_sz)]),
     "snarkv_mgpu_create": (_int, [ctypes.POINTER(_int), _int, _pp]),
     "snarkv_mgpu_destroy": (None, [_vp]),
     "snarkv_mgpu_size": (_int, [_vp]),
@@ -445,10 +446,10 @@ class Context:
         _check(self._lib.snarkv_sample_points_dev(self._h, seed, first, n, d_out))
 
     @staticmethod
-    def launch_points(n):
+    def launch_points(n, window_bits=0):
         """points one launch of the Pippenger kernels processes for an n-point MSM (n, or the chunk of the chunk pipeline)"""
         v = ctypes.c_size_t(0)
-        _check(load_library().snarkv_g1_msm_launch_points(n, ctypes.byref(v)))
+        _check(load_library().snarkv_g1_msm_launch_points_ex(n, window_bits, ctypes.byref(v)))
         return v.value
 
     @staticmethod

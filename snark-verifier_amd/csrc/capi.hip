@@ -12,6 +12,21 @@
 
 namespace snarkv {
 
+// THE decision "does an n-point MSM run as the chunk pipeline over shared bucket grids?" -- one rule for the single
+// call (launch_msm_pippenger_auto), the batch (launch_msm_pippenger_many hands such jobs to the single call) and
+// snarkv_g1_msm_launch_points (what bench.py divides its per-launch roofline by).  *chunk = points per chunk.
+//   SNARKV_PIP_SPLIT   0 never, 1 (default) from three chunks, 2 from two     SNARKV_SPLIT_LOG2   chunk size (tuning)
+// An explicit window size or a lane context (a worker of a pipeline already) keeps the single launch.
+bool pip_chunk_pipeline(size_t n, int window_bits, bool is_lane, size_t* chunk) {
+  size_t c = (size_t)1 << 20;
+  if (const char* cl = getenv("SNARKV_SPLIT_LOG2")) c = (size_t)1 << std::max(16, std::min(23, atoi(cl)));
+  const char* e = getenv("SNARKV_PIP_SPLIT");
+  const int mode = e ? atoi(e) : 1;
+  const size_t min_chunks = mode == 2 ? 2 : 3;
+  if (chunk) *chunk = c;
+  return mode != 0 && (n + c - 1) / c >= min_chunks && window_bits == 0 && !is_lane;
+}
+
 static int stage_in(snarkv_ctx* ctx, int slot, const void* host, size_t bytes, void** d) {
   SNARKV_TRY(ctx_reserve(ctx, slot, bytes, d));
   SNARKV_HIP(hipMemcpyAsync(*d, host, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -59,14 +74,14 @@ int snarkv_ctx_set_throughput_hint(snarkv_ctx* ctx, int enabled) {
   return SNARKV_OK;
 }
 
-int snarkv_g1_msm_launch_points(size_t n, size_t* per_launch) {
+int snarkv_g1_msm_launch_points_ex(size_t n, int window_bits, size_t* per_launch) {
   if (!per_launch) return SNARKV_ERR_ARG;
-  const char* e = getenv("SNARKV_PIP_SPLIT");
-  const int mode = e ? atoi(e) : 1;
-  const size_t chunk = (size_t)1 << 20, chunks = (n + chunk - 1) / chunk;
-  *per_launch = (mode == 0 || chunks < (mode == 2 ? 2u : 3u)) ? n : chunk;
+  size_t chunk = 0;
+  *per_launch = snarkv::pip_chunk_pipeline(n, window_bits, false, &chunk) ? chunk : n;
   return SNARKV_OK;
 }
+
+int snarkv_g1_msm_launch_points(size_t n, size_t* per_launch) { return snarkv_g1_msm_launch_points_ex(n, 0, per_launch); }
 
 int snarkv_get_stage_timing(snarkv_ctx* ctx, float ms[SNARKV_PIP_STAGES]) {
   if (!ctx || !ctx->ev_ready) return SNARKV_ERR_ARG;
@@ -186,16 +201,12 @@ static int pippenger_maybe_split(snarkv_ctx* ctx, const void* d_s, const void* d
 }
 int snarkv::launch_msm_pippenger_auto(snarkv_ctx* ctx, const void* d_s, const void* d_p, size_t n, int window_bits,
                                       void* d_out, bool partial_out) {
-  size_t kChunk = (size_t)1 << 20;
-  if (const char* cl = getenv("SNARKV_SPLIT_LOG2")) kChunk = (size_t)1 << std::max(16, std::min(23, atoi(cl)));  // tuning knob
-  const char* e = getenv("SNARKV_PIP_SPLIT");  // 0 = never, 1 = default threshold (3 chunks), 2 = from 2 chunks on
-  const int mode = e ? atoi(e) : 1;
-  const size_t min_chunks = mode == 2 ? 2 : 3;
+  size_t kChunk = 0;
+  const bool split = pip_chunk_pipeline(n, window_bits, ctx->is_lane, &kChunk);
   const size_t chunks = (n + kChunk - 1) / kChunk;
   ctx->last_split_workers = 0;
   ctx->last_many_jobs = 0;
-  if (mode == 0 || chunks < min_chunks || window_bits != 0 || ctx->is_lane)
-    return launch_msm_pippenger(ctx, d_s, d_p, n, window_bits, d_out, partial_out);
+  if (!split) return launch_msm_pippenger(ctx, d_s, d_p, n, window_bits, d_out, partial_out);
   SNARKV_TRY(ctx_lanes(ctx));
   const bool tm = ctx->stage_timing;  // per-stage events: on the worker lanes (their LAST chunk); total on this stream
   if (tm && !ctx->ev_ready) {
@@ -266,17 +277,16 @@ int snarkv::launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void*
   ctx->last_many_jobs = 0;
   ctx->last_split_workers = 0;
   if (count == 0) return SNARKV_OK;
-  const size_t kLarge = (size_t)3 << 20;  // the chunk pipeline's threshold (launch_msm_pippenger_auto)
   uint32_t c0 = 0, w0 = 0, b0 = 0;
   bool uniform = true, large = false;
-  size_t nmax = 0, sig = count * 1000003u;
+  size_t nmax = 0, sig = count * 1000003u + (size_t)(uint32_t)window_bits;
   for (size_t i = 0; i < count; ++i) {
     if (n[i] == 0) return SNARKV_ERR_EMPTY;
     uint32_t c, w, b;
     SNARKV_TRY(pip_geometry(n[i], window_bits, &c, &w, &b));
     if (i == 0) c0 = c, w0 = w, b0 = b;
     uniform = uniform && c == c0;
-    large = large || (n[i] >= kLarge && window_bits == 0);
+    large = large || pip_chunk_pipeline(n[i], window_bits, false, nullptr);  // the same rule as the single call
     nmax = std::max(nmax, n[i]);
     sig = sig * 31 + n[i];
   }

@@ -137,6 +137,8 @@ int launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void* const* 
 // the product path of a large MSM: single launch, or the chunk pipeline over shared bucket grids (capi.hip)
 int launch_msm_pippenger_auto(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
                               void* d_out, bool partial_out);
+// does an n-point MSM run as the chunk pipeline over shared bucket grids? (the one rule: capi.hip)
+bool pip_chunk_pipeline(size_t n, int window_bits, bool is_lane, size_t* chunk);
 int pip_geometry(size_t n_total, int window_bits, uint32_t* c, uint32_t* windows, uint32_t* buckets_per_window);
 int launch_buckets_add(snarkv_ctx* ctx, void* d_dst, const void* d_src, size_t count);
 int launch_buckets_reduce(snarkv_ctx* ctx, const void* d_buckets, uint32_t c, uint32_t w0, uint32_t wcount, void* d_partial);

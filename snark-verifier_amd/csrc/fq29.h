@@ -241,6 +241,10 @@ SNARKV_HD Fq29 fq29_sqr(const Fq29& a) {
 #endif
 }
 
+#ifndef SNARKV_MADD_PAIRS
+#define SNARKV_MADD_PAIRS 0  // the interleaved-pair adder of g1_29.h (a recorded experiment, off: DESIGN.md section 4)
+#endif
+#if SNARKV_MADD_PAIRS  // the three generated pair bodies (4 000 lines of asm) are parsed only by a build that uses them
 // PAIRS of independent products, interleaved column by column (gen_fq29_mul_asm.py pair mode).  Same arithmetic, same
 // results as the single forms; what changes is the instruction after every asm statement: the compiler pads an asm
 // statement whose VGPR result is read by the very next instruction with `s_nop 0` (it must assume the asm wrote with
@@ -273,6 +277,7 @@ SNARKV_HD void fq29_mul2_mul(const Fq29& a, const Fq29& b, const Fq29& c, const 
   r2 = fq29_mul(e, f);
 #endif
 }
+#endif  // SNARKV_MADD_PAIRS
 
 // Unique representative in [0, p), carry-normalised.
 // canonical limbs of a value y in (-p, 2p) whose limbs 0..7 are already in [0, 2^29) -- in particular any OUTPUT of

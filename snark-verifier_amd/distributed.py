@@ -108,13 +108,23 @@ class ShardedMsmBatch:
     partial_bytes: int = 144
 
     def run(self, n_totals):
-        import torch
+        """`n_totals[i]` = points of MSM i over ALL ranks: this rank reduces `shard_range(n_totals[i], rank, world)`."""
         import torch.distributed as dist
 
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
-        k = len(n_totals)
-        parts = self.partials_fn([shard_range(n, rank, world) for n in n_totals])
+        return self._gather_fold(self.partials_fn([shard_range(n, rank, world) for n in n_totals]), len(n_totals))
+
+    def run_local(self, counts):
+        """Weak-scaling form: the caller already holds THIS rank's shard of every MSM (`counts[i]` points of it, 0
+        allowed: an empty shard contributes the identity partial); `partials_fn` receives `(0, counts[i])`."""
+        return self._gather_fold(self.partials_fn([(0, int(c)) for c in counts]), len(counts))
+
+    def _gather_fold(self, parts, k):
+        import torch
+        import torch.distributed as dist
+
+        world = dist.get_world_size() if dist.is_initialized() else 1
         assert parts.numel() == k * self.partial_bytes and parts.dtype == torch.uint8
         if world == 1:
             gathered = parts
@@ -127,7 +137,7 @@ class ShardedMsmBatch:
 
 def gpu_sharded_msm_batch(ctx, d_scalars, d_points, counts, window_bits=0, stream=None):
     """Product wiring of ShardedMsmBatch: `d_scalars[i]` / `d_points[i]` hold THIS rank's shard of MSM i (`counts[i]`
-    points, > 0).  Everything is enqueued on the context's stream, which must be torch's current stream for the
+    points; 0 = an empty shard, which contributes the identity).  Everything is enqueued on the context's stream, which must be torch's current stream for the
     collective to be ordered after the partials (create the context with `stream=torch_stream.cuda_stream` and pass that
     torch stream here); returns the device tensor of the K affine results (64 B each), valid after that stream."""
     import contextlib
@@ -139,11 +149,23 @@ def gpu_sharded_msm_batch(ctx, d_scalars, d_points, counts, window_bits=0, strea
     k = len(counts)
     keep = []
 
-    def partials_fn(_ranges):
+    def partials_fn(ranges):
+        # An empty local shard (n < world with the reference's ceil chunking, or a caller that passes 0) must not reach the
+        # device call: it returns SNARKV_ERR_EMPTY on THAT rank only and every peer would block in the all-gather.  Its
+        # 144-byte slot stays zero (ZZ = 0 is the identity partial); the other jobs go to the device as one batch.
         parts = torch.zeros(G1_PARTIAL_BYTES * k, dtype=torch.uint8, device=d_scalars[0].device)
         keep.append(parts)
-        ctx.msm_pippenger_many_partial_dev([t.data_ptr() for t in d_scalars], [t.data_ptr() for t in d_points], list(counts),
-                                           parts.data_ptr(), window_bits)
+        live = [i for i, (lo, hi) in enumerate(ranges) if hi > lo]
+        if len(live) == k:
+            ctx.msm_pippenger_many_partial_dev([t.data_ptr() for t in d_scalars], [t.data_ptr() for t in d_points],
+                                               [hi - lo for lo, hi in ranges], parts.data_ptr(), window_bits)
+        elif live:
+            dense = torch.zeros(G1_PARTIAL_BYTES * len(live), dtype=torch.uint8, device=parts.device)
+            keep.append(dense)
+            ctx.msm_pippenger_many_partial_dev([d_scalars[i].data_ptr() for i in live], [d_points[i].data_ptr() for i in live],
+                                               [ranges[i][1] - ranges[i][0] for i in live], dense.data_ptr(), window_bits)
+            idx = torch.tensor(live, dtype=torch.int64, device=parts.device)
+            parts.view(k, G1_PARTIAL_BYTES).index_copy_(0, idx, dense.view(len(live), G1_PARTIAL_BYTES))
         return parts
 
     def fold_fn(by_job, world, k_):
@@ -153,7 +175,7 @@ def gpu_sharded_msm_batch(ctx, d_scalars, d_points, counts, window_bits=0, strea
         return out
 
     with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
-        res = ShardedMsmBatch(partials_fn, fold_fn, G1_PARTIAL_BYTES).run(list(counts))
+        res = ShardedMsmBatch(partials_fn, fold_fn, G1_PARTIAL_BYTES).run_local(list(counts))
     res._keep_alive = keep  # the partials and the transposed gather buffer outlive the asynchronous launches that read them
                             # (all allocated while `stream` is current: the caching allocator ties them to it)
     return res

@@ -64,7 +64,11 @@ struct PReader {
   }
 };
 
-inline ExprPtr parse_expr(PReader& rd) {
+// depth-bounded like the serde-JSON / bincode readers (serde_json.hpp): a buffer of repeated tag 5 (Negated) would
+// otherwise recurse once per byte and overflow the stack instead of returning SNARKV_HOST_ERR_PANIC
+constexpr int kMaxExprDepth = 2048;
+inline ExprPtr parse_expr(PReader& rd, int depth = 0) {
+  if (depth > kMaxExprDepth) throw Panic("expression nested deeper than 2048 levels");
   auto e = std::make_shared<Expression>();
   switch (rd.u8()) {
     case 0: e->kind = Expression::Constant; e->scalar = rd.fr(); break;
@@ -72,15 +76,15 @@ inline ExprPtr parse_expr(PReader& rd) {
     case 2: e->kind = Expression::Lagrange; e->lagrange = rd.i32(); break;
     case 3: e->kind = Expression::Polynomial; e->query.poly = rd.u32(); e->query.rotation = rd.i32(); break;
     case 4: e->kind = Expression::Challenge; e->index = rd.u32(); break;
-    case 5: e->kind = Expression::Negated; e->ch.push_back(parse_expr(rd)); break;
-    case 6: e->kind = Expression::Sum; e->ch.push_back(parse_expr(rd)); e->ch.push_back(parse_expr(rd)); break;
-    case 7: e->kind = Expression::Product; e->ch.push_back(parse_expr(rd)); e->ch.push_back(parse_expr(rd)); break;
-    case 8: e->kind = Expression::Scaled; e->ch.push_back(parse_expr(rd)); e->scalar = rd.fr(); break;
+    case 5: e->kind = Expression::Negated; e->ch.push_back(parse_expr(rd, depth + 1)); break;
+    case 6: e->kind = Expression::Sum; e->ch.push_back(parse_expr(rd, depth + 1)); e->ch.push_back(parse_expr(rd, depth + 1)); break;
+    case 7: e->kind = Expression::Product; e->ch.push_back(parse_expr(rd, depth + 1)); e->ch.push_back(parse_expr(rd, depth + 1)); break;
+    case 8: e->kind = Expression::Scaled; e->ch.push_back(parse_expr(rd, depth + 1)); e->scalar = rd.fr(); break;
     case 9: {
       e->kind = Expression::DistributePowers;
       uint32_t n = rd.u32();
-      for (uint32_t i = 0; i < n; ++i) e->ch.push_back(parse_expr(rd));
-      e->ch.push_back(parse_expr(rd));
+      for (uint32_t i = 0; i < n; ++i) e->ch.push_back(parse_expr(rd, depth + 1));
+      e->ch.push_back(parse_expr(rd, depth + 1));
       break;
     }
     default: throw Panic("bad expression tag");
@@ -114,6 +118,7 @@ inline PlonkProtocol parse_protocol(const uint8_t* b, size_t len) {
     pr.instance_committing_key = ick;
   }
   uint8_t lin = rd.u8();
+  if (lin > 2) throw Panic("bad linearization tag");
   pr.linearization = lin == 0 ? Linearization::None : lin == 1 ? Linearization::WithoutConstant : Linearization::MinusVanishingTimesQuotient;
   for (uint32_t n = rd.u32(), i = 0; i < n; ++i) {
     std::vector<std::pair<size_t, size_t>> idx;

@@ -187,6 +187,8 @@ def plonk_succinct_verify_batch(protocol, dk, instances, proofs, n, mos=MOS_GWC1
             cap = 128 * max(cnt.value, 2 * cap // 128)
             continue
         _check(rc)
+        if rc != 1:  # 0 = Error::AssertionFailure mapped to "reject" by the C API: never a successful shard of zero accumulators
+            raise HostError(0, "plonk_succinct_verify_batch: verifier rejected (%s)" % (load_library().snarkv_host_last_error() or b"").decode(errors="replace"))
         return out.raw[: 128 * cnt.value]
 
 

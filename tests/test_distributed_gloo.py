@@ -134,6 +134,96 @@ def test_sharded_msm_batch_one_collective_for_the_whole_batch(world):
         assert out == exp
 
 
+class _HostCtx:
+    """CPU double of `Context` for the two entry points `gpu_sharded_msm_batch` calls: the "device pointers" are host
+    addresses of CPU tensors (ctypes reads / writes them), the arithmetic is the C oracle's.  Like the device entry point
+    it REFUSES an empty MSM (SNARKV_ERR_EMPTY) -- which is exactly what used to hang the peers in the all-gather."""
+
+    def __init__(self):
+        self.calls = []
+
+    def msm_pippenger_many_partial_dev(self, ds, dp, counts, out_ptr, window_bits=0):
+        import ctypes
+
+        import coracle as C
+
+        self.calls.append(list(counts))
+        if any(c <= 0 for c in counts):
+            raise RuntimeError("SNARKV_ERR_EMPTY")
+        for i, (s, p, c) in enumerate(zip(ds, dp, counts)):
+            pt = C.msm_pippenger(ctypes.string_at(s, 32 * c), ctypes.string_at(p, 64 * c), 1)
+            ctypes.memmove(out_ptr + 144 * i, pt + bytes(80), 144)
+
+    def fold_partials_many_dev(self, ptr, world, k, out_ptr):
+        import ctypes
+
+        import coracle as C
+
+        raw = ctypes.string_at(ptr, 144 * world * k)
+        for i in range(k):
+            acc = bytes(64)
+            for r in range(world):
+                o = 144 * (i * world + r)
+                acc = C.g1_add(acc, raw[o:o + 64])
+            ctypes.memmove(out_ptr + 64 * i, acc, 64)
+
+
+def _product_batch_worker(rank, world, port, sizes, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+
+    import coracle as C
+    from snark_verifier_amd.distributed import gpu_sharded_msm_batch, shard_range
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ds, dp, counts = [], [], []
+    for i, n in enumerate(sizes):  # this rank's shard of MSM i, as the weak-scaling caller holds it
+        lo, hi = shard_range(n, rank, world)
+        s, p = C.sample_scalars(70 + i, n), C.sample_points(80 + i, n)
+        ds.append(torch.frombuffer(bytearray(s[32 * lo:32 * hi] or bytes(32)), dtype=torch.uint8))
+        dp.append(torch.frombuffer(bytearray(p[64 * lo:64 * hi] or bytes(64)), dtype=torch.uint8))
+        counts.append(hi - lo)
+    ctx = _HostCtx()
+    out = gpu_sharded_msm_batch(ctx, ds, dp, counts)
+    q.put((rank, bytes(out.numpy()), counts, ctx.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_product_batch_wiring_with_empty_local_shards(world):
+    """`gpu_sharded_msm_batch` ITSELF (the function `bench.py --gpus N` times) at world > 1 with MSMs smaller than the
+    world: the ranks whose shard of a job is empty must not hand that job to the device entry point (it fails with
+    SNARKV_ERR_EMPTY on that rank only and the peers would block in the collective) -- its 144-byte slot
+    stays the identity -- and every rank still ends with every job's single-process result."""
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import coracle as C
+
+    sizes = (1, 2, 37, 500, 1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() + world) % 2000
+    procs = [ctx.Process(target=_product_batch_worker, args=(r, world, port, sizes, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    exp = b"".join(C.msm_pippenger(C.sample_scalars(70 + i, n), C.sample_points(80 + i, n), 1) for i, n in enumerate(sizes))
+    assert any(0 in counts for _, _, counts, _ in got)  # the case under test occurred
+    for _, out, counts, calls in got:
+        assert out == exp
+        assert all(all(c > 0 for c in call) for call in calls)  # no empty job ever reached the device entry point
+        assert sum(len(c) for c in calls) == sum(1 for c in counts if c > 0)
+
+
 def test_shard_range_is_reference_chunking():
     from snark_verifier_amd.distributed import shard_range
 

@@ -70,3 +70,34 @@ def test_pippenger_2p20_every_supported_window_size_same_bytes(gpu_ctx):
     ref = _gpu_msm(gpu_ctx, ds, dp, n)
     for c in (13, 14, 15, 16, 17):
         assert _gpu_msm(gpu_ctx, ds, dp, n, window_bits=c) == ref, c
+
+
+def test_config4_2p24_bit_exact_vs_c_oracle(gpu_ctx):
+    """BASELINE config 4 at ITS size, bit for bit: 2^24 points on the bench seeds through the default path -- the only
+    size that takes the 16-chunk pipeline over shared bucket grids (capi.hip launch_msm_pippenger_auto) -- against the
+    threaded C restatement of util/msm.rs:308-343 on every host core (~20 s on the GPU box's 256 threads), and the same
+    expected bytes for the config's multi-GPU shape: 8 ranks x 2^21 points through `snarkv_g1_msm_pippenger_mgpu_dev`
+    (ranks emulated on device 0), point-sharded and bucket-sharded ("bucket-sum allreduce")."""
+    import torch
+
+    import snark_verifier_amd as sv
+
+    n = 1 << 24
+    ds, dp = _device_inputs(gpu_ctx, n)
+    s, p = bytes(ds.cpu().numpy()), bytes(dp.cpu().numpy())
+    assert s[-32 * 64:] == C.sample_scalars(SEED_S, 64, first=n - 64) and p[:64 * 64] == C.sample_points(SEED_P, 64)
+    exp = C.msm_pippenger(s, p, os.cpu_count() or 1)
+    del s, p
+    assert exp != bytes(64) and C.g1_is_on_curve(exp)
+    assert _gpu_msm(gpu_ctx, ds, dp, n) == exp
+    world, per = 8, n // 8
+    mg = sv.MultiGpu([0] * world)
+    try:
+        for variant in (sv.MultiGpu.POINT_SHARDED, sv.MultiGpu.BUCKET_SHARDED):
+            got = mg.msm_pippenger_dev([ds.data_ptr() + 32 * per * r for r in range(world)],
+                                       [dp.data_ptr() + 64 * per * r for r in range(world)], [per] * world, 0, variant)
+            assert got == exp, variant
+    finally:
+        mg.close()
+    del ds, dp
+    torch.cuda.empty_cache()
