@@ -297,7 +297,8 @@ int snarkv::launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void*
     return SNARKV_OK;
   }
   // jobs per round: bounded by the scratch footprint (~560 B per point + two bucket grids)
-  const size_t per_job = nmax * 560 + (size_t)w0 * b0 * SNARKV_G1_PARTIAL_BYTES * 2 + (1u << 20);
+  // (~560 B per point without the pair level, ~1 000 B more with it: prefix products + the half-length stream)
+  const size_t per_job = nmax * 1600 + (size_t)w0 * b0 * SNARKV_G1_PARTIAL_BYTES * 2 + (1u << 20);
   size_t G = std::min<size_t>(count, SNARKV_MANY_MAX_JOBS);
   G = std::max<size_t>(1, std::min<size_t>(G, ((size_t)48 << 30) / per_job));
   if (const char* eg = getenv("SNARKV_MANY_JOBS")) G = std::max<size_t>(1, std::min<size_t>(G, (size_t)atoi(eg)));

@@ -66,6 +66,12 @@ enum Slot {
   SLOT_IPA_OUT,
   SLOT_MGPU_GRID,
   SLOT_MGPU_RECV,
+  SLOT_COUNTS2,
+  SLOT_OFFSETS2,
+  SLOT_PAIR_PFX,
+  SLOT_PAIR_TOT,
+  SLOT_PAIR_PTS,
+  SLOT_PAIR_ENTRIES,
   SLOT_COUNT
 };
 

@@ -52,6 +52,7 @@
 #include <atomic>
 #include "ctx.hpp"
 #include "g1_29.h"
+#include "pair_tree.h"
 #ifndef SNARKV_GLV
 #define SNARKV_GLV 1  // 0: curves without the BN-shaped GLV lattice (the pasta build): one virtual point per point
 #endif
@@ -154,6 +155,7 @@ struct PipParams {
   uint32_t krun;     // entries per run (kRun, or kRunThroughput on a context with the throughput hint)
   uint32_t rpw;      // run slots reserved per window: ceil(max entries of a window / krun) + 1
   uint32_t wper;     // batched tail over several MSMs' grids laid end to end: windows per MSM (0: one MSM)
+  uint32_t pad;      // 1: k_sort_level2 pads every bucket's entry count to even (the pair level, pair_tree.h)
 };
 
 // c bits at offset lo of a kDigitBits-bit magnitude held in registers (selects, no dynamic indexing)
@@ -525,12 +527,19 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ data, c
 // scatter to HBM costs a 128-byte read-modify-write once the working set
 // outgrows L2/Infinity Cache.  Larger slices (skewed scalars) take the
 // two-pass global path.
+// PAD mode (p.pad, the pair level of pair_tree.h): every bucket's entry count is rounded up to EVEN with a skip entry
+// {bucket, kEntrySkip} behind its real ones, so that the entries (2i, 2i + 1) of the stream always share a bucket.  The
+// padded sizes are not known before the histogram, so key k's output region starts at its level-1 position plus
+// k * (nbins + 2), rounded to even -- room for one pad per bin -- and what is left of the room is given to the key's
+// last bin as further skip entries (a few hundred per MSM): no second scan, the stream stays bucket-sorted and dense.
+// counts / offsets describe the padded stream; counts2 / offsets2 the HALF-length stream of pair slots; the last key
+// leaves the padded total and the number of pair slots in misc[1] / misc[2].
 __global__ void __launch_bounds__(SNARKV_L2_THREADS) SNARKV_LEVEL2_ATTR
-    k_sort_level2(const uint2* __restrict__ tmp, const uint32_t* __restrict__ M, const uint32_t* __restrict__ total_ptr,
+    k_sort_level2(const uint2* __restrict__ tmp, const uint32_t* __restrict__ M, uint32_t* __restrict__ misc,
                   PipParams p, uint2* __restrict__ entries, uint32_t* __restrict__ counts,
-                  uint32_t* __restrict__ offsets) {
+                  uint32_t* __restrict__ offsets, uint32_t* __restrict__ counts2, uint32_t* __restrict__ offsets2) {
   SNARKV_RAISE_PRIO();
-  extern __shared__ uint32_t lds[];  // nbins counters | one scan word per lane | kSortCap items (uint2)
+  extern __shared__ uint32_t lds[];  // nbins counters | one scan word per lane | kSortCap (+ nbins + 4 in pad mode) items (uint2)
   const uint32_t nbins = 1u << p.low_bits;
   uint32_t* hist = lds;
   uint32_t* scan = lds + nbins;
@@ -538,8 +547,12 @@ __global__ void __launch_bounds__(SNARKV_L2_THREADS) SNARKV_LEVEL2_ATTR
   const uint32_t T = blockDim.x;
   uint32_t key = blockIdx.x;
   uint32_t begin = M[(size_t)key * p.mstride];
-  uint32_t end = (key + 1 < p.nkeys) ? M[(size_t)(key + 1) * p.mstride] : *total_ptr;
+  uint32_t end = (key + 1 < p.nkeys) ? M[(size_t)(key + 1) * p.mstride] : misc[0];
   uint32_t cnt_items = end - begin;
+  const uint32_t room = nbins + 2;
+  const uint32_t ob = p.pad ? ((begin + key * room + 1u) & ~1u) : begin;                // where this key's output starts
+  const uint32_t obn = p.pad ? ((end + (key + 1) * room + 1u) & ~1u) : end;             // ... and the next key's
+  const uint32_t capacity = obn - ob;
   bool fast = cnt_items <= kSortCap;
   for (uint32_t k = threadIdx.x; k < nbins; k += T) hist[k] = 0;
   __syncthreads();
@@ -560,11 +573,11 @@ __global__ void __launch_bounds__(SNARKV_L2_THREADS) SNARKV_LEVEL2_ATTR
     for (uint32_t e = begin + threadIdx.x; e < end; e += T) atomicAdd(&hist[tmp[e].x & low_mask], 1u);
   }
   __syncthreads();
-  // exclusive scan of hist: each lane owns a contiguous strip
+  // exclusive scan of the (padded) bin sizes: each lane owns a contiguous strip
   uint32_t per = (nbins + T - 1) / T;
   uint32_t s0 = threadIdx.x * per;
   uint32_t sum = 0;
-  for (uint32_t k = s0; k < s0 + per && k < nbins; ++k) sum += hist[k];
+  for (uint32_t k = s0; k < s0 + per && k < nbins; ++k) sum += p.pad ? ((hist[k] + 1u) & ~1u) : hist[k];
   scan[threadIdx.x] = sum;
   __syncthreads();
   for (uint32_t off = 1; off < T; off <<= 1) {
@@ -573,15 +586,38 @@ __global__ void __launch_bounds__(SNARKV_L2_THREADS) SNARKV_LEVEL2_ATTR
     scan[threadIdx.x] += t;
     __syncthreads();
   }
-  uint32_t run = scan[threadIdx.x] - sum;  // position inside the slice
+  uint32_t run = scan[threadIdx.x] - sum;  // position inside the key's output region
+  const uint32_t used = scan[T - 1];       // padded entries of the key; the rest of the region goes to the last bin
   uint32_t w = key / p.SB, sb = key % p.SB;
   uint32_t bucket0 = w * p.B + (sb << p.low_bits);
   for (uint32_t k = s0; k < s0 + per && k < nbins; ++k) {
     uint32_t cnt = hist[k];
-    counts[bucket0 + k] = cnt;
-    offsets[bucket0 + k] = begin + run;
-    hist[k] = run;  // becomes the cursor (slice-relative)
-    run += cnt;
+    uint32_t pc = p.pad ? ((cnt + 1u) & ~1u) : cnt;
+    if (p.pad && (cnt & 1u)) {
+      const uint2 pe = make_uint2(bucket0 + k, kEntrySkip);
+      if (fast) stage[run + cnt] = pe;
+      else entries[ob + run + cnt] = pe;
+    }
+    uint32_t tot = pc + ((p.pad && k == nbins - 1) ? capacity - used : 0u);
+    counts[bucket0 + k] = tot;
+    offsets[bucket0 + k] = ob + run;
+    if (p.pad) {
+      counts2[bucket0 + k] = tot >> 1;
+      offsets2[bucket0 + k] = (ob + run) >> 1;
+    }
+    hist[k] = run;  // becomes the cursor (region-relative)
+    run += pc;
+  }
+  if (p.pad) {
+    const uint2 fe = make_uint2(bucket0 + nbins - 1, kEntrySkip);
+    for (uint32_t e = used + threadIdx.x; e < capacity; e += T) {
+      if (fast) stage[e] = fe;
+      else entries[ob + e] = fe;
+    }
+    if (key == p.nkeys - 1 && threadIdx.x == 0) {
+      misc[1] = obn;
+      misc[2] = obn >> 1;
+    }
   }
   __syncthreads();
   if (fast) {
@@ -591,11 +627,124 @@ __global__ void __launch_bounds__(SNARKV_L2_THREADS) SNARKV_LEVEL2_ATTR
       if (e < cnt_items) stage[atomicAdd(&hist[mine[j].x & low_mask], 1u)] = mine[j];
     }
     __syncthreads();
-    for (uint32_t e = threadIdx.x; e < cnt_items; e += T) entries[begin + e] = stage[e];
+    for (uint32_t e = threadIdx.x; e < capacity; e += T) entries[ob + e] = stage[e];
   } else {
     for (uint32_t e = begin + threadIdx.x; e < end; e += T) {
       uint2 it = tmp[e];
-      entries[begin + atomicAdd(&hist[it.x & low_mask], 1u)] = it;
+      entries[ob + atomicAdd(&hist[it.x & low_mask], 1u)] = it;
+    }
+  }
+}
+
+// --------------------------------------------------------------- P3b (pair level, pair_tree.h)
+// One batched-affine addition level between the sort and the bucket accumulation: pair slot i = entries (2i, 2i + 1)
+// of the padded stream -> entry i of a half-length stream whose points are stored as lazy limbs.  6 field products per
+// addition instead of the 10 of the XYZZ mixed addition.  The per-lane code lives in pair_tree.h (host-testable).
+#ifndef SNARKV_PAIR_TREE_DEFAULT
+#define SNARKV_PAIR_TREE_DEFAULT 0  // until the A/B says otherwise (profiles/r03_ab_pair_tree.txt)
+#endif
+#ifndef SNARKV_PAIR_M
+#define SNARKV_PAIR_M 16   // pair slots per lane of k_pair_fwd / k_pair_bwd
+#endif
+#ifndef SNARKV_BINV_M
+#define SNARKV_BINV_M 32   // elements per lane of an inversion level
+#endif
+constexpr uint32_t kPairT = 256;      // lanes per workgroup of the pair / inversion kernels
+constexpr uint32_t kPairM = SNARKV_PAIR_M;
+constexpr uint32_t kBinvM = SNARKV_BINV_M;
+constexpr uint32_t kBinvFinalMax = 1024;  // k_binv_final: 256 lanes x 4 values + an LDS product tree
+
+__global__ void __launch_bounds__(kPairT)
+    k_pair_fwd(const uint2* __restrict__ entries, const uint32_t* __restrict__ misc, const G1Packed* __restrict__ pts,
+               int32_t* __restrict__ pfx, size_t S, int32_t* __restrict__ tot, size_t L) {
+  const uint32_t j = blockIdx.x * kPairT + threadIdx.x;
+  pair_fwd_lane(j, kPairT, kPairM, misc[2], reinterpret_cast<const PairEntry*>(entries), pts, pfx, S, tot, L);
+}
+
+__global__ void __launch_bounds__(kPairT)
+    k_pair_bwd(const uint2* __restrict__ entries, const uint32_t* __restrict__ misc, const G1Packed* __restrict__ pts,
+               const int32_t* __restrict__ pfx, size_t S, const int32_t* __restrict__ itot, size_t L,
+               uint2* __restrict__ out_entries, int32_t* __restrict__ out_pts) {
+  const uint32_t j = blockIdx.x * kPairT + threadIdx.x;
+  pair_bwd_lane(j, kPairT, kPairM, misc[2], reinterpret_cast<const PairEntry*>(entries), pts, pfx, S, itot, L,
+                reinterpret_cast<PairEntry*>(out_entries), out_pts);
+}
+
+__global__ void __launch_bounds__(kPairT)
+    k_binv_up(const int32_t* __restrict__ a, uint32_t N, size_t A, int32_t* __restrict__ pfx, int32_t* __restrict__ tot,
+              size_t L) {
+  SNARKV_RAISE_PRIO();
+  binv_up_lane(blockIdx.x * kPairT + threadIdx.x, kPairT, kBinvM, N, a, A, pfx, tot, L);
+}
+
+__global__ void __launch_bounds__(kPairT)
+    k_binv_down(int32_t* __restrict__ a, uint32_t N, size_t A, const int32_t* __restrict__ pfx,
+                const int32_t* __restrict__ itot, size_t L) {
+  SNARKV_RAISE_PRIO();
+  binv_down_lane(blockIdx.x * kPairT + threadIdx.x, kPairT, kBinvM, N, a, A, pfx, itot, L);
+}
+
+// a[0 .. N) -> inverses in place, N <= kBinvFinalMax, ONE workgroup: every lane multiplies its (up to 4) values, the 256
+// lane products are multiplied up a binary tree in LDS, lane 0 inverts the root (safegcd), the inverses come back down
+// the tree (inverse of a child = inverse of the parent x the sibling's product) and through each lane's values.
+__global__ void __launch_bounds__(kPairT) k_binv_final(int32_t* __restrict__ a, uint32_t N, size_t A) {
+  SNARKV_RAISE_PRIO();
+  __shared__ int32_t node[9][2 * kPairT];  // heap layout: root 1, leaves kPairT .. 2 kPairT - 1
+  const uint32_t tid = threadIdx.x;
+  auto nload = [&](uint32_t i) {
+    Fq29 r;
+#pragma unroll
+    for (int l = 0; l < 9; ++l) r.v[l] = node[l][i];
+    return r;
+  };
+  auto nstore = [&](uint32_t i, const Fq29& v) {
+#pragma unroll
+    for (int l = 0; l < 9; ++l) node[l][i] = v.v[l];
+  };
+  constexpr int kPer = kBinvFinalMax / kPairT;
+  Fq29 pre[kPer];  // pre[k] = product of the lane's values before the k-th
+  Fq29 pr = fq29_one();
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const uint32_t e = tid + (uint32_t)k * kPairT;
+    pre[k] = pr;
+    if (e < N) {
+      Fq29 d = soa_load(a, A, e);
+      pr = cnt ? fq29_mul(pr, d) : d;
+      ++cnt;
+    }
+  }
+  nstore(kPairT + tid, pr);
+  for (uint32_t w = kPairT / 2; w >= 1; w >>= 1) {
+    __syncthreads();
+    if (tid < w) nstore(w + tid, fq29_mul(nload(2 * (w + tid)), nload(2 * (w + tid) + 1)));
+  }
+  __syncthreads();
+  if (tid == 0) nstore(1, fq29_inv(nload(1)));
+  for (uint32_t w = 1; w < kPairT; w <<= 1) {
+    __syncthreads();
+    if (tid < w) {
+      const uint32_t nd = w + tid;
+      const Fq29 inv = nload(nd), l = nload(2 * nd), r = nload(2 * nd + 1);
+      nstore(2 * nd, fq29_mul(inv, r));
+      nstore(2 * nd + 1, fq29_mul(inv, l));
+    }
+  }
+  __syncthreads();
+  Fq29 I = nload(kPairT + tid);
+#pragma unroll
+  for (int k = kPer - 1; k >= 0; --k) {
+    const uint32_t e = tid + (uint32_t)k * kPairT;
+    if (e < N) {
+      --cnt;
+      if (cnt == 0) {
+        soa_store(a, A, e, I);
+      } else {
+        Fq29 d = soa_load(a, A, e);
+        soa_store(a, A, e, fq29_mul(I, pre[k]));
+        I = fq29_mul(I, d);
+      }
     }
   }
 }
@@ -607,10 +756,47 @@ __global__ void __launch_bounds__(SNARKV_L2_THREADS) SNARKV_LEVEL2_ATTR
 // and NO degeneracy test here: a flush is a plain store, so the lanes of a wave
 // (which change bucket at different iterations) never wait for each other's
 // checks.  P5 tests every bucket once and redoes the rare bad one carefully.
-template <int RUN>
+// The point an entry refers to, in the memory form of its stream:
+//   packed  (LIMB = false)  the level-1 stream: entry.y indexes the Montgomery point table (G1Packed, 64 B), bit 31 negates
+//   limb    (LIMB = true)   the half-length stream behind the pair level (pair_tree.h): 2 x 9 lazy limbs (72 B) at the
+//                           entry's own position, no sign -- and no 256-bit unpack
+template <bool LIMB>
+struct StreamPoint;
+template <>
+struct StreamPoint<false> {
+  G1Packed k;
+  __device__ __forceinline__ void load(const void* __restrict__ base, uint32_t y) {
+    k = reinterpret_cast<const G1Packed*>(base)[y & kEntryIdx];
+  }
+  __device__ __forceinline__ G1Affine29 get(uint32_t y) const {
+    G1Affine29 p = g1a29_unpack(k);  // 256-bit words -> 9 x 29-bit limbs, in registers
+    if (y >> 31) p.y = fq29_neg(p.y);
+    return p;
+  }
+};
+template <>
+struct StreamPoint<true> {
+  int2 q[9];
+  __device__ __forceinline__ void load(const void* __restrict__ base, uint32_t y) {
+    const int2* src = reinterpret_cast<const int2*>(reinterpret_cast<const int32_t*>(base) + 18 * (size_t)(y & kEntryIdx));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) q[i] = src[i];
+  }
+  __device__ __forceinline__ G1Affine29 get(uint32_t) const {
+    G1Affine29 p;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      (i < 4 ? p.x.v[2 * i] : i == 4 ? p.x.v[8] : p.y.v[2 * i - 9]) = q[i].x;
+      (i < 4 ? p.x.v[2 * i + 1] : i == 4 ? p.y.v[0] : p.y.v[2 * i - 8]) = q[i].y;
+    }
+    return p;
+  }
+};
+
+template <int RUN, bool LIMB>
 __global__ void __launch_bounds__(64, SNARKV_ACC_WAVES)
     k_accumulate(const uint2* __restrict__ entries, const uint32_t* __restrict__ total_ptr,
-                 const G1Packed* __restrict__ pts, G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ seg_ids,
+                 const void* __restrict__ pts, G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ seg_ids,
                  G1Xyzz29* __restrict__ seg_parts, const uint32_t* __restrict__ M, uint32_t mstride, uint32_t key_lo,
                  uint32_t key_hi, uint32_t nkeys, uint32_t run_base) {
   // the part of the sorted stream that belongs to level-1 keys [key_lo, key_hi): a group of windows
@@ -625,23 +811,28 @@ __global__ void __launch_bounds__(64, SNARKV_ACC_WAVES)
   uint32_t cur = entries[begin].x;
   bool first = true, fresh = true;
   G1Xyzz29 acc = xyzz29_identity();
+  // a bucket's part of the run is finished: head partial, or complete interior bucket.  `fresh` here means that part
+  // held skip entries only (pads / cancelled pairs of the pair level): no partial (kNoBucket), the bucket stays zero.
+  auto flush = [&]() {
+    if (first) {
+      seg_ids[2 * slot] = fresh ? kNoBucket : cur;
+      if (!fresh) seg_parts[2 * slot] = acc;
+      first = false;
+    } else if (!fresh) {
+      buckets[cur] = acc;  // complete interior bucket
+    }
+  };
   // software pipeline: the (entry -> point) gather of step e+1 is issued before the ~2 200-instruction
   // mixed addition of step e; two steps per trip with ping-pong registers, so the prefetched point is
   // consumed where it was loaded instead of being copied (18 moves per entry)
-  auto step = [&](const uint2& ent, const G1Packed& pk) {
-    G1Affine29 p = g1a29_unpack(pk);  // 256-bit words -> 9 x 29-bit limbs, in registers
+  auto step = [&](const uint2& ent, const StreamPoint<LIMB>& pk) {
     if (ent.x != cur) {
-      if (first) {
-        seg_ids[2 * slot] = cur;
-        seg_parts[2 * slot] = acc;
-        first = false;
-      } else {
-        buckets[cur] = acc;  // complete interior bucket
-      }
+      flush();
       cur = ent.x;
       fresh = true;
     }
-    if (ent.y >> 31) p.y = fq29_neg(p.y);
+    if (ent.y & kEntrySkip) return;
+    G1Affine29 p = pk.get(ent.y);
     if (fresh) {
       acc.x = p.x;
       acc.y = p.y;
@@ -653,43 +844,52 @@ __global__ void __launch_bounds__(64, SNARKV_ACC_WAVES)
     }
   };
   uint2 ent0 = entries[begin], ent1 = ent0;
-  G1Packed p0 = pts[ent0.y & 0x7FFFFFFFu], p1 = p0;
+  StreamPoint<LIMB> p0, p1;
+  p0.load(pts, ent0.y);
+  p1 = p0;
 #pragma unroll 1
   for (uint32_t e = begin; e < end; e += 2) {
     if (e + 1 < end) {
       ent1 = entries[e + 1];
-      p1 = pts[ent1.y & 0x7FFFFFFFu];
+      p1.load(pts, ent1.y);
     }
     step(ent0, p0);
     if (e + 1 < end) {
       if (e + 2 < end) {
         ent0 = entries[e + 2];
-        p0 = pts[ent0.y & 0x7FFFFFFFu];
+        p0.load(pts, ent0.y);
       }
       step(ent1, p1);
     }
   }
   if (first) {
-    seg_ids[2 * slot] = cur;
-    seg_parts[2 * slot] = acc;
+    seg_ids[2 * slot] = fresh ? kNoBucket : cur;
+    if (!fresh) seg_parts[2 * slot] = acc;
     seg_ids[2 * slot + 1] = kNoBucket;
   } else {
-    seg_ids[2 * slot + 1] = cur;
-    seg_parts[2 * slot + 1] = acc;
+    seg_ids[2 * slot + 1] = fresh ? kNoBucket : cur;
+    if (!fresh) seg_parts[2 * slot + 1] = acc;
   }
 }
 
 // --------------------------------------------------------------- P5
 // Careful recomputation of one bucket straight from its sorted entries (the
 // rare bucket in which a fast addition met P = +-Q: duplicate / opposite bases).
+template <bool LIMB>
 __device__ __noinline__ G1Xyzz29 bucket_from_entries_careful(const uint2* __restrict__ entries,
-                                                             const G1Packed* __restrict__ pts, uint32_t o,
+                                                             const void* __restrict__ pts, uint32_t o,
                                                              uint32_t cnt, uint32_t first, uint32_t stride) {
   G1Xyzz29 acc = xyzz29_identity();
   for (uint32_t e = o + first; e < o + cnt; e += stride) {
     uint2 ent = entries[e];
-    G1Affine29 p = g1a29_unpack(pts[ent.y & 0x7FFFFFFFu]);
-    if (ent.y >> 31) p.y = fq29_neg(p.y);
+    if (ent.y & kEntrySkip) continue;
+    StreamPoint<LIMB> sp;
+    sp.load(pts, ent.y);
+    G1Affine29 p = sp.get(ent.y);
+    if (LIMB) {  // lazy sums of the pair level: the careful adder compares and stores, so squeeze them first
+      p.x = fq29_canon_residue(p.x);
+      p.y = fq29_canon_residue(p.y);
+    }
     xyzz29_madd_careful(acc, p);
   }
   return acc;
@@ -711,9 +911,10 @@ __device__ __forceinline__ void run_span(const PipParams& p, const uint32_t* __r
   s1 = base + (o + cnt - 1 - first) / p.krun;
 }
 
+template <bool LIMB>
 __global__ void __launch_bounds__(64)
     k_combine(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, PipParams p,
-              const uint2* __restrict__ entries, const G1Packed* __restrict__ pts,
+              const uint2* __restrict__ entries, const void* __restrict__ pts,
               const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
               G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list,
               const uint32_t* __restrict__ M, uint32_t b_lo, uint32_t b_hi) {
@@ -746,7 +947,7 @@ __global__ void __launch_bounds__(64)
   }
   if (!touched) acc = buckets[b];  // interior to one run: P4 stored it
   bad = bad || xyzz29_is_degenerate(acc);
-  if (bad) acc = xyzz29_sanitize(bucket_from_entries_careful(entries, pts, o, cnt, 0, 1));
+  if (bad) acc = xyzz29_sanitize(bucket_from_entries_careful<LIMB>(entries, pts, o, cnt, 0, 1));
   if (touched || bad) buckets[b] = acc;
 }
 
@@ -754,9 +955,10 @@ __global__ void __launch_bounds__(64)
 // equal puts n entries into one bucket per window): one 256-lane workgroup per
 // bucket, lane-strided careful adds + LDS tree.  If any partial is degenerate
 // the whole bucket is recomputed carefully from its entries.
+template <bool LIMB>
 __global__ void __launch_bounds__(256)
     k_combine_big(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                  const uint2* __restrict__ entries, const G1Packed* __restrict__ pts,
+                  const uint2* __restrict__ entries, const void* __restrict__ pts,
                   const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
                   G1Xyzz29* __restrict__ buckets, const uint32_t* __restrict__ big_count,
                   const uint32_t* __restrict__ big_list, PipParams p, const uint32_t* __restrict__ M) {
@@ -782,7 +984,7 @@ __global__ void __launch_bounds__(256)
       }
   if (bad) atomicOr(&any_bad, 1);
   __syncthreads();
-  if (any_bad) acc = bucket_from_entries_careful(entries, pts, o, cnt, threadIdx.x, 256);
+  if (any_bad) acc = bucket_from_entries_careful<LIMB>(entries, pts, o, cnt, threadIdx.x, 256);
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (uint32_t st = 128; st >= 1; st >>= 1) {
@@ -1123,8 +1325,33 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   if (((uint32_t)p.W + p.gsz - 1) / p.gsz > 8) p.gsz = ((uint32_t)p.W + 7) / 8;  // at most 8 groups (events, counters)
   if (phases != PIP_PHASE_ALL) p.gsz = (uint32_t)p.W;
   p.krun = ctx->throughput_mode ? (uint32_t)kRunThroughput : latency_run_length((uint64_t)kHalves * n * (uint64_t)p.W);
+  // The pair level (P3b, pair_tree.h): one batched-affine addition level in front of the accumulation.  It adds seven
+  // launches and a latency chain (forward, the inversion levels, ONE field inversion, backward) to an MSM, so it is for
+  // callers that keep several MSMs in flight (the throughput hint; always on a batch's jobs and the chunk pipeline's
+  // lanes).  SNARKV_PAIR_TREE = 0 never, 1 with the hint (default), 2 always.  Same bytes either way.
+  int tree_mode = SNARKV_PAIR_TREE_DEFAULT;
+  if (const char* e = getenv("SNARKV_PAIR_TREE")) tree_mode = atoi(e);
+  const uint32_t nbins_l2 = 1u << p.low_bits;
+  const uint64_t pad_room = (uint64_t)p.nkeys * (nbins_l2 + 2) + 2;  // k_sort_level2, pad mode: room for one pad per bin
+  const bool tree = (tree_mode == 2 || (tree_mode == 1 && ctx->throughput_mode)) && p.gsz == (uint32_t)p.W &&
+                    (uint64_t)kHalves * n < kEntrySkip && max_entries + pad_room < kEntrySkip;
+  p.pad = tree ? 1u : 0u;
+  const uint64_t cap_entries = max_entries + (tree ? pad_room : 0);
+  auto round_up = [](uint64_t v, uint64_t q) { return (v + q - 1) / q * q; };
+  const uint64_t slots_max = (cap_entries + 1) / 2;                        // pair slots (upper bound; the live count is on the device)
+  const uint64_t pairL = round_up((slots_max + kPairM - 1) / kPairM, kPairT);  // lanes of k_pair_fwd / k_pair_bwd
+  const uint64_t pairS = pairL * kPairM;                                   // slot capacity = stride of the prefix array
+  uint64_t binvN[8];
+  int binv_levels = 0;  // binvN[0] = the pair lanes' totals; level q + 1 = the lane totals of level q; the last one <= kBinvFinalMax
+  binvN[0] = pairL;
+  while (binvN[binv_levels] > kBinvFinalMax && binv_levels < 6) {
+    binvN[binv_levels + 1] = round_up((binvN[binv_levels] + kBinvM - 1) / kBinvM, kPairT);
+    ++binv_levels;
+  }
   p.rpw = (uint32_t)(((uint64_t)kHalves * n + p.krun - 1) / p.krun) + 1;
-  uint32_t max_runs = (uint32_t)p.W * p.rpw;
+  uint32_t max_runs = (uint32_t)p.W * p.rpw;  // run slots (head / tail partial each)
+  // ... behind the pair level the runs are cut from the half-length stream, whose pad room can outweigh a tiny MSM's entries
+  if (tree) max_runs = std::max<uint32_t>(max_runs, (uint32_t)((slots_max + p.krun - 1) / p.krun) + 1);
   uint32_t mcount = p.nkeys * p.mstride;
   uint32_t scan_blocks = (mcount + 1023) / 1024;
   uint32_t chunks_per_window = (p.B + kChunk - 1) / kChunk;
@@ -1138,7 +1365,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   SNARKV_TRY(ctx_reserve(ctx, SLOT_OFFSETS, (size_t)p.nb * 4, &d_offsets));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_CURSOR, (size_t)mcount * 4, &d_M));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_BLOCKSUMS, (size_t)scan_blocks * 4 + 64, &d_blocksum));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_ENTRIES, max_entries * 8, &d_entries));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_ENTRIES, cap_entries * 8, &d_entries));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SORT_TMP, max_entries * 8, &d_tmp));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SEG_IDS, (size_t)max_runs * 8, &d_seg_ids));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SEG_PARTIALS, (size_t)max_runs * 2 * sizeof(G1Xyzz29), &d_seg_parts));
@@ -1148,7 +1375,23 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SHIFTED, (size_t)p.W * sizeof(G1Xyzz29), &d_shift));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_MISC, 64, &d_misc));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_BIG_LIST, (size_t)kMaxBig * 4 * 8, &d_big));
-  uint32_t* d_total = (uint32_t*)d_misc;
+  uint32_t* d_total = (uint32_t*)d_misc;  // [0] entries, [1] padded entries, [2] pair slots, [3] = 0, [4..11] big-bucket counters
+  void *d_counts2 = nullptr, *d_offsets2 = nullptr, *d_pair_pfx = nullptr, *d_pair_tot = nullptr, *d_pair_pts = nullptr,
+       *d_pair_entries = nullptr;
+  size_t binv_off[8] = {0};  // level q: values at d_pair_tot + binv_off[q] (9 x binvN[q] words), prefixes right behind
+  if (tree) {
+    SNARKV_TRY(ctx_reserve(ctx, SLOT_COUNTS2, (size_t)p.nb * 4, &d_counts2));
+    SNARKV_TRY(ctx_reserve(ctx, SLOT_OFFSETS2, (size_t)p.nb * 4, &d_offsets2));
+    SNARKV_TRY(ctx_reserve(ctx, SLOT_PAIR_PFX, (size_t)pairS * 36, &d_pair_pfx));
+    size_t words = 0;
+    for (int q = 0; q <= binv_levels; ++q) {
+      binv_off[q] = words;
+      words += 2 * 9 * (size_t)binvN[q];
+    }
+    SNARKV_TRY(ctx_reserve(ctx, SLOT_PAIR_TOT, words * 4, &d_pair_tot));
+    SNARKV_TRY(ctx_reserve(ctx, SLOT_PAIR_PTS, (size_t)pairS * 72, &d_pair_pts));
+    SNARKV_TRY(ctx_reserve(ctx, SLOT_PAIR_ENTRIES, (size_t)pairS * 8, &d_pair_entries));
+  }
   if ((size_t)p.nkeys * 4 > 65536) {
     set_last_error("pippenger: key table too large (nkeys=%u)", p.nkeys);
     return SNARKV_ERR_LENGTH;
@@ -1191,9 +1434,19 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
       hipLaunchKernelGGL(k_sort_scatter, dim3(p.nblk), dim3(SNARKV_TILE_THREADS), lds1, st, (const uint4*)d_glv, p,
                          (const uint32_t*)d_M, (uint2*)d_tmp);
     }
-    size_t lds2 = ((size_t)(1u << p.low_bits) + SNARKV_L2_THREADS + 1) * 4 + (size_t)kSortCap * 8;
+    size_t lds2 = ((size_t)nbins_l2 + SNARKV_L2_THREADS + 1) * 4 + ((size_t)kSortCap + (tree ? nbins_l2 + 4 : 0)) * 8;
+    if (lds2 > 64 * 1024) {
+      static std::atomic<uint64_t> attr2_set{0};  // per device: more dynamic LDS than the 64 KiB default
+      const uint64_t bit = 1ull << (ctx->device & 63);
+      if (!(attr2_set.load(std::memory_order_relaxed) & bit)) {
+        SNARKV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_level2),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr2_set.fetch_or(bit, std::memory_order_relaxed);
+      }
+    }
     hipLaunchKernelGGL(k_sort_level2, dim3(p.nkeys), dim3(SNARKV_L2_THREADS), lds2, st, (const uint2*)d_tmp, (const uint32_t*)d_M,
-                       (const uint32_t*)d_total, p, (uint2*)d_entries, (uint32_t*)d_counts, (uint32_t*)d_offsets);
+                       d_total, p, (uint2*)d_entries, (uint32_t*)d_counts, (uint32_t*)d_offsets, (uint32_t*)d_counts2,
+                       (uint32_t*)d_offsets2);
   }
   STAGE_MARK();  // 3: partition + level-2 sort
   if (phases & PIP_PHASE_ACC) SNARKV_HIP(hipMemsetAsync(d_buckets, 0, (size_t)p.nb * sizeof(G1Xyzz29), st));
@@ -1206,8 +1459,30 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   // accumulations on one stream now LOSES 15-25 % (1.50 -> 1.75-1.89 ms per MSM): 2 731 wavefronts leave a ninth of the
   // slots and the whole drain of every launch empty unless another MSM's accumulation overlaps it.)
   uint32_t* d_big_count = d_total + 4;  // one counter per window group
-  if (phases & PIP_PHASE_ACC) SNARKV_HIP(hipMemsetAsync(d_big_count, 0, 4 * 8, st));
+  if (phases & PIP_PHASE_ACC) SNARKV_HIP(hipMemsetAsync(d_total + 3, 0, 4 * 9, st));  // [3] = 0 (stream start of the pair level's half-length stream) + the counters
   if (tm_acc) SNARKV_HIP(hipEventRecord(ctx->ev[3], st));
+  if (tree && (phases & PIP_PHASE_ACC)) {
+    int32_t* tot0 = (int32_t*)d_pair_tot + binv_off[0];
+    hipLaunchKernelGGL(k_pair_fwd, dim3((uint32_t)(pairL / kPairT)), dim3(kPairT), 0, st, (const uint2*)d_entries,
+                       (const uint32_t*)d_total, (const G1Packed*)d_pts, (int32_t*)d_pair_pfx, (size_t)pairS, tot0, (size_t)pairL);
+    for (int q = 0; q < binv_levels; ++q) {
+      int32_t* a = (int32_t*)d_pair_tot + binv_off[q];
+      hipLaunchKernelGGL(k_binv_up, dim3((uint32_t)(binvN[q + 1] / kPairT)), dim3(kPairT), 0, st, (const int32_t*)a,
+                         (uint32_t)binvN[q], (size_t)binvN[q], a + 9 * binvN[q], (int32_t*)d_pair_tot + binv_off[q + 1],
+                         (size_t)binvN[q + 1]);
+    }
+    hipLaunchKernelGGL(k_binv_final, dim3(1), dim3(kPairT), 0, st, (int32_t*)d_pair_tot + binv_off[binv_levels],
+                       (uint32_t)binvN[binv_levels], (size_t)binvN[binv_levels]);
+    for (int q = binv_levels - 1; q >= 0; --q) {
+      int32_t* a = (int32_t*)d_pair_tot + binv_off[q];
+      hipLaunchKernelGGL(k_binv_down, dim3((uint32_t)(binvN[q + 1] / kPairT)), dim3(kPairT), 0, st, a, (uint32_t)binvN[q],
+                         (size_t)binvN[q], (const int32_t*)(a + 9 * binvN[q]), (const int32_t*)d_pair_tot + binv_off[q + 1],
+                         (size_t)binvN[q + 1]);
+    }
+    hipLaunchKernelGGL(k_pair_bwd, dim3((uint32_t)(pairL / kPairT)), dim3(kPairT), 0, st, (const uint2*)d_entries,
+                       (const uint32_t*)d_total, (const G1Packed*)d_pts, (const int32_t*)d_pair_pfx, (size_t)pairS,
+                       (const int32_t*)tot0, (size_t)pairL, (uint2*)d_pair_entries, (int32_t*)d_pair_pts);
+  }
   // Window groups (opt-in, see p.gsz above), top first: group j = windows [j gsz, (j+1) gsz).  Its accumulation runs on the context's stream;
   // its tail -- combine, bucket reduce, the 2^(c w) shift chain (the longest for the TOP windows: c w doublings, a
   // dependency chain no lane count shortens) -- runs on a side stream under the accumulation of the groups below it.
@@ -1225,13 +1500,20 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   }
   for (int j = (int)ngroups - 1; j >= 0; --j) {
     const uint32_t w0 = (uint32_t)j * p.gsz, w1 = std::min<uint32_t>((uint32_t)p.W, w0 + p.gsz), wcount = w1 - w0;
-    const uint32_t lanes = wcount * p.rpw;
-    auto acc_kernel = p.krun == 16u ? k_accumulate<16> : p.krun == 32u ? k_accumulate<32>
-                      : p.krun == (uint32_t)kRun ? k_accumulate<kRun> : k_accumulate<kRunThroughput>;
-    if (phases & PIP_PHASE_ACC)
+    const uint32_t lanes = tree ? (uint32_t)((slots_max + p.krun - 1) / p.krun) : wcount * p.rpw;
+    auto acc_kernel = p.krun == 16u ? k_accumulate<16, false> : p.krun == 32u ? k_accumulate<32, false>
+                      : p.krun == (uint32_t)kRun ? k_accumulate<kRun, false> : k_accumulate<kRunThroughput, false>;
+    auto acc_tree = p.krun == 16u ? k_accumulate<16, true> : p.krun == 32u ? k_accumulate<32, true>
+                    : p.krun == (uint32_t)kRun ? k_accumulate<kRun, true> : k_accumulate<kRunThroughput, true>;
+    if ((phases & PIP_PHASE_ACC) && !tree)
       hipLaunchKernelGGL(acc_kernel, dim3((lanes + 63) / 64), dim3(64), 0, st, (const uint2*)d_entries,
-                         (const uint32_t*)d_total, (const G1Packed*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
+                         (const uint32_t*)d_total, (const void*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
                          (G1Xyzz29*)d_seg_parts, (const uint32_t*)d_M, p.mstride, w0 * p.SB, w1 * p.SB, p.nkeys, w0 * p.rpw);
+    // behind the pair level: the half-length stream [0, misc[2]) of (entry, lazy-limb point) pairs, one window group
+    if ((phases & PIP_PHASE_ACC) && tree)
+      hipLaunchKernelGGL(acc_tree, dim3((lanes + 63) / 64), dim3(64), 0, st, (const uint2*)d_pair_entries,
+                         (const uint32_t*)(d_total + 2), (const void*)d_pair_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
+                         (G1Xyzz29*)d_seg_parts, (const uint32_t*)(d_total + 3), 0u, 0u, p.nkeys, p.nkeys, 0u);
     hipStream_t ts = st;
     if (j > 0) {
       ts = ctx->sub[j & 1]->stream;
@@ -1242,18 +1524,21 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
       if (tm_acc) SNARKV_HIP(hipEventRecord(ctx->ev[4], st));
     }
     if (phases & PIP_PHASE_ACC) {
-      hipLaunchKernelGGL(k_combine, dim3((wcount * p.B + 63) / 64), dim3(64), 0, ts, (const uint32_t*)d_counts,
-                         (const uint32_t*)d_offsets, p, (const uint2*)d_entries, (const G1Packed*)d_pts,
-                         (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets, d_big_count + j,
-                         (uint32_t*)d_big + (size_t)j * kMaxBig, (const uint32_t*)d_M, w0 * p.B, w1 * p.B);
+      // the stream the partials were cut from: the sorted entries, or the pair level's half-length stream
+      const uint32_t* cc = (const uint32_t*)(tree ? d_counts2 : d_counts);
+      const uint32_t* co = (const uint32_t*)(tree ? d_offsets2 : d_offsets);
+      const uint2* ce = (const uint2*)(tree ? d_pair_entries : d_entries);
+      const void* cp = tree ? (const void*)d_pair_pts : (const void*)d_pts;
+      const uint32_t* cm = tree ? (const uint32_t*)(d_total + 3) : (const uint32_t*)d_M;
+      hipLaunchKernelGGL(tree ? k_combine<true> : k_combine<false>, dim3((wcount * p.B + 63) / 64), dim3(64), 0, ts, cc, co, p,
+                         ce, cp, (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets,
+                         d_big_count + j, (uint32_t*)d_big + (size_t)j * kMaxBig, cm, w0 * p.B, w1 * p.B);
       // one workgroup per oversized bucket; idle workgroups exit at once
       uint32_t big_grid = (uint32_t)(lanes / kBigSpan + 1);
       if (big_grid > kMaxBig) big_grid = kMaxBig;
-      hipLaunchKernelGGL(k_combine_big, dim3(big_grid), dim3(256), 0, ts, (const uint32_t*)d_counts,
-                         (const uint32_t*)d_offsets, (const uint2*)d_entries, (const G1Packed*)d_pts,
+      hipLaunchKernelGGL(tree ? k_combine_big<true> : k_combine_big<false>, dim3(big_grid), dim3(256), 0, ts, cc, co, ce, cp,
                          (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets,
-                         (const uint32_t*)(d_big_count + j), (const uint32_t*)d_big + (size_t)j * kMaxBig, p,
-                         (const uint32_t*)d_M);
+                         (const uint32_t*)(d_big_count + j), (const uint32_t*)d_big + (size_t)j * kMaxBig, p, cm);
       if (tm_acc) SNARKV_HIP(hipEventRecord(ctx->ev[5], st));
     }
     if (j == 0) STAGE_MARK();  // 5: bucket combine (the bottom group's: the exposed one)
