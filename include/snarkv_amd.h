@@ -276,6 +276,18 @@ void snarkv_mgpu_destroy(snarkv_mgpu* mg);
 int snarkv_mgpu_size(const snarkv_mgpu* mg);
 snarkv_ctx* snarkv_mgpu_ctx(snarkv_mgpu* mg, int rank);              /* rank's context (to allocate / fill its shard) */
 int snarkv_mgpu_shard(const snarkv_mgpu* mg, size_t n_total, int rank, size_t* lo, size_t* hi);
+/* Directed pairs of DISTINCT devices of the handle: direct (xGMI) peer access enabled / not offered by the platform /
+ * offered but refused.  Copies work in all three cases (the runtime stages what it must); the last refusal's text is
+ * in snarkv_last_error() after snarkv_mgpu_create. */
+int snarkv_mgpu_peer_access(const snarkv_mgpu* mg, int* enabled, int* unavailable, int* failed);
+/* How the 144-byte partials travel: point-to-point peer copies to rank 0 + fold + broadcast of the result (default), or
+ * ONE grouped RCCL all-gather over xGMI (`ncclCommInitAll` over the handle's devices, which must be distinct) after
+ * which every rank folds.  Either way every rank's device holds the result afterwards (snarkv_mgpu_result_dev). */
+#define SNARKV_MGPU_TRANSPORT_PEER_COPY 0
+#define SNARKV_MGPU_TRANSPORT_RCCL 1
+int snarkv_mgpu_set_transport(snarkv_mgpu* mg, int transport);
+/* device pointer (on rank's device) of the 64-byte affine result of the handle's last MSM: all-reduce semantics */
+const void* snarkv_mgpu_result_dev(const snarkv_mgpu* mg, int rank);
 /* host buffers of the WHOLE MSM (sharded, staged and reduced inside); n >= 1 */
 int snarkv_g1_msm_pippenger_mgpu(snarkv_mgpu* mg, const uint8_t* scalars32, const uint8_t* points64, size_t n,
                                  int variant, uint8_t out64[64]);

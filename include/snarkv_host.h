@@ -12,6 +12,8 @@
  *                                         all 2N MSMs in ONE segmented device launch; output: every `KzgAccumulator`
  *   snarkv_host_kzg_as_accumulate         `KzgAs::create_proof` (non-zk; pcs/kzg/accumulation.rs:148-197) over m accumulators
  *                                         with a fresh Keccak (EVM) transcript, as examples/evm-verifier-with-accumulator.rs:357-380
+ *   snarkv_host_kzg_as_create_proof / _verify  the same in full: zk blind branch (accumulation.rs:163-175), Keccak or
+ *                                         Poseidon transcript, and `KzgAsProof::read` + `verify` on caller-supplied bytes
  *   snarkv_host_kzg_decide / _decide_all  `AccumulationDecider::{decide, decide_all}` (pcs/kzg/decider.rs:70-93)
  *   snarkv_host_aggregate                 the whole job: succinct-verify N proofs -> accumulate -> decide
  *   snarkv_host_plonk_verify              `PlonkVerifier::verify` (verifier/plonk.rs:133: succinct verify + decide_all)
@@ -91,6 +93,19 @@ int snarkv_host_plonk_succinct_verify_batch(const snarkv_host_protocol* protocol
 
 /* m accumulators -> one (KzgAs::create_proof, non-zk, fresh EVM transcript).  r_out32 (optional): the challenge r. */
 int snarkv_host_kzg_as_accumulate(const uint8_t* accs128, uint32_t m, uint8_t acc_out[128], uint8_t* r_out32);
+/* `KzgAs::create_proof` in full (pcs/kzg/accumulation.rs:148-197) over a FRESH transcript of kind `transcript`
+ * (SNARKV_HOST_TRANSCRIPT_EVM or _POSEIDON).  pk_g_sg128 = NULL: non-zk.  Otherwise the proving key's (g, s_g) pair
+ * (2 x 64 B) and `blind_scalar32` (32 B LE canonical Fr: what the reference draws from its rng) give the zk branch
+ * (accumulation.rs:163-175): the blind pair (s_g * b, g * b) is written to the transcript and accumulated last.
+ * Out: the accumulator, the bytes the transcript produced (the `KzgAsProof` a verifier reads; empty for non-zk;
+ * *proof_len is always set, SNARKV_HOST_ERR_CAPACITY when proof_cap is too small), and the challenge r. */
+int snarkv_host_kzg_as_create_proof(const uint8_t* accs128, uint32_t m, int transcript, const uint8_t* pk_g_sg128,
+                                    const uint8_t* blind_scalar32, uint8_t acc_out[128], uint8_t* proof_out,
+                                    size_t proof_cap, size_t* proof_len, uint8_t* r_out32);
+/* `KzgAsProof::read` + `KzgAs::verify` (accumulation.rs:114-137, 41-63) on CALLER-SUPPLIED proof bytes: the verifier's
+ * side of the call above (zk != 0: the proof carries the blind pair).  Bytes left over -> SNARKV_HOST_ERR_TRAILING. */
+int snarkv_host_kzg_as_verify(const uint8_t* accs128, uint32_t m, int transcript, int zk, const uint8_t* proof,
+                              size_t proof_len, uint8_t acc_out[128], uint8_t* r_out32);
 
 /* 1 accept / 0 reject.  decide_all: one batched device launch; ok_out (optional) = per-accumulator verdicts. */
 int snarkv_host_kzg_decide(const snarkv_host_dk* dk, const uint8_t acc128[128]);

@@ -85,6 +85,9 @@ _SIGNATURES = {
     "snarkv_mgpu_size": (_int, [_vp]),
     "snarkv_mgpu_ctx": (_vp, [_vp, _int]),
     "snarkv_mgpu_shard": (_int, [_vp, _sz, _int, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "snarkv_mgpu_peer_access": (_int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "snarkv_mgpu_set_transport": (_int, [_vp, _int]),
+    "snarkv_mgpu_result_dev": (_vp, [_vp, _int]),
     "snarkv_g1_msm_pippenger_mgpu": (_int, [_vp, _cp, _cp, _sz, _int, _vp]),
     "snarkv_g1_msm_pippenger_mgpu_dev": (_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_sz), _int, _int, _vp]),
     "snarkv_kzg_decide_batch_mgpu": (_int, [_vp, _cp, _cp, _cp, _cp, _sz, _vp]),
@@ -186,6 +189,22 @@ class MultiGpu:
             self.close()
         except Exception:
             pass
+
+    PEER_COPY, RCCL = 0, 1
+
+    def peer_access(self):
+        """(enabled, unavailable, failed) directed pairs of distinct devices: direct xGMI access on / not offered / refused"""
+        a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _check(self._lib.snarkv_mgpu_peer_access(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    def set_transport(self, transport):
+        """PEER_COPY (default) or RCCL (`ncclCommInitAll` + one grouped `ncclAllGather` of the 144-byte partials)"""
+        _check(self._lib.snarkv_mgpu_set_transport(self._h, transport))
+
+    def result_dev(self, rank):
+        """device pointer of rank's copy of the last MSM's 64-byte result (every rank holds it: all-reduce semantics)"""
+        return self._lib.snarkv_mgpu_result_dev(self._h, rank)
 
     def shard(self, n_total, rank):
         lo, hi = ctypes.c_size_t(0), ctypes.c_size_t(0)

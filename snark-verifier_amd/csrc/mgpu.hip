@@ -18,8 +18,18 @@
 //   snarkv_kzg_decide_batch_mgpu         `decide_all` (pcs/kzg/decider.rs:84-93) with the accumulators sharded over the
 //                                        ranks; no exchange (independent pairings), m verdict bytes gathered by the host.
 //
-// No collective library is needed for either: the only inter-GPU traffic is point-to-point copies, which is what RCCL's
-// all-gather of 144 B per rank would degenerate to (one process per GPU keeps using RCCL: snark-verifier_amd/distributed.py).
+// Transports of the 144-byte partials (snarkv_mgpu_set_transport):
+//   SNARKV_MGPU_TRANSPORT_PEER_COPY (default)  hipMemcpyPeerAsync to rank 0's device, fold there, the 64-byte result
+//                                              broadcast back so that EVERY rank's device holds it (all-reduce semantics,
+//                                              SURVEY.md 8e); no collective library involved
+//   SNARKV_MGPU_TRANSPORT_RCCL                 `ncclCommInitAll` over the handle's devices + ONE grouped `ncclAllGather`
+//                                              of 144 B per rank over xGMI -- what BASELINE's north_star names -- after
+//                                              which every rank folds all partials itself.  librccl is resolved at run
+//                                              time (dlopen: the copy already in the process, e.g. torch's, else
+//                                              /opt/rocm/lib) so the library carries no link-time dependency on it; RCCL
+//                                              refuses a device listed twice, so emulated ranks cannot use it.
+// (One process per GPU keeps using RCCL through torch.distributed: snark-verifier_amd/distributed.py.)
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -32,10 +42,50 @@ struct snarkv_mgpu {
   std::vector<hipEvent_t> filled;   // bucket-sharded: rank's grid is complete
   std::vector<void*> d_gather;      // on rank 0's device: world x 144 B
   std::vector<void*> d_part;        // per rank: its 144-byte partial
+  std::vector<void*> d_result;      // per rank: the 64-byte affine result of the last MSM (all-reduce semantics)
+  std::vector<void*> d_gather_all;  // RCCL transport: per rank world x 144 B
   std::vector<snarkv_dk*> dk;       // decide: one prepared key per rank (lazily, keyed by the last key bytes)
   uint8_t dk_bytes[320];
   bool dk_valid = false;
+  int transport = 0;
+  std::vector<void*> comms;         // RCCL transport: one ncclComm_t per rank (ncclCommInitAll)
+  int peer_enabled = 0, peer_unavailable = 0, peer_failed = 0;  // directed pairs of DISTINCT devices
 };
+
+namespace {
+// the five RCCL entry points of the transport, resolved at run time; rccl.h is not needed for these signatures
+struct RcclApi {
+  void* lib = nullptr;
+  int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+  int (*CommDestroy)(void* comm) = nullptr;
+  int (*AllGather)(const void* send, void* recv, size_t count, int datatype, void* comm, hipStream_t stream) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi* rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* nm : names)
+      if ((api.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD))) break;  // a copy already in the process (torch's) first
+    for (const char* nm : names)
+      if (!api.lib && (api.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+    if (api.lib) {
+      api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.lib, "ncclCommInitAll");
+      api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+      api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+      api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
+      api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    }
+  }
+  return (api.lib && api.CommInitAll && api.CommDestroy && api.AllGather && api.GroupStart && api.GroupEnd) ? &api : nullptr;
+}
+constexpr int kNcclUint8 = 1;  // ncclDataType_t: ncclInt8 = 0, ncclUint8 = 1 (nccl.h / rccl.h, stable ABI)
+}  // namespace
 
 namespace snarkv {
 
@@ -54,24 +104,54 @@ static int wait_for(snarkv_mgpu* mg, int g, int src) {
   return SNARKV_OK;
 }
 
-// partials of all ranks -> rank 0's device -> fold -> 64 host bytes
+// partials of all ranks -> fold -> the 64-byte result on EVERY rank's device (mg->d_result) and in out64
 static int gather_fold(snarkv_mgpu* mg, uint8_t out64[64]) {
   const int world = (int)mg->ctx.size();
   snarkv_ctx* c0 = mg->ctx[0];
-  for (int g = 0; g < world; ++g) {
-    snarkv_ctx* c = mg->ctx[g];
-    SNARKV_HIP(hipSetDevice(c->device));
-    // the copy is enqueued on the PRODUCING rank's stream (ordered after its kernels), then rank 0 waits for it
-    SNARKV_HIP(hipMemcpyPeerAsync((char*)mg->d_gather[0] + (size_t)g * SNARKV_G1_PARTIAL_BYTES, c0->device, mg->d_part[g],
-                                  c->device, SNARKV_G1_PARTIAL_BYTES, c->stream));
-    if (g != 0) SNARKV_TRY(wait_for(mg, 0, g));
+  if (mg->transport == SNARKV_MGPU_TRANSPORT_RCCL) {
+    RcclApi* nc = rccl_api();
+    if (!nc || (int)mg->comms.size() != world) {
+      set_last_error("mgpu: RCCL transport selected but not initialised");
+      return SNARKV_ERR_DEVICE;
+    }
+    // one grouped all-gather: rank g contributes its 144-byte partial, every rank receives [rank][144]
+    int rc = nc->GroupStart();
+    for (int g = 0; g < world && rc == 0; ++g) {
+      SNARKV_HIP(hipSetDevice(mg->ctx[g]->device));
+      rc = nc->AllGather(mg->d_part[g], mg->d_gather_all[g], SNARKV_G1_PARTIAL_BYTES, kNcclUint8, mg->comms[g], mg->ctx[g]->stream);
+    }
+    int rc2 = nc->GroupEnd();
+    if (rc != 0 || rc2 != 0) {
+      set_last_error("mgpu: ncclAllGather failed: %s", nc->GetErrorString ? nc->GetErrorString(rc ? rc : rc2) : "?");
+      return SNARKV_ERR_DEVICE;
+    }
+    for (int g = 0; g < world; ++g) {  // every rank folds all partials itself: all ranks hold the identical result
+      SNARKV_HIP(hipSetDevice(mg->ctx[g]->device));
+      SNARKV_TRY(launch_fold_partials(mg->ctx[g], mg->d_gather_all[g], (size_t)world, mg->d_result[g]));
+    }
+  } else {
+    for (int g = 0; g < world; ++g) {
+      snarkv_ctx* c = mg->ctx[g];
+      SNARKV_HIP(hipSetDevice(c->device));
+      // the copy is enqueued on the PRODUCING rank's stream (ordered after its kernels), then rank 0 waits for it
+      SNARKV_HIP(hipMemcpyPeerAsync((char*)mg->d_gather[0] + (size_t)g * SNARKV_G1_PARTIAL_BYTES, c0->device, mg->d_part[g],
+                                    c->device, SNARKV_G1_PARTIAL_BYTES, c->stream));
+      if (g != 0) SNARKV_TRY(wait_for(mg, 0, g));
+    }
+    SNARKV_HIP(hipSetDevice(c0->device));
+    SNARKV_TRY(launch_fold_partials(c0, mg->d_gather[0], (size_t)world, mg->d_result[0]));
+    // ... and back: the folded 64 bytes to every other rank's device (ordered after the fold: on rank 0's stream)
+    for (int g = 1; g < world; ++g)
+      SNARKV_HIP(hipMemcpyPeerAsync(mg->d_result[g], mg->ctx[g]->device, mg->d_result[0], c0->device, 64, c0->stream));
   }
   SNARKV_HIP(hipSetDevice(c0->device));
-  void* d_out;
-  SNARKV_TRY(ctx_reserve(c0, SLOT_OUT, 64, &d_out));
-  SNARKV_TRY(launch_fold_partials(c0, mg->d_gather[0], (size_t)world, d_out));
-  SNARKV_HIP(hipMemcpyAsync(out64, d_out, 64, hipMemcpyDeviceToHost, c0->stream));
+  SNARKV_HIP(hipMemcpyAsync(out64, mg->d_result[0], 64, hipMemcpyDeviceToHost, c0->stream));
   SNARKV_HIP(hipStreamSynchronize(c0->stream));
+  if (mg->transport == SNARKV_MGPU_TRANSPORT_RCCL)
+    for (int g = 1; g < world; ++g) {  // the other ranks' folds ran on their own streams
+      SNARKV_HIP(hipSetDevice(mg->ctx[g]->device));
+      SNARKV_HIP(hipStreamSynchronize(mg->ctx[g]->stream));
+    }
   return SNARKV_OK;
 }
 
@@ -169,23 +249,94 @@ int snarkv_mgpu_create(const int* devices, int n, snarkv_mgpu** out) {
     if (hipMalloc(&p, SNARKV_G1_PARTIAL_BYTES) != hipSuccess) return fail(SNARKV_ERR_DEVICE);
     mg->d_part.push_back(p);
   }
+  for (int g = 0; g < n; ++g) {
+    (void)hipSetDevice(devices[g]);
+    void* p = nullptr;
+    if (hipMalloc(&p, 64) != hipSuccess) return fail(SNARKV_ERR_DEVICE);
+    mg->d_result.push_back(p);
+  }
   (void)hipSetDevice(devices[0]);
   void* gbuf = nullptr;
   if (hipMalloc(&gbuf, (size_t)n * SNARKV_G1_PARTIAL_BYTES) != hipSuccess) return fail(SNARKV_ERR_DEVICE);
   mg->d_gather.push_back(gbuf);
-  // direct xGMI access between distinct devices where the platform allows it (peer copies work either way)
+  // Direct xGMI access between DISTINCT devices where the platform allows it.  Peer copies work either way (the runtime
+  // stages through the host when it must), so a pair that cannot be enabled is not fatal -- but it is not silent either:
+  // the counts are kept (snarkv_mgpu_peer_access) and the last refusal is left in snarkv_last_error().
   for (int a = 0; a < n; ++a)
     for (int b = 0; b < n; ++b) {
+      if (devices[a] == devices[b]) continue;
+      bool seen = false;  // count a directed device pair once, however many ranks share the devices
+      for (int a2 = 0; a2 <= a && !seen; ++a2)
+        for (int b2 = 0; b2 < (a2 == a ? b : n) && !seen; ++b2) seen = devices[a2] == devices[a] && devices[b2] == devices[b];
+      if (seen) continue;
       int can = 0;
-      if (devices[a] != devices[b] && hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
-        (void)hipSetDevice(devices[a]);
-        hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
-        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+      hipError_t e = hipDeviceCanAccessPeer(&can, devices[a], devices[b]);
+      if (e != hipSuccess || !can) {
+        ++mg->peer_unavailable;
+        set_last_error("mgpu: device %d cannot access device %d directly (%s): copies between them are staged by the runtime",
+                       devices[a], devices[b], e != hipSuccess ? hipGetErrorString(e) : "hipDeviceCanAccessPeer = 0");
+        (void)hipGetLastError();
+        continue;
       }
+      (void)hipSetDevice(devices[a]);
+      e = hipDeviceEnablePeerAccess(devices[b], 0);
+      if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) {
+        ++mg->peer_enabled;
+      } else {
+        ++mg->peer_failed;
+        set_last_error("mgpu: hipDeviceEnablePeerAccess(%d -> %d) failed: %s", devices[a], devices[b], hipGetErrorString(e));
+      }
+      (void)hipGetLastError();
     }
-  (void)hipGetLastError();
   *out = mg;
   return SNARKV_OK;
+}
+
+int snarkv_mgpu_peer_access(const snarkv_mgpu* mg, int* enabled, int* unavailable, int* failed) {
+  if (!mg) return SNARKV_ERR_ARG;
+  if (enabled) *enabled = mg->peer_enabled;
+  if (unavailable) *unavailable = mg->peer_unavailable;
+  if (failed) *failed = mg->peer_failed;
+  return SNARKV_OK;
+}
+
+int snarkv_mgpu_set_transport(snarkv_mgpu* mg, int transport) {
+  if (!mg || (transport != SNARKV_MGPU_TRANSPORT_PEER_COPY && transport != SNARKV_MGPU_TRANSPORT_RCCL)) return SNARKV_ERR_ARG;
+  if (transport == SNARKV_MGPU_TRANSPORT_RCCL && mg->comms.empty()) {
+    const int world = (int)mg->ctx.size();
+    RcclApi* nc = rccl_api();
+    if (!nc) {
+      set_last_error("mgpu: librccl could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+      return SNARKV_ERR_DEVICE;
+    }
+    std::vector<int> devs(world);
+    for (int g = 0; g < world; ++g) devs[g] = mg->ctx[g]->device;
+    for (int a = 0; a < world; ++a)
+      for (int b = a + 1; b < world; ++b)
+        if (devs[a] == devs[b]) {
+          set_last_error("mgpu: the RCCL transport needs distinct devices (device %d is listed twice)", devs[a]);
+          return SNARKV_ERR_ARG;
+        }
+    std::vector<void*> comms(world, nullptr);
+    int rc = nc->CommInitAll(comms.data(), world, devs.data());
+    if (rc != 0) {
+      set_last_error("mgpu: ncclCommInitAll over %d devices failed: %s", world, nc->GetErrorString ? nc->GetErrorString(rc) : "?");
+      return SNARKV_ERR_DEVICE;
+    }
+    mg->comms = comms;
+    for (int g = 0; g < world; ++g) {
+      SNARKV_HIP(hipSetDevice(devs[g]));
+      void* p = nullptr;
+      SNARKV_HIP(hipMalloc(&p, (size_t)world * SNARKV_G1_PARTIAL_BYTES));
+      mg->d_gather_all.push_back(p);
+    }
+  }
+  mg->transport = transport;
+  return SNARKV_OK;
+}
+
+const void* snarkv_mgpu_result_dev(const snarkv_mgpu* mg, int rank) {
+  return (mg && rank >= 0 && rank < (int)mg->d_result.size()) ? mg->d_result[rank] : nullptr;
 }
 
 void snarkv_mgpu_destroy(snarkv_mgpu* mg) {
@@ -199,6 +350,17 @@ void snarkv_mgpu_destroy(snarkv_mgpu* mg) {
     (void)hipSetDevice(mg->ctx[g]->device);
     (void)hipFree(mg->d_part[g]);
   }
+  for (size_t g = 0; g < mg->d_result.size(); ++g) {
+    (void)hipSetDevice(mg->ctx[g]->device);
+    (void)hipFree(mg->d_result[g]);
+  }
+  for (size_t g = 0; g < mg->d_gather_all.size(); ++g) {
+    (void)hipSetDevice(mg->ctx[g]->device);
+    (void)hipFree(mg->d_gather_all[g]);
+  }
+  if (RcclApi* nc = mg->comms.empty() ? nullptr : rccl_api())
+    for (void* c : mg->comms)
+      if (c) (void)nc->CommDestroy(c);
   if (!mg->d_gather.empty()) {
     (void)hipSetDevice(mg->ctx[0]->device);
     (void)hipFree(mg->d_gather[0]);

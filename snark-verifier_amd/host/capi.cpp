@@ -166,6 +166,42 @@ int aggregate_mos(const PlonkProtocol& pr, const KzgDecidingKey& dk, int transcr
 
 }  // namespace
 
+namespace {
+// `KzgAs::create_proof` over a fresh transcript of kind TR, then `KzgAsProof::read` of the bytes it wrote for r
+template <class TR>
+int kzg_as_create_proof_tr(const std::vector<KzgAccumulator>& accs, const KzgAsProvingKey& pk, const Fr& blind,
+                           uint8_t acc_out[128], std::vector<uint8_t>& proof, uint8_t* r_out32) {
+  TR t;
+  auto acc = KzgAs<Gwc19>::create_proof(pk, accs, t, blind);
+  if (!acc.ok()) return error_code(acc.err);
+  acc.value->to_bytes(acc_out);
+  proof = t.finalize();
+  if (r_out32) {
+    TR rd(proof);
+    auto pf = KzgAsProof::read(KzgAsVerifyingKey{pk.zk()}, accs, rd);
+    if (!pf.ok()) return error_code(pf.err);
+    pf.value->r.to_bytes(r_out32);
+  }
+  return 1;
+}
+template <class TR>
+int kzg_as_verify_tr(const std::vector<KzgAccumulator>& accs, bool zk, const uint8_t* proof, size_t proof_len,
+                     uint8_t acc_out[128], uint8_t* r_out32) {
+  TR t(std::vector<uint8_t>(proof, proof + proof_len));
+  auto pf = KzgAs<Gwc19>::read_proof(KzgAsVerifyingKey{zk}, accs, t);
+  if (!pf.ok()) return error_code(pf.err);
+  if (t.remaining() != 0) {
+    g_last_error = "trailing bytes after the accumulation proof";
+    return SNARKV_HOST_ERR_TRAILING;
+  }
+  auto acc = KzgAs<Gwc19>::verify(KzgAsVerifyingKey{zk}, accs, *pf.value);
+  if (!acc.ok()) return error_code(acc.err);
+  acc.value->to_bytes(acc_out);
+  if (r_out32) pf.value->r.to_bytes(r_out32);
+  return 1;
+}
+}  // namespace
+
 extern "C" {
 
 const char* snarkv_host_last_error(void) { return g_last_error.c_str(); }
@@ -286,6 +322,46 @@ int snarkv_host_kzg_as_accumulate(const uint8_t* accs128, uint32_t m, uint8_t ac
     acc.value->to_bytes(acc_out);
     if (r_out32) proof.value->r.to_bytes(r_out32);
     return 1;
+  });
+}
+
+int snarkv_host_kzg_as_create_proof(const uint8_t* accs128, uint32_t m, int transcript, const uint8_t* pk_g_sg128,
+                                    const uint8_t* blind_scalar32, uint8_t acc_out[128], uint8_t* proof_out,
+                                    size_t proof_cap, size_t* proof_len, uint8_t* r_out32) {
+  if (!accs128 || !acc_out || (pk_g_sg128 && !blind_scalar32)) return arg_error("null argument");
+  return guarded([&] {
+    auto accs = accs_from_bytes(accs128, m);
+    KzgAsProvingKey pk;
+    Fr blind;
+    if (pk_g_sg128) {  // zero-knowledge: the blind pair (s_g * b, g * b) goes into the proof (accumulation.rs:163-175)
+      pk.g = std::make_pair(G1Affine::from_bytes(pk_g_sg128), G1Affine::from_bytes(pk_g_sg128 + 64));
+      if (!Fr::from_bytes(blind_scalar32, &blind)) return arg_error("blind scalar is not a canonical Fr");
+    }
+    std::vector<uint8_t> proof;
+    int rc = transcript == SNARKV_HOST_TRANSCRIPT_EVM ? kzg_as_create_proof_tr<EvmTranscript>(accs, pk, blind, acc_out, proof, r_out32)
+             : transcript == SNARKV_HOST_TRANSCRIPT_POSEIDON ? kzg_as_create_proof_tr<PoseidonTranscript>(accs, pk, blind, acc_out, proof, r_out32)
+                                                             : arg_error("unknown transcript kind");
+    if (rc != 1) return rc;
+    if (proof_len) *proof_len = proof.size();
+    if (proof.size() > proof_cap || (proof.size() && !proof_out)) {
+      g_last_error = "proof buffer too small";
+      return SNARKV_HOST_ERR_CAPACITY;
+    }
+    if (proof.size()) memcpy(proof_out, proof.data(), proof.size());
+    return 1;
+  });
+}
+
+int snarkv_host_kzg_as_verify(const uint8_t* accs128, uint32_t m, int transcript, int zk, const uint8_t* proof,
+                              size_t proof_len, uint8_t acc_out[128], uint8_t* r_out32) {
+  if (!accs128 || !acc_out || (proof_len && !proof)) return arg_error("null argument");
+  return guarded([&] {
+    auto accs = accs_from_bytes(accs128, m);
+    static const uint8_t none = 0;
+    const uint8_t* pb = proof_len ? proof : &none;
+    if (transcript == SNARKV_HOST_TRANSCRIPT_EVM) return kzg_as_verify_tr<EvmTranscript>(accs, zk != 0, pb, proof_len, acc_out, r_out32);
+    if (transcript == SNARKV_HOST_TRANSCRIPT_POSEIDON) return kzg_as_verify_tr<PoseidonTranscript>(accs, zk != 0, pb, proof_len, acc_out, r_out32);
+    return arg_error("unknown transcript kind");
   });
 }
 

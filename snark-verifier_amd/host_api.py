@@ -35,6 +35,8 @@ _SIGNATURES = {
     "snarkv_host_plonk_succinct_verify_batch": (_int, [_vp, _vp, _int, _int, _cp, _sz, _cp, _sz, _u32, _int, _vp, _sz,
                                                         ctypes.POINTER(_u32)]),
     "snarkv_host_kzg_as_accumulate": (_int, [_cp, _u32, _vp, _vp]),
+    "snarkv_host_kzg_as_create_proof": (_int, [_cp, _u32, _int, _cp, _cp, _vp, _vp, _sz, _psz, _vp]),
+    "snarkv_host_kzg_as_verify": (_int, [_cp, _u32, _int, _int, _cp, _sz, _vp, _vp]),
     "snarkv_host_kzg_decide": (_int, [_vp, _cp]),
     "snarkv_host_kzg_decide_all": (_int, [_vp, _cp, _u32, _vp]),
     "snarkv_host_aggregate": (_int, [_vp, _vp, _int, _int, _cp, _sz, _cp, _sz, _u32, ctypes.c_uint,
@@ -197,6 +199,26 @@ def kzg_as_accumulate(accs):
     L = load_library()
     acc, r = ctypes.create_string_buffer(128), ctypes.create_string_buffer(32)
     _check(L.snarkv_host_kzg_as_accumulate(bytes(accs), len(accs) // 128, acc, r))
+    return acc.raw, r.raw
+
+
+def kzg_as_create_proof(accs, transcript=TRANSCRIPT_EVM, pk=None, blind_scalar=None):
+    """`KzgAs::create_proof` in full (accumulation.rs:148-197): `pk` = (g | s_g) 128 B and `blind_scalar` 32 B select the zk
+    branch.  -> (accumulator 128 B, proof bytes, challenge r 32 B)"""
+    L = load_library()
+    acc, r = ctypes.create_string_buffer(128), ctypes.create_string_buffer(32)
+    proof, n = ctypes.create_string_buffer(256), ctypes.c_size_t(0)
+    _check(L.snarkv_host_kzg_as_create_proof(bytes(accs), len(accs) // 128, transcript, pk, blind_scalar, acc, proof, len(proof),
+                                             ctypes.byref(n), r))
+    return acc.raw, proof.raw[: n.value], r.raw
+
+
+def kzg_as_verify(accs, proof, transcript=TRANSCRIPT_EVM, zk=False):
+    """`KzgAsProof::read` + `KzgAs::verify` (accumulation.rs:114-137, 41-63) on caller-supplied proof bytes
+    -> (accumulator 128 B, challenge r 32 B)"""
+    L = load_library()
+    acc, r = ctypes.create_string_buffer(128), ctypes.create_string_buffer(32)
+    _check(L.snarkv_host_kzg_as_verify(bytes(accs), len(accs) // 128, transcript, 1 if zk else 0, bytes(proof), len(proof), acc, r))
     return acc.raw, r.raw
 
 

@@ -220,3 +220,55 @@ def test_kzg_as_over_the_real_transcripts(H, kind):
         g2 = O.g2_to_bytes(O.G2_GEN)
         s_g2 = O.g2_to_bytes(O.g2_mul(O.G2_GEN, SECRET))
         assert H.hd_decide_all(g1(O.G1_GEN), g2, s_g2, acc_v, 1, 1) == 1
+
+
+@pytest.mark.parametrize("kind", ["evm", "poseidon"])
+def test_product_c_api_kzg_as_create_proof_and_verify(kind):
+    """The PRODUCT C API (include/snarkv_host.h, no test hooks): `KzgAs::create_proof` in full -- zk blind branch
+    (accumulation.rs:163-175) and both transcripts -- and `KzgAsProof::read` + `KzgAs::verify` on caller-supplied proof
+    bytes (accumulation.rs:114-137, 41-63), against the oracle's transcript and algebra; a tampered or truncated proof
+    and trailing bytes are errors, not accumulators."""
+    import transcript as T
+    from snark_verifier_amd import host_api as HA
+
+    tk = HA.TRANSCRIPT_EVM if kind == "evm" else HA.TRANSCRIPT_POSEIDON
+    rng = random.Random(41)
+    dk = HA.DecidingKey(g1(O.G1_GEN) + O.g2_to_bytes(O.G2_GEN) + O.g2_to_bytes(O.g2_mul(O.G2_GEN, SECRET)))
+    for m, zk in ((1, False), (5, False), (5, True), (33, True)):
+        accs = _mock_accumulators(rng, m)
+        pairs = [(O.g1_from_bytes(a[:64]), O.g1_from_bytes(a[64:])) for a in accs]
+        b = rng.randrange(1, O.R)
+        pk = g1(O.G1_GEN) + g1(O.g1_mul(O.G1_GEN, SECRET)) if zk else None
+        acc, proof, r = HA.kzg_as_create_proof(b"".join(accs), tk, pk, fr(b) if zk else None)
+        t = T.EvmTranscript() if kind == "evm" else T.PoseidonTranscript()
+        for lhs, rhs in pairs:
+            t.common_ec_point(lhs)
+            t.common_ec_point(rhs)
+        blind = None
+        if zk:
+            blind = (O.g1_mul(O.G1_GEN, SECRET * b % O.R), O.g1_mul(O.G1_GEN, b))
+            t.write_ec_point(blind[0])
+            t.write_ec_point(blind[1])
+        r_exp = t.squeeze_challenge()
+        exp = K.kzg_as_verify(pairs, r_exp, blind)
+        assert proof == t.finalize() and len(proof) == ((128 if kind == "evm" else 64) if zk else 0)
+        assert r == fr(r_exp) and acc == g1(exp[0]) + g1(exp[1])
+        # the verifier's side on those bytes
+        acc_v, r_v = HA.kzg_as_verify(b"".join(accs), proof, tk, zk)
+        assert acc_v == acc and r_v == r
+        assert HA.kzg_decide(dk, acc_v) is True
+        if not zk:
+            assert HA.kzg_as_accumulate(b"".join(accs))[0] == acc or kind != "evm"  # the round-2 entry point = this one, non-zk / EVM
+        with pytest.raises(HA.HostError):  # bytes left over
+            HA.kzg_as_verify(b"".join(accs), proof + b"\x00" * 32, tk, zk)
+        if zk:
+            with pytest.raises(HA.HostError):  # truncated: Error::Transcript
+                HA.kzg_as_verify(b"".join(accs), proof[:-1], tk, zk)
+            bad = bytearray(proof)
+            bad[5] ^= 1  # no longer a curve point (EVM: x | y big-endian; Poseidon: compressed x) -- or another point: a different accumulator
+            try:
+                acc_b, _ = HA.kzg_as_verify(b"".join(accs), bytes(bad), tk, zk)
+                assert acc_b != acc
+            except HA.HostError:
+                pass
+    dk.close()

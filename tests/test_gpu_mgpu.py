@@ -142,3 +142,55 @@ def test_mgpu_large_shards_take_the_chunk_pipeline(gpu_ctx, monkeypatch):
     got = mg.msm_pippenger_dev([ds.data_ptr(), ds.data_ptr() + 32 * per], [dp.data_ptr(), dp.data_ptr() + 64 * per], [per, per])
     assert got == single != bytes(64)
     mg.close()
+
+
+def test_mgpu_every_rank_holds_the_result_and_peer_status():
+    """All-reduce semantics (SURVEY.md 8e): after an MSM every rank's device holds the 64-byte result, not only rank 0's;
+    peer-access status is reported, not swallowed (on this 1-GPU box no pair of DISTINCT devices exists: all zero)."""
+    import ctypes
+
+    import torch
+
+    import snark_verifier_amd as sv
+
+    for variant in (0, 1):
+        mg = sv.MultiGpu([0] * 4)
+        assert mg.peer_access() == (0, 0, 0)
+        n = 3000
+        s, p = C.sample_scalars(0x61, n), C.sample_points(0x62, n)
+        exp = C.msm_pippenger(s, p, 8)
+        assert mg.msm_pippenger(s, p, variant) == exp
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        for r in range(4):
+            src = mg.result_dev(r)
+            assert src
+            tmp = torch.empty(64, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            assert hip.hipMemcpy(ctypes.c_void_p(tmp.data_ptr()), ctypes.c_void_p(src), 64, 3) == 0  # hipMemcpyDeviceToDevice
+            assert bytes(tmp.cpu().numpy()) == exp, (variant, r)
+        mg.close()
+
+
+def test_mgpu_rccl_transport_world_1_and_its_refusals():
+    """The RCCL transport of the C ABI (`ncclCommInitAll` + a grouped `ncclAllGather` of the 144-byte partials -- what
+    BASELINE's north_star names): on a 1-GPU box it can run with ONE rank (a communicator of one device); a device listed
+    twice is refused loudly (RCCL cannot build that communicator) and the handle keeps working on peer copies."""
+    import snark_verifier_amd as sv
+
+    n = 5000
+    s, p = C.sample_scalars(0x63, n), C.sample_points(0x64, n)
+    exp = C.msm_pippenger(s, p, 8)
+    mg = sv.MultiGpu([0])
+    mg.set_transport(sv.MultiGpu.RCCL)
+    assert mg.msm_pippenger(s, p, 0) == exp
+    assert mg.msm_pippenger(s, p, 1) == exp
+    mg.set_transport(sv.MultiGpu.PEER_COPY)
+    assert mg.msm_pippenger(s, p, 0) == exp
+    mg.close()
+    mg = sv.MultiGpu([0, 0])
+    with pytest.raises(sv.SnarkvError) as e:
+        mg.set_transport(sv.MultiGpu.RCCL)
+    assert "distinct devices" in str(e.value)
+    assert mg.msm_pippenger(s, p, 0) == exp  # still on peer copies
+    mg.close()
