@@ -31,15 +31,29 @@ struct G1Xyzz29 {
   Fq29 x, y, zz, zzz;
 };
 
-// Memory form of the Montgomery points the Pippenger gathers: each coordinate's canonical residue (< p < 2^256) as a
-// 256-bit little-endian integer, 64 bytes per point, 64-byte aligned -- ONE 64-byte sector per gather where the
+// Memory form of the Montgomery points the Pippenger gathers: each coordinate's canonical residue (< p < 2^256) in
+// 8 words (codecs below), 64 bytes per point, 64-byte aligned -- ONE 64-byte sector per gather where the
 // 72-byte limb form straddled two (and, 7 times out of 8, two 128-byte lines): rocprofv3 FETCH_SIZE of k_accumulate
 // halves.  The 9 x 29-bit limbs are cut out of the words in registers (a v_alignbit + v_and per limb).
 struct alignas(64) G1Packed {
   uint32_t w[16];
 };
 
+// Two codecs of a canonical residue (limbs 0..7 in [0, 2^29), limb 8 < 2^22) into 8 words:
+//   SNARKV_PACK_SPREAD = 0   the plain 256-bit little-endian integer: every limb straddles two words, a 64-bit funnel shift
+//                            + mask each -- ~64 instructions per coordinate in the compiled k_accumulate (the
+//                            "unpack regression", +128 per entry against the 72-byte limb form)
+//   SNARKV_PACK_SPREAD = 1   word i = limb i in its low 29 bits, and bits 3i .. 3i+2 of limb 8 (22 bits <= 8 x 3) in its top 3:
+//                            limbs 0..7 come out with ONE mask each, limb 8 with a shift / and-or per word
+// Both are injective on canonical residues (the pair level and the careful paths compare words for equality).
+#ifndef SNARKV_PACK_SPREAD
+#define SNARKV_PACK_SPREAD 0  // measured: no gain (k_accumulate 1.11 ms either way, profiles/r03_ab_combine_pack.txt) -- plain form kept
+#endif
 SNARKV_HD void fq29_pack256(const Fq29& a, uint32_t w[8]) {  // a: canonical residue, limbs in [0, 2^29)
+#if SNARKV_PACK_SPREAD
+#pragma unroll
+  for (int j = 0; j < 8; ++j) w[j] = (uint32_t)a.v[j] | ((((uint32_t)a.v[8] >> (3 * j)) & 7u) << 29);
+#else
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     int bit = 32 * j;
@@ -49,10 +63,19 @@ SNARKV_HD void fq29_pack256(const Fq29& a, uint32_t w[8]) {  // a: canonical res
     if (i + 2 < 9 && sh + 32 > 58) v |= (uint64_t)(uint32_t)a.v[i + 2] << 58;
     w[j] = (uint32_t)(v >> sh);
   }
+#endif
 }
 
 SNARKV_HD Fq29 fq29_unpack256(const uint32_t w[8]) {
   Fq29 a;
+#if SNARKV_PACK_SPREAD
+  uint32_t top = w[0] & 0xE0000000u;  // limb 8 gathered in the top bits, three per word, w0's lowest: then shifted down
+#pragma unroll
+  for (int i = 1; i < 8; ++i) top = (top >> 3) | (w[i] & 0xE0000000u);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a.v[i] = (int32_t)(w[i] & (uint32_t)kMask29);
+  a.v[8] = (int32_t)(top >> 8);
+#else
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
     int bit = 29 * i;
@@ -61,6 +84,7 @@ SNARKV_HD Fq29 fq29_unpack256(const uint32_t w[8]) {
     if (word + 1 < 8) v |= (uint64_t)w[word + 1] << 32;
     a.v[i] = (int32_t)((uint32_t)(v >> sh) & (uint32_t)kMask29);
   }
+#endif
   return a;
 }
 

@@ -640,6 +640,10 @@ __global__ void __launch_bounds__(SNARKV_L2_THREADS) SNARKV_LEVEL2_ATTR
 // One batched-affine addition level between the sort and the bucket accumulation: pair slot i = entries (2i, 2i + 1)
 // of the padded stream -> entry i of a half-length stream whose points are stored as lazy limbs.  6 field products per
 // addition instead of the 10 of the XYZZ mixed addition.  The per-lane code lives in pair_tree.h (host-testable).
+#ifndef SNARKV_COMBINE_PAIRS
+#define SNARKV_COMBINE_PAIRS 0  // k_combine: 1 = run-boundary lanes for the buckets that span two runs.  Measured level in a batch and
+                                // 13 % slower alone (0.082 -> 0.093 ms): profiles/r03_ab_combine_pack.txt -- off
+#endif
 #ifndef SNARKV_PAIR_TREE_DEFAULT
 #define SNARKV_PAIR_TREE_DEFAULT 0  // until the A/B says otherwise (profiles/r03_ab_pair_tree.txt)
 #endif
@@ -911,14 +915,52 @@ __device__ __forceinline__ void run_span(const PipParams& p, const uint32_t* __r
   s1 = base + (o + cnt - 1 - first) / p.krun;
 }
 
+// Two kinds of workgroup in ONE launch:
+//   blocks [0, bucket_blocks)   one lane per BUCKET, as described above -- except the buckets that span exactly two
+//                               consecutive runs, which are left to
+//   blocks beyond (PAIRS only)  one lane per RUN BOUNDARY t | t + 1: when the last bucket of run t continues as the head of
+//                               run t + 1 and ends there (the common case: with 64 entries per bucket on average nearly
+//                               every boundary falls inside a bucket), the lane adds the two partials -- ONE addition per
+//                               lane, every lane of the wavefront in the same instruction, where the per-bucket loop runs
+//                               its (inlined once) adder for every (run, head / tail) position at which ANY of its 64
+//                               buckets has a partial: ~2.4 additions' worth of issue slots per wavefront for ~0.7 useful.
 template <bool LIMB>
 __global__ void __launch_bounds__(64)
     k_combine(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, PipParams p,
               const uint2* __restrict__ entries, const void* __restrict__ pts,
               const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
               G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list,
-              const uint32_t* __restrict__ M, uint32_t b_lo, uint32_t b_hi) {
+              const uint32_t* __restrict__ M, uint32_t b_lo, uint32_t b_hi, uint32_t bucket_blocks, uint32_t run_base,
+              uint32_t nruns) {
   SNARKV_RAISE_PRIO();
+  constexpr bool PAIRS = !LIMB && SNARKV_COMBINE_PAIRS;  // (the half-length stream has all-skip partials, recorded as kNoBucket: per bucket only)
+  if (PAIRS && blockIdx.x >= bucket_blocks) {
+    const uint32_t t = (blockIdx.x - bucket_blocks) * blockDim.x + threadIdx.x;
+    if (t + 1 >= nruns) return;
+    const size_t s = (size_t)run_base + t;
+    int h = 1;
+    uint32_t b = seg_ids[2 * s + 1];  // the bucket of run t's last entry: its tail partial, or its head when the run is one bucket
+    if (b == kNoBucket) {
+      b = seg_ids[2 * s];
+      h = 0;
+    }
+    if (b < b_lo || b >= b_hi || seg_ids[2 * (s + 1)] != b) return;  // (slots beyond the stream hold stale ids: range-checked, then
+    const uint32_t cnt = counts[b], o = offsets[b];                     //  confirmed against the bucket's own span below)
+    if (cnt == 0) return;
+    size_t s0, s1;
+    run_span(p, M, b, o, cnt, s0, s1);
+    if (s0 != s || s1 != s + 1) return;
+    G1Xyzz29 acc = seg_parts[2 * s + h];
+    const G1Xyzz29 part = seg_parts[2 * (s + 1)];
+    bool bad = xyzz29_is_identity(acc) || xyzz29_is_identity(part);
+    if (!bad) {
+      xyzz29_add_fast(acc, part);
+      bad = fq29_limbs_all_zero(acc.zz) || xyzz29_is_degenerate(acc);
+    }
+    if (bad) acc = xyzz29_sanitize(bucket_from_entries_careful<LIMB>(entries, pts, o, cnt, 0, 1));
+    buckets[b] = acc;
+    return;
+  }
   uint32_t b = b_lo + blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= b_hi) return;
   uint32_t cnt = counts[b];
@@ -926,6 +968,7 @@ __global__ void __launch_bounds__(64)
   uint32_t o = offsets[b];
   size_t s0, s1;
   run_span(p, M, b, o, cnt, s0, s1);
+  if (PAIRS && s1 == s0 + 1) return;  // a run-boundary lane's
   if (s1 - s0 >= kBigSpan) {  // skewed scalars: hand the bucket to k_combine_big
     uint32_t slot = atomicAdd(big_count, 1u);
     if (slot < kMaxBig) {
@@ -1530,9 +1573,11 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
       const uint2* ce = (const uint2*)(tree ? d_pair_entries : d_entries);
       const void* cp = tree ? (const void*)d_pair_pts : (const void*)d_pts;
       const uint32_t* cm = tree ? (const uint32_t*)(d_total + 3) : (const uint32_t*)d_M;
-      hipLaunchKernelGGL(tree ? k_combine<true> : k_combine<false>, dim3((wcount * p.B + 63) / 64), dim3(64), 0, ts, cc, co, p,
+      const uint32_t bucket_blocks = (wcount * p.B + 63) / 64, pair_blocks = (tree || !SNARKV_COMBINE_PAIRS) ? 0u : (lanes + 63) / 64;
+      hipLaunchKernelGGL(tree ? k_combine<true> : k_combine<false>, dim3(bucket_blocks + pair_blocks), dim3(64), 0, ts, cc, co, p,
                          ce, cp, (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets,
-                         d_big_count + j, (uint32_t*)d_big + (size_t)j * kMaxBig, cm, w0 * p.B, w1 * p.B);
+                         d_big_count + j, (uint32_t*)d_big + (size_t)j * kMaxBig, cm, w0 * p.B, w1 * p.B, bucket_blocks,
+                         w0 * p.rpw, lanes);
       // one workgroup per oversized bucket; idle workgroups exit at once
       uint32_t big_grid = (uint32_t)(lanes / kBigSpan + 1);
       if (big_grid > kMaxBig) big_grid = kMaxBig;
