@@ -271,8 +271,89 @@ int snarkv::launch_msm_pippenger_auto(snarkv_ctx* ctx, const void* d_s, const vo
 // phase order (all sorts, then all accumulations) measured 6 % slower than this pipeline, tails in groups of 2-10 under
 // the later accumulations level, an occupancy cap on k_accumulate (LDS allocation) 3-9 % slower.
 // Job j's scratch is a private context (ctx->jobs[j]); results are the bytes of the single-MSM entry point.
+static int many_enqueue(snarkv_ctx* ctx, size_t count, const void* const* d_s, const void* const* d_p, const size_t* n,
+                        int window_bits, void* d_out, bool partial_out, bool capturing, bool* single_path);
+
+// The batch as a hipGraph.  A K-job batch is ~12 K kernel launches / memsets and ~3 K event operations over five
+// streams; a caller that submits the same batch again (same input / output pointers, sizes and options -- a proving
+// service's steady state, and bench.py's timed step) can replay it as ONE graph launch.  First call of a key: eager (it
+// allocates the scratch); second: captured (hipStreamBeginCapture on the context's stream, the other four streams join
+// through the existing events) and launched; from then on replayed until the key changes or any scratch buffer of the
+// contexts involved is reallocated.  SNARKV_MANY_GRAPH = 0 off (default until measured faster), 1 on.  Stage timing
+// (events read back by the host) and the fall-back paths run eagerly.
+static uint64_t many_scratch_epoch(const snarkv_ctx* ctx) {
+  uint64_t e = ctx->realloc_epoch;
+  for (int i = 0; i < ctx->njobs; ++i) e += ctx->jobs[i]->realloc_epoch;
+  for (int i = 0; i < 3 && ctx->sub_ready; ++i) e += ctx->sub[i]->realloc_epoch;
+  return e;
+}
+
 int snarkv::launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void* const* d_s, const void* const* d_p,
                                       const size_t* n, int window_bits, void* d_out, bool partial_out) {
+  const char* eg = getenv("SNARKV_MANY_GRAPH");
+  const bool want_graph = eg && atoi(eg) != 0 && !ctx->stage_timing && count > 1 && !ctx->is_lane;
+  bool single_path = false;
+  if (!want_graph) return many_enqueue(ctx, count, d_s, d_p, n, window_bits, d_out, partial_out, false, &single_path);
+  // key: everything a captured node bakes in
+  const size_t klen = (3 * count + 4) * sizeof(uint64_t);
+  uint64_t* key = (uint64_t*)malloc(klen);
+  if (!key) return SNARKV_ERR_DEVICE;
+  key[0] = count, key[1] = (uint64_t)(uint32_t)window_bits, key[2] = (uint64_t)(uintptr_t)d_out, key[3] = partial_out ? 1 : 0;
+  for (size_t i = 0; i < count; ++i) {
+    key[4 + 3 * i] = (uint64_t)(uintptr_t)d_s[i];
+    key[5 + 3 * i] = (uint64_t)(uintptr_t)d_p[i];
+    key[6 + 3 * i] = (uint64_t)n[i];
+  }
+  const bool same = ctx->many_graph_key && ctx->many_graph_key_len == klen && memcmp(ctx->many_graph_key, key, klen) == 0;
+  if (same && ctx->many_graph_state == 2 && ctx->many_graph && ctx->many_graph_epoch == many_scratch_epoch(ctx)) {
+    free(key);
+    SNARKV_HIP(hipGraphLaunch(ctx->many_graph, ctx->stream));
+    return SNARKV_OK;
+  }
+  if (ctx->many_graph) {  // stale: another key, or a buffer moved
+    (void)hipGraphExecDestroy(ctx->many_graph);
+    ctx->many_graph = nullptr;
+  }
+  if (!(same && ctx->many_graph_state >= 1)) {  // first sight of this key: eager, so that every buffer exists afterwards
+    free(ctx->many_graph_key);
+    ctx->many_graph_key = key;
+    ctx->many_graph_key_len = klen;
+    ctx->many_graph_state = 1;
+    return many_enqueue(ctx, count, d_s, d_p, n, window_bits, d_out, partial_out, false, &single_path);
+  }
+  free(key);
+  // second sight: capture.  Anything still queued on the five streams finishes first (the capture starts from a clean
+  // slate: no event recorded outside the capture is waited on inside it).
+  SNARKV_HIP(hipDeviceSynchronize());
+  const uint64_t epoch = many_scratch_epoch(ctx);
+  SNARKV_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+  int rc = many_enqueue(ctx, count, d_s, d_p, n, window_bits, d_out, partial_out, true, &single_path);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+  if (rc < 0 || e != hipSuccess || !g || single_path || epoch != many_scratch_epoch(ctx)) {
+    // not capturable this time (a fall-back path, an allocation inside, a runtime refusal): run it eagerly, stay eager
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    ctx->many_graph_state = 0;
+    if (rc < 0) return rc;
+    return many_enqueue(ctx, count, d_s, d_p, n, window_bits, d_out, partial_out, false, &single_path);
+  }
+  e = hipGraphInstantiate(&ctx->many_graph, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->many_graph = nullptr;
+    ctx->many_graph_state = 0;
+    return many_enqueue(ctx, count, d_s, d_p, n, window_bits, d_out, partial_out, false, &single_path);
+  }
+  ctx->many_graph_state = 2;
+  ctx->many_graph_epoch = epoch;
+  SNARKV_HIP(hipGraphLaunch(ctx->many_graph, ctx->stream));
+  return SNARKV_OK;
+}
+
+static int many_enqueue(snarkv_ctx* ctx, size_t count, const void* const* d_s, const void* const* d_p, const size_t* n,
+                        int window_bits, void* d_out, bool partial_out, bool capturing, bool* single_path) {
   const size_t ostride = partial_out ? SNARKV_G1_PARTIAL_BYTES : 64;
   ctx->last_many_jobs = 0;
   ctx->last_split_workers = 0;
@@ -292,6 +373,8 @@ int snarkv::launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void*
   }
   const char* em = getenv("SNARKV_MANY_MODE");  // 0: one MSM after the other through the single-call path (A/B knob)
   if (count == 1 || large || (em && atoi(em) == 0) || ctx->is_lane) {
+    *single_path = true;
+    if (capturing) return SNARKV_OK;  // the caller ends the capture and runs this path eagerly
     for (size_t i = 0; i < count; ++i)
       SNARKV_TRY(launch_msm_pippenger_auto(ctx, d_s[i], d_p[i], n[i], window_bits, (uint8_t*)d_out + ostride * i, partial_out));
     return SNARKV_OK;
@@ -326,19 +409,23 @@ int snarkv::launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void*
     for (int i = 0; i <= SNARKV_PIP_STAGES; ++i) SNARKV_HIP(hipEventCreate(&ctx->ev[i]));
     ctx->ev_ready = true;
   }
-  if (sig != ctx->many_sig) {  // a new shape may grow (free + reallocate) scratch that queued work still uses
+  if (sig != ctx->many_sig && !capturing) {  // a new shape may grow (free + reallocate) scratch that queued work still uses
     SNARKV_HIP(hipDeviceSynchronize());
     ctx->many_sig = sig;
   }
   hipStream_t S[3] = {ctx->stream, ctx->sub[0]->stream, ctx->sub[1]->stream};  // the accumulation streams
-  // the context's stream waits for everything queued on the other four streams, then they wait for it
-  auto join_and_fork = [&]() -> int {
-    for (int k = 0; k < 2; ++k) {
+  // the context's stream waits for everything queued on the other four streams (join), then they wait for it (fork).
+  // Inside a capture the first call only forks (the other streams are not part of the capture yet, and nothing is
+  // queued on them: the caller drained the device) and the last one only joins (a stream forked again would be left
+  // unjoined at hipStreamEndCapture).
+  auto join_and_fork = [&](bool join = true, bool fork = true) -> int {
+    for (int k = 0; k < 2 && join; ++k) {
       SNARKV_HIP(hipEventRecord(ctx->many_ev[k], ctx->hi_stream[k]));
       SNARKV_HIP(hipStreamWaitEvent(ctx->stream, ctx->many_ev[k], 0));
       SNARKV_HIP(hipEventRecord(ctx->sub_ev[k], S[k + 1]));
       SNARKV_HIP(hipStreamWaitEvent(ctx->stream, ctx->sub_ev[k], 0));
     }
+    if (!fork) return SNARKV_OK;
     SNARKV_HIP(hipEventRecord(ctx->sub_ev[4], ctx->stream));
     for (int k = 0; k < 2; ++k) {
       SNARKV_HIP(hipStreamWaitEvent(ctx->hi_stream[k], ctx->sub_ev[4], 0));
@@ -350,7 +437,7 @@ int snarkv::launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void*
   const size_t grid_bytes = (size_t)w0 * b0 * SNARKV_G1_PARTIAL_BYTES;
   if (uniform) SNARKV_TRY(ctx_reserve(ctx, SLOT_MGPU_GRID, grid_bytes * G, &d_grids));
   if (tm) SNARKV_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-  SNARKV_TRY(join_and_fork());  // inputs may still be in flight on the caller's stream
+  SNARKV_TRY(join_and_fork(!capturing, true));  // inputs may still be in flight on the caller's stream
   for (size_t lo = 0; lo < count; lo += G) {
     const size_t hi = std::min(count, lo + G);
     const bool last = hi == count;
@@ -371,7 +458,7 @@ int snarkv::launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void*
                                                (uint8_t*)d_out + ostride * i, partial_out, nullptr, nullptr));
       job->stage_timing = false;
     }
-    SNARKV_TRY(join_and_fork());
+    SNARKV_TRY(join_and_fork(true, !(capturing && last)));
     if (uniform) {
       SNARKV_TRY(launch_buckets_reduce_many(ctx, ctx->stream, d_grids, c0, w0, (uint32_t)(hi - lo),
                                             (uint8_t*)d_out + ostride * lo, partial_out));

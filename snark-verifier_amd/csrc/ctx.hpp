@@ -107,6 +107,14 @@ struct snarkv_ctx {
   hipEvent_t many_ev[2];
   hipStream_t hi_stream[2];  // high-priority streams of the batch pipeline (the sorts) + their join events (many_ev)
   bool hi_ready;
+  // the batch captured as a hipGraph (capi.hip launch_msm_pippenger_many): replayed while the call's key (every pointer,
+  // size and option) and the scratch epoch (no buffer of the contexts involved was reallocated since) are unchanged
+  hipGraphExec_t many_graph;
+  void* many_graph_key;       // malloc'd copy of the key bytes of the captured / warmed call
+  size_t many_graph_key_len;
+  uint64_t many_graph_epoch;  // scratch_epoch() at capture
+  int many_graph_state;       // 0 nothing, 1 warmed (ran once eagerly: scratch is allocated), 2 captured
+  uint64_t realloc_epoch;     // bumped by ctx_reserve whenever a slot is (re)allocated
 };
 
 struct snarkv_dk {

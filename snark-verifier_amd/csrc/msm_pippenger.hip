@@ -156,6 +156,7 @@ struct PipParams {
   uint32_t rpw;      // run slots reserved per window: ceil(max entries of a window / krun) + 1
   uint32_t wper;     // batched tail over several MSMs' grids laid end to end: windows per MSM (0: one MSM)
   uint32_t pad;      // 1: k_sort_level2 pads every bucket's entry count to even (the pair level, pair_tree.h)
+  uint32_t chunk_log2;  // P6: log2 of the buckets per k_bucket_reduce lane (kLog2Chunk; larger in a batched tail)
 };
 
 // c bits at offset lo of a kDigitBits-bit magnitude held in registers (selects, no dynamic indexing)
@@ -1149,13 +1150,14 @@ __global__ void __launch_bounds__(64)
   uint32_t j = bj * 64 + threadIdx.x;
   G1Xyzz29 run = xyzz29_identity(), acc = xyzz29_identity();
   if (j < chunks_per_window) {
-    uint32_t base = j * kChunk;
-    uint32_t top = base + kChunk < p.B ? base + kChunk : p.B;
+    const uint32_t chunk = 1u << p.chunk_log2;
+    uint32_t base = j * chunk;
+    uint32_t top = base + chunk < p.B ? base + chunk : p.B;
     const G1Xyzz29* bw = buckets + (size_t)w * p.B;
     if (chunk_sums<false>(bw, base, top, run, acc)) chunk_sums<true>(bw, base, top, run, acc);
   }
   G1Xyzz29 t, s;
-  wave_weighted_fold(sh, run, acc, xyzz29_identity(), kLog2Chunk, 0, t, s);
+  wave_weighted_fold(sh, run, acc, xyzz29_identity(), (int)p.chunk_log2, 0, t, s);
   if (threadIdx.x == 0) {
     block_parts[2 * (size_t)blockIdx.x] = t;
     block_parts[2 * (size_t)blockIdx.x + 1] = s;
@@ -1202,7 +1204,7 @@ __global__ void __launch_bounds__(64)
     else acc_t = x;
   }
   G1Xyzz29 r, total;
-  wave_weighted_fold(sh, run, acc_s, acc_t, 31 - __clz((int)per), kLog2BlockBuckets, r, total);
+  wave_weighted_fold(sh, run, acc_s, acc_t, 31 - __clz((int)per), 6 + (int)p.chunk_log2, r, total);  // a P6 block covers 64 chunks
   const uint32_t wl = p.wper ? w % p.wper : w;  // window index inside its own MSM
   if (!xyzz29_is_identity(r)) r = xyzz29_double_n_quad(r, p.c * (int)(wl + p.w0));
   if (lane == 0) shifted[w] = r;
@@ -1325,6 +1327,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   PipParams p;
   p.w0 = 0;
   p.wper = 0;
+  p.chunk_log2 = (uint32_t)kLog2Chunk;
   p.n = (uint32_t)n;
   p.c = window_bits > 0 ? window_bits : balance_window_bits(default_window_bits(n));
   if (p.c < 2) p.c = 2;
@@ -1656,6 +1659,7 @@ int launch_buckets_reduce(snarkv_ctx* ctx, const void* d_buckets, uint32_t c, ui
   p.B = 1u << (c - 1);
   p.nb = wcount * p.B;
   p.w0 = w0;
+  p.chunk_log2 = (uint32_t)kLog2Chunk;
   uint32_t chunks_per_window = (p.B + kChunk - 1) / kChunk;
   uint32_t blocks_per_window = (chunks_per_window + 63) / 64;
   void *d_wave, *d_shift;
@@ -1685,6 +1689,17 @@ int launch_buckets_reduce_many(snarkv_ctx* ctx, hipStream_t st, const void* d_gr
   p.w0 = 0;
   p.wper = windows;
   const uint32_t wtotal = windows * jobs;
+  // Buckets per k_bucket_reduce lane.  One MSM's reduce is a latency chain on a few hundred wavefronts: short chunks (8
+  // buckets: 16 serial additions + the 14-step fold) keep it short.  A batch's tail reduces `jobs` grids at once --
+  // thousands of wavefronts, throughput-bound, and exposed at the end of the batch (nothing is left to overlap it) --
+  // where the fold is 14 of every 30 additions: chunks of 32 do 78 additions per 32 buckets instead of 120.
+  // SNARKV_TAIL_CHUNK_LOG2 overrides (A/B knob); same bytes for any chunk size.
+  uint32_t cl2 = (uint32_t)kLog2Chunk;
+  if ((uint64_t)jobs * windows * (p.B >> 3) >= 4096 * 64ull) cl2 = 5;  // >= 4 096 wavefronts at 8 buckets per lane
+  if (const char* e = getenv("SNARKV_TAIL_CHUNK_LOG2")) cl2 = (uint32_t)std::max(1, std::min(8, atoi(e)));
+  while ((1u << cl2) > p.B && cl2 > 0) --cl2;
+  p.chunk_log2 = cl2;
+  const uint32_t kChunk = 1u << cl2;  // (shadows the single-MSM constant for the sizes below)
   uint32_t chunks_per_window = (p.B + kChunk - 1) / kChunk;
   uint32_t blocks_per_window = (chunks_per_window + 63) / 64;
   void *d_wave, *d_shift;

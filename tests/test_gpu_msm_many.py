@@ -168,3 +168,55 @@ def test_the_bench_shape_2p20_times_six_against_single_calls():
     assert st["total"] > 0 and st["bucket_accumulate"] > 0
     assert bytes(out.cpu().numpy()) == got
     ctx.close()
+
+
+def test_batch_replayed_as_a_hipgraph(monkeypatch):
+    """SNARKV_MANY_GRAPH=1: the first call of a (pointers, sizes, options) key runs eagerly, the second is captured as a
+    hipGraph over the five streams and launched, later ones are replays -- every call must give the oracle's bytes; NEW
+    input contents behind the same pointers are picked up by a replay; a different key, a ragged batch (per-job tails)
+    and a call that makes a job context's scratch grow (the captured addresses are stale: epoch check) fall back / are
+    re-captured correctly; with the knob off the same calls give the same bytes."""
+    import torch
+
+    import snark_verifier_amd as sv
+
+    monkeypatch.setenv("SNARKV_MANY_GRAPH", "1")
+    ctx = sv.Context(0)
+    for sizes in ([30000] * 5, [1, 2, 77, 4096, 65536, 3], [5000] * 70):  # uniform / ragged / several rounds
+        jobs = _jobs(sizes, 0x5100 + len(sizes))
+        exp = [C.msm_pippenger(s, p, 8) for s, p in jobs]
+        ds, dp = _upload(torch, jobs)
+        out = torch.zeros(64 * len(jobs), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        args = ([t.data_ptr() for t in ds], [t.data_ptr() for t in dp], sizes, out.data_ptr())
+        for rep in range(4):  # eager, capture + launch, replay, replay
+            out.zero_()
+            torch.cuda.synchronize()
+            ctx.msm_pippenger_many_dev(*args)
+            ctx.sync()
+            raw = bytes(out.cpu().numpy())
+            assert [raw[64 * i:64 * i + 64] for i in range(len(jobs))] == exp, (sizes[:3], rep)
+        # same pointers, new contents: a replay reads the buffers, not a snapshot
+        jobs2 = _jobs(sizes, 0x5200 + len(sizes))
+        for t, (s, _) in zip(ds, jobs2):
+            t.copy_(torch.frombuffer(bytearray(s), dtype=torch.uint8))
+        for t, (_, p) in zip(dp, jobs2):
+            t.copy_(torch.frombuffer(bytearray(p), dtype=torch.uint8))
+        torch.cuda.synchronize()
+        ctx.msm_pippenger_many_dev(*args)
+        ctx.sync()
+        raw = bytes(out.cpu().numpy())
+        assert [raw[64 * i:64 * i + 64] for i in range(len(jobs))] == [C.msm_pippenger(s, p, 8) for s, p in jobs2]
+    # a bigger batch on the same context grows the job contexts' scratch: the old graph's addresses are stale
+    small = _jobs([20000] * 3, 0x5300)
+    big = _jobs([90000] * 3, 0x5310)
+    for jobs in (small, small, small, big, big, big, small, small, small):
+        ds, dp = _upload(torch, jobs)
+        out = torch.zeros(64 * len(jobs), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.msm_pippenger_many_dev([t.data_ptr() for t in ds], [t.data_ptr() for t in dp], [len(s) // 32 for s, _ in jobs],
+                                   out.data_ptr())
+        ctx.sync()
+        raw = bytes(out.cpu().numpy())
+        assert [raw[64 * i:64 * i + 64] for i in range(len(jobs))] == [C.msm_pippenger(s, p, 8) for s, p in jobs]
+    ctx.close()
