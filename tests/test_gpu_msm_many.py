@@ -210,13 +210,18 @@ def test_batch_replayed_as_a_hipgraph(monkeypatch):
     # a bigger batch on the same context grows the job contexts' scratch: the old graph's addresses are stale
     small = _jobs([20000] * 3, 0x5300)
     big = _jobs([90000] * 3, 0x5310)
-    for jobs in (small, small, small, big, big, big, small, small, small):
+    sets = {}
+    for name, jobs in (("small", small), ("big", big)):
         ds, dp = _upload(torch, jobs)
-        out = torch.zeros(64 * len(jobs), dtype=torch.uint8, device="cuda")
+        sets[name] = (jobs, ds, dp, torch.zeros(64 * len(jobs), dtype=torch.uint8, device="cuda"))
+    torch.cuda.synchronize()
+    for name in ("small", "small", "small", "big", "big", "big", "small", "small", "small"):
+        jobs, ds, dp, out = sets[name]
+        out.zero_()
         torch.cuda.synchronize()
         ctx.msm_pippenger_many_dev([t.data_ptr() for t in ds], [t.data_ptr() for t in dp], [len(s) // 32 for s, _ in jobs],
                                    out.data_ptr())
         ctx.sync()
         raw = bytes(out.cpu().numpy())
-        assert [raw[64 * i:64 * i + 64] for i in range(len(jobs))] == [C.msm_pippenger(s, p, 8) for s, p in jobs]
+        assert [raw[64 * i:64 * i + 64] for i in range(len(jobs))] == [C.msm_pippenger(s, p, 8) for s, p in jobs], name
     ctx.close()
