@@ -226,7 +226,7 @@ def end_to_end_metrics():
 
     threads = max(1, min(64, os.cpu_count() or 1))
     out = {}
-    for tkind, tname in ((0, "evm"), (1, "poseidon"), (2, "poseidon")):
+    for tkind, tname in ((0, "evm"), (1, "poseidon"), (2, "poseidon"), (3, "poseidon")):
         path = os.path.join(ROOT, "tests", "golden", "bench_plonk_gwc19_%s_64.bin" % tname)
         if not os.path.exists(path):
             continue
@@ -243,10 +243,10 @@ def end_to_end_metrics():
                 if best is None or tm["total"] < best["total"]:
                     best = tm
             key = "end_to_end_aggregate_%d_proofs" % (n * rep) + (
-                "", "_poseidon_transcript_host_hashed", "_poseidon_transcript_device_hashed")[tkind]
+                "", "_poseidon_transcript_host_hashed", "_poseidon_transcript_device_hashed", "_poseidon_transcript_auto")[tkind]
             out[key] = {
                 "ms": best["total"], "proofs_per_s": n * rep / best["total"] * 1e3, "host_threads": threads,
-                ("ms_read_proofs_incl_device_hashing" if tkind == 2 else "ms_read_proofs_host"): best["read_proofs"],
+                ("ms_read_proofs_incl_device_hashing" if tkind == 2 else "ms_read_proofs" if tkind == 3 else "ms_read_proofs_host"): best["read_proofs"],
                 "ms_fr_algebra_host": best["fr_algebra"], "ms_msm_device_incl_h2d": best["msm_device"],
                 "ms_kzg_accumulate": best["accumulate"], "ms_decide": best["decide"],
                 "accepted": True, "matches_fixture_accumulator": (acc == fx["expected_acc"]) if rep == 1 else None,

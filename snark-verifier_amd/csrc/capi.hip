@@ -68,6 +68,8 @@ int snarkv_set_stage_timing(snarkv_ctx* ctx, int enabled) {
   return SNARKV_OK;
 }
 
+long long snarkv_ctx_graph_replays(const snarkv_ctx* ctx) { return ctx ? (long long)ctx->many_graph_launches : -1; }
+
 int snarkv_ctx_set_throughput_hint(snarkv_ctx* ctx, int enabled) {
   if (!ctx) return SNARKV_ERR_ARG;
   ctx->throughput_mode = enabled != 0;
@@ -308,6 +310,7 @@ int snarkv::launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void*
   if (same && ctx->many_graph_state == 2 && ctx->many_graph && ctx->many_graph_epoch == many_scratch_epoch(ctx)) {
     free(key);
     SNARKV_HIP(hipGraphLaunch(ctx->many_graph, ctx->stream));
+    ++ctx->many_graph_launches;
     return SNARKV_OK;
   }
   if (ctx->many_graph) {  // stale: another key, or a buffer moved
@@ -349,6 +352,7 @@ int snarkv::launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void*
   ctx->many_graph_state = 2;
   ctx->many_graph_epoch = epoch;
   SNARKV_HIP(hipGraphLaunch(ctx->many_graph, ctx->stream));
+  ++ctx->many_graph_launches;
   return SNARKV_OK;
 }
 

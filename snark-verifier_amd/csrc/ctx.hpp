@@ -115,6 +115,7 @@ struct snarkv_ctx {
   uint64_t many_graph_epoch;  // scratch_epoch() at capture
   int many_graph_state;       // 0 nothing, 1 warmed (ran once eagerly: scratch is allocated), 2 captured
   uint64_t realloc_epoch;     // bumped by ctx_reserve whenever a slot is (re)allocated
+  uint64_t many_graph_launches;  // hipGraphLaunch calls so far (snarkv_ctx_graph_replays: tests / diagnostics)
 };
 
 struct snarkv_dk {

@@ -105,6 +105,8 @@ int succinct_verify_batch(const PlonkProtocol& pr, const KzgDecidingKey& dk, int
   std::vector<PlonkProof<MOS>> pfs;
   bool trailing = false;
   Error e;
+  if (transcript == SNARKV_HOST_TRANSCRIPT_POSEIDON_AUTO)
+    transcript = n >= SNARKV_HOST_POSEIDON_DEVICE_MIN ? SNARKV_HOST_TRANSCRIPT_POSEIDON_DEVICE : SNARKV_HOST_TRANSCRIPT_POSEIDON;
   if (transcript == SNARKV_HOST_TRANSCRIPT_EVM) {
     e = read_all<MOS, EvmTranscript>(dk.svk, pr, insts, pbytes, strict, pfs, &trailing);
   } else if (transcript == SNARKV_HOST_TRANSCRIPT_POSEIDON) {
@@ -155,6 +157,8 @@ int aggregate_mos(const PlonkProtocol& pr, const KzgDecidingKey& dk, int transcr
   std::vector<std::vector<uint8_t>> pbytes;
   wire::split_batch(instances, ilen, proofs, prlen, n, insts, pbytes);
   if (threads == 0) threads = HostPool::get().size();
+  if (transcript == SNARKV_HOST_TRANSCRIPT_POSEIDON_AUTO)
+    transcript = n >= SNARKV_HOST_POSEIDON_DEVICE_MIN ? SNARKV_HOST_TRANSCRIPT_POSEIDON_DEVICE : SNARKV_HOST_TRANSCRIPT_POSEIDON;
   switch (transcript) {
     case SNARKV_HOST_TRANSCRIPT_EVM: return aggregate_run<MOS, EvmTranscript>(pr, dk, insts, pbytes, threads, timings_ms, acc_out);
     case SNARKV_HOST_TRANSCRIPT_POSEIDON: return aggregate_run<MOS, PoseidonTranscript>(pr, dk, insts, pbytes, threads, timings_ms, acc_out);

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libsnarkv_host.so"
 
 MOS_GWC19, MOS_BDFG21 = 0, 1
-TRANSCRIPT_EVM, TRANSCRIPT_POSEIDON, TRANSCRIPT_POSEIDON_DEVICE = 0, 1, 2
+TRANSCRIPT_EVM, TRANSCRIPT_POSEIDON, TRANSCRIPT_POSEIDON_DEVICE, TRANSCRIPT_POSEIDON_AUTO = 0, 1, 2, 3
 PROTOCOL_PACKED, PROTOCOL_SERDE_JSON, PROTOCOL_BINCODE = 0, 1, 2
 ERR_TRANSCRIPT, ERR_INVALID_INSTANCES, ERR_INVALID_PROTOCOL, ERR_OTHER, ERR_TRAILING = -10, -11, -12, -13, -14
 ERR_CAPACITY, ERR_ARG, ERR_PANIC, ERR_DEVICE = -6, -5, -100, -101

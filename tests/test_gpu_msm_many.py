@@ -182,6 +182,7 @@ def test_batch_replayed_as_a_hipgraph(monkeypatch):
 
     monkeypatch.setenv("SNARKV_MANY_GRAPH", "1")
     ctx = sv.Context(0)
+    seen = 0
     for sizes in ([30000] * 5, [1, 2, 77, 4096, 65536, 3], [5000] * 70):  # uniform / ragged / several rounds
         jobs = _jobs(sizes, 0x5100 + len(sizes))
         exp = [C.msm_pippenger(s, p, 8) for s, p in jobs]
@@ -196,6 +197,8 @@ def test_batch_replayed_as_a_hipgraph(monkeypatch):
             ctx.sync()
             raw = bytes(out.cpu().numpy())
             assert [raw[64 * i:64 * i + 64] for i in range(len(jobs))] == exp, (sizes[:3], rep)
+        assert ctx.graph_replays() >= seen + 3  # capture + launch, replay, replay: the graph path really ran
+        seen = ctx.graph_replays()
         # same pointers, new contents: a replay reads the buffers, not a snapshot
         jobs2 = _jobs(sizes, 0x5200 + len(sizes))
         for t, (s, _) in zip(ds, jobs2):
@@ -224,4 +227,5 @@ def test_batch_replayed_as_a_hipgraph(monkeypatch):
         ctx.sync()
         raw = bytes(out.cpu().numpy())
         assert [raw[64 * i:64 * i + 64] for i in range(len(jobs))] == [C.msm_pippenger(s, p, 8) for s, p in jobs], name
+    assert ctx.graph_replays() >= seen + 4  # small: capture + replay; big: capture + replay; small again: re-captured
     ctx.close()

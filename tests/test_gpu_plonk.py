@@ -304,3 +304,26 @@ def test_random_protocol_shapes_cpp_vs_oracle(H, seed):
     rc, accs = run(H, mos, kind, pr, [inst], [proof])
     assert rc == 1, (seed, lin, mos, kind)
     assert accs == b"".join(g1(a) + g1(b) for a, b in exp)
+
+
+def test_poseidon_auto_transcript_picks_by_batch_size():
+    """SNARKV_HOST_TRANSCRIPT_POSEIDON_AUTO (include/snarkv_host.h): host-hashed below SNARKV_HOST_POSEIDON_DEVICE_MIN
+    proofs, device-hashed from there on -- the same accumulator and verdict as either explicit kind on both sides of
+    the threshold (64 proofs; the same 64 replicated to 512)."""
+    from snark_verifier_amd import host_api as HA
+
+    fx = HA.read_fixture(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                                      "bench_plonk_gwc19_poseidon_64.bin"))
+    hp, hdk = HA.Protocol(fx["protocol"]), HA.DecidingKey(fx["dk"])
+    for rep in (1, 8):
+        got = {}
+        for kind in (HA.TRANSCRIPT_POSEIDON, HA.TRANSCRIPT_POSEIDON_DEVICE, HA.TRANSCRIPT_POSEIDON_AUTO):
+            ok, acc, tm = HA.aggregate(hp, hdk, fx["instances"] * rep, fx["proofs"] * rep, fx["n"] * rep, HA.MOS_GWC19, kind, 8,
+                                       timings=True)
+            assert ok
+            got[kind] = acc
+        assert len(set(got.values())) == 1
+        if rep == 1:
+            assert got[HA.TRANSCRIPT_POSEIDON_AUTO] == fx["expected_acc"]
+    hp.close()
+    hdk.close()
