@@ -342,11 +342,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path even at world size 1 (testing)")
+    ap.add_argument("--dry-run-doubles", default="",
+                    help="TEST HOOK (tests/test_bench_dry_run.py): path of a module providing CPU doubles of the device context; "
+                         "the multi-process control flow of this file (rendezvous, shards, batch call, all-gather, fold, max over "
+                         "ranks, the JSON line and its labels) then runs over gloo on CPU tensors.  Not a measurement: the line says so.")
     ap.add_argument("--inflight", type=int, default=0,
                     help="0 (default): the K timed steps are ONE batch call (snarkv_g1_msm_pippenger_many_dev: the library "
                          "pipelines them).  N >= 1: N independent single-MSM calls kept in flight instead (one context + HIP "
                          "stream each; 1 = strictly sequential) -- the round-1 / early round-2 way, kept for comparison")
     args = ap.parse_args()
+
+    import contextlib
 
     import torch
     import torch.distributed as dist
@@ -359,14 +365,40 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
+    dry = bool(args.dry_run_doubles)
+    if dry:  # CPU doubles of the device context: the control flow of the N > 1 path without a GPU (see --dry-run-doubles)
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("_bench_doubles", args.dry_run_doubles)
+        doubles = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(doubles)
+        args.no_cpu_baseline = args.no_secondary = True
+        dev = "cpu"
+        make_stream = lambda: None  # noqa: E731
+        make_ctx = lambda st: doubles.Context(local_rank)  # noqa: E731
+        dev_sync = lambda: None  # noqa: E731
+        on_stream = lambda st: contextlib.nullcontext()  # noqa: E731
+        launch_points = doubles.Context.launch_points
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = "cuda"
+        make_stream = torch.cuda.Stream
+        make_ctx = lambda st: sv.Context(local_rank, stream=st.cuda_stream)  # noqa: E731
+        dev_sync = torch.cuda.synchronize
+        on_stream = torch.cuda.stream
+        launch_points = sv.Context.launch_points
     use_dist = world > 1 or args.force_dist
+    if dry and not use_dist:
+        raise SystemExit("--dry-run-doubles exercises the multi-process path: launch with torch.distributed.run or add --force-dist")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     strong = args.total_log2n > 0
     if strong:
@@ -383,8 +415,8 @@ def main():
     inflight = 4 if batch else max(1, args.inflight)
     # explicit side streams only: a context given the NULL stream handle (torch's legacy default
     # stream) would create its own stream, invisible to the stream ordering torch.distributed relies on
-    streams = [torch.cuda.Stream() for _ in range(inflight)]
-    ctxs = [sv.Context(local_rank, stream=s.cuda_stream) for s in streams]
+    streams = [make_stream() for _ in range(inflight)]
+    ctxs = [make_ctx(s) for s in streams]
     ctx = ctxs[0]
     if inflight > 1:
         for c in ctxs:  # several MSMs in flight: the library's throughput hint (longer runs per lane; same bytes)
@@ -394,19 +426,19 @@ def main():
     # rank r owns [r*n, (r+1)*n) -- so an N-rank job is the MSM over [0, N*n) -- and the other slots ranges beyond N*n.
     # (Round 1 pointed all slots at the same arrays; distinct inputs keep the headline free of any cache sharing.)
     slot_first = [rank * n] + [(world + rank * (inflight - 1) + k) * n for k in range(inflight - 1)]
-    d_scalars_k = [torch.empty(32 * n, dtype=torch.uint8, device="cuda") for _ in range(inflight)]
-    d_points_k = [torch.empty(64 * n, dtype=torch.uint8, device="cuda") for _ in range(inflight)]
-    torch.cuda.synchronize()
+    d_scalars_k = [torch.empty(32 * n, dtype=torch.uint8, device=dev) for _ in range(inflight)]
+    d_points_k = [torch.empty(64 * n, dtype=torch.uint8, device=dev) for _ in range(inflight)]
+    dev_sync()
     for k in range(inflight):
         ctx.sample_scalars_dev(0x5EED0001, n, d_scalars_k[k].data_ptr(), first=slot_first[k])
         ctx.sample_points_dev(0x5EED0002, n, d_points_k[k].data_ptr(), first=slot_first[k])
     ctx.sync()
     d_scalars, d_points = d_scalars_k[0], d_points_k[0]
-    partials = [torch.zeros(sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda") for _ in range(inflight)]
-    gathereds = [torch.zeros(world * sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda") for _ in range(inflight)]
-    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
-    outs = [out] + [torch.zeros(64, dtype=torch.uint8, device="cuda") for _ in range(inflight - 1)]
-    torch.cuda.synchronize()
+    partials = [torch.zeros(sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device=dev) for _ in range(inflight)]
+    gathereds = [torch.zeros(world * sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device=dev) for _ in range(inflight)]
+    out = torch.zeros(64, dtype=torch.uint8, device=dev)
+    outs = [out] + [torch.zeros(64, dtype=torch.uint8, device=dev) for _ in range(inflight - 1)]
+    dev_sync()
     step_no = [0]
 
     # ---- batch submission: job i of a K-step batch works on input set i (disjoint ranges again; at most 32 sets, reused
@@ -415,13 +447,13 @@ def main():
         nsets = min(args.steps, 32)
         for k in range(inflight, nsets):
             first = (world * (1 + (inflight - 1)) + rank * (nsets - inflight) + (k - inflight)) * n
-            d_scalars_k.append(torch.empty(32 * n, dtype=torch.uint8, device="cuda"))
-            d_points_k.append(torch.empty(64 * n, dtype=torch.uint8, device="cuda"))
+            d_scalars_k.append(torch.empty(32 * n, dtype=torch.uint8, device=dev))
+            d_points_k.append(torch.empty(64 * n, dtype=torch.uint8, device=dev))
             ctx.sample_scalars_dev(0x5EED0001, n, d_scalars_k[k].data_ptr(), first=first)
             ctx.sample_points_dev(0x5EED0002, n, d_points_k[k].data_ptr(), first=first)
         ctx.sync()
         nsets = min(nsets, len(d_scalars_k))
-        b_out = torch.zeros(64 * args.steps, dtype=torch.uint8, device="cuda")
+        b_out = torch.zeros(64 * args.steps, dtype=torch.uint8, device=dev)
         job_s = [d_scalars_k[i % nsets].data_ptr() for i in range(args.steps)]
         job_p = [d_points_k[i % nsets].data_ptr() for i in range(args.steps)]
 
@@ -445,7 +477,7 @@ def main():
         else:
             # snark-verifier_amd/distributed.py: shard -> HIP partial -> RCCL all-gather (144 B/rank) -> HIP fold,
             # all three enqueued on slot k's stream (every rank issues the collectives in the same order)
-            with torch.cuda.stream(streams[k]):
+            with on_stream(streams[k]):
                 ctxs[k].msm_pippenger_partial_dev(d_scalars_k[k].data_ptr(), d_points_k[k].data_ptr(), n,
                                                   partials[k].data_ptr(), args.window_bits)
                 dist.all_gather_into_tensor(gathereds[k], partials[k])
@@ -454,7 +486,7 @@ def main():
     def barrier():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
 
     # Initialisation, not a benchmark step: every in-flight slot runs the path once so that its
     # context has allocated its scratch (hipMalloc of ~1 GiB, synchronous) before anything is timed --
@@ -539,7 +571,7 @@ def main():
         seq_stages = {k: v / 5 for k, v in seq_sum.items()}
 
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     result_hex = bytes(out.cpu().numpy()).hex()
@@ -548,7 +580,7 @@ def main():
         stages = {k: v / stage_cnt for k, v in stage_sum.items()}
         dom = max((k for k in stages if k != "total"), key=lambda k: stages[k])
         dom_ms = stages[dom]
-        launch_n = sv.Context.launch_points(n, args.window_bits)  # n, or the 2^20-point chunk large MSMs are pipelined in
+        launch_n = launch_points(n, args.window_bits)  # n, or the 2^20-point chunk large MSMs are pipelined in
         achieved = BYTES_PER_POINT * launch_n / (dom_ms * 1e-3) / 1e9
         line = {
             "metric": "BN254 G1 MSM points/sec at 2^%d" % (args.total_log2n if strong else args.log2n),
@@ -562,7 +594,7 @@ def main():
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "i32x9 (254-bit Montgomery Fq as 9 x 29-bit signed lazy limbs on the integer VALU, 64-bit column accumulators)",
-            "data": "synthetic",
+            "data": "synthetic" if not dry else "synthetic; DRY RUN on CPU doubles of the device context (a control-flow test, not a measurement)",
             "config": {
                 "workload": ("BN254 G1 Pippenger MSM, 2^%d random points/scalars IN TOTAL sharded over %d GPU(s) (2^%d each), "
                              "inputs resident in HBM, affine result (configs[3])" % (args.total_log2n, world, args.log2n)) if strong

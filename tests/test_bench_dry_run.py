@@ -1,0 +1,60 @@
+"""CPU: bench.py's N > 1 control flow before the driver ever has a multi-GPU node -- launched exactly
+as the driver launches it (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W`),
+with `--dry-run-doubles tests/bench_doubles.py` putting oracle-backed CPU doubles in place of the device context and gloo in
+place of RCCL.  What is checked: the rendezvous, the disjoint shards, the batch submission + ONE all-gather + folds, the
+max-over-ranks timing, and the single JSON line rank 0 prints: metric / unit / n_gpus / steps / scaling / the aggregate value
+N * n * K / t / config labels -- and that the result it reports equals the single-process MSM over all ranks' points."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import coracle as C
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(world, extra, port):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world),
+           "--dry-run-doubles", os.path.join(ROOT, "tests", "bench_doubles.py")] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE line, from rank 0 only
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_weak_scaling_line_from_n_ranks(world):
+    log2n, steps = 8, 3
+    d = _run(world, ["--steps", str(steps), "--warmup", "1", "--log2n", str(log2n)], 36000 + world + os.getpid() % 1000)
+    n = 1 << log2n
+    assert d["metric"] == "BN254 G1 MSM points/sec at 2^%d" % log2n and d["unit"] == "points/s"
+    assert d["n_gpus"] == world and d["steps"] == steps and d["warmup"] == 1
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["config"]["points_per_gpu"] == n and d["config"]["msms_in_flight"] == steps
+    assert abs(d["value"] - world * n * steps / (d["ms_per_step"] * steps * 1e-3)) < 1e-6 * d["value"]  # whole-job aggregate
+    assert "DRY RUN" in d["data"] and "cpu_baseline" not in d and "secondary" not in d
+    assert "point-sharded x%d" % world in d["config"]["parallelism"]
+    # slot 0 of rank r holds points [r n, (r + 1) n) of the seeded streams: the reported result is the MSM over [0, N n)
+    s, p = C.sample_scalars(0x5EED0001, world * n), C.sample_points(0x5EED0002, world * n)
+    assert d["config"]["result"] == C.msm_pippenger(s, p, 4).hex()
+
+
+def test_strong_scaling_line_config4_shape():
+    d = _run(2, ["--steps", "2", "--warmup", "1", "--total-log2n", "10"], 37000 + os.getpid() % 1000)
+    assert d["scaling"] == "strong" and d["metric"].endswith("2^10") and d["config"]["points_per_gpu"] == 512
+    assert "configs[3]" in d["config"]["workload"]
+    s, p = C.sample_scalars(0x5EED0001, 1024), C.sample_points(0x5EED0002, 1024)
+    assert d["config"]["result"] == C.msm_pippenger(s, p, 4).hex()
+
+
+def test_inflight_mode_under_dist():
+    """`--inflight 2`: single-MSM calls (partial -> all-gather -> fold per step) instead of the batch"""
+    d = _run(2, ["--steps", "3", "--warmup", "1", "--log2n", "7", "--inflight", "2"], 38000 + os.getpid() % 1000)
+    assert d["n_gpus"] == 2 and d["config"]["msms_in_flight"] == 2
+    s, p = C.sample_scalars(0x5EED0001, 256), C.sample_points(0x5EED0002, 256)
+    assert d["config"]["result"] == C.msm_pippenger(s, p, 4).hex()

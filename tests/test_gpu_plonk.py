@@ -5,6 +5,7 @@ proof bytes -> transcript -> expression evaluation -> MSMs on the MI355X ->
 pairing decide, against oracle/plonk.py on proofs FORGED under a toy SRS
 (no halo2 prover exists here; see oracle/plonk.py)."""
 import ctypes
+import os
 import random
 
 import pytest
