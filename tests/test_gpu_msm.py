@@ -310,9 +310,10 @@ def test_large_msm_chunk_pipelined_form_matches_unsplit(gpu_ctx, monkeypatch):
 
 
 def test_largest_config_2p24_split_linearity(gpu_ctx):
-    """BASELINE's largest size (2^24 points): too big for the CPU oracle in test time, so the
-    size-independent property -- MSM(all) == MSM(first part) + MSM(rest), through the
-    projective-partial + fold entry points the multi-GPU path uses -- at an uneven split."""
+    """BASELINE's largest size (2^24 points), the size-independent property: MSM(all) == MSM(first part) + MSM(rest),
+    through the projective-partial + fold entry points the multi-GPU path uses, at an uneven split (both parts take the
+    chunk pipeline).  The bit-for-bit comparison with the threaded C oracle at this size is
+    tests/test_gpu_fullsize.py::test_config4_2p24_bit_exact_vs_c_oracle."""
     import torch
 
     import snark_verifier_amd as sv
