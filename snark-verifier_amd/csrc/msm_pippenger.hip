@@ -62,6 +62,13 @@
 
 namespace snarkv {
 
+#ifndef SNARKV_FUSED_FILLS
+// 1: the three per-MSM fills (key x tile matrix 8 MB, bucket grid 36 MB, counters) are done by the kernels that own the
+// data -- k_prepare zeroes the matrix' padding column, k_sort_level2's last workgroup the counters, k_combine stores the
+// identity into empty buckets -- instead of three hipMemsetAsync per MSM (60 fill launches in a 20-job batch, each ~90 us
+// of queueing in front of a k_accumulate on its stream).  0: the memsets (A/B: profiles/r03_ab_fills.txt).
+#define SNARKV_FUSED_FILLS 7  // bit 0: the matrix' padding column, bit 1: the counters, bit 2: the bucket grid
+#endif
 #ifndef SNARKV_KRUN
 #define SNARKV_KRUN 64
 #endif
@@ -309,7 +316,7 @@ __global__ void __launch_bounds__(SNARKV_PREP_THREADS)
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) M[(size_t)k * p.mstride + tile] = lds[k];
-#if SNARKV_FUSED_FILLS
+#if SNARKV_FUSED_FILLS & 1
   // the padding column of the matrix (mstride = nblk | 1) must read as zero in the scan: one workgroup writes it
   if (blockIdx.x == 0 && p.mstride > p.nblk)
     for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) M[(size_t)k * p.mstride + p.nblk] = 0u;
@@ -625,7 +632,7 @@ __global__ void __launch_bounds__(SNARKV_L2_THREADS) SNARKV_LEVEL2_ATTR
       misc[2] = obn >> 1;
     }
   }
-#if SNARKV_FUSED_FILLS
+#if SNARKV_FUSED_FILLS & 2
   // [3] = 0 (start of the pair level's half-length stream), [4 .. 11] = the big-bucket counters of k_combine
   if (key == p.nkeys - 1 && threadIdx.x < 9) misc[3 + threadIdx.x] = 0u;
 #endif
@@ -650,13 +657,6 @@ __global__ void __launch_bounds__(SNARKV_L2_THREADS) SNARKV_LEVEL2_ATTR
 // One batched-affine addition level between the sort and the bucket accumulation: pair slot i = entries (2i, 2i + 1)
 // of the padded stream -> entry i of a half-length stream whose points are stored as lazy limbs.  6 field products per
 // addition instead of the 10 of the XYZZ mixed addition.  The per-lane code lives in pair_tree.h (host-testable).
-#ifndef SNARKV_FUSED_FILLS
-// 1: the three per-MSM fills (key x tile matrix 8 MB, bucket grid 36 MB, counters) are done by the kernels that own the
-// data -- k_prepare zeroes the matrix' padding column, k_sort_level2's last workgroup the counters, k_combine stores the
-// identity into empty buckets -- instead of three hipMemsetAsync per MSM (60 fill launches in a 20-job batch, each ~90 us
-// of queueing in front of a k_accumulate on its stream).  0: the memsets (A/B: profiles/r03_ab_fills.txt).
-#define SNARKV_FUSED_FILLS 1
-#endif
 #ifndef SNARKV_COMBINE_PAIRS
 #define SNARKV_COMBINE_PAIRS 0  // k_combine: 1 = run-boundary lanes for the buckets that span two runs.  Measured level in a batch and
                                 // 13 % slower alone (0.082 -> 0.093 ms): profiles/r03_ab_combine_pack.txt -- off
@@ -982,7 +982,7 @@ __global__ void __launch_bounds__(64)
   if (b >= b_hi) return;
   uint32_t cnt = counts[b];
   if (cnt == 0) {  // empty bucket = the identity (all-zero ZZ)
-#if SNARKV_FUSED_FILLS
+#if SNARKV_FUSED_FILLS & 4
     if (!LIMB) buckets[b] = xyzz29_identity();  // (behind the pair level the grid is zero-filled: all-skip buckets rely on it)
 #endif
     return;
@@ -1478,7 +1478,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   STAGE_MARK();  // 0
   size_t lds1 = (size_t)p.nkeys * 4;
   if (phases & PIP_PHASE_SORT) {
-    if (!SNARKV_FUSED_FILLS) SNARKV_HIP(hipMemsetAsync(d_M, 0, (size_t)mcount * 4, st));  // padding columns must read as zero
+    if (!(SNARKV_FUSED_FILLS & 1)) SNARKV_HIP(hipMemsetAsync(d_M, 0, (size_t)mcount * 4, st));  // padding columns must read as zero
     hipLaunchKernelGGL(k_prepare, dim3(p.nblk), dim3(SNARKV_PREP_THREADS), lds1, st, (const uint32_t*)d_scalars,
                        (const uint32_t*)d_points, (G1Packed*)d_pts, (uint4*)d_glv, p, (uint32_t*)d_M);
     STAGE_MARK();  // 1: prepare (GLV split, phi(P), to Montgomery) + digit histogram
@@ -1516,7 +1516,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
                        (uint32_t*)d_offsets2);
   }
   STAGE_MARK();  // 3: partition + level-2 sort
-  if ((phases & PIP_PHASE_ACC) && (!SNARKV_FUSED_FILLS || tree))
+  if ((phases & PIP_PHASE_ACC) && (!(SNARKV_FUSED_FILLS & 4) || tree))
     SNARKV_HIP(hipMemsetAsync(d_buckets, 0, (size_t)p.nb * sizeof(G1Xyzz29), st));
   // (Tried, both measured on MI355X and dropped: one shared stream for every k_accumulate of a device -- a software
   // pipeline across the in-flight MSMs -- and s_setprio on / off for the other kernels: the in-flight plateau moved by
@@ -1527,7 +1527,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   // accumulations on one stream now LOSES 15-25 % (1.50 -> 1.75-1.89 ms per MSM): 2 731 wavefronts leave a ninth of the
   // slots and the whole drain of every launch empty unless another MSM's accumulation overlaps it.)
   uint32_t* d_big_count = d_total + 4;  // one counter per window group
-  if ((phases & PIP_PHASE_ACC) && !SNARKV_FUSED_FILLS) SNARKV_HIP(hipMemsetAsync(d_total + 3, 0, 4 * 9, st));  // [3] = 0 (stream start of the pair level's half-length stream) + the counters
+  if ((phases & PIP_PHASE_ACC) && !(SNARKV_FUSED_FILLS & 2)) SNARKV_HIP(hipMemsetAsync(d_total + 3, 0, 4 * 9, st));  // [3] = 0 (stream start of the pair level's half-length stream) + the counters
   if (tm_acc) SNARKV_HIP(hipEventRecord(ctx->ev[3], st));
   if (tree && (phases & PIP_PHASE_ACC)) {
     int32_t* tot0 = (int32_t*)d_pair_tot + binv_off[0];
