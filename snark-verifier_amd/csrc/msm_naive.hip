@@ -62,12 +62,92 @@ __device__ __forceinline__ G1Xyzz29 half_scalar_mul(const G1Affine29& q, const u
   return acc;
 }
 
+// |k| * Q with a FIXED 3-bit window and signed digits, every lane of the wavefront in the same step:
+//   table    2Q, 3Q, 4Q (XYZZ) in LDS, one column per lane (limb-major: conflict-free); Q itself stays in registers
+//   digits   |k| = sum d_i 8^i, d_i in [-3, 4] (a digit above 4 becomes d - 8 with a carry up), 43 of them for 127 bits,
+//            recoded low to high into LDS bytes, consumed high to low
+//   step     acc <- 8 acc (three doublings; the identity doubles to itself), then acc += sign * T[|d|] by the full XYZZ
+//            addition, the operand picked by a per-lane LDS read
+// The bit-serial form above costs a WAVEFRONT 127 doublings + 127 mixed additions (some lane's bit is always set, so
+// the addition is issued at every step): ~2 400 field products.  This one: 3 + 129 doublings + 43 additions ~ 1 800,
+// and no lane waits for another's branch.  A fast addition can only meet P = +-Q here while acc is still the identity
+// (8 x prefix >= 8 > |d|), which `started` covers; the degenerate check + careful bit-serial redo stay as the net.
+#ifndef SNARKV_NAIVE_WINDOW
+#define SNARKV_NAIVE_WINDOW 1  // 0: the bit-serial double-and-add (A/B: profiles/r03_ab_naive_window.txt)
+#endif
+constexpr int kWinDigits = 43;  // ceil(127 / 3) + the carry into the one-bit top digit
+
+__device__ __forceinline__ G1Xyzz29 half_scalar_mul_w3(const G1Affine29& q, const uint32_t k[4], int32_t (*tab)[36][64],
+                                                       int8_t (*dig)[64]) {
+  const uint32_t lane = threadIdx.x;
+  // table: 2Q, 3Q, 4Q
+  G1Xyzz29 t2 = xyzz29_double_affine(q), t3 = t2;
+  xyzz29_madd_fast(t3, q);
+  G1Xyzz29 t4 = xyzz29_double(t2);
+  auto put = [&](int e, const G1Xyzz29& v) {
+#pragma unroll
+    for (int l = 0; l < 9; ++l) {
+      tab[e][l][lane] = v.x.v[l];
+      tab[e][9 + l][lane] = v.y.v[l];
+      tab[e][18 + l][lane] = v.zz.v[l];
+      tab[e][27 + l][lane] = v.zzz.v[l];
+    }
+  };
+  put(0, t2);
+  put(1, t3);
+  put(2, t4);
+  // signed digits, low to high
+  uint32_t carry = 0;
+  for (int i = 0; i < kWinDigits; ++i) {
+    const int bit = 3 * i, word = bit >> 5, sh = bit & 31;
+    uint32_t w0 = word == 0 ? k[0] : word == 1 ? k[1] : word == 2 ? k[2] : word == 3 ? k[3] : 0u;
+    uint32_t w1 = word == 0 ? k[1] : word == 1 ? k[2] : word == 2 ? k[3] : 0u;
+    uint32_t raw = (uint32_t)((((uint64_t)w1 << 32) | w0) >> sh) & 7u;
+    raw += carry;
+    carry = raw > 4u ? 1u : 0u;
+    dig[i][lane] = (int8_t)((int)raw - (carry ? 8 : 0));
+  }
+  // (the lane reads back only what it wrote: no barrier; the compiler keeps LDS accesses of one lane in order)
+  G1Xyzz29 acc = xyzz29_identity();
+  bool started = false;
+#pragma unroll 1
+  for (int i = kWinDigits - 1; i >= 0; --i) {
+    acc = xyzz29_double(xyzz29_double(xyzz29_double(acc)));  // 8 acc (all-zero stays all-zero)
+    const int d = dig[i][lane];
+    const int a = d < 0 ? -d : d;
+    if (a != 0) {
+      G1Xyzz29 sel;
+      if (a == 1) {
+        sel = xyzz29_from_affine(q);
+      } else {
+#pragma unroll
+        for (int l = 0; l < 9; ++l) {
+          sel.x.v[l] = tab[a - 2][l][lane];
+          sel.y.v[l] = tab[a - 2][9 + l][lane];
+          sel.zz.v[l] = tab[a - 2][18 + l][lane];
+          sel.zzz.v[l] = tab[a - 2][27 + l][lane];
+        }
+      }
+      if (d < 0) sel.y = fq29_neg(sel.y);
+      G1Xyzz29 sum = acc;
+      xyzz29_add_fast(sum, sel);
+      acc = started ? sum : sel;
+      started = true;
+    }
+  }
+  return acc;
+}
+
 // K1: one lane per (term, GLV half).  k = k1 + k2*lambda with |k_i| < 2^127
 // (glv.h) turns `*base * scalar` (reference native.rs:67), a 254-step chain,
 // into two independent 127-step chains on P and phi(P) = (beta x, y).
 __global__ void __launch_bounds__(64) k_term_scalar_mul(const uint32_t* __restrict__ scalars,
                                                          const uint32_t* __restrict__ points,
                                                          G1Xyzz29* __restrict__ out, uint32_t n_terms) {
+#if SNARKV_NAIVE_WINDOW
+  __shared__ int32_t tab[3][36][64];
+  __shared__ int8_t dig[kWinDigits][64];
+#endif
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= 2 * n_terms) return;
   uint32_t t = g >> 1, h = g & 1u;
@@ -90,7 +170,11 @@ __global__ void __launch_bounds__(64) k_term_scalar_mul(const uint32_t* __restri
     q.x = fq29_canon_residue(fq29_mul(q.x, beta));
   }
   if (neg) q.y = fq29_neg(q.y);
+#if SNARKV_NAIVE_WINDOW
+  G1Xyzz29 r = half_scalar_mul_w3(q, mag, tab, dig);
+#else
   G1Xyzz29 r = half_scalar_mul<false>(q, mag);
+#endif
   if (xyzz29_is_degenerate(r)) {  // P = +-Q met on the way (or a true identity): redo carefully
     r = half_scalar_mul<true>(q, mag);
     if (!xyzz29_is_identity(r) && xyzz29_is_degenerate(r)) r = xyzz29_identity();
