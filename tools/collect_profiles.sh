@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): every record the round's profiles/ directory keeps, written under gpurun_out/<tag>_*
 # (gpurun merges only gpurun_out/ back; copy what you want judged into profiles/).
-#   tools/collect_profiles.sh r02
+#   tools/collect_profiles.sh r03
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
@@ -30,6 +30,17 @@ stats 4inflight --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --infligh
 stats sequential --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --inflight 1
 stats with_secondary --steps 4 --warmup 1 --no-cpu-baseline
 stats 2p24_single --log2n 24 --inflight 1 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary
+# the timed batch as a kernel timeline (who overlaps whom): the window from the 45th k_prepare (2 x 20 initialisation / warm-up
+# jobs + the 4 slot calls) to the end of the batch's k_final
+rm -rf /tmp/prof_trace; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_trace -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+python $R/tools/trace_overlap.py /tmp/prof_trace --first 44 --count 20 --until-prepare 64 > $O/${TAG}_overlap_batch.txt 2>&1
+# the aggregation job alone (bench.py's second metric): kernel shares for secondary.aggregate_*.roofline.dominant_kernel
+for m in 64 1024; do
+  rm -rf /tmp/prof_a; rocprofv3 --kernel-trace --stats -d /tmp/prof_a -- python $R/tools/aggregate_job.py --proofs $m > /dev/null 2>&1
+  db=$(find /tmp/prof_a -name "*.db" | head -1)
+  if [ -n "$db" ]; then python $R/tools/rocpd_top_kernels.py $db $O/${TAG}_rocprofv3_kernel_stats_aggregate_$m.csv; else
+    f=$(find /tmp/prof_a -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_rocprofv3_kernel_stats_aggregate_$m.csv; fi
+done
 cd $R
 timeout 120 tools/ubench_issue > $O/${TAG}_ubench_issue.txt 2>&1
 ls -la $O | grep $TAG
