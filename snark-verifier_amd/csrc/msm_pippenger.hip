@@ -770,6 +770,26 @@ __global__ void __launch_bounds__(kPairT) k_binv_final(int32_t* __restrict__ a, 
   }
 }
 
+// The FUSED form of the pair level (pair_tree.h "pair RUNS", SNARKV_PAIR_TREE=3): lane t owns RUN entries of the padded
+// stream like a k_accumulate lane; k_pairrun_fwd leaves the prefix products of its RUN / 2 slots' denominators,
+// k_accumulate_pairs walks the slots in reverse, forms each affine pair sum (5 products) and adds it into the lane's XYZZ
+// accumulator (10 products): 16 products per TWO entries instead of 20, nothing written but the prefixes.
+template <int RUN>
+__global__ void __launch_bounds__(64)
+    k_pairrun_fwd(const uint2* __restrict__ entries, const uint32_t* __restrict__ misc, const G1Packed* __restrict__ pts,
+                  int32_t* __restrict__ pfx, int32_t* __restrict__ tot, size_t L) {
+  pairrun_fwd_lane(blockIdx.x * 64 + threadIdx.x, RUN, misc[1], reinterpret_cast<const PairEntry*>(entries), pts, pfx, tot, L);
+}
+
+template <int RUN>
+__global__ void __launch_bounds__(64, 2)
+    k_accumulate_pairs(const uint2* __restrict__ entries, const uint32_t* __restrict__ misc, const G1Packed* __restrict__ pts,
+                       const int32_t* __restrict__ pfx, const int32_t* __restrict__ itot, size_t L,
+                       G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ seg_ids, G1Xyzz29* __restrict__ seg_parts) {
+  pairrun_bwd_lane(blockIdx.x * 64 + threadIdx.x, RUN, misc[1], reinterpret_cast<const PairEntry*>(entries), pts, pfx, itot, L,
+                   buckets, seg_ids, seg_parts);
+}
+
 // --------------------------------------------------------------- P4
 // One lane = one run of kRun consecutive sorted entries.  Emits the partial of
 // the run's first bucket (head), of its last bucket if different (tail), and
@@ -1400,8 +1420,11 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   if (const char* e = getenv("SNARKV_PAIR_TREE")) tree_mode = atoi(e);
   const uint32_t nbins_l2 = 1u << p.low_bits;
   const uint64_t pad_room = (uint64_t)p.nkeys * (nbins_l2 + 2) + 2;  // k_sort_level2, pad mode: room for one pad per bin
-  const bool tree = (tree_mode == 2 || (tree_mode == 1 && ctx->throughput_mode)) && p.gsz == (uint32_t)p.W &&
+  const bool tree = (tree_mode >= 2 || (tree_mode == 1 && ctx->throughput_mode)) && p.gsz == (uint32_t)p.W &&
                     (uint64_t)kHalves * n < kEntrySkip && max_entries + pad_room < kEntrySkip;
+  // 3: the FUSED form -- the backward pass adds the pair sums straight into the bucket accumulators (k_accumulate_pairs);
+  // run lengths 64 / 96 only (the two the kernels are instantiated for)
+  const bool fused = tree && tree_mode == 3 && (p.krun == (uint32_t)kRun || p.krun == (uint32_t)kRunThroughput);
   p.pad = tree ? 1u : 0u;
   const uint64_t cap_entries = max_entries + (tree ? pad_room : 0);
   auto round_up = [](uint64_t v, uint64_t q) { return (v + q - 1) / q * q; };
@@ -1410,7 +1433,8 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   const uint64_t pairS = pairL * kPairM;                                   // slot capacity = stride of the prefix array
   uint64_t binvN[8];
   int binv_levels = 0;  // binvN[0] = the pair lanes' totals; level q + 1 = the lane totals of level q; the last one <= kBinvFinalMax
-  binvN[0] = pairL;
+  const uint64_t fusedL = round_up((cap_entries + p.krun - 1) / p.krun + 1, 256);  // lanes of the fused kernels (every one writes a total)
+  binvN[0] = fused ? fusedL : pairL;
   while (binvN[binv_levels] > kBinvFinalMax && binv_levels < 6) {
     binvN[binv_levels + 1] = round_up((binvN[binv_levels] + kBinvM - 1) / kBinvM, kPairT);
     ++binv_levels;
@@ -1419,6 +1443,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   uint32_t max_runs = (uint32_t)p.W * p.rpw;  // run slots (head / tail partial each)
   // ... behind the pair level the runs are cut from the half-length stream, whose pad room can outweigh a tiny MSM's entries
   if (tree) max_runs = std::max<uint32_t>(max_runs, (uint32_t)((slots_max + p.krun - 1) / p.krun) + 1);
+  if (fused) max_runs = std::max<uint32_t>(max_runs, (uint32_t)fusedL);
   uint32_t mcount = p.nkeys * p.mstride;
   uint32_t scan_blocks = (mcount + 1023) / 1024;
   uint32_t chunks_per_window = (p.B + kChunk - 1) / kChunk;
@@ -1449,15 +1474,17 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   if (tree) {
     SNARKV_TRY(ctx_reserve(ctx, SLOT_COUNTS2, (size_t)p.nb * 4, &d_counts2));
     SNARKV_TRY(ctx_reserve(ctx, SLOT_OFFSETS2, (size_t)p.nb * 4, &d_offsets2));
-    SNARKV_TRY(ctx_reserve(ctx, SLOT_PAIR_PFX, (size_t)pairS * 36, &d_pair_pfx));
+    SNARKV_TRY(ctx_reserve(ctx, SLOT_PAIR_PFX, fused ? (size_t)fusedL * (p.krun / 2) * 36 : (size_t)pairS * 36, &d_pair_pfx));
     size_t words = 0;
     for (int q = 0; q <= binv_levels; ++q) {
       binv_off[q] = words;
       words += 2 * 9 * (size_t)binvN[q];
     }
     SNARKV_TRY(ctx_reserve(ctx, SLOT_PAIR_TOT, words * 4, &d_pair_tot));
-    SNARKV_TRY(ctx_reserve(ctx, SLOT_PAIR_PTS, (size_t)pairS * 72, &d_pair_pts));
-    SNARKV_TRY(ctx_reserve(ctx, SLOT_PAIR_ENTRIES, (size_t)pairS * 8, &d_pair_entries));
+    if (!fused) {
+      SNARKV_TRY(ctx_reserve(ctx, SLOT_PAIR_PTS, (size_t)pairS * 72, &d_pair_pts));
+      SNARKV_TRY(ctx_reserve(ctx, SLOT_PAIR_ENTRIES, (size_t)pairS * 8, &d_pair_entries));
+    }
   }
   if ((size_t)p.nkeys * 4 > 65536) {
     set_last_error("pippenger: key table too large (nkeys=%u)", p.nkeys);
@@ -1531,8 +1558,13 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   if (tm_acc) SNARKV_HIP(hipEventRecord(ctx->ev[3], st));
   if (tree && (phases & PIP_PHASE_ACC)) {
     int32_t* tot0 = (int32_t*)d_pair_tot + binv_off[0];
-    hipLaunchKernelGGL(k_pair_fwd, dim3((uint32_t)(pairL / kPairT)), dim3(kPairT), 0, st, (const uint2*)d_entries,
-                       (const uint32_t*)d_total, (const G1Packed*)d_pts, (int32_t*)d_pair_pfx, (size_t)pairS, tot0, (size_t)pairL);
+    if (fused)
+      hipLaunchKernelGGL(p.krun == (uint32_t)kRun ? k_pairrun_fwd<kRun> : k_pairrun_fwd<kRunThroughput>, dim3((uint32_t)(fusedL / 64)),
+                         dim3(64), 0, st, (const uint2*)d_entries, (const uint32_t*)d_total, (const G1Packed*)d_pts,
+                         (int32_t*)d_pair_pfx, tot0, (size_t)fusedL);
+    else
+      hipLaunchKernelGGL(k_pair_fwd, dim3((uint32_t)(pairL / kPairT)), dim3(kPairT), 0, st, (const uint2*)d_entries,
+                         (const uint32_t*)d_total, (const G1Packed*)d_pts, (int32_t*)d_pair_pfx, (size_t)pairS, tot0, (size_t)pairL);
     for (int q = 0; q < binv_levels; ++q) {
       int32_t* a = (int32_t*)d_pair_tot + binv_off[q];
       hipLaunchKernelGGL(k_binv_up, dim3((uint32_t)(binvN[q + 1] / kPairT)), dim3(kPairT), 0, st, (const int32_t*)a,
@@ -1547,9 +1579,15 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
                          (size_t)binvN[q], (const int32_t*)(a + 9 * binvN[q]), (const int32_t*)d_pair_tot + binv_off[q + 1],
                          (size_t)binvN[q + 1]);
     }
-    hipLaunchKernelGGL(k_pair_bwd, dim3((uint32_t)(pairL / kPairT)), dim3(kPairT), 0, st, (const uint2*)d_entries,
-                       (const uint32_t*)d_total, (const G1Packed*)d_pts, (const int32_t*)d_pair_pfx, (size_t)pairS,
-                       (const int32_t*)tot0, (size_t)pairL, (uint2*)d_pair_entries, (int32_t*)d_pair_pts);
+    if (fused)
+      hipLaunchKernelGGL(p.krun == (uint32_t)kRun ? k_accumulate_pairs<kRun> : k_accumulate_pairs<kRunThroughput>,
+                         dim3((uint32_t)(fusedL / 64)), dim3(64), 0, st, (const uint2*)d_entries, (const uint32_t*)d_total,
+                         (const G1Packed*)d_pts, (const int32_t*)d_pair_pfx, (const int32_t*)tot0, (size_t)fusedL,
+                         (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids, (G1Xyzz29*)d_seg_parts);
+    else
+      hipLaunchKernelGGL(k_pair_bwd, dim3((uint32_t)(pairL / kPairT)), dim3(kPairT), 0, st, (const uint2*)d_entries,
+                         (const uint32_t*)d_total, (const G1Packed*)d_pts, (const int32_t*)d_pair_pfx, (size_t)pairS,
+                         (const int32_t*)tot0, (size_t)pairL, (uint2*)d_pair_entries, (int32_t*)d_pair_pts);
   }
   // Window groups (opt-in, see p.gsz above), top first: group j = windows [j gsz, (j+1) gsz).  Its accumulation runs on the context's stream;
   // its tail -- combine, bucket reduce, the 2^(c w) shift chain (the longest for the TOP windows: c w doublings, a
@@ -1568,7 +1606,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   }
   for (int j = (int)ngroups - 1; j >= 0; --j) {
     const uint32_t w0 = (uint32_t)j * p.gsz, w1 = std::min<uint32_t>((uint32_t)p.W, w0 + p.gsz), wcount = w1 - w0;
-    const uint32_t lanes = tree ? (uint32_t)((slots_max + p.krun - 1) / p.krun) : wcount * p.rpw;
+    const uint32_t lanes = fused ? (uint32_t)fusedL : tree ? (uint32_t)((slots_max + p.krun - 1) / p.krun) : wcount * p.rpw;
     auto acc_kernel = p.krun == 16u ? k_accumulate<16, false> : p.krun == 32u ? k_accumulate<32, false>
                       : p.krun == (uint32_t)kRun ? k_accumulate<kRun, false> : k_accumulate<kRunThroughput, false>;
     auto acc_tree = p.krun == 16u ? k_accumulate<16, true> : p.krun == 32u ? k_accumulate<32, true>
@@ -1578,7 +1616,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
                          (const uint32_t*)d_total, (const void*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
                          (G1Xyzz29*)d_seg_parts, (const uint32_t*)d_M, p.mstride, w0 * p.SB, w1 * p.SB, p.nkeys, w0 * p.rpw);
     // behind the pair level: the half-length stream [0, misc[2]) of (entry, lazy-limb point) pairs, one window group
-    if ((phases & PIP_PHASE_ACC) && tree)
+    if ((phases & PIP_PHASE_ACC) && tree && !fused)
       hipLaunchKernelGGL(acc_tree, dim3((lanes + 63) / 64), dim3(64), 0, st, (const uint2*)d_pair_entries,
                          (const uint32_t*)(d_total + 2), (const void*)d_pair_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
                          (G1Xyzz29*)d_seg_parts, (const uint32_t*)(d_total + 3), 0u, 0u, p.nkeys, p.nkeys, 0u);
@@ -1593,20 +1631,22 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
     }
     if (phases & PIP_PHASE_ACC) {
       // the stream the partials were cut from: the sorted entries, or the pair level's half-length stream
-      const uint32_t* cc = (const uint32_t*)(tree ? d_counts2 : d_counts);
-      const uint32_t* co = (const uint32_t*)(tree ? d_offsets2 : d_offsets);
-      const uint2* ce = (const uint2*)(tree ? d_pair_entries : d_entries);
-      const void* cp = tree ? (const void*)d_pair_pts : (const void*)d_pts;
+      // (the fused form cuts its runs from the PADDED level-1 stream itself: packed points, stream start 0)
+      const bool half = tree && !fused;
+      const uint32_t* cc = (const uint32_t*)(half ? d_counts2 : d_counts);
+      const uint32_t* co = (const uint32_t*)(half ? d_offsets2 : d_offsets);
+      const uint2* ce = (const uint2*)(half ? d_pair_entries : d_entries);
+      const void* cp = half ? (const void*)d_pair_pts : (const void*)d_pts;
       const uint32_t* cm = tree ? (const uint32_t*)(d_total + 3) : (const uint32_t*)d_M;
       const uint32_t bucket_blocks = (wcount * p.B + 63) / 64, pair_blocks = (tree || !SNARKV_COMBINE_PAIRS) ? 0u : (lanes + 63) / 64;
-      hipLaunchKernelGGL(tree ? k_combine<true> : k_combine<false>, dim3(bucket_blocks + pair_blocks), dim3(64), 0, ts, cc, co, p,
+      hipLaunchKernelGGL(half ? k_combine<true> : k_combine<false>, dim3(bucket_blocks + pair_blocks), dim3(64), 0, ts, cc, co, p,
                          ce, cp, (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets,
                          d_big_count + j, (uint32_t*)d_big + (size_t)j * kMaxBig, cm, w0 * p.B, w1 * p.B, bucket_blocks,
                          w0 * p.rpw, lanes);
       // one workgroup per oversized bucket; idle workgroups exit at once
       uint32_t big_grid = (uint32_t)(lanes / kBigSpan + 1);
       if (big_grid > kMaxBig) big_grid = kMaxBig;
-      hipLaunchKernelGGL(tree ? k_combine_big<true> : k_combine_big<false>, dim3(big_grid), dim3(256), 0, ts, cc, co, ce, cp,
+      hipLaunchKernelGGL(half ? k_combine_big<true> : k_combine_big<false>, dim3(big_grid), dim3(256), 0, ts, cc, co, ce, cp,
                          (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets,
                          (const uint32_t*)(d_big_count + j), (const uint32_t*)d_big + (size_t)j * kMaxBig, p, cm);
       if (tm_acc) SNARKV_HIP(hipEventRecord(ctx->ev[5], st));

@@ -23,6 +23,7 @@
 // Everything here is per-lane code with explicit indices (no threadIdx): the kernels call it with their lane id, and
 // tests/hosttest runs the same functions in host loops against the big-integer oracle.
 #pragma once
+#include <stddef.h>
 #include "g1_29.h"
 
 namespace snarkv {
@@ -184,6 +185,141 @@ SNARKV_HD void pair_bwd_lane(uint32_t j, uint32_t T, uint32_t m, uint32_t nslots
       out_pts[18 * i + 9 + l] = y3.v[l];
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ fused form (pair RUNS)
+// The level above writes its sums out (72 B per slot) and a second kernel accumulates them.  The fused form keeps the
+// run structure of the bucket accumulation instead: lane t owns RUN consecutive entries of the PADDED stream (RUN even:
+// H = RUN / 2 pair slots), the forward kernel leaves the prefix products of its slots' denominators, and the backward
+// kernel walks the same slots in reverse, forms each affine pair sum and adds it straight into the lane's XYZZ bucket
+// accumulator -- head / tail partials and interior buckets exactly as k_accumulate leaves them for k_combine.  No sums
+// are written or re-read, and the half-length stream never exists: 3.0 GB through the fabric per MSM instead of 4.3.
+// Prefix scratch is private to the two kernels: element (wavefront, slot k, limb, lane) -- every store one segment.
+constexpr uint32_t kPairNoBucket = 0xFFFFFFFFu;  // == kNoBucket of msm_pippenger.hip
+
+SNARKV_HD size_t pairrun_pfx_index(uint32_t t, uint32_t H, uint32_t k, int limb) {
+  return ((((size_t)(t >> 6) * H + k) * 9 + (size_t)limb) << 6) + (t & 63u);
+}
+
+// what a slot contributes: kind + (for ADD / DBL) the operands; `d` = its denominator (1 for the other kinds)
+struct PairSlot {
+  uint32_t kind;
+  Fq29 x0, y0, x1, y1;  // y carry their signs
+};
+SNARKV_HD PairSlot pair_slot_load(const PairEntry& e0, const PairEntry& e1, const G1Packed* pts, bool need_y) {
+  PairSlot s;
+  s.kind = pair_kind_of_flags(e0, e1);
+  s.x0 = s.y0 = s.x1 = s.y1 = fq29_zero();
+  if (s.kind == PAIR_SKIP) return s;
+  const G1Packed& a = pts[e0.y & kEntryIdx];
+  if (s.kind == PAIR_COPY) {
+    if (need_y) {
+      s.x0 = fq29_unpack256(a.w);
+      s.y0 = fq29_unpack256(a.w + 8);
+      if (e0.y >> 31) s.y0 = fq29_neg(s.y0);
+    }
+    return s;
+  }
+  const G1Packed& b = pts[e1.y & kEntryIdx];
+  s.kind = pair_refine(e0, e1, a.w, b.w, a.w + 8, b.w + 8);
+  if (s.kind == PAIR_CANCEL) return s;
+  s.x0 = fq29_unpack256(a.w);
+  s.x1 = fq29_unpack256(b.w);
+  if (need_y || s.kind == PAIR_DBL) {
+    s.y0 = fq29_unpack256(a.w + 8);
+    if (e0.y >> 31) s.y0 = fq29_neg(s.y0);
+  }
+  if (need_y) {
+    s.y1 = fq29_unpack256(b.w + 8);
+    if (e1.y >> 31) s.y1 = fq29_neg(s.y1);
+  }
+  return s;
+}
+
+// forward: lane t, entries [t RUN, min((t + 1) RUN, stop)); `stop` = padded entries (even).  tot[t] = the product of the
+// lane's denominators (1 for a lane beyond the stream: the inversion levels run over every lane)
+SNARKV_HD void pairrun_fwd_lane(uint32_t t, uint32_t RUN, uint32_t stop, const PairEntry* entries, const G1Packed* pts,
+                                int32_t* pfx, int32_t* tot, size_t L) {
+  const uint64_t begin = (uint64_t)t * RUN;
+  const uint32_t H = RUN / 2;
+  Fq29 pr = fq29_one();
+  bool have = false;
+  if (begin < stop) {
+    const uint32_t nsl = (uint32_t)(((stop - begin > RUN) ? RUN : (stop - begin)) / 2);
+    for (uint32_t k = 0; k < nsl; ++k) {
+      if (k > 0) {
+#pragma unroll
+        for (int l = 0; l < 9; ++l) pfx[pairrun_pfx_index(t, H, k, l)] = pr.v[l];
+      }
+      const PairEntry e0 = entries[begin + 2 * k], e1 = entries[begin + 2 * k + 1];
+      const PairSlot sl = pair_slot_load(e0, e1, pts, false);
+      if (sl.kind != PAIR_ADD && sl.kind != PAIR_DBL) continue;
+      const Fq29 d = pair_denominator(sl.kind, sl.x0, sl.x1, sl.y0);
+      pr = have ? fq29_mul(pr, d) : d;
+      have = true;
+    }
+  }
+  soa_store(tot, L, t, fq29_norm(pr));
+}
+
+// backward + accumulate: itot[t] = 1 / tot[t].  Leaves, for run slot t (as k_accumulate does): seg_ids[2t] / seg_parts[2t] =
+// the partial of the run's FIRST bucket, [2t + 1] = of its LAST bucket if different (kPairNoBucket otherwise, and for a
+// part that held skip slots only), complete interior buckets straight in `buckets`.
+SNARKV_HD void pairrun_bwd_lane(uint32_t t, uint32_t RUN, uint32_t stop, const PairEntry* entries, const G1Packed* pts,
+                                const int32_t* pfx, const int32_t* itot, size_t L, G1Xyzz29* buckets, uint32_t* seg_ids,
+                                G1Xyzz29* seg_parts) {
+  const uint64_t begin = (uint64_t)t * RUN;
+  if (begin >= stop) return;
+  const uint32_t H = RUN / 2;
+  const uint32_t nsl = (uint32_t)(((stop - begin > RUN) ? RUN : (stop - begin)) / 2);
+  Fq29 I = soa_load(itot, L, t);
+  uint32_t cur = entries[begin + 2 * (nsl - 1)].bucket;
+  bool tail_written = false, fresh = true;
+  G1Xyzz29 acc = xyzz29_identity();
+  for (int k = (int)nsl - 1; k >= 0; --k) {
+    const PairEntry e0 = entries[begin + 2 * k], e1 = entries[begin + 2 * k + 1];
+    if (e0.bucket != cur) {  // walking down: the bucket above is finished
+      if (!tail_written) {
+        seg_ids[2 * (size_t)t + 1] = fresh ? kPairNoBucket : cur;
+        if (!fresh) seg_parts[2 * (size_t)t + 1] = acc;
+        tail_written = true;
+      } else if (!fresh) {
+        buckets[cur] = acc;  // complete interior bucket
+      }
+      cur = e0.bucket;
+      fresh = true;
+    }
+    const PairSlot sl = pair_slot_load(e0, e1, pts, true);
+    if (sl.kind == PAIR_SKIP || sl.kind == PAIR_CANCEL) continue;
+    G1Affine29 p;
+    if (sl.kind == PAIR_COPY) {
+      p.x = sl.x0;
+      p.y = sl.y0;
+    } else {
+      const Fq29 d = pair_denominator(sl.kind, sl.x0, sl.x1, sl.y0);
+      Fq29 inv = I;
+      if (k > 0) {
+        Fq29 pr;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) pr.v[l] = pfx[pairrun_pfx_index(t, H, (uint32_t)k, l)];
+        inv = fq29_mul(I, pr);
+        I = fq29_mul(I, d);
+      }
+      pair_sum(sl.kind, sl.x0, sl.y0, sl.x1, sl.y1, inv, p.x, p.y);
+    }
+    if (fresh) {
+      acc.x = p.x;
+      acc.y = p.y;
+      acc.zz = fq29_one();
+      acc.zzz = fq29_one();
+      fresh = false;
+    } else {
+      xyzz29_madd_fast(acc, p);
+    }
+  }
+  seg_ids[2 * (size_t)t] = fresh ? kPairNoBucket : cur;
+  if (!fresh) seg_parts[2 * (size_t)t] = acc;
+  if (!tail_written) seg_ids[2 * (size_t)t + 1] = kPairNoBucket;
 }
 
 // ---- the same trick on plain arrays of field elements (the lane totals): a[0 .. N) -> inverses in place ----------------

@@ -378,3 +378,31 @@ extern "C" int ht_pair_level(const uint8_t* points64, uint32_t npts, const uint3
   return levels;
 }
 
+// ---------------- fused pair RUNS (pair_tree.h pairrun_*): forward lanes, inverted totals, backward + accumulate lanes, then a
+// plain per-bucket stitch of what they left (interior buckets + head / tail partials) -> one affine point per bucket.
+// entries: `stop` (even) padded (bucket, y) entries sorted by bucket, buckets numbered 0 .. nb-1.
+extern "C" int ht_pair_runs(const uint8_t* points64, uint32_t npts, const uint32_t* entries, uint32_t stop, uint32_t RUN,
+                            uint32_t nb, uint8_t* out_xy) {
+  std::vector<G1Packed> pts(npts);
+  for (uint32_t i = 0; i < npts; ++i) pts[i] = g1a29_pack(load_g1_29(points64 + 64 * i));
+  const PairEntry* ent = reinterpret_cast<const PairEntry*>(entries);
+  const uint32_t lanes = ((stop + RUN - 1) / RUN + 63) / 64 * 64 + 64;  // whole wavefronts, one of them beyond the stream
+  const uint32_t H = RUN / 2;
+  std::vector<int32_t> pfx((size_t)(lanes / 64) * H * 9 * 64, 0), tot(9 * (size_t)lanes, 0);
+  for (uint32_t t = 0; t < lanes; ++t) pairrun_fwd_lane(t, RUN, stop, ent, pts.data(), pfx.data(), tot.data(), lanes);
+  for (uint32_t t = 0; t < lanes; ++t) soa_store(tot.data(), lanes, t, fq29_inv(soa_load(tot.data(), lanes, t)));
+  std::vector<G1Xyzz29> buckets(nb, xyzz29_identity()), parts(2 * (size_t)lanes, xyzz29_identity());
+  std::vector<uint32_t> ids(2 * (size_t)lanes, 0xFFFFFFFFu);
+  for (uint32_t t = 0; t < lanes; ++t)
+    pairrun_bwd_lane(t, RUN, stop, ent, pts.data(), pfx.data(), tot.data(), lanes, buckets.data(), ids.data(), parts.data());
+  int nparts = 0;
+  for (size_t q = 0; q < ids.size(); ++q)
+    if (ids[q] != 0xFFFFFFFFu) {
+      if (ids[q] >= nb) return -1;
+      xyzz29_add_careful(buckets[ids[q]], parts[q]);
+      ++nparts;
+    }
+  for (uint32_t b = 0; b < nb; ++b) store_g1_29(xyzz29_to_affine(buckets[b]), out_xy + 64 * (size_t)b);
+  return nparts;
+}
+

@@ -90,3 +90,46 @@ def test_pair_level_equal_x_distinct_points_and_identity_free_inputs(hosttest_li
         exp = _expected(pts, entries[2 * i], entries[2 * i + 1])
         assert oxy[64 * i:64 * i + 64] == O.g1_to_bytes(exp)
         assert bool(oe[2 * i + 1] & SKIP) == (exp is None)
+
+
+@pytest.mark.parametrize("RUN,seed", [(4, 1), (16, 2), (64, 3), (96, 4), (2, 5)])
+def test_fused_pair_runs_bucket_sums(hosttest_lib, RUN, seed):
+    """The FUSED form (pairrun_fwd_lane / pairrun_bwd_lane: the backward pass adds every pair sum straight into the lane's
+    bucket accumulator and leaves head / tail partials + interior buckets as k_accumulate does): every bucket of a padded
+    stream must come out as the sum of its entries -- buckets of 1 .. 40 entries, so they start / end / span anywhere
+    relative to the runs, incl. runs of skip slots only, doublings and cancelling pairs."""
+    rng = random.Random(77 + seed)
+    npts = 30
+    raw = C.sample_points(0x9A20 + seed, npts)
+    pts = [raw[64 * i:64 * i + 64] for i in range(npts)]
+    entries, expected, nb = [], [], 60
+    for b in range(nb):
+        cnt = rng.choice([0, 1, 2, 3, 5, 8, 13, 40])
+        real = []
+        for _ in range(cnt):
+            kind = rng.random()
+            a = rng.randrange(npts)
+            sg = rng.choice([0, NEG])
+            if kind < 0.1 and real:        # repeat the previous entry: a doubling when they pair up
+                real.append(real[-1])
+            elif kind < 0.2 and real:      # ... or its opposite: a cancelling pair
+                real.append((real[-1][0], real[-1][1] ^ NEG))
+            else:
+                real.append((b, a | sg))
+        pad = [(b, SKIP)] * (len(real) % 2)
+        if rng.random() < 0.15:
+            pad += [(b, SKIP)] * (2 * rng.randrange(1, 4))  # the filler a key's last bin gets: whole skip slots
+        entries += real + pad
+        acc = None
+        for e in real:
+            acc = O.g1_add(acc, _expected(pts, e, (0, SKIP)))
+        expected.append(acc)
+    stop = len(entries)
+    assert stop % 2 == 0
+    flat = (ctypes.c_uint32 * (2 * stop))(*[w for e in entries for w in e])
+    out = ctypes.create_string_buffer(64 * nb)
+    hosttest_lib.ht_pair_runs.restype = ctypes.c_int
+    rc = hosttest_lib.ht_pair_runs(b"".join(pts), npts, flat, stop, RUN, nb, out)
+    assert rc >= 0
+    for b in range(nb):
+        assert out.raw[64 * b:64 * b + 64] == O.g1_to_bytes(expected[b]), (RUN, b)
