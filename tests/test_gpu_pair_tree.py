@@ -13,9 +13,13 @@ import coracle as C
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def tree_on(monkeypatch):
-    monkeypatch.setenv("SNARKV_PAIR_TREE", "2")
+@pytest.fixture(params=["2", "3"], ids=["two-kernel", "fused"])
+def tree_on(monkeypatch, request):
+    """2 = the level as its own kernels + a half-length stream; 3 = the FUSED form (k_pairrun_fwd / k_accumulate_pairs: the
+    backward pass adds the pair sums straight into the bucket accumulators; runs of 64 / 96 entries, i.e. >= 2^20 points
+    or a context with the throughput hint -- other run lengths fall back to form 2)"""
+    monkeypatch.setenv("SNARKV_PAIR_TREE", request.param)
+    return request.param
 
 
 def test_golden_cases_with_pair_level(gpu_ctx, golden_msm, tree_on):
@@ -26,8 +30,15 @@ def test_golden_cases_with_pair_level(gpu_ctx, golden_msm, tree_on):
 
 @pytest.mark.parametrize("n", [1, 2, 3, 31, 64, 65, 1000, 4097, (1 << 16) + 3, 1 << 18])
 def test_ragged_sizes_vs_c_oracle(gpu_ctx, n, tree_on):
+    import snark_verifier_amd as sv
+
     s, p = C.sample_scalars(300 + n, n), C.sample_points(400 + n, n)
-    assert gpu_ctx.msm_pippenger(s, p) == C.msm_pippenger(s, p, 8)
+    exp = C.msm_pippenger(s, p, 8)
+    assert gpu_ctx.msm_pippenger(s, p) == exp
+    hinted = sv.Context(0)
+    hinted.set_throughput_hint(True)  # 96-entry runs: the fused form at every size
+    assert hinted.msm_pippenger(s, p) == exp
+    hinted.close()
 
 
 def test_exceptional_pairs_inside_buckets(gpu_ctx, tree_on, monkeypatch):
@@ -41,6 +52,10 @@ def test_exceptional_pairs_inside_buckets(gpu_ctx, tree_on, monkeypatch):
     for i in range(0, n, 97):
         pts[i] = bytes(64)                                            # identity bases contribute nothing
     p = b"".join(pts)
+    import snark_verifier_amd as sv
+
+    hinted = sv.Context(0)
+    hinted.set_throughput_hint(True)
     for name, sc in (
         ("all_same_scalar", [0x1234567] * n),                 # one bucket per window holds everything
         ("two_values", [5 + (i & 1) for i in range(n)]),
@@ -51,16 +66,20 @@ def test_exceptional_pairs_inside_buckets(gpu_ctx, tree_on, monkeypatch):
         s = C.sample_scalars(0x72, n) if sc is None else b"".join(O.fe_to_bytes(x) for x in sc)
         exp = C.msm_pippenger(s, p, 8)
         assert gpu_ctx.msm_pippenger(s, p) == exp, name
+        assert hinted.msm_pippenger(s, p) == exp, name
         monkeypatch.setenv("SNARKV_PAIR_TREE", "0")
         assert gpu_ctx.msm_pippenger(s, p) == exp, name
-        monkeypatch.setenv("SNARKV_PAIR_TREE", "2")
+        monkeypatch.setenv("SNARKV_PAIR_TREE", tree_on)
     # P and -P with the SAME scalar, adjacent in every bucket: whole buckets cancel
     half = C.sample_points(0x73, 500)
     both = b"".join(half[64 * i:64 * i + 64] + O.g1_to_bytes(O.g1_neg(O.g1_from_bytes(half[64 * i:64 * i + 64]))) for i in range(500))
     sc = C.sample_scalars(0x74, 500)
     s2 = b"".join(sc[32 * i:32 * i + 32] * 2 for i in range(500))
     assert gpu_ctx.msm_pippenger(s2, both) == bytes(64)
+    assert hinted.msm_pippenger(s2, both) == bytes(64)
     assert gpu_ctx.msm_pippenger(s2 + O.fe_to_bytes(9), both + O.g1_to_bytes(O.G1_GEN)) == O.g1_to_bytes(O.g1_mul(O.G1_GEN, 9))
+    assert hinted.msm_pippenger(s2 + O.fe_to_bytes(9), both + O.g1_to_bytes(O.G1_GEN)) == O.g1_to_bytes(O.g1_mul(O.G1_GEN, 9))
+    hinted.close()
 
 
 def test_window_sizes_and_hint(gpu_ctx, tree_on):
@@ -104,8 +123,9 @@ def test_2p20_bench_seeds_bit_exact_with_pair_level(gpu_ctx, tree_on):
     assert bytes(out.cpu().numpy()) == exp
 
 
-def test_batch_and_chunk_pipeline_with_pair_level(gpu_ctx, monkeypatch):
-    """SNARKV_PAIR_TREE=1: the level follows the throughput hint -- a batch's job contexts and the chunk pipeline's
+@pytest.mark.parametrize("mode", ["1", "3"])
+def test_batch_and_chunk_pipeline_with_pair_level(gpu_ctx, monkeypatch, mode):
+    """SNARKV_PAIR_TREE=1 (3: the fused form): the level follows the throughput hint -- a batch's job contexts and the chunk pipeline's
     worker lanes always carry it -- and the bytes equal the level-off single calls."""
     import torch
 
@@ -119,7 +139,7 @@ def test_batch_and_chunk_pipeline_with_pair_level(gpu_ctx, monkeypatch):
         exp.append(gpu_ctx.msm_pippenger(s, p))
         assert exp[-1] == C.msm_pippenger(s, p, 8)
     out = torch.zeros(64 * len(sizes), dtype=torch.uint8, device="cuda")
-    monkeypatch.setenv("SNARKV_PAIR_TREE", "1")
+    monkeypatch.setenv("SNARKV_PAIR_TREE", mode)
     gpu_ctx.msm_pippenger_many_dev([t.data_ptr() for t in ds], [t.data_ptr() for t in dp], sizes, out.data_ptr())
     gpu_ctx.sync()
     assert bytes(out.cpu().numpy()) == b"".join(exp)
