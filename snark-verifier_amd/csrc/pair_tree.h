@@ -201,37 +201,62 @@ SNARKV_HD size_t pairrun_pfx_index(uint32_t t, uint32_t H, uint32_t k, int limb)
   return ((((size_t)(t >> 6) * H + k) * 9 + (size_t)limb) << 6) + (t & 63u);
 }
 
-// what a slot contributes: kind + (for ADD / DBL) the operands; `d` = its denominator (1 for the other kinds)
+// A slot as the kernels hold it between its loads and its arithmetic: the two entries and the raw (packed) words of the
+// two points.  Loading is separate from using so that slot k - 1 (backward) / k + 1 (forward) is in flight while slot k's
+// ~3 500 instructions run -- the same software pipeline as k_accumulate's.
+struct PairRaw {
+  PairEntry e0, e1;
+  uint32_t a[16], b[16];  // x | y words of e0's / e1's point (stale when the entry is a pad)
+};
+template <bool NEED_Y>
+SNARKV_HD void pair_raw_load(PairRaw& r, const PairEntry* entries, size_t i0, const G1Packed* pts) {
+  r.e0 = entries[i0];
+  r.e1 = entries[i0 + 1];
+  const uint32_t ia = (r.e0.y & kEntrySkip) ? 0u : (r.e0.y & kEntryIdx);  // a pad reads point 0: always mapped, never used
+  const uint32_t ib = (r.e1.y & kEntrySkip) ? ia : (r.e1.y & kEntryIdx);
+  const uint32_t* pa = pts[ia].w;
+  const uint32_t* pb = pts[ib].w;
+#pragma unroll
+  for (int j = 0; j < (NEED_Y ? 16 : 8); ++j) {
+    r.a[j] = pa[j];
+    r.b[j] = pb[j];
+  }
+}
+
+// what a slot contributes: kind + (for ADD / DBL) the operands; y carry their signs
 struct PairSlot {
   uint32_t kind;
-  Fq29 x0, y0, x1, y1;  // y carry their signs
+  Fq29 x0, y0, x1, y1;
 };
-SNARKV_HD PairSlot pair_slot_load(const PairEntry& e0, const PairEntry& e1, const G1Packed* pts, bool need_y) {
+// NEED_Y = false (the forward pass): only what the denominator needs; the y words are then read from memory in the rare
+// x0 == x1 case (`pts`), not from the raw slot
+template <bool NEED_Y>
+SNARKV_HD PairSlot pair_slot_decode(const PairRaw& r, const G1Packed* pts) {
   PairSlot s;
-  s.kind = pair_kind_of_flags(e0, e1);
+  s.kind = pair_kind_of_flags(r.e0, r.e1);
   s.x0 = s.y0 = s.x1 = s.y1 = fq29_zero();
   if (s.kind == PAIR_SKIP) return s;
-  const G1Packed& a = pts[e0.y & kEntryIdx];
   if (s.kind == PAIR_COPY) {
-    if (need_y) {
-      s.x0 = fq29_unpack256(a.w);
-      s.y0 = fq29_unpack256(a.w + 8);
-      if (e0.y >> 31) s.y0 = fq29_neg(s.y0);
+    if (NEED_Y) {
+      s.x0 = fq29_unpack256(r.a);
+      s.y0 = fq29_unpack256(r.a + 8);
+      if (r.e0.y >> 31) s.y0 = fq29_neg(s.y0);
     }
     return s;
   }
-  const G1Packed& b = pts[e1.y & kEntryIdx];
-  s.kind = pair_refine(e0, e1, a.w, b.w, a.w + 8, b.w + 8);
+  const uint32_t* ya = NEED_Y ? r.a + 8 : pts[r.e0.y & kEntryIdx].w + 8;
+  const uint32_t* yb = NEED_Y ? r.b + 8 : pts[r.e1.y & kEntryIdx].w + 8;
+  s.kind = pair_refine(r.e0, r.e1, r.a, r.b, ya, yb);
   if (s.kind == PAIR_CANCEL) return s;
-  s.x0 = fq29_unpack256(a.w);
-  s.x1 = fq29_unpack256(b.w);
-  if (need_y || s.kind == PAIR_DBL) {
-    s.y0 = fq29_unpack256(a.w + 8);
-    if (e0.y >> 31) s.y0 = fq29_neg(s.y0);
+  s.x0 = fq29_unpack256(r.a);
+  s.x1 = fq29_unpack256(r.b);
+  if (NEED_Y || s.kind == PAIR_DBL) {
+    s.y0 = fq29_unpack256(ya);
+    if (r.e0.y >> 31) s.y0 = fq29_neg(s.y0);
   }
-  if (need_y) {
-    s.y1 = fq29_unpack256(b.w + 8);
-    if (e1.y >> 31) s.y1 = fq29_neg(s.y1);
+  if (NEED_Y) {
+    s.y1 = fq29_unpack256(yb);
+    if (r.e1.y >> 31) s.y1 = fq29_neg(s.y1);
   }
   return s;
 }
@@ -246,13 +271,16 @@ SNARKV_HD void pairrun_fwd_lane(uint32_t t, uint32_t RUN, uint32_t stop, const P
   bool have = false;
   if (begin < stop) {
     const uint32_t nsl = (uint32_t)(((stop - begin > RUN) ? RUN : (stop - begin)) / 2);
+    PairRaw cur, nxt;
+    pair_raw_load<false>(nxt, entries, begin, pts);
     for (uint32_t k = 0; k < nsl; ++k) {
+      cur = nxt;
+      if (k + 1 < nsl) pair_raw_load<false>(nxt, entries, begin + 2 * (k + 1), pts);  // in flight during slot k's product
       if (k > 0) {
 #pragma unroll
         for (int l = 0; l < 9; ++l) pfx[pairrun_pfx_index(t, H, k, l)] = pr.v[l];
       }
-      const PairEntry e0 = entries[begin + 2 * k], e1 = entries[begin + 2 * k + 1];
-      const PairSlot sl = pair_slot_load(e0, e1, pts, false);
+      const PairSlot sl = pair_slot_decode<false>(cur, pts);
       if (sl.kind != PAIR_ADD && sl.kind != PAIR_DBL) continue;
       const Fq29 d = pair_denominator(sl.kind, sl.x0, sl.x1, sl.y0);
       pr = have ? fq29_mul(pr, d) : d;
@@ -273,23 +301,35 @@ SNARKV_HD void pairrun_bwd_lane(uint32_t t, uint32_t RUN, uint32_t stop, const P
   const uint32_t H = RUN / 2;
   const uint32_t nsl = (uint32_t)(((stop - begin > RUN) ? RUN : (stop - begin)) / 2);
   Fq29 I = soa_load(itot, L, t);
-  uint32_t cur = entries[begin + 2 * (nsl - 1)].bucket;
+  PairRaw cur, nxt;
+  Fq29 pr_cur = fq29_one(), pr_nxt = fq29_one();
+  auto load = [&](int k) {  // slot k's entries, points and prefix
+    pair_raw_load<true>(nxt, entries, begin + 2 * (size_t)k, pts);
+    if (k > 0) {
+#pragma unroll
+      for (int l = 0; l < 9; ++l) pr_nxt.v[l] = pfx[pairrun_pfx_index(t, H, (uint32_t)k, l)];
+    }
+  };
+  load((int)nsl - 1);
+  uint32_t cur_b = nxt.e0.bucket;
   bool tail_written = false, fresh = true;
   G1Xyzz29 acc = xyzz29_identity();
   for (int k = (int)nsl - 1; k >= 0; --k) {
-    const PairEntry e0 = entries[begin + 2 * k], e1 = entries[begin + 2 * k + 1];
-    if (e0.bucket != cur) {  // walking down: the bucket above is finished
+    cur = nxt;
+    pr_cur = pr_nxt;
+    if (k > 0) load(k - 1);  // in flight during slot k's ~3 500 instructions
+    if (cur.e0.bucket != cur_b) {  // walking down: the bucket above is finished
       if (!tail_written) {
-        seg_ids[2 * (size_t)t + 1] = fresh ? kPairNoBucket : cur;
+        seg_ids[2 * (size_t)t + 1] = fresh ? kPairNoBucket : cur_b;
         if (!fresh) seg_parts[2 * (size_t)t + 1] = acc;
         tail_written = true;
       } else if (!fresh) {
-        buckets[cur] = acc;  // complete interior bucket
+        buckets[cur_b] = acc;  // complete interior bucket
       }
-      cur = e0.bucket;
+      cur_b = cur.e0.bucket;
       fresh = true;
     }
-    const PairSlot sl = pair_slot_load(e0, e1, pts, true);
+    const PairSlot sl = pair_slot_decode<true>(cur, pts);
     if (sl.kind == PAIR_SKIP || sl.kind == PAIR_CANCEL) continue;
     G1Affine29 p;
     if (sl.kind == PAIR_COPY) {
@@ -299,10 +339,7 @@ SNARKV_HD void pairrun_bwd_lane(uint32_t t, uint32_t RUN, uint32_t stop, const P
       const Fq29 d = pair_denominator(sl.kind, sl.x0, sl.x1, sl.y0);
       Fq29 inv = I;
       if (k > 0) {
-        Fq29 pr;
-#pragma unroll
-        for (int l = 0; l < 9; ++l) pr.v[l] = pfx[pairrun_pfx_index(t, H, (uint32_t)k, l)];
-        inv = fq29_mul(I, pr);
+        inv = fq29_mul(I, pr_cur);
         I = fq29_mul(I, d);
       }
       pair_sum(sl.kind, sl.x0, sl.y0, sl.x1, sl.y1, inv, p.x, p.y);
@@ -317,7 +354,7 @@ SNARKV_HD void pairrun_bwd_lane(uint32_t t, uint32_t RUN, uint32_t stop, const P
       xyzz29_madd_fast(acc, p);
     }
   }
-  seg_ids[2 * (size_t)t] = fresh ? kPairNoBucket : cur;
+  seg_ids[2 * (size_t)t] = fresh ? kPairNoBucket : cur_b;
   if (!fresh) seg_parts[2 * (size_t)t] = acc;
   if (!tail_written) seg_ids[2 * (size_t)t + 1] = kPairNoBucket;
 }
