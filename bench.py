@@ -322,8 +322,8 @@ def cpu_baseline_aggregate(ds, dp, offs, n1, nproofs, n2):
     dt_dec = time.perf_counter() - t1
     dt = time.perf_counter() - t0
     return {"value": nproofs / dt, "unit": "proofs/s", "cores": 1, "kind": "port", "includes_decide": True,
-            "sample": "the 64-proof job's %d MSM terms, naive double-and-add loop of native.rs:61-71 restated in C, then one "
-                      "pairing decide (%.1f ms), 1 thread, %.2f s in all; not a halo2curves measurement" % (n1 + n2, dt_dec * 1e3, dt)}
+            "sample": "the %d-proof job's %d MSM terms, naive double-and-add loop of native.rs:61-71 restated in C, then one "
+                      "pairing decide (%.1f ms), 1 thread, %.2f s in all; not a halo2curves measurement" % (nproofs, n1 + n2, dt_dec * 1e3, dt)}
 
 
 def main():
