@@ -139,6 +139,7 @@ constexpr uint32_t kSortCap = 7168;     // S4: items a workgroup sorts entirely 
 constexpr uint32_t kSortTarget = 3072;  // S1: average items per (window, high bits) key
 constexpr uint32_t kMaxKeys = 16384;    // S1: LDS counters per tile workgroup (64 KiB)
 constexpr uint32_t kBigSpan = 24;       // P5: buckets spanning more runs go to the cooperative kernel
+constexpr uint32_t kBigGrid = 128;   // P5: workgroups of k_combine_big (they walk the list of oversized buckets)
 constexpr uint32_t kMaxBig = 8192;   // S1: (window, high bits) keys per window <= 128
 constexpr uint32_t kNoBucket = 0xFFFFFFFFu;
 
@@ -1051,36 +1052,41 @@ __global__ void __launch_bounds__(256)
   __shared__ G1Xyzz29 sh[256];
   __shared__ int any_bad;
   uint32_t nbig = *big_count < kMaxBig ? *big_count : kMaxBig;
-  if (blockIdx.x >= nbig) return;
-  uint32_t b = big_list[blockIdx.x];
-  uint32_t o = offsets[b], cnt = counts[b];
-  size_t s0, s1;
-  run_span(p, M, b, o, cnt, s0, s1);
-  if (threadIdx.x == 0) any_bad = 0;
-  __syncthreads();
-  G1Xyzz29 acc = xyzz29_identity();
-  bool bad = false;
-  for (size_t s = s0 + threadIdx.x; s <= s1; s += 256)
-    for (int h = 0; h < 2; ++h)
-      if (seg_ids[2 * s + h] == b) {
-        G1Xyzz29 part = seg_parts[2 * s + h];
-        bad = bad || xyzz29_is_degenerate(part);
-        xyzz29_add_careful(acc, part);
-      }
-  if (bad) atomicOr(&any_bad, 1);
-  __syncthreads();
-  if (any_bad) acc = bucket_from_entries_careful<LIMB>(entries, pts, o, cnt, threadIdx.x, 256);
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (uint32_t st = 128; st >= 1; st >>= 1) {
-    if (threadIdx.x < st) {
-      G1Xyzz29 a = sh[threadIdx.x];
-      xyzz29_add_careful(a, sh[threadIdx.x + st]);
-      sh[threadIdx.x] = a;
-    }
+  // a FIXED small grid walks the list (normally empty: uniform scalars have no bucket over kBigSpan runs): a grid sized
+  // for the worst case is thousands of 256-lane workgroups that only exit -- 0.3 ms of queueing behind the accumulation's
+  // wavefronts on the very stream the next MSM's k_accumulate waits on (profiles/r03_overlap_batch.txt)
+  for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+    uint32_t b = big_list[bi];
+    uint32_t o = offsets[b], cnt = counts[b];
+    size_t s0, s1;
+    run_span(p, M, b, o, cnt, s0, s1);
+    if (threadIdx.x == 0) any_bad = 0;
     __syncthreads();
+    G1Xyzz29 acc = xyzz29_identity();
+    bool bad = false;
+    for (size_t s = s0 + threadIdx.x; s <= s1; s += 256)
+      for (int h = 0; h < 2; ++h)
+        if (seg_ids[2 * s + h] == b) {
+          G1Xyzz29 part = seg_parts[2 * s + h];
+          bad = bad || xyzz29_is_degenerate(part);
+          xyzz29_add_careful(acc, part);
+        }
+    if (bad) atomicOr(&any_bad, 1);
+    __syncthreads();
+    if (any_bad) acc = bucket_from_entries_careful<LIMB>(entries, pts, o, cnt, threadIdx.x, 256);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t st = 128; st >= 1; st >>= 1) {
+      if (threadIdx.x < st) {
+        G1Xyzz29 a = sh[threadIdx.x];
+        xyzz29_add_careful(a, sh[threadIdx.x + st]);
+        sh[threadIdx.x] = a;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) buckets[b] = xyzz29_sanitize(sh[0]);
+    __syncthreads();  // sh / any_bad are reused by the next bucket of this workgroup
   }
-  if (threadIdx.x == 0) buckets[b] = xyzz29_sanitize(sh[0]);
 }
 
 // --------------------------------------------------------------- P6
@@ -1645,7 +1651,9 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
                          w0 * p.rpw, lanes);
       // one workgroup per oversized bucket; idle workgroups exit at once
       uint32_t big_grid = (uint32_t)(lanes / kBigSpan + 1);
-      if (big_grid > kMaxBig) big_grid = kMaxBig;
+      uint32_t big_cap = kBigGrid;
+      if (const char* e = getenv("SNARKV_BIG_GRID")) big_cap = (uint32_t)std::max(1, std::min((int)kMaxBig, atoi(e)));  // A/B knob
+      if (big_grid > big_cap) big_grid = big_cap;
       hipLaunchKernelGGL(half ? k_combine_big<true> : k_combine_big<false>, dim3(big_grid), dim3(256), 0, ts, cc, co, ce, cp,
                          (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets,
                          (const uint32_t*)(d_big_count + j), (const uint32_t*)d_big + (size_t)j * kMaxBig, p, cm);
