@@ -139,7 +139,7 @@ constexpr uint32_t kSortCap = 7168;     // S4: items a workgroup sorts entirely 
 constexpr uint32_t kSortTarget = 3072;  // S1: average items per (window, high bits) key
 constexpr uint32_t kMaxKeys = 16384;    // S1: LDS counters per tile workgroup (64 KiB)
 constexpr uint32_t kBigSpan = 24;       // P5: buckets spanning more runs go to the cooperative kernel
-constexpr uint32_t kBigGrid = 128;   // P5: workgroups of k_combine_big (they walk the list of oversized buckets)
+constexpr uint32_t kBigGrid = 8192;  // P5: workgroups of k_combine_big (they walk the list of oversized buckets; 128 measured level)
 constexpr uint32_t kMaxBig = 8192;   // S1: (window, high bits) keys per window <= 128
 constexpr uint32_t kNoBucket = 0xFFFFFFFFu;
 
@@ -1052,9 +1052,10 @@ __global__ void __launch_bounds__(256)
   __shared__ G1Xyzz29 sh[256];
   __shared__ int any_bad;
   uint32_t nbig = *big_count < kMaxBig ? *big_count : kMaxBig;
-  // a FIXED small grid walks the list (normally empty: uniform scalars have no bucket over kBigSpan runs): a grid sized
-  // for the worst case is thousands of 256-lane workgroups that only exit -- 0.3 ms of queueing behind the accumulation's
-  // wavefronts on the very stream the next MSM's k_accumulate waits on (profiles/r03_overlap_batch.txt)
+  // the grid walks the list (normally empty: uniform scalars have no bucket over kBigSpan runs).  A grid sized for the
+  // worst case is thousands of 256-lane workgroups that only exit -- 0.3 ms of queueing behind the accumulation's wavefronts
+  // in a batch (profiles/r03_overlap_batch.txt); capping it at 128 workgroups (SNARKV_BIG_GRID) was measured: one MSM alone
+  // -0.5 %, the batch +0.9 % (the freed stream time goes to one more resident accumulation, which slows the others): level
   for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
     uint32_t b = big_list[bi];
     uint32_t o = offsets[b], cnt = counts[b];
