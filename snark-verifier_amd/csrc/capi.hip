@@ -338,7 +338,7 @@ int snarkv::launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void*
     if (g) (void)hipGraphDestroy(g);
     (void)hipGetLastError();
     ctx->many_graph_state = 0;
-    if (rc < 0) return rc;
+    // (an error inside the capture may be the capture's own -- e.g. a synchronising call it forbids: the eager run decides)
     return many_enqueue(ctx, count, d_s, d_p, n, window_bits, d_out, partial_out, false, &single_path);
   }
   e = hipGraphInstantiate(&ctx->many_graph, g, nullptr, nullptr, 0);
