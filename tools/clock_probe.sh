@@ -1,17 +1,17 @@
 #!/bin/bash
-# dev tool (GPU box): the GPU's clocks and power while the bench's batch runs (rocm-smi sampled every ~0.2 s next to a long
-# batch), to put a number on "the chip clocks to its power budget under k_accumulate" (DESIGN.md section 4).
-#   tools/clock_probe.sh > gpurun_out/r03_clocks_under_load.txt
+# dev tool (GPU box): the GPU's clocks and power while the bench's workload runs (rocm-smi sampled next to back-to-back
+# batches of 20 MSMs of 2^20 points), to put a number on "the chip clocks to its power budget under k_accumulate"
+# (DESIGN.md section 4).      tools/clock_probe.sh > gpurun_out/r03_clocks_under_load.txt
 cd "$(dirname "$0")/.."
-echo "# idle:"; rocm-smi --showclocks --showpower --showmaxpower 2>/dev/null | grep -E "sclk|mclk|fclk|socclk|Power" | sed 's/^/  /'
-python bench.py --steps 400 --warmup 4 --no-cpu-baseline --no-secondary > /tmp/probe_bench.json 2>/dev/null &
+echo "# idle:"; rocm-smi --showclocks --showpower --showmaxpower 2>/dev/null | grep -E "sclk|mclk|fclk|Power" | sed 's/^/  /'
+rm -f /tmp/load_loop.ready
+python tools/load_loop.py --seconds 8 > /tmp/load_loop.out 2>&1 &
 BP=$!
-sleep 6   # import + input generation + the initialisation passes
-echo "# under load (python bench.py --steps 400: ~0.6 s of back-to-back batches), one sample per line:"
+for i in $(seq 1 600); do [ -f /tmp/load_loop.ready ] && break; sleep 0.1; done
+echo "# under load (back-to-back batches of 20 x 2^20-point MSMs), one rocm-smi sample per line:"
 while kill -0 $BP 2>/dev/null; do
-  rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Average Graphics Package Power|Current Socket Graphics Package Power" | tr '\n' ' ' | sed 's/  */ /g'; echo
-  sleep 0.15
+  rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|mclk|Power \(W\)" | sed 's/GPU\[0\]\t*: //' | tr '\n' '|' | sed 's/  */ /g'; echo
+  sleep 0.1
 done
 wait $BP
-python -c "
-import json; d=json.load(open('/tmp/probe_bench.json')); print('# bench: %.4f ms per MSM at %d steps' % (d['ms_per_step'], d['steps']))"
+cat /tmp/load_loop.out | tail -1
