@@ -275,6 +275,9 @@ int snarkv::launch_msm_pippenger_auto(snarkv_ctx* ctx, const void* d_s, const vo
 // Job j's scratch is a private context (ctx->jobs[j]); results are the bytes of the single-MSM entry point.
 static int many_enqueue(snarkv_ctx* ctx, size_t count, const void* const* d_s, const void* const* d_p, const size_t* n,
                         int window_bits, void* d_out, bool partial_out, bool capturing, bool* single_path);
+#ifndef SNARKV_MANY_TAIL_DEFAULT
+#define SNARKV_MANY_TAIL_DEFAULT 0  // 1: every job's bucket reduce under the batch's accumulations (see many_enqueue)
+#endif
 
 // The batch as a hipGraph.  A K-job batch is ~12 K kernel launches / memsets and ~3 K event operations over five
 // streams; a caller that submits the same batch again (same input / output pointers, sizes and options -- a proving
@@ -437,6 +440,8 @@ static int many_enqueue(snarkv_ctx* ctx, size_t count, const void* const* d_s, c
     }
     return SNARKV_OK;
   };
+  const char* et = getenv("SNARKV_MANY_TAIL");
+  const bool job_tail = et ? atoi(et) != 0 : SNARKV_MANY_TAIL_DEFAULT != 0;
   void* d_grids = nullptr;
   const size_t grid_bytes = (size_t)w0 * b0 * SNARKV_G1_PARTIAL_BYTES;
   if (uniform) SNARKV_TRY(ctx_reserve(ctx, SLOT_MGPU_GRID, grid_bytes * G, &d_grids));
@@ -456,6 +461,10 @@ static int many_enqueue(snarkv_ctx* ctx, size_t count, const void* const* d_s, c
       SNARKV_HIP(hipStreamWaitEvent(sb, job->grp_ev[0], 0));
       SNARKV_TRY(launch_msm_pippenger_phases(job, sb, PIP_PHASE_ACC, d_s[i], d_p[i], n[i], window_bits, nullptr, false,
                                              nullptr, grid));
+      // SNARKV_MANY_TAIL=1: the job's bucket reduce right behind its combine, on its accumulation stream -- under the
+      // other jobs' accumulations instead of in the exposed tail of the batch (only the shift chains + sums stay there)
+      if (uniform && job_tail)
+        SNARKV_TRY(launch_bucket_reduce_job(ctx, sb, d_grids, c0, w0, (uint32_t)(hi - lo), (uint32_t)(i - lo)));
       // a ragged batch (different window sizes) cannot share one tail: each job's own, behind its accumulation
       if (!uniform)
         SNARKV_TRY(launch_msm_pippenger_phases(job, sb, PIP_PHASE_TAIL, d_s[i], d_p[i], n[i], window_bits,
@@ -465,7 +474,7 @@ static int many_enqueue(snarkv_ctx* ctx, size_t count, const void* const* d_s, c
     SNARKV_TRY(join_and_fork(true, !(capturing && last)));
     if (uniform) {
       SNARKV_TRY(launch_buckets_reduce_many(ctx, ctx->stream, d_grids, c0, w0, (uint32_t)(hi - lo),
-                                            (uint8_t*)d_out + ostride * lo, partial_out));
+                                            (uint8_t*)d_out + ostride * lo, partial_out, job_tail));
       if (!last) SNARKV_TRY(join_and_fork());  // the next round overwrites the grids
     }
     if (last) ctx->last_many_jobs = (int)(hi - lo);

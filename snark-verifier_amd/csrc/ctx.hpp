@@ -145,7 +145,10 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
                                 size_t n, int window_bits, void* d_out, bool partial_out, void* d_buckets_out,
                                 void* d_grid);
 int launch_buckets_reduce_many(snarkv_ctx* ctx, hipStream_t st, const void* d_grids, uint32_t c, uint32_t windows,
-                               uint32_t jobs, void* d_out, bool partial_out);
+                               uint32_t jobs, void* d_out, bool partial_out, bool reduce_done = false);
+// one job's bucket reduce of such a batched tail, under the batch's accumulations (msm_pippenger.hip)
+int launch_bucket_reduce_job(snarkv_ctx* ctx, hipStream_t st, const void* d_grids, uint32_t c, uint32_t windows,
+                             uint32_t jobs, uint32_t job);
 // `count` independent MSMs, phase-ordered over private job contexts (capi.hip)
 int launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void* const* d_scalars, const void* const* d_points,
                               const size_t* n, int window_bits, void* d_out, bool partial_out);

@@ -165,6 +165,7 @@ struct PipParams {
   uint32_t wper;     // batched tail over several MSMs' grids laid end to end: windows per MSM (0: one MSM)
   uint32_t pad;      // 1: k_sort_level2 pads every bucket's entry count to even (the pair level, pair_tree.h)
   uint32_t chunk_log2;  // P6: log2 of the buckets per k_bucket_reduce lane (kLog2Chunk; larger in a batched tail)
+  uint32_t low_prio;    // P6: 1 = k_bucket_reduce keeps the default wave priority (a job's reduce UNDER a batch's accumulations)
 };
 
 // c bits at offset lo of a kDigitBits-bit magnitude held in registers (selects, no dynamic indexing)
@@ -1192,7 +1193,7 @@ constexpr int kLog2BlockBuckets = 6 + kLog2Chunk;  // a P6 block covers 64 * kCh
 __global__ void __launch_bounds__(64)
     k_bucket_reduce(const G1Xyzz29* __restrict__ buckets, G1Xyzz29* __restrict__ block_parts, PipParams p,
                     uint32_t chunks_per_window, uint32_t blocks_per_window) {
-  SNARKV_RAISE_PRIO();
+  if (!p.low_prio) SNARKV_RAISE_PRIO();
   __shared__ G1Xyzz29 sh[64];
   uint32_t w = blockIdx.x / blocks_per_window, bj = blockIdx.x % blocks_per_window;
   uint32_t j = bj * 64 + threadIdx.x;
@@ -1376,6 +1377,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   p.w0 = 0;
   p.wper = 0;
   p.chunk_log2 = (uint32_t)kLog2Chunk;
+  p.low_prio = 0;
   p.n = (uint32_t)n;
   p.c = window_bits > 0 ? window_bits : balance_window_bits(default_window_bits(n));
   if (p.c < 2) p.c = 2;
@@ -1749,9 +1751,14 @@ int launch_buckets_reduce(snarkv_ctx* ctx, const void* d_buckets, uint32_t c, ui
 // The tail of `jobs` MSMs of the same geometry whose bucket grids lie end to end ([job][window][bucket]): three
 // launches for all of them (a tail is latency-bound -- 14-step folds and the 2^(c w) doubling chains -- so `jobs` of
 // them cost what one does), out[job] = the affine sum (64 B) or the projective partial.
-int launch_buckets_reduce_many(snarkv_ctx* ctx, hipStream_t st, const void* d_grids, uint32_t c, uint32_t windows,
-                               uint32_t jobs, void* d_out, bool partial_out) {
+// geometry + scratch of a batched tail over `jobs` grids
+struct TailGeom {
   PipParams p;
+  uint32_t chunks_per_window, blocks_per_window;
+  void *d_wave, *d_shift;
+};
+static int tail_geometry(snarkv_ctx* ctx, uint32_t c, uint32_t windows, uint32_t jobs, TailGeom* g) {
+  PipParams& p = g->p;
   memset(&p, 0, sizeof p);
   p.c = (int)c;
   p.W = (int)(windows * jobs);
@@ -1761,26 +1768,54 @@ int launch_buckets_reduce_many(snarkv_ctx* ctx, hipStream_t st, const void* d_gr
   p.wper = windows;
   const uint32_t wtotal = windows * jobs;
   // Buckets per k_bucket_reduce lane.  One MSM's reduce is a latency chain on a few hundred wavefronts: short chunks (8
-  // buckets: 16 serial additions + the 14-step fold) keep it short.  A batch's tail reduces `jobs` grids at once --
-  // thousands of wavefronts, throughput-bound, and exposed at the end of the batch (nothing is left to overlap it) --
-  // where the fold is 14 of every 30 additions: chunks of 32 do 78 additions per 32 buckets instead of 120.
-  // SNARKV_TAIL_CHUNK_LOG2 overrides (A/B knob); same bytes for any chunk size.
+  // buckets: 16 serial additions + the 14-step fold) keep it short.  A batch's tail reduces `jobs` grids -- thousands of
+  // wavefronts, throughput-bound -- where the fold is 14 of every 30 additions: chunks of 32 do 78 additions per 32
+  // buckets instead of 120.  SNARKV_TAIL_CHUNK_LOG2 overrides (A/B knob); same bytes for any chunk size.
   uint32_t cl2 = (uint32_t)kLog2Chunk;
   if ((uint64_t)jobs * windows * (p.B >> 3) >= 4096 * 64ull) cl2 = 5;  // >= 4 096 wavefronts at 8 buckets per lane
   if (const char* e = getenv("SNARKV_TAIL_CHUNK_LOG2")) cl2 = (uint32_t)std::max(1, std::min(8, atoi(e)));
   while ((1u << cl2) > p.B && cl2 > 0) --cl2;
   p.chunk_log2 = cl2;
-  const uint32_t kChunk = 1u << cl2;  // (shadows the single-MSM constant for the sizes below)
-  uint32_t chunks_per_window = (p.B + kChunk - 1) / kChunk;
-  uint32_t blocks_per_window = (chunks_per_window + 63) / 64;
-  void *d_wave, *d_shift;
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_CHUNK_PARTIALS, 2 * (size_t)blocks_per_window * wtotal * sizeof(G1Xyzz29), &d_wave));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_SHIFTED, (size_t)wtotal * sizeof(G1Xyzz29), &d_shift));
-  hipLaunchKernelGGL(k_bucket_reduce, dim3(blocks_per_window * wtotal), dim3(64), 0, st, (const G1Xyzz29*)d_grids,
-                     (G1Xyzz29*)d_wave, p, chunks_per_window, blocks_per_window);
-  hipLaunchKernelGGL(k_shift_windows, dim3(wtotal), dim3(64), 0, st, (const G1Xyzz29*)d_wave, (G1Xyzz29*)d_shift, p,
-                     blocks_per_window);
-  hipLaunchKernelGGL(k_final, dim3(jobs), dim3(64), 0, st, (const G1Xyzz29*)d_shift, windows, (uint32_t*)d_out,
+  const uint32_t chunk = 1u << cl2;
+  g->chunks_per_window = (p.B + chunk - 1) / chunk;
+  g->blocks_per_window = (g->chunks_per_window + 63) / 64;
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_CHUNK_PARTIALS, 2 * (size_t)g->blocks_per_window * wtotal * sizeof(G1Xyzz29), &g->d_wave));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_SHIFTED, (size_t)wtotal * sizeof(G1Xyzz29), &g->d_shift));
+  return SNARKV_OK;
+}
+
+// ONE job's bucket reduce of a batched tail, on a stream of the caller's choice (its accumulation stream: the reduce then
+// runs UNDER the other jobs' accumulations, at the default wave priority, instead of in the exposed tail of the batch);
+// `job` indexes the grids laid end to end and the block partials of launch_buckets_reduce_many(..., reduce_done = true)
+int launch_bucket_reduce_job(snarkv_ctx* ctx, hipStream_t st, const void* d_grids, uint32_t c, uint32_t windows,
+                             uint32_t jobs, uint32_t job) {
+  TailGeom g;
+  SNARKV_TRY(tail_geometry(ctx, c, windows, jobs, &g));
+  PipParams pj = g.p;
+  pj.W = (int)windows;
+  pj.low_prio = 1;
+  hipLaunchKernelGGL(k_bucket_reduce, dim3(g.blocks_per_window * windows), dim3(64), 0, st,
+                     (const G1Xyzz29*)d_grids + (size_t)job * windows * g.p.B,
+                     (G1Xyzz29*)g.d_wave + 2 * (size_t)g.blocks_per_window * windows * job, pj, g.chunks_per_window,
+                     g.blocks_per_window);
+  SNARKV_HIP(hipGetLastError());
+  return SNARKV_OK;
+}
+
+// The tail of `jobs` MSMs of the same geometry whose bucket grids lie end to end ([job][window][bucket]): three
+// launches for all of them, out[job] = the affine sum (64 B) or the projective partial.  reduce_done: the jobs' bucket
+// reduces were launched one by one already (launch_bucket_reduce_job): only the shift chains and the final sums are left.
+int launch_buckets_reduce_many(snarkv_ctx* ctx, hipStream_t st, const void* d_grids, uint32_t c, uint32_t windows,
+                               uint32_t jobs, void* d_out, bool partial_out, bool reduce_done) {
+  TailGeom g;
+  SNARKV_TRY(tail_geometry(ctx, c, windows, jobs, &g));
+  const uint32_t wtotal = windows * jobs;
+  if (!reduce_done)
+    hipLaunchKernelGGL(k_bucket_reduce, dim3(g.blocks_per_window * wtotal), dim3(64), 0, st, (const G1Xyzz29*)d_grids,
+                       (G1Xyzz29*)g.d_wave, g.p, g.chunks_per_window, g.blocks_per_window);
+  hipLaunchKernelGGL(k_shift_windows, dim3(wtotal), dim3(64), 0, st, (const G1Xyzz29*)g.d_wave, (G1Xyzz29*)g.d_shift, g.p,
+                     g.blocks_per_window);
+  hipLaunchKernelGGL(k_final, dim3(jobs), dim3(64), 0, st, (const G1Xyzz29*)g.d_shift, windows, (uint32_t*)d_out,
                      partial_out ? 1 : 0);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;

@@ -229,3 +229,20 @@ def test_batch_replayed_as_a_hipgraph(monkeypatch):
         assert [raw[64 * i:64 * i + 64] for i in range(len(jobs))] == [C.msm_pippenger(s, p, 8) for s, p in jobs], name
     assert ctx.graph_replays() >= seen + 4  # small: capture + replay; big: capture + replay; small again: re-captured
     ctx.close()
+
+
+def test_per_job_bucket_reduce_under_the_accumulations(gpu_ctx, monkeypatch):
+    """SNARKV_MANY_TAIL=1: every job's bucket reduce is enqueued behind its own combine (on its accumulation stream, default
+    wave priority) and the batched tail only runs the shift chains + final sums -- same bytes as the default schedule
+    (one batched reduce at the end), for one round and for several, affine and partial outputs."""
+    import torch
+
+    for sizes in ([40000] * 7, [3000] * 70):
+        jobs = _jobs(sizes, 0x5400 + len(sizes))
+        exp = [C.msm_pippenger(s, p, 8) for s, p in jobs]
+        monkeypatch.setenv("SNARKV_MANY_TAIL", "1")
+        assert _many(gpu_ctx, torch, jobs) == exp
+        part = _many(gpu_ctx, torch, jobs, partial=True)
+        monkeypatch.setenv("SNARKV_MANY_TAIL", "0")
+        assert _many(gpu_ctx, torch, jobs) == exp
+        assert _many(gpu_ctx, torch, jobs, partial=True) == part
