@@ -1771,8 +1771,22 @@ static int tail_geometry(snarkv_ctx* ctx, uint32_t c, uint32_t windows, uint32_t
   // buckets: 16 serial additions + the 14-step fold) keep it short.  A batch's tail reduces `jobs` grids -- thousands of
   // wavefronts, throughput-bound -- where the fold is 14 of every 30 additions: chunks of 32 do 78 additions per 32
   // buckets instead of 120.  SNARKV_TAIL_CHUNK_LOG2 overrides (A/B knob); same bytes for any chunk size.
+  // The chunk is picked by that model: rounds of the machine's wave slots (194 VGPRs: two wavefronts per SIMD) x the
+  // additions of one wavefront, 2 chunk + 14 -- 16 buckets per lane for 20 or 40 grids of 8 x 32 768 buckets, 8 for one.
   uint32_t cl2 = (uint32_t)kLog2Chunk;
-  if ((uint64_t)jobs * windows * (p.B >> 3) >= 4096 * 64ull) cl2 = 5;  // >= 4 096 wavefronts at 8 buckets per lane
+  {
+    static int slots = 0;  // 2 wavefronts x 4 SIMDs x CUs
+    if (!slots) {
+      hipDeviceProp_t prop;
+      slots = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0 ? 8 * prop.multiProcessorCount : 2048;
+    }
+    uint64_t best = ~0ull;
+    for (uint32_t q = (uint32_t)kLog2Chunk; q <= 6; ++q) {
+      const uint64_t blocks = ((uint64_t)(p.B >> q) + 63) / 64, waves = (uint64_t)jobs * windows * (blocks ? blocks : 1);
+      const uint64_t cost = ((waves + slots - 1) / slots) * (2ull * (1u << q) + 14);
+      if (cost < best) best = cost, cl2 = q;
+    }
+  }
   if (const char* e = getenv("SNARKV_TAIL_CHUNK_LOG2")) cl2 = (uint32_t)std::max(1, std::min(8, atoi(e)));
   while ((1u << cl2) > p.B && cl2 > 0) --cl2;
   p.chunk_log2 = cl2;
