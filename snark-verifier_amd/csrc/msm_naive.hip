@@ -63,7 +63,9 @@ __device__ __forceinline__ G1Xyzz29 half_scalar_mul(const G1Affine29& q, const u
 }
 
 // |k| * Q with a FIXED 3-bit window and signed digits, every lane of the wavefront in the same step:
-//   table    2Q, 3Q, 4Q (XYZZ) in LDS, one column per lane (limb-major: conflict-free); Q itself stays in registers
+//   table    2Q, 3Q, 4Q (XYZZ) in a global scratch, one column per lane (limb-major: every access one segment; it stays in
+//            L2) -- not in LDS: 27 KB per wavefront there capped a CU at five wavefronts, and with several launches in
+//            flight the kernel's throughput fell back to the bit-serial form's; Q itself stays in registers
 //   digits   |k| = sum d_i 8^i, d_i in [-3, 4] (a digit above 4 becomes d - 8 with a carry up), 43 of them for 127 bits,
 //            recoded low to high into LDS bytes, consumed high to low
 //   step     acc <- 8 acc (three doublings; the identity doubles to itself), then acc += sign * T[|d|] by the full XYZZ
@@ -75,11 +77,16 @@ __device__ __forceinline__ G1Xyzz29 half_scalar_mul(const G1Affine29& q, const u
 #ifndef SNARKV_NAIVE_WINDOW
 #define SNARKV_NAIVE_WINDOW 1  // 0: the bit-serial double-and-add (A/B: profiles/r03_ab_naive_window.txt)
 #endif
+#ifndef SNARKV_NAIVE_WAVES
+#define SNARKV_NAIVE_WAVES 2  // wavefronts per SIMD k_term_scalar_mul is compiled for (3: 168 VGPRs + 48 B of spills)
+#endif
 constexpr int kWinDigits = 43;  // ceil(127 / 3) + the carry into the one-bit top digit
 
-__device__ __forceinline__ G1Xyzz29 half_scalar_mul_w3(const G1Affine29& q, const uint32_t k[4], int32_t (*tab)[36][64],
+__device__ __forceinline__ G1Xyzz29 half_scalar_mul_w3(const G1Affine29& q, const uint32_t k[4], int32_t* __restrict__ tabg,
                                                        int8_t (*dig)[64]) {
   const uint32_t lane = threadIdx.x;
+  // this wavefront's slice of the scratch: [entry 0..2][limb 0..35][lane]
+  int32_t(*tab)[36][64] = reinterpret_cast<int32_t(*)[36][64]>(tabg + (size_t)blockIdx.x * 3 * 36 * 64);
   // table: 2Q, 3Q, 4Q
   G1Xyzz29 t2 = xyzz29_double_affine(q), t3 = t2;
   xyzz29_madd_fast(t3, q);
@@ -141,11 +148,11 @@ __device__ __forceinline__ G1Xyzz29 half_scalar_mul_w3(const G1Affine29& q, cons
 // K1: one lane per (term, GLV half).  k = k1 + k2*lambda with |k_i| < 2^127
 // (glv.h) turns `*base * scalar` (reference native.rs:67), a 254-step chain,
 // into two independent 127-step chains on P and phi(P) = (beta x, y).
-__global__ void __launch_bounds__(64) k_term_scalar_mul(const uint32_t* __restrict__ scalars,
+__global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES) k_term_scalar_mul(const uint32_t* __restrict__ scalars,
                                                          const uint32_t* __restrict__ points,
-                                                         G1Xyzz29* __restrict__ out, uint32_t n_terms) {
+                                                         G1Xyzz29* __restrict__ out, uint32_t n_terms,
+                                                         int32_t* __restrict__ tabg) {
 #if SNARKV_NAIVE_WINDOW
-  __shared__ int32_t tab[3][36][64];
   __shared__ int8_t dig[kWinDigits][64];
 #endif
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -171,7 +178,7 @@ __global__ void __launch_bounds__(64) k_term_scalar_mul(const uint32_t* __restri
   }
   if (neg) q.y = fq29_neg(q.y);
 #if SNARKV_NAIVE_WINDOW
-  G1Xyzz29 r = half_scalar_mul_w3(q, mag, tab, dig);
+  G1Xyzz29 r = half_scalar_mul_w3(q, mag, tabg, dig);
 #else
   G1Xyzz29 r = half_scalar_mul<false>(q, mag);
 #endif
@@ -418,8 +425,10 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
   const uint32_t J = chunks_for(n_terms);
   if (J == 1) {
     uint32_t blocks = (uint32_t)((2 * n_terms + 63) / 64);
+    void* d_tab = nullptr;  // the fixed-window tables: 3 XYZZ points per lane
+    SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_CHAIN, (size_t)blocks * 3 * 36 * 64 * 4, &d_tab));
     hipLaunchKernelGGL(k_term_scalar_mul, dim3(blocks), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,
-                       (const uint32_t*)d_points, (G1Xyzz29*)d_terms, (uint32_t)n_terms);
+                       (const uint32_t*)d_points, (G1Xyzz29*)d_terms, (uint32_t)n_terms, (int32_t*)d_tab);
   } else {
     void* d_chain = nullptr;
     void* d_mags = nullptr;
