@@ -80,7 +80,10 @@ def main():
     cmd = [build.HIPCC] + build.FLAGS + ["-S", "--cuda-device-only", os.path.join(build.CSRC, "msm_pippenger.hip"), "-o", asm]
     subprocess.run(cmd, check=True, capture_output=True)
     text = open(asm).read().split("\n")
-    start = next(i for i, l in enumerate(text) if re.match(r"^_ZN6snarkv\d+%s\w*:" % args.kernel, l))
+    # the kernel itself (a template instantiation `...k_accumulateILi64ELb0EE...` or a plain `...k_fooE...`), not a longer name
+    # that merely starts with it (k_accumulate_pairs); of a template the <.., false> (packed point table) instantiation first
+    cands = [i for i, l in enumerate(text) if re.match(r"^_ZN6snarkv\d+%s[IE]\w*:" % args.kernel, l)]
+    start = next((i for i in cands if "Lb0" in text[i]), cands[0])
     end = next(i for i in range(start, len(text)) if text[i].startswith(".Lfunc_end"))
     body = text[start + 1:end]
     # the loop: every basic block annotated "in Loop: Header=BBn_m" or "Inner Loop Header"
