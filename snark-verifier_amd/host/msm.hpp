@@ -3,6 +3,7 @@
 #pragma once
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <optional>
 #include <unordered_map>
 #include <vector>
@@ -23,20 +24,37 @@ class Msm {
 
  private:
   static constexpr size_t kIndexThreshold = 48;
-  std::unordered_multimap<uint64_t, size_t> index_;  // first 8 bytes of x -> position (only past the threshold)
+  // first 8 bytes of x -> position; built only past the threshold and never copied (a copy rebuilds it on its first
+  // `push` past the threshold): the verifier clones Msms freely -- ~90 short-lived ones per proof -- and a hash table
+  // member made every one of them cost a constructor / destructor pair
+  using Index = std::unordered_multimap<uint64_t, size_t>;
+  std::unique_ptr<Index> index_;
   static uint64_t key_of(const Point& p) {
     uint64_t k;
     memcpy(&k, p.b, 8);
     return k;
   }
   void rebuild_index() {
-    index_.clear();
-    for (size_t i = 0; i < bases.size(); ++i) index_.emplace(key_of(*bases[i]), i);
+    if (!index_) index_ = std::make_unique<Index>();
+    index_->clear();
+    index_->reserve(2 * bases.size() + 64);
+    for (size_t i = 0; i < bases.size(); ++i) index_->emplace(key_of(*bases[i]), i);
   }
 
  public:
-
   Msm() = default;
+  Msm(const Msm& o) : constant(o.constant), scalars(o.scalars), bases(o.bases) {}
+  Msm(Msm&&) = default;
+  Msm& operator=(const Msm& o) {
+    if (this != &o) {
+      constant = o.constant;
+      scalars = o.scalars;
+      bases = o.bases;
+      index_.reset();
+    }
+    return *this;
+  }
+  Msm& operator=(Msm&&) = default;
   // msm.rs:46-51
   static Msm from_constant(const Scalar& c) {
     Msm m;
@@ -70,6 +88,7 @@ class Msm {
   // first, then the terms in insertion order (msm.rs:81-98).
   std::vector<std::pair<Scalar, Point>> pairs(const std::optional<Point>& gen) const {
     std::vector<std::pair<Scalar, Point>> out;
+    out.reserve(scalars.size() + 1);
     if (constant) {
       if (!gen) throw Panic("Msm has a constant but no generator was given (reference: unwrap, msm.rs:93)");
       out.emplace_back(*constant, L::ec_point_load_const(*gen));
@@ -103,14 +122,14 @@ class Msm {
           return;
         }
     } else {
-      if (index_.size() != bases.size()) rebuild_index();
-      auto range = index_.equal_range(key_of(*b));
+      if (!index_ || index_->size() != bases.size()) rebuild_index();
+      auto range = index_->equal_range(key_of(*b));
       for (auto it = range.first; it != range.second; ++it)
         if (*bases[it->second] == *b) {
           scalars[it->second] += s;
           return;
         }
-      index_.emplace(key_of(*b), bases.size());
+      index_->emplace(key_of(*b), bases.size());
     }
     scalars.push_back(s);
     bases.push_back(b);

@@ -88,6 +88,15 @@ int hd_fr_inv(const uint8_t* a, uint8_t* out) {
   return 1;
 }
 
+// the exponentiation form of the same inverse (the cross-check of the Euclid-based `invert`)
+int hd_fr_inv_fermat(const uint8_t* a, uint8_t* out) {
+  Fr x, y;
+  Fr::from_bytes(a, &x);
+  if (!x.invert_fermat(&y)) return 0;
+  y.to_bytes(out);
+  return 1;
+}
+
 // Msm::evaluate through the loader (msm.rs:81-98): in = g(64) commitments-format with ONE Msm
 int hd_msm_evaluate(const uint8_t* in, int with_gen, uint8_t* out64) {
   return guarded([&] {

@@ -16,7 +16,12 @@ def test_fr_mul_inv():
         for b in vals[:8] + [rng.choice(vals)]:
             L.hd_fr_mul(O.fe_to_bytes(a), O.fe_to_bytes(b), o)
             assert O.fe_from_bytes(o.raw) == a * b % O.R
-    for a in vals[1:40]:
+    # `invert` is Kaliski's almost-inverse + a 2^k correction whose branch depends on the iteration count k:
+    # small values, powers of two (few subtractions, many shifts), r - small and random values cover both branches
+    edge = [1 << i for i in range(0, 254, 7)] + [(1 << i) - 1 for i in range(2, 254, 11)] + [O.R - (1 << i) for i in range(0, 250, 13)]
+    o2 = ctypes.create_string_buffer(32)
+    for a in vals[1:] + edge + [rng.randrange(1, 1 << rng.randrange(1, 254)) for _ in range(300)]:
         assert L.hd_fr_inv(O.fe_to_bytes(a), o) == 1
         assert O.fe_from_bytes(o.raw) == pow(a, -1, O.R)
+        assert L.hd_fr_inv_fermat(O.fe_to_bytes(a), o2) == 1 and o2.raw == o.raw
     assert L.hd_fr_inv(O.fe_to_bytes(0), o) == 0
