@@ -63,6 +63,13 @@ typedef struct snarkv_poseidon snarkv_poseidon;
 int snarkv_ctx_create(int device, void* hip_stream, snarkv_ctx** out);
 void snarkv_ctx_destroy(snarkv_ctx* ctx);
 int snarkv_ctx_sync(snarkv_ctx* ctx);
+/* Pinned host memory owned by the context, for callers that assemble their inputs themselves: the host-pointer
+ * entry points (`snarkv_g1_msm_batched`, `snarkv_g1_msm_pippenger`, ...) copy with hipMemcpyAsync, which is a DMA
+ * out of pinned memory and a bounce copy out of pageable memory (2.4 MB of MSM terms: ~0.1 ms against ~0.3 ms).
+ * SNARKV_HOST_BUFFERS independent slots, grow-only; a pointer stays valid until the same slot is requested with a
+ * larger size (or the context is destroyed).  One user per context at a time, like every call on a context.   */
+#define SNARKV_HOST_BUFFERS 4
+int snarkv_ctx_host_buffer(snarkv_ctx* ctx, int slot, size_t bytes, void** out);
 const char* snarkv_last_error(void);
 const char* snarkv_version(void);
 
@@ -154,6 +161,8 @@ int bn254_g1_msm_naive(const uint8_t* scalars32, const uint8_t* points64, size_t
 int bn254_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, const uint32_t* offsets, size_t n_msm,
                          uint8_t* out);
 int bn254_g1_msm_pippenger(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]);
+/* snarkv_ctx_host_buffer of the default context (callers serialise their use of it, as they do its calls) */
+int bn254_host_buffer(int slot, size_t bytes, void** out);
 int bn254_kzg_decide(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],
                      const uint8_t acc128[128]);
 int bn254_kzg_decide_batch(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],

@@ -22,6 +22,7 @@ extern "C" {
 int snarkv_pallas_ctx_create(int device, void* hip_stream, snarkv_ctx** out);
 void snarkv_pallas_ctx_destroy(snarkv_ctx* ctx);
 int snarkv_pallas_ctx_sync(snarkv_ctx* ctx);
+int snarkv_pallas_ctx_host_buffer(snarkv_ctx* ctx, int slot, size_t bytes, void** out); /* as snarkv_ctx_host_buffer */
 const char* snarkv_pallas_last_error(void);
 const char* snarkv_pallas_version(void);
 
@@ -60,6 +61,7 @@ int pallas_g1_msm_naive(const uint8_t* scalars32, const uint8_t* points64, size_
 int pallas_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, const uint32_t* offsets, size_t n_msm,
                           uint8_t* out);
 int pallas_g1_msm_pippenger(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]);
+int pallas_host_buffer(int slot, size_t bytes, void** out); /* as bn254_host_buffer */
 int pallas_ipa_dk_create(const uint8_t* g_points64, size_t n, snarkv_ipa_dk** out);
 int pallas_ipa_decide_batch(const snarkv_ipa_dk* dk, const uint8_t* xi32, const uint8_t* u64, size_t m, uint8_t* ok);
 

@@ -18,6 +18,7 @@ from ._lib import (  # noqa: F401
     lib_path,
     load_library,
     SNARKV_FLAG_VALIDATE,
+    SNARKV_HOST_BUFFERS,
     SNARKV_ERR_EMPTY,
     SNARKV_ERR_LENGTH,
     SNARKV_ERR_ENCODING,
@@ -40,6 +41,7 @@ __all__ = [
     "lib_path",
     "load_library",
     "SNARKV_FLAG_VALIDATE",
+    "SNARKV_HOST_BUFFERS",
     "SNARKV_ERR_EMPTY",
     "SNARKV_ERR_LENGTH",
     "SNARKV_ERR_ENCODING",

@@ -13,6 +13,7 @@ SNARKV_ERR_ENCODING = -3
 SNARKV_ERR_DEVICE = -4
 SNARKV_ERR_ARG = -5
 SNARKV_FLAG_VALIDATE = 1
+SNARKV_HOST_BUFFERS = 4  # include/snarkv_amd.h
 SNARKV_PIP_STAGES = 9
 PIP_STAGE_NAMES = [
     "total", "prepare_glv_montgomery_histogram", "scan", "partition_sort", "bucket_accumulate",
@@ -47,6 +48,8 @@ _SIGNATURES = {
     "snarkv_ctx_create": (_int, [_int, _vp, _pp]),
     "snarkv_ctx_destroy": (None, [_vp]),
     "snarkv_ctx_sync": (_int, [_vp]),
+    "snarkv_ctx_host_buffer": (_int, [_vp, _int, _sz, _pp]),
+    "bn254_host_buffer": (_int, [_int, _sz, _pp]),
     "snarkv_last_error": (_cp, []),
     "snarkv_version": (_cp, []),
     "snarkv_g1_msm_naive": (_int, [_vp, _cp, _cp, _sz, _u32, _vp]),
@@ -158,6 +161,8 @@ def _check(rc):
 
 
 def _as_bytes(x):
+    if isinstance(x, ctypes.Array):  # Context.host_buffer: pinned memory, passed through by address
+        return x
     if isinstance(x, (bytes, bytearray, memoryview)):
         return bytes(x)
     tb = getattr(x, "tobytes", None)  # numpy
@@ -365,6 +370,14 @@ class Context:
 
     def sync(self):
         _check(self._lib.snarkv_ctx_sync(self._h))
+
+    def host_buffer(self, slot, nbytes):
+        """Pinned host memory owned by the context (`snarkv_ctx_host_buffer`): a ctypes char array over it
+        (accepted by the msm_* methods in place of bytes).  Inputs
+        assembled there reach the device by DMA when passed to the host-pointer entry points."""
+        p = ctypes.c_void_p()
+        _check(self._lib.snarkv_ctx_host_buffer(self._h, int(slot), int(nbytes), ctypes.byref(p)))
+        return (ctypes.c_char * int(nbytes)).from_address(p.value)
 
     def set_throughput_hint(self, enabled=True):
         """Several MSMs in flight on several contexts: longer runs per lane (less work per MSM, longer single-MSM latency)."""

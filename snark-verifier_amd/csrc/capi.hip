@@ -762,6 +762,13 @@ int bn254_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, cons
   return snarkv_g1_msm_batched(c, scalars32, points64, offsets, n_msm, 0, out);
 }
 
+int bn254_host_buffer(int slot, size_t bytes, void** out) {
+  SNARKV_DEFAULT_CALL_LOCK();
+  snarkv_ctx* c;
+  SNARKV_TRY(default_ctx(&c));
+  return snarkv_ctx_host_buffer(c, slot, bytes, out);
+}
+
 int bn254_g1_msm_pippenger(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]) {
   SNARKV_DEFAULT_CALL_LOCK();
   snarkv_ctx* c;

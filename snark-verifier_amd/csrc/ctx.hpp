@@ -83,8 +83,10 @@ struct snarkv_ctx {
   bool own_stream;
   void* buf[snarkv::SLOT_COUNT];
   size_t cap[snarkv::SLOT_COUNT];
-  void* pinned;  // small pinned host staging area
-  size_t pinned_cap;
+  // pinned host buffers handed to the caller (snarkv_ctx_host_buffer): inputs packed there reach the device by DMA
+  // instead of the runtime's bounce copy of pageable memory
+  void* hbuf[SNARKV_HOST_BUFFERS];
+  size_t hbuf_cap[SNARKV_HOST_BUFFERS];
   bool stage_timing;
   float stage_ms[SNARKV_PIP_STAGES];
   hipEvent_t ev[SNARKV_PIP_STAGES + 1];

@@ -119,6 +119,10 @@ int pallas_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, con
   PALLAS_DEFAULT_CTX();
   return snarkv_pallas_g1_msm_batched(c, scalars32, points64, offsets, n_msm, 0, out);
 }
+int pallas_host_buffer(int slot, size_t bytes, void** out) {
+  PALLAS_DEFAULT_CTX();
+  return snarkv_pallas_ctx_host_buffer(c, slot, bytes, out);
+}
 int pallas_g1_msm_pippenger(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]) {
   PALLAS_DEFAULT_CTX();
   return snarkv_pallas_g1_msm_pippenger(c, scalars32, points64, n, out64);

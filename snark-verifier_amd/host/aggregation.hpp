@@ -122,8 +122,10 @@ struct Aggregator {
     std::vector<typename SV::Pairs> jobs(2 * n);
     std::vector<double> t_read(n, 0.0);
     constexpr bool kDeviceHash = std::is_same<TR, PoseidonTranscriptOnDevice>::value;
-    // a Keccak proof costs ~30 us of host work (a thread start ~ one proof), a Poseidon one ~0.5 ms
-    constexpr size_t grain = std::is_same<TR, PoseidonTranscript>::value ? 1 : 16;
+    // a Keccak proof costs ~60 us of host work, waking a pool worker ~10 us, a Poseidon proof ~0.5 ms: two proofs per
+    // worker are worth a wake-up (64 proofs: 0.55 -> 0.17 ms of host time against 16 per worker; gpurun_out probe, r3)
+    size_t grain = std::is_same<TR, PoseidonTranscript>::value ? 1 : 2;
+    if (const char* e = getenv("SNARKV_HOST_GRAIN")) grain = (size_t)std::max(1, atoi(e));  // tuning knob
     double device_hash_ms = 0;
     if constexpr (kDeviceHash) {
       Error e = read_proofs_device_hashed(svk, pr, instances, proofs, threads, pfs);

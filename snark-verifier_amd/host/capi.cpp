@@ -86,7 +86,7 @@ Error read_all(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
     }
     left[i] = t.remaining() != 0;
     pfs[i] = std::move(*pf.value);
-  }, std::is_same<TR, PoseidonTranscript>::value ? 1 : 16);
+  }, std::is_same<TR, PoseidonTranscript>::value ? 1 : 2);
   for (auto& e : errs)
     if (!e.ok()) return e;
   if (strict)

@@ -141,6 +141,7 @@ class HostPool {
   HostPool() {
     unsigned hc = std::max(1u, std::thread::hardware_concurrency());
     unsigned k = std::min(64u, hc);
+    if (const char* e = getenv("SNARKV_HOST_POOL")) k = (unsigned)std::max(1, std::min(512, atoi(e)));  // tuning knob
     for (unsigned i = 0; i < k; ++i) workers_.emplace_back([this] { loop(); });
   }
   ~HostPool() {
@@ -203,7 +204,9 @@ inline void parallel_for(size_t n, unsigned threads, F&& fn, size_t grain = 16) 
 
 // The context-free C-ABI entry points share one process-global device context
 // (`multi_scalar_multiplication` has no `&self`, loader.rs:108): host threads
-// that reach the device through the loader take turns.
+// that reach the device through the loader take turns.  The lock also covers the default context's pinned host
+// buffers (packing happens under it), and `parallel_for` may be called while holding it: tasks of the pool therefore
+// never take this lock (they are host-only parsing and field algebra).
 inline std::mutex& device_mutex() {
   static std::mutex m;
   return m;
@@ -265,7 +268,13 @@ struct GpuNativeLoader {
       offs.push_back(offs.back() + (uint32_t)m.size());
     }
     const size_t total = offs.back();
-    std::vector<uint8_t> s(32 * total), p(64 * total);
+    // the terms are packed straight into the device library's pinned host buffers (the copy to the device is then a
+    // DMA, not the runtime's bounce copy of pageable memory); they belong to the default context, so the device lock
+    // is taken before packing
+    std::lock_guard<std::mutex> lock(device_mutex());
+    uint8_t *s = nullptr, *p = nullptr;
+    if (SNARKV_DEV(host_buffer)(0, 32 * total, (void**)&s) != SNARKV_OK || SNARKV_DEV(host_buffer)(1, 64 * total, (void**)&p) != SNARKV_OK)
+      throw std::runtime_error(std::string("host_buffer: ") + SNARKV_DEV_LAST_ERROR());
     auto pack = [&](size_t lo, size_t hi) {  // Montgomery -> canonical bytes is one field product per scalar
       for (size_t k = lo; k < hi; ++k) {
         size_t o = offs[k];
@@ -284,8 +293,7 @@ struct GpuNativeLoader {
       pack(0, msms.size());
     }
     std::vector<G1Affine> out(msms.size());
-    std::lock_guard<std::mutex> lock(device_mutex());
-    int rc = SNARKV_DEV(g1_msm_batched)(s.data(), p.data(), offs.data(), msms.size(), out.empty() ? nullptr : out[0].b);
+    int rc = SNARKV_DEV(g1_msm_batched)(s, p, offs.data(), msms.size(), out.empty() ? nullptr : out[0].b);
     if (rc != SNARKV_OK) throw std::runtime_error(std::string("g1_msm_batched: ") + SNARKV_DEV_LAST_ERROR());
     return out;
   }

@@ -189,7 +189,12 @@ inline G1Affine multi_scalar_multiplication(const std::vector<Fr>& scalars, cons
   if (scalars.size() != bases.size()) throw Panic("multi_scalar_multiplication: scalars.len() != bases.len() (msm.rs:309)");
   if (scalars.empty()) throw Panic("multi_scalar_multiplication of no terms (reference: scalars[0], msm.rs:265)");
   const size_t n = scalars.size();
-  std::vector<uint8_t> s(32 * n), p(64 * n);
+  // packed into the default context's pinned host buffers (loader.hpp `device_mutex`): 96 B per term reach the device
+  // by DMA, and a repeated call does not fault in 96 B per term of fresh pageable memory first
+  std::lock_guard<std::mutex> lock(device_mutex());
+  uint8_t *s = nullptr, *p = nullptr;
+  if (SNARKV_DEV(host_buffer)(0, 32 * n, (void**)&s) != SNARKV_OK || SNARKV_DEV(host_buffer)(1, 64 * n, (void**)&p) != SNARKV_OK)
+    throw std::runtime_error(std::string("host_buffer: ") + SNARKV_DEV_LAST_ERROR());
   auto pack = [&](size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; ++i) {
       scalars[i].to_bytes(&s[32 * i]);
@@ -203,8 +208,7 @@ inline G1Affine multi_scalar_multiplication(const std::vector<Fr>& scalars, cons
     pack(0, n);
   }
   G1Affine out;
-  std::lock_guard<std::mutex> lock(device_mutex());
-  int rc = SNARKV_DEV(g1_msm_pippenger)(s.data(), p.data(), n, out.b);
+  int rc = SNARKV_DEV(g1_msm_pippenger)(s, p, n, out.b);
   if (rc != SNARKV_OK) throw std::runtime_error(std::string("g1_msm_pippenger: ") + SNARKV_DEV_LAST_ERROR());
   return out;
 }

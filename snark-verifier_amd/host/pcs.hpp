@@ -14,6 +14,9 @@
 // Rust traits become C++ templates over the multi-open scheme tag (Gwc19 /
 // Bdfg21), exactly as `KzgAs<M, MOS>` is generic over `MOS`.
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <map>
 #include <memory>
@@ -192,7 +195,12 @@ struct KzgAs {
       for (size_t i = 0; i < bases->size(); ++i) m.push(powers_of_r[i], (*bases)[i]);
       two.push_back(m.pairs(std::nullopt));
     }
+    const bool trace = getenv("SNARKV_HOST_TRACE") != nullptr;  // dev aid: host / device split of this step on stderr
+    auto t0 = std::chrono::steady_clock::now();
     auto pts = L::multi_scalar_multiplication_batch(two);
+    if (trace)
+      fprintf(stderr, "KzgAs::verify: %zu + %zu terms, device call %.3f ms\n", two[0].size(), two[1].size(),
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return Result<KzgAccumulator>::Ok(KzgAccumulator{pts[0], pts[1]});
   }
 

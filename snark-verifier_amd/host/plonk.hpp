@@ -647,7 +647,7 @@ struct PlonkSuccinctVerifier {
       }
       jobs[2 * i] = std::move(prs.value->first);
       jobs[2 * i + 1] = std::move(prs.value->second);
-    });
+    }, 2);
     for (auto& e : errs)
       if (!e.ok()) return R::Err(e);
     auto pts = jobs.empty() ? std::vector<G1Affine>() : L::multi_scalar_multiplication_batch(jobs);

@@ -25,6 +25,7 @@ def load_library():
             "snarkv_pallas_ctx_create": (ctypes.c_int, [ctypes.c_int, vp, ctypes.POINTER(vp)]),
             "snarkv_pallas_ctx_destroy": (None, [vp]),
             "snarkv_pallas_ctx_sync": (ctypes.c_int, [vp]),
+            "snarkv_pallas_ctx_host_buffer": (ctypes.c_int, [vp, ctypes.c_int, sz, ctypes.POINTER(vp)]),
             "snarkv_pallas_last_error": (ctypes.c_char_p, []),
             "snarkv_pallas_version": (ctypes.c_char_p, []),
             "snarkv_pallas_g1_msm_pippenger": (ctypes.c_int, [vp, vp, vp, sz, vp]),

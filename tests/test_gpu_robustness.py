@@ -303,3 +303,26 @@ def test_empty_shard_contributes_the_identity(gpu_ctx):
     gpu_ctx.fold_partials_dev(gathered.data_ptr(), world, out.data_ptr())
     gpu_ctx.sync()
     assert bytes(out.cpu().numpy()) == C.msm_pippenger(s, p, 1)
+
+
+def test_inputs_in_pinned_host_buffers(gpu_ctx):
+    """`snarkv_ctx_host_buffer`: inputs assembled in the context's pinned memory give the same bytes as pageable
+    ones, the slots are independent, and a slot that grows stays usable."""
+    import ctypes
+
+    for n in (50, 3000):  # the second request outgrows the first: the slots are reallocated
+        s, p = C.sample_scalars(61 + n, n), C.sample_points(62 + n, n)
+        hs, hp = gpu_ctx.host_buffer(0, 32 * n), gpu_ctx.host_buffer(1, 64 * n)
+        assert ctypes.addressof(hs) != ctypes.addressof(hp)
+        ctypes.memmove(hs, s, len(s))
+        ctypes.memmove(hp, p, len(p))
+        offs = [0, 7, n // 2, n]
+        want = C.msm_batched(s, p, offs)
+        assert gpu_ctx.msm_batched(hs, hp, offs) == want == gpu_ctx.msm_batched(s, p, offs)
+        assert gpu_ctx.msm_pippenger(hs, hp) == C.msm_pippenger(s, p, 2)
+    again = gpu_ctx.host_buffer(0, 64)  # a smaller request returns the same (grown) slot
+    assert ctypes.addressof(again) == ctypes.addressof(gpu_ctx.host_buffer(0, 32 * 3000))
+    import snark_verifier_amd as sv
+
+    with pytest.raises(sv.SnarkvError):
+        gpu_ctx.host_buffer(sv.SNARKV_HOST_BUFFERS, 16)
