@@ -26,7 +26,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# hardware queues the HIP runtime spreads this process's streams over (default 4): the package sets the same default on
+# import; here too because the runtime reads it at its first call, which torch may make first (see snark-verifier_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
+AGG_JOBS_IN_FLIGHT = 16  # aggregation jobs kept in flight (one context each) in the `_pipelined` lines of the second metric
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 BYTES_PER_POINT = 96    # 64 B affine point + 32 B scalar, read once
 
@@ -153,7 +157,8 @@ def secondary_metrics(sv, torch, ctxs, cpu=True):
             same = all(bytes(a.cpu().numpy()) == bytes(acc[0].cpu().numpy()) for a in acc[1:])
             out["aggregate_%d_proofs_pipelined" % nproofs] = {
                 "ms_per_job": ms, "proofs_per_s": nproofs / ms * 1e3, "msm_terms": n1 + n2,
-                "includes_decide": True, "jobs_in_flight": len(ctxs), "results_identical": same,
+                "includes_decide": True, "jobs_in_flight": len(ctxs), "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "results_identical": same,
                 "roofline": aggregate_roofline(nproofs, ms)}
         if cpu:  # 64 proofs ~0.15 s, 1 024 proofs ~2.5 s of one host thread
             out["aggregate_%d_proofs" % nproofs]["cpu_baseline"] = cpu_baseline_aggregate(ds, dp, offs, n1, nproofs, n2)
@@ -710,7 +715,7 @@ def main():
             cb["sample_is_the_whole_workload"] = m == n
             line["cpu_baseline"] = cb
         if not use_dist and not args.no_secondary:
-            extra_streams = [torch.cuda.Stream() for _ in range(max(0, 8 - len(ctxs)))]  # kept alive
+            extra_streams = [torch.cuda.Stream() for _ in range(max(0, AGG_JOBS_IN_FLIGHT - len(ctxs)))]  # kept alive
             extra = [sv.Context(local_rank, stream=st.cuda_stream) for st in extra_streams]
             line["secondary"] = secondary_metrics(sv, torch, ctxs + extra, cpu=not args.no_cpu_baseline)
             e2e = end_to_end_metrics()

@@ -39,6 +39,12 @@ static int fetch_out(snarkv_ctx* ctx, const void* d, void* host, size_t bytes) {
   return SNARKV_OK;
 }
 
+// HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams sharing a queue serialise.
+// The batch scheduler uses five streams and a server keeps many latency-bound aggregation jobs in flight on contexts of
+// their own (16 queues: 2.5x the proofs/s of 64-proof jobs, profiles/r03_agg_hw_queues.txt).  The runtime reads the
+// variable at its first call: this runs when the library is loaded and never overrides the caller's own setting.
+__attribute__((constructor)) static void snarkv_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 static std::mutex g_default_mu;
 static snarkv_ctx* g_default_ctx = nullptr;
 // The context-free entry points share ONE context (stream + scratch): calls from different host
