@@ -426,7 +426,9 @@ static int many_enqueue(snarkv_ctx* ctx, size_t count, const void* const* d_s, c
     SNARKV_HIP(hipDeviceSynchronize());
     ctx->many_sig = sig;
   }
-  hipStream_t S[3] = {ctx->stream, ctx->sub[0]->stream, ctx->sub[1]->stream};  // the accumulation streams
+  hipStream_t S[4] = {ctx->stream, ctx->sub[0]->stream, ctx->sub[1]->stream, ctx->sub[2]->stream};  // the accumulation streams
+  int nS = 3;  // three of them by default: 2 / 4 measured level or worse (SNARKV_MANY_ACC_STREAMS: A/B knob)
+  if (const char* es = getenv("SNARKV_MANY_ACC_STREAMS")) nS = std::max(1, std::min(4, atoi(es)));
   // the context's stream waits for everything queued on the other four streams (join), then they wait for it (fork).
   // Inside a capture the first call only forks (the other streams are not part of the capture yet, and nothing is
   // queued on them: the caller drained the device) and the last one only joins (a stream forked again would be left
@@ -435,15 +437,15 @@ static int many_enqueue(snarkv_ctx* ctx, size_t count, const void* const* d_s, c
     for (int k = 0; k < 2 && join; ++k) {
       SNARKV_HIP(hipEventRecord(ctx->many_ev[k], ctx->hi_stream[k]));
       SNARKV_HIP(hipStreamWaitEvent(ctx->stream, ctx->many_ev[k], 0));
+    }
+    for (int k = 0; k + 1 < nS && join; ++k) {
       SNARKV_HIP(hipEventRecord(ctx->sub_ev[k], S[k + 1]));
       SNARKV_HIP(hipStreamWaitEvent(ctx->stream, ctx->sub_ev[k], 0));
     }
     if (!fork) return SNARKV_OK;
     SNARKV_HIP(hipEventRecord(ctx->sub_ev[4], ctx->stream));
-    for (int k = 0; k < 2; ++k) {
-      SNARKV_HIP(hipStreamWaitEvent(ctx->hi_stream[k], ctx->sub_ev[4], 0));
-      SNARKV_HIP(hipStreamWaitEvent(S[k + 1], ctx->sub_ev[4], 0));
-    }
+    for (int k = 0; k < 2; ++k) SNARKV_HIP(hipStreamWaitEvent(ctx->hi_stream[k], ctx->sub_ev[4], 0));
+    for (int k = 0; k + 1 < nS; ++k) SNARKV_HIP(hipStreamWaitEvent(S[k + 1], ctx->sub_ev[4], 0));
     return SNARKV_OK;
   };
   const char* et = getenv("SNARKV_MANY_TAIL");
@@ -460,7 +462,7 @@ static int many_enqueue(snarkv_ctx* ctx, size_t count, const void* const* d_s, c
       snarkv_ctx* job = ctx->jobs[i - lo];
       job->stage_timing = tm && last;
       void* grid = uniform ? (uint8_t*)d_grids + grid_bytes * (i - lo) : nullptr;
-      hipStream_t sa = ctx->hi_stream[(i - lo) % 2], sb = S[(i - lo) % 3];
+      hipStream_t sa = ctx->hi_stream[(i - lo) % 2], sb = S[(i - lo) % nS];
       SNARKV_TRY(launch_msm_pippenger_phases(job, sa, PIP_PHASE_SORT, d_s[i], d_p[i], n[i], window_bits, nullptr, false,
                                              nullptr, grid));
       SNARKV_HIP(hipEventRecord(job->grp_ev[0], sa));
