@@ -41,6 +41,16 @@ for m in 64 1024; do
   if [ -n "$db" ]; then python $R/tools/rocpd_top_kernels.py $db $O/${TAG}_rocprofv3_kernel_stats_aggregate_$m.csv; else
     f=$(find /tmp/prof_a -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_rocprofv3_kernel_stats_aggregate_$m.csv; fi
 done
+# ... and with jobs in flight: by hardware-queue count, and the kernel durations under 16-fold overlap
+cd $R
+for q in 4 16; do GPU_MAX_HW_QUEUES=$q python tools/aggregate_inflight.py --inflight 1 8 16 32 2>/dev/null | grep queues=; done > $O/${TAG}_agg_hw_queues_final.txt
+cd /tmp
+for m in 64 1024; do
+  rm -rf /tmp/prof_a; rocprofv3 --kernel-trace --stats -d /tmp/prof_a -- python $R/tools/aggregate_inflight.py --proofs $m --inflight 16 > /dev/null 2>&1
+  db=$(find /tmp/prof_a -name "*.db" | head -1)
+  if [ -n "$db" ]; then python $R/tools/rocpd_top_kernels.py $db $O/${TAG}_rocprofv3_kernel_stats_aggregate_inflight16_$m.csv; else
+    f=$(find /tmp/prof_a -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_rocprofv3_kernel_stats_aggregate_inflight16_$m.csv; fi
+done
 cd $R
 timeout 120 tools/ubench_issue > $O/${TAG}_ubench_issue.txt 2>&1
 ls -la $O | grep $TAG
