@@ -342,32 +342,35 @@ __global__ void __launch_bounds__(64) k_term_chunks(const G1Xyzz29* __restrict__
   }
 }
 
-// K2: one block per MSM folds its 2 x terms partials (`reduce(|a,v| a+v)`,
-// native.rs:68), then `to_affine()` (native.rs:70).  One wavefront for the
-// ~21-term MSMs of a proof; four for long segments (the (m+1)-term MSMs of
-// KzgAs::verify), where the strided pre-sum is the critical path.
-template <int THREADS>
+// K2: G lanes per MSM fold its 2 x terms partials (`reduce(|a,v| a+v)`, native.rs:68), then `to_affine()`
+// (native.rs:70).  G = 16 for the ~21-term MSMs of a proof: four MSMs share a wavefront -- 3 strided additions + a
+// 4-level tree is as deep as 1 + 6 levels over 64 lanes, in a quarter of the wavefronts, and four lanes instead of one are
+// live in the inversion (with many jobs in flight the folds were a quarter of the issued work); G = 64 for longer
+// segments; 256 lanes for the (m + 1)-term MSMs of KzgAs::verify, where the strided pre-sum is the critical path.
+template <int THREADS, int G>
 __global__ void __launch_bounds__(THREADS) k_segment_fold(const G1Xyzz29* __restrict__ parts,
                                                            const uint32_t* __restrict__ offsets,
-                                                           uint32_t* __restrict__ out) {
+                                                           uint32_t* __restrict__ out, uint32_t n_msm) {
+  static_assert(THREADS % G == 0 && (G & (G - 1)) == 0, "G lanes per MSM: a power of two dividing the workgroup");
   __shared__ G1Xyzz29 sh[THREADS];
-  uint32_t k = blockIdx.x;
-  uint32_t lo = 2 * offsets[k], hi = 2 * offsets[k + 1];
-  uint32_t lane = threadIdx.x;
+  const uint32_t tid = threadIdx.x, lane = tid % G;
+  const uint32_t k = blockIdx.x * (THREADS / G) + tid / G;
+  const bool live = k < n_msm;
+  const uint32_t lo = live ? 2 * offsets[k] : 0, hi = live ? 2 * offsets[k + 1] : 0;
   G1Xyzz29 acc = xyzz29_identity();
-  for (uint32_t i = lo + lane; i < hi; i += THREADS) xyzz29_add_careful(acc, parts[i]);
-  sh[lane] = acc;
+  for (uint32_t i = lo + lane; i < hi; i += G) xyzz29_add_careful(acc, parts[i]);
+  sh[tid] = acc;
   __syncthreads();
-  for (uint32_t s = THREADS / 2; s >= 1; s >>= 1) {
+  for (uint32_t s = G / 2; s >= 1; s >>= 1) {
     if (lane < s) {
-      G1Xyzz29 a = sh[lane];
-      xyzz29_add_careful(a, sh[lane + s]);
-      sh[lane] = a;
+      G1Xyzz29 a = sh[tid];
+      xyzz29_add_careful(a, sh[tid + s]);
+      sh[tid] = a;
     }
     __syncthreads();
   }
-  if (lane == 0) {
-    G1Affine29 r = xyzz29_to_affine(sh[0]);
+  if (lane == 0 && live) {
+    G1Affine29 r = xyzz29_to_affine(sh[tid]);
     uint32_t w[16];
     g1a29_to_canonical(r, w);
     uint4* o = reinterpret_cast<uint4*>(out + (size_t)k * 16);
@@ -454,12 +457,18 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
     hipLaunchKernelGGL(k_term_chunks, dim3((n_lanes + 63) / 64), dim3(64), 0, ctx->stream,
                        (const G1Xyzz29*)d_chain, (const uint4*)d_mags, (G1Xyzz29*)d_terms, n_lanes, J, bits);
   }
-  if (n_terms >= 128 * n_msm)
-    hipLaunchKernelGGL(k_segment_fold<256>, dim3((uint32_t)n_msm), dim3(256), 0, ctx->stream,
-                       (const G1Xyzz29*)d_terms, (const uint32_t*)d_offsets, (uint32_t*)d_out);
-  else
-    hipLaunchKernelGGL(k_segment_fold<64>, dim3((uint32_t)n_msm), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_terms,
-                       (const uint32_t*)d_offsets, (uint32_t*)d_out);
+  const char* eg = getenv("SNARKV_FOLD_GROUP");  // 16 / 64 / 256: force the lanes per MSM (test / A-B knob)
+  const int force = eg ? atoi(eg) : 0;
+  const uint32_t nm = (uint32_t)n_msm;
+  if (force == 256 || (!force && n_terms >= 128 * n_msm))
+    hipLaunchKernelGGL((k_segment_fold<256, 256>), dim3(nm), dim3(256), 0, ctx->stream, (const G1Xyzz29*)d_terms,
+                       (const uint32_t*)d_offsets, (uint32_t*)d_out, nm);
+  else if (force == 64 || (!force && n_terms > 32 * n_msm))
+    hipLaunchKernelGGL((k_segment_fold<64, 64>), dim3(nm), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_terms,
+                       (const uint32_t*)d_offsets, (uint32_t*)d_out, nm);
+  else  // <= 64 partials per MSM on average: four MSMs per wavefront
+    hipLaunchKernelGGL((k_segment_fold<64, 16>), dim3((nm + 3) / 4), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_terms,
+                       (const uint32_t*)d_offsets, (uint32_t*)d_out, nm);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }
