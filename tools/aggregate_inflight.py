@@ -16,11 +16,17 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--proofs", type=int, nargs="*", default=[64, 1024])
 ap.add_argument("--inflight", type=int, nargs="*", default=[1, 4, 8, 16, 32])
 ap.add_argument("--rounds", type=int, default=4)
+ap.add_argument("--dummy-streams", type=int, default=0, help="streams created (and kept) before the jobs' own: does their queue mapping matter?")
+ap.add_argument("--dummy-priority", type=int, default=0)
 a = ap.parse_args()
 g2 = bytes.fromhex(
     "edf692d95cbdde46ddda5ef7d422436779445c5e66006a42761e1f12efde0018c212f3aeb785e49712e7a9353349aaf1255dfb31b7bf60723a480d9293938e19"
     "aa7dfa6601cce64c7bd3430c69e7d1e38f40cb8d8071ab4aeb6d8cdba55ec8125b9722d1dcdaac55f38eb37033314bbc95330c69ad999eec75f05f58d0890609")
 g1 = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
+dummies = [torch.cuda.Stream(priority=a.dummy_priority) for _ in range(a.dummy_streams)]
+for d_ in dummies:
+    with torch.cuda.stream(d_):
+        torch.zeros(1, device="cuda")
 nmax = max(a.inflight)
 streams = [torch.cuda.Stream() for _ in range(nmax)]
 ctxs = [sv.Context(0, stream=s.cuda_stream) for s in streams]
