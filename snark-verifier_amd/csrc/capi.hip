@@ -403,7 +403,10 @@ static int many_enqueue(snarkv_ctx* ctx, size_t count, const void* const* d_s, c
   SNARKV_TRY(ctx_lanes(ctx));
   while ((size_t)ctx->njobs < G) {
     snarkv_ctx* j = nullptr;
-    SNARKV_TRY(snarkv_ctx_create(ctx->device, nullptr, &j));
+    // a job context is scratch + events only (its phases are enqueued on the scheduler's streams): it borrows this
+    // context's stream handle instead of creating a stream of its own -- the runtime maps streams onto its hardware
+    // queues in creation order, and dozens of idle streams would shift the mapping of every stream created after them
+    SNARKV_TRY(snarkv_ctx_create(ctx->device, (void*)ctx->stream, &j));
     j->is_lane = true;
     j->throughput_mode = true;  // long runs: other accumulations are always resident next to a job's
     for (int e = 0; e < 16; ++e) SNARKV_HIP(hipEventCreateWithFlags(&j->grp_ev[e], hipEventDisableTiming));
