@@ -156,11 +156,20 @@ int snarkv_kzg_pairing_value(snarkv_ctx* ctx, const snarkv_dk* dk, const uint8_t
  * SNARKV_ERR_ENCODING.                                                      */
 int snarkv_g1_validate(snarkv_ctx* ctx, const uint8_t* points64, size_t n);
 
+/* ---- compressed points of a Poseidon transcript ----------------------------- *
+ * `C::from_bytes(&data)` of `PoseidonTranscript::read_ec_point`
+ * (snark-verifier/src/system/halo2/transcript/halo2.rs:260-273) for a whole batch: n x 32 bytes (x little-endian,
+ * bit 254 = parity of y, bit 255 = identity) -> n x 64 bytes x || y (the identity: zeros) and ok[i] = 1, or ok[i] = 0
+ * where `from_bytes` is `None` (x >= p, no such point, malformed identity).  One square root per point: the host
+ * front half of a 1 024-proof aggregation spent 2.4 ms there.  SNARKV_OK, or an error code for bad arguments.   */
+int snarkv_g1_decompress(snarkv_ctx* ctx, const uint8_t* in32, size_t n, uint8_t* out64, uint8_t* ok);
+
 /* ---- context-free entry points (process-global default context) -------- */
 int bn254_g1_msm_naive(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]);
 int bn254_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, const uint32_t* offsets, size_t n_msm,
                          uint8_t* out);
 int bn254_g1_msm_pippenger(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]);
+int bn254_g1_decompress(const uint8_t* in32, size_t n, uint8_t* out64, uint8_t* ok);
 /* snarkv_ctx_host_buffer of the default context (callers serialise their use of it, as they do its calls) */
 int bn254_host_buffer(int slot, size_t bytes, void** out);
 int bn254_kzg_decide(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],

@@ -50,6 +50,8 @@ _SIGNATURES = {
     "snarkv_ctx_sync": (_int, [_vp]),
     "snarkv_ctx_host_buffer": (_int, [_vp, _int, _sz, _pp]),
     "bn254_host_buffer": (_int, [_int, _sz, _pp]),
+    "snarkv_g1_decompress": (_int, [_vp, _cp, _sz, _vp, _vp]),
+    "bn254_g1_decompress": (_int, [_cp, _sz, _vp, _vp]),
     "snarkv_last_error": (_cp, []),
     "snarkv_version": (_cp, []),
     "snarkv_g1_msm_naive": (_int, [_vp, _cp, _cp, _sz, _u32, _vp]),
@@ -370,6 +372,17 @@ class Context:
 
     def sync(self):
         _check(self._lib.snarkv_ctx_sync(self._h))
+
+    def g1_decompress(self, compressed):
+        """Batch `G1Affine::from_bytes` (halo2.rs:260-273): n x 32 bytes -> (n x 64 bytes, [valid])."""
+        c = _as_bytes(compressed)
+        if len(c) % 32:
+            raise SnarkvError(SNARKV_ERR_LENGTH, "compressed points are 32 bytes each")
+        n = len(c) // 32
+        out = ctypes.create_string_buffer(max(64 * n, 1))
+        ok = ctypes.create_string_buffer(max(n, 1))
+        _check(self._lib.snarkv_g1_decompress(self._h, c if n else b"\x00", n, out, ok))
+        return out.raw[: 64 * n], [b != 0 for b in ok.raw[:n]]
 
     def host_buffer(self, slot, nbytes):
         """Pinned host memory owned by the context (`snarkv_ctx_host_buffer`): a ctypes char array over it

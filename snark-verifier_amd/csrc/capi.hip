@@ -168,6 +168,19 @@ int snarkv_g1_msm_batched(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8
   return fetch_out(ctx, d_out, out, n_msm * 64);
 }
 
+int snarkv_g1_decompress(snarkv_ctx* ctx, const uint8_t* in32, size_t n, uint8_t* out64, uint8_t* ok) {
+  if (!ctx || (n && (!in32 || !out64 || !ok))) return SNARKV_ERR_ARG;
+  if (n == 0) return SNARKV_OK;
+  if (n > 0xFFFFFFFFull) return SNARKV_ERR_LENGTH;
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  void *d_in, *d_out;
+  SNARKV_TRY(stage_in(ctx, SLOT_IN_POINTS, in32, n * 32, &d_in));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_OUT, n * 64 + n, &d_out));  // the points, then one validity byte each
+  SNARKV_TRY(launch_g1_decompress(ctx, d_in, n, d_out, (uint8_t*)d_out + n * 64));
+  SNARKV_HIP(hipMemcpyAsync(ok, (const uint8_t*)d_out + n * 64, n, hipMemcpyDeviceToHost, ctx->stream));
+  return fetch_out(ctx, d_out, out64, n * 64);
+}
+
 int snarkv_g1_msm_naive(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8_t* points64, size_t n,
                         uint32_t flags, uint8_t out64[64]) {
   if (n == 0) return SNARKV_ERR_EMPTY;
@@ -771,6 +784,13 @@ int bn254_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, cons
   snarkv_ctx* c;
   SNARKV_TRY(default_ctx(&c));
   return snarkv_g1_msm_batched(c, scalars32, points64, offsets, n_msm, 0, out);
+}
+
+int bn254_g1_decompress(const uint8_t* in32, size_t n, uint8_t* out64, uint8_t* ok) {
+  SNARKV_DEFAULT_CALL_LOCK();
+  snarkv_ctx* c;
+  SNARKV_TRY(default_ctx(&c));
+  return snarkv_g1_decompress(c, in32, n, out64, ok);
 }
 
 int bn254_host_buffer(int slot, size_t bytes, void** out) {

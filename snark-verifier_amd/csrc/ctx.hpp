@@ -139,6 +139,7 @@ inline snarkv_ctx* ctx_lane(snarkv_ctx* ctx, size_t i) { return (i % 4 == 3) ? c
 // kernels' host-side launchers (each enqueues on ctx->stream)
 int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, const void* d_offsets,
                        size_t n_msm, size_t n_terms, void* d_out);
+int launch_g1_decompress(snarkv_ctx* ctx, const void* d_in32, size_t n, void* d_out64, void* d_ok);
 int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
                          void* d_out, bool partial_out, void* d_buckets_out = nullptr);
 // one Pippenger cut into phases, each on a stream of the caller's choice (msm_pippenger.hip); `ctx` owns the scratch

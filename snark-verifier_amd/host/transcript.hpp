@@ -816,10 +816,15 @@ class PoseidonTranscriptT : public Transcript {
       return Result<G1Affine>::Err(Error{Error::Transcript, "failed to fill whole buffer"});
     G1Affine p;
     bool ok = true;
+    const uint8_t* enc = stream_.data() + pos_;
+    const size_t read_index = point_offsets_.size();
+    point_offsets_.push_back(pos_);
     if (next_decoded_ < decoded_in_.size()) {
       p = decoded_in_[next_decoded_++];  // second parsing pass: the square root was taken in the first
+    } else if (read_index < hints_.size() && hint_matches(hints_[read_index], enc)) {
+      p = hints_[read_index];  // decompressed by the device for the whole batch (snarkv_g1_decompress)
     } else {
-      ok = g1_decompress(stream_.data() + pos_, &p);
+      ok = g1_decompress(enc, &p);
     }
     pos_ += 32;
     if (!ok) return Result<G1Affine>::Err(Error{Error::Transcript, "Invalid elliptic curve point encoding in proof"});
@@ -853,6 +858,16 @@ class PoseidonTranscriptT : public Transcript {
   Sponge buf_;
   std::vector<G1Affine> decoded_, decoded_in_;  // points decompressed by this pass / handed over by an earlier one
   size_t next_decoded_ = 0;
+  std::vector<size_t> point_offsets_;           // stream position of every point read so far
+  std::vector<G1Affine> hints_;                 // candidate decodings by read index; (0, 0) = none
+  // A hint is used only if it IS the decoding of these 32 bytes: a finite point whose x equals the encoded x and whose
+  // y has the encoded parity (on the curve by construction: the device checks y^2 = x^3 + 3 before answering).
+  // Identities, invalid encodings and anything that does not match go through g1_decompress as before.
+  static bool hint_matches(const G1Affine& h, const uint8_t enc[32]) {
+    if (enc[31] >> 7) return false;
+    if (h.is_identity()) return false;
+    return memcmp(enc, h.b, 31) == 0 && (enc[31] & 0x3F) == h.b[31] && ((enc[31] >> 6) & 1) == (h.b[32] & 1);
+  }
 
  public:
   std::vector<G1Affine>& decoded_points() { return decoded_; }
@@ -860,6 +875,10 @@ class PoseidonTranscriptT : public Transcript {
     decoded_in_ = std::move(pts);
     next_decoded_ = 0;
   }
+  // where this pass read its points (the layout is the protocol's: the same for every proof of it)
+  const std::vector<size_t>& point_offsets() const { return point_offsets_; }
+  // decodings computed elsewhere for the k-th point read, checked against the bytes before use
+  void set_point_hints(std::vector<G1Affine> pts) { hints_ = std::move(pts); }
 };
 using PoseidonTranscript = PoseidonTranscriptT<Poseidon>;
 

@@ -328,3 +328,52 @@ def test_poseidon_auto_transcript_picks_by_batch_size():
             assert got[HA.TRANSCRIPT_POSEIDON_AUTO] == fx["expected_acc"]
     hp.close()
     hdk.close()
+
+
+def test_device_decompressed_points_keep_the_host_verdicts():
+    """The device-hashed Poseidon path decompresses the whole batch's points in one launch (`bn254_g1_decompress`) and
+    hands them to the parsing pass as hints that are checked against the bytes.  Tampered batches must end exactly as
+    on the host-hashed path: a corrupted x (another point, or no point at all), a flipped parity bit, a proof of another
+    length (which keeps the host path) -- same verdict, same error text, same accumulator."""
+    import struct
+
+    from snark_verifier_amd import host_api as HA
+
+    fx = HA.read_fixture(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                                      "bench_plonk_gwc19_poseidon_64.bin"))
+    hp, hdk = HA.Protocol(fx["protocol"]), HA.DecidingKey(fx["dk"])
+    blob = fx["proofs"]
+    starts, off = [], 0
+    for _ in range(fx["n"]):
+        ln, = struct.unpack_from("<I", blob, off)
+        starts.append((off + 4, ln))
+        off += 4 + ln
+
+    def outcome(proofs, kind):
+        try:
+            ok, acc = HA.aggregate(hp, hdk, fx["instances"], proofs, fx["n"], HA.MOS_GWC19, kind, 8)
+            return ("rc", ok, acc if ok else None)
+        except HA.HostError as e:
+            return ("err", e.code if hasattr(e, "code") else None, str(e))
+
+    def both(proofs):
+        a, b = outcome(proofs, HA.TRANSCRIPT_POSEIDON), outcome(proofs, HA.TRANSCRIPT_POSEIDON_DEVICE)
+        assert a == b, (a, b)
+        return a
+
+    assert both(blob) == ("rc", True, fx["expected_acc"])
+    s5 = starts[5][0]
+    for mutate in (lambda m: m.__setitem__(s5, m[s5] ^ 1),                 # x of the first point of proof 5
+                   lambda m: m.__setitem__(s5 + 31, m[s5 + 31] ^ 0x40),    # its parity bit: the other root
+                   lambda m: m.__setitem__(s5 + 31, m[s5 + 31] | 0x80),    # an identity flag on a finite x
+                   lambda m: m.__setitem__(starts[63][0] + 32 + 7, m[starts[63][0] + 32 + 7] ^ 0x55)):  # second point, last proof
+        m = bytearray(blob)
+        mutate(m)
+        r = both(bytes(m))
+        assert r != ("rc", True, fx["expected_acc"])
+    # a proof that is one scalar longer: another length -> no device hints for it, the same ending on both paths
+    s9, l9 = starts[9]
+    longer = blob[:s9 - 4] + struct.pack("<I", l9 + 32) + blob[s9:s9 + l9] + bytes(32) + blob[s9 + l9:]
+    both(longer)
+    hp.close()
+    hdk.close()

@@ -68,3 +68,60 @@ def test_error_codes(gpu_ctx):
     with pytest.raises(sv.SnarkvError):  # t out of range
         sv.PoseidonSpec(gpu_ctx, 9, 8, 8, 60, T.poseidon_opt_tables(5, 8, 60))
     spec.close()
+
+
+def test_g1_decompress_batch_vs_oracle(gpu_ctx):
+    """`snarkv_g1_decompress` = `C::from_bytes` of PoseidonTranscript::read_ec_point (halo2.rs:260-273) for a batch:
+    both parities, the identity, and every way an encoding can be invalid -- against the oracle's restatement."""
+    import coracle as C
+    import transcript as T
+
+    n = 300
+    pts = C.sample_points(71, n)
+    enc, want, valid = [], [], []
+
+    def push(b):
+        b = bytes(b)
+        enc.append(b)
+        try:
+            pt = T.g1_decompress(b)
+            want.append(bytes(64) if pt is None else pt[0].to_bytes(32, "little") + pt[1].to_bytes(32, "little"))
+            valid.append(True)
+        except T.TranscriptError:
+            want.append(bytes(64))
+            valid.append(False)
+
+    for i in range(n):
+        x = int.from_bytes(pts[64 * i:64 * i + 32], "little")
+        y = int.from_bytes(pts[64 * i + 32:64 * i + 64], "little")
+        push(T.g1_compress((x, y)))
+        push(T.g1_compress((x, O.P - y)))  # the other root: the other parity
+    assert want[0] == pts[:64]
+    push(T.g1_compress(None))                                   # the identity
+    bad_inf = bytearray(T.g1_compress(None)); bad_inf[0] = 1    # identity flag with a non-zero x
+    push(bad_inf)
+    bad_inf2 = bytearray(T.g1_compress(None)); bad_inf2[31] |= 0x40  # identity flag with the parity bit
+    push(bad_inf2)
+    big = bytearray(O.P.to_bytes(32, "little"))                 # x = p: not canonical
+    push(big)
+    big2 = bytearray((O.P + 5).to_bytes(32, "little"))
+    push(big2)
+    rng = random.Random(9)
+    non_res = 0
+    while non_res < 20:                                          # x with x^3 + 3 not a square: no such point
+        x = rng.randrange(O.P)
+        if pow((x * x * x + 3) % O.P, (O.P - 1) // 2, O.P) != 1:
+            b = bytearray(x.to_bytes(32, "little"))
+            b[31] |= rng.randrange(2) << 6
+            push(b)
+            non_res += 1
+    for x in (0, 1, 2, O.P - 1):                                 # small / extreme x, whatever they decode to
+        for s in (0, 1):
+            b = bytearray(x.to_bytes(32, "little"))
+            b[31] |= s << 6
+            push(b)
+    got, ok = gpu_ctx.g1_decompress(b"".join(enc))
+    assert ok == valid
+    for i, w in enumerate(want):
+        assert got[64 * i:64 * i + 64] == w, i
+    assert gpu_ctx.g1_decompress(b"") == (b"", [])
