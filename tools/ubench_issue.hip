@@ -63,6 +63,14 @@ PROBE(ashr64_4chains, 64, R16("v_ashrrev_i64 v[0:1], 29, v[0:1]\n v_ashrrev_i64 
 PROBE(mullo_dep, 64, R16(R4("v_mul_lo_u32 v0, v0, s44\n")))
 PROBE(mullo_4chains, 64, R16("v_mul_lo_u32 v0, v0, s44\n v_mul_lo_u32 v4, v4, s44\n v_mul_lo_u32 v8, v8, s44\n v_mul_lo_u32 v12, v12, s44\n"))
 PROBE(nop_only, 64, R16(R4("s_nop 0\n")))
+// 9b. cross-lane moves of the latency-bound kernels (decide rounds, Poseidon): DPP adds, dependent on themselves
+// (the required wait state before a DPP read of a fresh VGPR is written out as the compiler would) and over 4 / 9 registers
+PROBE(dpp_quad_dep, 64, R16(R2("s_nop 1\n v_add_u32_dpp v0, v0, v0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n")))
+PROBE(dpp_quad_4regs, 64, R16("v_add_u32_dpp v0, v0, v0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_u32_dpp v4, v4, v4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_u32_dpp v8, v8, v8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_u32_dpp v12, v12, v12 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"))
+PROBE(dpp_mirror_4regs, 64, R16("v_add_u32_dpp v0, v0, v0 row_half_mirror row_mask:0xf bank_mask:0xf\n v_add_u32_dpp v4, v4, v4 row_half_mirror row_mask:0xf bank_mask:0xf\n v_add_u32_dpp v8, v8, v8 row_half_mirror row_mask:0xf bank_mask:0xf\n v_add_u32_dpp v12, v12, v12 row_half_mirror row_mask:0xf bank_mask:0xf\n"))
+PROBE(dpp_shr_4regs, 64, R16("v_mov_b32_dpp v0, v2 row_shr:4 row_mask:0xf bank_mask:0xa\n v_mov_b32_dpp v4, v6 row_shr:4 row_mask:0xf bank_mask:0xa\n v_mov_b32_dpp v8, v10 row_shr:4 row_mask:0xf bank_mask:0xa\n v_mov_b32_dpp v12, v14 row_shr:4 row_mask:0xf bank_mask:0xa\n"))
+// a mad result read by a DPP add two instructions later (product -> butterfly, as the kernels do)
+PROBE(mad_then_dpp, 64, R16(MAD("v[0:1]", "v2", "v3") "v_and_b32 v4, s46, v4\n s_nop 0\n v_add_u32_dpp v8, v0, v8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"))
 PROBE(mov_4chains, 64, R16("v_mov_b32 v0, v2\n v_mov_b32 v4, v6\n v_mov_b32 v8, v10\n v_mov_b32 v12, v14\n"))
 PROBE(lshladd64_dep, 64, R16(R4("v_lshl_add_u64 v[0:1], v[0:1], 0, v[2:3]\n")))
 // 10. one Montgomery COLUMN as the compiler emits it today (9 operand/reduction mads, nop, mul_lo, and, mad, nop, shift) ...
@@ -127,7 +135,7 @@ int main() {
   }
   RUN(mad_dep) RUN(mad_dep_nop_each) RUN(mad_dep_nop_8th) RUN(mad_2chains) RUN(mad_4chains) RUN(mad_dep_sgpr)
   RUN(mad_dep_bankconf) RUN(mad_dep_scarry) RUN(and_dep) RUN(and_4chains) RUN(sub_4chains) RUN(ashr64_dep)
-  RUN(ashr64_4chains) RUN(mullo_dep) RUN(mullo_4chains) RUN(nop_only) RUN(mov_4chains) RUN(lshladd64_dep)
+  RUN(ashr64_4chains) RUN(mullo_dep) RUN(mullo_4chains) RUN(nop_only) RUN(dpp_quad_dep) RUN(dpp_quad_4regs) RUN(dpp_mirror_4regs) RUN(dpp_shr_4regs) RUN(mad_then_dpp) RUN(mov_4chains) RUN(lshladd64_dep)
   RUN(column_today) RUN(column_lean) RUN(column_lean_x2)
   return 0;
 }
