@@ -377,3 +377,43 @@ def test_device_decompressed_points_keep_the_host_verdicts():
     both(longer)
     hp.close()
     hdk.close()
+
+
+def test_concurrent_aggregations_from_host_threads():
+    """Several host threads in `snarkv_host_aggregate` at once (ctypes releases the GIL): the device lock is held while
+    the terms are packed into the default context's pinned buffers (loader.hpp), the host pool runs one job at a time,
+    the Poseidon path takes the device for its hashing and decompression launches -- every call must still return the
+    fixture's accumulator, whatever the interleaving."""
+    import threading
+
+    from snark_verifier_amd import host_api as HA
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    jobs = []
+    for name, kind in (("bench_plonk_gwc19_evm_64.bin", HA.TRANSCRIPT_EVM),
+                       ("bench_plonk_gwc19_poseidon_64.bin", HA.TRANSCRIPT_POSEIDON_DEVICE),
+                       ("bench_plonk_gwc19_poseidon_64.bin", HA.TRANSCRIPT_POSEIDON)):
+        fx = HA.read_fixture(os.path.join(root, name))
+        jobs.append((fx, HA.Protocol(fx["protocol"]), HA.DecidingKey(fx["dk"]), kind))
+    bad = []
+
+    def worker(k):
+        fx, hp, hdk, kind = jobs[k % len(jobs)]
+        for _ in range(4):
+            try:
+                ok, acc = HA.aggregate(hp, hdk, fx["instances"], fx["proofs"], fx["n"], HA.MOS_GWC19, kind, 8)
+                if not ok or acc != fx["expected_acc"]:
+                    bad.append((k, "wrong result"))
+            except Exception as e:  # noqa: BLE001
+                bad.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a worker is stuck (lock order?)"
+    assert not bad, bad
+    for _, hp, hdk, _ in jobs:
+        hp.close()
+        hdk.close()
