@@ -258,6 +258,27 @@ def end_to_end_metrics():
                 "input": os.path.basename(path) + (" x%d" % rep if rep > 1 else "")}
         hp.close()
         hdk.close()
+    # 16 jobs of 64 proofs in ONE call (`snarkv_host_aggregate_many`: a service batching its requests): three device
+    # launches whatever the number of jobs, so small jobs share them -- compare end_to_end_aggregate_64_proofs x 16
+    path = os.path.join(ROOT, "tests", "golden", "bench_plonk_gwc19_evm_64.bin")
+    if os.path.exists(path):
+        fx = H.read_fixture(path)
+        hp, hdk = H.Protocol(fx["protocol"]), H.DecidingKey(fx["dk"])
+        J = 16
+        best = None
+        for _ in range(5):
+            ok, accs, oks, tm = H.aggregate_many(hp, hdk, fx["instances"] * J, fx["proofs"] * J, [fx["n"]] * J, H.MOS_GWC19, 0,
+                                                 threads, timings=True)
+            if best is None or tm["total"] < best["total"]:
+                best = tm
+        out["end_to_end_aggregate_16_jobs_of_64_proofs_one_call"] = {
+            "ms": best["total"], "ms_per_job": best["total"] / J, "proofs_per_s": fx["n"] * J / best["total"] * 1e3,
+            "jobs": J, "host_threads": threads, "ms_read_proofs_host": best["read_proofs"],
+            "ms_fr_algebra_host": best["fr_algebra"], "ms_msm_device_incl_h2d": best["msm_device"],
+            "ms_kzg_accumulate": best["accumulate"], "ms_decide": best["decide"], "accepted": bool(ok),
+            "matches_fixture_accumulator": all(a == fx["expected_acc"] for a in accs), "input": os.path.basename(path) + " x16 jobs"}
+        hp.close()
+        hdk.close()
     # config 5 on its own input: 1 024 DISTINCT proofs (tests/golden/bench_plonk_gwc19_evm_1024.bin)
     path = os.path.join(ROOT, "tests", "golden", "bench_plonk_gwc19_evm_1024.bin")
     if os.path.exists(path):

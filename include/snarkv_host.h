@@ -16,6 +16,7 @@
  *                                         Poseidon transcript, and `KzgAsProof::read` + `verify` on caller-supplied bytes
  *   snarkv_host_kzg_decide / _decide_all  `AccumulationDecider::{decide, decide_all}` (pcs/kzg/decider.rs:70-93)
  *   snarkv_host_aggregate                 the whole job: succinct-verify N proofs -> accumulate -> decide
+ *   snarkv_host_aggregate_many            several such jobs sharing their three device launches
  *   snarkv_host_plonk_verify              `PlonkVerifier::verify` (verifier/plonk.rs:133: succinct verify + decide_all)
  *
  * Byte layouts: Fr / Fq 32 B little-endian canonical; G1 64 B x|y (identity = zeros); G2 128 B x.c0|x.c1|y.c0|y.c1;
@@ -122,6 +123,17 @@ int snarkv_host_kzg_decide_all(const snarkv_host_dk* dk, const uint8_t* accs128,
 int snarkv_host_aggregate(const snarkv_host_protocol* protocol, const snarkv_host_dk* dk, int mos, int transcript,
                           const uint8_t* instances, size_t instances_len, const uint8_t* proofs, size_t proofs_len,
                           uint32_t n, unsigned host_threads, double* timings_ms, uint8_t* acc_out);
+
+/* SEVERAL such jobs in one call (a service batching its requests): `job_sizes[k]` consecutive proofs of the two blobs
+ * belong to job k.  Per job exactly what snarkv_host_aggregate returns for its proofs -- accs_out: n_jobs x 128 bytes,
+ * ok_out: the pairing verdict per job -- but the device runs three launches whatever n_jobs is (every proof's MSMs,
+ * every job's two KzgAs MSMs, every job's pairing check): the launches of a small job are latency chains that fill a
+ * fraction of the GPU, and 16 jobs of 64 proofs cost what one job of 1 024 does.  Returns 1 if every job is accepted,
+ * 0 if some job is rejected (see ok_out), a negative code for malformed input (no partial results).              */
+int snarkv_host_aggregate_many(const snarkv_host_protocol* protocol, const snarkv_host_dk* dk, int mos, int transcript,
+                               const uint8_t* instances, size_t instances_len, const uint8_t* proofs, size_t proofs_len,
+                               const uint32_t* job_sizes, uint32_t n_jobs, unsigned host_threads, double* timings_ms,
+                               uint8_t* accs_out, uint8_t* ok_out);
 
 /* PlonkVerifier::verify on N proofs: succinct verify (one launch) then ONE decide_all over every accumulator. */
 int snarkv_host_plonk_verify(const snarkv_host_protocol* protocol, const snarkv_host_dk* dk, int mos, int transcript,

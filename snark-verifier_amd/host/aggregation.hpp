@@ -156,12 +156,13 @@ struct Aggregator {
     return Error{};
   }
 
-  // succinct-verify every proof and fold the accumulators into one
-  static Result<KzgAccumulator> aggregate(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
-                                          const std::vector<std::vector<std::vector<Fr>>>& instances,
-                                          const std::vector<std::vector<uint8_t>>& proofs, unsigned threads,
-                                          AggregationTimings* tm = nullptr) {
-    using R = Result<KzgAccumulator>;
+  // The front half of a job: succinct-verify every proof -- `read_proof` + the host half of `verify` on `threads` host
+  // threads, all 2 n MSMs in ONE segmented launch -- and return, per proof, its new accumulator followed by the old ones
+  // it carried (verifier/plonk.rs:58-92).
+  static Result<std::vector<std::vector<KzgAccumulator>>> succinct_verify_all(
+      const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr, const std::vector<std::vector<std::vector<Fr>>>& instances,
+      const std::vector<std::vector<uint8_t>>& proofs, unsigned threads, AggregationTimings* tm = nullptr) {
+    using R = Result<std::vector<std::vector<KzgAccumulator>>>;
     using clk = std::chrono::steady_clock;
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const size_t n = proofs.size();
@@ -208,14 +209,11 @@ struct Aggregator {
     auto t2 = clk::now();
     auto pts = L::multi_scalar_multiplication_batch(jobs);
     auto t3 = clk::now();
-    std::vector<KzgAccumulator> accs;
+    std::vector<std::vector<KzgAccumulator>> out(n);
     for (size_t i = 0; i < n; ++i) {
-      accs.push_back(KzgAccumulator{pts[2 * i], pts[2 * i + 1]});
-      accs.insert(accs.end(), pfs[i].old_accumulators.begin(), pfs[i].old_accumulators.end());
+      out[i].push_back(KzgAccumulator{pts[2 * i], pts[2 * i + 1]});
+      out[i].insert(out[i].end(), pfs[i].old_accumulators.begin(), pfs[i].old_accumulators.end());
     }
-    EvmTranscript at;
-    auto acc = KzgAs<MOS>::create_proof(KzgAsProvingKey{}, accs, at, Fr());
-    auto t4 = clk::now();
     if (tm) {
       double host = ms(t0, t2), read_sum = 0;
       for (double x : t_read) read_sum += x;
@@ -229,10 +227,102 @@ struct Aggregator {
         tm->fr_algebra = host - device_hash_ms;
       }
       tm->msm_device = ms(t2, t3);
-      tm->accumulate = ms(t3, t4);
-      tm->total = ms(t0, t4);
+      tm->total = ms(t0, t3);
+    }
+    return R::Ok(std::move(out));
+  }
+
+  // succinct-verify every proof and fold the accumulators into one
+  static Result<KzgAccumulator> aggregate(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
+                                          const std::vector<std::vector<std::vector<Fr>>>& instances,
+                                          const std::vector<std::vector<uint8_t>>& proofs, unsigned threads,
+                                          AggregationTimings* tm = nullptr) {
+    using R = Result<KzgAccumulator>;
+    using clk = std::chrono::steady_clock;
+    auto per_proof = succinct_verify_all(svk, pr, instances, proofs, threads, tm);
+    if (!per_proof.ok()) return R::Err(per_proof.err);
+    auto t3 = clk::now();
+    std::vector<KzgAccumulator> accs;
+    for (auto& v : *per_proof.value) accs.insert(accs.end(), v.begin(), v.end());
+    EvmTranscript at;
+    auto acc = KzgAs<MOS>::create_proof(KzgAsProvingKey{}, accs, at, Fr());
+    if (tm) {
+      tm->accumulate = std::chrono::duration<double, std::milli>(clk::now() - t3).count();
+      tm->total += tm->accumulate;
     }
     return acc;
+  }
+
+  // SEVERAL jobs in one call (a verifier service batching its requests; all proofs of one protocol).  `sizes[k]` proofs
+  // belong to job k, in order.  The device sees THREE launches whatever the number of jobs -- every proof's two MSMs,
+  // every job's two KzgAs MSMs, every job's pairing check -- so that small jobs, whose launches are latency chains that
+  // fill a fraction of the GPU, share them: 16 jobs of 64 proofs cost what one job of 1 024 does.  Per job the result is
+  // exactly `aggregate` + `decide` on its proofs (same transcript, same accumulator bytes).
+  struct ManyResult {
+    std::vector<KzgAccumulator> accs;  // one per job
+    std::vector<uint8_t> ok;           // the pairing verdict per job
+  };
+  static Result<ManyResult> aggregate_and_decide_many(const KzgDecidingKey& dk, const PlonkProtocol& pr,
+                                                      const std::vector<std::vector<std::vector<Fr>>>& instances,
+                                                      const std::vector<std::vector<uint8_t>>& proofs,
+                                                      const std::vector<uint32_t>& sizes, unsigned threads,
+                                                      AggregationTimings* tm = nullptr) {
+    using R = Result<ManyResult>;
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    size_t total = 0;
+    for (uint32_t k : sizes) {
+      if (k == 0) return R::Err(Error{Error::InvalidInstances, "a job without proofs"});
+      total += k;
+    }
+    if (sizes.empty() || total != proofs.size()) return R::Err(Error{Error::InvalidInstances, "job sizes do not add up to the proofs"});
+    dk.handle();  // G2 line tables: per-key setup, not per-proof work
+    auto per_proof = succinct_verify_all(dk.svk, pr, instances, proofs, threads, tm);
+    if (!per_proof.ok()) return R::Err(per_proof.err);
+    auto t3 = clk::now();
+    // per job: the accumulation transcript and the pair lists of `KzgAs::verify` (host), independent across jobs
+    const size_t J = sizes.size();
+    std::vector<size_t> first(J + 1, 0);
+    for (size_t k = 0; k < J; ++k) first[k + 1] = first[k] + sizes[k];
+    std::vector<std::vector<KzgAccumulator>> accs(J);
+    std::vector<std::vector<std::pair<Fr, G1Affine>>> two(2 * J);
+    std::vector<Error> errs(J);
+    parallel_for(J, threads, [&](size_t k) {
+      for (size_t i = first[k]; i < first[k + 1]; ++i)
+        accs[k].insert(accs[k].end(), (*per_proof.value)[i].begin(), (*per_proof.value)[i].end());
+      EvmTranscript at;
+      auto pf = KzgAs<MOS>::read_proof(KzgAsVerifyingKey{}, accs[k], at);  // absorbs the accumulators, squeezes r: what create_proof does without a blind
+      if (!pf.ok()) {
+        errs[k] = pf.err;
+        return;
+      }
+      auto pairs = KzgAs<MOS>::verify_pairs(accs[k], *pf.value);
+      two[2 * k] = std::move(pairs.first);
+      two[2 * k + 1] = std::move(pairs.second);
+    }, 1);
+    for (auto& e : errs)
+      if (!e.ok()) return R::Err(e);
+    auto pts = L::multi_scalar_multiplication_batch(two);
+    auto t4 = clk::now();
+    ManyResult out;
+    out.ok.resize(J);
+    std::vector<uint8_t> bytes(128 * J);
+    for (size_t k = 0; k < J; ++k) {
+      out.accs.push_back(KzgAccumulator{pts[2 * k], pts[2 * k + 1]});
+      out.accs.back().to_bytes(&bytes[128 * k]);
+    }
+    {
+      snarkv_dk* h = dk.handle();
+      std::lock_guard<std::mutex> lock(device_mutex());
+      int rc = bn254_kzg_dk_decide_batch(h, bytes.data(), J, out.ok.data());
+      if (rc < 0) throw std::runtime_error(std::string("bn254_kzg_dk_decide_batch: ") + snarkv_last_error());
+    }
+    if (tm) {
+      tm->accumulate = ms(t3, t4);
+      tm->decide = ms(t4, clk::now());
+      tm->total += tm->accumulate + tm->decide;
+    }
+    return R::Ok(std::move(out));
   }
 
   // ... and decide it: Ok(()) / Err(AssertionFailure), as `PlonkVerifier::verify` + `decide`

@@ -150,6 +150,55 @@ int aggregate_run(const PlonkProtocol& pr, const KzgDecidingKey& dk, const std::
   return e.ok() ? 1 : error_code(e);
 }
 
+template <class MOS, class TR>
+int aggregate_many_run(const PlonkProtocol& pr, const KzgDecidingKey& dk, const std::vector<std::vector<std::vector<Fr>>>& insts,
+                       const std::vector<std::vector<uint8_t>>& proofs, const std::vector<uint32_t>& sizes, unsigned threads,
+                       double* timings_ms, uint8_t* accs_out, uint8_t* ok_out) {
+  AggregationTimings tm;
+  auto r = Aggregator<MOS, TR>::aggregate_and_decide_many(dk, pr, insts, proofs, sizes, threads, &tm);
+  if (!r.ok()) return error_code(r.err);
+  if (timings_ms) {
+    timings_ms[0] = tm.read_proofs;
+    timings_ms[1] = tm.fr_algebra;
+    timings_ms[2] = tm.msm_device;
+    timings_ms[3] = tm.accumulate;
+    timings_ms[4] = tm.decide;
+    timings_ms[5] = tm.total;
+  }
+  int all = 1;
+  for (size_t k = 0; k < sizes.size(); ++k) {
+    if (accs_out) r.value->accs[k].to_bytes(accs_out + 128 * k);
+    if (ok_out) ok_out[k] = r.value->ok[k];
+    if (!r.value->ok[k]) all = 0;
+  }
+  return all;
+}
+
+template <class MOS>
+int aggregate_many_mos(const PlonkProtocol& pr, const KzgDecidingKey& dk, int transcript, const uint8_t* instances, size_t ilen,
+                       const uint8_t* proofs, size_t prlen, const uint32_t* job_sizes, uint32_t n_jobs, unsigned threads,
+                       double* timings_ms, uint8_t* accs_out, uint8_t* ok_out) {
+  std::vector<uint32_t> sizes(job_sizes, job_sizes + n_jobs);
+  uint64_t n = 0;
+  for (uint32_t k : sizes) n += k;
+  if (n == 0 || n > 0xFFFFFFFFull) return arg_error("job sizes");
+  std::vector<std::vector<std::vector<Fr>>> insts;
+  std::vector<std::vector<uint8_t>> pbytes;
+  wire::split_batch(instances, ilen, proofs, prlen, (uint32_t)n, insts, pbytes);
+  if (threads == 0) threads = HostPool::get().size();
+  if (transcript == SNARKV_HOST_TRANSCRIPT_POSEIDON_AUTO)
+    transcript = n >= SNARKV_HOST_POSEIDON_DEVICE_MIN ? SNARKV_HOST_TRANSCRIPT_POSEIDON_DEVICE : SNARKV_HOST_TRANSCRIPT_POSEIDON;
+  switch (transcript) {
+    case SNARKV_HOST_TRANSCRIPT_EVM:
+      return aggregate_many_run<MOS, EvmTranscript>(pr, dk, insts, pbytes, sizes, threads, timings_ms, accs_out, ok_out);
+    case SNARKV_HOST_TRANSCRIPT_POSEIDON:
+      return aggregate_many_run<MOS, PoseidonTranscript>(pr, dk, insts, pbytes, sizes, threads, timings_ms, accs_out, ok_out);
+    case SNARKV_HOST_TRANSCRIPT_POSEIDON_DEVICE:
+      return aggregate_many_run<MOS, PoseidonTranscriptOnDevice>(pr, dk, insts, pbytes, sizes, threads, timings_ms, accs_out, ok_out);
+    default: return arg_error("unknown transcript kind");
+  }
+}
+
 template <class MOS>
 int aggregate_mos(const PlonkProtocol& pr, const KzgDecidingKey& dk, int transcript, const uint8_t* instances, size_t ilen,
                   const uint8_t* proofs, size_t prlen, uint32_t n, unsigned threads, double* timings_ms, uint8_t* acc_out) {
@@ -404,6 +453,22 @@ int snarkv_host_aggregate(const snarkv_host_protocol* protocol, const snarkv_hos
       return aggregate_mos<Gwc19>(protocol->pr, dk->dk, transcript, instances, instances_len, proofs, proofs_len, n, host_threads, timings_ms, acc_out);
     if (mos == SNARKV_HOST_MOS_BDFG21)
       return aggregate_mos<Bdfg21>(protocol->pr, dk->dk, transcript, instances, instances_len, proofs, proofs_len, n, host_threads, timings_ms, acc_out);
+    return arg_error("unknown multi-open scheme");
+  });
+}
+
+int snarkv_host_aggregate_many(const snarkv_host_protocol* protocol, const snarkv_host_dk* dk, int mos, int transcript,
+                               const uint8_t* instances, size_t instances_len, const uint8_t* proofs, size_t proofs_len,
+                               const uint32_t* job_sizes, uint32_t n_jobs, unsigned host_threads, double* timings_ms,
+                               uint8_t* accs_out, uint8_t* ok_out) {
+  if (!protocol || !dk || !instances || !proofs || !job_sizes || n_jobs == 0) return arg_error("null argument");
+  return guarded([&] {
+    if (mos == SNARKV_HOST_MOS_GWC19)
+      return aggregate_many_mos<Gwc19>(protocol->pr, dk->dk, transcript, instances, instances_len, proofs, proofs_len, job_sizes,
+                                       n_jobs, host_threads, timings_ms, accs_out, ok_out);
+    if (mos == SNARKV_HOST_MOS_BDFG21)
+      return aggregate_many_mos<Bdfg21>(protocol->pr, dk->dk, transcript, instances, instances_len, proofs, proofs_len, job_sizes,
+                                        n_jobs, host_threads, timings_ms, accs_out, ok_out);
     return arg_error("unknown multi-open scheme");
   });
 }

@@ -176,6 +176,22 @@ struct KzgAs {
   // The two `evaluate(None)` go to the device as ONE segmented launch.
   static Result<KzgAccumulator> verify(const KzgAsVerifyingKey&, const std::vector<KzgAccumulator>& instances,
                                        const KzgAsProof& proof) {
+    auto pairs = verify_pairs(instances, proof);
+    std::vector<std::vector<std::pair<Fr, G1Affine>>> two;
+    two.push_back(std::move(pairs.first));
+    two.push_back(std::move(pairs.second));
+    const bool trace = getenv("SNARKV_HOST_TRACE") != nullptr;  // dev aid: host / device split of this step on stderr
+    auto t0 = std::chrono::steady_clock::now();
+    auto pts = L::multi_scalar_multiplication_batch(two);
+    if (trace)
+      fprintf(stderr, "KzgAs::verify: %zu + %zu terms, device call %.3f ms\n", two[0].size(), two[1].size(),
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return Result<KzgAccumulator>::Ok(KzgAccumulator{pts[0], pts[1]});
+  }
+  // the host half of `verify`: the (scalar, base) lists of its two MSMs  sum r^i lhs_i ,  sum r^i rhs_i  (blind pair last),
+  // for callers that put the MSMs of SEVERAL accumulation steps into one launch (aggregation.hpp)
+  static std::pair<std::vector<std::pair<Fr, G1Affine>>, std::vector<std::pair<Fr, G1Affine>>> verify_pairs(
+      const std::vector<KzgAccumulator>& instances, const KzgAsProof& proof) {
     std::vector<const G1Affine*> lhs, rhs;
     for (auto& a : instances) {
       lhs.push_back(&a.lhs);
@@ -195,13 +211,7 @@ struct KzgAs {
       for (size_t i = 0; i < bases->size(); ++i) m.push(powers_of_r[i], (*bases)[i]);
       two.push_back(m.pairs(std::nullopt));
     }
-    const bool trace = getenv("SNARKV_HOST_TRACE") != nullptr;  // dev aid: host / device split of this step on stderr
-    auto t0 = std::chrono::steady_clock::now();
-    auto pts = L::multi_scalar_multiplication_batch(two);
-    if (trace)
-      fprintf(stderr, "KzgAs::verify: %zu + %zu terms, device call %.3f ms\n", two[0].size(), two[1].size(),
-              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    return Result<KzgAccumulator>::Ok(KzgAccumulator{pts[0], pts[1]});
+    return {std::move(two[0]), std::move(two[1])};
   }
 
   // accumulation.rs:148-197 (prover side; identical arithmetic).  `blind_scalar`

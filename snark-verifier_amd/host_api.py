@@ -41,6 +41,8 @@ _SIGNATURES = {
     "snarkv_host_kzg_decide_all": (_int, [_vp, _cp, _u32, _vp]),
     "snarkv_host_aggregate": (_int, [_vp, _vp, _int, _int, _cp, _sz, _cp, _sz, _u32, ctypes.c_uint,
                                      ctypes.POINTER(ctypes.c_double), _vp]),
+    "snarkv_host_aggregate_many": (_int, [_vp, _vp, _int, _int, _cp, _sz, _cp, _sz, ctypes.POINTER(ctypes.c_uint32), _u32,
+                                          ctypes.c_uint, ctypes.POINTER(ctypes.c_double), _vp, _vp]),
     "snarkv_host_plonk_verify": (_int, [_vp, _vp, _int, _int, _cp, _sz, _cp, _sz, _u32]),
     "snarkv_host_accumulator_to_limbs": (_int, [_cp, _vp]),
     "snarkv_host_accumulator_from_limbs": (_int, [_cp, _vp]),
@@ -245,6 +247,25 @@ def aggregate(protocol, dk, instances, proofs, n, mos=MOS_GWC19, transcript=TRAN
         names = ("read_proofs", "fr_algebra", "msm_device", "accumulate", "decide", "total")
         return rc == 1, acc.raw, dict(zip(names, list(tm)))
     return rc == 1, acc.raw
+
+
+def aggregate_many(protocol, dk, instances, proofs, job_sizes, mos=MOS_GWC19, transcript=TRANSCRIPT_EVM, host_threads=0,
+                   timings=False):
+    """several aggregation jobs in one call (`snarkv_host_aggregate_many`): `job_sizes[k]` consecutive proofs of the blobs
+    are job k -> (every job accepted, [accumulator 128 B per job], [verdict per job][, timings dict])"""
+    L = load_library()
+    tm = (ctypes.c_double * 6)()
+    J = len(job_sizes)
+    sizes = (ctypes.c_uint32 * J)(*job_sizes)
+    accs = ctypes.create_string_buffer(128 * J)
+    ok = ctypes.create_string_buffer(J)
+    rc = _check(L.snarkv_host_aggregate_many(protocol._h, dk._h, mos, transcript, instances, len(instances), proofs, len(proofs),
+                                             sizes, J, host_threads, tm, accs, ok))
+    out = (rc == 1, [accs.raw[128 * k:128 * k + 128] for k in range(J)], [b != 0 for b in ok.raw[:J]])
+    if timings:
+        names = ("read_proofs", "fr_algebra", "msm_device", "accumulate", "decide", "total")
+        return out + (dict(zip(names, list(tm))),)
+    return out
 
 
 def plonk_verify(protocol, dk, instances, proofs, n, mos=MOS_GWC19, transcript=TRANSCRIPT_EVM):

@@ -417,3 +417,69 @@ def test_concurrent_aggregations_from_host_threads():
     for _, hp, hdk, _ in jobs:
         hp.close()
         hdk.close()
+
+
+def test_aggregate_many_equals_one_call_per_job():
+    """`snarkv_host_aggregate_many`: several jobs sharing their three device launches give, per job, the accumulator and
+    the verdict of `snarkv_host_aggregate` on that job's proofs -- for ragged job sizes, both Keccak and Poseidon
+    transcripts, and with one job made to fail its pairing check (a proof swapped for another job's valid one changes
+    nothing; a tampered evaluation does)."""
+    import struct
+
+    from snark_verifier_amd import host_api as HA
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    for name, kind in (("bench_plonk_gwc19_evm_64.bin", HA.TRANSCRIPT_EVM),
+                       ("bench_plonk_gwc19_poseidon_64.bin", HA.TRANSCRIPT_POSEIDON_DEVICE),
+                       ("bench_plonk_gwc19_poseidon_64.bin", HA.TRANSCRIPT_POSEIDON)):
+        fx = HA.read_fixture(os.path.join(root, name))
+        hp, hdk = HA.Protocol(fx["protocol"]), HA.DecidingKey(fx["dk"])
+        # split the blobs per proof
+        pblob, iblob = fx["proofs"], fx["instances"]
+        proofs, off = [], 0
+        for _ in range(fx["n"]):
+            ln, = struct.unpack_from("<I", pblob, off)
+            proofs.append(pblob[off:off + 4 + ln])
+            off += 4 + ln
+        insts, off = [], 0
+        for _ in range(fx["n"]):
+            start = off
+            cols, = struct.unpack_from("<I", iblob, off)
+            off += 4
+            for _c in range(cols):
+                m, = struct.unpack_from("<I", iblob, off)
+                off += 4 + 32 * m
+            insts.append(iblob[start:off])
+        assert off == len(iblob)
+        sizes = [5, 1, 30, 28]
+        assert sum(sizes) == fx["n"]
+        # tamper one scalar of a proof of job 2 (the last 32 bytes of a Gwc19 proof are an opening point or scalar:
+        # flip a byte in the middle of the proof instead, inside the evaluations)
+        bad = bytearray(proofs[10])
+        bad[4 + len(bad) // 2] ^= 1
+        variants = {"clean": list(proofs), "tampered": proofs[:10] + [bytes(bad)] + proofs[11:]}
+        for label, plist in variants.items():
+            want, first = [], 0
+            for k in sizes:
+                try:
+                    ok, acc = HA.aggregate(hp, hdk, b"".join(insts[first:first + k]), b"".join(plist[first:first + k]), k,
+                                           HA.MOS_GWC19, kind, 8)
+                    want.append((ok, acc))
+                except HA.HostError as e:
+                    want.append(("err", str(e)))
+                first += k
+            if any(w[0] == "err" for w in want):  # a malformed proof fails the whole call, as it fails its own job
+                with pytest.raises(HA.HostError):
+                    HA.aggregate_many(hp, hdk, b"".join(insts), b"".join(plist), sizes, HA.MOS_GWC19, kind, 8)
+                continue
+            allok, accs, oks = HA.aggregate_many(hp, hdk, b"".join(insts), b"".join(plist), sizes, HA.MOS_GWC19, kind, 8)
+            assert oks == [w[0] for w in want], (name, label)
+            assert accs == [w[1] for w in want], (name, label)
+            assert allok == all(oks)
+            if label == "clean":
+                assert allok
+        # the sizes must add up
+        with pytest.raises(HA.HostError):
+            HA.aggregate_many(hp, hdk, b"".join(insts), b"".join(proofs), [5, 1, 30, 0, 28], HA.MOS_GWC19, kind, 8)
+        hp.close()
+        hdk.close()
