@@ -160,6 +160,35 @@ def secondary_metrics(sv, torch, ctxs, cpu=True):
                 "includes_decide": True, "jobs_in_flight": len(ctxs), "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "results_identical": same,
                 "roofline": aggregate_roofline(nproofs, ms)}
+        # ... and AGG_JOBS_IN_FLIGHT jobs MERGED into one set of launches (what snarkv_host_aggregate_many does with the
+        # jobs of one call): one segmented launch for every proof's MSMs, one for the 2 J KzgAs MSMs, one decide_batch(J)
+        J = AGG_JOBS_IN_FLIGHT
+        offs_m = [0]
+        for _ in range(nproofs * J):
+            offs_m += [offs_m[-1] + 21, offs_m[-1] + 24]
+        offs2_m = [k * (nproofs + 1) for k in range(2 * J + 1)]
+        n1m, n2m = offs_m[-1], offs2_m[-1]
+        dsm = torch.empty(32 * max(n1m, n2m), dtype=torch.uint8, device="cuda")
+        dpm = torch.empty(64 * max(n1m, n2m), dtype=torch.uint8, device="cuda")
+        ctx.sample_scalars_dev(0x5EED0003, max(n1m, n2m), dsm.data_ptr())
+        ctx.sample_points_dev(0x5EED0004, max(n1m, n2m), dpm.data_ptr())
+        o1m = torch.tensor(offs_m, dtype=torch.int32, device="cuda")
+        o2m = torch.tensor(offs2_m, dtype=torch.int32, device="cuda")
+        out1m = torch.zeros(64 * (len(offs_m) - 1), dtype=torch.uint8, device="cuda")
+        accm = torch.zeros(128 * J, dtype=torch.uint8, device="cuda")
+        okm = torch.zeros(J, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+
+        def merged():
+            ctx.msm_batched_dev(dsm.data_ptr(), dpm.data_ptr(), o1m.data_ptr(), len(offs_m) - 1, n1m, out1m.data_ptr())
+            ctx.msm_batched_dev(dsm.data_ptr(), dpm.data_ptr(), o2m.data_ptr(), 2 * J, n2m, accm.data_ptr())
+            ctx.decide_batch_dev(dk, accm.data_ptr(), J, okm.data_ptr())
+
+        ms = min(t_ms(merged, reps=2, warm=1) for _ in range(3)) / J
+        out["aggregate_%d_proofs_merged" % nproofs] = {
+            "ms_per_job": ms, "proofs_per_s": nproofs / ms * 1e3, "msm_terms": (n1m + n2m) // J, "includes_decide": True,
+            "jobs_merged": J, "launch_sets": 1, "roofline": aggregate_roofline(nproofs, ms)}
+        del dsm, dpm, out1m
         if cpu:  # 64 proofs ~0.15 s, 1 024 proofs ~2.5 s of one host thread
             out["aggregate_%d_proofs" % nproofs]["cpu_baseline"] = cpu_baseline_aggregate(ds, dp, offs, n1, nproofs, n2)
     one = torch.frombuffer(bytearray((g1 + g1) * 1024), dtype=torch.uint8).cuda()
