@@ -150,6 +150,9 @@ def secondary_metrics(sv, torch, ctxs, cpu=True):
                                                  "jobs_in_flight": 1,
                                                  "roofline": aggregate_roofline(nproofs, ms)}
         if len(ctxs) > 1:
+            for c in ctxs:  # other launches are in flight next to each context's: the library's throughput hint (the
+                c.set_throughput_hint(True)  # joint fixed-window form above 16 384 terms: less work, a longer chain)
+
             def wave():
                 for k in range(len(ctxs)):
                     job(k)
@@ -160,6 +163,8 @@ def secondary_metrics(sv, torch, ctxs, cpu=True):
                 "includes_decide": True, "jobs_in_flight": len(ctxs), "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "results_identical": same,
                 "roofline": aggregate_roofline(nproofs, ms)}
+            for c in ctxs:
+                c.set_throughput_hint(False)
         # ... and AGG_JOBS_IN_FLIGHT jobs MERGED into one set of launches (what snarkv_host_aggregate_many does with the
         # jobs of one call): one segmented launch for every proof's MSMs, one for the 2 J KzgAs MSMs, one decide_batch(J)
         J = AGG_JOBS_IN_FLIGHT

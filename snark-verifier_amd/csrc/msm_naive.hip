@@ -189,6 +189,129 @@ __global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES) k_term_scalar_mul(cons
   out[g] = r;
 }
 
+// K1 for LARGE launches: one lane per TERM, both GLV halves in one chain (Straus): k P = k1 P + k2 phi(P) shares the
+// doublings of its two 127-step ladders -- 129 doublings + 2 x 43 additions (~2 400 products) instead of
+// 2 x (129 + 43) (~3 600) per term, a third less issued work, on a chain a third longer.  Worth it only where the
+// launch is throughput-bound (tens of thousands of terms, or several launches in flight: the context's throughput
+// hint); a single 1 024-proof job keeps the two-lane form, whose 0.8 ms is a latency.
+//   table    2P, 3P, 4P as in half_scalar_mul_w3, plus beta X of each: phi(a P) = (beta X, Y, ZZ, ZZZ)
+//   digits   two signed 3-bit streams (LDS bytes), the signs of the halves folded into the digits' signs
+// A fast addition meets P = +-Q only if  u + v lambda = +-d (mod r)  for the prefixes u, v of the two halves and a digit
+// d: with v = 0 this is the one-chain case (`started`), otherwise (u -+ d, v) would be a non-zero vector of the GLV lattice
+// with both coordinates below 2^127 -- possible for crafted scalars at best; the degenerate flag + the careful redo of
+// both halves is the net, as above.  Output: the term's partial in slot 2 t, the identity in slot 2 t + 1 (K2 unchanged).
+__global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES) k_term_scalar_mul_joint(const uint32_t* __restrict__ scalars,
+                                                                                   const uint32_t* __restrict__ points,
+                                                                                   G1Xyzz29* __restrict__ out, uint32_t n_terms,
+                                                                                   int32_t* __restrict__ tabg) {
+  __shared__ int8_t dig[2][kWinDigits][64];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x;
+  if (t >= n_terms) return;
+  uint32_t k[8], pw[16], halves[8];
+  load_words16(scalars + (size_t)t * 8, k, 2);
+  load_words16(points + (size_t)t * 16, pw, 4);
+  glv_decompose(k, halves);
+  const G1Affine29 q = g1a29_from_canonical(pw);
+  uint32_t mag[2][4];
+  uint32_t neg[2], any = 0;
+  for (int h = 0; h < 2; ++h) {
+    for (int j = 0; j < 4; ++j) mag[h][j] = halves[4 * h + j];
+    neg[h] = mag[h][3] >> 31;
+    mag[h][3] &= 0x7FFFFFFFu;
+    any |= mag[h][0] | mag[h][1] | mag[h][2] | mag[h][3];
+  }
+  out[2 * (size_t)t + 1] = xyzz29_identity();
+  if (g1a29_is_identity(q) || any == 0) {
+    out[2 * (size_t)t] = xyzz29_identity();
+    return;
+  }
+  constexpr int32_t bl[9] = SNARKV_GLV_BETA29_LIMBS;
+  Fq29 beta;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) beta.v[j] = bl[j];
+  // this wavefront's slice of the scratch: [entry 0..2][limb 0..44][lane]: X, Y, ZZ, ZZZ, beta X
+  int32_t(*tab)[45][64] = reinterpret_cast<int32_t(*)[45][64]>(tabg + (size_t)blockIdx.x * 3 * 45 * 64);
+  {
+    G1Xyzz29 t2 = xyzz29_double_affine(q), t3 = t2;
+    xyzz29_madd_fast(t3, q);
+    G1Xyzz29 t4 = xyzz29_double(t2);
+    auto put = [&](int e, const G1Xyzz29& v) {
+      const Fq29 bx = fq29_mul(v.x, beta);
+#pragma unroll
+      for (int l = 0; l < 9; ++l) {
+        tab[e][l][lane] = v.x.v[l];
+        tab[e][9 + l][lane] = v.y.v[l];
+        tab[e][18 + l][lane] = v.zz.v[l];
+        tab[e][27 + l][lane] = v.zzz.v[l];
+        tab[e][36 + l][lane] = bx.v[l];
+      }
+    };
+    put(0, t2);
+    put(1, t3);
+    put(2, t4);
+  }
+  const Fq29 qbx = fq29_mul(q.x, beta);  // x of phi(P)
+  for (int h = 0; h < 2; ++h) {
+    uint32_t carry = 0;
+    for (int i = 0; i < kWinDigits; ++i) {
+      const int bit = 3 * i, word = bit >> 5, sh = bit & 31;
+      uint32_t w0 = word == 0 ? mag[h][0] : word == 1 ? mag[h][1] : word == 2 ? mag[h][2] : word == 3 ? mag[h][3] : 0u;
+      uint32_t w1 = word == 0 ? mag[h][1] : word == 1 ? mag[h][2] : word == 2 ? mag[h][3] : 0u;
+      uint32_t raw = (uint32_t)((((uint64_t)w1 << 32) | w0) >> sh) & 7u;
+      raw += carry;
+      carry = raw > 4u ? 1u : 0u;
+      int d = (int)raw - (carry ? 8 : 0);
+      dig[h][i][lane] = (int8_t)(neg[h] ? -d : d);  // the half's sign folded in
+    }
+  }
+  G1Xyzz29 acc = xyzz29_identity();
+  bool started = false;
+#pragma unroll 1
+  for (int i = kWinDigits - 1; i >= 0; --i) {
+    acc = xyzz29_double(xyzz29_double(xyzz29_double(acc)));  // 8 acc (all-zero stays all-zero)
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      const int d = dig[h][i][lane];
+      const int a = d < 0 ? -d : d;
+      if (a != 0) {
+        G1Xyzz29 sel;
+        if (a == 1) {
+          sel = xyzz29_from_affine(q);
+          if (h) sel.x = qbx;
+        } else {
+          const int xo = h ? 36 : 0;
+#pragma unroll
+          for (int l = 0; l < 9; ++l) {
+            sel.x.v[l] = tab[a - 2][xo + l][lane];
+            sel.y.v[l] = tab[a - 2][9 + l][lane];
+            sel.zz.v[l] = tab[a - 2][18 + l][lane];
+            sel.zzz.v[l] = tab[a - 2][27 + l][lane];
+          }
+        }
+        if (d < 0) sel.y = fq29_neg(sel.y);
+        G1Xyzz29 sum = acc;
+        xyzz29_add_fast(sum, sel);
+        acc = started ? sum : sel;
+        started = true;
+      }
+    }
+  }
+  if (xyzz29_is_degenerate(acc)) {  // an exceptional addition on the way (or a true identity): both halves, carefully
+    G1Affine29 q1 = q, q2 = q;
+    q2.x = fq29_canon_residue(qbx);
+    if (neg[0]) q1.y = fq29_neg(q1.y);
+    if (neg[1]) q2.y = fq29_neg(q2.y);
+    G1Xyzz29 r1 = half_scalar_mul<true>(q1, mag[0]);
+    if (!xyzz29_is_identity(r1) && xyzz29_is_degenerate(r1)) r1 = xyzz29_identity();
+    G1Xyzz29 r2 = half_scalar_mul<true>(q2, mag[1]);
+    if (!xyzz29_is_identity(r2) && xyzz29_is_degenerate(r2)) r2 = xyzz29_identity();
+    out[2 * (size_t)t] = r1;
+    out[2 * (size_t)t + 1] = r2;  // the fold adds them with the careful adder
+    return;
+  }
+  out[2 * (size_t)t] = acc;
+}
+
 // ---- chunked form of K1 for SMALL batches (the machine is far from full) ----
 // A 127-step chain per lane leaves >90 % of the SIMDs idle when a job has a
 // few thousand terms.  Split every half-scalar into J chunks of 128/J bits:
@@ -432,11 +555,22 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
   SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_PARTIALS, 2 * n_terms * sizeof(G1Xyzz29), &d_terms));
   const uint32_t J = chunks_for(n_terms);
   if (J == 1) {
-    uint32_t blocks = (uint32_t)((2 * n_terms + 63) / 64);
-    void* d_tab = nullptr;  // the fixed-window tables: 3 XYZZ points per lane
-    SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_CHAIN, (size_t)blocks * 3 * 36 * 64 * 4, &d_tab));
-    hipLaunchKernelGGL(k_term_scalar_mul, dim3(blocks), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,
-                       (const uint32_t*)d_points, (G1Xyzz29*)d_terms, (uint32_t)n_terms, (int32_t*)d_tab);
+    // throughput-bound launches (tens of thousands of terms, or other launches in flight next to this context's: its
+    // throughput hint) take the one-lane-per-term joint form: a third less issued work on a third longer chain
+    const char* ej = getenv("SNARKV_NAIVE_JOINT");  // 0 / 1: force (test / A-B knob)
+    const bool joint = ej ? atoi(ej) != 0 : (n_terms >= 49152 || ctx->throughput_mode);
+    void* d_tab = nullptr;  // the fixed-window tables: 3 XYZZ points (+ beta X in the joint form) per lane
+    if (joint) {
+      uint32_t blocks = (uint32_t)((n_terms + 63) / 64);
+      SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_CHAIN, (size_t)blocks * 3 * 45 * 64 * 4, &d_tab));
+      hipLaunchKernelGGL(k_term_scalar_mul_joint, dim3(blocks), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,
+                         (const uint32_t*)d_points, (G1Xyzz29*)d_terms, (uint32_t)n_terms, (int32_t*)d_tab);
+    } else {
+      uint32_t blocks = (uint32_t)((2 * n_terms + 63) / 64);
+      SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_CHAIN, (size_t)blocks * 3 * 36 * 64 * 4, &d_tab));
+      hipLaunchKernelGGL(k_term_scalar_mul, dim3(blocks), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,
+                         (const uint32_t*)d_points, (G1Xyzz29*)d_terms, (uint32_t)n_terms, (int32_t*)d_tab);
+    }
   } else {
     void* d_chain = nullptr;
     void* d_mags = nullptr;

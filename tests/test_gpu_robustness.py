@@ -326,3 +326,41 @@ def test_inputs_in_pinned_host_buffers(gpu_ctx):
 
     with pytest.raises(sv.SnarkvError):
         gpu_ctx.host_buffer(sv.SNARKV_HOST_BUFFERS, 16)
+
+
+def test_joint_fixed_window_form_of_large_segmented_launches(gpu_ctx):
+    """Above 16 384 terms a segmented launch multiplies with the fixed-window kernel; with the context's throughput hint
+    (or from 49 152 terms) it takes the JOINT form -- one lane per term, both GLV halves on shared doublings
+    (k_term_scalar_mul_joint).  Ragged segments, scalars that stress the two digit streams (0, 1, r - 1, lambda and small
+    combinations a + b lambda whose halves are tiny, 2^k, all-ones), repeated and opposite points, identities."""
+    rng = random.Random(77)
+    n = 20000
+    s = bytearray(C.sample_scalars(81, n))
+    p = bytearray(C.sample_points(82, n))
+    lam = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd  # a cube root of unity mod r (glv.h)
+    assert pow(lam, 3, O.R) == 1 and lam != 1
+    special = [0, 1, 2, 7, 8, 9, O.R - 1, O.R - 2, lam, (lam * lam) % O.R, (1 + lam) % O.R, (3 + 4 * lam) % O.R,
+               (O.R - 5 * lam) % O.R, (8 * lam + 1) % O.R, (1 << 126) % O.R, (1 << 127) % O.R, (1 << 253) % O.R, (1 << 254) - 1 - O.R]
+    special += [(1 << k) for k in range(0, 250, 17)]
+    for i, v in enumerate(special):
+        s[32 * (100 + i):32 * (101 + i)] = (v % O.R).to_bytes(32, "little")
+    # repeated / opposite points inside one segment, and identities
+    for i in range(40):
+        p[64 * (300 + i):64 * (301 + i)] = p[64 * 300:64 * 301]
+    x = int.from_bytes(p[64 * 350:64 * 350 + 32], "little")
+    y = int.from_bytes(p[64 * 350 + 32:64 * 351], "little")
+    p[64 * 351:64 * 352] = x.to_bytes(32, "little") + (O.P - y).to_bytes(32, "little")
+    s[32 * 351:32 * 352] = s[32 * 350:32 * 351]  # k P + k (-P) = O
+    for i in (400, 401, 777):
+        p[64 * i:64 * (i + 1)] = bytes(64)
+    cuts = sorted(rng.sample(range(1, n), 900))
+    offs = [0] + cuts + [n]
+    offs = [o for o in offs if not (349 < o <= 351)]  # keep the opposite pair in one segment
+    want = C.msm_batched(bytes(s), bytes(p), offs)
+    gpu_ctx.set_throughput_hint(True)
+    try:
+        got = gpu_ctx.msm_batched(bytes(s), bytes(p), offs)
+    finally:
+        gpu_ctx.set_throughput_hint(False)
+    assert got == want
+    assert gpu_ctx.msm_batched(bytes(s), bytes(p), offs) == want  # and the two-lane form on the same input
