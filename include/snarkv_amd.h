@@ -320,9 +320,6 @@ int snarkv_kzg_decide_batch_mgpu(snarkv_mgpu* mg, const uint8_t g1_64[64], const
  * the sorted stream into longer runs per lane -- less total work per MSM (-3.5 % at 2^20 with 4 in flight) at the price of a
  * longer single-MSM latency (+4 %), because one MSM alone no longer fills every wave slot.  Same bytes either way. */
 int snarkv_ctx_set_throughput_hint(snarkv_ctx* ctx, int enabled);
-/* diagnostics: how many times a batch call on this context was served by launching its captured hipGraph
- * (SNARKV_MANY_GRAPH=1; csrc/capi.hip launch_msm_pippenger_many) instead of enqueueing its kernels one by one */
-long long snarkv_ctx_graph_replays(const snarkv_ctx* ctx);
 /* points ONE launch of the Pippenger kernels processes for an n-point MSM: n itself, or the 2^20-point chunk of the
  * chunk pipeline large MSMs run as (csrc/capi.hip pippenger_maybe_split) -- what a per-launch roofline divides by */
 int snarkv_g1_msm_launch_points(size_t n, size_t* per_launch);

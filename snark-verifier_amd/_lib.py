@@ -85,7 +85,6 @@ _SIGNATURES = {
     "snarkv_ctx_set_throughput_hint": (_int, [_vp, _int]),
     "snarkv_g1_msm_launch_points": (_int, [_sz, ctypes.POINTER(_sz)]),
     "snarkv_g1_msm_launch_points_ex": (_int, [_sz, _int, ctypes.POINTER(_sz)]),
-    "snarkv_ctx_graph_replays": (ctypes.c_longlong, [_vp]),
     "snarkv_mgpu_create": (_int, [ctypes.POINTER(_int), _int, _pp]),
     "snarkv_mgpu_destroy": (None, [_vp]),
     "snarkv_mgpu_size": (_int, [_vp]),
@@ -452,10 +451,6 @@ class Context:
     # ---- device-pointer entry points (ints from tensor.data_ptr()) ----
     def msm_pippenger_dev(self, d_scalars, d_points, n, d_out, window_bits=0):
         _check(self._lib.snarkv_g1_msm_pippenger_dev(self._h, d_scalars, d_points, n, window_bits, d_out))
-
-    def graph_replays(self):
-        """batch calls served by launching the captured hipGraph (SNARKV_MANY_GRAPH=1)"""
-        return int(self._lib.snarkv_ctx_graph_replays(self._h))
 
     def msm_pippenger_many_dev(self, d_scalars, d_points, counts, d_out, window_bits=0):
         """`len(counts)` independent MSMs in one phase-ordered call: d_out[64 i ..] = MSM i (device pointers as ints)."""

@@ -15,11 +15,10 @@ namespace snarkv {
 // THE decision "does an n-point MSM run as the chunk pipeline over shared bucket grids?" -- one rule for the single
 // call (launch_msm_pippenger_auto), the batch (launch_msm_pippenger_many hands such jobs to the single call) and
 // snarkv_g1_msm_launch_points (what bench.py divides its per-launch roofline by).  *chunk = points per chunk.
-//   SNARKV_PIP_SPLIT   0 never, 1 (default) from three chunks, 2 from two     SNARKV_SPLIT_LOG2   chunk size (tuning)
+//   SNARKV_PIP_SPLIT   0 never, 1 (default) from three chunks, 2 from two
 // An explicit window size or a lane context (a worker of a pipeline already) keeps the single launch.
 bool pip_chunk_pipeline(size_t n, int window_bits, bool is_lane, size_t* chunk) {
-  size_t c = (size_t)1 << 20;
-  if (const char* cl = getenv("SNARKV_SPLIT_LOG2")) c = (size_t)1 << std::max(16, std::min(23, atoi(cl)));
+  const size_t c = (size_t)1 << 20;  // chunk size: the 2^20-point MSM's window geometry, point table inside the Infinity Cache
   const char* e = getenv("SNARKV_PIP_SPLIT");
   const int mode = e ? atoi(e) : 1;
   const size_t min_chunks = mode == 2 ? 2 : 3;
@@ -40,10 +39,10 @@ static int fetch_out(snarkv_ctx* ctx, const void* d, void* host, size_t bytes) {
 }
 
 // HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams sharing a queue serialise.
-// The batch scheduler uses five streams and a server keeps many latency-bound aggregation jobs in flight on contexts of
-// their own (16 queues: 2.5x the proofs/s of 64-proof jobs, profiles/r03_agg_hw_queues.txt).  The runtime reads the
-// variable at its first call: this runs when the library is loaded and never overrides the caller's own setting.
-__attribute__((constructor)) static void snarkv_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// A server that keeps many latency-bound aggregation jobs in flight on contexts of their own wants 16 (2.5x the proofs/s
+// of 64-proof jobs, profiles/r03_agg_hw_queues.txt).  That is a process-wide runtime setting read at the runtime's first
+// call, so the library does NOT touch it when it is loaded: the caller exports GPU_MAX_HW_QUEUES=16 before its first HIP
+// call (the Python package does so on import unless the variable is set, INTEGRATION.md shows the Rust line).
 
 static std::mutex g_default_mu;
 static snarkv_ctx* g_default_ctx = nullptr;
@@ -73,8 +72,6 @@ int snarkv_set_stage_timing(snarkv_ctx* ctx, int enabled) {
   ctx->stage_timing = enabled != 0;
   return SNARKV_OK;
 }
-
-long long snarkv_ctx_graph_replays(const snarkv_ctx* ctx) { return ctx ? (long long)ctx->many_graph_launches : -1; }
 
 int snarkv_ctx_set_throughput_hint(snarkv_ctx* ctx, int enabled) {
   if (!ctx) return SNARKV_ERR_ARG;
@@ -238,8 +235,7 @@ int snarkv::launch_msm_pippenger_auto(snarkv_ctx* ctx, const void* d_s, const vo
   uint32_t c = 0, windows = 0, bpw = 0;
   SNARKV_TRY(pip_geometry(kChunk, 0, &c, &windows, &bpw));
   const size_t nb = (size_t)windows * bpw, grid_bytes = nb * SNARKV_G1_PARTIAL_BYTES;
-  int kWorkers = 2;  // 2 vs 3 measured level (2^24: 24.7 vs 25.3 ms); two keep the footprint at ~2 GiB
-  if (const char* wl = getenv("SNARKV_SPLIT_WORKERS")) kWorkers = std::max(1, std::min(3, atoi(wl)));  // tuning knob
+  const int kWorkers = 2;  // 2 vs 3 measured level (2^24: 24.7 vs 25.3 ms); two keep the footprint at ~2 GiB
   void *grid[3], *tmp[3];
   bool started[3] = {false, false, false};
   for (int w = 0; w < kWorkers; ++w) {
@@ -292,94 +288,10 @@ int snarkv::launch_msm_pippenger_auto(snarkv_ctx* ctx, const void* d_s, const vo
 // phase order (all sorts, then all accumulations) measured 6 % slower than this pipeline, tails in groups of 2-10 under
 // the later accumulations level, an occupancy cap on k_accumulate (LDS allocation) 3-9 % slower.
 // Job j's scratch is a private context (ctx->jobs[j]); results are the bytes of the single-MSM entry point.
-static int many_enqueue(snarkv_ctx* ctx, size_t count, const void* const* d_s, const void* const* d_p, const size_t* n,
-                        int window_bits, void* d_out, bool partial_out, bool capturing, bool* single_path);
-#ifndef SNARKV_MANY_TAIL_DEFAULT
-#define SNARKV_MANY_TAIL_DEFAULT 0  // 1: every job's bucket reduce under the batch's accumulations (see many_enqueue)
-#endif
-
-// The batch as a hipGraph.  A K-job batch is ~12 K kernel launches / memsets and ~3 K event operations over five
-// streams; a caller that submits the same batch again (same input / output pointers, sizes and options -- a proving
-// service's steady state, and bench.py's timed step) can replay it as ONE graph launch.  First call of a key: eager (it
-// allocates the scratch); second: captured (hipStreamBeginCapture on the context's stream, the other four streams join
-// through the existing events) and launched; from then on replayed until the key changes or any scratch buffer of the
-// contexts involved is reallocated.  SNARKV_MANY_GRAPH = 0 off (default until measured faster), 1 on.  Stage timing
-// (events read back by the host) and the fall-back paths run eagerly.
-static uint64_t many_scratch_epoch(const snarkv_ctx* ctx) {
-  uint64_t e = ctx->realloc_epoch;
-  for (int i = 0; i < ctx->njobs; ++i) e += ctx->jobs[i]->realloc_epoch;
-  for (int i = 0; i < 3 && ctx->sub_ready; ++i) e += ctx->sub[i]->realloc_epoch;
-  return e;
-}
-
+// (Measured and removed, round 3: the batch captured and replayed as ONE hipGraph -- 1.2 % slower than this eager
+// enqueue, whose host side runs 1.5 ms ahead of a 30 ms batch anyway: profiles/r03_ab_scheduling.txt, git tag exp/many-graph.)
 int snarkv::launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void* const* d_s, const void* const* d_p,
                                       const size_t* n, int window_bits, void* d_out, bool partial_out) {
-  const char* eg = getenv("SNARKV_MANY_GRAPH");
-  const bool want_graph = eg && atoi(eg) != 0 && !ctx->stage_timing && count > 1 && !ctx->is_lane;
-  bool single_path = false;
-  if (!want_graph) return many_enqueue(ctx, count, d_s, d_p, n, window_bits, d_out, partial_out, false, &single_path);
-  // key: everything a captured node bakes in
-  const size_t klen = (3 * count + 4) * sizeof(uint64_t);
-  uint64_t* key = (uint64_t*)malloc(klen);
-  if (!key) return SNARKV_ERR_DEVICE;
-  key[0] = count, key[1] = (uint64_t)(uint32_t)window_bits, key[2] = (uint64_t)(uintptr_t)d_out, key[3] = partial_out ? 1 : 0;
-  for (size_t i = 0; i < count; ++i) {
-    key[4 + 3 * i] = (uint64_t)(uintptr_t)d_s[i];
-    key[5 + 3 * i] = (uint64_t)(uintptr_t)d_p[i];
-    key[6 + 3 * i] = (uint64_t)n[i];
-  }
-  const bool same = ctx->many_graph_key && ctx->many_graph_key_len == klen && memcmp(ctx->many_graph_key, key, klen) == 0;
-  if (same && ctx->many_graph_state == 2 && ctx->many_graph && ctx->many_graph_epoch == many_scratch_epoch(ctx)) {
-    free(key);
-    SNARKV_HIP(hipGraphLaunch(ctx->many_graph, ctx->stream));
-    ++ctx->many_graph_launches;
-    return SNARKV_OK;
-  }
-  if (ctx->many_graph) {  // stale: another key, or a buffer moved
-    (void)hipGraphExecDestroy(ctx->many_graph);
-    ctx->many_graph = nullptr;
-  }
-  if (!(same && ctx->many_graph_state >= 1)) {  // first sight of this key: eager, so that every buffer exists afterwards
-    free(ctx->many_graph_key);
-    ctx->many_graph_key = key;
-    ctx->many_graph_key_len = klen;
-    ctx->many_graph_state = 1;
-    return many_enqueue(ctx, count, d_s, d_p, n, window_bits, d_out, partial_out, false, &single_path);
-  }
-  free(key);
-  // second sight: capture.  Anything still queued on the five streams finishes first (the capture starts from a clean
-  // slate: no event recorded outside the capture is waited on inside it).
-  SNARKV_HIP(hipDeviceSynchronize());
-  const uint64_t epoch = many_scratch_epoch(ctx);
-  SNARKV_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
-  int rc = many_enqueue(ctx, count, d_s, d_p, n, window_bits, d_out, partial_out, true, &single_path);
-  hipGraph_t g = nullptr;
-  hipError_t e = hipStreamEndCapture(ctx->stream, &g);
-  if (rc < 0 || e != hipSuccess || !g || single_path || epoch != many_scratch_epoch(ctx)) {
-    // not capturable this time (a fall-back path, an allocation inside, a runtime refusal): run it eagerly, stay eager
-    if (g) (void)hipGraphDestroy(g);
-    (void)hipGetLastError();
-    ctx->many_graph_state = 0;
-    // (an error inside the capture may be the capture's own -- e.g. a synchronising call it forbids: the eager run decides)
-    return many_enqueue(ctx, count, d_s, d_p, n, window_bits, d_out, partial_out, false, &single_path);
-  }
-  e = hipGraphInstantiate(&ctx->many_graph, g, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(g);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    ctx->many_graph = nullptr;
-    ctx->many_graph_state = 0;
-    return many_enqueue(ctx, count, d_s, d_p, n, window_bits, d_out, partial_out, false, &single_path);
-  }
-  ctx->many_graph_state = 2;
-  ctx->many_graph_epoch = epoch;
-  SNARKV_HIP(hipGraphLaunch(ctx->many_graph, ctx->stream));
-  ++ctx->many_graph_launches;
-  return SNARKV_OK;
-}
-
-static int many_enqueue(snarkv_ctx* ctx, size_t count, const void* const* d_s, const void* const* d_p, const size_t* n,
-                        int window_bits, void* d_out, bool partial_out, bool capturing, bool* single_path) {
   const size_t ostride = partial_out ? SNARKV_G1_PARTIAL_BYTES : 64;
   ctx->last_many_jobs = 0;
   ctx->last_split_workers = 0;
@@ -399,15 +311,12 @@ static int many_enqueue(snarkv_ctx* ctx, size_t count, const void* const* d_s, c
   }
   const char* em = getenv("SNARKV_MANY_MODE");  // 0: one MSM after the other through the single-call path (A/B knob)
   if (count == 1 || large || (em && atoi(em) == 0) || ctx->is_lane) {
-    *single_path = true;
-    if (capturing) return SNARKV_OK;  // the caller ends the capture and runs this path eagerly
     for (size_t i = 0; i < count; ++i)
       SNARKV_TRY(launch_msm_pippenger_auto(ctx, d_s[i], d_p[i], n[i], window_bits, (uint8_t*)d_out + ostride * i, partial_out));
     return SNARKV_OK;
   }
   // jobs per round: bounded by the scratch footprint (~560 B per point + two bucket grids)
-  // (~560 B per point without the pair level, ~1 000 B more with it: prefix products + the half-length stream)
-  const size_t per_job = nmax * 1600 + (size_t)w0 * b0 * SNARKV_G1_PARTIAL_BYTES * 2 + (1u << 20);
+  const size_t per_job = nmax * 600 + (size_t)w0 * b0 * SNARKV_G1_PARTIAL_BYTES * 2 + (1u << 20);
   size_t G = std::min<size_t>(count, SNARKV_MANY_MAX_JOBS);
   G = std::max<size_t>(1, std::min<size_t>(G, ((size_t)48 << 30) / per_job));
   if (const char* eg = getenv("SNARKV_MANY_JOBS")) G = std::max<size_t>(1, std::min<size_t>(G, (size_t)atoi(eg)));
@@ -422,8 +331,8 @@ static int many_enqueue(snarkv_ctx* ctx, size_t count, const void* const* d_s, c
     SNARKV_TRY(snarkv_ctx_create(ctx->device, (void*)ctx->stream, &j));
     j->is_lane = true;
     j->throughput_mode = true;  // long runs: other accumulations are always resident next to a job's
-    for (int e = 0; e < 16; ++e) SNARKV_HIP(hipEventCreateWithFlags(&j->grp_ev[e], hipEventDisableTiming));
-    j->grp_ev_ready = true;
+    SNARKV_HIP(hipEventCreateWithFlags(&j->sorted_ev, hipEventDisableTiming));  // the job's sort is done (its accumulation waits for it)
+    j->sorted_ev_ready = true;
     ctx->jobs[ctx->njobs++] = j;
   }
   if (!ctx->hi_ready) {
@@ -438,39 +347,32 @@ static int many_enqueue(snarkv_ctx* ctx, size_t count, const void* const* d_s, c
     for (int i = 0; i <= SNARKV_PIP_STAGES; ++i) SNARKV_HIP(hipEventCreate(&ctx->ev[i]));
     ctx->ev_ready = true;
   }
-  if (sig != ctx->many_sig && !capturing) {  // a new shape may grow (free + reallocate) scratch that queued work still uses
+  if (sig != ctx->many_sig) {  // a new shape may grow (free + reallocate) scratch that queued work still uses
     SNARKV_HIP(hipDeviceSynchronize());
     ctx->many_sig = sig;
   }
-  hipStream_t S[4] = {ctx->stream, ctx->sub[0]->stream, ctx->sub[1]->stream, ctx->sub[2]->stream};  // the accumulation streams
-  int nS = 3;  // three of them by default: 2 / 4 measured level or worse (SNARKV_MANY_ACC_STREAMS: A/B knob)
-  if (const char* es = getenv("SNARKV_MANY_ACC_STREAMS")) nS = std::max(1, std::min(4, atoi(es)));
-  // the context's stream waits for everything queued on the other four streams (join), then they wait for it (fork).
-  // Inside a capture the first call only forks (the other streams are not part of the capture yet, and nothing is
-  // queued on them: the caller drained the device) and the last one only joins (a stream forked again would be left
-  // unjoined at hipStreamEndCapture).
-  auto join_and_fork = [&](bool join = true, bool fork = true) -> int {
-    for (int k = 0; k < 2 && join; ++k) {
+  hipStream_t S[3] = {ctx->stream, ctx->sub[0]->stream, ctx->sub[1]->stream};  // the accumulation streams
+  constexpr int nS = 3;  // three of them: 2 / 4 measured level or worse (profiles/r02_sweep_many.txt)
+  // the context's stream waits for everything queued on the other four streams (join), then they wait for it (fork)
+  auto join_and_fork = [&]() -> int {
+    for (int k = 0; k < 2; ++k) {
       SNARKV_HIP(hipEventRecord(ctx->many_ev[k], ctx->hi_stream[k]));
       SNARKV_HIP(hipStreamWaitEvent(ctx->stream, ctx->many_ev[k], 0));
     }
-    for (int k = 0; k + 1 < nS && join; ++k) {
+    for (int k = 0; k + 1 < nS; ++k) {
       SNARKV_HIP(hipEventRecord(ctx->sub_ev[k], S[k + 1]));
       SNARKV_HIP(hipStreamWaitEvent(ctx->stream, ctx->sub_ev[k], 0));
     }
-    if (!fork) return SNARKV_OK;
     SNARKV_HIP(hipEventRecord(ctx->sub_ev[4], ctx->stream));
     for (int k = 0; k < 2; ++k) SNARKV_HIP(hipStreamWaitEvent(ctx->hi_stream[k], ctx->sub_ev[4], 0));
     for (int k = 0; k + 1 < nS; ++k) SNARKV_HIP(hipStreamWaitEvent(S[k + 1], ctx->sub_ev[4], 0));
     return SNARKV_OK;
   };
-  const char* et = getenv("SNARKV_MANY_TAIL");
-  const bool job_tail = et ? atoi(et) != 0 : SNARKV_MANY_TAIL_DEFAULT != 0;
   void* d_grids = nullptr;
   const size_t grid_bytes = (size_t)w0 * b0 * SNARKV_G1_PARTIAL_BYTES;
   if (uniform) SNARKV_TRY(ctx_reserve(ctx, SLOT_MGPU_GRID, grid_bytes * G, &d_grids));
   if (tm) SNARKV_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-  SNARKV_TRY(join_and_fork(!capturing, true));  // inputs may still be in flight on the caller's stream
+  SNARKV_TRY(join_and_fork());  // inputs may still be in flight on the caller's stream
   for (size_t lo = 0; lo < count; lo += G) {
     const size_t hi = std::min(count, lo + G);
     const bool last = hi == count;
@@ -481,24 +383,20 @@ static int many_enqueue(snarkv_ctx* ctx, size_t count, const void* const* d_s, c
       hipStream_t sa = ctx->hi_stream[(i - lo) % 2], sb = S[(i - lo) % nS];
       SNARKV_TRY(launch_msm_pippenger_phases(job, sa, PIP_PHASE_SORT, d_s[i], d_p[i], n[i], window_bits, nullptr, false,
                                              nullptr, grid));
-      SNARKV_HIP(hipEventRecord(job->grp_ev[0], sa));
-      SNARKV_HIP(hipStreamWaitEvent(sb, job->grp_ev[0], 0));
+      SNARKV_HIP(hipEventRecord(job->sorted_ev, sa));
+      SNARKV_HIP(hipStreamWaitEvent(sb, job->sorted_ev, 0));
       SNARKV_TRY(launch_msm_pippenger_phases(job, sb, PIP_PHASE_ACC, d_s[i], d_p[i], n[i], window_bits, nullptr, false,
                                              nullptr, grid));
-      // SNARKV_MANY_TAIL=1: the job's bucket reduce right behind its combine, on its accumulation stream -- under the
-      // other jobs' accumulations instead of in the exposed tail of the batch (only the shift chains + sums stay there)
-      if (uniform && job_tail)
-        SNARKV_TRY(launch_bucket_reduce_job(ctx, sb, d_grids, c0, w0, (uint32_t)(hi - lo), (uint32_t)(i - lo)));
       // a ragged batch (different window sizes) cannot share one tail: each job's own, behind its accumulation
       if (!uniform)
         SNARKV_TRY(launch_msm_pippenger_phases(job, sb, PIP_PHASE_TAIL, d_s[i], d_p[i], n[i], window_bits,
                                                (uint8_t*)d_out + ostride * i, partial_out, nullptr, nullptr));
       job->stage_timing = false;
     }
-    SNARKV_TRY(join_and_fork(true, !(capturing && last)));
+    SNARKV_TRY(join_and_fork());
     if (uniform) {
       SNARKV_TRY(launch_buckets_reduce_many(ctx, ctx->stream, d_grids, c0, w0, (uint32_t)(hi - lo),
-                                            (uint8_t*)d_out + ostride * lo, partial_out, job_tail));
+                                            (uint8_t*)d_out + ostride * lo, partial_out));
       if (!last) SNARKV_TRY(join_and_fork());  // the next round overwrites the grids
     }
     if (last) ctx->last_many_jobs = (int)(hi - lo);

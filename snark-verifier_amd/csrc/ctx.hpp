@@ -66,12 +66,6 @@ enum Slot {
   SLOT_IPA_OUT,
   SLOT_MGPU_GRID,
   SLOT_MGPU_RECV,
-  SLOT_COUNTS2,
-  SLOT_OFFSETS2,
-  SLOT_PAIR_PFX,
-  SLOT_PAIR_TOT,
-  SLOT_PAIR_PTS,
-  SLOT_PAIR_ENTRIES,
   SLOT_COUNT
 };
 
@@ -95,9 +89,8 @@ struct snarkv_ctx {
   snarkv_ctx* sub[4];
   hipEvent_t sub_ev[5];
   bool sub_ready;
-  // window-group pipeline of one Pippenger (msm_pippenger.hip): [j] group j accumulated, [8 + j] group j's tail done
-  hipEvent_t grp_ev[16];
-  bool grp_ev_ready;
+  hipEvent_t sorted_ev;  // job contexts of a batch: this job's prepare + sort is done (its accumulation waits for it)
+  bool sorted_ev_ready;
   int last_split_workers;  // > 0: the last Pippenger ran as a chunk pipeline on that many worker lanes (stage timing)
   bool throughput_mode;  // several MSMs are kept in flight next to this context's (snarkv_ctx_set_throughput_hint; always on lanes)
   bool is_lane;          // a private sub-context of another context (never starts lanes of its own)
@@ -109,15 +102,6 @@ struct snarkv_ctx {
   hipEvent_t many_ev[2];
   hipStream_t hi_stream[2];  // high-priority streams of the batch pipeline (the sorts) + their join events (many_ev)
   bool hi_ready;
-  // the batch captured as a hipGraph (capi.hip launch_msm_pippenger_many): replayed while the call's key (every pointer,
-  // size and option) and the scratch epoch (no buffer of the contexts involved was reallocated since) are unchanged
-  hipGraphExec_t many_graph;
-  void* many_graph_key;       // malloc'd copy of the key bytes of the captured / warmed call
-  size_t many_graph_key_len;
-  uint64_t many_graph_epoch;  // scratch_epoch() at capture
-  int many_graph_state;       // 0 nothing, 1 warmed (ran once eagerly: scratch is allocated), 2 captured
-  uint64_t realloc_epoch;     // bumped by ctx_reserve whenever a slot is (re)allocated
-  uint64_t many_graph_launches;  // hipGraphLaunch calls so far (snarkv_ctx_graph_replays: tests / diagnostics)
 };
 
 struct snarkv_dk {
@@ -148,10 +132,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
                                 size_t n, int window_bits, void* d_out, bool partial_out, void* d_buckets_out,
                                 void* d_grid);
 int launch_buckets_reduce_many(snarkv_ctx* ctx, hipStream_t st, const void* d_grids, uint32_t c, uint32_t windows,
-                               uint32_t jobs, void* d_out, bool partial_out, bool reduce_done = false);
-// one job's bucket reduce of such a batched tail, under the batch's accumulations (msm_pippenger.hip)
-int launch_bucket_reduce_job(snarkv_ctx* ctx, hipStream_t st, const void* d_grids, uint32_t c, uint32_t windows,
-                             uint32_t jobs, uint32_t job);
+                               uint32_t jobs, void* d_out, bool partial_out);
 // `count` independent MSMs, phase-ordered over private job contexts (capi.hip)
 int launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void* const* d_scalars, const void* const* d_points,
                               const size_t* n, int window_bits, void* d_out, bool partial_out);

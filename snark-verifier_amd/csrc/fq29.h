@@ -241,43 +241,9 @@ SNARKV_HD Fq29 fq29_sqr(const Fq29& a) {
 #endif
 }
 
-#ifndef SNARKV_MADD_PAIRS
-#define SNARKV_MADD_PAIRS 0  // the interleaved-pair adder of g1_29.h (a recorded experiment, off: DESIGN.md section 4)
-#endif
-#if SNARKV_MADD_PAIRS  // the three generated pair bodies (4 000 lines of asm) are parsed only by a build that uses them
-// PAIRS of independent products, interleaved column by column (gen_fq29_mul_asm.py pair mode).  Same arithmetic, same
-// results as the single forms; what changes is the instruction after every asm statement: the compiler pads an asm
-// statement whose VGPR result is read by the very next instruction with `s_nop 0` (it must assume the asm wrote with
-// dst_sel), ~27 times per single product; with a second product's column in between there is nothing to pad.
-// r1 = a * b, r2 = c * d
-SNARKV_HD void fq29_mul_mul(const Fq29& a, const Fq29& b, const Fq29& c, const Fq29& d, Fq29& r1, Fq29& r2) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNARKV_NO_SMAD_ASM)
-#include "fq29_mul_mul_asm.inc"
-#else
-  r1 = fq29_mul(a, b);
-  r2 = fq29_mul(c, d);
-#endif
-}
-// r1 = a^2, r2 = c^2 (both carry-normalised)
-SNARKV_HD void fq29_sqr_sqr(const Fq29& a, const Fq29& c, Fq29& r1, Fq29& r2) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNARKV_NO_SMAD_ASM)
-#include "fq29_sqr_sqr_asm.inc"
-#else
-  r1 = fq29_sqr(a);
-  r2 = fq29_sqr(c);
-#endif
-}
-// r1 = a * b + c * d (one reduction, operand bounds of fq29_mul2), r2 = e * f
-SNARKV_HD void fq29_mul2_mul(const Fq29& a, const Fq29& b, const Fq29& c, const Fq29& d, const Fq29& e, const Fq29& f,
-                             Fq29& r1, Fq29& r2) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNARKV_NO_SMAD_ASM)
-#include "fq29_mul2_mul_asm.inc"
-#else
-  r1 = fq29_mul2(a, b, c, d);
-  r2 = fq29_mul(e, f);
-#endif
-}
-#endif  // SNARKV_MADD_PAIRS
+// (Measured and removed, round 2: PAIRS of independent products interleaved column by column -- 2 404 -> 2 278 issued
+// instructions per bucket addition, one MSM alone level, four in flight 1-5 % slower: profiles/r02_ab_pairs.txt, git tag
+// exp/madd-pairs.)
 
 // Unique representative in [0, p), carry-normalised.
 // canonical limbs of a value y in (-p, 2p) whose limbs 0..7 are already in [0, 2^29) -- in particular any OUTPUT of

@@ -39,21 +39,11 @@ struct alignas(64) G1Packed {
   uint32_t w[16];
 };
 
-// Two codecs of a canonical residue (limbs 0..7 in [0, 2^29), limb 8 < 2^22) into 8 words:
-//   SNARKV_PACK_SPREAD = 0   the plain 256-bit little-endian integer: every limb straddles two words, a 64-bit funnel shift
-//                            + mask each -- ~64 instructions per coordinate in the compiled k_accumulate (the
-//                            "unpack regression", +128 per entry against the 72-byte limb form)
-//   SNARKV_PACK_SPREAD = 1   word i = limb i in its low 29 bits, and bits 3i .. 3i+2 of limb 8 (22 bits <= 8 x 3) in its top 3:
-//                            limbs 0..7 come out with ONE mask each, limb 8 with a shift / and-or per word
-// Both are injective on canonical residues (the pair level and the careful paths compare words for equality).
-#ifndef SNARKV_PACK_SPREAD
-#define SNARKV_PACK_SPREAD 0  // measured: no gain (k_accumulate 1.11 ms either way, profiles/r03_ab_combine_pack.txt) -- plain form kept
-#endif
+// The codec of a canonical residue (limbs 0..7 in [0, 2^29), limb 8 < 2^22): the plain 256-bit little-endian integer.
+// Every limb straddles two words: a 64-bit funnel shift + mask each.  (Measured and removed, round 3: limbs 0..7 in the low
+// 29 bits of the words and limb 8 spread over their top bits -- fewer instructions, k_accumulate 1.11 ms either way:
+// profiles/r03_ab_combine_pack.txt, git tag exp/pack-spread.)
 SNARKV_HD void fq29_pack256(const Fq29& a, uint32_t w[8]) {  // a: canonical residue, limbs in [0, 2^29)
-#if SNARKV_PACK_SPREAD
-#pragma unroll
-  for (int j = 0; j < 8; ++j) w[j] = (uint32_t)a.v[j] | ((((uint32_t)a.v[8] >> (3 * j)) & 7u) << 29);
-#else
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     int bit = 32 * j;
@@ -63,19 +53,10 @@ SNARKV_HD void fq29_pack256(const Fq29& a, uint32_t w[8]) {  // a: canonical res
     if (i + 2 < 9 && sh + 32 > 58) v |= (uint64_t)(uint32_t)a.v[i + 2] << 58;
     w[j] = (uint32_t)(v >> sh);
   }
-#endif
 }
 
 SNARKV_HD Fq29 fq29_unpack256(const uint32_t w[8]) {
   Fq29 a;
-#if SNARKV_PACK_SPREAD
-  uint32_t top = w[0] & 0xE0000000u;  // limb 8 gathered in the top bits, three per word, w0's lowest: then shifted down
-#pragma unroll
-  for (int i = 1; i < 8; ++i) top = (top >> 3) | (w[i] & 0xE0000000u);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) a.v[i] = (int32_t)(w[i] & (uint32_t)kMask29);
-  a.v[8] = (int32_t)(top >> 8);
-#else
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
     int bit = 29 * i;
@@ -84,7 +65,6 @@ SNARKV_HD Fq29 fq29_unpack256(const uint32_t w[8]) {
     if (word + 1 < 8) v |= (uint64_t)w[word + 1] << 32;
     a.v[i] = (int32_t)((uint32_t)(v >> sh) & (uint32_t)kMask29);
   }
-#endif
   return a;
 }
 
@@ -146,33 +126,6 @@ SNARKV_HD void xyzz29_finish(G1Xyzz29& acc, const Fq29& u1, const Fq29& s1, cons
 }
 
 // acc += P (affine, non-identity), acc non-identity.  madd-2008-s, 8M + 2S.
-// Interleaved product pairs: OFF.  Measured on MI355X (interleaved A/B medians, two sessions): the pairs take the issued
-// instructions of k_accumulate from 2 404 to 2 278 per entry (s_nop 203 -> 78) and one MSM alone gains 1.4 % on the kernel,
-// but with four MSMs in flight -- the headline mode -- the paired form is 1-5 % SLOWER: there the chip is at its power
-// budget, an s_nop costs no energy, and a denser instruction stream comes back as a lower clock.
-#ifndef SNARKV_MADD_PAIRS
-#define SNARKV_MADD_PAIRS 0
-#endif
-#if SNARKV_MADD_PAIRS
-// The ten products as four interleaved pairs and two singles (fq29.h: pairs) -- the dependency graph allows
-//   (U2, S2) -> (PP, RR) -> (PPP, Q) -> X3 -> (Y3 [two products, one reduction], ZZ3) -> ZZZ3
-// Same values in the same lazy bounds as the sequential form below.
-SNARKV_HD void xyzz29_madd_fast(G1Xyzz29& acc, const G1Affine29& p) {
-  Fq29 u2, s2, pp, rr, ppp, q, y3, zz3;
-  fq29_mul_mul(p.x, acc.zz, p.y, acc.zzz, u2, s2);
-  Fq29 pn = fq29_norm(fq29_sub(u2, acc.x));  // limbs (-2^29, 2^30) -> norm
-  Fq29 rn = fq29_norm(fq29_sub(s2, acc.y));
-  fq29_sqr_sqr(pn, rn, pp, rr);
-  fq29_mul_mul(pn, pp, acc.x, pp, ppp, q);
-  Fq29 x3 = fq29_norm(fq29_sub(fq29_sub(rr, ppp), fq29_dbl(q)));  // limbs before norm in (-3*2^29, 2^29)
-  Fq29 t = fq29_sub(q, x3);                                         // |limb| < 2^29
-  fq29_mul2_mul(rn, t, fq29_neg(acc.y), ppp, acc.zz, pp, y3, zz3);
-  acc.zzz = fq29_mul(acc.zzz, ppp);
-  acc.x = x3;
-  acc.y = y3;
-  acc.zz = zz3;
-}
-#else
 SNARKV_HD void xyzz29_madd_fast(G1Xyzz29& acc, const G1Affine29& p) {
   Fq29 u2 = fq29_mul(p.x, acc.zz);
   Fq29 s2 = fq29_mul(p.y, acc.zzz);
@@ -184,7 +137,6 @@ SNARKV_HD void xyzz29_madd_fast(G1Xyzz29& acc, const G1Affine29& p) {
   acc.zz = fq29_mul(acc.zz, pp);
   acc.zzz = fq29_mul(acc.zzz, ppp);
 }
-#endif
 
 // acc += b, both non-identity.  add-2008-s, 12M + 2S.
 SNARKV_HD void xyzz29_add_fast(G1Xyzz29& acc, const G1Xyzz29& b) {

@@ -537,11 +537,6 @@ static uint32_t chunks_for(size_t n_terms) {
     int v = atoi(e);
     if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) return (uint32_t)v;
   }
-  if (n_terms > 16384)
-    if (const char* e = getenv("SNARKV_NAIVE_CHUNKS_BIG")) {  // tuning knob: the chunked form above the one-lane threshold
-      int v = atoi(e);
-      if (v == 1 || v == 2 || v == 4 || v == 8) return (uint32_t)v;
-    }
   if (n_terms <= 2048) return 16;
   if (n_terms <= 4096) return 8;
   if (n_terms <= 8192) return 4;

@@ -52,7 +52,6 @@
 #include <atomic>
 #include "ctx.hpp"
 #include "g1_29.h"
-#include "pair_tree.h"
 #ifndef SNARKV_GLV
 #define SNARKV_GLV 1  // 0: curves without the BN-shaped GLV lattice (the pasta build): one virtual point per point
 #endif
@@ -62,13 +61,6 @@
 
 namespace snarkv {
 
-#ifndef SNARKV_FUSED_FILLS
-// 1: the three per-MSM fills (key x tile matrix 8 MB, bucket grid 36 MB, counters) are done by the kernels that own the
-// data -- k_prepare zeroes the matrix' padding column, k_sort_level2's last workgroup the counters, k_combine stores the
-// identity into empty buckets -- instead of three hipMemsetAsync per MSM (60 fill launches in a 20-job batch, each ~90 us
-// of queueing in front of a k_accumulate on its stream).  0: the memsets (A/B: profiles/r03_ab_fills.txt).
-#define SNARKV_FUSED_FILLS 7  // bit 0: the matrix' padding column, bit 1: the counters, bit 2: the bucket grid
-#endif
 #ifndef SNARKV_KRUN
 #define SNARKV_KRUN 64
 #endif
@@ -83,9 +75,6 @@ namespace snarkv {
 // -3.4 %, one MSM alone level (profiles/r02_ab_coresidency.txt).
 #define SNARKV_TILE_THREADS 256
 #endif
-#ifndef SNARKV_SCATTER_WINDOW_MAJOR
-#define SNARKV_SCATTER_WINDOW_MAJOR 1  // k_sort_scatter walks its tile window by window (see there)
-#endif
 #ifndef SNARKV_SCATTER_ATTR
 #define SNARKV_SCATTER_ATTR __attribute__((amdgpu_waves_per_eu(5)))  // k_sort_scatter_staged: 96 VGPRs (120 uncapped, no spills either way)
 #endif
@@ -97,9 +86,6 @@ namespace snarkv {
 #endif
 #ifndef SNARKV_PREP_THREADS
 #define SNARKV_PREP_THREADS SNARKV_TILE_THREADS  // lanes of a k_prepare workgroup (one tile)
-#endif
-#ifndef SNARKV_SCATTER_STAGED
-#define SNARKV_SCATTER_STAGED 1  // k_sort_scatter_staged (LDS-staged, coalesced write-out) instead of k_sort_scatter
 #endif
 #ifndef SNARKV_XCD_TILES
 #define SNARKV_XCD_TILES 1  // tiles -> workgroups so that an XCD owns a contiguous tile range (xcd_tile)
@@ -156,16 +142,9 @@ struct PipParams {
   uint32_t tile;   // scalars per tile workgroup
   uint32_t mstride;  // row stride of the key x tile matrix (odd: no power-of-two channel aliasing)
   uint32_t w0;       // index of the first window held (bucket-sharded reduce of a window range; 0 otherwise)
-  // window groups (single-MSM latency pipeline, launch_msm_pippenger): the sorted stream is accumulated group by
-  // group, top windows first, and a group's combine / bucket reduce / shift chain runs on a side stream under the
-  // accumulation of the next groups.  Runs are cut relative to the START of their group's part of the stream.
-  uint32_t gsz;      // windows per group (W = one group: the whole stream, runs cut from offset 0)
   uint32_t krun;     // entries per run (kRun, or kRunThroughput on a context with the throughput hint)
-  uint32_t rpw;      // run slots reserved per window: ceil(max entries of a window / krun) + 1
   uint32_t wper;     // batched tail over several MSMs' grids laid end to end: windows per MSM (0: one MSM)
-  uint32_t pad;      // 1: k_sort_level2 pads every bucket's entry count to even (the pair level, pair_tree.h)
   uint32_t chunk_log2;  // P6: log2 of the buckets per k_bucket_reduce lane (kLog2Chunk; larger in a batched tail)
-  uint32_t low_prio;    // P6: 1 = k_bucket_reduce keeps the default wave priority (a job's reduce UNDER a batch's accumulations)
 };
 
 // c bits at offset lo of a kDigitBits-bit magnitude held in registers (selects, no dynamic indexing)
@@ -318,71 +297,19 @@ __global__ void __launch_bounds__(SNARKV_PREP_THREADS)
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) M[(size_t)k * p.mstride + tile] = lds[k];
-#if SNARKV_FUSED_FILLS & 1
   // the padding column of the matrix (mstride = nblk | 1) must read as zero in the scan: one workgroup writes it
+  // (the per-MSM fills are done by the kernels that own the data, not by hipMemsetAsync: profiles/r03_ab_scheduling.txt)
   if (blockIdx.x == 0 && p.mstride > p.nblk)
     for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) M[(size_t)k * p.mstride + p.nblk] = 0u;
-#endif
 }
 
 // --------------------------------------------------------------- S3
-// Stable partition by (window, high bits).  M has been scanned (key-major,
-// tile-minor), so M[key][tile] is where this tile's items of that key start;
-// LDS cursors hand out the slots -- no global atomics.
-__global__ void __launch_bounds__(SNARKV_TILE_THREADS)
-    k_sort_scatter(const uint4* __restrict__ glv, PipParams p, const uint32_t* __restrict__ M,
-                   uint2* __restrict__ tmp) {
-  SNARKV_RAISE_PRIO();
-  extern __shared__ uint32_t lds[];  // nkeys cursors
-  const uint32_t tile = xcd_tile(blockIdx.x, p.nblk);
-  for (uint32_t k = threadIdx.x; k < p.nkeys; k += blockDim.x) lds[k] = M[(size_t)k * p.mstride + tile];
-  __syncthreads();
-  uint32_t lo = tile * p.tile;
-  uint32_t hi = lo + p.tile < p.n ? lo + p.tile : p.n;
-#if SNARKV_SCATTER_WINDOW_MAJOR
-  // WINDOW-major: the workgroup walks its tile once per window, so that only that window's SB key streams are open at
-  // a time (SB lines of 128 B per workgroup: 2 MiB per XCD at 2^20 points, inside the 4 MiB L2, where a line collects
-  // its 16 entries before it is written back).  Scalar-major order keeps W*SB lines open per workgroup -- 16 MiB per XCD
-  // -- and the L2 evicts them half-written: WRITE_SIZE was 3.5x the payload (profiles/r02_pmc_hbm_traffic.txt).  The
-  // digit source (16 B per half-scalar) is re-read per window, out of L2 / the Infinity Cache.
-  for (int w = 0; w < p.W; ++w) {
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-#pragma unroll
-      for (uint32_t h = 0; h < (uint32_t)kHalves; ++h) {
-        uint32_t v = kHalves * i + h;  // virtual point: P (h=0) or phi(P) (h=1)
-        uint32_t d[kDigitWords];
-        uint32_t sgn = load_digit_source(glv, v, d);
-        digit_of_window(d, sgn, p, w, [&](uint32_t key, uint32_t bucket, uint32_t neg) {
-          uint32_t pos = atomicAdd(&lds[key], 1u);
-          tmp[pos] = make_uint2(bucket, v | (neg << 31));
-        });
-      }
-    }
-    __syncthreads();  // the whole workgroup moves on to the next window together
-  }
-#else
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-#pragma unroll
-    for (uint32_t h = 0; h < (uint32_t)kHalves; ++h) {
-      uint32_t v = kHalves * i + h;  // virtual point: P (h=0) or phi(P) (h=1)
-      uint32_t d[kDigitWords];
-      uint32_t sgn = load_digit_source(glv, v, d);
-      for_each_digit(d, sgn, p, [&](uint32_t key, uint32_t bucket, uint32_t neg) {
-        uint32_t pos = atomicAdd(&lds[key], 1u);
-        tmp[pos] = make_uint2(bucket, v | (neg << 31));
-      });
-    }
-  }
-#endif
-}
-
-// The same partition with its writes STAGED through LDS (the default; k_sort_scatter above is the direct form: the
-// fall-back for geometries whose counters do not fit, and the comparison).  A workgroup owns ONE tile of kStageScalars
-// scalars, keeps their digit sources in registers, and per window counts its entries per key, scans the counts, places
-// the entries in LDS in key order and writes them out with consecutive lanes on consecutive addresses: a (tile, key)
-// run leaves as whole 64-128-byte segments instead of 8-byte stores issued at unrelated times.  The L2 does not merge
-// those: WRITE_SIZE was 3.5x the payload with the direct form (2.8x walking the tile window by window), 1.0x staged
-// (profiles/r02_pmc_hbm_traffic.txt); partition + sort 0.28 -> 0.19 ms at 2^20 points.
+// Stable partition by (window, high bits).  M has been scanned (key-major, tile-minor), so M[key][tile] is where this
+// tile's items of that key start.  The writes are STAGED through LDS: a workgroup owns ONE tile of kStageScalars scalars
+// and per window counts its entries per key, scans the counts, places the entries in LDS in key order and writes them
+// out with consecutive lanes on consecutive addresses: a (tile, key) run leaves as whole 64-128-byte segments instead
+// of 8-byte stores issued at unrelated times (the L2 does not merge those: WRITE_SIZE was 3.5x the payload with direct
+// stores, 1.0x staged -- profiles/r02_pmc_hbm_traffic.txt; the direct kernel: git tag exp/scatter-direct).
 constexpr uint32_t kStageScalars = SNARKV_TILE_BASE;                    // scalars per staged workgroup = the tile
 constexpr uint32_t kStageItems = kStageScalars / SNARKV_TILE_THREADS;   // ... per lane
 static_assert(kStageScalars % SNARKV_TILE_THREADS == 0, "a staged tile gives every lane the same number of scalars");
@@ -542,19 +469,12 @@ __global__ void __launch_bounds__(256) k_scan_add(uint32_t* __restrict__ data, c
 // scatter to HBM costs a 128-byte read-modify-write once the working set
 // outgrows L2/Infinity Cache.  Larger slices (skewed scalars) take the
 // two-pass global path.
-// PAD mode (p.pad, the pair level of pair_tree.h): every bucket's entry count is rounded up to EVEN with a skip entry
-// {bucket, kEntrySkip} behind its real ones, so that the entries (2i, 2i + 1) of the stream always share a bucket.  The
-// padded sizes are not known before the histogram, so key k's output region starts at its level-1 position plus
-// k * (nbins + 2), rounded to even -- room for one pad per bin -- and what is left of the room is given to the key's
-// last bin as further skip entries (a few hundred per MSM): no second scan, the stream stays bucket-sorted and dense.
-// counts / offsets describe the padded stream; counts2 / offsets2 the HALF-length stream of pair slots; the last key
-// leaves the padded total and the number of pair slots in misc[1] / misc[2].
 __global__ void __launch_bounds__(SNARKV_L2_THREADS) SNARKV_LEVEL2_ATTR
     k_sort_level2(const uint2* __restrict__ tmp, const uint32_t* __restrict__ M, uint32_t* __restrict__ misc,
                   PipParams p, uint2* __restrict__ entries, uint32_t* __restrict__ counts,
-                  uint32_t* __restrict__ offsets, uint32_t* __restrict__ counts2, uint32_t* __restrict__ offsets2) {
+                  uint32_t* __restrict__ offsets) {
   SNARKV_RAISE_PRIO();
-  extern __shared__ uint32_t lds[];  // nbins counters | one scan word per lane | kSortCap (+ nbins + 4 in pad mode) items (uint2)
+  extern __shared__ uint32_t lds[];  // nbins counters | one scan word per lane | kSortCap items (uint2)
   const uint32_t nbins = 1u << p.low_bits;
   uint32_t* hist = lds;
   uint32_t* scan = lds + nbins;
@@ -564,10 +484,6 @@ __global__ void __launch_bounds__(SNARKV_L2_THREADS) SNARKV_LEVEL2_ATTR
   uint32_t begin = M[(size_t)key * p.mstride];
   uint32_t end = (key + 1 < p.nkeys) ? M[(size_t)(key + 1) * p.mstride] : misc[0];
   uint32_t cnt_items = end - begin;
-  const uint32_t room = nbins + 2;
-  const uint32_t ob = p.pad ? ((begin + key * room + 1u) & ~1u) : begin;                // where this key's output starts
-  const uint32_t obn = p.pad ? ((end + (key + 1) * room + 1u) & ~1u) : end;             // ... and the next key's
-  const uint32_t capacity = obn - ob;
   bool fast = cnt_items <= kSortCap;
   for (uint32_t k = threadIdx.x; k < nbins; k += T) hist[k] = 0;
   __syncthreads();
@@ -588,11 +504,11 @@ __global__ void __launch_bounds__(SNARKV_L2_THREADS) SNARKV_LEVEL2_ATTR
     for (uint32_t e = begin + threadIdx.x; e < end; e += T) atomicAdd(&hist[tmp[e].x & low_mask], 1u);
   }
   __syncthreads();
-  // exclusive scan of the (padded) bin sizes: each lane owns a contiguous strip
+  // exclusive scan of the bin sizes: each lane owns a contiguous strip
   uint32_t per = (nbins + T - 1) / T;
   uint32_t s0 = threadIdx.x * per;
   uint32_t sum = 0;
-  for (uint32_t k = s0; k < s0 + per && k < nbins; ++k) sum += p.pad ? ((hist[k] + 1u) & ~1u) : hist[k];
+  for (uint32_t k = s0; k < s0 + per && k < nbins; ++k) sum += hist[k];
   scan[threadIdx.x] = sum;
   __syncthreads();
   for (uint32_t off = 1; off < T; off <<= 1) {
@@ -601,43 +517,18 @@ __global__ void __launch_bounds__(SNARKV_L2_THREADS) SNARKV_LEVEL2_ATTR
     scan[threadIdx.x] += t;
     __syncthreads();
   }
-  uint32_t run = scan[threadIdx.x] - sum;  // position inside the key's output region
-  const uint32_t used = scan[T - 1];       // padded entries of the key; the rest of the region goes to the last bin
+  uint32_t run = scan[threadIdx.x] - sum;  // position inside the key's slice
   uint32_t w = key / p.SB, sb = key % p.SB;
   uint32_t bucket0 = w * p.B + (sb << p.low_bits);
   for (uint32_t k = s0; k < s0 + per && k < nbins; ++k) {
     uint32_t cnt = hist[k];
-    uint32_t pc = p.pad ? ((cnt + 1u) & ~1u) : cnt;
-    if (p.pad && (cnt & 1u)) {
-      const uint2 pe = make_uint2(bucket0 + k, kEntrySkip);
-      if (fast) stage[run + cnt] = pe;
-      else entries[ob + run + cnt] = pe;
-    }
-    uint32_t tot = pc + ((p.pad && k == nbins - 1) ? capacity - used : 0u);
-    counts[bucket0 + k] = tot;
-    offsets[bucket0 + k] = ob + run;
-    if (p.pad) {
-      counts2[bucket0 + k] = tot >> 1;
-      offsets2[bucket0 + k] = (ob + run) >> 1;
-    }
-    hist[k] = run;  // becomes the cursor (region-relative)
-    run += pc;
+    counts[bucket0 + k] = cnt;
+    offsets[bucket0 + k] = begin + run;
+    hist[k] = run;  // becomes the cursor (slice-relative)
+    run += cnt;
   }
-  if (p.pad) {
-    const uint2 fe = make_uint2(bucket0 + nbins - 1, kEntrySkip);
-    for (uint32_t e = used + threadIdx.x; e < capacity; e += T) {
-      if (fast) stage[e] = fe;
-      else entries[ob + e] = fe;
-    }
-    if (key == p.nkeys - 1 && threadIdx.x == 0) {
-      misc[1] = obn;
-      misc[2] = obn >> 1;
-    }
-  }
-#if SNARKV_FUSED_FILLS & 2
-  // [3] = 0 (start of the pair level's half-length stream), [4 .. 11] = the big-bucket counters of k_combine
-  if (key == p.nkeys - 1 && threadIdx.x < 9) misc[3 + threadIdx.x] = 0u;
-#endif
+  // the big-bucket counter of k_combine (a per-MSM fill done by the kernel that runs before its user, not a memset)
+  if (key == p.nkeys - 1 && threadIdx.x == 0) misc[4] = 0u;
   __syncthreads();
   if (fast) {
 #pragma unroll
@@ -646,150 +537,13 @@ __global__ void __launch_bounds__(SNARKV_L2_THREADS) SNARKV_LEVEL2_ATTR
       if (e < cnt_items) stage[atomicAdd(&hist[mine[j].x & low_mask], 1u)] = mine[j];
     }
     __syncthreads();
-    for (uint32_t e = threadIdx.x; e < capacity; e += T) entries[ob + e] = stage[e];
+    for (uint32_t e = threadIdx.x; e < cnt_items; e += T) entries[begin + e] = stage[e];
   } else {
     for (uint32_t e = begin + threadIdx.x; e < end; e += T) {
       uint2 it = tmp[e];
-      entries[ob + atomicAdd(&hist[it.x & low_mask], 1u)] = it;
+      entries[begin + atomicAdd(&hist[it.x & low_mask], 1u)] = it;
     }
   }
-}
-
-// --------------------------------------------------------------- P3b (pair level, pair_tree.h)
-// One batched-affine addition level between the sort and the bucket accumulation: pair slot i = entries (2i, 2i + 1)
-// of the padded stream -> entry i of a half-length stream whose points are stored as lazy limbs.  6 field products per
-// addition instead of the 10 of the XYZZ mixed addition.  The per-lane code lives in pair_tree.h (host-testable).
-#ifndef SNARKV_COMBINE_PAIRS
-#define SNARKV_COMBINE_PAIRS 0  // k_combine: 1 = run-boundary lanes for the buckets that span two runs.  Measured level in a batch and
-                                // 13 % slower alone (0.082 -> 0.093 ms): profiles/r03_ab_combine_pack.txt -- off
-#endif
-#ifndef SNARKV_PAIR_TREE_DEFAULT
-#define SNARKV_PAIR_TREE_DEFAULT 0  // until the A/B says otherwise (profiles/r03_ab_pair_tree.txt)
-#endif
-#ifndef SNARKV_PAIR_M
-#define SNARKV_PAIR_M 16   // pair slots per lane of k_pair_fwd / k_pair_bwd
-#endif
-#ifndef SNARKV_BINV_M
-#define SNARKV_BINV_M 32   // elements per lane of an inversion level
-#endif
-constexpr uint32_t kPairT = 256;      // lanes per workgroup of the pair / inversion kernels
-constexpr uint32_t kPairM = SNARKV_PAIR_M;
-constexpr uint32_t kBinvM = SNARKV_BINV_M;
-constexpr uint32_t kBinvFinalMax = 1024;  // k_binv_final: 256 lanes x 4 values + an LDS product tree
-
-__global__ void __launch_bounds__(kPairT)
-    k_pair_fwd(const uint2* __restrict__ entries, const uint32_t* __restrict__ misc, const G1Packed* __restrict__ pts,
-               int32_t* __restrict__ pfx, size_t S, int32_t* __restrict__ tot, size_t L) {
-  const uint32_t j = blockIdx.x * kPairT + threadIdx.x;
-  pair_fwd_lane(j, kPairT, kPairM, misc[2], reinterpret_cast<const PairEntry*>(entries), pts, pfx, S, tot, L);
-}
-
-__global__ void __launch_bounds__(kPairT)
-    k_pair_bwd(const uint2* __restrict__ entries, const uint32_t* __restrict__ misc, const G1Packed* __restrict__ pts,
-               const int32_t* __restrict__ pfx, size_t S, const int32_t* __restrict__ itot, size_t L,
-               uint2* __restrict__ out_entries, int32_t* __restrict__ out_pts) {
-  const uint32_t j = blockIdx.x * kPairT + threadIdx.x;
-  pair_bwd_lane(j, kPairT, kPairM, misc[2], reinterpret_cast<const PairEntry*>(entries), pts, pfx, S, itot, L,
-                reinterpret_cast<PairEntry*>(out_entries), out_pts);
-}
-
-__global__ void __launch_bounds__(kPairT)
-    k_binv_up(const int32_t* __restrict__ a, uint32_t N, size_t A, int32_t* __restrict__ pfx, int32_t* __restrict__ tot,
-              size_t L) {
-  SNARKV_RAISE_PRIO();
-  binv_up_lane(blockIdx.x * kPairT + threadIdx.x, kPairT, kBinvM, N, a, A, pfx, tot, L);
-}
-
-__global__ void __launch_bounds__(kPairT)
-    k_binv_down(int32_t* __restrict__ a, uint32_t N, size_t A, const int32_t* __restrict__ pfx,
-                const int32_t* __restrict__ itot, size_t L) {
-  SNARKV_RAISE_PRIO();
-  binv_down_lane(blockIdx.x * kPairT + threadIdx.x, kPairT, kBinvM, N, a, A, pfx, itot, L);
-}
-
-// a[0 .. N) -> inverses in place, N <= kBinvFinalMax, ONE workgroup: every lane multiplies its (up to 4) values, the 256
-// lane products are multiplied up a binary tree in LDS, lane 0 inverts the root (safegcd), the inverses come back down
-// the tree (inverse of a child = inverse of the parent x the sibling's product) and through each lane's values.
-__global__ void __launch_bounds__(kPairT) k_binv_final(int32_t* __restrict__ a, uint32_t N, size_t A) {
-  SNARKV_RAISE_PRIO();
-  __shared__ int32_t node[9][2 * kPairT];  // heap layout: root 1, leaves kPairT .. 2 kPairT - 1
-  const uint32_t tid = threadIdx.x;
-  auto nload = [&](uint32_t i) {
-    Fq29 r;
-#pragma unroll
-    for (int l = 0; l < 9; ++l) r.v[l] = node[l][i];
-    return r;
-  };
-  auto nstore = [&](uint32_t i, const Fq29& v) {
-#pragma unroll
-    for (int l = 0; l < 9; ++l) node[l][i] = v.v[l];
-  };
-  constexpr int kPer = kBinvFinalMax / kPairT;
-  Fq29 pre[kPer];  // pre[k] = product of the lane's values before the k-th
-  Fq29 pr = fq29_one();
-  int cnt = 0;
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    const uint32_t e = tid + (uint32_t)k * kPairT;
-    pre[k] = pr;
-    if (e < N) {
-      Fq29 d = soa_load(a, A, e);
-      pr = cnt ? fq29_mul(pr, d) : d;
-      ++cnt;
-    }
-  }
-  nstore(kPairT + tid, pr);
-  for (uint32_t w = kPairT / 2; w >= 1; w >>= 1) {
-    __syncthreads();
-    if (tid < w) nstore(w + tid, fq29_mul(nload(2 * (w + tid)), nload(2 * (w + tid) + 1)));
-  }
-  __syncthreads();
-  if (tid == 0) nstore(1, fq29_inv(nload(1)));
-  for (uint32_t w = 1; w < kPairT; w <<= 1) {
-    __syncthreads();
-    if (tid < w) {
-      const uint32_t nd = w + tid;
-      const Fq29 inv = nload(nd), l = nload(2 * nd), r = nload(2 * nd + 1);
-      nstore(2 * nd, fq29_mul(inv, r));
-      nstore(2 * nd + 1, fq29_mul(inv, l));
-    }
-  }
-  __syncthreads();
-  Fq29 I = nload(kPairT + tid);
-#pragma unroll
-  for (int k = kPer - 1; k >= 0; --k) {
-    const uint32_t e = tid + (uint32_t)k * kPairT;
-    if (e < N) {
-      --cnt;
-      if (cnt == 0) {
-        soa_store(a, A, e, I);
-      } else {
-        Fq29 d = soa_load(a, A, e);
-        soa_store(a, A, e, fq29_mul(I, pre[k]));
-        I = fq29_mul(I, d);
-      }
-    }
-  }
-}
-
-// The FUSED form of the pair level (pair_tree.h "pair RUNS", SNARKV_PAIR_TREE=3): lane t owns RUN entries of the padded
-// stream like a k_accumulate lane; k_pairrun_fwd leaves the prefix products of its RUN / 2 slots' denominators,
-// k_accumulate_pairs walks the slots in reverse, forms each affine pair sum (5 products) and adds it into the lane's XYZZ
-// accumulator (10 products): 16 products per TWO entries instead of 20, nothing written but the prefixes.
-template <int RUN>
-__global__ void __launch_bounds__(64)
-    k_pairrun_fwd(const uint2* __restrict__ entries, const uint32_t* __restrict__ misc, const G1Packed* __restrict__ pts,
-                  int32_t* __restrict__ pfx, int32_t* __restrict__ tot, size_t L) {
-  pairrun_fwd_lane(blockIdx.x * 64 + threadIdx.x, RUN, misc[1], reinterpret_cast<const PairEntry*>(entries), pts, pfx, tot, L);
-}
-
-template <int RUN>
-__global__ void __launch_bounds__(64, 2)
-    k_accumulate_pairs(const uint2* __restrict__ entries, const uint32_t* __restrict__ misc, const G1Packed* __restrict__ pts,
-                       const int32_t* __restrict__ pfx, const int32_t* __restrict__ itot, size_t L,
-                       G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ seg_ids, G1Xyzz29* __restrict__ seg_parts) {
-  pairrun_bwd_lane(blockIdx.x * 64 + threadIdx.x, RUN, misc[1], reinterpret_cast<const PairEntry*>(entries), pts, pfx, itot, L,
-                   buckets, seg_ids, seg_parts);
 }
 
 // --------------------------------------------------------------- P4
@@ -799,83 +553,54 @@ __global__ void __launch_bounds__(64, 2)
 // and NO degeneracy test here: a flush is a plain store, so the lanes of a wave
 // (which change bucket at different iterations) never wait for each other's
 // checks.  P5 tests every bucket once and redoes the rare bad one carefully.
-// The point an entry refers to, in the memory form of its stream:
-//   packed  (LIMB = false)  the level-1 stream: entry.y indexes the Montgomery point table (G1Packed, 64 B), bit 31 negates
-//   limb    (LIMB = true)   the half-length stream behind the pair level (pair_tree.h): 2 x 9 lazy limbs (72 B) at the
-//                           entry's own position, no sign -- and no 256-bit unpack
-template <bool LIMB>
-struct StreamPoint;
-template <>
-struct StreamPoint<false> {
-  G1Packed k;
-  __device__ __forceinline__ void load(const void* __restrict__ base, uint32_t y) {
-    k = reinterpret_cast<const G1Packed*>(base)[y & kEntryIdx];
-  }
-  __device__ __forceinline__ G1Affine29 get(uint32_t y) const {
-    G1Affine29 p = g1a29_unpack(k);  // 256-bit words -> 9 x 29-bit limbs, in registers
-    if (y >> 31) p.y = fq29_neg(p.y);
-    return p;
-  }
-};
-template <>
-struct StreamPoint<true> {
-  int2 q[9];
-  __device__ __forceinline__ void load(const void* __restrict__ base, uint32_t y) {
-    const int2* src = reinterpret_cast<const int2*>(reinterpret_cast<const int32_t*>(base) + 18 * (size_t)(y & kEntryIdx));
-#pragma unroll
-    for (int i = 0; i < 9; ++i) q[i] = src[i];
-  }
-  __device__ __forceinline__ G1Affine29 get(uint32_t) const {
-    G1Affine29 p;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      (i < 4 ? p.x.v[2 * i] : i == 4 ? p.x.v[8] : p.y.v[2 * i - 9]) = q[i].x;
-      (i < 4 ? p.x.v[2 * i + 1] : i == 4 ? p.y.v[0] : p.y.v[2 * i - 8]) = q[i].y;
-    }
-    return p;
-  }
-};
+// An entry is {bucket id, point index | sign << 31}; the point is gathered from the Montgomery table (G1Packed: ONE
+// 64-byte sector) and its 9 x 29-bit limbs are cut out of the 256-bit words in registers.
+// (Measured and removed, round 3: a batched-affine pair level in front of this kernel, in two forms -- bit-exact, 25-37 %
+// slower per MSM because its passes are random 64-byte gathers at 3.6-3.8 TB/s: profiles/r03_ab_pair_tree.txt, git tag
+// exp/pair-tree.)
+constexpr uint32_t kEntryIdx = 0x7FFFFFFFu;  // point index bits of an entry's .y (bit 31 = negate)
 
-template <int RUN, bool LIMB>
+__device__ __forceinline__ G1Affine29 entry_point(const G1Packed& k, uint32_t y) {
+  G1Affine29 p = g1a29_unpack(k);
+  if (y >> 31) p.y = fq29_neg(p.y);
+  return p;
+}
+
+template <int RUN>
 __global__ void __launch_bounds__(64, SNARKV_ACC_WAVES)
     k_accumulate(const uint2* __restrict__ entries, const uint32_t* __restrict__ total_ptr,
-                 const void* __restrict__ pts, G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ seg_ids,
-                 G1Xyzz29* __restrict__ seg_parts, const uint32_t* __restrict__ M, uint32_t mstride, uint32_t key_lo,
-                 uint32_t key_hi, uint32_t nkeys, uint32_t run_base) {
-  // the part of the sorted stream that belongs to level-1 keys [key_lo, key_hi): a group of windows
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t gfirst = M[(size_t)key_lo * mstride];
-  uint32_t stop = key_hi < nkeys ? M[(size_t)key_hi * mstride] : *total_ptr;
-  uint64_t begin64 = (uint64_t)gfirst + (uint64_t)t * RUN;
+                 const G1Packed* __restrict__ pts, G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ seg_ids,
+                 G1Xyzz29* __restrict__ seg_parts) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t stop = *total_ptr;
+  const uint64_t begin64 = (uint64_t)t * RUN;
   if (begin64 >= stop) return;
-  uint32_t begin = (uint32_t)begin64;
-  uint32_t end = (stop - begin > (uint32_t)RUN) ? begin + RUN : stop;
-  size_t slot = (size_t)run_base + t;
+  const uint32_t begin = (uint32_t)begin64;
+  const uint32_t end = (stop - begin > (uint32_t)RUN) ? begin + RUN : stop;
+  const size_t slot = t;
   uint32_t cur = entries[begin].x;
   bool first = true, fresh = true;
   G1Xyzz29 acc = xyzz29_identity();
-  // a bucket's part of the run is finished: head partial, or complete interior bucket.  `fresh` here means that part
-  // held skip entries only (pads / cancelled pairs of the pair level): no partial (kNoBucket), the bucket stays zero.
+  // a bucket's part of the run is finished: head partial, or complete interior bucket
   auto flush = [&]() {
     if (first) {
-      seg_ids[2 * slot] = fresh ? kNoBucket : cur;
-      if (!fresh) seg_parts[2 * slot] = acc;
+      seg_ids[2 * slot] = cur;
+      seg_parts[2 * slot] = acc;
       first = false;
-    } else if (!fresh) {
+    } else {
       buckets[cur] = acc;  // complete interior bucket
     }
   };
   // software pipeline: the (entry -> point) gather of step e+1 is issued before the ~2 200-instruction
   // mixed addition of step e; two steps per trip with ping-pong registers, so the prefetched point is
   // consumed where it was loaded instead of being copied (18 moves per entry)
-  auto step = [&](const uint2& ent, const StreamPoint<LIMB>& pk) {
+  auto step = [&](const uint2& ent, const G1Packed& pk) {
     if (ent.x != cur) {
       flush();
       cur = ent.x;
       fresh = true;
     }
-    if (ent.y & kEntrySkip) return;
-    G1Affine29 p = pk.get(ent.y);
+    G1Affine29 p = entry_point(pk, ent.y);
     if (fresh) {
       acc.x = p.x;
       acc.y = p.y;
@@ -887,55 +612,52 @@ __global__ void __launch_bounds__(64, SNARKV_ACC_WAVES)
     }
   };
   uint2 ent0 = entries[begin], ent1 = ent0;
-  StreamPoint<LIMB> p0, p1;
-  p0.load(pts, ent0.y);
-  p1 = p0;
+  G1Packed p0 = pts[ent0.y & kEntryIdx], p1 = p0;
 #pragma unroll 1
   for (uint32_t e = begin; e < end; e += 2) {
     if (e + 1 < end) {
       ent1 = entries[e + 1];
-      p1.load(pts, ent1.y);
+      p1 = pts[ent1.y & kEntryIdx];
     }
     step(ent0, p0);
     if (e + 1 < end) {
       if (e + 2 < end) {
         ent0 = entries[e + 2];
-        p0.load(pts, ent0.y);
+        p0 = pts[ent0.y & kEntryIdx];
       }
       step(ent1, p1);
     }
   }
   if (first) {
-    seg_ids[2 * slot] = fresh ? kNoBucket : cur;
-    if (!fresh) seg_parts[2 * slot] = acc;
+    seg_ids[2 * slot] = cur;
+    seg_parts[2 * slot] = acc;
     seg_ids[2 * slot + 1] = kNoBucket;
   } else {
-    seg_ids[2 * slot + 1] = fresh ? kNoBucket : cur;
-    if (!fresh) seg_parts[2 * slot + 1] = acc;
+    seg_ids[2 * slot + 1] = cur;
+    seg_parts[2 * slot + 1] = acc;
   }
 }
 
 // --------------------------------------------------------------- P5
 // Careful recomputation of one bucket straight from its sorted entries (the
 // rare bucket in which a fast addition met P = +-Q: duplicate / opposite bases).
-template <bool LIMB>
 __device__ __noinline__ G1Xyzz29 bucket_from_entries_careful(const uint2* __restrict__ entries,
-                                                             const void* __restrict__ pts, uint32_t o,
+                                                             const G1Packed* __restrict__ pts, uint32_t o,
                                                              uint32_t cnt, uint32_t first, uint32_t stride) {
   G1Xyzz29 acc = xyzz29_identity();
   for (uint32_t e = o + first; e < o + cnt; e += stride) {
     uint2 ent = entries[e];
-    if (ent.y & kEntrySkip) continue;
-    StreamPoint<LIMB> sp;
-    sp.load(pts, ent.y);
-    G1Affine29 p = sp.get(ent.y);
-    if (LIMB) {  // lazy sums of the pair level: the careful adder compares and stores, so squeeze them first
-      p.x = fq29_canon_residue(p.x);
-      p.y = fq29_canon_residue(p.y);
-    }
+    G1Affine29 p = entry_point(pts[ent.y & kEntryIdx], ent.y);
     xyzz29_madd_careful(acc, p);
   }
   return acc;
+}
+
+// the run slots [s0, s1] that hold partials of a bucket whose entries are entries[o, o + cnt): runs are cut every
+// p.krun entries from the start of the sorted stream
+__device__ __forceinline__ void run_span(const PipParams& p, uint32_t o, uint32_t cnt, size_t& s0, size_t& s1) {
+  s0 = o / p.krun;
+  s1 = (o + cnt - 1) / p.krun;
 }
 
 // One lane per bucket: stitch the partials of the runs it spans (or pick up the
@@ -943,76 +665,24 @@ __device__ __noinline__ G1Xyzz29 bucket_from_entries_careful(const uint2* __rest
 // bucket: a fast addition that met an exceptional case left ZZ = 0 (mod p)
 // (sticky through every later addition; an exact-zero ZZ partial is the same
 // signal, a run never legitimately produces the identity).
-// the run slots [s0, s1] that hold partials of bucket b (its entries are entries[o, o + cnt)): runs are cut every kRun
-// entries counted from the start of the bucket's WINDOW GROUP in the sorted stream, slots are reserved per window
-__device__ __forceinline__ void run_span(const PipParams& p, const uint32_t* __restrict__ M, uint32_t b, uint32_t o,
-                                         uint32_t cnt, size_t& s0, size_t& s1) {
-  uint32_t w0 = ((b / p.B) / p.gsz) * p.gsz;  // first window of the group
-  uint32_t first = M[(size_t)(w0 * p.SB) * p.mstride];
-  size_t base = (size_t)w0 * p.rpw;
-  s0 = base + (o - first) / p.krun;
-  s1 = base + (o + cnt - 1 - first) / p.krun;
-}
-
-// Two kinds of workgroup in ONE launch:
-//   blocks [0, bucket_blocks)   one lane per BUCKET, as described above -- except the buckets that span exactly two
-//                               consecutive runs, which are left to
-//   blocks beyond (PAIRS only)  one lane per RUN BOUNDARY t | t + 1: when the last bucket of run t continues as the head of
-//                               run t + 1 and ends there (the common case: with 64 entries per bucket on average nearly
-//                               every boundary falls inside a bucket), the lane adds the two partials -- ONE addition per
-//                               lane, every lane of the wavefront in the same instruction, where the per-bucket loop runs
-//                               its (inlined once) adder for every (run, head / tail) position at which ANY of its 64
-//                               buckets has a partial: ~2.4 additions' worth of issue slots per wavefront for ~0.7 useful.
-template <bool LIMB>
+// (Measured and removed, round 3: run-boundary lanes for the buckets that span exactly two runs -- level in a batch,
+// 13 % slower alone: profiles/r03_ab_combine_pack.txt, git tag exp/combine-pairs.)
 __global__ void __launch_bounds__(64)
     k_combine(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, PipParams p,
-              const uint2* __restrict__ entries, const void* __restrict__ pts,
+              const uint2* __restrict__ entries, const G1Packed* __restrict__ pts,
               const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
-              G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list,
-              const uint32_t* __restrict__ M, uint32_t b_lo, uint32_t b_hi, uint32_t bucket_blocks, uint32_t run_base,
-              uint32_t nruns) {
+              G1Xyzz29* __restrict__ buckets, uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list) {
   SNARKV_RAISE_PRIO();
-  constexpr bool PAIRS = !LIMB && SNARKV_COMBINE_PAIRS;  // (the half-length stream has all-skip partials, recorded as kNoBucket: per bucket only)
-  if (PAIRS && blockIdx.x >= bucket_blocks) {
-    const uint32_t t = (blockIdx.x - bucket_blocks) * blockDim.x + threadIdx.x;
-    if (t + 1 >= nruns) return;
-    const size_t s = (size_t)run_base + t;
-    int h = 1;
-    uint32_t b = seg_ids[2 * s + 1];  // the bucket of run t's last entry: its tail partial, or its head when the run is one bucket
-    if (b == kNoBucket) {
-      b = seg_ids[2 * s];
-      h = 0;
-    }
-    if (b < b_lo || b >= b_hi || seg_ids[2 * (s + 1)] != b) return;  // (slots beyond the stream hold stale ids: range-checked, then
-    const uint32_t cnt = counts[b], o = offsets[b];                     //  confirmed against the bucket's own span below)
-    if (cnt == 0) return;
-    size_t s0, s1;
-    run_span(p, M, b, o, cnt, s0, s1);
-    if (s0 != s || s1 != s + 1) return;
-    G1Xyzz29 acc = seg_parts[2 * s + h];
-    const G1Xyzz29 part = seg_parts[2 * (s + 1)];
-    bool bad = xyzz29_is_identity(acc) || xyzz29_is_identity(part);
-    if (!bad) {
-      xyzz29_add_fast(acc, part);
-      bad = fq29_limbs_all_zero(acc.zz) || xyzz29_is_degenerate(acc);
-    }
-    if (bad) acc = xyzz29_sanitize(bucket_from_entries_careful<LIMB>(entries, pts, o, cnt, 0, 1));
-    buckets[b] = acc;
-    return;
-  }
-  uint32_t b = b_lo + blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= b_hi) return;
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.nb) return;
   uint32_t cnt = counts[b];
-  if (cnt == 0) {  // empty bucket = the identity (all-zero ZZ)
-#if SNARKV_FUSED_FILLS & 4
-    if (!LIMB) buckets[b] = xyzz29_identity();  // (behind the pair level the grid is zero-filled: all-skip buckets rely on it)
-#endif
+  if (cnt == 0) {  // empty bucket = the identity (all-zero ZZ): stored here, the grid is never memset
+    buckets[b] = xyzz29_identity();
     return;
   }
   uint32_t o = offsets[b];
   size_t s0, s1;
-  run_span(p, M, b, o, cnt, s0, s1);
-  if (PAIRS && s1 == s0 + 1) return;  // a run-boundary lane's
+  run_span(p, o, cnt, s0, s1);
   if (s1 - s0 >= kBigSpan) {  // skewed scalars: hand the bucket to k_combine_big
     uint32_t slot = atomicAdd(big_count, 1u);
     if (slot < kMaxBig) {
@@ -1034,7 +704,7 @@ __global__ void __launch_bounds__(64)
   }
   if (!touched) acc = buckets[b];  // interior to one run: P4 stored it
   bad = bad || xyzz29_is_degenerate(acc);
-  if (bad) acc = xyzz29_sanitize(bucket_from_entries_careful<LIMB>(entries, pts, o, cnt, 0, 1));
+  if (bad) acc = xyzz29_sanitize(bucket_from_entries_careful(entries, pts, o, cnt, 0, 1));
   if (touched || bad) buckets[b] = acc;
 }
 
@@ -1042,26 +712,23 @@ __global__ void __launch_bounds__(64)
 // equal puts n entries into one bucket per window): one 256-lane workgroup per
 // bucket, lane-strided careful adds + LDS tree.  If any partial is degenerate
 // the whole bucket is recomputed carefully from its entries.
-template <bool LIMB>
 __global__ void __launch_bounds__(256)
     k_combine_big(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                  const uint2* __restrict__ entries, const void* __restrict__ pts,
+                  const uint2* __restrict__ entries, const G1Packed* __restrict__ pts,
                   const uint32_t* __restrict__ seg_ids, const G1Xyzz29* __restrict__ seg_parts,
                   G1Xyzz29* __restrict__ buckets, const uint32_t* __restrict__ big_count,
-                  const uint32_t* __restrict__ big_list, PipParams p, const uint32_t* __restrict__ M) {
+                  const uint32_t* __restrict__ big_list, PipParams p) {
   SNARKV_RAISE_PRIO();
   __shared__ G1Xyzz29 sh[256];
   __shared__ int any_bad;
   uint32_t nbig = *big_count < kMaxBig ? *big_count : kMaxBig;
-  // the grid walks the list (normally empty: uniform scalars have no bucket over kBigSpan runs).  A grid sized for the
-  // worst case is thousands of 256-lane workgroups that only exit -- 0.3 ms of queueing behind the accumulation's wavefronts
-  // in a batch (profiles/r03_overlap_batch.txt); capping it at 128 workgroups (SNARKV_BIG_GRID) was measured: one MSM alone
-  // -0.5 %, the batch +0.9 % (the freed stream time goes to one more resident accumulation, which slows the others): level
+  // the grid walks the list (normally empty: uniform scalars have no bucket over kBigSpan runs); capping the grid at
+  // 128 workgroups was measured level (one MSM alone -0.5 %, the batch +0.9 %)
   for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
     uint32_t b = big_list[bi];
     uint32_t o = offsets[b], cnt = counts[b];
     size_t s0, s1;
-    run_span(p, M, b, o, cnt, s0, s1);
+    run_span(p, o, cnt, s0, s1);
     if (threadIdx.x == 0) any_bad = 0;
     __syncthreads();
     G1Xyzz29 acc = xyzz29_identity();
@@ -1075,7 +742,7 @@ __global__ void __launch_bounds__(256)
         }
     if (bad) atomicOr(&any_bad, 1);
     __syncthreads();
-    if (any_bad) acc = bucket_from_entries_careful<LIMB>(entries, pts, o, cnt, threadIdx.x, 256);
+    if (any_bad) acc = bucket_from_entries_careful(entries, pts, o, cnt, threadIdx.x, 256);
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (uint32_t st = 128; st >= 1; st >>= 1) {
@@ -1193,7 +860,7 @@ constexpr int kLog2BlockBuckets = 6 + kLog2Chunk;  // a P6 block covers 64 * kCh
 __global__ void __launch_bounds__(64)
     k_bucket_reduce(const G1Xyzz29* __restrict__ buckets, G1Xyzz29* __restrict__ block_parts, PipParams p,
                     uint32_t chunks_per_window, uint32_t blocks_per_window) {
-  if (!p.low_prio) SNARKV_RAISE_PRIO();
+  SNARKV_RAISE_PRIO();
   __shared__ G1Xyzz29 sh[64];
   uint32_t w = blockIdx.x / blocks_per_window, bj = blockIdx.x % blocks_per_window;
   uint32_t j = bj * 64 + threadIdx.x;
@@ -1369,7 +1036,10 @@ int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_p
 //   PIP_PHASE_TAIL  P6-P9  bucket reduce, shift chains, final            (bucket grid -> d_out)
 // `ctx` owns the scratch (its own stream is not used unless passed as `st`); `d_grid`, when given, is the bucket grid
 // to fill in place of the context's own (a batch lays its MSMs' grids end to end for one batched tail).  Every call
-// of one MSM must pass the same n / window_bits; window groups and stage marks exist only for PIP_PHASE_ALL.
+// of one MSM must pass the same n / window_bits; stage marks exist only for PIP_PHASE_ALL.
+// (Measured and removed: window groups -- the sorted stream accumulated group by group, top windows first, each group's
+// tail on a side stream: 1 / 2 / 4 / 8 groups -> single-MSM latency 2.23 / 2.55 / 2.90 / 4.51 ms,
+// profiles/r02_sweep_gsz.txt, git tag exp/window-groups.)
 int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, const void* d_scalars, const void* d_points,
                                 size_t n, int window_bits, void* d_out, bool partial_out, void* d_buckets_out,
                                 void* d_grid) {
@@ -1377,7 +1047,6 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   p.w0 = 0;
   p.wper = 0;
   p.chunk_log2 = (uint32_t)kLog2Chunk;
-  p.low_prio = 0;
   p.n = (uint32_t)n;
   p.c = window_bits > 0 ? window_bits : balance_window_bits(default_window_bits(n));
   if (p.c < 2) p.c = 2;
@@ -1392,14 +1061,10 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   p.low_bits = (p.c - 1) - high;
   p.SB = p.B >> p.low_bits;
   p.nkeys = (uint32_t)p.W * p.SB;
-  // tile: >= 16 items per (tile, key) stream so partition writes fill 128-byte lines
+  // the staged partition (k_sort_scatter_staged) owns one tile of exactly SNARKV_TILE_BASE scalars per workgroup
   p.tile = SNARKV_TILE_BASE;
-  // the staged partition (k_sort_scatter_staged) owns one tile of exactly SNARKV_TILE_BASE scalars per workgroup; the
-  // direct form needs >= 16 items per (tile, key) stream for its writes to fill lines
+  static_assert(kStageItems * kHalves <= 32, "a staged lane keeps one sign bit per entry in a 32-bit word");
   const size_t lds_staged = ((size_t)3 * p.SB + 16 + (p.SB & 1u)) * 4 + (size_t)kStageScalars * kHalves * 8;
-  const char* direct = getenv("SNARKV_SCATTER_DIRECT");  // test / comparison knob: the direct partition kernel
-  const bool staged = SNARKV_SCATTER_STAGED && lds_staged <= 96 * 1024 && kStageItems * kHalves <= 32 && !(direct && atoi(direct));
-  while (!staged && p.tile < 65536 && (uint64_t)p.tile * kHalves * p.W < 16ull * p.nkeys) p.tile *= 2;
   p.nblk = (uint32_t)((n + p.tile - 1) / p.tile);
   p.mstride = p.nblk | 1u;
   uint64_t max_entries = (uint64_t)kHalves * (uint64_t)n * (uint64_t)p.W;
@@ -1407,52 +1072,12 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
     set_last_error("pippenger: n=%zu out of range", n);
     return SNARKV_ERR_LENGTH;
   }
-  // window groups: OFF by default (one group = the whole stream).  Measured on MI355X at 2^20 points (VERDICT r1 item 7,
-  // profiles/r02_sweep_gsz.txt): 1 / 2 / 4 / 8 groups -> single-MSM latency 2.23 / 2.55 / 2.90 / 4.51 ms.  A group's
-  // k_accumulate holds a third (or less) of the wave slots for a full wave lifetime (64 entries ~ 0.33 ms), so the
-  // accumulation stretches by more than the tail it hides, and the LAST group's tail -- bucket reduce and the two
-  // 14-step folds, latency-bound whatever the window count -- stays on the critical path.  SNARKV_PIP_GSZ=<windows per
-  // group> switches it on for experiments; results are the same bytes.
-  p.gsz = (uint32_t)p.W;
-  if (const char* e = getenv("SNARKV_PIP_GSZ")) {
-    int v = atoi(e);
-    if (v >= 1) p.gsz = (uint32_t)std::min(v, p.W);
+  if ((size_t)p.nkeys * 4 > 65536 || lds_staged > 96 * 1024) {
+    set_last_error("pippenger: key table too large (nkeys=%u)", p.nkeys);
+    return SNARKV_ERR_LENGTH;
   }
-  if (((uint32_t)p.W + p.gsz - 1) / p.gsz > 8) p.gsz = ((uint32_t)p.W + 7) / 8;  // at most 8 groups (events, counters)
-  if (phases != PIP_PHASE_ALL) p.gsz = (uint32_t)p.W;
-  p.krun = ctx->throughput_mode ? (uint32_t)kRunThroughput : latency_run_length((uint64_t)kHalves * n * (uint64_t)p.W);
-  // The pair level (P3b, pair_tree.h): one batched-affine addition level in front of the accumulation.  It adds seven
-  // launches and a latency chain (forward, the inversion levels, ONE field inversion, backward) to an MSM, so it is for
-  // callers that keep several MSMs in flight (the throughput hint; always on a batch's jobs and the chunk pipeline's
-  // lanes).  SNARKV_PAIR_TREE = 0 never, 1 with the hint (default), 2 always.  Same bytes either way.
-  int tree_mode = SNARKV_PAIR_TREE_DEFAULT;
-  if (const char* e = getenv("SNARKV_PAIR_TREE")) tree_mode = atoi(e);
-  const uint32_t nbins_l2 = 1u << p.low_bits;
-  const uint64_t pad_room = (uint64_t)p.nkeys * (nbins_l2 + 2) + 2;  // k_sort_level2, pad mode: room for one pad per bin
-  const bool tree = (tree_mode >= 2 || (tree_mode == 1 && ctx->throughput_mode)) && p.gsz == (uint32_t)p.W &&
-                    (uint64_t)kHalves * n < kEntrySkip && max_entries + pad_room < kEntrySkip;
-  // 3: the FUSED form -- the backward pass adds the pair sums straight into the bucket accumulators (k_accumulate_pairs);
-  // run lengths 64 / 96 only (the two the kernels are instantiated for)
-  const bool fused = tree && tree_mode == 3 && (p.krun == (uint32_t)kRun || p.krun == (uint32_t)kRunThroughput);
-  p.pad = tree ? 1u : 0u;
-  const uint64_t cap_entries = max_entries + (tree ? pad_room : 0);
-  auto round_up = [](uint64_t v, uint64_t q) { return (v + q - 1) / q * q; };
-  const uint64_t slots_max = (cap_entries + 1) / 2;                        // pair slots (upper bound; the live count is on the device)
-  const uint64_t pairL = round_up((slots_max + kPairM - 1) / kPairM, kPairT);  // lanes of k_pair_fwd / k_pair_bwd
-  const uint64_t pairS = pairL * kPairM;                                   // slot capacity = stride of the prefix array
-  uint64_t binvN[8];
-  int binv_levels = 0;  // binvN[0] = the pair lanes' totals; level q + 1 = the lane totals of level q; the last one <= kBinvFinalMax
-  const uint64_t fusedL = round_up((cap_entries + p.krun - 1) / p.krun + 1, 256);  // lanes of the fused kernels (every one writes a total)
-  binvN[0] = fused ? fusedL : pairL;
-  while (binvN[binv_levels] > kBinvFinalMax && binv_levels < 6) {
-    binvN[binv_levels + 1] = round_up((binvN[binv_levels] + kBinvM - 1) / kBinvM, kPairT);
-    ++binv_levels;
-  }
-  p.rpw = (uint32_t)(((uint64_t)kHalves * n + p.krun - 1) / p.krun) + 1;
-  uint32_t max_runs = (uint32_t)p.W * p.rpw;  // run slots (head / tail partial each)
-  // ... behind the pair level the runs are cut from the half-length stream, whose pad room can outweigh a tiny MSM's entries
-  if (tree) max_runs = std::max<uint32_t>(max_runs, (uint32_t)((slots_max + p.krun - 1) / p.krun) + 1);
-  if (fused) max_runs = std::max<uint32_t>(max_runs, (uint32_t)fusedL);
+  p.krun = ctx->throughput_mode ? (uint32_t)kRunThroughput : latency_run_length(max_entries);
+  const uint32_t max_runs = (uint32_t)((max_entries + p.krun - 1) / p.krun) + 1;  // run slots (head / tail partial each)
   uint32_t mcount = p.nkeys * p.mstride;
   uint32_t scan_blocks = (mcount + 1023) / 1024;
   uint32_t chunks_per_window = (p.B + kChunk - 1) / kChunk;
@@ -1466,7 +1091,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   SNARKV_TRY(ctx_reserve(ctx, SLOT_OFFSETS, (size_t)p.nb * 4, &d_offsets));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_CURSOR, (size_t)mcount * 4, &d_M));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_BLOCKSUMS, (size_t)scan_blocks * 4 + 64, &d_blocksum));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_ENTRIES, cap_entries * 8, &d_entries));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_ENTRIES, max_entries * 8, &d_entries));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SORT_TMP, max_entries * 8, &d_tmp));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SEG_IDS, (size_t)max_runs * 8, &d_seg_ids));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SEG_PARTIALS, (size_t)max_runs * 2 * sizeof(G1Xyzz29), &d_seg_parts));
@@ -1475,30 +1100,9 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   SNARKV_TRY(ctx_reserve(ctx, SLOT_CHUNK_PARTIALS, 2 * (size_t)blocks_per_window * p.W * sizeof(G1Xyzz29), &d_wave));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_SHIFTED, (size_t)p.W * sizeof(G1Xyzz29), &d_shift));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_MISC, 64, &d_misc));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_BIG_LIST, (size_t)kMaxBig * 4 * 8, &d_big));
-  uint32_t* d_total = (uint32_t*)d_misc;  // [0] entries, [1] padded entries, [2] pair slots, [3] = 0, [4..11] big-bucket counters
-  void *d_counts2 = nullptr, *d_offsets2 = nullptr, *d_pair_pfx = nullptr, *d_pair_tot = nullptr, *d_pair_pts = nullptr,
-       *d_pair_entries = nullptr;
-  size_t binv_off[8] = {0};  // level q: values at d_pair_tot + binv_off[q] (9 x binvN[q] words), prefixes right behind
-  if (tree) {
-    SNARKV_TRY(ctx_reserve(ctx, SLOT_COUNTS2, (size_t)p.nb * 4, &d_counts2));
-    SNARKV_TRY(ctx_reserve(ctx, SLOT_OFFSETS2, (size_t)p.nb * 4, &d_offsets2));
-    SNARKV_TRY(ctx_reserve(ctx, SLOT_PAIR_PFX, fused ? (size_t)fusedL * (p.krun / 2) * 36 : (size_t)pairS * 36, &d_pair_pfx));
-    size_t words = 0;
-    for (int q = 0; q <= binv_levels; ++q) {
-      binv_off[q] = words;
-      words += 2 * 9 * (size_t)binvN[q];
-    }
-    SNARKV_TRY(ctx_reserve(ctx, SLOT_PAIR_TOT, words * 4, &d_pair_tot));
-    if (!fused) {
-      SNARKV_TRY(ctx_reserve(ctx, SLOT_PAIR_PTS, (size_t)pairS * 72, &d_pair_pts));
-      SNARKV_TRY(ctx_reserve(ctx, SLOT_PAIR_ENTRIES, (size_t)pairS * 8, &d_pair_entries));
-    }
-  }
-  if ((size_t)p.nkeys * 4 > 65536) {
-    set_last_error("pippenger: key table too large (nkeys=%u)", p.nkeys);
-    return SNARKV_ERR_LENGTH;
-  }
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_BIG_LIST, (size_t)kMaxBig * 4, &d_big));
+  uint32_t* d_total = (uint32_t*)d_misc;  // [0] entries of the sorted stream, [4] big-bucket counter of k_combine
+  uint32_t* d_big_count = d_total + 4;
 
   const bool tm = ctx->stage_timing && phases == PIP_PHASE_ALL;
   const bool tm_acc = ctx->stage_timing && phases == PIP_PHASE_ACC;  // a batch times its accumulations: ev[3] .. ev[4] .. ev[5]
@@ -1512,10 +1116,10 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
     ctx->ev_ready = true;
   }
   STAGE_MARK();  // 0
-  size_t lds1 = (size_t)p.nkeys * 4;
   if (phases & PIP_PHASE_SORT) {
-    if (!(SNARKV_FUSED_FILLS & 1)) SNARKV_HIP(hipMemsetAsync(d_M, 0, (size_t)mcount * 4, st));  // padding columns must read as zero
-    hipLaunchKernelGGL(k_prepare, dim3(p.nblk), dim3(SNARKV_PREP_THREADS), lds1, st, (const uint32_t*)d_scalars,
+    // (no hipMemsetAsync anywhere: the matrix' padding column, the counters and the empty buckets are filled by
+    // k_prepare / k_sort_level2 / k_combine themselves -- 60 fill launches per 20-job batch less, level in time)
+    hipLaunchKernelGGL(k_prepare, dim3(p.nblk), dim3(SNARKV_PREP_THREADS), (size_t)p.nkeys * 4, st, (const uint32_t*)d_scalars,
                        (const uint32_t*)d_points, (G1Packed*)d_pts, (uint4*)d_glv, p, (uint32_t*)d_M);
     STAGE_MARK();  // 1: prepare (GLV split, phi(P), to Montgomery) + digit histogram
     hipLaunchKernelGGL(k_scan_local, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (uint32_t*)d_blocksum, mcount);
@@ -1523,167 +1127,61 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
     hipLaunchKernelGGL(k_scan_add, dim3(scan_blocks), dim3(256), 0, st, (uint32_t*)d_M, (const uint32_t*)d_blocksum,
                        mcount);
     STAGE_MARK();  // 2: scan
-    if (staged) {
-      static std::atomic<uint64_t> attr_set{0};  // per device: more dynamic LDS than the 64 KiB default
-      const uint64_t bit = 1ull << (ctx->device & 63);
-      if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
-        SNARKV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_scatter_staged),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        attr_set.fetch_or(bit, std::memory_order_relaxed);
-      }
-      hipLaunchKernelGGL(k_sort_scatter_staged, dim3(p.nblk), dim3(SNARKV_TILE_THREADS), lds_staged, st, (const uint4*)d_glv,
-                         p, (const uint32_t*)d_M, (uint2*)d_tmp);
-    } else {
-      hipLaunchKernelGGL(k_sort_scatter, dim3(p.nblk), dim3(SNARKV_TILE_THREADS), lds1, st, (const uint4*)d_glv, p,
-                         (const uint32_t*)d_M, (uint2*)d_tmp);
+    static std::atomic<uint64_t> attr_set{0};  // per device: more dynamic LDS than the 64 KiB default
+    const uint64_t bit = 1ull << (ctx->device & 63);
+    if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
+      SNARKV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_scatter_staged),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
-    size_t lds2 = ((size_t)nbins_l2 + SNARKV_L2_THREADS + 1) * 4 + ((size_t)kSortCap + (tree ? nbins_l2 + 4 : 0)) * 8;
-    if (lds2 > 64 * 1024) {
-      static std::atomic<uint64_t> attr2_set{0};  // per device: more dynamic LDS than the 64 KiB default
-      const uint64_t bit = 1ull << (ctx->device & 63);
-      if (!(attr2_set.load(std::memory_order_relaxed) & bit)) {
-        SNARKV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_level2),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        attr2_set.fetch_or(bit, std::memory_order_relaxed);
-      }
-    }
+    hipLaunchKernelGGL(k_sort_scatter_staged, dim3(p.nblk), dim3(SNARKV_TILE_THREADS), lds_staged, st, (const uint4*)d_glv,
+                       p, (const uint32_t*)d_M, (uint2*)d_tmp);
+    const uint32_t nbins_l2 = 1u << p.low_bits;
+    const size_t lds2 = ((size_t)nbins_l2 + SNARKV_L2_THREADS + 1) * 4 + (size_t)kSortCap * 8;  // < 64 KiB: nbins <= 1 024
     hipLaunchKernelGGL(k_sort_level2, dim3(p.nkeys), dim3(SNARKV_L2_THREADS), lds2, st, (const uint2*)d_tmp, (const uint32_t*)d_M,
-                       d_total, p, (uint2*)d_entries, (uint32_t*)d_counts, (uint32_t*)d_offsets, (uint32_t*)d_counts2,
-                       (uint32_t*)d_offsets2);
+                       d_total, p, (uint2*)d_entries, (uint32_t*)d_counts, (uint32_t*)d_offsets);
   }
   STAGE_MARK();  // 3: partition + level-2 sort
-  if ((phases & PIP_PHASE_ACC) && (!(SNARKV_FUSED_FILLS & 4) || tree))
-    SNARKV_HIP(hipMemsetAsync(d_buckets, 0, (size_t)p.nb * sizeof(G1Xyzz29), st));
-  // (Tried, both measured on MI355X and dropped: one shared stream for every k_accumulate of a device -- a software
-  // pipeline across the in-flight MSMs -- and s_setprio on / off for the other kernels: the in-flight plateau moved by
-  // less than the run-to-run spread either way.  SQ counters show why: k_accumulate keeps every SIMD's VALU busy
-  // (3.7 cycles per instruction at 3 waves) at the ~1.8 GHz the power budget allows, and the other kernels add 25 %
-  // more VALU instructions: the plateau is total issued work, not scheduling.  DESIGN.md section 4.
-  // Re-measured with the throughput hint's 96-entry runs (profiles/r02_sweep_accstream2.txt): serialising the
-  // accumulations on one stream now LOSES 15-25 % (1.50 -> 1.75-1.89 ms per MSM): 2 731 wavefronts leave a ninth of the
-  // slots and the whole drain of every launch empty unless another MSM's accumulation overlaps it.)
-  uint32_t* d_big_count = d_total + 4;  // one counter per window group
-  if ((phases & PIP_PHASE_ACC) && !(SNARKV_FUSED_FILLS & 2)) SNARKV_HIP(hipMemsetAsync(d_total + 3, 0, 4 * 9, st));  // [3] = 0 (stream start of the pair level's half-length stream) + the counters
+  // (Scheduling experiments measured and dropped -- a shared accumulate stream across in-flight MSMs, s_setprio on / off,
+  // an occupancy cap on k_accumulate: DESIGN.md section 4.  The plateau is total issued work, not scheduling.)
   if (tm_acc) SNARKV_HIP(hipEventRecord(ctx->ev[3], st));
-  if (tree && (phases & PIP_PHASE_ACC)) {
-    int32_t* tot0 = (int32_t*)d_pair_tot + binv_off[0];
-    if (fused)
-      hipLaunchKernelGGL(p.krun == (uint32_t)kRun ? k_pairrun_fwd<kRun> : k_pairrun_fwd<kRunThroughput>, dim3((uint32_t)(fusedL / 64)),
-                         dim3(64), 0, st, (const uint2*)d_entries, (const uint32_t*)d_total, (const G1Packed*)d_pts,
-                         (int32_t*)d_pair_pfx, tot0, (size_t)fusedL);
-    else
-      hipLaunchKernelGGL(k_pair_fwd, dim3((uint32_t)(pairL / kPairT)), dim3(kPairT), 0, st, (const uint2*)d_entries,
-                         (const uint32_t*)d_total, (const G1Packed*)d_pts, (int32_t*)d_pair_pfx, (size_t)pairS, tot0, (size_t)pairL);
-    for (int q = 0; q < binv_levels; ++q) {
-      int32_t* a = (int32_t*)d_pair_tot + binv_off[q];
-      hipLaunchKernelGGL(k_binv_up, dim3((uint32_t)(binvN[q + 1] / kPairT)), dim3(kPairT), 0, st, (const int32_t*)a,
-                         (uint32_t)binvN[q], (size_t)binvN[q], a + 9 * binvN[q], (int32_t*)d_pair_tot + binv_off[q + 1],
-                         (size_t)binvN[q + 1]);
-    }
-    hipLaunchKernelGGL(k_binv_final, dim3(1), dim3(kPairT), 0, st, (int32_t*)d_pair_tot + binv_off[binv_levels],
-                       (uint32_t)binvN[binv_levels], (size_t)binvN[binv_levels]);
-    for (int q = binv_levels - 1; q >= 0; --q) {
-      int32_t* a = (int32_t*)d_pair_tot + binv_off[q];
-      hipLaunchKernelGGL(k_binv_down, dim3((uint32_t)(binvN[q + 1] / kPairT)), dim3(kPairT), 0, st, a, (uint32_t)binvN[q],
-                         (size_t)binvN[q], (const int32_t*)(a + 9 * binvN[q]), (const int32_t*)d_pair_tot + binv_off[q + 1],
-                         (size_t)binvN[q + 1]);
-    }
-    if (fused)
-      hipLaunchKernelGGL(p.krun == (uint32_t)kRun ? k_accumulate_pairs<kRun> : k_accumulate_pairs<kRunThroughput>,
-                         dim3((uint32_t)(fusedL / 64)), dim3(64), 0, st, (const uint2*)d_entries, (const uint32_t*)d_total,
-                         (const G1Packed*)d_pts, (const int32_t*)d_pair_pfx, (const int32_t*)tot0, (size_t)fusedL,
-                         (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids, (G1Xyzz29*)d_seg_parts);
-    else
-      hipLaunchKernelGGL(k_pair_bwd, dim3((uint32_t)(pairL / kPairT)), dim3(kPairT), 0, st, (const uint2*)d_entries,
-                         (const uint32_t*)d_total, (const G1Packed*)d_pts, (const int32_t*)d_pair_pfx, (size_t)pairS,
-                         (const int32_t*)tot0, (size_t)pairL, (uint2*)d_pair_entries, (int32_t*)d_pair_pts);
+  if (phases & PIP_PHASE_ACC) {
+    auto acc_kernel = p.krun == 16u ? k_accumulate<16> : p.krun == 32u ? k_accumulate<32>
+                      : p.krun == (uint32_t)kRun ? k_accumulate<kRun> : k_accumulate<kRunThroughput>;
+    hipLaunchKernelGGL(acc_kernel, dim3((max_runs + 63) / 64), dim3(64), 0, st, (const uint2*)d_entries,
+                       (const uint32_t*)d_total, (const G1Packed*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
+                       (G1Xyzz29*)d_seg_parts);
   }
-  // Window groups (opt-in, see p.gsz above), top first: group j = windows [j gsz, (j+1) gsz).  Its accumulation runs on the context's stream;
-  // its tail -- combine, bucket reduce, the 2^(c w) shift chain (the longest for the TOP windows: c w doublings, a
-  // dependency chain no lane count shortens) -- runs on a side stream under the accumulation of the groups below it.
-  // Only the bottom group's tail (the shortest chains) is left exposed.
-  const uint32_t ngroups = ((uint32_t)p.W + p.gsz - 1) / p.gsz;
-  // (Measured and dropped: capping k_accumulate at 12 / 10 / 9 / 8 wavefronts per CU with an unused LDS allocation, so that
-  // the other kernels of in-flight MSMs always find wave slots: 3-9 % slower the tighter the cap -- the accumulation
-  // needs its three wavefronts per SIMD more than the others need the room.)
-  if (ngroups > 1) {
-    SNARKV_TRY(ctx_lanes(ctx));
-    if (!ctx->grp_ev_ready) {
-      for (int i = 0; i < 16; ++i) SNARKV_HIP(hipEventCreateWithFlags(&ctx->grp_ev[i], hipEventDisableTiming));
-      ctx->grp_ev_ready = true;
-    }
+  STAGE_MARK();  // 4: bucket accumulate
+  if (tm_acc) SNARKV_HIP(hipEventRecord(ctx->ev[4], st));
+  if (phases & PIP_PHASE_ACC) {
+    hipLaunchKernelGGL(k_combine, dim3((p.nb + 63) / 64), dim3(64), 0, st, (const uint32_t*)d_counts,
+                       (const uint32_t*)d_offsets, p, (const uint2*)d_entries, (const G1Packed*)d_pts,
+                       (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets, d_big_count,
+                       (uint32_t*)d_big);
+    // one workgroup per oversized bucket; idle workgroups exit at once
+    const uint32_t big_grid = std::min<uint32_t>(max_runs / kBigSpan + 1, kBigGrid);
+    hipLaunchKernelGGL(k_combine_big, dim3(big_grid), dim3(256), 0, st, (const uint32_t*)d_counts,
+                       (const uint32_t*)d_offsets, (const uint2*)d_entries, (const G1Packed*)d_pts,
+                       (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets,
+                       (const uint32_t*)d_big_count, (const uint32_t*)d_big, p);
+    if (tm_acc) SNARKV_HIP(hipEventRecord(ctx->ev[5], st));
   }
-  for (int j = (int)ngroups - 1; j >= 0; --j) {
-    const uint32_t w0 = (uint32_t)j * p.gsz, w1 = std::min<uint32_t>((uint32_t)p.W, w0 + p.gsz), wcount = w1 - w0;
-    const uint32_t lanes = fused ? (uint32_t)fusedL : tree ? (uint32_t)((slots_max + p.krun - 1) / p.krun) : wcount * p.rpw;
-    auto acc_kernel = p.krun == 16u ? k_accumulate<16, false> : p.krun == 32u ? k_accumulate<32, false>
-                      : p.krun == (uint32_t)kRun ? k_accumulate<kRun, false> : k_accumulate<kRunThroughput, false>;
-    auto acc_tree = p.krun == 16u ? k_accumulate<16, true> : p.krun == 32u ? k_accumulate<32, true>
-                    : p.krun == (uint32_t)kRun ? k_accumulate<kRun, true> : k_accumulate<kRunThroughput, true>;
-    if ((phases & PIP_PHASE_ACC) && !tree)
-      hipLaunchKernelGGL(acc_kernel, dim3((lanes + 63) / 64), dim3(64), 0, st, (const uint2*)d_entries,
-                         (const uint32_t*)d_total, (const void*)d_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
-                         (G1Xyzz29*)d_seg_parts, (const uint32_t*)d_M, p.mstride, w0 * p.SB, w1 * p.SB, p.nkeys, w0 * p.rpw);
-    // behind the pair level: the half-length stream [0, misc[2]) of (entry, lazy-limb point) pairs, one window group
-    if ((phases & PIP_PHASE_ACC) && tree && !fused)
-      hipLaunchKernelGGL(acc_tree, dim3((lanes + 63) / 64), dim3(64), 0, st, (const uint2*)d_pair_entries,
-                         (const uint32_t*)(d_total + 2), (const void*)d_pair_pts, (G1Xyzz29*)d_buckets, (uint32_t*)d_seg_ids,
-                         (G1Xyzz29*)d_seg_parts, (const uint32_t*)(d_total + 3), 0u, 0u, p.nkeys, p.nkeys, 0u);
-    hipStream_t ts = st;
-    if (j > 0) {
-      ts = ctx->sub[j & 1]->stream;
-      SNARKV_HIP(hipEventRecord(ctx->grp_ev[j], st));
-      SNARKV_HIP(hipStreamWaitEvent(ts, ctx->grp_ev[j], 0));
-    } else {
-      STAGE_MARK();  // 4: bucket accumulate (all groups)
-      if (tm_acc) SNARKV_HIP(hipEventRecord(ctx->ev[4], st));
-    }
-    if (phases & PIP_PHASE_ACC) {
-      // the stream the partials were cut from: the sorted entries, or the pair level's half-length stream
-      // (the fused form cuts its runs from the PADDED level-1 stream itself: packed points, stream start 0)
-      const bool half = tree && !fused;
-      const uint32_t* cc = (const uint32_t*)(half ? d_counts2 : d_counts);
-      const uint32_t* co = (const uint32_t*)(half ? d_offsets2 : d_offsets);
-      const uint2* ce = (const uint2*)(half ? d_pair_entries : d_entries);
-      const void* cp = half ? (const void*)d_pair_pts : (const void*)d_pts;
-      const uint32_t* cm = tree ? (const uint32_t*)(d_total + 3) : (const uint32_t*)d_M;
-      const uint32_t bucket_blocks = (wcount * p.B + 63) / 64, pair_blocks = (tree || !SNARKV_COMBINE_PAIRS) ? 0u : (lanes + 63) / 64;
-      hipLaunchKernelGGL(half ? k_combine<true> : k_combine<false>, dim3(bucket_blocks + pair_blocks), dim3(64), 0, ts, cc, co, p,
-                         ce, cp, (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets,
-                         d_big_count + j, (uint32_t*)d_big + (size_t)j * kMaxBig, cm, w0 * p.B, w1 * p.B, bucket_blocks,
-                         w0 * p.rpw, lanes);
-      // one workgroup per oversized bucket; idle workgroups exit at once
-      uint32_t big_grid = (uint32_t)(lanes / kBigSpan + 1);
-      uint32_t big_cap = kBigGrid;
-      if (const char* e = getenv("SNARKV_BIG_GRID")) big_cap = (uint32_t)std::max(1, std::min((int)kMaxBig, atoi(e)));  // A/B knob
-      if (big_grid > big_cap) big_grid = big_cap;
-      hipLaunchKernelGGL(half ? k_combine_big<true> : k_combine_big<false>, dim3(big_grid), dim3(256), 0, ts, cc, co, ce, cp,
-                         (const uint32_t*)d_seg_ids, (const G1Xyzz29*)d_seg_parts, (G1Xyzz29*)d_buckets,
-                         (const uint32_t*)(d_big_count + j), (const uint32_t*)d_big + (size_t)j * kMaxBig, p, cm);
-      if (tm_acc) SNARKV_HIP(hipEventRecord(ctx->ev[5], st));
-    }
-    if (j == 0) STAGE_MARK();  // 5: bucket combine (the bottom group's: the exposed one)
-    if (!d_buckets_out && (phases & PIP_PHASE_TAIL)) {
-      PipParams pg = p;
-      pg.W = (int)wcount;
-      pg.w0 = p.w0 + w0;
-      G1Xyzz29* gw = (G1Xyzz29*)d_wave + 2 * (size_t)blocks_per_window * w0;
-      hipLaunchKernelGGL(k_bucket_reduce, dim3(blocks_per_window * wcount), dim3(64), 0, ts,
-                         (const G1Xyzz29*)d_buckets + (size_t)w0 * p.B, gw, pg, chunks_per_window, blocks_per_window);
-      if (j == 0) STAGE_MARK();  // 6: bucket reduce
-      hipLaunchKernelGGL(k_shift_windows, dim3(wcount), dim3(64), 0, ts, (const G1Xyzz29*)gw, (G1Xyzz29*)d_shift + w0, pg,
-                         blocks_per_window);
-    }
-    if (j > 0) SNARKV_HIP(hipEventRecord(ctx->grp_ev[8 + j], ts));
-  }
-  for (uint32_t j = 1; j < ngroups; ++j) SNARKV_HIP(hipStreamWaitEvent(st, ctx->grp_ev[8 + j], 0));
+  STAGE_MARK();  // 5: bucket combine
   if (d_buckets_out) {  // bucket-sharded variant: hand the (sanitised) bucket sums out and stop here
     if (phases & PIP_PHASE_ACC)
       SNARKV_HIP(hipMemcpyAsync(d_buckets_out, d_buckets, (size_t)p.nb * sizeof(G1Xyzz29), hipMemcpyDeviceToDevice, st));
     SNARKV_HIP(hipGetLastError());
     return SNARKV_OK;
   }
-  STAGE_MARK();  // 7: window sums + 2^(cw) shift chains (all groups joined)
+  if (phases & PIP_PHASE_TAIL)
+    hipLaunchKernelGGL(k_bucket_reduce, dim3(blocks_per_window * p.W), dim3(64), 0, st, (const G1Xyzz29*)d_buckets,
+                       (G1Xyzz29*)d_wave, p, chunks_per_window, blocks_per_window);
+  STAGE_MARK();  // 6: bucket reduce
+  if (phases & PIP_PHASE_TAIL)
+    hipLaunchKernelGGL(k_shift_windows, dim3(p.W), dim3(64), 0, st, (const G1Xyzz29*)d_wave, (G1Xyzz29*)d_shift, p,
+                       blocks_per_window);
+  STAGE_MARK();  // 7: window sums + 2^(cw) shift chains
   if (phases & PIP_PHASE_TAIL)
     hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, st, (const G1Xyzz29*)d_shift, (uint32_t)p.W, (uint32_t*)d_out,
                        partial_out ? 1 : 0);
@@ -1770,7 +1268,7 @@ static int tail_geometry(snarkv_ctx* ctx, uint32_t c, uint32_t windows, uint32_t
   // Buckets per k_bucket_reduce lane.  One MSM's reduce is a latency chain on a few hundred wavefronts: short chunks (8
   // buckets: 16 serial additions + the 14-step fold) keep it short.  A batch's tail reduces `jobs` grids -- thousands of
   // wavefronts, throughput-bound -- where the fold is 14 of every 30 additions: chunks of 32 do 78 additions per 32
-  // buckets instead of 120.  SNARKV_TAIL_CHUNK_LOG2 overrides (A/B knob); same bytes for any chunk size.
+  // buckets instead of 120.  Same bytes for any chunk size.
   // The chunk is picked by that model: rounds of the machine's wave slots (194 VGPRs: two wavefronts per SIMD) x the
   // additions of one wavefront, 2 chunk + 14 -- 16 buckets per lane for 20 or 40 grids of 8 x 32 768 buckets, 8 for one.
   uint32_t cl2 = (uint32_t)kLog2Chunk;
@@ -1787,7 +1285,6 @@ static int tail_geometry(snarkv_ctx* ctx, uint32_t c, uint32_t windows, uint32_t
       if (cost < best) best = cost, cl2 = q;
     }
   }
-  if (const char* e = getenv("SNARKV_TAIL_CHUNK_LOG2")) cl2 = (uint32_t)std::max(1, std::min(8, atoi(e)));
   while ((1u << cl2) > p.B && cl2 > 0) --cl2;
   p.chunk_log2 = cl2;
   const uint32_t chunk = 1u << cl2;
@@ -1798,35 +1295,17 @@ static int tail_geometry(snarkv_ctx* ctx, uint32_t c, uint32_t windows, uint32_t
   return SNARKV_OK;
 }
 
-// ONE job's bucket reduce of a batched tail, on a stream of the caller's choice (its accumulation stream: the reduce then
-// runs UNDER the other jobs' accumulations, at the default wave priority, instead of in the exposed tail of the batch);
-// `job` indexes the grids laid end to end and the block partials of launch_buckets_reduce_many(..., reduce_done = true)
-int launch_bucket_reduce_job(snarkv_ctx* ctx, hipStream_t st, const void* d_grids, uint32_t c, uint32_t windows,
-                             uint32_t jobs, uint32_t job) {
-  TailGeom g;
-  SNARKV_TRY(tail_geometry(ctx, c, windows, jobs, &g));
-  PipParams pj = g.p;
-  pj.W = (int)windows;
-  pj.low_prio = 1;
-  hipLaunchKernelGGL(k_bucket_reduce, dim3(g.blocks_per_window * windows), dim3(64), 0, st,
-                     (const G1Xyzz29*)d_grids + (size_t)job * windows * g.p.B,
-                     (G1Xyzz29*)g.d_wave + 2 * (size_t)g.blocks_per_window * windows * job, pj, g.chunks_per_window,
-                     g.blocks_per_window);
-  SNARKV_HIP(hipGetLastError());
-  return SNARKV_OK;
-}
-
 // The tail of `jobs` MSMs of the same geometry whose bucket grids lie end to end ([job][window][bucket]): three
-// launches for all of them, out[job] = the affine sum (64 B) or the projective partial.  reduce_done: the jobs' bucket
-// reduces were launched one by one already (launch_bucket_reduce_job): only the shift chains and the final sums are left.
+// launches for all of them, out[job] = the affine sum (64 B) or the projective partial.
+// (Measured and removed: every job's bucket reduce behind its own combine, under the other jobs' accumulations --
+// 1-14 % slower, profiles/r03_ab_scheduling.txt, git tag exp/many-tail.)
 int launch_buckets_reduce_many(snarkv_ctx* ctx, hipStream_t st, const void* d_grids, uint32_t c, uint32_t windows,
-                               uint32_t jobs, void* d_out, bool partial_out, bool reduce_done) {
+                               uint32_t jobs, void* d_out, bool partial_out) {
   TailGeom g;
   SNARKV_TRY(tail_geometry(ctx, c, windows, jobs, &g));
   const uint32_t wtotal = windows * jobs;
-  if (!reduce_done)
-    hipLaunchKernelGGL(k_bucket_reduce, dim3(g.blocks_per_window * wtotal), dim3(64), 0, st, (const G1Xyzz29*)d_grids,
-                       (G1Xyzz29*)g.d_wave, g.p, g.chunks_per_window, g.blocks_per_window);
+  hipLaunchKernelGGL(k_bucket_reduce, dim3(g.blocks_per_window * wtotal), dim3(64), 0, st, (const G1Xyzz29*)d_grids,
+                     (G1Xyzz29*)g.d_wave, g.p, g.chunks_per_window, g.blocks_per_window);
   hipLaunchKernelGGL(k_shift_windows, dim3(wtotal), dim3(64), 0, st, (const G1Xyzz29*)g.d_wave, (G1Xyzz29*)g.d_shift, g.p,
                      g.blocks_per_window);
   hipLaunchKernelGGL(k_final, dim3(jobs), dim3(64), 0, st, (const G1Xyzz29*)g.d_shift, windows, (uint32_t*)d_out,

@@ -59,7 +59,7 @@ struct Aggregator {
                                          std::vector<PlonkProof<MOS>>& pfs) {
     const size_t n = proofs.size();
     const int T = 5, RATE = 4, R_F = 8, R_P = 60;  // examples/evm-verifier-with-accumulator.rs:36-39
-    const bool trace = getenv("SNARKV_HOST_TRACE") != nullptr;  // dev aid: the four stages of this phase on stderr
+    constexpr bool trace = SNARKV_HOST_TRACE != 0;  // dev aid: the four stages of this phase on stderr
     using clk = std::chrono::steady_clock;
     auto lap = [last = clk::now()]() mutable {
       auto now = clk::now();

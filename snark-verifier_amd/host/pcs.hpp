@@ -27,6 +27,9 @@
 
 #include "msm.hpp"
 
+#ifndef SNARKV_HOST_TRACE
+#define SNARKV_HOST_TRACE 0  // build with -DSNARKV_HOST_TRACE=1 for the host / device split of the phases on stderr (dev aid)
+#endif
 namespace snarkv_host {
 
 using L = GpuNativeLoader;
@@ -180,7 +183,7 @@ struct KzgAs {
     std::vector<std::vector<std::pair<Fr, G1Affine>>> two;
     two.push_back(std::move(pairs.first));
     two.push_back(std::move(pairs.second));
-    const bool trace = getenv("SNARKV_HOST_TRACE") != nullptr;  // dev aid: host / device split of this step on stderr
+    constexpr bool trace = SNARKV_HOST_TRACE != 0;  // dev aid: host / device split of this step on stderr
     auto t0 = std::chrono::steady_clock::now();
     auto pts = L::multi_scalar_multiplication_batch(two);
     if (trace)

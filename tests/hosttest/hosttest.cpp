@@ -9,7 +9,6 @@
 #include "../../snark-verifier_amd/csrc/pairing_coop.h"
 #include "../../snark-verifier_amd/csrc/pairing_coop29.h"
 #include "../../snark-verifier_amd/csrc/fr29.h"
-#include "../../snark-verifier_amd/csrc/pair_tree.h"
 #include <vector>
 
 using namespace snarkv;
@@ -321,88 +320,5 @@ extern "C" int ht_g1_pack_roundtrip(const uint8_t* p64, uint8_t* out64, uint8_t*
   g1a29_to_canonical(b, o);
   memcpy(out64, o, 64);
   return ok;
-}
-
-// ---------------- batched-affine pair level (pair_tree.h): every lane of the kernels run one by one on the host --------
-// points64: npts canonical affine points; entries: 2 * nslots (bucket, y) words; T lanes per workgroup, m slots per lane,
-// m2 elements per lane of the inversion levels (recursion down to <= final_max values, inverted one by one here where
-// the device uses an LDS product tree).  out_entries: nslots (bucket, y); out_xy: nslots canonical affine points
-// ((0, 0) for skip slots).  Returns the number of inversion levels used.
-extern "C" int ht_pair_level(const uint8_t* points64, uint32_t npts, const uint32_t* entries, uint32_t nslots, uint32_t T, uint32_t m,
-                  uint32_t m2, uint32_t final_max, uint32_t* out_entries, uint8_t* out_xy) {
-  std::vector<G1Packed> pts(npts);
-  for (uint32_t i = 0; i < npts; ++i) pts[i] = g1a29_pack(load_g1_29(points64 + 64 * i));
-  const PairEntry* ent = reinterpret_cast<const PairEntry*>(entries);
-  auto lanes_of = [&](size_t n, uint32_t mm) { size_t l = (n + mm - 1) / mm; return (l + T - 1) / T * T; };
-  const size_t L1 = lanes_of(nslots, m), S = L1 * m;
-  std::vector<int32_t> pfx(9 * S, 0), tot(9 * L1, 0);
-  for (uint32_t j = 0; j < L1; ++j) pair_fwd_lane(j, T, m, nslots, ent, pts.data(), pfx.data(), S, tot.data(), L1);
-  // recursive inversion of tot[0 .. L1)
-  struct Level { std::vector<int32_t> a, pfx; size_t n, stride; };
-  std::vector<Level> lv;
-  lv.push_back(Level{tot, {}, L1, L1});
-  int levels = 0;
-  while (lv.back().n > final_max && lanes_of(lv.back().n, m2) < lv.back().n) {  // a level shrinks n by m2 until one workgroup is left
-    Level& cur = lv.back();
-    const size_t Ln = lanes_of(cur.n, m2);
-    cur.pfx.assign(9 * cur.stride, 0);
-    std::vector<int32_t> t2(9 * Ln, 0);
-    for (uint32_t j = 0; j < Ln; ++j) binv_up_lane(j, T, m2, (uint32_t)cur.n, cur.a.data(), cur.stride, cur.pfx.data(), t2.data(), Ln);
-    lv.push_back(Level{t2, {}, Ln, Ln});  // every lane of a touched workgroup holds a value (1 for a lane without elements)
-    ++levels;
-  }
-  {
-    Level& f = lv.back();
-    for (size_t e = 0; e < f.n; ++e) soa_store(f.a.data(), f.stride, e, fq29_inv(soa_load(f.a.data(), f.stride, e)));
-  }
-  for (size_t q = lv.size() - 1; q > 0; --q) {
-    Level& up = lv[q - 1];
-    Level& dn = lv[q];
-    for (uint32_t j = 0; j < dn.stride; ++j) binv_down_lane(j, T, m2, (uint32_t)up.n, up.a.data(), up.stride, up.pfx.data(), dn.a.data(), dn.stride);
-  }
-  std::vector<int32_t> opts(18 * S, 0);
-  std::vector<PairEntry> oent(S);
-  for (uint32_t j = 0; j < L1; ++j)
-    pair_bwd_lane(j, T, m, nslots, ent, pts.data(), pfx.data(), S, lv[0].a.data(), L1, oent.data(), opts.data());
-  for (uint32_t i = 0; i < nslots; ++i) {
-    out_entries[2 * i] = oent[i].bucket;
-    out_entries[2 * i + 1] = oent[i].y;
-    G1Affine29 r;
-    for (int l = 0; l < 9; ++l) {
-      r.x.v[l] = opts[18 * (size_t)i + l];
-      r.y.v[l] = opts[18 * (size_t)i + 9 + l];
-    }
-    if (oent[i].y & kEntrySkip) memset(out_xy + 64 * (size_t)i, 0, 64);
-    else store_g1_29(r, out_xy + 64 * (size_t)i);
-  }
-  return levels;
-}
-
-// ---------------- fused pair RUNS (pair_tree.h pairrun_*): forward lanes, inverted totals, backward + accumulate lanes, then a
-// plain per-bucket stitch of what they left (interior buckets + head / tail partials) -> one affine point per bucket.
-// entries: `stop` (even) padded (bucket, y) entries sorted by bucket, buckets numbered 0 .. nb-1.
-extern "C" int ht_pair_runs(const uint8_t* points64, uint32_t npts, const uint32_t* entries, uint32_t stop, uint32_t RUN,
-                            uint32_t nb, uint8_t* out_xy) {
-  std::vector<G1Packed> pts(npts);
-  for (uint32_t i = 0; i < npts; ++i) pts[i] = g1a29_pack(load_g1_29(points64 + 64 * i));
-  const PairEntry* ent = reinterpret_cast<const PairEntry*>(entries);
-  const uint32_t lanes = ((stop + RUN - 1) / RUN + 63) / 64 * 64 + 64;  // whole wavefronts, one of them beyond the stream
-  const uint32_t H = RUN / 2;
-  std::vector<int32_t> pfx((size_t)(lanes / 64) * H * 9 * 64, 0), tot(9 * (size_t)lanes, 0);
-  for (uint32_t t = 0; t < lanes; ++t) pairrun_fwd_lane(t, RUN, stop, ent, pts.data(), pfx.data(), tot.data(), lanes);
-  for (uint32_t t = 0; t < lanes; ++t) soa_store(tot.data(), lanes, t, fq29_inv(soa_load(tot.data(), lanes, t)));
-  std::vector<G1Xyzz29> buckets(nb, xyzz29_identity()), parts(2 * (size_t)lanes, xyzz29_identity());
-  std::vector<uint32_t> ids(2 * (size_t)lanes, 0xFFFFFFFFu);
-  for (uint32_t t = 0; t < lanes; ++t)
-    pairrun_bwd_lane(t, RUN, stop, ent, pts.data(), pfx.data(), tot.data(), lanes, buckets.data(), ids.data(), parts.data());
-  int nparts = 0;
-  for (size_t q = 0; q < ids.size(); ++q)
-    if (ids[q] != 0xFFFFFFFFu) {
-      if (ids[q] >= nb) return -1;
-      xyzz29_add_careful(buckets[ids[q]], parts[q]);
-      ++nparts;
-    }
-  for (uint32_t b = 0; b < nb; ++b) store_g1_29(xyzz29_to_affine(buckets[b]), out_xy + 64 * (size_t)b);
-  return nparts;
 }
 

@@ -319,11 +319,8 @@ def test_packed_point_memory_form_roundtrip(hosttest_lib):
         assert out.raw == b
         if b != bytes(64):
             x, y = int.from_bytes(b[:32], "little"), int.from_bytes(b[32:], "little")
-            # the packed form (g1_29.h): the plain 256-bit integer, or with -DSNARKV_PACK_SPREAD=1 word i = limb i | bits 3i..3i+2
-            # of limb 8 << 29 (a measured, level, alternative: profiles/r03_ab_combine_pack.txt)
+            # the packed form (g1_29.h): each coordinate's canonical Montgomery residue as a plain 256-bit integer
             for raw32, v in ((packed.raw[:32], x * R261 % O.P), (packed.raw[32:], y * R261 % O.P)):
-                limbs = [(v >> (29 * i)) & ((1 << 29) - 1) for i in range(9)]
-                words = [limbs[i] | (((limbs[8] >> (3 * i)) & 7) << 29) for i in range(8)]
-                assert raw32 in (v.to_bytes(32, "little"), b"".join(w.to_bytes(4, "little") for w in words))
+                assert raw32 == v.to_bytes(32, "little")
         else:
             assert packed.raw == bytes(64)

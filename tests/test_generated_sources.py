@@ -19,7 +19,7 @@ def test_curve_constants_are_current():
 
 
 def test_multiplier_bodies_are_current():
-    for kind in ("mul", "mul2", "sqr", "mul_mul", "sqr_sqr", "mul2_mul"):
+    for kind in ("mul", "mul2", "sqr"):
         assert _gen("gen_fq29_mul_asm.py", kind) == open(os.path.join(CSRC, "fq29_%s_asm.inc" % kind)).read(), kind
     assert _gen("gen_fq_mul_asm.py") == open(os.path.join(CSRC, "fq_mul_asm.inc")).read()
 

@@ -164,19 +164,6 @@ def test_chunk_base_chain_one_lane_and_four_lanes(gpu_ctx, golden_msm, quad, mon
         assert gpu_ctx.msm_naive(s, p) == C.msm_pippenger(s, p, 2), chunks
 
 
-def test_direct_partition_kernel_gives_the_same_bytes(gpu_ctx, monkeypatch):
-    """`k_sort_scatter` (8-byte stores straight to HBM, tiles grown until a (tile, key) run fills a line) is the fall-back
-    of the LDS-staged partition for geometries whose counters do not fit; SNARKV_SCATTER_DIRECT=1 forces it."""
-    n = 150_000
-    s, p = C.sample_scalars(41, n), C.sample_points(42, n)
-    exp = C.msm_pippenger(s, p, 8)
-    assert gpu_ctx.msm_pippenger(s, p) == exp
-    monkeypatch.setenv("SNARKV_SCATTER_DIRECT", "1")
-    assert gpu_ctx.msm_pippenger(s, p) == exp
-    for m in (1, 2049, 5000):
-        assert gpu_ctx.msm_pippenger(s[:32 * m], p[:64 * m]) == C.msm_pippenger(s[:32 * m], p[:64 * m], 2), m
-
-
 def test_device_sampler_matches_oracle(gpu_ctx):
     import torch
 

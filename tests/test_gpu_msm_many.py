@@ -168,95 +168,3 @@ def test_the_bench_shape_2p20_times_six_against_single_calls():
     assert st["total"] > 0 and st["bucket_accumulate"] > 0
     assert bytes(out.cpu().numpy()) == got
     ctx.close()
-
-
-def test_batch_replayed_as_a_hipgraph(monkeypatch):
-    """SNARKV_MANY_GRAPH=1: the first call of a (pointers, sizes, options) key runs eagerly, the second is captured as a
-    hipGraph over the five streams and launched, later ones are replays -- every call must give the oracle's bytes; NEW
-    input contents behind the same pointers are picked up by a replay; a different key, a ragged batch (per-job tails)
-    and a call that makes a job context's scratch grow (the captured addresses are stale: epoch check) fall back / are
-    re-captured correctly; with the knob off the same calls give the same bytes."""
-    import torch
-
-    import snark_verifier_amd as sv
-
-    monkeypatch.setenv("SNARKV_MANY_GRAPH", "1")
-    ctx = sv.Context(0)
-    seen = 0
-    for sizes in ([30000] * 5, [1, 2, 77, 4096, 65536, 3], [5000] * 70):  # uniform / ragged / several rounds
-        jobs = _jobs(sizes, 0x5100 + len(sizes))
-        exp = [C.msm_pippenger(s, p, 8) for s, p in jobs]
-        ds, dp = _upload(torch, jobs)
-        out = torch.zeros(64 * len(jobs), dtype=torch.uint8, device="cuda")
-        torch.cuda.synchronize()
-        args = ([t.data_ptr() for t in ds], [t.data_ptr() for t in dp], sizes, out.data_ptr())
-        for rep in range(4):  # eager, capture + launch, replay, replay
-            out.zero_()
-            torch.cuda.synchronize()
-            ctx.msm_pippenger_many_dev(*args)
-            ctx.sync()
-            raw = bytes(out.cpu().numpy())
-            assert [raw[64 * i:64 * i + 64] for i in range(len(jobs))] == exp, (sizes[:3], rep)
-        assert ctx.graph_replays() >= seen + 3  # capture + launch, replay, replay: the graph path really ran
-        seen = ctx.graph_replays()
-        # same pointers, new contents: a replay reads the buffers, not a snapshot
-        jobs2 = _jobs(sizes, 0x5200 + len(sizes))
-        for t, (s, _) in zip(ds, jobs2):
-            t.copy_(torch.frombuffer(bytearray(s), dtype=torch.uint8))
-        for t, (_, p) in zip(dp, jobs2):
-            t.copy_(torch.frombuffer(bytearray(p), dtype=torch.uint8))
-        torch.cuda.synchronize()
-        ctx.msm_pippenger_many_dev(*args)
-        ctx.sync()
-        raw = bytes(out.cpu().numpy())
-        assert [raw[64 * i:64 * i + 64] for i in range(len(jobs))] == [C.msm_pippenger(s, p, 8) for s, p in jobs2]
-    # a bigger batch on the same context grows the job contexts' scratch: the old graph's addresses are stale
-    small = _jobs([20000] * 3, 0x5300)
-    big = _jobs([90000] * 3, 0x5310)
-    sets = {}
-    for name, jobs in (("small", small), ("big", big)):
-        ds, dp = _upload(torch, jobs)
-        sets[name] = (jobs, ds, dp, torch.zeros(64 * len(jobs), dtype=torch.uint8, device="cuda"))
-    torch.cuda.synchronize()
-    for name in ("small", "small", "small", "big", "big", "big", "small", "small", "small"):
-        jobs, ds, dp, out = sets[name]
-        out.zero_()
-        torch.cuda.synchronize()
-        ctx.msm_pippenger_many_dev([t.data_ptr() for t in ds], [t.data_ptr() for t in dp], [len(s) // 32 for s, _ in jobs],
-                                   out.data_ptr())
-        ctx.sync()
-        raw = bytes(out.cpu().numpy())
-        assert [raw[64 * i:64 * i + 64] for i in range(len(jobs))] == [C.msm_pippenger(s, p, 8) for s, p in jobs], name
-    assert ctx.graph_replays() >= seen + 4  # small: capture + replay; big: capture + replay; small again: re-captured
-    ctx.close()
-
-
-def test_per_job_bucket_reduce_under_the_accumulations(gpu_ctx, monkeypatch):
-    """SNARKV_MANY_TAIL=1: every job's bucket reduce is enqueued behind its own combine (on its accumulation stream, default
-    wave priority) and the batched tail only runs the shift chains + final sums -- same bytes as the default schedule
-    (one batched reduce at the end), for one round and for several; the projective partials (not canonical: XYZZ
-    coordinates depend on the order of additions) fold to the same points."""
-    import torch
-
-    import snark_verifier_amd as sv
-
-    def folded(parts):
-        out = []
-        for pr in parts:
-            d = torch.frombuffer(bytearray(pr), dtype=torch.uint8).cuda()
-            o = torch.zeros(64, dtype=torch.uint8, device="cuda")
-            torch.cuda.synchronize()
-            gpu_ctx.fold_partials_dev(d.data_ptr(), 1, o.data_ptr())
-            gpu_ctx.sync()
-            out.append(bytes(o.cpu().numpy()))
-        return out
-
-    for sizes in ([40000] * 7, [3000] * 70):
-        jobs = _jobs(sizes, 0x5400 + len(sizes))
-        exp = [C.msm_pippenger(s, p, 8) for s, p in jobs]
-        for mode in ("1", "0"):
-            monkeypatch.setenv("SNARKV_MANY_TAIL", mode)
-            assert _many(gpu_ctx, torch, jobs) == exp, mode
-            part = _many(gpu_ctx, torch, jobs, partial=True)
-            assert all(len(x) == sv.G1_PARTIAL_BYTES for x in part)
-            assert folded(part[:5]) == exp[:5], mode
