@@ -23,19 +23,11 @@
 #include "pairing.h"
 #include "pairing_coop.h"
 #include "pairing_coop29.h"
+#include "decide_w.h"
+#include "decide_sched.hpp"
+#include <mutex>
 
 namespace snarkv {
-
-// line table in the lazy 29-bit form the decide kernel consumes:
-// c[0..5] = cy.c0, cy.c1, cx.c0, cx.c1, cw.c0, cw.c1 (canonical residues)
-struct LineCoeff29 {
-  Fq29 c[6];
-};
-struct G2Prepared29 {
-  LineCoeff29 line[kLinesPerG2];
-  uint32_t is_identity;
-  uint32_t pad[3];
-};
 
 size_t g2_prepared_bytes() { return sizeof(G2Prepared) + sizeof(G2Prepared29); }
 static size_t prep29_offset() { return 2 * sizeof(G2Prepared); }
@@ -558,6 +550,110 @@ __global__ void __launch_bounds__(kDecideThreads * TEAMS)
   }
 }
 
+// ------------------------------------------------------------------ D2: the program-driven latency form (decide_w.h)
+// One workgroup of four wavefronts per accumulator; wavefronts (2 d, 2 d + 1) are duo d.  LDS: the value array of
+// decide_w.h, then the program (two 8-byte operations per round).
+__global__ void __launch_bounds__(256)
+    k_decide_w(const G2Prepared29* __restrict__ prep, const uint32_t* __restrict__ accs, uint32_t m,
+               uint8_t* __restrict__ ok, uint32_t* __restrict__ gt_out, const uint2* __restrict__ prog, int rounds, int result) {
+  extern __shared__ Fq29P wt_lds[];
+  __shared__ Fq29 pt[2][2];
+  __shared__ int live[2];
+  __shared__ uint32_t canon[12][8];
+  uint2* prog_lds = reinterpret_cast<uint2*>(wt_lds + kWtValues);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, duo = wave >> 1, half = wave & 1;
+  const uint32_t i = blockIdx.x;
+  if (i >= m) return;
+  const uint32_t* a = accs + (size_t)i * 32;
+  if (tid < 4) {  // lhs.x, lhs.y, rhs.x, rhs.y -> Montgomery
+    uint32_t w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = a[8 * tid + j];
+    pt[tid >> 1][tid & 1] = fq29_canon_residue(fq29_from_canonical(w));
+  }
+  for (int j = tid; j < 52; j += 256) wt_store(wt_lds, kWtConstBase + j, wt_const_value(j));
+  for (int j = tid; j < 2 * rounds; j += 256) prog_lds[j] = prog[j];
+  __syncthreads();
+  if (tid < 2) live[tid] = !(fq29_limbs_all_zero(pt[tid][0]) && fq29_limbs_all_zero(pt[tid][1])) && !prep[tid].is_identity;
+  __syncthreads();
+  for (int t = tid; t < 2 * kLinesPerG2 * 3; t += 256) {
+    const int pair = t / (kLinesPerG2 * 3), rem = t % (kLinesPerG2 * 3);
+    wt_eval_line(wt_lds, prep, pair, rem / 3, rem % 3, pt[pair][0], pt[pair][1], live[pair] != 0);
+  }
+  __syncthreads();
+  uint2 raw = prog_lds[duo];
+  for (int r = 0; r < rounds; ++r) {
+    WtOp op;
+    {
+      const uint32_t w0 = __builtin_amdgcn_readfirstlane(raw.x), w1 = __builtin_amdgcn_readfirstlane(raw.y);
+      op.dst = (uint16_t)w0, op.a = (uint16_t)(w0 >> 16), op.b = (uint16_t)w1, op.kind = (uint8_t)(w1 >> 16), op.flags = (uint8_t)(w1 >> 24);
+    }
+    if (r + 1 < rounds) raw = prog_lds[2 * (r + 1) + duo];  // the next round's operation, fetched under this one
+    if (op.kind == WT_FQ2INV) {
+      if (half == 0 && lane == 0) wt_fq2inv(wt_lds, op);
+    } else if (op.kind != WT_IDLE) {
+      const Fq29 own = wt_squeeze(group8_sum(wt_task(wt_lds, op, half, lane)));
+      Fq29 other;  // the other u-component of the same power of w: 8 lanes away in the row
+#pragma unroll
+      for (int q = 0; q < 9; ++q) other.v[q] = (int32_t)dpp_u32<0x128>((uint32_t)own.v[q]);  // row_ror:8
+      wt_write(wt_lds, op, half, lane, own, other);
+    }
+    __syncthreads();
+  }
+  if (tid < 12) fq29_to_canonical(wt_load(wt_lds, result + tid), canon[tid]);
+  __syncthreads();
+  if (tid == 0 && ok) {
+    bool one = canon[0][0] == 1u;
+    for (int c = 0; c < 12; ++c)
+      for (int j = (c == 0 ? 1 : 0); j < 8; ++j) one = one && canon[c][j] == 0u;
+    ok[i] = one ? 1 : 0;
+  }
+  if (gt_out && tid < 12) {
+    // tower byte order: c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2  =  w^0, w^2, w^4, w^1, w^3, w^5
+    const int wexp[6] = {0, 2, 4, 1, 3, 5};
+    int pos = tid >> 1, e = tid & 1;
+    uint32_t* dstw = gt_out + (size_t)i * 96 + (size_t)(2 * pos + e) * 8;
+    for (int j = 0; j < 8; ++j) dstw[j] = canon[2 * wexp[pos] + e][j];
+  }
+}
+
+// the program, built once per process and uploaded once per device
+struct WtDeviceProgram {
+  uint2* d_prog = nullptr;
+  int rounds = 0, result = 0;
+  size_t lds_bytes = 0;
+};
+static int wt_device_program(int device, const WtDeviceProgram** out) {
+  static std::mutex mu;
+  static WtProgram host;
+  static bool built = false;
+  static WtDeviceProgram dev[64];
+  std::lock_guard<std::mutex> lk(mu);
+  if (!built) {
+    host = wt_build_program();
+    built = true;
+  }
+  WtDeviceProgram& d = dev[device & 63];
+  if (!d.d_prog) {
+    static_assert(sizeof(WtOp) == sizeof(uint2), "an operation is one 8-byte word pair");
+    std::vector<uint2> packed(host.ops.size());
+    for (size_t q = 0; q < host.ops.size(); ++q) {
+      const WtOp& o = host.ops[q];
+      packed[q].x = (uint32_t)o.dst | ((uint32_t)o.a << 16);
+      packed[q].y = (uint32_t)o.b | ((uint32_t)o.kind << 16) | ((uint32_t)o.flags << 24);
+    }
+    SNARKV_HIP(hipMalloc(&d.d_prog, packed.size() * sizeof(uint2)));
+    SNARKV_HIP(hipMemcpy(d.d_prog, packed.data(), packed.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    d.rounds = host.rounds;
+    d.result = host.result;
+    d.lds_bytes = kWtLdsBytes + packed.size() * sizeof(uint2);
+    SNARKV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_decide_w), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)d.lds_bytes));
+  }
+  *out = &d;
+  return SNARKV_OK;
+}
+
 int launch_g2_prepare(snarkv_ctx* ctx, const void* d_g2x2_256, void* d_prep) {
   hipLaunchKernelGGL(k_g2_prepare, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)d_g2x2_256,
                      (G2Prepared*)d_prep);
@@ -579,17 +675,23 @@ int launch_validate_g2(snarkv_ctx* ctx, const void* d_g2x2_256, int* bad_host) {
   return SNARKV_OK;
 }
 
-// Small batches take the two-team kernel (shorter dependency chain, 4 wavefronts
-// per accumulator); large ones the one-team kernel (2 wavefronts, same products,
-// four workgroups per CU).  Both give the same bits.
+// Which form: batches of up to 256 accumulators take the program-driven latency kernel (one workgroup of four
+// wavefronts + ~115 KiB of LDS per accumulator: one per CU), larger ones the one-team throughput kernel (two wavefronts,
+// 29 KiB, four workgroups per CU).  SNARKV_DECIDE_FORM = 1 (one team) / 2 (two teams, the round-3 latency form) / 3
+// (program) forces one (test / A-B knob).  All give the same bits.
 int launch_decide(snarkv_ctx* ctx, const void* d_prep, const void* d_accs, size_t m, void* d_ok, void* d_gt) {
   const G2Prepared29* d29 = reinterpret_cast<const G2Prepared29*>((const char*)d_prep + prep29_offset());
-  int teams = m <= 512 ? 2 : 1;
-  if (const char* e = getenv("SNARKV_DECIDE_TEAMS")) {
+  int form = m <= 256 ? 3 : 1;
+  if (const char* e = getenv("SNARKV_DECIDE_FORM")) {
     int v = atoi(e);
-    if (v == 1 || v == 2) teams = v;
+    if (v >= 1 && v <= 3) form = v;
   }
-  if (teams == 2)
+  if (form == 3) {
+    const WtDeviceProgram* wp = nullptr;
+    SNARKV_TRY(wt_device_program(ctx->device, &wp));
+    hipLaunchKernelGGL(k_decide_w, dim3((uint32_t)m), dim3(256), wp->lds_bytes, ctx->stream, d29, (const uint32_t*)d_accs,
+                       (uint32_t)m, (uint8_t*)d_ok, (uint32_t*)d_gt, (const uint2*)wp->d_prog, wp->rounds, wp->result);
+  } else if (form == 2)
     hipLaunchKernelGGL(k_decide<2>, dim3((uint32_t)m), dim3(2 * kDecideThreads), 0, ctx->stream, d29,
                        (const uint32_t*)d_accs, (uint32_t)m, (uint8_t*)d_ok, (uint32_t*)d_gt);
   else

@@ -9,6 +9,7 @@
 #include "../../snark-verifier_amd/csrc/pairing_coop.h"
 #include "../../snark-verifier_amd/csrc/pairing_coop29.h"
 #include "../../snark-verifier_amd/csrc/fr29.h"
+#include "../../snark-verifier_amd/csrc/decide_sched.hpp"
 #include <vector>
 
 using namespace snarkv;
@@ -273,6 +274,87 @@ void ht_coop3_fq12_mul_iter(const uint8_t* a, const uint8_t* b, int rounds, int 
     fc[c] = fq_from_canonical(w);
   }
   store_fq12(coop_tower_from_flat(fc), out);
+}
+// ---------------- the program-driven decide kernel (decide_w.h, decide_sched.hpp), emulated lane by lane -----------------
+// q2 = the two G2 points of the pairing product (256 bytes canonical; the SECOND one is used as given: pass -s_g2),
+// acc = lhs || rhs.  Runs the set-up and every round of the scheduled program exactly as k_decide_w does -- 4 wavefronts of
+// 64 lanes, tasks / squeeze / xi copies by the device functions, the DPP exchanges as explicit sums -- with every store of a
+// round applied after all its loads (the scheduler's contract: no operation writes what its round reads).
+// info[0..3] = rounds, LDS registers used, critical path, operations.  Returns 0, or -1 if a round violates the contract.
+int ht_decide_w(const uint8_t* q2, const uint8_t* acc, uint8_t* out, int* info) {
+  static WtProgram prog = wt_build_program();
+  std::vector<G2Prepared29> prep(2);
+  for (int k = 0; k < 2; ++k) {
+    G2Prepared* p8 = new G2Prepared;
+    G2Affine qa{load_fq2(q2 + 128 * k), load_fq2(q2 + 128 * k + 64)};
+    g2_prepare(qa, *p8);
+    prep[k].is_identity = p8->is_identity;
+    for (int idx = 0; idx < kLinesPerG2 && !p8->is_identity; ++idx) {
+      const LineCoeff& l = p8->line[idx];
+      const Fq* src[6] = {&l.cy.c0, &l.cy.c1, &l.cx.c0, &l.cx.c1, &l.cw.c0, &l.cw.c1};
+      for (int c = 0; c < 6; ++c) {
+        uint32_t w[8];
+        fq_to_canonical(*src[c], w);
+        prep[k].line[idx].c[c] = fq29_canon_residue(fq29_from_canonical(w));
+      }
+    }
+    delete p8;
+  }
+  std::vector<Fq29P> lds(kWtValues);
+  memset(lds.data(), 0, lds.size() * sizeof(Fq29P));
+  Fq29 pt[2][2];
+  int live[2];
+  for (int t = 0; t < 4; ++t) pt[t >> 1][t & 1] = fq29_canon_residue(load29(acc + 32 * t));
+  for (int j = 0; j < 52; ++j) wt_store(lds.data(), kWtConstBase + j, wt_const_value(j));
+  for (int k = 0; k < 2; ++k)
+    live[k] = !(fq29_limbs_all_zero(pt[k][0]) && fq29_limbs_all_zero(pt[k][1])) && !prep[k].is_identity;
+  for (int t = 0; t < 2 * kLinesPerG2 * 3; ++t) {
+    const int pair = t / (kLinesPerG2 * 3), rem = t % (kLinesPerG2 * 3);
+    wt_eval_line(lds.data(), prep.data(), pair, rem / 3, rem % 3, pt[pair][0], pt[pair][1], live[pair] != 0);
+  }
+  int nops = 0;
+  for (int r = 0; r < prog.rounds; ++r) {
+    std::vector<Fq29P> next = lds;  // stores land here
+    for (int duo = 0; duo < 2; ++duo) {
+      const WtOp op = prog.ops[2 * r + duo];
+      if (op.kind == WT_IDLE) continue;
+      ++nops;
+      // contract: the destination is not read by either operation of this round
+      for (int d2 = 0; d2 < 2; ++d2) {
+        const WtOp o2 = prog.ops[2 * r + d2];
+        if (o2.kind == WT_IDLE) continue;
+        const int lo = op.dst, hi = op.dst + (op.kind == WT_FQ2INV ? 2 : kWtDense);
+        if ((o2.a >= lo && o2.a < hi) || (o2.b >= lo && o2.b < hi)) return -1;
+        if (d2 != duo && o2.dst == op.dst) return -1;
+      }
+      if (op.kind == WT_FQ2INV) {
+        wt_fq2inv(next.data(), op);  // reads a's coefficient 0 (unchanged in `next`: nothing else wrote it), writes the scalar register
+        continue;
+      }
+      for (int half = 0; half < 2; ++half) {
+        Fq29 own[8];
+        for (int g = 0; g < 8; ++g) {
+          Fq29 s = fq29_zero();
+          for (int jj = 0; jj < 8; ++jj) {
+            const Fq29 v = wt_task(lds.data(), op, half, 8 * g + jj);
+            for (int q = 0; q < 9; ++q) s.v[q] = (int32_t)((uint32_t)s.v[q] + (uint32_t)v.v[q]);
+          }
+          own[g] = wt_squeeze(s);
+        }
+        for (int g = 0; g < 8; ++g) wt_write(next.data(), op, half, 8 * g, own[g], own[g ^ 1]);
+      }
+    }
+    lds.swap(next);
+  }
+  Fq fc[12];
+  for (int c = 0; c < 12; ++c) {
+    uint32_t w[8];
+    fq29_to_canonical(wt_load(lds.data(), prog.result + c), w);
+    fc[c] = fq_from_canonical(w);
+  }
+  store_fq12(coop_tower_from_flat(fc), out);
+  if (info) info[0] = prog.rounds, info[1] = prog.regs_used, info[2] = prog.critical_path, info[3] = nops;
+  return 0;
 }
 void ht29_fq_mul2(const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d, int neg_c, uint8_t* out) {
   Fq29 cc = load29(c);

@@ -324,3 +324,23 @@ def test_packed_point_memory_form_roundtrip(hosttest_lib):
                 assert raw32 == v.to_bytes(32, "little")
         else:
             assert packed.raw == bytes(64)
+
+
+def test_program_driven_decide_kernel_on_the_host(hosttest_lib, golden_decider):
+    """decide_w.h + decide_sched.hpp: the whole scheduled program of the latency decide kernel (Miller loop with the line
+    products computed ahead, exact final exponentiation) run lane by lane on the host gives the oracle's Gt bytes on every
+    golden accumulator (accepting, rejecting, identity pairs), the schedule never writes a register its round reads, and
+    it fits the LDS registers."""
+    import ctypes
+
+    L = hosttest_lib
+    g2 = bytes.fromhex(golden_decider["g2"])
+    ns_g2 = O.g2_to_bytes(O.g2_neg(O.g2_from_bytes(bytes.fromhex(golden_decider["s_g2"]))))
+    info = (ctypes.c_int * 4)()
+    o = _buf(384)
+    for case in golden_decider["cases"]:
+        assert L.ht_decide_w(g2 + ns_g2, bytes.fromhex(case["acc"]), o, info) == 0, case["name"]
+        assert o.raw == bytes.fromhex(case["gt"]), case["name"]
+    rounds, regs, crit, nops = list(info)
+    assert crit <= rounds <= crit + 40, (rounds, crit)  # the two duos keep the critical path fed
+    assert regs <= 16 and nops > 500

@@ -18,11 +18,11 @@ def dk(gpu_ctx, golden_decider):
     k.close()
 
 
-@pytest.mark.parametrize("teams", ["1", "2"])
+@pytest.mark.parametrize("teams", ["1", "2", "3"])
 def test_golden_decide_and_gt_value(gpu_ctx, dk, golden_decider, teams, monkeypatch):
     """Both kernel forms (decider.hip: one-team throughput form, two-team latency
     form) must give the exact Gt element, identity pairs included."""
-    monkeypatch.setenv("SNARKV_DECIDE_TEAMS", teams)
+    monkeypatch.setenv("SNARKV_DECIDE_FORM", teams)
     for case in golden_decider["cases"]:
         acc = bytes.fromhex(case["acc"])
         assert gpu_ctx.decide(dk, acc) == case["accept"], case["name"]
@@ -30,9 +30,9 @@ def test_golden_decide_and_gt_value(gpu_ctx, dk, golden_decider, teams, monkeypa
         assert gpu_ctx.pairing_value(dk, acc) == bytes.fromhex(case["gt"]), case["name"]
 
 
-@pytest.mark.parametrize("teams", ["1", "2"])
+@pytest.mark.parametrize("teams", ["1", "2", "3"])
 def test_decide_all_batch(gpu_ctx, dk, golden_decider, teams, monkeypatch):
-    monkeypatch.setenv("SNARKV_DECIDE_TEAMS", teams)
+    monkeypatch.setenv("SNARKV_DECIDE_FORM", teams)
     cases = golden_decider["cases"]
     accs = b"".join(bytes.fromhex(c["acc"]) for c in cases)
     allok, oks = gpu_ctx.decide_batch(dk, accs)

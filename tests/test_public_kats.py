@@ -159,14 +159,14 @@ def test_eip196_on_device(gpu_ctx, kats):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("teams", ["1", "2"])
+@pytest.mark.parametrize("teams", ["1", "2", "3"])
 def test_eip197_pairing_check_on_device(gpu_ctx, kats, teams, monkeypatch):
     """e(P1,Q1) e(P2,Q2) = 1 fed to the HIP decider as e(lhs, g2) e(rhs, -s_g2) with g2 := Q2,
     s_g2 := -Q1, lhs := P2, rhs := P1, for both kernel forms; cases of more than two pairs two pairs at a time
     (every sub-product against the big-integer oracle)."""
     import snark_verifier_amd as sv
 
-    monkeypatch.setenv("SNARKV_DECIDE_TEAMS", teams)
+    monkeypatch.setenv("SNARKV_DECIDE_FORM", teams)
     n = 0
     for c in kats["eip197_pairing_check"]:
         for (p1, q1), (p2, q2), ok in _two_pair_checks(c):

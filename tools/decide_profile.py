@@ -14,5 +14,5 @@ names = ["load+lines", "miller", "inversion", "easy part", "3 x exp_by_x", "hard
 for _ in range(3):
     raw = ctx.pairing_value(dk, g1 + g1)
 st = struct.unpack("<7Q", raw[:56])
-print("teams=%s" % os.environ.get("SNARKV_DECIDE_TEAMS", "auto"),
+print("teams=%s" % os.environ.get("SNARKV_DECIDE_FORM", "auto"),
       {n: "%.1f us" % ((st[k + 1] - st[k]) / 100.0) for k, n in enumerate(names)}, "total %.1f us" % ((st[6] - st[0]) / 100.0))
