@@ -51,6 +51,16 @@ extern "C" {
 #define SNARKV_ERR_ARG (-5)      /* null pointer / bad handle             */
 
 #define SNARKV_FLAG_VALIDATE 1u
+/* Field elements in halo2curves' IN-MEMORY form instead of the wire form: Fr / Fq as the four little-endian u64 limbs of
+ * a * 2^256 mod r (mod p) -- what `Fr`, `Fq`, `G1Affine { x, y }`, `G2Affine` hold in memory (`[u64; 4]`, Montgomery
+ * R = 2^256; the identity is (0, 0) in both forms), so a Rust caller passes `&[Fr]` / `&[G1Affine]` as they lie and gets
+ * a `G1Affine` back, with no `to_repr()` / `from_repr()` per element (reference util/msm.rs:308 takes exactly those slices;
+ * msm.rs:264 converts the scalars itself).  Covers scalars, G1 / G2 points and accumulators in, G1 points out of every
+ * BN254 entry point below except the IPA, Poseidon-transcript and test-hook ones (`snarkv_kzg_pairing_value` returns
+ * canonical Gt bytes; compressed points into `snarkv_g1_decompress` are the wire form by definition, its output follows
+ * the flag).  Cost on the device: the points enter the kernels' 9 x 29-bit domain by one product either way (another
+ * constant); a scalar costs one Fr product more (k_prepare +12 %, ~1 % of a 2^20-point MSM). */
+#define SNARKV_FLAG_MONTGOMERY 2u
 
 typedef struct snarkv_ctx snarkv_ctx;
 typedef struct snarkv_dk snarkv_dk;
@@ -72,6 +82,12 @@ int snarkv_ctx_sync(snarkv_ctx* ctx);
 int snarkv_ctx_host_buffer(snarkv_ctx* ctx, int slot, size_t bytes, void** out);
 const char* snarkv_last_error(void);
 const char* snarkv_version(void);
+/* Default flags of a context (SNARKV_FLAG_*): OR-ed into the `flags` argument of every call on it, and THE flags of the
+ * entry points that have no such argument (`*_dev`, `*_many_*`, the sampling utilities, `snarkv_g1_decompress`).  A
+ * `snarkv_mgpu` handle's ranks are contexts of their own (`snarkv_mgpu_ctx`); `bn254_set_flags` sets the process-global
+ * context's.  Unknown bits are SNARKV_ERR_ARG. */
+int snarkv_ctx_set_flags(snarkv_ctx* ctx, uint32_t flags);
+uint32_t snarkv_ctx_get_flags(const snarkv_ctx* ctx);
 
 /* ---- A3: NativeLoader::multi_scalar_multiplication --------------------- *
  * replaces snark-verifier/src/loader/native.rs:61-71
@@ -165,6 +181,7 @@ int snarkv_g1_validate(snarkv_ctx* ctx, const uint8_t* points64, size_t n);
 int snarkv_g1_decompress(snarkv_ctx* ctx, const uint8_t* in32, size_t n, uint8_t* out64, uint8_t* ok);
 
 /* ---- context-free entry points (process-global default context) -------- */
+int bn254_set_flags(uint32_t flags); /* e.g. SNARKV_FLAG_MONTGOMERY once at start-up: every bn254_* call then speaks halo2curves' in-memory form */
 int bn254_g1_msm_naive(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]);
 int bn254_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, const uint32_t* offsets, size_t n_msm,
                          uint8_t* out);

@@ -28,6 +28,7 @@ from ._lib import (  # noqa: F401,E402
     lib_path,
     load_library,
     SNARKV_FLAG_VALIDATE,
+    SNARKV_FLAG_MONTGOMERY,
     SNARKV_HOST_BUFFERS,
     SNARKV_ERR_EMPTY,
     SNARKV_ERR_LENGTH,
@@ -51,6 +52,7 @@ __all__ = [
     "lib_path",
     "load_library",
     "SNARKV_FLAG_VALIDATE",
+    "SNARKV_FLAG_MONTGOMERY",
     "SNARKV_HOST_BUFFERS",
     "SNARKV_ERR_EMPTY",
     "SNARKV_ERR_LENGTH",

@@ -13,6 +13,7 @@ SNARKV_ERR_ENCODING = -3
 SNARKV_ERR_DEVICE = -4
 SNARKV_ERR_ARG = -5
 SNARKV_FLAG_VALIDATE = 1
+SNARKV_FLAG_MONTGOMERY = 2  # halo2curves' in-memory form (a * 2^256 mod r / mod p) instead of the canonical wire form
 SNARKV_HOST_BUFFERS = 4  # include/snarkv_amd.h
 SNARKV_PIP_STAGES = 9
 PIP_STAGE_NAMES = [
@@ -83,6 +84,9 @@ _SIGNATURES = {
     "snarkv_sample_points_dev": (_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp]),
     "snarkv_ubench_valu": (_int, [_vp, _int, _int, ctypes.POINTER(ctypes.c_double)]),
     "snarkv_ctx_set_throughput_hint": (_int, [_vp, _int]),
+    "snarkv_ctx_set_flags": (_int, [_vp, _u32]),
+    "snarkv_ctx_get_flags": (_u32, [_vp]),
+    "bn254_set_flags": (_int, [_u32]),
     "snarkv_g1_msm_launch_points": (_int, [_sz, ctypes.POINTER(_sz)]),
     "snarkv_g1_msm_launch_points_ex": (_int, [_sz, _int, ctypes.POINTER(_sz)]),
     "snarkv_mgpu_create": (_int, [ctypes.POINTER(_int), _int, _pp]),
@@ -390,6 +394,14 @@ class Context:
         p = ctypes.c_void_p()
         _check(self._lib.snarkv_ctx_host_buffer(self._h, int(slot), int(nbytes), ctypes.byref(p)))
         return (ctypes.c_char * int(nbytes)).from_address(p.value)
+
+    def set_flags(self, flags):
+        """Default flags of the context (`snarkv_ctx_set_flags`): SNARKV_FLAG_MONTGOMERY makes every call on it -- the
+        device-resident ones and the samplers included -- speak halo2curves' in-memory form."""
+        _check(self._lib.snarkv_ctx_set_flags(self._h, int(flags)))
+
+    def get_flags(self):
+        return int(self._lib.snarkv_ctx_get_flags(self._h))
 
     def set_throughput_hint(self, enabled=True):
         """Several MSMs in flight on several contexts: longer runs per lane (less work per MSM, longer single-MSM latency)."""

@@ -44,6 +44,20 @@ static int fetch_out(snarkv_ctx* ctx, const void* d, void* host, size_t bytes) {
 // call, so the library does NOT touch it when it is loaded: the caller exports GPU_MAX_HW_QUEUES=16 before its first HIP
 // call (the Python package does so on import unless the variable is set, INTEGRATION.md shows the Rust line).
 
+// The encoding of a call = the context's default flags | the call's own: kept in ctx->mont while the call enqueues its
+// kernels (every launcher reads it), restored on the way out.
+struct CallFlags {
+  snarkv_ctx* c;
+  bool saved;
+  CallFlags(snarkv_ctx* ctx, uint32_t call_flags) : c(ctx), saved(ctx ? ctx->mont : false) {
+    if (c) c->mont = ((c->flags | call_flags) & SNARKV_FLAG_MONTGOMERY) != 0;
+  }
+  ~CallFlags() {
+    if (c) c->mont = saved;
+  }
+};
+#define SNARKV_CALL_FLAGS(ctx, f) CallFlags _call_flags((ctx), (f))
+
 static std::mutex g_default_mu;
 static snarkv_ctx* g_default_ctx = nullptr;
 // The context-free entry points share ONE context (stream + scratch): calls from different host
@@ -72,6 +86,15 @@ int snarkv_set_stage_timing(snarkv_ctx* ctx, int enabled) {
   ctx->stage_timing = enabled != 0;
   return SNARKV_OK;
 }
+
+int snarkv_ctx_set_flags(snarkv_ctx* ctx, uint32_t flags) {
+  if (!ctx || (flags & ~(SNARKV_FLAG_VALIDATE | SNARKV_FLAG_MONTGOMERY))) return SNARKV_ERR_ARG;
+  ctx->flags = flags;
+  ctx->mont = (flags & SNARKV_FLAG_MONTGOMERY) != 0;
+  return SNARKV_OK;
+}
+
+uint32_t snarkv_ctx_get_flags(const snarkv_ctx* ctx) { return ctx ? ctx->flags : 0u; }
 
 int snarkv_ctx_set_throughput_hint(snarkv_ctx* ctx, int enabled) {
   if (!ctx) return SNARKV_ERR_ARG;
@@ -134,7 +157,7 @@ int snarkv_get_stage_timing(snarkv_ctx* ctx, float ms[SNARKV_PIP_STAGES]) {
 }
 
 static int check_validate(snarkv_ctx* ctx, const void* d_s, const void* d_p, size_t n, uint32_t flags) {
-  if (!(flags & SNARKV_FLAG_VALIDATE)) return SNARKV_OK;
+  if (!((flags | ctx->flags) & SNARKV_FLAG_VALIDATE)) return SNARKV_OK;
   int bad = 0;
   SNARKV_TRY(launch_validate(ctx, d_s, d_p, n, &bad));
   if (bad) {
@@ -155,6 +178,7 @@ int snarkv_g1_msm_batched(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8
   }
   size_t n = offsets[n_msm];
   SNARKV_HIP(hipSetDevice(ctx->device));
+  SNARKV_CALL_FLAGS(ctx, flags);
   void *d_s, *d_p, *d_o, *d_out;
   SNARKV_TRY(stage_in(ctx, SLOT_IN_SCALARS, scalars32, n * 32, &d_s));
   SNARKV_TRY(stage_in(ctx, SLOT_IN_POINTS, points64, n * 64, &d_p));
@@ -248,6 +272,7 @@ int snarkv::launch_msm_pippenger_auto(snarkv_ctx* ctx, const void* d_s, const vo
     size_t lo = k * kChunk, len = std::min(kChunk, n - lo);
     int w = (int)(k % kWorkers);
     snarkv_ctx* lane = ctx->sub[w];
+    lane->mont = ctx->mont;
     lane->stage_timing = tm;
     // the chunk's bucket sums (sanitised XYZZ, zero = identity): straight into the worker's grid the first time, added to it after
     SNARKV_TRY(launch_msm_pippenger(lane, (const char*)d_s + 32 * lo, (const char*)d_p + 64 * lo, len, (int)c, nullptr, false,
@@ -378,6 +403,7 @@ int snarkv::launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void*
     const bool last = hi == count;
     for (size_t i = lo; i < hi; ++i) {
       snarkv_ctx* job = ctx->jobs[i - lo];
+      job->mont = ctx->mont;
       job->stage_timing = tm && last;
       void* grid = uniform ? (uint8_t*)d_grids + grid_bytes * (i - lo) : nullptr;
       hipStream_t sa = ctx->hi_stream[(i - lo) % 2], sb = S[(i - lo) % nS];
@@ -431,6 +457,7 @@ int snarkv_g1_msm_pippenger(snarkv_ctx* ctx, const uint8_t* scalars32, const uin
   if (!ctx || !scalars32 || !points64 || !out64) return SNARKV_ERR_ARG;
   if (n == 0) return SNARKV_ERR_EMPTY;  // reference panics: msm.rs:265
   SNARKV_HIP(hipSetDevice(ctx->device));
+  SNARKV_CALL_FLAGS(ctx, flags);
   void *d_s, *d_p, *d_out;
   SNARKV_TRY(stage_in(ctx, SLOT_IN_SCALARS, scalars32, n * 32, &d_s));
   SNARKV_TRY(stage_in(ctx, SLOT_IN_POINTS, points64, n * 64, &d_p));
@@ -508,6 +535,8 @@ int snarkv_dk_create(snarkv_ctx* ctx, const uint8_t g1_64[64], const uint8_t g2_
                      const uint8_t s_g2_128[128], uint32_t flags, snarkv_dk** out) {
   if (!ctx || !g1_64 || !g2_128 || !s_g2_128 || !out) return SNARKV_ERR_ARG;
   SNARKV_HIP(hipSetDevice(ctx->device));
+  SNARKV_CALL_FLAGS(ctx, flags);
+  flags |= ctx->flags;
   uint8_t both[256];
   memcpy(both, g2_128, 128);
   memcpy(both + 128, s_g2_128, 128);
@@ -576,6 +605,8 @@ int snarkv_kzg_decide_batch(snarkv_ctx* ctx, const snarkv_dk* dk, const uint8_t*
   if (!ctx || !dk || !accs128 || !ok) return SNARKV_ERR_ARG;
   if (m == 0) return 1;  // decide_all over an empty list is Ok(()) (decider.rs:84-93)
   SNARKV_HIP(hipSetDevice(ctx->device));
+  SNARKV_CALL_FLAGS(ctx, flags);
+  flags |= ctx->flags;
   void *d_a, *d_ok;
   SNARKV_TRY(stage_in(ctx, SLOT_IN_POINTS, accs128, m * 128, &d_a));
   SNARKV_TRY(ctx_reserve(ctx, SLOT_OUT, m, &d_ok));
@@ -647,6 +678,13 @@ int snarkv_g1_validate(snarkv_ctx* ctx, const uint8_t* points64, size_t n) {
 }
 
 // ---- context-free entry points -------------------------------------------
+int bn254_set_flags(uint32_t flags) {
+  SNARKV_DEFAULT_CALL_LOCK();
+  snarkv_ctx* c;
+  SNARKV_TRY(default_ctx(&c));
+  return snarkv_ctx_set_flags(c, flags);
+}
+
 int bn254_g1_validate(const uint8_t* points64, size_t n) {
   SNARKV_DEFAULT_CALL_LOCK();
   snarkv_ctx* c;

@@ -81,6 +81,8 @@ struct snarkv_ctx {
   // instead of the runtime's bounce copy of pageable memory
   void* hbuf[SNARKV_HOST_BUFFERS];
   size_t hbuf_cap[SNARKV_HOST_BUFFERS];
+  uint32_t flags;  // default flags of the context (snarkv_ctx_set_flags), OR-ed into every call's own
+  bool mont;       // SNARKV_FLAG_MONTGOMERY in effect for the call being enqueued (set by the entry points)
   bool stage_timing;
   float stage_ms[SNARKV_PIP_STAGES];
   hipEvent_t ev[SNARKV_PIP_STAGES + 1];

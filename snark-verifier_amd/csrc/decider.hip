@@ -48,21 +48,30 @@ __device__ __forceinline__ void store_fq_canonical(const Fq& a, uint32_t* __rest
 
 // g2x2: g2 (128 B canonical) || s_g2 (128 B canonical).  Lane 0 prepares g2,
 // lane 1 prepares -s_g2.
-__global__ void __launch_bounds__(64) k_g2_prepare(const uint32_t* __restrict__ g2x2, G2Prepared* __restrict__ prep) {
+// mont: the coordinates arrive in halo2curves' in-memory form (a * 2^256 mod p), which IS fq.h's representation
+__device__ __forceinline__ Fq load_fq_words(const uint32_t* __restrict__ src, uint32_t mont) {
+  if (!mont) return load_fq_canonical(src);
+  Fq r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = src[i];
+  return r;
+}
+
+__global__ void __launch_bounds__(64) k_g2_prepare(const uint32_t* __restrict__ g2x2, G2Prepared* __restrict__ prep, uint32_t mont) {
   uint32_t k = threadIdx.x;
   if (k >= 2) return;
   const uint32_t* src = g2x2 + k * 32;
   G2Affine q;
-  q.x.c0 = load_fq_canonical(src);
-  q.x.c1 = load_fq_canonical(src + 8);
-  q.y.c0 = load_fq_canonical(src + 16);
-  q.y.c1 = load_fq_canonical(src + 24);
+  q.x.c0 = load_fq_words(src, mont);
+  q.x.c1 = load_fq_words(src + 8, mont);
+  q.y.c0 = load_fq_words(src + 16, mont);
+  q.y.c1 = load_fq_words(src + 24, mont);
   if (k == 1) q.y = fq2_neg(q.y);
   g2_prepare(q, prep[k]);
 }
 
 // y^2 == x^3 + 3/(9+u) and canonical coordinates, for both G2 points.
-__global__ void __launch_bounds__(64) k_validate_g2(const uint32_t* __restrict__ g2x2, int* __restrict__ bad) {
+__global__ void __launch_bounds__(64) k_validate_g2(const uint32_t* __restrict__ g2x2, int* __restrict__ bad, uint32_t mont) {
   uint32_t k = threadIdx.x;
   if (k >= 2) return;
   const uint32_t* src = g2x2 + k * 32;
@@ -70,10 +79,10 @@ __global__ void __launch_bounds__(64) k_validate_g2(const uint32_t* __restrict__
   for (int j = 0; j < 4; ++j) ok = ok && fq_canonical_in_range(src + 8 * j);
   if (ok) {
     G2Affine q;
-    q.x.c0 = load_fq_canonical(src);
-    q.x.c1 = load_fq_canonical(src + 8);
-    q.y.c0 = load_fq_canonical(src + 16);
-    q.y.c1 = load_fq_canonical(src + 24);
+    q.x.c0 = load_fq_words(src, mont);
+    q.x.c1 = load_fq_words(src + 8, mont);
+    q.y.c0 = load_fq_words(src + 16, mont);
+    q.y.c1 = load_fq_words(src + 24, mont);
     if (!(fq2_is_zero(q.x) && fq2_is_zero(q.y))) {
       constexpr uint32_t bc0[8] = BN254_TWIST_B_C0_MONT;
       constexpr uint32_t bc1[8] = BN254_TWIST_B_C1_MONT;
@@ -376,7 +385,7 @@ static __device__ __noinline__ void coop_exp_by_x(int dst, int a) {
 template <int TEAMS>
 __global__ void __launch_bounds__(kDecideThreads * TEAMS)
     k_decide(const G2Prepared29* __restrict__ prep, const uint32_t* __restrict__ accs, uint32_t m,
-             uint8_t* __restrict__ ok, uint32_t* __restrict__ gt_out) {
+             uint8_t* __restrict__ ok, uint32_t* __restrict__ gt_out, uint32_t mont) {
   const int tid = threadIdx.x;
   const uint32_t i = blockIdx.x;
   if (i >= m) return;
@@ -386,7 +395,7 @@ __global__ void __launch_bounds__(kDecideThreads * TEAMS)
     uint32_t w[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) w[j] = a[8 * tid + j];
-    g_sh.pt[tid >> 1][tid & 1] = fq29_canon_residue(fq29_from_canonical(w));
+    g_sh.pt[tid >> 1][tid & 1] = fq29_canon_residue(fq29_from_words(w, mont != 0));
   }
   if (tid < 12) coop_store(RF, tid, tid == 0 ? fq29_one() : fq29_zero());
   if (tid < 12) {
@@ -555,7 +564,8 @@ __global__ void __launch_bounds__(kDecideThreads * TEAMS)
 // decide_w.h, then the program (two 8-byte operations per round).
 __global__ void __launch_bounds__(256)
     k_decide_w(const G2Prepared29* __restrict__ prep, const uint32_t* __restrict__ accs, uint32_t m,
-               uint8_t* __restrict__ ok, uint32_t* __restrict__ gt_out, const uint2* __restrict__ prog, int rounds, int result) {
+               uint8_t* __restrict__ ok, uint32_t* __restrict__ gt_out, const uint2* __restrict__ prog, int rounds, int result,
+               uint32_t mont) {
   extern __shared__ Fq29P wt_lds[];
   __shared__ Fq29 pt[2][2];
   __shared__ int live[2];
@@ -569,7 +579,7 @@ __global__ void __launch_bounds__(256)
     uint32_t w[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) w[j] = a[8 * tid + j];
-    pt[tid >> 1][tid & 1] = fq29_canon_residue(fq29_from_canonical(w));
+    pt[tid >> 1][tid & 1] = fq29_canon_residue(fq29_from_words(w, mont != 0));
   }
   for (int j = tid; j < 52; j += 256) wt_store(wt_lds, kWtConstBase + j, wt_const_value(j));
   for (int j = tid; j < 2 * rounds; j += 256) prog_lds[j] = prog[j];
@@ -656,7 +666,7 @@ static int wt_device_program(int device, const WtDeviceProgram** out) {
 
 int launch_g2_prepare(snarkv_ctx* ctx, const void* d_g2x2_256, void* d_prep) {
   hipLaunchKernelGGL(k_g2_prepare, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)d_g2x2_256,
-                     (G2Prepared*)d_prep);
+                     (G2Prepared*)d_prep, ctx->mont ? 1u : 0u);
   G2Prepared29* d29 = reinterpret_cast<G2Prepared29*>((char*)d_prep + prep29_offset());
   hipLaunchKernelGGL(k_g2_to29, dim3((2 * kLinesPerG2 * 6 + 255) / 256), dim3(256), 0, ctx->stream,
                      (const G2Prepared*)d_prep, d29);
@@ -668,7 +678,8 @@ int launch_validate_g2(snarkv_ctx* ctx, const void* d_g2x2_256, int* bad_host) {
   void* d_bad = nullptr;
   SNARKV_TRY(ctx_reserve(ctx, SLOT_FLAGS, 64, &d_bad));
   SNARKV_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
-  hipLaunchKernelGGL(k_validate_g2, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)d_g2x2_256, (int*)d_bad);
+  hipLaunchKernelGGL(k_validate_g2, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)d_g2x2_256, (int*)d_bad,
+                     ctx->mont ? 1u : 0u);
   SNARKV_HIP(hipGetLastError());
   SNARKV_HIP(hipMemcpyAsync(bad_host, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   SNARKV_HIP(hipStreamSynchronize(ctx->stream));
@@ -681,6 +692,7 @@ int launch_validate_g2(snarkv_ctx* ctx, const void* d_g2x2_256, int* bad_host) {
 // (program) forces one (test / A-B knob).  All give the same bits.
 int launch_decide(snarkv_ctx* ctx, const void* d_prep, const void* d_accs, size_t m, void* d_ok, void* d_gt) {
   const G2Prepared29* d29 = reinterpret_cast<const G2Prepared29*>((const char*)d_prep + prep29_offset());
+  const uint32_t mont = ctx->mont ? 1u : 0u;  // the accumulators' points in halo2curves' in-memory form
   int form = m <= 256 ? 3 : 1;
   if (const char* e = getenv("SNARKV_DECIDE_FORM")) {
     int v = atoi(e);
@@ -690,13 +702,13 @@ int launch_decide(snarkv_ctx* ctx, const void* d_prep, const void* d_accs, size_
     const WtDeviceProgram* wp = nullptr;
     SNARKV_TRY(wt_device_program(ctx->device, &wp));
     hipLaunchKernelGGL(k_decide_w, dim3((uint32_t)m), dim3(256), wp->lds_bytes, ctx->stream, d29, (const uint32_t*)d_accs,
-                       (uint32_t)m, (uint8_t*)d_ok, (uint32_t*)d_gt, (const uint2*)wp->d_prog, wp->rounds, wp->result);
+                       (uint32_t)m, (uint8_t*)d_ok, (uint32_t*)d_gt, (const uint2*)wp->d_prog, wp->rounds, wp->result, mont);
   } else if (form == 2)
     hipLaunchKernelGGL(k_decide<2>, dim3((uint32_t)m), dim3(2 * kDecideThreads), 0, ctx->stream, d29,
-                       (const uint32_t*)d_accs, (uint32_t)m, (uint8_t*)d_ok, (uint32_t*)d_gt);
+                       (const uint32_t*)d_accs, (uint32_t)m, (uint8_t*)d_ok, (uint32_t*)d_gt, mont);
   else
     hipLaunchKernelGGL(k_decide<1>, dim3((uint32_t)m), dim3(kDecideThreads), 0, ctx->stream, d29,
-                       (const uint32_t*)d_accs, (uint32_t)m, (uint8_t*)d_ok, (uint32_t*)d_gt);
+                       (const uint32_t*)d_accs, (uint32_t)m, (uint8_t*)d_ok, (uint32_t*)d_gt, mont);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }

@@ -37,7 +37,7 @@ __device__ __noinline__ Fq29 fq29_pow_p_plus_1_over_4(const Fq29& a) {
 }
 
 __global__ void __launch_bounds__(64) k_g1_decompress(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                       uint8_t* __restrict__ ok, uint32_t n) {
+                                                       uint8_t* __restrict__ ok, uint32_t n, uint32_t mont) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint4* src = reinterpret_cast<const uint4*>(in + (size_t)i * 8);
@@ -82,6 +82,10 @@ __global__ void __launch_bounds__(64) k_g1_decompress(const uint32_t* __restrict
         o[j] = w[j];
         o[8 + j] = yc[j];
       }
+      if (mont) {  // SNARKV_FLAG_MONTGOMERY: the point in halo2curves' in-memory form (the compressed input is the wire form)
+        fq29_to_words(x, o, true);
+        fq29_to_words(fq29_from_canonical(yc), o + 8, true);
+      }
     }
   }
   uint4* dst = reinterpret_cast<uint4*>(out + (size_t)i * 16);
@@ -92,7 +96,7 @@ __global__ void __launch_bounds__(64) k_g1_decompress(const uint32_t* __restrict
 
 int launch_g1_decompress(snarkv_ctx* ctx, const void* d_in32, size_t n, void* d_out64, void* d_ok) {
   hipLaunchKernelGGL(k_g1_decompress, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const uint32_t*)d_in32,
-                     (uint32_t*)d_out64, (uint8_t*)d_ok, (uint32_t)n);
+                     (uint32_t*)d_out64, (uint8_t*)d_ok, (uint32_t)n, ctx->mont ? 1u : 0u);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }

@@ -276,8 +276,10 @@ SNARKV_HD Fq29 fq29_canon_residue(const Fq29& x) { return fq29_canon_of_product(
 
 SNARKV_HD bool fq29_is_zero_mod_p(const Fq29& x) { return fq29_limbs_all_zero(fq29_canon_residue(x)); }
 
-// boundary codecs: 8 x u32 canonical integer <-> Montgomery (R = 2^261) limbs
-SNARKV_HD Fq29 fq29_from_canonical(const uint32_t w[8]) {
+// boundary codecs: 8 x u32 words <-> Montgomery (R = 2^261) limbs.  The words are the canonical integer a < p
+// (`PrimeField::to_repr`, the wire form) or, with `mont`, halo2curves' IN-MEMORY form: the four u64 limbs of
+// a * 2^256 mod p.  Either way ONE product by a constant: 2^522 / 2^266 on the way in, 1 / 2^256 on the way out.
+SNARKV_HD Fq29 fq29_limbs_of_words(const uint32_t w[8]) {
   Fq29 a;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
@@ -287,18 +289,25 @@ SNARKV_HD Fq29 fq29_from_canonical(const uint32_t w[8]) {
     if (word + 1 < 8) v |= (uint64_t)w[word + 1] << 32;
     a.v[i] = (int32_t)((uint32_t)(v >> sh) & (uint32_t)kMask29);
   }
+  return a;
+}
+SNARKV_HD Fq29 fq29_from_words(const uint32_t w[8], bool mont) {
   constexpr int32_t r2[9] = SNARKV_FQ29_R2_LIMBS;
+  constexpr int32_t m_in[9] = SNARKV_FQ29_M256_IN_LIMBS;
   Fq29 b;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) b.v[i] = r2[i];
-  return fq29_mul(a, b);
+  for (int i = 0; i < 9; ++i) b.v[i] = mont ? m_in[i] : r2[i];
+  return fq29_mul(fq29_limbs_of_words(w), b);
 }
+SNARKV_HD Fq29 fq29_from_canonical(const uint32_t w[8]) { return fq29_from_words(w, false); }
 
-SNARKV_HD void fq29_to_canonical(const Fq29& a, uint32_t w[8]) {
-  Fq29 one_raw = fq29_zero();
-  one_raw.v[0] = 1;
-  Fq29 y = fq29_mul(fq29_norm(a), one_raw);  // a * R^-1: out of Montgomery form
-  // canonicalise the plain integer residue
+SNARKV_HD void fq29_to_words(const Fq29& a, uint32_t w[8], bool mont) {
+  constexpr int32_t m_out[9] = SNARKV_FQ29_M256_OUT_LIMBS;
+  Fq29 mult;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) mult.v[i] = mont ? m_out[i] : (i == 0 ? 1 : 0);
+  Fq29 y = fq29_mul(fq29_norm(a), mult);  // a * R^-1 [* 2^256]: out of the 2^261 domain
+  // canonicalise the residue
   Fq29 t;
   int32_t neg = y.v[8] >> 31;
 #pragma unroll
@@ -327,6 +336,7 @@ SNARKV_HD void fq29_to_canonical(const Fq29& a, uint32_t w[8]) {
     if (word + 1 < 8) w[word + 1] |= (uint32_t)(v >> 32);
   }
 }
+SNARKV_HD void fq29_to_canonical(const Fq29& a, uint32_t w[8]) { fq29_to_words(a, w, false); }
 
 // x - round(x/p) p for |x| up to ~64p, x carry-normalised: the quotient is
 // estimated from the top limb (bits 232..), exact to +-1, so |result| < 1.5p.

@@ -156,4 +156,48 @@ SNARKV_HD void fr29_to_canonical(const Fr29& a, uint32_t w[8]) {
   }
 }
 
+// halo2curves' in-memory Fr (the four u64 limbs of a * 2^256 mod r) -> the canonical integer a: one Montgomery product by
+// 2^5 (x * 32 * 2^-261 = x * 2^-256), then the conditional +r / -r of fr29_to_canonical
+SNARKV_HD void fr_words_from_mont256(const uint32_t in[8], uint32_t out[8]) {
+  Fr29 a;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    int bit = 29 * i;
+    int word = bit >> 5, sh = bit & 31;
+    uint64_t v = in[word];
+    if (word + 1 < 8) v |= (uint64_t)in[word + 1] << 32;
+    a.v[i] = (int32_t)((uint32_t)(v >> sh) & (uint32_t)kMask29);
+  }
+  Fr29 m = fr29_zero();
+  m.v[0] = 32;
+  Fr29 y = fr29_mul(a, m);
+  Fr29 t;
+  int32_t neg = y.v[8] >> 31;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) t.v[i] = y.v[i] + (fr29_r(i) & neg);
+  t = fr29_norm(t);
+  Fr29 d;
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int32_t s = t.v[i] - fr29_r(i) + c;
+    d.v[i] = s & kMask29;
+    c = s >> 29;
+  }
+  d.v[8] = t.v[8] - fr29_r(8) + c;
+  int32_t keep = d.v[8] >> 31;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) t.v[i] = (t.v[i] & keep) | (d.v[i] & ~keep);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[j] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    int bit = 29 * i;
+    int word = bit >> 5, sh = bit & 31;
+    uint64_t v = (uint64_t)(uint32_t)t.v[i] << sh;
+    out[word] |= (uint32_t)v;
+    if (word + 1 < 8) out[word + 1] |= (uint32_t)(v >> 32);
+  }
+}
+
 }  // namespace snarkv

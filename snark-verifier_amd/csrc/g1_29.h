@@ -350,7 +350,8 @@ SNARKV_HD G1Affine29 xyzz29_to_affine(const G1Xyzz29& p) {
   return r;
 }
 
-SNARKV_HD G1Affine29 g1a29_from_canonical(const uint32_t w[16]) {
+// 16 words x || y -> Montgomery affine point; the identity is 64 zero bytes in both encodings (halo2curves' (0, 0))
+SNARKV_HD G1Affine29 g1a29_from_words(const uint32_t w[16], bool mont) {
   G1Affine29 r;
   bool id = true;
 #pragma unroll
@@ -361,15 +362,17 @@ SNARKV_HD G1Affine29 g1a29_from_canonical(const uint32_t w[16]) {
     return r;
   }
   // canonical residues so that the stored affine point has limbs in [0, 2^29)
-  r.x = fq29_canon_of_product(fq29_from_canonical(w));  // fq29_from_canonical ends in a product (by R^2)
-  r.y = fq29_canon_of_product(fq29_from_canonical(w + 8));
+  r.x = fq29_canon_of_product(fq29_from_words(w, mont));  // fq29_from_words ends in a product
+  r.y = fq29_canon_of_product(fq29_from_words(w + 8, mont));
   return r;
 }
+SNARKV_HD G1Affine29 g1a29_from_canonical(const uint32_t w[16]) { return g1a29_from_words(w, false); }
 
-SNARKV_HD void g1a29_to_canonical(const G1Affine29& p, uint32_t w[16]) {
-  fq29_to_canonical(p.x, w);
-  fq29_to_canonical(p.y, w + 8);
+SNARKV_HD void g1a29_to_words(const G1Affine29& p, uint32_t w[16], bool mont) {
+  fq29_to_words(p.x, w, mont);
+  fq29_to_words(p.y, w + 8, mont);
 }
+SNARKV_HD void g1a29_to_canonical(const G1Affine29& p, uint32_t w[16]) { g1a29_to_words(p, w, false); }
 
 SNARKV_HD G1Affine29 g1a29_neg(const G1Affine29& p) {
   G1Affine29 r;

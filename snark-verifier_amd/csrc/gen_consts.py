@@ -39,6 +39,9 @@ def generic_section(p, r, b, name):
     print("#define SNARKV_FQ29_NINV 0x%08x  // -p^-1 mod 2^29" % ((-pow(p, -1, 1 << 29)) % (1 << 29)))
     print("#define SNARKV_FQ29_ONE_LIMBS { %s }  // 2^261 mod p" % lim29(r29 % p))
     print("#define SNARKV_FQ29_R2_LIMBS { %s }  // 2^522 mod p" % lim29(r29 * r29 % p))
+    # halo2curves / pasta_curves keep field elements as a * 2^256 mod p in 4 x u64: in by 2^266 (-> a * 2^261), out by 2^256
+    print("#define SNARKV_FQ29_M256_IN_LIMBS { %s }  // 2^266 mod p" % lim29((1 << 266) % p))
+    print("#define SNARKV_FQ29_M256_OUT_LIMBS { %s }  // 2^256 mod p" % lim29(MONT_R % p))
     print("#define SNARKV_FR29_P_LIMBS { %s }  // r" % lim29(r))
     print("#define SNARKV_FR29_NINV 0x%08x  // -r^-1 mod 2^29" % ((-pow(r, -1, 1 << 29)) % (1 << 29)))
     print("#define SNARKV_FR29_ONE_LIMBS { %s }  // 2^261 mod r" % lim29(r29 % r))

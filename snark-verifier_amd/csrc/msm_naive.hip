@@ -19,6 +19,7 @@
 #include "g1.h"
 #include "g1_29.h"
 #include "glv.h"
+#include "fr29.h"
 
 namespace snarkv {
 
@@ -32,6 +33,23 @@ __device__ __forceinline__ void load_words16(const uint32_t* __restrict__ src, u
     dst[4 * i + 2] = v.z;
     dst[4 * i + 3] = v.w;
   }
+}
+
+// One (scalar, base) term as the boundary hands it over: canonical integers (the wire form), or -- `mont` -- halo2curves'
+// in-memory form, a * 2^256 mod r resp. mod p in 4 x u64 (SNARKV_FLAG_MONTGOMERY).  The point enters the 9 x 29-bit
+// Montgomery domain by ONE product either way (another constant); the scalar costs one Fr product more when `mont`.
+__device__ __forceinline__ G1Affine29 load_term(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points,
+                                                size_t t, uint32_t mont, uint32_t (&k)[8]) {
+  uint32_t pw[16];
+  load_words16(scalars + t * 8, k, 2);
+  load_words16(points + t * 16, pw, 4);
+  if (mont) {
+    uint32_t c[8];
+    fr_words_from_mont256(k, c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k[j] = c[j];
+  }
+  return g1a29_from_words(pw, mont != 0);
 }
 
 // |k| * Q for a 127-bit magnitude: left-to-right double-and-add on the lazy
@@ -151,20 +169,18 @@ __device__ __forceinline__ G1Xyzz29 half_scalar_mul_w3(const G1Affine29& q, cons
 __global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES) k_term_scalar_mul(const uint32_t* __restrict__ scalars,
                                                          const uint32_t* __restrict__ points,
                                                          G1Xyzz29* __restrict__ out, uint32_t n_terms,
-                                                         int32_t* __restrict__ tabg) {
+                                                         int32_t* __restrict__ tabg, uint32_t mont) {
 #if SNARKV_NAIVE_WINDOW
   __shared__ int8_t dig[kWinDigits][64];
 #endif
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= 2 * n_terms) return;
   uint32_t t = g >> 1, h = g & 1u;
-  uint32_t k[8], pw[16], halves[8];
-  load_words16(scalars + (size_t)t * 8, k, 2);
-  load_words16(points + (size_t)t * 16, pw, 4);
+  uint32_t k[8], halves[8];
+  G1Affine29 q = load_term(scalars, points, t, mont, k);
   glv_decompose(k, halves);
   uint32_t mag[4] = {halves[4 * h], halves[4 * h + 1], halves[4 * h + 2], halves[4 * h + 3] & 0x7FFFFFFFu};
   uint32_t neg = halves[4 * h + 3] >> 31;
-  G1Affine29 q = g1a29_from_canonical(pw);
   if (g1a29_is_identity(q) || (mag[0] | mag[1] | mag[2] | mag[3]) == 0) {
     out[g] = xyzz29_identity();
     return;
@@ -203,15 +219,13 @@ __global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES) k_term_scalar_mul(cons
 __global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES) k_term_scalar_mul_joint(const uint32_t* __restrict__ scalars,
                                                                                    const uint32_t* __restrict__ points,
                                                                                    G1Xyzz29* __restrict__ out, uint32_t n_terms,
-                                                                                   int32_t* __restrict__ tabg) {
+                                                                                   int32_t* __restrict__ tabg, uint32_t mont) {
   __shared__ int8_t dig[2][kWinDigits][64];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x;
   if (t >= n_terms) return;
-  uint32_t k[8], pw[16], halves[8];
-  load_words16(scalars + (size_t)t * 8, k, 2);
-  load_words16(points + (size_t)t * 16, pw, 4);
+  uint32_t k[8], halves[8];
+  const G1Affine29 q = load_term(scalars, points, t, mont, k);
   glv_decompose(k, halves);
-  const G1Affine29 q = g1a29_from_canonical(pw);
   uint32_t mag[2][4];
   uint32_t neg[2], any = 0;
   for (int h = 0; h < 2; ++h) {
@@ -326,17 +340,15 @@ __global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES) k_term_scalar_mul_join
 __global__ void __launch_bounds__(64) k_term_chain(const uint32_t* __restrict__ scalars,
                                                     const uint32_t* __restrict__ points,
                                                     G1Xyzz29* __restrict__ chain, uint4* __restrict__ mags,
-                                                    uint32_t n_terms, uint32_t J, uint32_t bits) {
+                                                    uint32_t n_terms, uint32_t J, uint32_t bits, uint32_t mont) {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= 2 * n_terms) return;
   uint32_t t = g >> 1, h = g & 1u;
-  uint32_t k[8], pw[16], halves[8];
-  load_words16(scalars + (size_t)t * 8, k, 2);
-  load_words16(points + (size_t)t * 16, pw, 4);
+  uint32_t k[8], halves[8];
+  G1Affine29 q = load_term(scalars, points, t, mont, k);
   glv_decompose(k, halves);
   uint4 mag = make_uint4(halves[4 * h], halves[4 * h + 1], halves[4 * h + 2], halves[4 * h + 3] & 0x7FFFFFFFu);
   uint32_t neg = halves[4 * h + 3] >> 31;
-  G1Affine29 q = g1a29_from_canonical(pw);
   if (g1a29_is_identity(q)) mag = make_uint4(0, 0, 0, 0);  // all digits zero -> identity partial
   mags[g] = mag;
   if (h) {
@@ -363,18 +375,16 @@ __global__ void __launch_bounds__(64) k_term_chain(const uint32_t* __restrict__ 
 __global__ void __launch_bounds__(64) k_term_chain_quad(const uint32_t* __restrict__ scalars,
                                                          const uint32_t* __restrict__ points,
                                                          G1Xyzz29* __restrict__ chain, uint4* __restrict__ mags,
-                                                         uint32_t n_terms, uint32_t J, uint32_t bits) {
+                                                         uint32_t n_terms, uint32_t J, uint32_t bits, uint32_t mont) {
   uint32_t lane4 = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t g = lane4 >> 2, q = lane4 & 3u;  // a quad never straddles a wavefront; all four lanes take the same branches
   if (g >= 2 * n_terms) return;
   uint32_t t = g >> 1, h = g & 1u;
-  uint32_t k[8], pw[16], halves[8];
-  load_words16(scalars + (size_t)t * 8, k, 2);
-  load_words16(points + (size_t)t * 16, pw, 4);
+  uint32_t k[8], halves[8];
+  G1Affine29 p = load_term(scalars, points, t, mont, k);
   glv_decompose(k, halves);
   uint4 mag = make_uint4(halves[4 * h], halves[4 * h + 1], halves[4 * h + 2], halves[4 * h + 3] & 0x7FFFFFFFu);
   uint32_t neg = halves[4 * h + 3] >> 31;
-  G1Affine29 p = g1a29_from_canonical(pw);
   if (g1a29_is_identity(p)) mag = make_uint4(0, 0, 0, 0);
   if (q == 0) mags[g] = mag;
   if (h) {
@@ -473,7 +483,7 @@ __global__ void __launch_bounds__(64) k_term_chunks(const G1Xyzz29* __restrict__
 template <int THREADS, int G>
 __global__ void __launch_bounds__(THREADS) k_segment_fold(const G1Xyzz29* __restrict__ parts,
                                                            const uint32_t* __restrict__ offsets,
-                                                           uint32_t* __restrict__ out, uint32_t n_msm) {
+                                                           uint32_t* __restrict__ out, uint32_t n_msm, uint32_t mont) {
   static_assert(THREADS % G == 0 && (G & (G - 1)) == 0, "G lanes per MSM: a power of two dividing the workgroup");
   __shared__ G1Xyzz29 sh[THREADS];
   const uint32_t tid = threadIdx.x, lane = tid % G;
@@ -495,7 +505,7 @@ __global__ void __launch_bounds__(THREADS) k_segment_fold(const G1Xyzz29* __rest
   if (lane == 0 && live) {
     G1Affine29 r = xyzz29_to_affine(sh[tid]);
     uint32_t w[16];
-    g1a29_to_canonical(r, w);
+    g1a29_to_words(r, w, mont != 0);
     uint4* o = reinterpret_cast<uint4*>(out + (size_t)k * 16);
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
@@ -505,7 +515,7 @@ __global__ void __launch_bounds__(THREADS) k_segment_fold(const G1Xyzz29* __rest
 // Optional input validation (SNARKV_FLAG_VALIDATE): canonical scalars (< r),
 // canonical coordinates (< p), on-curve.  bad[0] counts offenders.
 __global__ void k_validate(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points, uint32_t n,
-                           int* __restrict__ bad) {
+                           int* __restrict__ bad, uint32_t mont) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   bool ok = true;
@@ -525,7 +535,16 @@ __global__ void k_validate(const uint32_t* __restrict__ scalars, const uint32_t*
     uint32_t pw[16];
     load_words16(points + (size_t)i * 16, pw, 4);
     ok = ok && fq_canonical_in_range(pw) && fq_canonical_in_range(pw + 8);
-    if (ok) ok = g1a_is_on_curve(g1a_from_canonical(pw));
+    if (ok) {
+      G1Affine q;  // fq.h's domain is R = 2^256: the in-memory form IS its representation
+      if (mont) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q.x.v[j] = pw[j], q.y.v[j] = pw[8 + j];
+      } else {
+        q = g1a_from_canonical(pw);
+      }
+      ok = g1a_is_on_curve(q);
+    }
   }
   if (!ok) atomicAdd(bad, 1);
 }
@@ -547,6 +566,7 @@ static uint32_t chunks_for(size_t n_terms) {
 int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, const void* d_offsets,
                        size_t n_msm, size_t n_terms, void* d_out) {
   void* d_terms = nullptr;
+  const uint32_t mont = ctx->mont ? 1u : 0u;  // SNARKV_FLAG_MONTGOMERY: terms in and points out in halo2curves' in-memory form
   SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_PARTIALS, 2 * n_terms * sizeof(G1Xyzz29), &d_terms));
   const uint32_t J = chunks_for(n_terms);
   if (J == 1) {
@@ -559,12 +579,12 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
       uint32_t blocks = (uint32_t)((n_terms + 63) / 64);
       SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_CHAIN, (size_t)blocks * 3 * 45 * 64 * 4, &d_tab));
       hipLaunchKernelGGL(k_term_scalar_mul_joint, dim3(blocks), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,
-                         (const uint32_t*)d_points, (G1Xyzz29*)d_terms, (uint32_t)n_terms, (int32_t*)d_tab);
+                         (const uint32_t*)d_points, (G1Xyzz29*)d_terms, (uint32_t)n_terms, (int32_t*)d_tab, mont);
     } else {
       uint32_t blocks = (uint32_t)((2 * n_terms + 63) / 64);
       SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_CHAIN, (size_t)blocks * 3 * 36 * 64 * 4, &d_tab));
       hipLaunchKernelGGL(k_term_scalar_mul, dim3(blocks), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,
-                         (const uint32_t*)d_points, (G1Xyzz29*)d_terms, (uint32_t)n_terms, (int32_t*)d_tab);
+                         (const uint32_t*)d_points, (G1Xyzz29*)d_terms, (uint32_t)n_terms, (int32_t*)d_tab, mont);
     }
   } else {
     void* d_chain = nullptr;
@@ -578,10 +598,10 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
     if (quad)
       hipLaunchKernelGGL(k_term_chain_quad, dim3((uint32_t)((8 * n_terms + 63) / 64)), dim3(64), 0, ctx->stream,
                          (const uint32_t*)d_scalars, (const uint32_t*)d_points, (G1Xyzz29*)d_chain, (uint4*)d_mags,
-                         (uint32_t)n_terms, J, bits);
+                         (uint32_t)n_terms, J, bits, mont);
     else
       hipLaunchKernelGGL(k_term_chain, dim3(blocks_a), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,
-                         (const uint32_t*)d_points, (G1Xyzz29*)d_chain, (uint4*)d_mags, (uint32_t)n_terms, J, bits);
+                         (const uint32_t*)d_points, (G1Xyzz29*)d_chain, (uint4*)d_mags, (uint32_t)n_terms, J, bits, mont);
     uint32_t n_lanes = (uint32_t)(2 * n_terms * J);
     hipLaunchKernelGGL(k_term_chunks, dim3((n_lanes + 63) / 64), dim3(64), 0, ctx->stream,
                        (const G1Xyzz29*)d_chain, (const uint4*)d_mags, (G1Xyzz29*)d_terms, n_lanes, J, bits);
@@ -591,13 +611,13 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
   const uint32_t nm = (uint32_t)n_msm;
   if (force == 256 || (!force && n_terms >= 128 * n_msm))
     hipLaunchKernelGGL((k_segment_fold<256, 256>), dim3(nm), dim3(256), 0, ctx->stream, (const G1Xyzz29*)d_terms,
-                       (const uint32_t*)d_offsets, (uint32_t*)d_out, nm);
+                       (const uint32_t*)d_offsets, (uint32_t*)d_out, nm, mont);
   else if (force == 64 || (!force && n_terms > 32 * n_msm))
     hipLaunchKernelGGL((k_segment_fold<64, 64>), dim3(nm), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_terms,
-                       (const uint32_t*)d_offsets, (uint32_t*)d_out, nm);
+                       (const uint32_t*)d_offsets, (uint32_t*)d_out, nm, mont);
   else  // <= 64 partials per MSM on average: four MSMs per wavefront
     hipLaunchKernelGGL((k_segment_fold<64, 16>), dim3((nm + 3) / 4), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_terms,
-                       (const uint32_t*)d_offsets, (uint32_t*)d_out, nm);
+                       (const uint32_t*)d_offsets, (uint32_t*)d_out, nm, mont);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }
@@ -608,7 +628,7 @@ int launch_validate(snarkv_ctx* ctx, const void* d_scalars, const void* d_points
   SNARKV_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
   uint32_t blocks = (uint32_t)((n + 255) / 256);
   hipLaunchKernelGGL(k_validate, dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t*)d_scalars,
-                     (const uint32_t*)d_points, (uint32_t)n, (int*)d_bad);
+                     (const uint32_t*)d_points, (uint32_t)n, (int*)d_bad, ctx->mont ? 1u : 0u);
   SNARKV_HIP(hipGetLastError());
   SNARKV_HIP(hipMemcpyAsync(bad_host, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   SNARKV_HIP(hipStreamSynchronize(ctx->stream));

@@ -52,6 +52,7 @@
 #include <atomic>
 #include "ctx.hpp"
 #include "g1_29.h"
+#include "fr29.h"
 #ifndef SNARKV_GLV
 #define SNARKV_GLV 1  // 0: curves without the BN-shaped GLV lattice (the pasta build): one virtual point per point
 #endif
@@ -145,6 +146,7 @@ struct PipParams {
   uint32_t krun;     // entries per run (kRun, or kRunThroughput on a context with the throughput hint)
   uint32_t wper;     // batched tail over several MSMs' grids laid end to end: windows per MSM (0: one MSM)
   uint32_t chunk_log2;  // P6: log2 of the buckets per k_bucket_reduce lane (kLog2Chunk; larger in a batched tail)
+  uint32_t mont;     // P0: 1 = scalars and points arrive in halo2curves' in-memory form (a * 2^256 mod r / mod p): SNARKV_FLAG_MONTGOMERY
 };
 
 // c bits at offset lo of a kDigitBits-bit magnitude held in registers (selects, no dynamic indexing)
@@ -264,12 +266,18 @@ __global__ void __launch_bounds__(SNARKV_PREP_THREADS)
       w[4 * j + 2] = v.z;
       w[4 * j + 3] = v.w;
     }
-    G1Affine29 a = g1a29_from_canonical(w);
+    G1Affine29 a = g1a29_from_words(w, p.mont != 0);  // one product by a constant either way
     bool ident = g1a29_is_identity(a);
     pts[kHalves * (size_t)i] = g1a29_pack(a);
     const uint4* ks = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
     uint4 k0 = ks[0], k1 = ks[1];
     uint32_t k[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w}, o[8];
+    if (p.mont) {  // the scalar's in-memory form -> its canonical integer: one Fr product more (~12 % of this kernel)
+      uint32_t kc[8];
+      fr_words_from_mont256(k, kc);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) k[j] = kc[j];
+    }
 #if SNARKV_GLV
     constexpr int32_t bl[9] = SNARKV_GLV_BETA29_LIMBS;
     Fq29 beta;
@@ -930,7 +938,7 @@ __global__ void __launch_bounds__(64)
 // result = sum_w shifted[w]; 64 lanes, LDS tree, then `to_affine` (or the
 // projective partial for the multi-GPU fold).  Also used for the fold itself.
 __global__ void __launch_bounds__(64)
-    k_final(const G1Xyzz29* __restrict__ parts, uint32_t count, uint32_t* __restrict__ out, int partial_out) {
+    k_final(const G1Xyzz29* __restrict__ parts, uint32_t count, uint32_t* __restrict__ out, int partial_out, uint32_t mont) {
   SNARKV_RAISE_PRIO();
   __shared__ G1Xyzz29 sh[64];
   uint32_t lane = threadIdx.x;
@@ -959,7 +967,7 @@ __global__ void __launch_bounds__(64)
     } else {
       G1Affine29 r = xyzz29_to_affine(sh[0]);
       uint32_t w[16];
-      g1a29_to_canonical(r, w);
+      g1a29_to_words(r, w, mont != 0);
       for (int i = 0; i < 16; ++i) out[i] = w[i];
     }
   }
@@ -968,14 +976,14 @@ __global__ void __launch_bounds__(64)
 // `jobs` folds in one launch: d_partials = [job][count] partials, d_out64s = [job] affine points
 int launch_fold_partials_many(snarkv_ctx* ctx, const void* d_partials, size_t count, size_t jobs, void* d_out64s) {
   hipLaunchKernelGGL(k_final, dim3((uint32_t)jobs), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_partials, (uint32_t)count,
-                     (uint32_t*)d_out64s, 0);
+                     (uint32_t*)d_out64s, 0, ctx->mont ? 1u : 0u);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }
 
 int launch_fold_partials(snarkv_ctx* ctx, const void* d_partials, size_t count, void* d_out64, bool partial_out) {
   hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_partials, (uint32_t)count,
-                     (uint32_t*)d_out64, partial_out ? 1 : 0);
+                     (uint32_t*)d_out64, partial_out ? 1 : 0, ctx->mont ? 1u : 0u);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }
@@ -1047,6 +1055,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   p.w0 = 0;
   p.wper = 0;
   p.chunk_log2 = (uint32_t)kLog2Chunk;
+  p.mont = ctx->mont ? 1u : 0u;
   p.n = (uint32_t)n;
   p.c = window_bits > 0 ? window_bits : balance_window_bits(default_window_bits(n));
   if (p.c < 2) p.c = 2;
@@ -1184,7 +1193,7 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
   STAGE_MARK();  // 7: window sums + 2^(cw) shift chains
   if (phases & PIP_PHASE_TAIL)
     hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, st, (const G1Xyzz29*)d_shift, (uint32_t)p.W, (uint32_t*)d_out,
-                       partial_out ? 1 : 0);
+                       partial_out ? 1 : 0, p.mont);
   STAGE_MARK();  // 8: final sum + to_affine
 #undef STAGE_MARK
   SNARKV_HIP(hipGetLastError());
@@ -1241,7 +1250,7 @@ int launch_buckets_reduce(snarkv_ctx* ctx, const void* d_buckets, uint32_t c, ui
                      (G1Xyzz29*)d_wave, p, chunks_per_window, blocks_per_window);
   hipLaunchKernelGGL(k_shift_windows, dim3(wcount), dim3(64), 0, st, (const G1Xyzz29*)d_wave, (G1Xyzz29*)d_shift, p,
                      blocks_per_window);
-  hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, st, (const G1Xyzz29*)d_shift, wcount, (uint32_t*)d_partial, 1);
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(64), 0, st, (const G1Xyzz29*)d_shift, wcount, (uint32_t*)d_partial, 1, 0u);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }
@@ -1309,7 +1318,7 @@ int launch_buckets_reduce_many(snarkv_ctx* ctx, hipStream_t st, const void* d_gr
   hipLaunchKernelGGL(k_shift_windows, dim3(wtotal), dim3(64), 0, st, (const G1Xyzz29*)g.d_wave, (G1Xyzz29*)g.d_shift, g.p,
                      g.blocks_per_window);
   hipLaunchKernelGGL(k_final, dim3(jobs), dim3(64), 0, st, (const G1Xyzz29*)g.d_shift, windows, (uint32_t*)d_out,
-                     partial_out ? 1 : 0);
+                     partial_out ? 1 : 0, ctx->mont ? 1u : 0u);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }

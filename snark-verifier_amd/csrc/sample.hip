@@ -18,7 +18,7 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t& s) {
 }
 
 // 4 stream words, top two bits cleared (< 2^254), one conditional subtraction of r.
-__global__ void k_sample_scalars(uint64_t seed, uint64_t first, uint32_t n, uint32_t* __restrict__ out) {
+__global__ void k_sample_scalars(uint64_t seed, uint64_t first, uint32_t n, uint32_t* __restrict__ out, uint32_t mont) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   constexpr uint32_t r[8] = BN254_R_LIMBS;
@@ -37,19 +37,40 @@ __global__ void k_sample_scalars(uint64_t seed, uint64_t first, uint32_t n, uint
     d[j] = (uint32_t)x;
     borrow = (x >> 32) & 1u;
   }
-  uint4* o = reinterpret_cast<uint4*>(out + (size_t)i * 8);
-  if (borrow) {
-    o[0] = make_uint4(w[0], w[1], w[2], w[3]);
-    o[1] = make_uint4(w[4], w[5], w[6], w[7]);
-  } else {
-    o[0] = make_uint4(d[0], d[1], d[2], d[3]);
-    o[1] = make_uint4(d[4], d[5], d[6], d[7]);
+  if (!borrow) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = d[j];
   }
+  if (mont) {  // the same scalar in halo2curves' in-memory form: s * 2^256 mod r, by 256 modular doublings (set-up code)
+    for (int t = 0; t < 256; ++t) {
+      uint32_t c = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        uint32_t nw = (w[j] << 1) | c;
+        c = w[j] >> 31;
+        w[j] = nw;
+      }
+      borrow = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        uint64_t x = (uint64_t)w[j] - r[j] - borrow;
+        d[j] = (uint32_t)x;
+        borrow = (x >> 32) & 1u;
+      }
+      if (c || !borrow) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = d[j];
+      }
+    }
+  }
+  uint4* o = reinterpret_cast<uint4*>(out + (size_t)i * 8);
+  o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  o[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
 // x from the stream (< 2^252), incremented until x^3+3 is a square; p = 3 mod 4
 // so y = (x^3+3)^((p+1)/4); the root with even canonical y is kept.
-__global__ void __launch_bounds__(64) k_sample_points(uint64_t seed, uint64_t first, uint32_t n, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_sample_points(uint64_t seed, uint64_t first, uint32_t n, uint32_t* __restrict__ out, uint32_t mont) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   constexpr uint32_t e[8] = BN254_P_PLUS_1_DIV_4_LIMBS;
@@ -81,7 +102,14 @@ __global__ void __launch_bounds__(64) k_sample_points(uint64_t seed, uint64_t fi
   uint32_t xw[8], yw[8];
   fq_to_canonical(x, xw);
   fq_to_canonical(y, yw);
-  if (yw[0] & 1u) fq_to_canonical(fq_neg(y), yw);
+  if (yw[0] & 1u) {
+    y = fq_neg(y);
+    fq_to_canonical(y, yw);
+  }
+  if (mont) {  // fq.h's domain is R = 2^256: its words ARE halo2curves' in-memory form
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xw[j] = x.v[j], yw[j] = y.v[j];
+  }
   uint4* o = reinterpret_cast<uint4*>(out + (size_t)i * 16);
   o[0] = make_uint4(xw[0], xw[1], xw[2], xw[3]);
   o[1] = make_uint4(xw[4], xw[5], xw[6], xw[7]);
@@ -165,14 +193,14 @@ int launch_ubench(snarkv_ctx* ctx, int which, int iters, double* ops_per_s) {
 
 int launch_sample_scalars(snarkv_ctx* ctx, uint64_t seed, uint64_t first, size_t n, void* d_out) {
   hipLaunchKernelGGL(k_sample_scalars, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, seed, first,
-                     (uint32_t)n, (uint32_t*)d_out);
+                     (uint32_t)n, (uint32_t*)d_out, ctx->mont ? 1u : 0u);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }
 
 int launch_sample_points(snarkv_ctx* ctx, uint64_t seed, uint64_t first, size_t n, void* d_out) {
   hipLaunchKernelGGL(k_sample_points, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, ctx->stream, seed, first,
-                     (uint32_t)n, (uint32_t*)d_out);
+                     (uint32_t)n, (uint32_t*)d_out, ctx->mont ? 1u : 0u);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }

@@ -356,6 +356,24 @@ int ht_decide_w(const uint8_t* q2, const uint8_t* acc, uint8_t* out, int* info) 
   if (info) info[0] = prog.rounds, info[1] = prog.regs_used, info[2] = prog.critical_path, info[3] = nops;
   return 0;
 }
+// ---------------- SNARKV_FLAG_MONTGOMERY codecs (fq29.h fq29_from_words / fq29_to_words, fr29.h fr_words_from_mont256) ---------
+// in: 32 bytes; mode 0: canonical -> in-memory form (a * 2^256 mod p) through the 29-bit domain; 1: the reverse;
+// 2: Fr in-memory -> canonical.  Exactly the device functions.
+void ht_mont_codec(const uint8_t* in, int mode, uint8_t* out) {
+  uint32_t w[8], o[8];
+  memcpy(w, in, 32);
+  if (mode == 0) fq29_to_words(fq29_from_words(w, false), o, true);
+  else if (mode == 1) fq29_to_words(fq29_from_words(w, true), o, false);
+  else fr_words_from_mont256(w, o);
+  memcpy(out, o, 32);
+}
+// a point through g1a29_from_words / g1a29_to_words in the given encodings
+void ht_g1_recode(const uint8_t* in64, int mont_in, int mont_out, uint8_t* out64) {
+  uint32_t w[16], o[16];
+  memcpy(w, in64, 64);
+  g1a29_to_words(g1a29_from_words(w, mont_in != 0), o, mont_out != 0);
+  memcpy(out64, o, 64);
+}
 void ht29_fq_mul2(const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d, int neg_c, uint8_t* out) {
   Fq29 cc = load29(c);
   if (neg_c) cc = fq29_neg(cc);

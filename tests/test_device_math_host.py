@@ -344,3 +344,31 @@ def test_program_driven_decide_kernel_on_the_host(hosttest_lib, golden_decider):
     rounds, regs, crit, nops = list(info)
     assert crit <= rounds <= crit + 40, (rounds, crit)  # the two duos keep the critical path fed
     assert regs <= 16 and nops > 500
+
+
+def test_montgomery_boundary_codecs(hosttest_lib):
+    """SNARKV_FLAG_MONTGOMERY: the device's codecs for halo2curves' in-memory form (a * 2^256 mod p in 4 x u64) against plain
+    integer arithmetic -- Fq both ways, the Fr scalar reduction, whole points incl. the identity."""
+    import mont_util as M
+
+    L = hosttest_lib
+    rng = random.Random(77)
+    o = _buf(32)
+    for v in [0, 1, 2, O.P - 1, O.P - 2, (1 << 253) + 5, (1 << 29) - 1, 1 << 232] + [rng.randrange(O.P) for _ in range(40)]:
+        b = v.to_bytes(32, "little")
+        L.ht_mont_codec(b, 0, o)
+        assert o.raw == M.fe_to_mont(b, O.P), v
+        L.ht_mont_codec(b, 1, o)
+        assert o.raw == M.fe_from_mont(b, O.P), v
+    for v in [0, 1, O.R - 1, (1 << 253) + 9] + [rng.randrange(O.R) for _ in range(40)]:
+        b = v.to_bytes(32, "little")
+        L.ht_mont_codec(M.fe_to_mont(b, O.R), 2, o)
+        assert o.raw == b, v
+    o64 = _buf(64)
+    for pt in [O.g1_to_bytes(O.g1_mul(O.G1_GEN, rng.randrange(1, O.R))) for _ in range(8)] + [bytes(64)]:
+        L.ht_g1_recode(pt, 0, 1, o64)
+        assert o64.raw == M.coords_to_mont(pt)
+        L.ht_g1_recode(M.coords_to_mont(pt), 1, 0, o64)
+        assert o64.raw == pt
+        L.ht_g1_recode(M.coords_to_mont(pt), 1, 1, o64)
+        assert o64.raw == M.coords_to_mont(pt)
