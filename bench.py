@@ -147,7 +147,7 @@ def secondary_metrics(sv, torch, ctxs, cpu=True):
         ms = t_ms(lambda: job(0))
         out["aggregate_%d_proofs" % nproofs] = {"ms": ms, "proofs_per_s": nproofs / ms * 1e3,
                                                  "msm_terms": n1 + n2, "includes_decide": True,
-                                                 "jobs_in_flight": 1,
+                                                 "jobs_in_flight": 1, "timing": "mean of 5 calls, ONE job at a time (the named config)",
                                                  "roofline": aggregate_roofline(nproofs, ms)}
         if len(ctxs) > 1:
             for c in ctxs:  # other launches are in flight next to each context's: the library's throughput hint (the
@@ -161,7 +161,8 @@ def secondary_metrics(sv, torch, ctxs, cpu=True):
             out["aggregate_%d_proofs_pipelined" % nproofs] = {
                 "ms_per_job": ms, "proofs_per_s": nproofs / ms * 1e3, "msm_terms": n1 + n2,
                 "includes_decide": True, "jobs_in_flight": len(ctxs), "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-                "results_identical": same,
+                "results_identical": same, "timing": "best of 3 timed regions of 4 x 16 jobs", "best_of": 3,
+                "NOT_the_named_config": "16 jobs in flight on 16 contexts / hardware queues: a throughput figure",
                 "roofline": aggregate_roofline(nproofs, ms)}
             for c in ctxs:
                 c.set_throughput_hint(False)
@@ -192,7 +193,9 @@ def secondary_metrics(sv, torch, ctxs, cpu=True):
         ms = min(t_ms(merged, reps=2, warm=1) for _ in range(3)) / J
         out["aggregate_%d_proofs_merged" % nproofs] = {
             "ms_per_job": ms, "proofs_per_s": nproofs / ms * 1e3, "msm_terms": (n1m + n2m) // J, "includes_decide": True,
-            "jobs_merged": J, "launch_sets": 1, "roofline": aggregate_roofline(nproofs, ms)}
+            "jobs_merged": J, "launch_sets": 1, "timing": "best of 3 timed regions of 2 merged calls", "best_of": 3,
+            "NOT_the_named_config": "16 jobs merged into one set of launches: a throughput figure",
+            "roofline": aggregate_roofline(nproofs, ms)}
         del dsm, dpm, out1m
         if cpu:  # 64 proofs ~0.15 s, 1 024 proofs ~2.5 s of one host thread
             out["aggregate_%d_proofs" % nproofs]["cpu_baseline"] = cpu_baseline_aggregate(ds, dp, offs, n1, nproofs, n2)
@@ -224,6 +227,87 @@ def secondary_metrics(sv, torch, ctxs, cpu=True):
     return out
 
 
+def host_resident_metrics(sv, torch, ctx, d_scalars_k, d_points_k, n, steps, slot_results, nsets):
+    """The drop-in rate a caller holding HOST slices sees (`util::msm::multi_scalar_multiplication(&[Fr], &[G1Affine])`,
+    util/msm.rs:308): K jobs whose scalars / points lie in pinned host memory, through snarkv_g1_msm_pippenger_many (uploads
+    on a copy stream, a job's kernels wait for its own upload only), against the link's own rate measured with the same
+    buffers -- and the same batch with SNARKV_FLAG_MONTGOMERY (halo2curves' in-memory form: no per-element conversion on
+    the host at all).  Never `value`: that is the HBM-resident rate."""
+    import ctypes
+
+    sets = min(4, nsets)  # 96 MiB of pinned memory each
+    hs = ctx.host_buffer(0, 32 * n * sets)
+    hp = ctx.host_buffer(1, 64 * n * sets)
+    for k in range(sets):
+        ctypes.memmove(ctypes.addressof(hs) + 32 * n * k, d_scalars_k[k].cpu().numpy().ctypes.data, 32 * n)
+        ctypes.memmove(ctypes.addressof(hp) + 64 * n * k, d_points_k[k].cpu().numpy().ctypes.data, 64 * n)
+    ps = [ctypes.addressof(hs) + 32 * n * (i % sets) for i in range(steps)]
+    pp = [ctypes.addressof(hp) + 64 * n * (i % sets) for i in range(steps)]
+    res = ctx.msm_pippenger_many_host(ps, pp, [n] * steps)  # initialisation: staging buffers, job contexts
+    ok = all(res[i] == slot_results[i % sets] for i in range(steps) if i % sets < len(slot_results))
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = ctx.msm_pippenger_many_host(ps, pp, [n] * steps)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    # the link alone: the same uploads with no kernel behind them
+    dst = torch.empty(96 * n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    src_s = torch.frombuffer(hs, dtype=torch.uint8)
+    src_p = torch.frombuffer(hp, dtype=torch.uint8)
+    link = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            k = i % sets
+            dst[: 32 * n].copy_(src_s[32 * n * k: 32 * n * (k + 1)], non_blocking=True)
+            dst[32 * n:].copy_(src_p[64 * n * k: 64 * n * (k + 1)], non_blocking=True)
+        torch.cuda.synchronize()
+        d = time.perf_counter() - t0
+        link = d if link is None else min(link, d)
+    out = {
+        "value": n * steps / best, "unit": "points/s", "ms_per_msm": best / steps * 1e3, "jobs": steps, "best_of": 3,
+        "entry_point": "snarkv_g1_msm_pippenger_many (host pointers; pinned memory from snarkv_ctx_host_buffer)",
+        "results_match_the_device_resident_batch": ok,
+        "pcie_bound": {"points_per_s": n * steps / link, "gb_per_s": 96.0 * n * steps / link / 1e9, "ms_per_msm": link / steps * 1e3,
+                       "how": "the same %d x 96 MiB uploads from the same pinned buffers with no kernel behind them (torch copy_, "
+                              "non_blocking), best of 3" % steps},
+        "fraction_of_pcie_bound": link / best,
+    }
+    # the same batch in halo2curves' in-memory form: inputs sampled by a context whose default is SNARKV_FLAG_MONTGOMERY
+    mctx = sv.Context(torch.cuda.current_device())
+    mctx.set_flags(sv.SNARKV_FLAG_MONTGOMERY)
+    ms_t, mp_t = torch.empty(32 * n, dtype=torch.uint8, device="cuda"), torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    mctx.sample_scalars_dev(0x5EED0001, n, ms_t.data_ptr())  # input set 0 again, the other encoding
+    mctx.sample_points_dev(0x5EED0002, n, mp_t.data_ptr())
+    mctx.sync()
+    hs2, hp2 = mctx.host_buffer(0, 32 * n), mctx.host_buffer(1, 64 * n)
+    ctypes.memmove(ctypes.addressof(hs2), ms_t.cpu().numpy().ctypes.data, 32 * n)
+    ctypes.memmove(ctypes.addressof(hp2), mp_t.cpu().numpy().ctypes.data, 64 * n)
+    a_s, a_p = [ctypes.addressof(hs2)] * steps, [ctypes.addressof(hp2)] * steps
+    r = mctx.msm_pippenger_many_host(a_s, a_p, [n] * steps)
+    bestm = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = mctx.msm_pippenger_many_host(a_s, a_p, [n] * steps)
+        d = time.perf_counter() - t0
+        bestm = d if bestm is None else min(bestm, d)
+    # decode the Montgomery result on the host (one point) and compare with the canonical one
+    P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    dec = b"".join((int.from_bytes(r[0][j:j + 32], "little") * pow(1 << 256, -1, P) % P).to_bytes(32, "little") for j in (0, 32))
+    out["in_memory_form"] = {"value": n * steps / bestm, "unit": "points/s", "ms_per_msm": bestm / steps * 1e3,
+                             "flags": "SNARKV_FLAG_MONTGOMERY", "decoded_result_matches": dec == slot_results[0],
+                             "note": "scalars and points as halo2curves holds them in memory (a * 2^256 in 4 x u64), result likewise; "
+                                     "every job reads the one pinned input set"}
+    mctx.close()
+    return out
+
+
 def aggregate_roofline(nproofs, ms):
     """SURVEY.md 8(d) for the second metric: one proof = 24 (scalar, point) pairs x 96 B = 2 304 B, + the KzgAs step's
     2 x (m + 1) pairs x 96 B, + 128 B for the decided accumulator -- algorithmic bytes of the whole job over its
@@ -248,7 +332,8 @@ def _aggregate_dominant_kernel(nproofs):
         rows = list(csv.DictReader(open(paths[-1])))
         top = max(rows, key=lambda r: float(r["TotalDurationUs"]))
         return {"name": top["Name"].split("(")[0], "share": float(top["Percentage"]) / 100.0,
-                "avg_us": float(top["AverageUs"]), "source": os.path.relpath(paths[-1], ROOT)}
+                "avg_us": float(top["AverageUs"]), "from_profile": os.path.relpath(paths[-1], ROOT),
+                "note": "read from the committed rocprofv3 summary, not measured by this run"}
     except Exception as e:  # a malformed record must not break the bench line
         return {"error": str(e)}
 
@@ -401,6 +486,7 @@ def main():
                          "--total-log2n 24); overrides --log2n")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-host-resident", action="store_true", help="skip the host-resident (PCIe-inclusive) batch measurement")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path even at world size 1 (testing)")
     ap.add_argument("--dry-run-doubles", default="",
                     help="TEST HOOK (tests/test_bench_dry_run.py): path of a module providing CPU doubles of the device context; "
@@ -614,33 +700,43 @@ def main():
 
     # single-MSM latency (strictly sequential), outside the timed region, for the record
     lat_ms, seq_stages = None, None
-    if not use_dist:
-        torch.cuda.synchronize()
+    if not dry:  # (local single-MSM calls: also on every rank of a multi-GPU run, outside its timed region)
+        dev_sync()
+        lat_out = torch.zeros(64, dtype=torch.uint8, device=dev)  # (its own buffer: `out` holds the job's result)
         # one caller, one MSM at a time: no hint
         ctx.set_throughput_hint(False)
         for _ in range(2):
-            ctx.msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, out.data_ptr(), args.window_bits)
+            ctx.msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, lat_out.data_ptr(), args.window_bits)
         ctx.sync()
         t1 = time.perf_counter()
         for _ in range(8):
-            ctx.msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, out.data_ptr(), args.window_bits)
+            ctx.msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, lat_out.data_ptr(), args.window_bits)
             ctx.sync()
         lat_ms = (time.perf_counter() - t1) / 8 * 1e3
-        assert bytes(out.cpu().numpy()) == slot_results[0]  # the latency mode gives the same bytes as the hinted in-flight run
+        # the latency mode gives the same bytes as the hinted in-flight run (multi-GPU: slot 0's result is the fold over all ranks)
+        assert use_dist or bytes(lat_out.cpu().numpy()) == slot_results[0]
         # unshared per-stage durations, for the roofline of the dominant kernel
         ctx.set_stage_timing(True)
         seq_sum = {}
         for _ in range(5):
-            ctx.msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, out.data_ptr(), args.window_bits)
+            ctx.msm_pippenger_dev(d_scalars.data_ptr(), d_points.data_ptr(), n, lat_out.data_ptr(), args.window_bits)
             for k, v in ctx.get_stage_timing().items():  # syncs
                 seq_sum[k] = seq_sum.get(k, 0.0) + v
         ctx.set_stage_timing(False)
         seq_stages = {k: v / 5 for k, v in seq_sum.items()}
 
+    host_res = None
+    if not use_dist and not dry and batch and not args.no_host_resident:
+        host_res = host_resident_metrics(sv, torch, ctx, d_scalars_k, d_points_k, n, args.steps, slot_results, nsets)
+    rccl_ranks_seen = None
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # how many ranks the communicator really spans: a sum of ones over RCCL (gloo in the dry run)
+        ones = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rccl_ranks_seen = int(ones.item())
     result_hex = bytes(out.cpu().numpy()).hex()
 
     if rank == 0:
@@ -648,7 +744,12 @@ def main():
         dom = max((k for k in stages if k != "total"), key=lambda k: stages[k])
         dom_ms = stages[dom]
         launch_n = launch_points(n, args.window_bits)  # n, or the 2^20-point chunk large MSMs are pipelined in
-        achieved = BYTES_PER_POINT * launch_n / (dom_ms * 1e-3) / 1e9
+        # the dominant kernel's per-launch duration: ONE launch alone on the GPU (sequential single-MSM calls, HIP events on
+        # the context's stream).  In the timed batch ~1.5 launches of it are co-resident, so an in-batch launch lasts longer
+        # than ms_per_step -- that stretched figure is kept as `frac_in_batch`; it is not the kernel's speed.
+        dom_alone_ms = (seq_stages or {}).get(dom, 0.0) or dom_ms
+        achieved = BYTES_PER_POINT * launch_n / (dom_alone_ms * 1e-3) / 1e9
+        achieved_in_batch = BYTES_PER_POINT * launch_n / (dom_ms * 1e-3) / 1e9
         line = {
             "metric": "BN254 G1 MSM points/sec at 2^%d" % (args.total_log2n if strong else args.log2n),
             "value": world * n * args.steps / dt,
@@ -684,6 +785,7 @@ def main():
                                                            # in-flight contexts; always on a batch's jobs); the single-MSM latency and
                                                            # the sequential stage times are taken without it
                 "single_msm_latency_ms": lat_ms,
+                "rccl_ranks_seen": rccl_ranks_seen,  # sum of ones over the process group (null: single process, no collective)
                 "result": result_hex,
             },
             "roofline": {
@@ -693,14 +795,19 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
+                "kernel_ms": dom_alone_ms,
+                "achieved_in_batch": achieved_in_batch,
+                "frac_in_batch": achieved_in_batch / HBM_PEAK_GBPS,
+                "kernel_ms_in_batch": dom_ms,
                 # HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC record of THIS tree's kernels
                 # (tools/pmc_traffic.py -> profiles/r*_pmc_hbm_traffic*.json, keyed by the kernel-source hash); null when
                 # no record matches the sources.
                 "traffic": None,  # filled below from the PMC record of THESE kernels, or left null
 
-                "note": "algorithmic 96 B/point x %d points per launch / avg HIP-event duration of the dominant stage in the "
-                        "timed region (where %d MSMs overlap, so one launch shares the GPU); the path is "
-                        "integer-VALU-bound (~160 Fq products per point), see DESIGN.md" % (launch_n, 3 if batch else inflight),
+                "note": "algorithmic 96 B/point x %d points per launch / the dominant kernel's avg HIP-event duration with ONE "
+                        "launch on the GPU (`kernel_ms`, <= ms_per_step); `*_in_batch`: the same launch inside the timed region, "
+                        "stretched by the %s launches of its kind that share the GPU there.  The path is integer-VALU-bound "
+                        "(~160 Fq products per point), see DESIGN.md section 4" % (launch_n, "~1.5" if batch else str(inflight)),
             },
             "stages_ms": stages,
         }
@@ -712,11 +819,22 @@ def main():
             k = pmc["kernels"][kname]
             line["roofline"]["traffic"] = k["bytes_corrected"]
             line["roofline"]["traffic_as_counted"] = k["bytes_as_counted"]
+            line["roofline"]["traffic_fetch_factor"] = k.get("fetch_factor")
             line["roofline"]["traffic_source"] = where + " (kernel_source_hash %s)" % pmc["kernel_source_hash"]
+            # the kernel's own byte accounting: one 64-byte point gather + one 8-byte entry per (half-scalar, window), the
+            # run partials and the bucket grid written once
+            Wn = -(-128 // 16) if not args.window_bits else -(-128 // args.window_bits)
+            entries = 2 * launch_n * Wn
+            model = entries * 72 + (entries // 96 + 1) * 288 + Wn * (1 << 15) * 144
+            line["roofline"]["traffic_model_bytes"] = model
+            line["roofline"]["traffic_over_algorithmic"] = k["bytes_corrected"] / (BYTES_PER_POINT * launch_n)
             line["roofline"]["traffic_note"] = (
-                "per launch of k_accumulate; it gathers every Montgomery point once per window (8 windows x 2^21 half-scalar "
-                "entries), mostly out of the 256 MiB Infinity Cache (the counter sits on the fabric side of L2 and includes "
-                "those hits) -- inherent to bucket accumulation, not re-reads of the 96 B/point input")
+                "per launch of k_accumulate, fabric side of L2 (Infinity-Cache hits included).  FETCH_SIZE on gfx950 tallies the "
+                "128-byte requests of wide coalesced reads at 64 B (x2, calibrated on k_prepare's 96 B/point stream: see the "
+                "record) but counts this kernel's 64-byte point gathers as they are (x1): the figure agrees with the byte "
+                "model (%d entries x (64 + 8) B + partials + grid = %.2f GB) within ~20 %%.  ~%.0fx the 96 B/point input: every "
+                "Montgomery point is gathered once per window -- inherent to bucket accumulation, not re-reads of the input"
+                % (entries, model / 1e9, k["bytes_corrected"] / (BYTES_PER_POINT * launch_n)))
         else:
             line["roofline"]["traffic_source"] = where if not pmc else "record has no %s" % kname
         # issue roofline of the dominant kernel from its ISA (tools/isa_stats.py), same hash rule
@@ -754,15 +872,14 @@ def main():
             # launch's duration stretches with the number of its kind resident at once: sum of launch durations / wall time
             conc = dom_ms * args.steps / (dt * 1e3)
             line["roofline"]["launches_resident_on_average"] = conc
-            line["roofline"]["frac_per_resident_launch"] = line["roofline"]["frac"] * max(conc, 1.0)
             line["roofline"]["overlap_note"] = (
-                "`frac` is per launch as prescribed; with %s %.2f launches of this kernel share the GPU on average, "
-                "so its duration (%.2f ms) is not the kernel's own speed -- `frac_unshared` (one MSM at a time) is"
-                % ("a batch's accumulations on three streams" if batch else "%d MSMs in flight" % inflight, conc, dom_ms))
+                "with %s %.2f launches of this kernel share the GPU on average in the timed region, so an in-batch launch lasts "
+                "%.2f ms (> ms_per_step) -- `frac_in_batch`; `frac` uses the launch alone (%.3f ms)"
+                % ("a batch's accumulations on three streams" if batch else "%d MSMs in flight" % inflight, conc, dom_ms, dom_alone_ms))
         if seq_stages:
             dseq = seq_stages.get(dom, 0.0)
             line["stages_ms_sequential"] = seq_stages
-            if dseq > 0:
+            if dseq > 0:  # (kept under the round-2 / round-3 names too: the same numbers as `achieved` / `frac`)
                 line["roofline"]["achieved_unshared"] = BYTES_PER_POINT * launch_n / (dseq * 1e-3) / 1e9
                 line["roofline"]["frac_unshared"] = line["roofline"]["achieved_unshared"] / HBM_PEAK_GBPS
         if not args.no_cpu_baseline and world == 1:
@@ -776,11 +893,28 @@ def main():
             cb["gpu_matches_on_sample"] = bytes(chk.cpu().numpy()) == cpu_out
             cb["sample_is_the_whole_workload"] = m == n
             line["cpu_baseline"] = cb
+        if host_res:
+            line["host_resident"] = host_res
         if not use_dist and not args.no_secondary:
             line["secondary"] = secondary_metrics(sv, torch, agg_ctxs, cpu=not args.no_cpu_baseline)
             e2e = end_to_end_metrics()
             if e2e:
                 line["secondary"].update(e2e)
+            # LAST key of the line (a log tail keeps it): the named BASELINE configs, ONE job at a time, then the others
+            sec = line["secondary"]
+            line["named_configs"] = {
+                "msm_2p%d_points_per_s" % args.log2n: line["value"],
+                "aggregate_64_proofs_one_job_ms": sec.get("aggregate_64_proofs", {}).get("ms"),
+                "aggregate_1024_proofs_one_job_ms": sec.get("aggregate_1024_proofs", {}).get("ms"),
+                "decide_all_1_ms": sec.get("decide_all_1", {}).get("ms"),
+                "end_to_end_aggregate_1024_distinct_proofs_ms": sec.get("end_to_end_aggregate_1024_distinct_proofs", {}).get("ms"),
+                "host_resident_points_per_s": (host_res or {}).get("value"),
+                "NOT_one_job (16 jobs in flight / merged, proofs per s)": {
+                    "aggregate_64_proofs_pipelined": sec.get("aggregate_64_proofs_pipelined", {}).get("proofs_per_s"),
+                    "aggregate_64_proofs_merged": sec.get("aggregate_64_proofs_merged", {}).get("proofs_per_s"),
+                    "aggregate_1024_proofs_pipelined": sec.get("aggregate_1024_proofs_pipelined", {}).get("proofs_per_s"),
+                    "aggregate_1024_proofs_merged": sec.get("aggregate_1024_proofs_merged", {}).get("proofs_per_s")},
+            }
         print(json.dumps(line), flush=True)
 
     if use_dist:

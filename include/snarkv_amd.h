@@ -130,6 +130,17 @@ int snarkv_g1_msm_batched_dev(snarkv_ctx* ctx, const void* d_scalars32, const vo
 #define SNARKV_MANY_MAX_JOBS 64
 int snarkv_g1_msm_pippenger_many_dev(snarkv_ctx* ctx, size_t count, const void* const* d_scalars32,
                                      const void* const* d_points64, const size_t* n, int window_bits, void* d_out64s);
+/* The batch with HOST-resident inputs (what a caller holding `&[Fr]` / `&[G1Affine]` slices has; with
+ * SNARKV_FLAG_MONTGOMERY they are passed as they lie in memory): job i's 96 n[i] bytes are uploaded on a copy stream of the
+ * context, and its kernels wait for ITS upload only, so the link and the GPU work at the same time -- a batch of 2^20-point
+ * MSMs runs at the PCIe rate (~1.8 ms per MSM on Gen5 x16) instead of upload + 1.5 ms each.  Pin the sources
+ * (snarkv_ctx_host_buffer, or snarkv_host_register on memory the caller owns): pageable memory is copied through the
+ * runtime's bounce buffer at about a third of the rate.  Synchronous: out64s[64 i ..] is valid on return. */
+int snarkv_g1_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const uint8_t* const* scalars32,
+                                 const uint8_t* const* points64, const size_t* n, uint32_t flags, uint8_t* out64s);
+/* hipHostRegister / hipHostUnregister for callers without a HIP binding (pin a Vec's buffer once, reuse it for many calls) */
+int snarkv_host_register(void* p, size_t bytes);
+int snarkv_host_unregister(void* p);
 /* the same with projective partials out (count x SNARKV_G1_PARTIAL_BYTES): a rank's shard of `count` multi-GPU MSMs --
  * ONE all-gather of all the partials, then snarkv_g1_fold_partials_dev per MSM                                        */
 int snarkv_g1_msm_pippenger_many_partial_dev(snarkv_ctx* ctx, size_t count, const void* const* d_scalars32,

@@ -85,6 +85,9 @@ _SIGNATURES = {
     "snarkv_ubench_valu": (_int, [_vp, _int, _int, ctypes.POINTER(ctypes.c_double)]),
     "snarkv_ctx_set_throughput_hint": (_int, [_vp, _int]),
     "snarkv_ctx_set_flags": (_int, [_vp, _u32]),
+    "snarkv_g1_msm_pippenger_many": (_int, [_vp, _sz, _vp, _vp, _vp, _u32, _vp]),
+    "snarkv_host_register": (_int, [_vp, _sz]),
+    "snarkv_host_unregister": (_int, [_vp]),
     "snarkv_ctx_get_flags": (_u32, [_vp]),
     "bn254_set_flags": (_int, [_u32]),
     "snarkv_g1_msm_launch_points": (_int, [_sz, ctypes.POINTER(_sz)]),
@@ -394,6 +397,26 @@ class Context:
         p = ctypes.c_void_p()
         _check(self._lib.snarkv_ctx_host_buffer(self._h, int(slot), int(nbytes), ctypes.byref(p)))
         return (ctypes.c_char * int(nbytes)).from_address(p.value)
+
+    def msm_pippenger_many_host(self, scalars, points, counts, flags=0):
+        """`snarkv_g1_msm_pippenger_many`: host-resident batch, uploads overlapped with the kernels.  scalars / points:
+        lists of host addresses (ints, e.g. into `host_buffer`s) or bytes-like objects; returns the 64-byte results."""
+        k = len(counts)
+        keep = []
+
+        def addr(x):
+            if isinstance(x, int):
+                return x
+            b = (ctypes.c_char * len(x)).from_buffer_copy(x) if isinstance(x, (bytes, bytearray, memoryview)) else x
+            keep.append(b)
+            return ctypes.addressof(b)
+
+        ps = (ctypes.c_void_p * k)(*[addr(x) for x in scalars])
+        pp = (ctypes.c_void_p * k)(*[addr(x) for x in points])
+        cn = (ctypes.c_size_t * k)(*[int(c) for c in counts])
+        out = ctypes.create_string_buffer(max(64 * k, 1))
+        _check(self._lib.snarkv_g1_msm_pippenger_many(self._h, k, ps, pp, cn, int(flags), out))
+        return [out.raw[64 * i:64 * i + 64] for i in range(k)]
 
     def set_flags(self, flags):
         """Default flags of the context (`snarkv_ctx_set_flags`): SNARKV_FLAG_MONTGOMERY makes every call on it -- the

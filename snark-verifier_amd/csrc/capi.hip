@@ -5,6 +5,7 @@
 #include <string.h>
 #include <algorithm>
 #include <mutex>
+#include <vector>
 #include <stdlib.h>
 #include "ctx.hpp"
 
@@ -316,7 +317,7 @@ int snarkv::launch_msm_pippenger_auto(snarkv_ctx* ctx, const void* d_s, const vo
 // (Measured and removed, round 3: the batch captured and replayed as ONE hipGraph -- 1.2 % slower than this eager
 // enqueue, whose host side runs 1.5 ms ahead of a 30 ms batch anyway: profiles/r03_ab_scheduling.txt, git tag exp/many-graph.)
 int snarkv::launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void* const* d_s, const void* const* d_p,
-                                      const size_t* n, int window_bits, void* d_out, bool partial_out) {
+                                      const size_t* n, int window_bits, void* d_out, bool partial_out, hipEvent_t* ready) {
   const size_t ostride = partial_out ? SNARKV_G1_PARTIAL_BYTES : 64;
   ctx->last_many_jobs = 0;
   ctx->last_split_workers = 0;
@@ -336,8 +337,10 @@ int snarkv::launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void*
   }
   const char* em = getenv("SNARKV_MANY_MODE");  // 0: one MSM after the other through the single-call path (A/B knob)
   if (count == 1 || large || (em && atoi(em) == 0) || ctx->is_lane) {
-    for (size_t i = 0; i < count; ++i)
+    for (size_t i = 0; i < count; ++i) {
+      if (ready) SNARKV_HIP(hipStreamWaitEvent(ctx->stream, ready[i], 0));
       SNARKV_TRY(launch_msm_pippenger_auto(ctx, d_s[i], d_p[i], n[i], window_bits, (uint8_t*)d_out + ostride * i, partial_out));
+    }
     return SNARKV_OK;
   }
   // jobs per round: bounded by the scratch footprint (~560 B per point + two bucket grids)
@@ -407,6 +410,7 @@ int snarkv::launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void*
       job->stage_timing = tm && last;
       void* grid = uniform ? (uint8_t*)d_grids + grid_bytes * (i - lo) : nullptr;
       hipStream_t sa = ctx->hi_stream[(i - lo) % 2], sb = S[(i - lo) % nS];
+      if (ready) SNARKV_HIP(hipStreamWaitEvent(sa, ready[i], 0));
       SNARKV_TRY(launch_msm_pippenger_phases(job, sa, PIP_PHASE_SORT, d_s[i], d_p[i], n[i], window_bits, nullptr, false,
                                              nullptr, grid));
       SNARKV_HIP(hipEventRecord(job->sorted_ev, sa));
@@ -450,6 +454,93 @@ int snarkv_g1_msm_pippenger_many_partial_dev(snarkv_ctx* ctx, size_t count, cons
     if (!d_scalars32[i] || !d_points64[i]) return SNARKV_ERR_ARG;
   SNARKV_HIP(hipSetDevice(ctx->device));
   return launch_msm_pippenger_many(ctx, count, d_scalars32, d_points64, n, window_bits, d_partials, true);
+}
+
+// HOST-resident batch: job i's scalars / points are uploaded on a copy stream of their own, one event per job, and the
+// batch scheduler makes a job's first kernel wait for ITS event only -- the uploads of jobs i + 1 .. run under the
+// kernels of jobs .. i.  A 2^20-point job is 96 MiB: ~1.8 ms over PCIe Gen5 x16 against ~1.5 ms of kernels, so a batch
+// runs at the link's rate (bench.py `host_resident`).  Pinned sources (snarkv_ctx_host_buffer, snarkv_host_register) are
+// DMA reads; pageable ones go through the runtime's bounce buffer at about a third of the rate.
+int snarkv_g1_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const uint8_t* const* scalars32,
+                                 const uint8_t* const* points64, const size_t* n, uint32_t flags, uint8_t* out64s) {
+  if (!ctx || (count && (!scalars32 || !points64 || !n || !out64s))) return SNARKV_ERR_ARG;
+  if (count == 0) return SNARKV_OK;
+  size_t total = 0;
+  for (size_t i = 0; i < count; ++i) {
+    if (!scalars32[i] || !points64[i]) return SNARKV_ERR_ARG;
+    if (n[i] == 0) return SNARKV_ERR_EMPTY;
+    total += n[i];
+  }
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  SNARKV_CALL_FLAGS(ctx, flags);
+  // staging for as many jobs at a time as fit 12 GiB (a 2^20-point job is 96 MiB); more run as successive sub-batches
+  const size_t kStageCap = (size_t)12 << 30;
+  if (!ctx->copy_ready) {
+    SNARKV_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    ctx->copy_ready = true;
+  }
+  std::vector<hipEvent_t> evs(count, nullptr);
+  auto drop_events = [&]() {
+    for (auto e : evs)
+      if (e) (void)hipEventDestroy(e);
+  };
+  int rc = SNARKV_OK;
+  for (size_t lo = 0; lo < count && rc == SNARKV_OK;) {
+    size_t hi = lo, pts = 0;
+    while (hi < count && (hi == lo || (pts + n[hi]) * 96 <= kStageCap)) pts += n[hi++];
+    void *d_s = nullptr, *d_p = nullptr, *d_out = nullptr;
+    rc = ctx_reserve(ctx, SLOT_IN_SCALARS, pts * 32, &d_s);
+    if (rc == SNARKV_OK) rc = ctx_reserve(ctx, SLOT_IN_POINTS, pts * 64, &d_p);
+    if (rc == SNARKV_OK) rc = ctx_reserve(ctx, SLOT_OUT, (hi - lo) * 64, &d_out);
+    if (rc != SNARKV_OK) break;
+    std::vector<const void*> ps(hi - lo), pp(hi - lo);
+    // the staging buffers may still be read by work queued on the context's stream: the uploads start behind it
+    hipEvent_t& fence = evs[lo];  // (re-recorded below as job lo's own event)
+    if (!fence && hipEventCreateWithFlags(&fence, hipEventDisableTiming) != hipSuccess) { rc = SNARKV_ERR_DEVICE; break; }
+    (void)hipEventRecord(fence, ctx->stream);
+    (void)hipStreamWaitEvent(ctx->copy_stream, fence, 0);
+    size_t off = 0;
+    for (size_t i = lo; i < hi && rc == SNARKV_OK; ++i) {
+      ps[i - lo] = (const uint8_t*)d_s + 32 * off;
+      pp[i - lo] = (const uint8_t*)d_p + 64 * off;
+      if (hipMemcpyAsync((void*)ps[i - lo], scalars32[i], n[i] * 32, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess ||
+          hipMemcpyAsync((void*)pp[i - lo], points64[i], n[i] * 64, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess ||
+          (!evs[i] && hipEventCreateWithFlags(&evs[i], hipEventDisableTiming) != hipSuccess) ||
+          hipEventRecord(evs[i], ctx->copy_stream) != hipSuccess) {
+        set_last_error("host-resident batch: upload of job %zu failed: %s", i, hipGetErrorString(hipGetLastError()));
+        rc = SNARKV_ERR_DEVICE;
+      }
+      off += n[i];
+    }
+    if (rc != SNARKV_OK) break;
+    if ((flags | ctx->flags) & SNARKV_FLAG_VALIDATE) {  // validation reads everything: no overlap on this path
+      (void)hipStreamSynchronize(ctx->copy_stream);
+      rc = check_validate(ctx, d_s, d_p, pts, flags);
+      if (rc != SNARKV_OK) break;
+    }
+    rc = launch_msm_pippenger_many(ctx, hi - lo, ps.data(), pp.data(), n + lo, 0, d_out, false, evs.data() + lo);
+    if (rc == SNARKV_OK) rc = fetch_out(ctx, d_out, out64s + 64 * lo, (hi - lo) * 64);
+    lo = hi;
+  }
+  if (rc != SNARKV_OK) {
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  drop_events();
+  return rc;
+}
+
+// hipHostRegister / hipHostUnregister for callers without a HIP binding: pins `bytes` at `p` (e.g. a Vec<G1Affine>'s
+// buffer) so that the uploads above are DMA reads straight out of it
+int snarkv_host_register(void* p, size_t bytes) {
+  if (!p || !bytes) return SNARKV_ERR_ARG;
+  SNARKV_HIP(hipHostRegister(p, bytes, hipHostRegisterDefault));
+  return SNARKV_OK;
+}
+int snarkv_host_unregister(void* p) {
+  if (!p) return SNARKV_ERR_ARG;
+  SNARKV_HIP(hipHostUnregister(p));
+  return SNARKV_OK;
 }
 
 int snarkv_g1_msm_pippenger(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8_t* points64, size_t n,

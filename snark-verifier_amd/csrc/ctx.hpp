@@ -101,6 +101,8 @@ struct snarkv_ctx {
   int njobs;
   int last_many_jobs;    // > 0: the last call was a batch of that many jobs per round (stage timing reads the jobs' events)
   size_t many_sig;       // shape of the last batch (a new shape may grow scratch: synchronise first)
+  hipStream_t copy_stream;   // host-resident batches (snarkv_g1_msm_pippenger_many): the uploads, one event per job
+  bool copy_ready;
   hipEvent_t many_ev[2];
   hipStream_t hi_stream[2];  // high-priority streams of the batch pipeline (the sorts) + their join events (many_ev)
   bool hi_ready;
@@ -136,8 +138,10 @@ int launch_msm_pippenger_phases(snarkv_ctx* ctx, hipStream_t st, int phases, con
 int launch_buckets_reduce_many(snarkv_ctx* ctx, hipStream_t st, const void* d_grids, uint32_t c, uint32_t windows,
                                uint32_t jobs, void* d_out, bool partial_out);
 // `count` independent MSMs, phase-ordered over private job contexts (capi.hip)
+// `ready` (optional): one event per job -- its inputs are in place (uploads of a host-resident batch); a job's first kernel
+// waits for its event only, so the uploads of later jobs run under the kernels of earlier ones
 int launch_msm_pippenger_many(snarkv_ctx* ctx, size_t count, const void* const* d_scalars, const void* const* d_points,
-                              const size_t* n, int window_bits, void* d_out, bool partial_out);
+                              const size_t* n, int window_bits, void* d_out, bool partial_out, hipEvent_t* ready = nullptr);
 // the product path of a large MSM: single launch, or the chunk pipeline over shared bucket grids (capi.hip)
 int launch_msm_pippenger_auto(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
                               void* d_out, bool partial_out);

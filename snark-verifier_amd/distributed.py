@@ -16,6 +16,25 @@ from dataclasses import dataclass
 from typing import Callable
 
 
+def all_gather_bytes(part):
+    """every rank's `part` (uint8, same length), concatenated in rank order, on `part`'s device.  RCCL ("nccl") gathers device
+    tensors directly; any other backend (gloo: CPU ranks, or several processes sharing ONE GPU, which RCCL refuses) is
+    host-staged -- the payloads here are 144-byte partials and 128-byte accumulators."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    if part.device.type != "cuda" or dist.get_backend() == "nccl":
+        out = torch.empty(world * part.numel(), dtype=torch.uint8, device=part.device)
+        dist.all_gather_into_tensor(out, part)
+        return out
+    torch.cuda.current_stream().synchronize()
+    host = part.cpu()
+    out = torch.empty(world * host.numel(), dtype=torch.uint8)
+    dist.all_gather_into_tensor(out, host)
+    return out.to(part.device)
+
+
 def shard_range(n_total: int, rank: int, world: int):
     """Contiguous shard [lo, hi) of rank `rank`: chunk = ceil(n / world), as
     `Integer::div_ceil(&scalars.len(), &num_threads)` (msm.rs:322)."""
@@ -46,11 +65,7 @@ class ShardedMsm:
         lo, hi = shard_range(n_total, rank, world)
         part = self.partial_fn(lo, hi)
         assert part.numel() == self.partial_bytes and part.dtype == torch.uint8
-        if world == 1:
-            gathered = part
-        else:
-            gathered = torch.empty(world * self.partial_bytes, dtype=torch.uint8, device=part.device)
-            dist.all_gather_into_tensor(gathered, part)
+        gathered = part if world == 1 else all_gather_bytes(part)
         return self.fold_fn(gathered, world)
 
 
@@ -126,11 +141,7 @@ class ShardedMsmBatch:
 
         world = dist.get_world_size() if dist.is_initialized() else 1
         assert parts.numel() == k * self.partial_bytes and parts.dtype == torch.uint8
-        if world == 1:
-            gathered = parts
-        else:
-            gathered = torch.empty(world * k * self.partial_bytes, dtype=torch.uint8, device=parts.device)
-            dist.all_gather_into_tensor(gathered, parts)  # [rank][job][partial]
+        gathered = parts if world == 1 else all_gather_bytes(parts)  # [rank][job][partial]
         by_job = gathered.view(world, k, self.partial_bytes).transpose(0, 1).contiguous()  # [job][rank][partial]
         return self.fold_fn(by_job, world, k)
 
@@ -225,9 +236,15 @@ class BucketShardedMsm:
         else:
             counts = [shard_range(self.windows, r, world) for r in range(world)]
             own = (w1 - w0) * wbytes
-            recv = torch.empty(world * own, dtype=torch.uint8, device=grid.device)
-            dist.all_to_all_single(recv, grid, output_split_sizes=[own] * world,
-                                   input_split_sizes=[(b - a) * wbytes for a, b in counts])
+            splits = [(b - a) * wbytes for a, b in counts]
+            if grid.device.type != "cuda" or dist.get_backend() == "nccl":
+                recv = torch.empty(world * own, dtype=torch.uint8, device=grid.device)
+                dist.all_to_all_single(recv, grid, output_split_sizes=[own] * world, input_split_sizes=splits)
+            else:  # host-staged (gloo with device-resident grids: several processes on one GPU)
+                torch.cuda.current_stream().synchronize()
+                recv_h = torch.empty(world * own, dtype=torch.uint8)
+                dist.all_to_all_single(recv_h, grid.cpu(), output_split_sizes=[own] * world, input_split_sizes=splits)
+                recv = recv_h.to(grid.device)
             mine = recv[:own]
             for r in range(1, world):
                 if own:
@@ -237,11 +254,7 @@ class BucketShardedMsm:
         else:  # more ranks than windows: this rank contributes the identity
             part = torch.zeros(self.partial_bytes, dtype=torch.uint8, device=grid.device)
         assert part.numel() == self.partial_bytes
-        if world == 1:
-            gathered = part
-        else:
-            gathered = torch.empty(world * self.partial_bytes, dtype=torch.uint8, device=part.device)
-            dist.all_gather_into_tensor(gathered, part)
+        gathered = part if world == 1 else all_gather_bytes(part)
         return self.fold_fn(gathered, world)
 
 
@@ -312,11 +325,7 @@ class ShardedIpaDecide:
         else:  # more ranks than points: the identity
             part = torch.zeros(self.partial_bytes, dtype=torch.uint8, device="cuda" if world > 1 and dist.get_backend() == "nccl" else "cpu")
         assert part.numel() == self.partial_bytes and part.dtype == torch.uint8
-        if world == 1:
-            gathered = part
-        else:
-            gathered = torch.empty(world * self.partial_bytes, dtype=torch.uint8, device=part.device)
-            dist.all_gather_into_tensor(gathered, part)
+        gathered = part if world == 1 else all_gather_bytes(part)
         got = self.fold_fn(gathered, world)
         return bytes(got.cpu().numpy()) == bytes(u)
 

@@ -39,6 +39,7 @@ def test_weak_scaling_line_from_n_ranks(world):
     assert abs(d["value"] - world * n * steps / (d["ms_per_step"] * steps * 1e-3)) < 1e-6 * d["value"]  # whole-job aggregate
     assert "DRY RUN" in d["data"] and "cpu_baseline" not in d and "secondary" not in d
     assert "point-sharded x%d" % world in d["config"]["parallelism"]
+    assert d["config"]["rccl_ranks_seen"] == world  # the sum of ones over the process group: the communicator spans every rank
     # slot 0 of rank r holds points [r n, (r + 1) n) of the seeded streams: the reported result is the MSM over [0, N n)
     s, p = C.sample_scalars(0x5EED0001, world * n), C.sample_points(0x5EED0002, world * n)
     assert d["config"]["result"] == C.msm_pippenger(s, p, 4).hex()
