@@ -22,7 +22,7 @@
 namespace snarkv {
 
 // a^((p + 1) / 4): the square root of a square, for p = 3 (mod 4).  Lane-uniform exponent: no divergence.
-__device__ __noinline__ Fq29 fq29_pow_p_plus_1_over_4(const Fq29& a) {
+__device__ __noinline__ Fq29 fq29_pow_p_plus_1_over_4(const Fq29 a) {  // by value: registers, not the stack
   constexpr uint32_t e[8] = {0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u,
                              0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};  // (p + 1) / 4 < 2^253
   Fq29 res = fq29_one();

@@ -602,7 +602,12 @@ SNARKV_HD void s30_update_de(S30& d, S30& e, const int32_t t[4], const S30& m, u
 }
 
 // a^-1 mod p for a in [0, p) (0 -> 0); plain integers, 8 x u32 little-endian
-SNARKV_HD_NOINLINE void fq_words_inv_safegcd(const uint32_t a[8], uint32_t out[8]) {
+// (by value: array parameters of a non-inlined device function live on the stack -- 80 bytes of scratch per lane in every
+// kernel that inverts: profiles/r03_kernel_resource_usage.txt)
+SNARKV_HD_NOINLINE U256w fq_words_inv_safegcd_v(const U256w av) {
+  const uint32_t* a = av.w;
+  U256w outv;
+  uint32_t* out = outv.w;
   const S30 m = s30_modulus();
   const uint32_t minv30 = s30_modulus_inv30();
   S30 f = m, g, d, e;
@@ -678,6 +683,15 @@ SNARKV_HD_NOINLINE void fq_words_inv_safegcd(const uint32_t a[8], uint32_t out[8
     if (word < 8) out[word] |= (uint32_t)tt;
     if (word + 1 < 8) out[word + 1] |= (uint32_t)(tt >> 32);
   }
+  return outv;
+}
+SNARKV_HD void fq_words_inv_safegcd(const uint32_t a[8], uint32_t out[8]) {
+  U256w x;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x.w[i] = a[i];
+  const U256w r = fq_words_inv_safegcd_v(x);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = r.w[i];
 }
 
 // Field inverse in the Montgomery domain; a within (-8p, 8p), result

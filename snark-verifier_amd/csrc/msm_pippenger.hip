@@ -649,16 +649,18 @@ __global__ void __launch_bounds__(64, SNARKV_ACC_WAVES)
 // --------------------------------------------------------------- P5
 // Careful recomputation of one bucket straight from its sorted entries (the
 // rare bucket in which a fast addition met P = +-Q: duplicate / opposite bases).
-__device__ __noinline__ G1Xyzz29 bucket_from_entries_careful(const uint2* __restrict__ entries,
-                                                             const G1Packed* __restrict__ pts, uint32_t o,
-                                                             uint32_t cnt, uint32_t first, uint32_t stride) {
+// The result goes to memory (`out`: the bucket itself, or the caller's LDS slot), not back by value: a 144-byte return of
+// a non-inlined function travels through the stack (160 bytes of scratch per lane in k_combine until round 4).
+__device__ __noinline__ void bucket_from_entries_careful(const uint2* __restrict__ entries, const G1Packed* __restrict__ pts,
+                                                         uint32_t o, uint32_t cnt, uint32_t first, uint32_t stride,
+                                                         bool sanitize, G1Xyzz29* out) {
   G1Xyzz29 acc = xyzz29_identity();
   for (uint32_t e = o + first; e < o + cnt; e += stride) {
     uint2 ent = entries[e];
     G1Affine29 p = entry_point(pts[ent.y & kEntryIdx], ent.y);
     xyzz29_madd_careful(acc, p);
   }
-  return acc;
+  *out = sanitize ? xyzz29_sanitize(acc) : acc;
 }
 
 // the run slots [s0, s1] that hold partials of a bucket whose entries are entries[o, o + cnt): runs are cut every
@@ -712,8 +714,8 @@ __global__ void __launch_bounds__(64)
   }
   if (!touched) acc = buckets[b];  // interior to one run: P4 stored it
   bad = bad || xyzz29_is_degenerate(acc);
-  if (bad) acc = xyzz29_sanitize(bucket_from_entries_careful(entries, pts, o, cnt, 0, 1));
-  if (touched || bad) buckets[b] = acc;
+  if (bad) bucket_from_entries_careful(entries, pts, o, cnt, 0, 1, true, &buckets[b]);
+  else if (touched) buckets[b] = acc;
 }
 
 // Buckets that span many runs (skewed scalar distributions: e.g. all scalars
@@ -750,8 +752,8 @@ __global__ void __launch_bounds__(256)
         }
     if (bad) atomicOr(&any_bad, 1);
     __syncthreads();
-    if (any_bad) acc = bucket_from_entries_careful(entries, pts, o, cnt, threadIdx.x, 256);
-    sh[threadIdx.x] = acc;
+    if (any_bad) bucket_from_entries_careful(entries, pts, o, cnt, threadIdx.x, 256, false, &sh[threadIdx.x]);
+    else sh[threadIdx.x] = acc;
     __syncthreads();
     for (uint32_t st = 128; st >= 1; st >>= 1) {
       if (threadIdx.x < st) {
@@ -822,9 +824,11 @@ __device__ __forceinline__ bool chunk_sums(const G1Xyzz29* __restrict__ bw, uint
 // the two weighting steps, 6 more scan steps whose lane 0 ends with the sum.
 // Careful adders throughout: partial sums of neighbouring lanes can coincide or
 // cancel (duplicated points), and 14 adds per wave are not worth a redo path.
+// (`total` goes straight to `total_dst` -- lane 0 stores it when it exists, null: not wanted -- instead of living through
+// the remaining eight steps: the compiler kept those 144 bytes on the stack.)
 __device__ __forceinline__ void wave_weighted_fold(G1Xyzz29* sh, const G1Xyzz29& run, const G1Xyzz29& acc,
                                                    const G1Xyzz29& extra, int log2_l, int log2_scale,
-                                                   G1Xyzz29& out, G1Xyzz29& total) {
+                                                   G1Xyzz29& out, G1Xyzz29* total_dst) {
   const uint32_t lane = threadIdx.x;
   G1Xyzz29 x = run;
 #pragma unroll 1
@@ -834,7 +838,7 @@ __device__ __forceinline__ void wave_weighted_fold(G1Xyzz29* sh, const G1Xyzz29&
     G1Xyzz29 y;
     int ndbl = 0;
     if (step == 6) {
-      total = sh[0];
+      if (lane == 0 && total_dst) *total_dst = sh[0];
       x = xyzz29_sel(lane >= 1, x, xyzz29_identity());
       y = acc;
       ndbl = log2_l;
@@ -880,12 +884,9 @@ __global__ void __launch_bounds__(64)
     const G1Xyzz29* bw = buckets + (size_t)w * p.B;
     if (chunk_sums<false>(bw, base, top, run, acc)) chunk_sums<true>(bw, base, top, run, acc);
   }
-  G1Xyzz29 t, s;
-  wave_weighted_fold(sh, run, acc, xyzz29_identity(), (int)p.chunk_log2, 0, t, s);
-  if (threadIdx.x == 0) {
-    block_parts[2 * (size_t)blockIdx.x] = t;
-    block_parts[2 * (size_t)blockIdx.x + 1] = s;
-  }
+  G1Xyzz29 t;
+  wave_weighted_fold(sh, run, acc, xyzz29_identity(), (int)p.chunk_log2, 0, t, &block_parts[2 * (size_t)blockIdx.x + 1]);
+  if (threadIdx.x == 0) block_parts[2 * (size_t)blockIdx.x] = t;
 }
 
 // --------------------------------------------------------------- P8
@@ -927,8 +928,8 @@ __global__ void __launch_bounds__(64)
     else if (k == 1) run = x;
     else acc_t = x;
   }
-  G1Xyzz29 r, total;
-  wave_weighted_fold(sh, run, acc_s, acc_t, 31 - __clz((int)per), 6 + (int)p.chunk_log2, r, total);  // a P6 block covers 64 chunks
+  G1Xyzz29 r;
+  wave_weighted_fold(sh, run, acc_s, acc_t, 31 - __clz((int)per), 6 + (int)p.chunk_log2, r, nullptr);  // a P6 block covers 64 chunks
   const uint32_t wl = p.wper ? w % p.wper : w;  // window index inside its own MSM
   if (!xyzz29_is_identity(r)) r = xyzz29_double_n_quad(r, p.c * (int)(wl + p.w0));
   if (lane == 0) shifted[w] = r;

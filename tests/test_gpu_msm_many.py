@@ -168,3 +168,42 @@ def test_the_bench_shape_2p20_times_six_against_single_calls():
     assert st["total"] > 0 and st["bucket_accumulate"] > 0
     assert bytes(out.cpu().numpy()) == got
     ctx.close()
+
+
+def test_host_resident_batch(gpu_ctx, monkeypatch):
+    """`snarkv_g1_msm_pippenger_many` (host pointers: the uploads run on a copy stream under the kernels of earlier jobs):
+    every job = the oracle, from pageable bytes and from the context's pinned buffers, uniform / ragged / more jobs than a
+    round / the one-after-the-other fall-back; validation and the error codes of the single-call entry point."""
+    import ctypes
+
+    import snark_verifier_amd as sv
+
+    for sizes in ([30_000] * 5, [1, 77, 4096, 65_536, 3], [2000 + 11 * i for i in range(70)]):
+        jobs = _jobs(sizes, 0x5600 + len(sizes))
+        exp = [C.msm_pippenger(s, p, 8) for s, p in jobs]
+        assert gpu_ctx.msm_pippenger_many_host([s for s, _ in jobs], [p for _, p in jobs], sizes) == exp, sizes[:3]
+    # pinned sources (snarkv_ctx_host_buffer), passed by address
+    sizes = [50_000, 20_000, 50_000]
+    jobs = _jobs(sizes, 0x5700)
+    hs, hp = gpu_ctx.host_buffer(2, 32 * sum(sizes)), gpu_ctx.host_buffer(3, 64 * sum(sizes))
+    ps, pp, off = [], [], 0
+    for (s, p), n in zip(jobs, sizes):
+        ctypes.memmove(ctypes.addressof(hs) + 32 * off, s, 32 * n)
+        ctypes.memmove(ctypes.addressof(hp) + 64 * off, p, 64 * n)
+        ps.append(ctypes.addressof(hs) + 32 * off), pp.append(ctypes.addressof(hp) + 64 * off)
+        off += n
+    exp = [C.msm_pippenger(s, p, 8) for s, p in jobs]
+    assert gpu_ctx.msm_pippenger_many_host(ps, pp, sizes) == exp
+    assert gpu_ctx.msm_pippenger_many_host(ps, pp, sizes, sv.SNARKV_FLAG_VALIDATE) == exp
+    monkeypatch.setenv("SNARKV_MANY_MODE", "0")  # one MSM after the other: each waits for its own upload
+    assert gpu_ctx.msm_pippenger_many_host(ps, pp, sizes) == exp
+    monkeypatch.delenv("SNARKV_MANY_MODE")
+    bad = bytearray(jobs[1][1])
+    bad[64 * 5] ^= 1
+    with pytest.raises(sv.SnarkvError) as e:
+        gpu_ctx.msm_pippenger_many_host([s for s, _ in jobs], [jobs[0][1], bytes(bad), jobs[2][1]], sizes, sv.SNARKV_FLAG_VALIDATE)
+    assert e.value.code == -3
+    with pytest.raises(sv.SnarkvError) as e:
+        gpu_ctx.msm_pippenger_many_host([jobs[0][0], b"\x00" * 32], [jobs[0][1], b"\x00" * 64], [sizes[0], 0])
+    assert e.value.code == -1
+    assert gpu_ctx.msm_pippenger_many_host([], [], []) == []
