@@ -238,9 +238,13 @@ def host_resident_metrics(sv, torch, ctx, d_scalars_k, d_points_k, n, steps, slo
     sets = min(4, nsets)  # 96 MiB of pinned memory each
     hs = ctx.host_buffer(0, 32 * n * sets)
     hp = ctx.host_buffer(1, 64 * n * sets)
+    def to_pinned(dst_addr, dev_tensor, nbytes):
+        a = dev_tensor.cpu().numpy()  # (kept alive across the copy)
+        ctypes.memmove(dst_addr, a.ctypes.data, nbytes)
+
     for k in range(sets):
-        ctypes.memmove(ctypes.addressof(hs) + 32 * n * k, d_scalars_k[k].cpu().numpy().ctypes.data, 32 * n)
-        ctypes.memmove(ctypes.addressof(hp) + 64 * n * k, d_points_k[k].cpu().numpy().ctypes.data, 64 * n)
+        to_pinned(ctypes.addressof(hs) + 32 * n * k, d_scalars_k[k], 32 * n)
+        to_pinned(ctypes.addressof(hp) + 64 * n * k, d_points_k[k], 64 * n)
     ps = [ctypes.addressof(hs) + 32 * n * (i % sets) for i in range(steps)]
     pp = [ctypes.addressof(hp) + 64 * n * (i % sets) for i in range(steps)]
     res = ctx.msm_pippenger_many_host(ps, pp, [n] * steps)  # initialisation: staging buffers, job contexts
@@ -286,8 +290,8 @@ def host_resident_metrics(sv, torch, ctx, d_scalars_k, d_points_k, n, steps, slo
     mctx.sample_points_dev(0x5EED0002, n, mp_t.data_ptr())
     mctx.sync()
     hs2, hp2 = mctx.host_buffer(0, 32 * n), mctx.host_buffer(1, 64 * n)
-    ctypes.memmove(ctypes.addressof(hs2), ms_t.cpu().numpy().ctypes.data, 32 * n)
-    ctypes.memmove(ctypes.addressof(hp2), mp_t.cpu().numpy().ctypes.data, 64 * n)
+    to_pinned(ctypes.addressof(hs2), ms_t, 32 * n)
+    to_pinned(ctypes.addressof(hp2), mp_t, 64 * n)
     a_s, a_p = [ctypes.addressof(hs2)] * steps, [ctypes.addressof(hp2)] * steps
     r = mctx.msm_pippenger_many_host(a_s, a_p, [n] * steps)
     bestm = None

@@ -20,6 +20,7 @@
 #include "g1_29.h"
 #include "glv.h"
 #include "fr29.h"
+#include <algorithm>
 
 namespace snarkv {
 
@@ -326,6 +327,287 @@ __global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES) k_term_scalar_mul_join
   out[2 * (size_t)t] = acc;
 }
 
+// K1 for THROUGHPUT-bound launches, continued: up to kGroupMax terms OF ONE SEGMENT per lane on shared doublings.  The joint
+// form above spends 129 doublings (~1 160 products) per term next to its 2 x 43 additions (~1 200); a segment's sum is
+// what the caller wants, so the terms a lane owns can share ONE accumulator and its doublings: per term 1 160 / K + 1 200
+// products -- K = 3: 1 590, K = 4: 1 490 against 2 360 -- on a chain K times as long per step, i.e. for launches that fill
+// the machine several times over (16 merged 1 024-proof jobs: 393 216 terms).
+//   lanes     segment s of L_s terms gets ceil(L_s / K) lanes; K in {2, 3, 4} is chosen ON THE DEVICE (the offsets live
+//             there) as the cheapest by  lanes x (1 160 + K x 1 200): three small kernels count, choose + scan, fill the
+//             lane -> segment map, and a lane finds its segment by binary search
+//   grid      at most the machine's resident wavefronts; a block walks its share of the lanes, so the table scratch is
+//             sized by the machine, not by the launch
+//   tables    per term Q (x, y, beta x) and 2Q, 3Q, 4Q (XYZZ + beta X) in the global scratch, limb-major per lane as above
+//   digits    signed 3-bit, both halves, as NIBBLES in LDS (K x 2 x 22 bytes per lane)
+// Output: the group's sum in the slot of its first term, the identity in the group's other slots (the fold is unchanged).
+// A degenerate accumulator (P = +-Q met: e.g. a base listed twice in one group) sends every term of the group through the
+// careful bit-serial form, as in the joint kernel.
+constexpr int kGroupMax = 4;
+constexpr int kGroupRows = 27 + 3 * 45;  // table rows per term: Q's x, y, beta x; then 2Q, 3Q, 4Q with 45 rows each
+
+__global__ void __launch_bounds__(256) k_gmap_count(const uint32_t* __restrict__ offsets, uint32_t n_msm, uint32_t* __restrict__ bsum) {
+  __shared__ uint32_t sh[3][256];
+  const uint32_t tid = threadIdx.x, nblk = gridDim.x;
+  uint32_t c[3] = {0, 0, 0};
+  for (uint32_t q = 0; q < 4; ++q) {
+    const uint32_t sg = blockIdx.x * 1024 + q * 256 + tid;
+    if (sg < n_msm) {
+      const uint32_t L = offsets[sg + 1] - offsets[sg];
+      c[0] += (L + 1) / 2, c[1] += (L + 2) / 3, c[2] += (L + 3) / 4;
+    }
+  }
+  for (int k = 0; k < 3; ++k) sh[k][tid] = c[k];
+  __syncthreads();
+  for (uint32_t st = 128; st >= 1; st >>= 1) {
+    if (tid < st)
+      for (int k = 0; k < 3; ++k) sh[k][tid] += sh[k][tid + st];
+    __syncthreads();
+  }
+  if (tid < 3) bsum[tid * nblk + blockIdx.x] = sh[tid][0];
+}
+
+// one block: totals per K, the choice, and the exclusive scan of the chosen K's block sums (in place in its row)
+__global__ void __launch_bounds__(1024) k_gmap_choose(uint32_t* __restrict__ bsum, uint32_t nblk, uint32_t* __restrict__ choice,
+                                                      uint32_t force_k) {
+  __shared__ uint32_t sh[1024];
+  __shared__ uint32_t tot[3], run, kk;
+  const uint32_t tid = threadIdx.x;
+  for (int k = 0; k < 3; ++k) {
+    uint32_t a = 0;
+    for (uint32_t b = tid; b < nblk; b += 1024) a += bsum[k * nblk + b];
+    sh[tid] = a;
+    __syncthreads();
+    for (uint32_t st = 512; st >= 1; st >>= 1) {
+      if (tid < st) sh[tid] += sh[tid + st];
+      __syncthreads();
+    }
+    if (tid == 0) tot[k] = sh[0];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    uint32_t best = 0;
+    unsigned long long bc = ~0ull;
+    for (uint32_t k = 0; k < 3; ++k) {
+      const unsigned long long cost = (unsigned long long)tot[k] * (1160ull + (k + 2) * 1200ull);
+      if (cost < bc) bc = cost, best = k;
+    }
+    if (force_k >= 2 && force_k <= 4) best = force_k - 2;
+    kk = best;
+    run = 0;
+    choice[0] = best + 2;
+    choice[1] = tot[best];
+  }
+  __syncthreads();
+  uint32_t* row = bsum + kk * nblk;
+  for (uint32_t base = 0; base < nblk; base += 1024) {
+    const uint32_t idx = base + tid;
+    const uint32_t v = idx < nblk ? row[idx] : 0;
+    sh[tid] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+      const uint32_t t = tid >= off ? sh[tid - off] : 0;
+      __syncthreads();
+      sh[tid] += t;
+      __syncthreads();
+    }
+    const uint32_t r0 = run;
+    if (idx < nblk) row[idx] = r0 + sh[tid] - v;
+    __syncthreads();
+    if (tid == 1023) run = r0 + sh[1023];
+    __syncthreads();
+  }
+}
+
+// base[s] = lanes before segment s for the chosen K; base[n_msm] = all of them
+__global__ void __launch_bounds__(256) k_gmap_fill(const uint32_t* __restrict__ offsets, uint32_t n_msm, const uint32_t* __restrict__ bsum,
+                                                   const uint32_t* __restrict__ choice, uint32_t* __restrict__ base) {
+  __shared__ uint32_t sh[256];
+  const uint32_t tid = threadIdx.x, nblk = gridDim.x, K = choice[0];
+  uint32_t c[4], mine = 0;
+  for (uint32_t q = 0; q < 4; ++q) {
+    const uint32_t sg = blockIdx.x * 1024 + tid * 4 + q;
+    c[q] = sg < n_msm ? (offsets[sg + 1] - offsets[sg] + K - 1) / K : 0;
+    mine += c[q];
+  }
+  sh[tid] = mine;
+  __syncthreads();
+  for (uint32_t off = 1; off < 256; off <<= 1) {
+    const uint32_t t = tid >= off ? sh[tid - off] : 0;
+    __syncthreads();
+    sh[tid] += t;
+    __syncthreads();
+  }
+  uint32_t run = bsum[(K - 2) * nblk + blockIdx.x] + sh[tid] - mine;
+  for (uint32_t q = 0; q < 4; ++q) {
+    const uint32_t sg = blockIdx.x * 1024 + tid * 4 + q;
+    if (sg < n_msm) base[sg] = run;
+    run += c[q];
+  }
+  if (blockIdx.x == 0 && tid == 0) base[n_msm] = choice[1];
+}
+
+__global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES)
+    k_term_scalar_mul_group(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points, G1Xyzz29* __restrict__ out,
+                            const uint32_t* __restrict__ offsets, uint32_t n_msm, const uint32_t* __restrict__ base,
+                            const uint32_t* __restrict__ choice, int32_t* __restrict__ tabg, uint32_t mont) {
+  __shared__ uint8_t dig[kGroupMax][2][(kWinDigits + 1) / 2][64];
+  const uint32_t lane = threadIdx.x, K = choice[0], T = choice[1];
+  int32_t(*tab)[kGroupRows][64] = reinterpret_cast<int32_t(*)[kGroupRows][64]>(tabg + (size_t)blockIdx.x * kGroupMax * kGroupRows * 64);
+  constexpr int32_t bl[9] = SNARKV_GLV_BETA29_LIMBS;
+  Fq29 beta;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) beta.v[j] = bl[j];
+#pragma unroll 1
+  for (uint32_t g0 = blockIdx.x * 64; g0 < T; g0 += gridDim.x * 64) {
+    const uint32_t g = g0 + lane;
+    const bool live = g < T;
+    uint32_t first = 0, cnt = 0;
+    if (live) {  // the segment whose lanes include g: the last s with base[s] <= g
+      uint32_t lo = 0, hi = n_msm;  // base[lo] <= g < base[hi]
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (base[mid] <= g) lo = mid;
+        else hi = mid;
+      }
+      first = offsets[lo] + (g - base[lo]) * K;
+      const uint32_t end = offsets[lo + 1];
+      cnt = end - first < K ? end - first : K;
+    }
+    // ---- per term: table + digits
+#pragma unroll 1
+    for (uint32_t j = 0; j < K; ++j) {
+      bool has = live && j < cnt;
+      uint32_t mag[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, neg[2] = {0, 0};
+      if (has) {
+        uint32_t k[8], halves[8];
+        const G1Affine29 q = load_term(scalars, points, first + j, mont, k);
+        glv_decompose(k, halves);
+        uint32_t any = 0;
+        for (int h = 0; h < 2; ++h) {
+          for (int w = 0; w < 4; ++w) mag[h][w] = halves[4 * h + w];
+          neg[h] = mag[h][3] >> 31;
+          mag[h][3] &= 0x7FFFFFFFu;
+          any |= mag[h][0] | mag[h][1] | mag[h][2] | mag[h][3];
+        }
+        if (g1a29_is_identity(q) || any == 0) {
+          has = false;  // contributes nothing: all digits zero, table untouched
+        } else {
+          const Fq29 qbx = fq29_mul(q.x, beta);
+#pragma unroll
+          for (int l = 0; l < 9; ++l) {
+            tab[j][l][lane] = q.x.v[l];
+            tab[j][9 + l][lane] = q.y.v[l];
+            tab[j][18 + l][lane] = qbx.v[l];
+          }
+          G1Xyzz29 t2 = xyzz29_double_affine(q), t3 = t2;
+          xyzz29_madd_fast(t3, q);
+          G1Xyzz29 t4 = xyzz29_double(t2);
+          auto put = [&](int e, const G1Xyzz29& v) {
+            const Fq29 bx = fq29_mul(v.x, beta);
+            const int r0 = 27 + 45 * e;
+#pragma unroll
+            for (int l = 0; l < 9; ++l) {
+              tab[j][r0 + l][lane] = v.x.v[l];
+              tab[j][r0 + 9 + l][lane] = v.y.v[l];
+              tab[j][r0 + 18 + l][lane] = v.zz.v[l];
+              tab[j][r0 + 27 + l][lane] = v.zzz.v[l];
+              tab[j][r0 + 36 + l][lane] = bx.v[l];
+            }
+          };
+          put(0, t2);
+          put(1, t3);
+          put(2, t4);
+        }
+      }
+      for (int h = 0; h < 2; ++h) {
+        uint32_t carry = 0, pend = 0;
+        for (int i = 0; i < kWinDigits; ++i) {
+          const int bit = 3 * i, word = bit >> 5, sh = bit & 31;
+          uint32_t w0 = word == 0 ? mag[h][0] : word == 1 ? mag[h][1] : word == 2 ? mag[h][2] : word == 3 ? mag[h][3] : 0u;
+          uint32_t w1 = word == 0 ? mag[h][1] : word == 1 ? mag[h][2] : word == 2 ? mag[h][3] : 0u;
+          uint32_t raw = (uint32_t)((((uint64_t)w1 << 32) | w0) >> sh) & 7u;
+          raw += carry;
+          carry = raw > 4u ? 1u : 0u;
+          int d = (int)raw - (carry ? 8 : 0);
+          if (neg[h]) d = -d;
+          const uint32_t enc = has ? (uint32_t)(d + 4) : 4u;  // 4 = the digit 0
+          if (i & 1) dig[j][h][i >> 1][lane] = (uint8_t)(pend | (enc << 4));
+          else pend = enc;
+        }
+        dig[j][h][kWinDigits >> 1][lane] = (uint8_t)(pend | (4u << 4));  // 43 digits: the last byte holds one
+      }
+    }
+    // ---- the shared chain
+    G1Xyzz29 acc = xyzz29_identity();
+    bool started = false;
+#pragma unroll 1
+    for (int i = kWinDigits - 1; i >= 0; --i) {
+      acc = xyzz29_double(xyzz29_double(xyzz29_double(acc)));  // 8 acc (all-zero stays all-zero)
+#pragma unroll 1
+      for (uint32_t jh = 0; jh < 2 * K; ++jh) {
+        const uint32_t j = jh >> 1, h = jh & 1u;
+        const int d = (int)((dig[j][h][i >> 1][lane] >> ((i & 1) * 4)) & 15u) - 4;
+        const int a = d < 0 ? -d : d;
+        if (a != 0) {
+          G1Xyzz29 sel;
+          if (a == 1) {
+            const int xo = h ? 18 : 0;
+#pragma unroll
+            for (int l = 0; l < 9; ++l) {
+              sel.x.v[l] = tab[j][xo + l][lane];
+              sel.y.v[l] = tab[j][9 + l][lane];
+            }
+            sel.zz = fq29_one();
+            sel.zzz = fq29_one();
+          } else {
+            const int r0 = 27 + 45 * (a - 2), xo = h ? 36 : 0;
+#pragma unroll
+            for (int l = 0; l < 9; ++l) {
+              sel.x.v[l] = tab[j][r0 + xo + l][lane];
+              sel.y.v[l] = tab[j][r0 + 9 + l][lane];
+              sel.zz.v[l] = tab[j][r0 + 18 + l][lane];
+              sel.zzz.v[l] = tab[j][r0 + 27 + l][lane];
+            }
+          }
+          if (d < 0) sel.y = fq29_neg(sel.y);
+          G1Xyzz29 sum = acc;
+          xyzz29_add_fast(sum, sel);
+          acc = started ? sum : sel;
+          started = true;
+        }
+      }
+    }
+    if (!live) continue;
+    if (started && xyzz29_is_degenerate(acc)) {  // an exceptional addition on the way: every term of the group, carefully
+#pragma unroll 1
+      for (uint32_t j = 0; j < cnt; ++j) {
+        uint32_t k[8], halves[8], m0[4], m1[4];
+        const G1Affine29 q = load_term(scalars, points, first + j, mont, k);
+        glv_decompose(k, halves);
+        for (int w = 0; w < 4; ++w) m0[w] = halves[w], m1[w] = halves[4 + w];
+        const uint32_t n0 = m0[3] >> 31, n1 = m1[3] >> 31;
+        m0[3] &= 0x7FFFFFFFu, m1[3] &= 0x7FFFFFFFu;
+        G1Xyzz29 r1 = xyzz29_identity(), r2 = xyzz29_identity();
+        if (!g1a29_is_identity(q)) {
+          G1Affine29 q1 = q, q2 = q;
+          q2.x = fq29_canon_residue(fq29_mul(q.x, beta));
+          if (n0) q1.y = fq29_neg(q1.y);
+          if (n1) q2.y = fq29_neg(q2.y);
+          if ((m0[0] | m0[1] | m0[2] | m0[3]) != 0) r1 = half_scalar_mul<true>(q1, m0);
+          if (!xyzz29_is_identity(r1) && xyzz29_is_degenerate(r1)) r1 = xyzz29_identity();
+          if ((m1[0] | m1[1] | m1[2] | m1[3]) != 0) r2 = half_scalar_mul<true>(q2, m1);
+          if (!xyzz29_is_identity(r2) && xyzz29_is_degenerate(r2)) r2 = xyzz29_identity();
+        }
+        out[2 * (size_t)(first + j)] = r1;
+        out[2 * (size_t)(first + j) + 1] = r2;  // the fold adds them with the careful adder
+      }
+      continue;
+    }
+    out[2 * (size_t)first] = started ? acc : xyzz29_identity();
+    for (uint32_t q = 1; q < 2 * cnt; ++q) out[2 * (size_t)first + q] = xyzz29_identity();
+  }
+}
+
 // ---- chunked form of K1 for SMALL batches (the machine is far from full) ----
 // A 127-step chain per lane leaves >90 % of the SIMDs idle when a job has a
 // few thousand terms.  Split every half-scalar into J chunks of 128/J bits:
@@ -572,10 +854,33 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
   if (J == 1) {
     // throughput-bound launches (tens of thousands of terms, or other launches in flight next to this context's: its
     // throughput hint) take the one-lane-per-term joint form: a third less issued work on a third longer chain
-    const char* ej = getenv("SNARKV_NAIVE_JOINT");  // 0 / 1: force (test / A-B knob)
-    const bool joint = ej ? atoi(ej) != 0 : (n_terms >= 49152 || ctx->throughput_mode);
+    const char* ej = getenv("SNARKV_NAIVE_JOINT");  // 0 two-lane / 1 joint / 2 group (3, 4, 5: group with K = 2, 3, 4): test / A-B knob
+    const int jmode = ej ? atoi(ej) : ((n_terms >= 49152 || ctx->throughput_mode) ? (n_terms >= 2 * n_msm ? 2 : 1) : 0);
     void* d_tab = nullptr;  // the fixed-window tables: 3 XYZZ points (+ beta X in the joint form) per lane
-    if (joint) {
+    if (jmode >= 2) {
+      // several terms of a segment per lane on shared doublings; the lane -> segment map is built on the device
+      static int slots = 0;  // resident wavefronts of this kernel: 2 per SIMD
+      if (!slots) {
+        hipDeviceProp_t prop;
+        slots = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0 ? 8 * prop.multiProcessorCount : 2048;
+      }
+      const uint32_t nblk = (uint32_t)((n_msm + 1023) / 1024);
+      const size_t max_lanes = n_terms / 2 + n_msm + 1;
+      const uint32_t grid = (uint32_t)std::min<size_t>((size_t)slots, (max_lanes + 63) / 64);
+      void* d_map = nullptr;
+      SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_MAGS, ((size_t)3 * nblk + n_msm + 1 + 8) * 4, &d_map));
+      uint32_t* bsum = (uint32_t*)d_map;
+      uint32_t* choice = bsum + 3 * (size_t)nblk;
+      uint32_t* base = choice + 8;
+      SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_CHAIN, (size_t)grid * kGroupMax * kGroupRows * 64 * 4, &d_tab));
+      hipLaunchKernelGGL(k_gmap_count, dim3(nblk), dim3(256), 0, ctx->stream, (const uint32_t*)d_offsets, (uint32_t)n_msm, bsum);
+      hipLaunchKernelGGL(k_gmap_choose, dim3(1), dim3(1024), 0, ctx->stream, bsum, nblk, choice, (uint32_t)(jmode >= 3 ? jmode - 1 : 0));
+      hipLaunchKernelGGL(k_gmap_fill, dim3(nblk), dim3(256), 0, ctx->stream, (const uint32_t*)d_offsets, (uint32_t)n_msm,
+                         (const uint32_t*)bsum, (const uint32_t*)choice, base);
+      hipLaunchKernelGGL(k_term_scalar_mul_group, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,
+                         (const uint32_t*)d_points, (G1Xyzz29*)d_terms, (const uint32_t*)d_offsets, (uint32_t)n_msm,
+                         (const uint32_t*)base, (const uint32_t*)choice, (int32_t*)d_tab, mont);
+    } else if (jmode == 1) {
       uint32_t blocks = (uint32_t)((n_terms + 63) / 64);
       SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_CHAIN, (size_t)blocks * 3 * 45 * 64 * 4, &d_tab));
       hipLaunchKernelGGL(k_term_scalar_mul_joint, dim3(blocks), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,

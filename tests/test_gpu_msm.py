@@ -164,6 +164,69 @@ def test_chunk_base_chain_one_lane_and_four_lanes(gpu_ctx, golden_msm, quad, mon
         assert gpu_ctx.msm_naive(s, p) == C.msm_pippenger(s, p, 2), chunks
 
 
+@pytest.mark.parametrize("mode", ["0", "1", "2", "3", "4", "5"])
+def test_fixed_window_term_kernels_two_lane_joint_and_group(gpu_ctx, golden_msm, mode, monkeypatch):
+    """The one-launch term kernels of the segmented MSM (SNARKV_NAIVE_CHUNKS = 1): two lanes per term, one lane per term on
+    shared doublings (joint), and SEVERAL TERMS OF A SEGMENT per lane (group: 2 = the device picks K, 3 / 4 / 5 force
+    K = 2 / 3 / 4).  Same bytes as the oracle on segments shorter, equal to and longer than K, with identity bases, zero
+    scalars, a base listed twice with the same and with the opposite scalar inside one group (the degenerate fall-back),
+    scalars built from the GLV lambda, and on every golden case in one launch."""
+    monkeypatch.setenv("SNARKV_NAIVE_CHUNKS", "1")
+    monkeypatch.setenv("SNARKV_NAIVE_JOINT", mode)
+    n = 700
+    s, p = bytearray(C.sample_scalars(61, n)), bytearray(C.sample_points(62, n))
+    p[64 * 7:64 * 8] = bytes(64)              # an identity base
+    s[32 * 9:32 * 10] = bytes(32)             # a zero scalar
+    p[64 * 11:64 * 12] = p[64 * 10:64 * 11]   # a repeated base ...
+    s[32 * 11:32 * 12] = s[32 * 10:32 * 11]   # ... with the same scalar: P + P inside a group
+    p[64 * 13:64 * 14] = p[64 * 12:64 * 13]
+    s[32 * 13:32 * 14] = ((O.R - int.from_bytes(s[32 * 12:32 * 13], "little")) % O.R).to_bytes(32, "little")  # ... and -k: cancels
+    lam = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23  # a cube root of unity mod r
+    assert pow(lam, 3, O.R) == 1
+    for i, k in enumerate((lam, O.R - lam, lam + 1, (lam * lam) % O.R, 1, O.R - 1, 4, 8)):
+        s[32 * (20 + i):32 * (21 + i)] = k.to_bytes(32, "little")
+    s, p = bytes(s), bytes(p)
+    offs = [0, 1, 3, 6, 10, 15, 15 + 21, 15 + 24, 100, 101, 300, n]
+    assert gpu_ctx.msm_batched(s, p, offs) == C.msm_batched(s, p, offs)
+    assert gpu_ctx.msm_naive(s, p) == C.msm_pippenger(s, p, 2)
+    s = b"".join(bytes.fromhex(c["scalars"]) for c in golden_msm)
+    p = b"".join(bytes.fromhex(c["points"]) for c in golden_msm)
+    offs = [0]
+    for c in golden_msm:
+        offs.append(offs[-1] + len(c["scalars"]) // 64)
+    assert gpu_ctx.msm_batched(s, p, offs) == b"".join(bytes.fromhex(c["expected"]) for c in golden_msm)
+
+
+def test_group_kernel_walks_more_lanes_than_the_grid(gpu_ctx, monkeypatch):
+    """more segments than one block of the lane map (150 000 terms in segments of 1 .. 9, against the oracle), and more lane
+    groups than resident wavefronts -- the blocks walk their share -- (400 000 terms in pairs with K = 2: 200 000 lanes on a
+    grid of at most 131 072; against the two-lane kernel, itself pinned to the oracle above)"""
+    import torch
+
+    monkeypatch.setenv("SNARKV_NAIVE_CHUNKS", "1")
+    monkeypatch.setenv("SNARKV_NAIVE_JOINT", "2")
+    n = 150_000
+    s, p = C.sample_scalars(71, n), C.sample_points(72, n)
+    offs, k = [0], 0
+    while offs[-1] < n:
+        offs.append(min(n, offs[-1] + 1 + (k * 7) % 9))
+        k += 1
+    assert gpu_ctx.msm_batched(s, p, offs) == C.msm_batched(s, p, offs)
+    n = 400_000
+    ds = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+    dp = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+    do = torch.arange(0, n + 1, 2, dtype=torch.int32, device="cuda")
+    out = [torch.zeros(64 * (n // 2), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    gpu_ctx.sample_scalars_dev(73, n, ds.data_ptr())
+    gpu_ctx.sample_points_dev(74, n, dp.data_ptr())
+    for mode, o in (("3", out[0]), ("0", out[1])):
+        monkeypatch.setenv("SNARKV_NAIVE_JOINT", mode)
+        gpu_ctx.msm_batched_dev(ds.data_ptr(), dp.data_ptr(), do.data_ptr(), n // 2, n, o.data_ptr())
+        gpu_ctx.sync()
+    assert torch.equal(out[0], out[1]) and int(out[0].count_nonzero()) > 60 * (n // 2)
+
+
 def test_device_sampler_matches_oracle(gpu_ctx):
     import torch
 
