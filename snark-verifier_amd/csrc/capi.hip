@@ -839,11 +839,21 @@ int bn254_kzg_decide_batch(const uint8_t g1_64[64], const uint8_t g2_128[128], c
   SNARKV_DEFAULT_CALL_LOCK();
   snarkv_ctx* c;
   SNARKV_TRY(default_ctx(&c));
-  snarkv_dk* dk = nullptr;
-  SNARKV_TRY(snarkv_dk_create(c, g1_64, g2_128, s_g2_128, 0, &dk));
-  int rc = snarkv_kzg_decide_batch(c, dk, accs128, m, 0, ok);
-  snarkv_dk_destroy(dk);
-  return rc;
+  if (!g1_64 || !g2_128 || !s_g2_128) return SNARKV_ERR_ARG;
+  // The reference rebuilds `G2Prepared` on every decide (decider.rs:74); a verifier decides against ONE key, so the last
+  // key's line tables are kept (the 320 key bytes + the encoding they were given in are the cache tag).
+  static snarkv_dk* cached = nullptr;
+  static uint8_t tag[321];
+  uint8_t now[321];
+  memcpy(now, g1_64, 64), memcpy(now + 64, g2_128, 128), memcpy(now + 192, s_g2_128, 128);
+  now[320] = c->mont ? 1 : 0;
+  if (!cached || memcmp(tag, now, sizeof now) != 0) {
+    if (cached) snarkv_dk_destroy(cached);
+    cached = nullptr;
+    SNARKV_TRY(snarkv_dk_create(c, g1_64, g2_128, s_g2_128, 0, &cached));
+    memcpy(tag, now, sizeof now);
+  }
+  return snarkv_kzg_decide_batch(c, cached, accs128, m, 0, ok);
 }
 
 int bn254_kzg_decide(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],

@@ -110,7 +110,7 @@ struct snarkv_ctx {
 
 struct snarkv_dk {
   int device;
-  void* d_prep;  // 2 x G2Prepared (g2, -s_g2)
+  void* d_prep;  // 2 x G2Prepared29 (g2, -s_g2): the line tables the decide kernels read
   uint8_t g1[64];
 };
 

@@ -4,9 +4,9 @@
 //   decide     : e(lhs, g2) * e(rhs, -s_g2) == 1
 //   decide_all : the same for every accumulator of a list (decider.rs:84-93)
 //
-//   D0 k_g2_prepare : once per deciding key -- line tables of g2 and -s_g2
+//   D0 k_g2_prepare_w : once per deciding key -- line tables of g2 and -s_g2
 //                     (the reference's `G2Prepared::from`, redone there on
-//                     every call, decider.rs:74)
+//                     every call, decider.rs:74), one wavefront per key (g2_prepare_w.h)
 //   D1 k_decide     : ONE 128-lane WORKGROUP per accumulator (pairing_coop29.h):
 //                     2-pair Miller loop with shared squarings + exact final
 //                     exponentiation + `is_identity`; every Fq12 product is one
@@ -25,91 +25,41 @@
 #include "pairing_coop29.h"
 #include "decide_w.h"
 #include "decide_sched.hpp"
+#include "g2_prepare_w.h"
 #include <mutex>
 
 namespace snarkv {
 
-size_t g2_prepared_bytes() { return sizeof(G2Prepared) + sizeof(G2Prepared29); }
-static size_t prep29_offset() { return 2 * sizeof(G2Prepared); }
+size_t g2_prepared_bytes() { return sizeof(G2Prepared29); }  // per point; a key holds two (g2, -s_g2)
+static size_t prep29_offset() { return 0; }
 
-__device__ __forceinline__ Fq load_fq_canonical(const uint32_t* __restrict__ src) {
-  uint32_t w[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) w[i] = src[i];
-  return fq_from_canonical(w);
-}
-
-__device__ __forceinline__ void store_fq_canonical(const Fq& a, uint32_t* __restrict__ dst) {
-  uint32_t w[8];
-  fq_to_canonical(a, w);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) dst[i] = w[i];
-}
-
-// g2x2: g2 (128 B canonical) || s_g2 (128 B canonical).  Lane 0 prepares g2,
-// lane 1 prepares -s_g2.
-// mont: the coordinates arrive in halo2curves' in-memory form (a * 2^256 mod p), which IS fq.h's representation
-__device__ __forceinline__ Fq load_fq_words(const uint32_t* __restrict__ src, uint32_t mont) {
-  if (!mont) return load_fq_canonical(src);
-  Fq r;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) r.v[i] = src[i];
-  return r;
-}
-
-__global__ void __launch_bounds__(64) k_g2_prepare(const uint32_t* __restrict__ g2x2, G2Prepared* __restrict__ prep, uint32_t mont) {
-  uint32_t k = threadIdx.x;
-  if (k >= 2) return;
-  const uint32_t* src = g2x2 + k * 32;
-  G2Affine q;
-  q.x.c0 = load_fq_words(src, mont);
-  q.x.c1 = load_fq_words(src + 8, mont);
-  q.y.c0 = load_fq_words(src + 16, mont);
-  q.y.c1 = load_fq_words(src + 24, mont);
-  if (k == 1) q.y = fq2_neg(q.y);
-  g2_prepare(q, prep[k]);
-}
-
-// y^2 == x^3 + 3/(9+u) and canonical coordinates, for both G2 points.
+// y^2 == x^3 + 3/(9+u) and canonical coordinates, for both G2 points (lanes 0, 1), on the lazy 29-bit field (all inline:
+// the tower functions of tower.h take their operands by reference and would put them on the stack)
 __global__ void __launch_bounds__(64) k_validate_g2(const uint32_t* __restrict__ g2x2, int* __restrict__ bad, uint32_t mont) {
   uint32_t k = threadIdx.x;
   if (k >= 2) return;
   const uint32_t* src = g2x2 + k * 32;
   bool ok = true;
-  for (int j = 0; j < 4; ++j) ok = ok && fq_canonical_in_range(src + 8 * j);
+  for (int j = 0; j < 4; ++j) ok = ok && fq_canonical_in_range(src + 8 * j);  // (the in-memory form is reduced as well)
   if (ok) {
-    G2Affine q;
-    q.x.c0 = load_fq_words(src, mont);
-    q.x.c1 = load_fq_words(src + 8, mont);
-    q.y.c0 = load_fq_words(src + 16, mont);
-    q.y.c1 = load_fq_words(src + 24, mont);
-    if (!(fq2_is_zero(q.x) && fq2_is_zero(q.y))) {
-      constexpr uint32_t bc0[8] = BN254_TWIST_B_C0_MONT;
-      constexpr uint32_t bc1[8] = BN254_TWIST_B_C1_MONT;
-      Fq2 b;
-      for (int i = 0; i < 8; ++i) {
-        b.c0.v[i] = bc0[i];
-        b.c1.v[i] = bc1[i];
-      }
-      Fq2 lhs = fq2_sqr(q.y);
-      Fq2 rhs = fq2_add(fq2_mul(fq2_sqr(q.x), q.x), b);
-      ok = fq2_eq(lhs, rhs);
+    Fq29 x0 = fq29_canon_residue(fq29_from_words(src, mont != 0)), x1 = fq29_canon_residue(fq29_from_words(src + 8, mont != 0));
+    Fq29 y0 = fq29_canon_residue(fq29_from_words(src + 16, mont != 0)), y1 = fq29_canon_residue(fq29_from_words(src + 24, mont != 0));
+    const bool id = fq29_limbs_all_zero(x0) && fq29_limbs_all_zero(x1) && fq29_limbs_all_zero(y0) && fq29_limbs_all_zero(y1);
+    if (!id) {
+      constexpr uint32_t bc[2][8] = {BN254_TWIST_B_C0_MONT, BN254_TWIST_B_C1_MONT};
+      auto mul = [](const Fq29& a0, const Fq29& a1, const Fq29& b0, const Fq29& b1, Fq29& r0, Fq29& r1) {
+        r0 = fq29_mul2(a0, b0, fq29_neg(a1), b1);
+        r1 = fq29_mul2(a0, b1, a1, b0);
+      };
+      Fq29 l0, l1, s0, s1, c0, c1;
+      mul(y0, y1, y0, y1, l0, l1);                                  // y^2
+      mul(x0, x1, x0, x1, s0, s1);                                  // x^2
+      mul(fq29_norm(s0), fq29_norm(s1), x0, x1, c0, c1);            // x^3
+      const Fq29 r0 = fq29_add(c0, g2w_from_mont32(bc[0])), r1 = fq29_add(c1, g2w_from_mont32(bc[1]));
+      ok = fq29_is_zero_mod_p(fq29_sub(l0, r0)) && fq29_is_zero_mod_p(fq29_sub(l1, r1));
     }
   }
   if (!ok) atomicAdd(bad, 1);
-}
-
-// 8x32 Montgomery (R = 2^256) line tables -> 29-bit Montgomery (R = 2^261)
-__global__ void __launch_bounds__(256) k_g2_to29(const G2Prepared* __restrict__ prep, G2Prepared29* __restrict__ out) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= 2 * kLinesPerG2 * 6) return;
-  int k = j / (kLinesPerG2 * 6), rem = j % (kLinesPerG2 * 6), idx = rem / 6, c = rem % 6;
-  const LineCoeff& l = prep[k].line[idx];
-  const Fq& src = c == 0 ? l.cy.c0 : c == 1 ? l.cy.c1 : c == 2 ? l.cx.c0 : c == 3 ? l.cx.c1 : c == 4 ? l.cw.c0 : l.cw.c1;
-  uint32_t w[8];
-  fq_to_canonical(src, w);
-  out[k].line[idx].c[c] = fq29_canon_residue(fq29_from_canonical(w));
-  if (rem == 0) out[k].is_identity = prep[k].is_identity;
 }
 
 // ------------------------------------------------------------------ D1
@@ -119,7 +69,7 @@ struct CoopReg {  // an Fq12 in the flat basis (c = 2i+e <-> u^e w^i)
   Fq29 v[12];
 };
 
-enum { RF = 0, RT, RINV, RFX, RFX2, RFX3, RY0, RY1, RY2, RY3, RY4, RY5, RY6, RT0, RT1, RM0, RM1, RM2, RM3, RS, RONE, RZERO, RCOUNT };
+enum { RF = 0, RT, RINV, RFX, RFX2, RFX3, RY0, RY1, RY2, RY3, RY4, RY5, RY6, RT0, RT1, RONE, RZERO, RCOUNT };
 
 struct CoopShared {
   CoopReg r[RCOUNT];
@@ -131,12 +81,9 @@ struct CoopShared {
 // One workgroup = one accumulator; the whole state lives in LDS (file scope so
 // that every helper addresses it with ds_* instructions, not flat pointers).
 __shared__ CoopShared g_sh;
-// line tables evaluated at this accumulator's points.  One-team kernel: l0 = cy*yP,
-// l1 = cx*xP per pair and line (l2 = cw is read from the key: 29 KB, four
-// workgroups per CU).  Two-team kernel: all three coefficients (44 KB), so that
-// every operand of a round is one LDS address.
+// line tables evaluated at this accumulator's points: l0 = cy*yP, l1 = cx*xP per pair and line
+// (l2 = cw is read from the key: 29 KB, four workgroups per CU)
 __shared__ Fq29 g_lines4[2][kLinesPerG2][4];
-__shared__ Fq29 g_lines6[2][kLinesPerG2][6];
 
 static __device__ __forceinline__ void coop_store(int dst, int c, const Fq29& val) { g_sh.r[dst].v[c] = val; }
 
@@ -206,91 +153,6 @@ static __device__ __forceinline__ void coop_mul_b(int dst, int a, int b_reg, int
 static __device__ __noinline__ void coop_mulr(int dst, int a, int b) { coop_mul_b(dst, a, b, 0, 0, nullptr); }
 static __device__ __noinline__ void coop_mull(int pair, int idx, const G2Prepared29* __restrict__ prep) {
   coop_mul_b(RF, RF, -1, pair, idx, prep);
-}
-
-// ---- two-team rounds (latency form, 256 lanes) -------------------------------
-// Team 0 (lanes 0..127) and team 1 (lanes 128..255) each run one product per
-// round, on different operands, between the same two barriers.  Used where the
-// dependency chain leaves a second product free: the pair products l1*l2 of
-// the NEXT Miller lines while f is being squared, and R *= S next to S <- S^2
-// in the right-to-left exponentiations by x.
-enum { OP_REG = 0, OP_LINE = 1 };
-struct CoopOpnd {
-  int kind, x, y;  // REG: x = register; LINE: x = pair, y = line index
-};
-struct CoopOp {
-  int dst;  // < 0: idle
-  CoopOpnd a, b;
-};
-
-static __device__ __forceinline__ CoopOpnd opnd_reg(int r) { return CoopOpnd{OP_REG, r, 0}; }
-static __device__ __forceinline__ CoopOpnd opnd_line(int pair, int idx) { return CoopOpnd{OP_LINE, pair, idx}; }
-static __device__ __forceinline__ CoopOpnd opnd_one() { return CoopOpnd{OP_REG, RONE, 0}; }
-static __device__ __forceinline__ CoopOp op_idle() { return CoopOp{-1, opnd_one(), opnd_one()}; }
-static __device__ __forceinline__ CoopOp op_mul(int dst, CoopOpnd a, CoopOpnd b) { return CoopOp{dst, a, b}; }
-
-// LDS address of coefficient u^e w^i of an operand; zero coefficients of a
-// line (w^2, w^4, w^5) point into the all-zero register.  No branches: the four
-// operand reads of a round issue back to back.
-static __device__ __forceinline__ const Fq29* opnd_coeff(const CoopOpnd& o, int i, int e) {
-  const int slot = i < 2 ? i : (i == 3 ? 2 : -1);
-  const Fq29* reg = &g_sh.r[o.kind == OP_REG ? o.x : RZERO].v[2 * i + e];
-  const Fq29* line = slot >= 0 ? &g_lines6[o.x & 1][o.y][2 * slot + e] : &g_sh.r[RZERO].v[0];
-  return o.kind == OP_LINE ? line : reg;
-}
-
-static __device__ __noinline__ void coop_round2(const CoopOp opA, const CoopOp opB) {
-  const int tid = threadIdx.x;
-  const bool team1 = tid >= 128;
-  CoopOp op = team1 ? opB : opA;  // wavefront-uniform: keep it in scalar registers
-  op.dst = __builtin_amdgcn_readfirstlane(op.dst);
-  op.a.kind = __builtin_amdgcn_readfirstlane(op.a.kind);
-  op.a.x = __builtin_amdgcn_readfirstlane(op.a.x);
-  op.a.y = __builtin_amdgcn_readfirstlane(op.a.y);
-  op.b.kind = __builtin_amdgcn_readfirstlane(op.b.kind);
-  op.b.x = __builtin_amdgcn_readfirstlane(op.b.x);
-  op.b.y = __builtin_amdgcn_readfirstlane(op.b.y);
-  const Coop3Lane L = coop3_lane(tid & 127);
-  Fq29 val = fq29_zero();
-  if (op.dst >= 0 && L.active) {
-    const Fq29 a0 = *opnd_coeff(op.a, L.i1, 0);
-    const Fq29 a1 = *opnd_coeff(op.a, L.i1, 1);
-    const Fq29 y0 = *opnd_coeff(op.b, L.i2, L.e);
-    const Fq29 y1 = *opnd_coeff(op.b, L.i2, 1 - L.e);
-    val = coop3_product(L.e, a0, a1, y0, y1);
-  }
-  Fq29 lo, hi;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    lo.v[i] = L.high ? 0 : val.v[i];
-    hi.v[i] = L.high ? val.v[i] : 0;
-  }
-  lo = group8_sum(lo);
-  hi = group8_sum(hi);
-  Fq29 hp;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) hp.v[i] = (int32_t)dpp_u32<0x128>((uint32_t)hi.v[i]);
-  const bool writer = op.dst >= 0 && (tid & 7) == 0 && L.k < 6;
-  Fq29 res = fq29_zero();
-  if (writer) res = coop3_finalize(L.e, lo, hi, hp);
-  __syncthreads();
-  if (writer) coop_store(op.dst, 2 * L.k + L.e, res);
-  __syncthreads();
-}
-
-// dst = a^x, right to left: S <- S^2 (team 0) next to R <- R*S (team 1); 63 rounds instead of 89
-static __device__ __noinline__ void coop_exp_by_x2(int dst, int a) {
-  const int tid = threadIdx.x;
-  if (tid < 12) {
-    g_sh.r[RS].v[tid] = g_sh.r[a].v[tid];
-    g_sh.r[dst].v[tid] = g_sh.r[RONE].v[tid];
-  }
-  __syncthreads();
-  for (int i = 0; i <= 62; ++i) {
-    CoopOp sq = i < 62 ? op_mul(RS, opnd_reg(RS), opnd_reg(RS)) : op_idle();
-    CoopOp ml = ((BN254_X_U64 >> i) & 1ull) ? op_mul(dst, opnd_reg(dst), opnd_reg(RS)) : op_idle();
-    coop_round2(sq, ml);
-  }
 }
 
 // dst = conj(a): negate the odd powers of w (the c1 half of the tower)
@@ -382,8 +244,8 @@ static __device__ __noinline__ void coop_exp_by_x(int dst, int a) {
 #define DECIDE_STAMP(n) do { } while (0)
 #endif
 
-template <int TEAMS>
-__global__ void __launch_bounds__(kDecideThreads * TEAMS)
+// The THROUGHPUT form (large decide_all batches): one 128-lane team per accumulator, 29 KB of LDS, four workgroups per CU.
+__global__ void __launch_bounds__(kDecideThreads)
     k_decide(const G2Prepared29* __restrict__ prep, const uint32_t* __restrict__ accs, uint32_t m,
              uint8_t* __restrict__ ok, uint32_t* __restrict__ gt_out, uint32_t mont) {
   const int tid = threadIdx.x;
@@ -408,23 +270,15 @@ __global__ void __launch_bounds__(kDecideThreads * TEAMS)
                      !prep[tid].is_identity;
   // every line of both pairs evaluated at this accumulator's points, up front
   // and in parallel (2 x 102 x 4 products): l0 = cy*yP, l1 = cx*xP
-  if (TEAMS == 1) {
-    for (int j = tid; j < 2 * kLinesPerG2 * 4; j += kDecideThreads) {
-      int k = j / (kLinesPerG2 * 4), rem = j % (kLinesPerG2 * 4), idx = rem / 4, c = rem % 4;
-      g_lines4[k][idx][c] = fq29_mul(prep[k].line[idx].c[c], g_sh.pt[k][c < 2 ? 1 : 0]);
-    }
-  } else {
-    for (int j = tid; j < 2 * kLinesPerG2 * 6; j += 2 * kDecideThreads) {
-      int k = j / (kLinesPerG2 * 6), rem = j % (kLinesPerG2 * 6), idx = rem / 6, c = rem % 6;
-      Fq29 v = prep[k].line[idx].c[c];
-      g_lines6[k][idx][c] = c < 4 ? fq29_mul(v, g_sh.pt[k][c < 2 ? 1 : 0]) : v;
-    }
+  for (int j = tid; j < 2 * kLinesPerG2 * 4; j += kDecideThreads) {
+    int k = j / (kLinesPerG2 * 4), rem = j % (kLinesPerG2 * 4), idx = rem / 4, c = rem % 4;
+    g_lines4[k][idx][c] = fq29_mul(prep[k].line[idx].c[c], g_sh.pt[k][c < 2 ? 1 : 0]);
   }
   __syncthreads();
 
   DECIDE_STAMP(1);
   // ---- Miller loop (2 pairs, shared squarings); identity pairs contribute 1
-  if (TEAMS == 1) {
+  {
     int idx = 0;
     for (int b = kAteBits - 2; b >= 0; --b) {
       coop_mulr(RF, RF, RF);
@@ -442,45 +296,6 @@ __global__ void __launch_bounds__(kDecideThreads * TEAMS)
         if (g_sh.live[k]) coop_mull(k, idx, prep);
       ++idx;
     }
-  } else {
-    // team 1 runs ahead producing M_k = l1_k * l2_k (line k of both pairs) into a
-    // ring of four registers; team 0 runs f <- f^2, f <- f * M_k [, f <- f * M_k+1].
-    const bool live0 = g_sh.live[0] != 0, live1 = g_sh.live[1] != 0;
-    int made = 0, used = 0;      // pair products finished / consumed (in earlier rounds)
-    int b = kAteBits - 2;        // current bit
-    int phase = 0;               // 0: square; 1: first line; 2: second line (set bits)
-    int tail = 0;                // the two closing lines
-    while (used < kLinesPerG2) {
-      CoopOp main = op_idle(), aux = op_idle();
-      bool main_is_mul = false;
-      if (b >= 0 && phase == 0) {
-        main = op_mul(RF, opnd_reg(RF), opnd_reg(RF));
-      } else if (made > used) {
-        main = op_mul(RF, opnd_reg(RF), opnd_reg(RM0 + (used & 3)));
-        main_is_mul = true;
-      }
-      if (made < kLinesPerG2 && made - used < 4)
-        aux = op_mul(RM0 + (made & 3), live0 ? opnd_line(0, made) : opnd_one(), live1 ? opnd_line(1, made) : opnd_one());
-      coop_round2(main, aux);
-      if (aux.dst >= 0) ++made;
-      if (main.dst >= 0) {
-        if (!main_is_mul) {
-          phase = 1;
-        } else {
-          ++used;
-          if (b >= 0) {
-            if (phase == 1 && ate_bit(b)) {
-              phase = 2;
-            } else {
-              phase = 0;
-              --b;
-            }
-          } else {
-            ++tail;
-          }
-        }
-      }
-    }
   }
 
   DECIDE_STAMP(2);
@@ -492,19 +307,9 @@ __global__ void __launch_bounds__(kDecideThreads * TEAMS)
   coop_frob(RT, RF, 2);
   coop_mulr(RF, RT, RF);            // ^(p^2+1)
   DECIDE_STAMP(4);
-#ifdef SNARKV_T2_OLDEXP
-  if (true) {
-#else
-  if (TEAMS == 1) {
-#endif
-    coop_exp_by_x(RFX, RF);
-    coop_exp_by_x(RFX2, RFX);
-    coop_exp_by_x(RFX3, RFX2);
-  } else {
-    coop_exp_by_x2(RFX, RF);
-    coop_exp_by_x2(RFX2, RFX);
-    coop_exp_by_x2(RFX3, RFX2);
-  }
+  coop_exp_by_x(RFX, RF);
+  coop_exp_by_x(RFX2, RFX);
+  coop_exp_by_x(RFX3, RFX2);
   DECIDE_STAMP(5);
   coop_frob(RY0, RF, 1);
   coop_frob(RT, RF, 2);
@@ -556,6 +361,58 @@ __global__ void __launch_bounds__(kDecideThreads * TEAMS)
     int pos = tid >> 1, e = tid & 1;
     uint32_t* dstw = gt_out + (size_t)i * 96 + (size_t)(2 * pos + e) * 8;
     for (int j = 0; j < 8; ++j) dstw[j] = canon[2 * wexp[pos] + e][j];
+  }
+}
+
+// ------------------------------------------------------------------ D0: the line tables, one wavefront per key (g2_prepare_w.h)
+// g2x2: g2 (128 B) || s_g2 (128 B), canonical or in-memory form; lanes 16 p + 2 t + e: point p, task t of the level, component e.
+// Point 1 is NEGATED (the decider pairs rhs with -s_g2).  out[p]: the 29-bit table the decide kernels read.
+__global__ void __launch_bounds__(64) k_g2_prepare_w(const uint32_t* __restrict__ g2x2, G2Prepared29* __restrict__ out,
+                                                      const G2wTask* __restrict__ prog, uint32_t mont) {
+  __shared__ Fq2_29P sl[2][kG2wSlots];
+  __shared__ int ident[2];
+  const int lane = threadIdx.x, pt = lane >> 4, t = (lane & 15) >> 1, e = lane & 1;
+  const bool worker = pt < 2 && t < kG2wTasks;
+  if (lane < 8) {  // the four coordinates of both points
+    const int p = lane >> 2, c = lane & 3;  // c: x.c0, x.c1, y.c0, y.c1
+    Fq29 v = fq29_canon_residue(fq29_from_words(g2x2 + 32 * p + 8 * c, mont != 0));
+    if (p == 1 && c >= 2) v = fq29_canon_residue(fq29_neg(v));
+    sl[p][c < 2 ? kG2wSlotQX : kG2wSlotQY].c[c & 1] = v;
+    sl[p][c < 2 ? kG2wSlotTX : kG2wSlotTYA].c[c & 1] = v;
+  } else if (lane < 8 + 24) {  // the constants of the program
+    const int q = lane - 8, p = q / 12, k = (q % 12) >> 1, ee = q & 1;
+    sl[p][k].c[ee] = g2w_const(k, ee);  // slots 0 .. 5: ONE, B3, G12, G13, G22, G23
+  } else if (lane < 8 + 24 + 8) {
+    const int q = lane - 32, p = q >> 2, k = (q >> 1) & 1, ee = q & 1;
+    sl[p][k ? kG2wSlotTZ : kG2wSlotTYB].c[ee] = (k && !ee) ? fq29_one() : fq29_zero();  // Z = 1, YB = 0
+  }
+  __syncthreads();
+  if (lane < 2) {
+    const Fq2_29P &x = sl[lane][kG2wSlotQX], &y = sl[lane][kG2wSlotQY];
+    ident[lane] = fq29_limbs_all_zero(x.c[0]) && fq29_limbs_all_zero(x.c[1]) && fq29_limbs_all_zero(y.c[0]) && fq29_limbs_all_zero(y.c[1]);
+    out[lane].is_identity = (uint32_t)ident[lane];
+  }
+  __syncthreads();
+  G2wTask nxt;
+  nxt.used = 0;
+  if (worker) nxt = prog[t];
+#pragma unroll 1
+  for (int lv = 0; lv < kG2wLevels; ++lv) {
+    Fq29 val = fq29_zero();
+    const G2wTask tk = nxt;
+    if (worker && lv + 1 < kG2wLevels) nxt = prog[(lv + 1) * kG2wTasks + t];  // fetched under this level's products
+    const bool act = worker && tk.used && !ident[pt];
+    if (act) val = g2w_task(sl[pt], tk, e);
+    __syncthreads();  // (one wavefront: no barrier instruction -- the loads of the level are done before its stores)
+    if (act) {
+      if (tk.dst >= 0) {
+        sl[pt][tk.dst].c[e] = val;
+      } else {  // a line coefficient: canonical residue into the table
+        const Fq29 cv = fq29_canon_of_product(val);
+        out[pt].line[tk.out / 3].c[2 * (tk.out % 3) + e] = cv;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -665,11 +522,21 @@ static int wt_device_program(int device, const WtDeviceProgram** out) {
 }
 
 int launch_g2_prepare(snarkv_ctx* ctx, const void* d_g2x2_256, void* d_prep) {
-  hipLaunchKernelGGL(k_g2_prepare, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)d_g2x2_256,
-                     (G2Prepared*)d_prep, ctx->mont ? 1u : 0u);
+  static std::mutex mu;
+  static G2wTask* d_prog[64] = {nullptr};
+  G2wTask* prog = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    G2wTask*& slot = d_prog[ctx->device & 63];
+    if (!slot) {  // the level program: uploaded once per device
+      SNARKV_HIP(hipMalloc(&slot, sizeof(kG2wProg)));
+      SNARKV_HIP(hipMemcpy(slot, kG2wProg, sizeof(kG2wProg), hipMemcpyHostToDevice));
+    }
+    prog = slot;
+  }
   G2Prepared29* d29 = reinterpret_cast<G2Prepared29*>((char*)d_prep + prep29_offset());
-  hipLaunchKernelGGL(k_g2_to29, dim3((2 * kLinesPerG2 * 6 + 255) / 256), dim3(256), 0, ctx->stream,
-                     (const G2Prepared*)d_prep, d29);
+  hipLaunchKernelGGL(k_g2_prepare_w, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)d_g2x2_256, d29, (const G2wTask*)prog,
+                     ctx->mont ? 1u : 0u);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }
@@ -687,27 +554,24 @@ int launch_validate_g2(snarkv_ctx* ctx, const void* d_g2x2_256, int* bad_host) {
 }
 
 // Which form: batches of up to 256 accumulators take the program-driven latency kernel (one workgroup of four
-// wavefronts + ~115 KiB of LDS per accumulator: one per CU), larger ones the one-team throughput kernel (two wavefronts,
-// 29 KiB, four workgroups per CU).  SNARKV_DECIDE_FORM = 1 (one team) / 2 (two teams, the round-3 latency form) / 3
-// (program) forces one (test / A-B knob).  All give the same bits.
+// wavefronts + ~95 KiB of LDS per accumulator: one per CU), larger ones the one-team throughput kernel (two wavefronts,
+// 29 KiB, four workgroups per CU).  SNARKV_DECIDE_FORM = 1 (one team) / 3 (program) forces one (test / A-B knob); both give
+// the same bits.  (The round-3 two-team latency form, 0.87 ms per decide against 0.56: profiles/r04_ab_decide_wave.txt.)
 int launch_decide(snarkv_ctx* ctx, const void* d_prep, const void* d_accs, size_t m, void* d_ok, void* d_gt) {
   const G2Prepared29* d29 = reinterpret_cast<const G2Prepared29*>((const char*)d_prep + prep29_offset());
   const uint32_t mont = ctx->mont ? 1u : 0u;  // the accumulators' points in halo2curves' in-memory form
   int form = m <= 256 ? 3 : 1;
   if (const char* e = getenv("SNARKV_DECIDE_FORM")) {
     int v = atoi(e);
-    if (v >= 1 && v <= 3) form = v;
+    if (v == 1 || v == 3) form = v;
   }
   if (form == 3) {
     const WtDeviceProgram* wp = nullptr;
     SNARKV_TRY(wt_device_program(ctx->device, &wp));
     hipLaunchKernelGGL(k_decide_w, dim3((uint32_t)m), dim3(256), wp->lds_bytes, ctx->stream, d29, (const uint32_t*)d_accs,
                        (uint32_t)m, (uint8_t*)d_ok, (uint32_t*)d_gt, (const uint2*)wp->d_prog, wp->rounds, wp->result, mont);
-  } else if (form == 2)
-    hipLaunchKernelGGL(k_decide<2>, dim3((uint32_t)m), dim3(2 * kDecideThreads), 0, ctx->stream, d29,
-                       (const uint32_t*)d_accs, (uint32_t)m, (uint8_t*)d_ok, (uint32_t*)d_gt, mont);
-  else
-    hipLaunchKernelGGL(k_decide<1>, dim3((uint32_t)m), dim3(kDecideThreads), 0, ctx->stream, d29,
+  } else
+    hipLaunchKernelGGL(k_decide, dim3((uint32_t)m), dim3(kDecideThreads), 0, ctx->stream, d29,
                        (const uint32_t*)d_accs, (uint32_t)m, (uint8_t*)d_ok, (uint32_t*)d_gt, mont);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;

@@ -206,144 +206,29 @@ __global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES) k_term_scalar_mul(cons
   out[g] = r;
 }
 
-// K1 for LARGE launches: one lane per TERM, both GLV halves in one chain (Straus): k P = k1 P + k2 phi(P) shares the
-// doublings of its two 127-step ladders -- 129 doublings + 2 x 43 additions (~2 400 products) instead of
-// 2 x (129 + 43) (~3 600) per term, a third less issued work, on a chain a third longer.  Worth it only where the
-// launch is throughput-bound (tens of thousands of terms, or several launches in flight: the context's throughput
-// hint); a single 1 024-proof job keeps the two-lane form, whose 0.8 ms is a latency.
-//   table    2P, 3P, 4P as in half_scalar_mul_w3, plus beta X of each: phi(a P) = (beta X, Y, ZZ, ZZZ)
-//   digits   two signed 3-bit streams (LDS bytes), the signs of the halves folded into the digits' signs
-// A fast addition meets P = +-Q only if  u + v lambda = +-d (mod r)  for the prefixes u, v of the two halves and a digit
-// d: with v = 0 this is the one-chain case (`started`), otherwise (u -+ d, v) would be a non-zero vector of the GLV lattice
-// with both coordinates below 2^127 -- possible for crafted scalars at best; the degenerate flag + the careful redo of
-// both halves is the net, as above.  Output: the term's partial in slot 2 t, the identity in slot 2 t + 1 (K2 unchanged).
-__global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES) k_term_scalar_mul_joint(const uint32_t* __restrict__ scalars,
-                                                                                   const uint32_t* __restrict__ points,
-                                                                                   G1Xyzz29* __restrict__ out, uint32_t n_terms,
-                                                                                   int32_t* __restrict__ tabg, uint32_t mont) {
-  __shared__ int8_t dig[2][kWinDigits][64];
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x;
-  if (t >= n_terms) return;
-  uint32_t k[8], halves[8];
-  const G1Affine29 q = load_term(scalars, points, t, mont, k);
-  glv_decompose(k, halves);
-  uint32_t mag[2][4];
-  uint32_t neg[2], any = 0;
-  for (int h = 0; h < 2; ++h) {
-    for (int j = 0; j < 4; ++j) mag[h][j] = halves[4 * h + j];
-    neg[h] = mag[h][3] >> 31;
-    mag[h][3] &= 0x7FFFFFFFu;
-    any |= mag[h][0] | mag[h][1] | mag[h][2] | mag[h][3];
-  }
-  out[2 * (size_t)t + 1] = xyzz29_identity();
-  if (g1a29_is_identity(q) || any == 0) {
-    out[2 * (size_t)t] = xyzz29_identity();
-    return;
-  }
-  constexpr int32_t bl[9] = SNARKV_GLV_BETA29_LIMBS;
-  Fq29 beta;
-#pragma unroll
-  for (int j = 0; j < 9; ++j) beta.v[j] = bl[j];
-  // this wavefront's slice of the scratch: [entry 0..2][limb 0..44][lane]: X, Y, ZZ, ZZZ, beta X
-  int32_t(*tab)[45][64] = reinterpret_cast<int32_t(*)[45][64]>(tabg + (size_t)blockIdx.x * 3 * 45 * 64);
-  {
-    G1Xyzz29 t2 = xyzz29_double_affine(q), t3 = t2;
-    xyzz29_madd_fast(t3, q);
-    G1Xyzz29 t4 = xyzz29_double(t2);
-    auto put = [&](int e, const G1Xyzz29& v) {
-      const Fq29 bx = fq29_mul(v.x, beta);
-#pragma unroll
-      for (int l = 0; l < 9; ++l) {
-        tab[e][l][lane] = v.x.v[l];
-        tab[e][9 + l][lane] = v.y.v[l];
-        tab[e][18 + l][lane] = v.zz.v[l];
-        tab[e][27 + l][lane] = v.zzz.v[l];
-        tab[e][36 + l][lane] = bx.v[l];
-      }
-    };
-    put(0, t2);
-    put(1, t3);
-    put(2, t4);
-  }
-  const Fq29 qbx = fq29_mul(q.x, beta);  // x of phi(P)
-  for (int h = 0; h < 2; ++h) {
-    uint32_t carry = 0;
-    for (int i = 0; i < kWinDigits; ++i) {
-      const int bit = 3 * i, word = bit >> 5, sh = bit & 31;
-      uint32_t w0 = word == 0 ? mag[h][0] : word == 1 ? mag[h][1] : word == 2 ? mag[h][2] : word == 3 ? mag[h][3] : 0u;
-      uint32_t w1 = word == 0 ? mag[h][1] : word == 1 ? mag[h][2] : word == 2 ? mag[h][3] : 0u;
-      uint32_t raw = (uint32_t)((((uint64_t)w1 << 32) | w0) >> sh) & 7u;
-      raw += carry;
-      carry = raw > 4u ? 1u : 0u;
-      int d = (int)raw - (carry ? 8 : 0);
-      dig[h][i][lane] = (int8_t)(neg[h] ? -d : d);  // the half's sign folded in
-    }
-  }
-  G1Xyzz29 acc = xyzz29_identity();
-  bool started = false;
-#pragma unroll 1
-  for (int i = kWinDigits - 1; i >= 0; --i) {
-    acc = xyzz29_double(xyzz29_double(xyzz29_double(acc)));  // 8 acc (all-zero stays all-zero)
-#pragma unroll 1
-    for (int h = 0; h < 2; ++h) {
-      const int d = dig[h][i][lane];
-      const int a = d < 0 ? -d : d;
-      if (a != 0) {
-        G1Xyzz29 sel;
-        if (a == 1) {
-          sel = xyzz29_from_affine(q);
-          if (h) sel.x = qbx;
-        } else {
-          const int xo = h ? 36 : 0;
-#pragma unroll
-          for (int l = 0; l < 9; ++l) {
-            sel.x.v[l] = tab[a - 2][xo + l][lane];
-            sel.y.v[l] = tab[a - 2][9 + l][lane];
-            sel.zz.v[l] = tab[a - 2][18 + l][lane];
-            sel.zzz.v[l] = tab[a - 2][27 + l][lane];
-          }
-        }
-        if (d < 0) sel.y = fq29_neg(sel.y);
-        G1Xyzz29 sum = acc;
-        xyzz29_add_fast(sum, sel);
-        acc = started ? sum : sel;
-        started = true;
-      }
-    }
-  }
-  if (xyzz29_is_degenerate(acc)) {  // an exceptional addition on the way (or a true identity): both halves, carefully
-    G1Affine29 q1 = q, q2 = q;
-    q2.x = fq29_canon_residue(qbx);
-    if (neg[0]) q1.y = fq29_neg(q1.y);
-    if (neg[1]) q2.y = fq29_neg(q2.y);
-    G1Xyzz29 r1 = half_scalar_mul<true>(q1, mag[0]);
-    if (!xyzz29_is_identity(r1) && xyzz29_is_degenerate(r1)) r1 = xyzz29_identity();
-    G1Xyzz29 r2 = half_scalar_mul<true>(q2, mag[1]);
-    if (!xyzz29_is_identity(r2) && xyzz29_is_degenerate(r2)) r2 = xyzz29_identity();
-    out[2 * (size_t)t] = r1;
-    out[2 * (size_t)t + 1] = r2;  // the fold adds them with the careful adder
-    return;
-  }
-  out[2 * (size_t)t] = acc;
-}
-
-// K1 for THROUGHPUT-bound launches, continued: up to kGroupMax terms OF ONE SEGMENT per lane on shared doublings.  The joint
-// form above spends 129 doublings (~1 160 products) per term next to its 2 x 43 additions (~1 200); a segment's sum is
-// what the caller wants, so the terms a lane owns can share ONE accumulator and its doublings: per term 1 160 / K + 1 200
-// products -- K = 3: 1 590, K = 4: 1 490 against 2 360 -- on a chain K times as long per step, i.e. for launches that fill
-// the machine several times over (16 merged 1 024-proof jobs: 393 216 terms).
+// K1 for THROUGHPUT-bound launches: one lane per GROUP of up to kGroupMax terms OF ONE SEGMENT, both GLV halves of every
+// term, ONE accumulator and one doubling chain for all of them (Straus), and AFFINE tables so that every addition is mixed.
+// The two-lane form above spends 129 doublings (~1 160 products) per half-scalar next to 43 full additions; here a term
+// costs 1 160 / K + 2 x 43 x 7/8 mixed additions (~750) + ~80 for its table: K = 3: ~1 220 products against ~3 600 -- on a
+// chain K times as long per step, so only for launches that fill the machine (tens of thousands of terms, or several
+// launches in flight: the context's throughput hint).  Round 3 had the K = 1 case with projective tables (one lane per
+// term: 2 360 products); measured steps: profiles/r04_ab_naive_group.txt.
 //   lanes     segment s of L_s terms gets ceil(L_s / K) lanes; K in {2, 3, 4} is chosen ON THE DEVICE (the offsets live
-//             there) as the cheapest by  lanes x (1 160 + K x 1 200): three small kernels count, choose + scan, fill the
+//             there) as the cheapest by  lanes x (1 160 + K x 830): three small kernels count, choose + scan, fill the
 //             lane -> segment map, and a lane finds its segment by binary search
 //   grid      at most the machine's resident wavefronts; a block walks its share of the lanes, so the table scratch is
 //             sized by the machine, not by the launch
-//   tables    per term Q (x, y, beta x) and 2Q, 3Q, 4Q (XYZZ + beta X) in the global scratch, limb-major per lane as above
+//   tables    per term Q, 2Q, 3Q, 4Q as AFFINE points (x, y, beta x) in the global scratch, limb-major per lane: 2Q .. 4Q of
+//             all the lane's terms are brought to affine by ONE field inversion (Montgomery's trick over <= 12 elements: 8
+//             products each + an inversion worth ~55), which turns 14-product additions into 10-product ones
 //   digits    signed 3-bit, both halves, as NIBBLES in LDS (K x 2 x 22 bytes per lane)
 // Output: the group's sum in the slot of its first term, the identity in the group's other slots (the fold is unchanged).
 // A degenerate accumulator (P = +-Q met: e.g. a base listed twice in one group) sends every term of the group through the
-// careful bit-serial form, as in the joint kernel.
+// careful bit-serial form.  A fast addition meets P = +-Q otherwise only if  sum_j (u_j + v_j lambda) P_j = +-d P_i  for
+// prefixes u, v of the lane's scalars: for independent bases never, for crafted ones the degenerate flag is the net.
 constexpr int kGroupMax = 4;
-constexpr int kGroupRows = 27 + 3 * 45;  // table rows per term: Q's x, y, beta x; then 2Q, 3Q, 4Q with 45 rows each
+constexpr int kGroupRows = 27 + 3 * 45 + 9;  // table rows per term: Q's x, y, beta x; 2Q, 3Q, 4Q with 45 rows each while they are
+                                             // built (X, Y, ZZ, ZZZ, prefix product; x, y, beta x afterwards); the prefix before the term
 
 __global__ void __launch_bounds__(256) k_gmap_count(const uint32_t* __restrict__ offsets, uint32_t n_msm, uint32_t* __restrict__ bsum) {
   __shared__ uint32_t sh[3][256];
@@ -388,7 +273,7 @@ __global__ void __launch_bounds__(1024) k_gmap_choose(uint32_t* __restrict__ bsu
     uint32_t best = 0;
     unsigned long long bc = ~0ull;
     for (uint32_t k = 0; k < 3; ++k) {
-      const unsigned long long cost = (unsigned long long)tot[k] * (1160ull + (k + 2) * 1200ull);
+      const unsigned long long cost = (unsigned long long)tot[k] * (1160ull + (k + 2) * 830ull);
       if (cost < bc) bc = cost, best = k;
     }
     if (force_k >= 2 && force_k <= 4) best = force_k - 2;
@@ -473,7 +358,9 @@ __global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES)
       const uint32_t end = offsets[lo + 1];
       cnt = end - first < K ? end - first : K;
     }
-    // ---- per term: table + digits
+    // ---- per term: Q and the XYZZ forms of 2Q, 3Q, 4Q into the scratch, the running product of their ZZ ZZZ; digits
+    uint32_t hasm = 0;
+    Fq29 running = fq29_one();
 #pragma unroll 1
     for (uint32_t j = 0; j < K; ++j) {
       bool has = live && j < cnt;
@@ -492,18 +379,20 @@ __global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES)
         if (g1a29_is_identity(q) || any == 0) {
           has = false;  // contributes nothing: all digits zero, table untouched
         } else {
+          hasm |= 1u << j;
           const Fq29 qbx = fq29_mul(q.x, beta);
 #pragma unroll
           for (int l = 0; l < 9; ++l) {
             tab[j][l][lane] = q.x.v[l];
             tab[j][9 + l][lane] = q.y.v[l];
             tab[j][18 + l][lane] = qbx.v[l];
+            tab[j][162 + l][lane] = running.v[l];  // the prefix product before this term's three elements
           }
           G1Xyzz29 t2 = xyzz29_double_affine(q), t3 = t2;
           xyzz29_madd_fast(t3, q);
           G1Xyzz29 t4 = xyzz29_double(t2);
           auto put = [&](int e, const G1Xyzz29& v) {
-            const Fq29 bx = fq29_mul(v.x, beta);
+            running = fq29_mul(running, fq29_mul(v.zz, v.zzz));
             const int r0 = 27 + 45 * e;
 #pragma unroll
             for (int l = 0; l < 9; ++l) {
@@ -511,7 +400,7 @@ __global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES)
               tab[j][r0 + 9 + l][lane] = v.y.v[l];
               tab[j][r0 + 18 + l][lane] = v.zz.v[l];
               tab[j][r0 + 27 + l][lane] = v.zzz.v[l];
-              tab[j][r0 + 36 + l][lane] = bx.v[l];
+              tab[j][r0 + 36 + l][lane] = running.v[l];  // ... including this element
             }
           };
           put(0, t2);
@@ -537,7 +426,39 @@ __global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES)
         dig[j][h][kWinDigits >> 1][lane] = (uint8_t)(pend | (4u << 4));  // 43 digits: the last byte holds one
       }
     }
-    // ---- the shared chain
+    // ---- 2Q, 3Q, 4Q of every term to affine: one inversion for the lane, then backwards through the prefix products
+    if (hasm) {
+      Fq29 inv = fq29_inv(running);  // 1 / (product of all ZZ ZZZ); a doubling or addition of table building never gives ZZ = 0
+#pragma unroll 1
+      for (int j = (int)K - 1; j >= 0; --j) {
+        if (!((hasm >> j) & 1u)) continue;
+#pragma unroll 1
+        for (int e = 2; e >= 0; --e) {
+          const int r0 = 27 + 45 * e, rp = e == 0 ? 162 : r0 - 45 + 36;  // where the prefix BEFORE this element lies
+          Fq29 X, Y, ZZ, ZZZ, prev;
+#pragma unroll
+          for (int l = 0; l < 9; ++l) {
+            X.v[l] = tab[j][r0 + l][lane];
+            Y.v[l] = tab[j][r0 + 9 + l][lane];
+            ZZ.v[l] = tab[j][r0 + 18 + l][lane];
+            ZZZ.v[l] = tab[j][r0 + 27 + l][lane];
+            prev.v[l] = tab[j][rp + l][lane];
+          }
+          const Fq29 izn = fq29_mul(inv, prev);   // 1 / (ZZ ZZZ) of this element
+          inv = fq29_mul(inv, fq29_mul(ZZ, ZZZ));  // ... and the inverse of the product up to the previous one
+          const Fq29 xa = fq29_mul(X, fq29_mul(izn, ZZZ));            // X / ZZ
+          const Fq29 ya = fq29_mul(fq29_norm(Y), fq29_mul(izn, ZZ));  // Y / ZZZ
+          const Fq29 bxa = fq29_mul(xa, beta);
+#pragma unroll
+          for (int l = 0; l < 9; ++l) {
+            tab[j][r0 + l][lane] = xa.v[l];
+            tab[j][r0 + 9 + l][lane] = ya.v[l];
+            tab[j][r0 + 18 + l][lane] = bxa.v[l];
+          }
+        }
+      }
+    }
+    // ---- the shared chain: acc <- 8 acc, then one MIXED addition per non-zero digit of every (term, half)
     G1Xyzz29 acc = xyzz29_identity();
     bool started = false;
 #pragma unroll 1
@@ -549,30 +470,17 @@ __global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES)
         const int d = (int)((dig[j][h][i >> 1][lane] >> ((i & 1) * 4)) & 15u) - 4;
         const int a = d < 0 ? -d : d;
         if (a != 0) {
-          G1Xyzz29 sel;
-          if (a == 1) {
-            const int xo = h ? 18 : 0;
+          const int r0 = a == 1 ? 0 : 27 + 45 * (a - 2), xo = h ? 18 : 0;
+          G1Affine29 sel;
 #pragma unroll
-            for (int l = 0; l < 9; ++l) {
-              sel.x.v[l] = tab[j][xo + l][lane];
-              sel.y.v[l] = tab[j][9 + l][lane];
-            }
-            sel.zz = fq29_one();
-            sel.zzz = fq29_one();
-          } else {
-            const int r0 = 27 + 45 * (a - 2), xo = h ? 36 : 0;
-#pragma unroll
-            for (int l = 0; l < 9; ++l) {
-              sel.x.v[l] = tab[j][r0 + xo + l][lane];
-              sel.y.v[l] = tab[j][r0 + 9 + l][lane];
-              sel.zz.v[l] = tab[j][r0 + 18 + l][lane];
-              sel.zzz.v[l] = tab[j][r0 + 27 + l][lane];
-            }
+          for (int l = 0; l < 9; ++l) {
+            sel.x.v[l] = tab[j][r0 + xo + l][lane];
+            sel.y.v[l] = tab[j][r0 + 9 + l][lane];
           }
           if (d < 0) sel.y = fq29_neg(sel.y);
           G1Xyzz29 sum = acc;
-          xyzz29_add_fast(sum, sel);
-          acc = started ? sum : sel;
+          xyzz29_madd_fast(sum, sel);
+          acc = started ? sum : xyzz29_from_affine(sel);
           started = true;
         }
       }
@@ -853,11 +761,11 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
   const uint32_t J = chunks_for(n_terms);
   if (J == 1) {
     // throughput-bound launches (tens of thousands of terms, or other launches in flight next to this context's: its
-    // throughput hint) take the one-lane-per-term joint form: a third less issued work on a third longer chain
-    const char* ej = getenv("SNARKV_NAIVE_JOINT");  // 0 two-lane / 1 joint / 2 group (3, 4, 5: group with K = 2, 3, 4): test / A-B knob
-    const int jmode = ej ? atoi(ej) : ((n_terms >= 49152 || ctx->throughput_mode) ? (n_terms >= 2 * n_msm ? 2 : 1) : 0);
-    void* d_tab = nullptr;  // the fixed-window tables: 3 XYZZ points (+ beta X in the joint form) per lane
-    if (jmode >= 2) {
+    // throughput hint) take the grouped form: a third of the issued work on a chain K times as long
+    const char* ej = getenv("SNARKV_NAIVE_JOINT");  // 0 two lanes per term / 1 groups (K chosen on the device) / 2, 3, 4: groups of that K (test / A-B knob)
+    const int jmode = ej ? atoi(ej) : ((n_terms >= 49152 || ctx->throughput_mode) ? 1 : 0);
+    void* d_tab = nullptr;  // the fixed-window tables, limb-major per lane
+    if (jmode >= 1) {
       // several terms of a segment per lane on shared doublings; the lane -> segment map is built on the device
       static int slots = 0;  // resident wavefronts of this kernel: 2 per SIMD
       if (!slots) {
@@ -874,17 +782,12 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
       uint32_t* base = choice + 8;
       SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_CHAIN, (size_t)grid * kGroupMax * kGroupRows * 64 * 4, &d_tab));
       hipLaunchKernelGGL(k_gmap_count, dim3(nblk), dim3(256), 0, ctx->stream, (const uint32_t*)d_offsets, (uint32_t)n_msm, bsum);
-      hipLaunchKernelGGL(k_gmap_choose, dim3(1), dim3(1024), 0, ctx->stream, bsum, nblk, choice, (uint32_t)(jmode >= 3 ? jmode - 1 : 0));
+      hipLaunchKernelGGL(k_gmap_choose, dim3(1), dim3(1024), 0, ctx->stream, bsum, nblk, choice, (uint32_t)(jmode >= 2 ? jmode : 0));
       hipLaunchKernelGGL(k_gmap_fill, dim3(nblk), dim3(256), 0, ctx->stream, (const uint32_t*)d_offsets, (uint32_t)n_msm,
                          (const uint32_t*)bsum, (const uint32_t*)choice, base);
       hipLaunchKernelGGL(k_term_scalar_mul_group, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,
                          (const uint32_t*)d_points, (G1Xyzz29*)d_terms, (const uint32_t*)d_offsets, (uint32_t)n_msm,
                          (const uint32_t*)base, (const uint32_t*)choice, (int32_t*)d_tab, mont);
-    } else if (jmode == 1) {
-      uint32_t blocks = (uint32_t)((n_terms + 63) / 64);
-      SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_CHAIN, (size_t)blocks * 3 * 45 * 64 * 4, &d_tab));
-      hipLaunchKernelGGL(k_term_scalar_mul_joint, dim3(blocks), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,
-                         (const uint32_t*)d_points, (G1Xyzz29*)d_terms, (uint32_t)n_terms, (int32_t*)d_tab, mont);
     } else {
       uint32_t blocks = (uint32_t)((2 * n_terms + 63) / 64);
       SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_CHAIN, (size_t)blocks * 3 * 36 * 64 * 4, &d_tab));
@@ -911,13 +814,11 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
     hipLaunchKernelGGL(k_term_chunks, dim3((n_lanes + 63) / 64), dim3(64), 0, ctx->stream,
                        (const G1Xyzz29*)d_chain, (const uint4*)d_mags, (G1Xyzz29*)d_terms, n_lanes, J, bits);
   }
-  const char* eg = getenv("SNARKV_FOLD_GROUP");  // 16 / 64 / 256: force the lanes per MSM (test / A-B knob)
-  const int force = eg ? atoi(eg) : 0;
   const uint32_t nm = (uint32_t)n_msm;
-  if (force == 256 || (!force && n_terms >= 128 * n_msm))
+  if (n_terms >= 128 * n_msm)
     hipLaunchKernelGGL((k_segment_fold<256, 256>), dim3(nm), dim3(256), 0, ctx->stream, (const G1Xyzz29*)d_terms,
                        (const uint32_t*)d_offsets, (uint32_t*)d_out, nm, mont);
-  else if (force == 64 || (!force && n_terms > 32 * n_msm))
+  else if (n_terms > 32 * n_msm)
     hipLaunchKernelGGL((k_segment_fold<64, 64>), dim3(nm), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_terms,
                        (const uint32_t*)d_offsets, (uint32_t*)d_out, nm, mont);
   else  // <= 64 partials per MSM on average: four MSMs per wavefront

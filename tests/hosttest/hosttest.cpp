@@ -10,6 +10,7 @@
 #include "../../snark-verifier_amd/csrc/pairing_coop29.h"
 #include "../../snark-verifier_amd/csrc/fr29.h"
 #include "../../snark-verifier_amd/csrc/decide_sched.hpp"
+#include "../../snark-verifier_amd/csrc/g2_prepare_w.h"
 #include <vector>
 
 using namespace snarkv;
@@ -356,6 +357,68 @@ int ht_decide_w(const uint8_t* q2, const uint8_t* acc, uint8_t* out, int* info) 
   if (info) info[0] = prog.rounds, info[1] = prog.regs_used, info[2] = prog.critical_path, info[3] = nops;
   return 0;
 }
+// ---------------- the wavefront-parallel G2 line tables (g2_prepare_w.h), emulated level by level ---------------------------
+// q = one G2 point (128 bytes canonical).  Runs the generated level program exactly as k_g2_prepare_w does for one point
+// (every task's two components from the slots as they were BEFORE the level, stores after) and compares every line
+// coefficient with pairing.h g2_prepare brought to the same 29-bit canonical form.  Returns the number of mismatching
+// coefficients (0 = identical tables), -1 for the identity.
+int ht_g2_prepare_w(const uint8_t* q, int negate_y) {
+  G2Affine qa{load_fq2(q), load_fq2(q + 64)};
+  if (negate_y) qa.y = fq2_neg(qa.y);
+  G2Prepared* ref = new G2Prepared;
+  g2_prepare(qa, *ref);
+  if (ref->is_identity) {
+    delete ref;
+    return -1;
+  }
+  std::vector<Fq2_29P> sl(kG2wSlots);
+  for (auto& x : sl) x.c[0] = x.c[1] = fq29_zero();
+  auto put = [&](int slot, const Fq2& v) {
+    const Fq* c[2] = {&v.c0, &v.c1};
+    for (int e = 0; e < 2; ++e) {
+      uint32_t w[8];
+      fq_to_canonical(*c[e], w);
+      sl[slot].c[e] = fq29_canon_residue(fq29_from_canonical(w));
+    }
+  };
+  put(kG2wSlotQX, qa.x), put(kG2wSlotQY, qa.y), put(kG2wSlotTX, qa.x), put(kG2wSlotTYA, qa.y);
+  for (int k = 0; k < 6; ++k)
+    for (int e = 0; e < 2; ++e) sl[k].c[e] = g2w_const(k, e);
+  sl[kG2wSlotTZ].c[0] = fq29_one();
+  std::vector<Fq29> lines(kLinesPerG2 * 6, fq29_zero());
+  for (int lv = 0; lv < kG2wLevels; ++lv) {
+    Fq29 val[kG2wTasks][2];
+    for (int t = 0; t < kG2wTasks; ++t)
+      for (int e = 0; e < 2; ++e)
+        if (kG2wProg[lv][t].used) val[t][e] = g2w_task(sl.data(), kG2wProg[lv][t], e);
+    for (int t = 0; t < kG2wTasks; ++t) {
+      const G2wTask& tk = kG2wProg[lv][t];
+      if (!tk.used) continue;
+      for (int e = 0; e < 2; ++e) {
+        if (tk.dst >= 0) sl[tk.dst].c[e] = val[t][e];
+        else lines[(tk.out / 3) * 6 + 2 * (tk.out % 3) + e] = fq29_canon_of_product(val[t][e]);
+      }
+    }
+  }
+  int bad = 0;
+  for (int idx = 0; idx < kLinesPerG2; ++idx) {
+    const LineCoeff& l = ref->line[idx];
+    const Fq* src[6] = {&l.cy.c0, &l.cy.c1, &l.cx.c0, &l.cx.c1, &l.cw.c0, &l.cw.c1};
+    for (int c = 0; c < 6; ++c) {
+      uint32_t w[8];
+      fq_to_canonical(*src[c], w);
+      const Fq29 want = fq29_canon_residue(fq29_from_canonical(w));
+      for (int i = 0; i < 9; ++i)
+        if (want.v[i] != lines[idx * 6 + c].v[i]) {
+          ++bad;
+          break;
+        }
+    }
+  }
+  delete ref;
+  return bad;
+}
+
 // ---------------- SNARKV_FLAG_MONTGOMERY codecs (fq29.h fq29_from_words / fq29_to_words, fr29.h fr_words_from_mont256) ---------
 // in: 32 bytes; mode 0: canonical -> in-memory form (a * 2^256 mod p) through the 29-bit domain; 1: the reverse;
 // 2: Fr in-memory -> canonical.  Exactly the device functions.

@@ -372,3 +372,17 @@ def test_montgomery_boundary_codecs(hosttest_lib):
         assert o64.raw == pt
         L.ht_g1_recode(M.coords_to_mont(pt), 1, 1, o64)
         assert o64.raw == M.coords_to_mont(pt)
+
+
+def test_wavefront_parallel_g2_line_tables_on_the_host(hosttest_lib, golden_decider):
+    """g2_prepare_w.h + the generated level program: every line coefficient of both points of the golden key (g2, -s_g2) and of
+    random G2 points equals pairing.h's one-lane g2_prepare in the 29-bit canonical form the decide kernels read."""
+    L = hosttest_lib
+    g2, s_g2 = bytes.fromhex(golden_decider["g2"]), bytes.fromhex(golden_decider["s_g2"])
+    assert L.ht_g2_prepare_w(g2, 0) == 0
+    assert L.ht_g2_prepare_w(s_g2, 1) == 0
+    rng = random.Random(31)
+    for _ in range(3):
+        q = O.g2_to_bytes(O.g2_mul(O.G2_GEN, rng.randrange(1, O.R)))
+        assert L.ht_g2_prepare_w(q, 0) == 0
+    assert L.ht_g2_prepare_w(bytes(128), 0) == -1

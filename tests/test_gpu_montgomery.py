@@ -41,7 +41,7 @@ def test_golden_msms_in_memory_form(gpu_ctx, golden_msm):
 @pytest.mark.parametrize("chunks", ["1", "4", "16"])
 @pytest.mark.parametrize("joint", ["0", "1"])
 def test_every_term_kernel_in_memory_form(gpu_ctx, monkeypatch, chunks, joint):
-    """the four term kernels of the segmented MSM (fixed window two-lane / joint, one-lane and four-lane chains)"""
+    """the four term kernels of the segmented MSM (fixed window two-lane / grouped, one-lane and four-lane chains)"""
     sv = _sv()
     monkeypatch.setenv("SNARKV_NAIVE_CHUNKS", chunks)
     monkeypatch.setenv("SNARKV_NAIVE_JOINT", joint)
@@ -128,7 +128,7 @@ def test_chunk_pipeline_in_memory_form(monkeypatch):
     ctx.close()
 
 
-@pytest.mark.parametrize("form", ["1", "2", "3"])
+@pytest.mark.parametrize("form", ["1", "3"])
 def test_decider_in_memory_form(gpu_ctx, golden_decider, form, monkeypatch):
     """deciding key (G2Affine coordinates) and accumulators in the in-memory form: same verdicts, same Gt bytes"""
     sv = _sv()

@@ -164,11 +164,11 @@ def test_chunk_base_chain_one_lane_and_four_lanes(gpu_ctx, golden_msm, quad, mon
         assert gpu_ctx.msm_naive(s, p) == C.msm_pippenger(s, p, 2), chunks
 
 
-@pytest.mark.parametrize("mode", ["0", "1", "2", "3", "4", "5"])
-def test_fixed_window_term_kernels_two_lane_joint_and_group(gpu_ctx, golden_msm, mode, monkeypatch):
-    """The one-launch term kernels of the segmented MSM (SNARKV_NAIVE_CHUNKS = 1): two lanes per term, one lane per term on
-    shared doublings (joint), and SEVERAL TERMS OF A SEGMENT per lane (group: 2 = the device picks K, 3 / 4 / 5 force
-    K = 2 / 3 / 4).  Same bytes as the oracle on segments shorter, equal to and longer than K, with identity bases, zero
+@pytest.mark.parametrize("mode", ["0", "1", "2", "3", "4"])
+def test_fixed_window_term_kernels_two_lane_and_group(gpu_ctx, golden_msm, mode, monkeypatch):
+    """The one-launch term kernels of the segmented MSM (SNARKV_NAIVE_CHUNKS = 1): two lanes per term (0), and SEVERAL TERMS OF
+    A SEGMENT per lane on shared doublings with affine tables (group: 1 = the device picks K, 2 / 3 / 4 force K).  Same
+    bytes as the oracle on segments shorter, equal to and longer than K, with identity bases, zero
     scalars, a base listed twice with the same and with the opposite scalar inside one group (the degenerate fall-back),
     scalars built from the GLV lambda, and on every golden case in one launch."""
     monkeypatch.setenv("SNARKV_NAIVE_CHUNKS", "1")
@@ -204,7 +204,7 @@ def test_group_kernel_walks_more_lanes_than_the_grid(gpu_ctx, monkeypatch):
     import torch
 
     monkeypatch.setenv("SNARKV_NAIVE_CHUNKS", "1")
-    monkeypatch.setenv("SNARKV_NAIVE_JOINT", "2")
+    monkeypatch.setenv("SNARKV_NAIVE_JOINT", "1")
     n = 150_000
     s, p = C.sample_scalars(71, n), C.sample_points(72, n)
     offs, k = [0], 0
@@ -220,7 +220,7 @@ def test_group_kernel_walks_more_lanes_than_the_grid(gpu_ctx, monkeypatch):
     torch.cuda.synchronize()
     gpu_ctx.sample_scalars_dev(73, n, ds.data_ptr())
     gpu_ctx.sample_points_dev(74, n, dp.data_ptr())
-    for mode, o in (("3", out[0]), ("0", out[1])):
+    for mode, o in (("2", out[0]), ("0", out[1])):
         monkeypatch.setenv("SNARKV_NAIVE_JOINT", mode)
         gpu_ctx.msm_batched_dev(ds.data_ptr(), dp.data_ptr(), do.data_ptr(), n // 2, n, o.data_ptr())
         gpu_ctx.sync()

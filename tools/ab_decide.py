@@ -9,7 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--sizes", default="1,16,64,256,1024")
-ap.add_argument("--forms", default="2,3,1")
+ap.add_argument("--forms", default="3,1")
 a = ap.parse_args()
 ctx = sv.Context(0)
 g2 = bytes.fromhex("edf692d95cbdde46ddda5ef7d422436779445c5e66006a42761e1f12efde0018c212f3aeb785e49712e7a9353349aaf1255dfb31b7bf60723a480d9293938e19aa7dfa6601cce64c7bd3430c69e7d1e38f40cb8d8071ab4aeb6d8cdba55ec8125b9722d1dcdaac55f38eb37033314bbc95330c69ad999eec75f05f58d0890609")
