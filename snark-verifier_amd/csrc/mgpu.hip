@@ -33,6 +33,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
+#include <string>
 #include <vector>
 #include "ctx.hpp"
 
@@ -63,16 +65,22 @@ struct RcclApi {
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
+static std::string g_rccl_why;  // why the library could not be loaded (dlerror() clears itself: read once, here)
 RcclApi* rccl_api() {
   static RcclApi api;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  static std::once_flag once;
+  std::call_once(once, [] {
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char* nm : names)
       if ((api.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD))) break;  // a copy already in the process (torch's) first
-    for (const char* nm : names)
-      if (!api.lib && (api.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+    for (const char* nm : names) {
+      if (api.lib) break;
+      api.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+      if (!api.lib) {
+        const char* e = dlerror();
+        if (e) g_rccl_why = e;
+      }
+    }
     if (api.lib) {
       api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.lib, "ncclCommInitAll");
       api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
@@ -81,7 +89,7 @@ RcclApi* rccl_api() {
       api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
       api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
     }
-  }
+  });
   return (api.lib && api.CommInitAll && api.CommDestroy && api.AllGather && api.GroupStart && api.GroupEnd) ? &api : nullptr;
 }
 constexpr int kNcclUint8 = 1;  // ncclDataType_t: ncclInt8 = 0, ncclUint8 = 1 (nccl.h / rccl.h, stable ABI)
@@ -116,11 +124,17 @@ static int gather_fold(snarkv_mgpu* mg, uint8_t out64[64]) {
     }
     // one grouped all-gather: rank g contributes its 144-byte partial, every rank receives [rank][144]
     int rc = nc->GroupStart();
-    for (int g = 0; g < world && rc == 0; ++g) {
-      SNARKV_HIP(hipSetDevice(mg->ctx[g]->device));
+    hipError_t herr = hipSuccess;  // (no early return inside the group: GroupEnd always closes it)
+    for (int g = 0; g < world && rc == 0 && herr == hipSuccess; ++g) {
+      herr = hipSetDevice(mg->ctx[g]->device);
+      if (herr != hipSuccess) break;
       rc = nc->AllGather(mg->d_part[g], mg->d_gather_all[g], SNARKV_G1_PARTIAL_BYTES, kNcclUint8, mg->comms[g], mg->ctx[g]->stream);
     }
     int rc2 = nc->GroupEnd();
+    if (herr != hipSuccess) {
+      set_last_error("mgpu: hipSetDevice inside the all-gather group: %s", hipGetErrorString(herr));
+      return SNARKV_ERR_DEVICE;
+    }
     if (rc != 0 || rc2 != 0) {
       set_last_error("mgpu: ncclAllGather failed: %s", nc->GetErrorString ? nc->GetErrorString(rc ? rc : rc2) : "?");
       return SNARKV_ERR_DEVICE;
@@ -306,7 +320,7 @@ int snarkv_mgpu_set_transport(snarkv_mgpu* mg, int transport) {
     const int world = (int)mg->ctx.size();
     RcclApi* nc = rccl_api();
     if (!nc) {
-      set_last_error("mgpu: librccl could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+      set_last_error("mgpu: librccl could not be loaded (%s)", g_rccl_why.empty() ? "symbols missing" : g_rccl_why.c_str());
       return SNARKV_ERR_DEVICE;
     }
     std::vector<int> devs(world);

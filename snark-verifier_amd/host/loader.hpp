@@ -127,6 +127,11 @@ class HostPool {
     lk.unlock();
     if (job.err) std::rethrow_exception(job.err);
   }
+  // true on the pool's own threads (a task that fans out runs inline; a task must never take the device lock)
+  static bool& in_worker() {
+    static thread_local bool flag = false;
+    return flag;
+  }
 
  private:
   struct Job {
@@ -151,10 +156,6 @@ class HostPool {
     }
     cv_.notify_all();
     for (auto& w : workers_) w.join();
-  }
-  static bool& in_worker() {
-    static thread_local bool flag = false;
-    return flag;
   }
   void loop() {
     in_worker() = true;
@@ -209,6 +210,9 @@ inline void parallel_for(size_t n, unsigned threads, F&& fn, size_t grain = 16) 
 // never take this lock (they are host-only parsing and field algebra).
 inline std::mutex& device_mutex() {
   static std::mutex m;
+  // lock order: device_mutex -> the pool's submit lock (packing fans out under the device lock).  A pool task that took
+  // the device lock would close the cycle: refuse it loudly instead of deadlocking some day.
+  if (HostPool::in_worker()) throw std::logic_error("device_mutex() from a pool worker: tasks of the host pool must stay host-only");
   return m;
 }
 

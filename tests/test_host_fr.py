@@ -19,6 +19,10 @@ def test_fr_mul_inv():
     # `invert` is Kaliski's almost-inverse + a 2^k correction whose branch depends on the iteration count k:
     # small values, powers of two (few subtractions, many shifts), r - small and random values cover both branches
     edge = [1 << i for i in range(0, 254, 7)] + [(1 << i) - 1 for i in range(2, 254, 11)] + [O.R - (1 << i) for i in range(0, 250, 13)]
+    # the branch is taken on the MONTGOMERY residue x = a * 2^256: small and power-of-two x (k < 257, and the k = 257 / 258
+    # cases whose unreduced operand meets mont_mul) need a = x * 2^-256
+    rinv = pow(1 << 256, -1, O.R)
+    edge += [(1 << j) * rinv % O.R for j in list(range(0, 12)) + [64, 128, 200, 252, 253]] + [(O.R - 1) * rinv % O.R, 3 * rinv % O.R]
     o2 = ctypes.create_string_buffer(32)
     for a in vals[1:] + edge + [rng.randrange(1, 1 << rng.randrange(1, 254)) for _ in range(300)]:
         assert L.hd_fr_inv(O.fe_to_bytes(a), o) == 1
