@@ -102,7 +102,6 @@ SNARKV_HD Fq29 wt_load(const Fq29P* lds, int idx) {
 SNARKV_HD void wt_store(Fq29P* lds, int idx, const Fq29& x) {
 #pragma unroll
   for (int i = 0; i < 9; ++i) lds[idx].v[i] = x.v[i];
-  lds[idx].v[9] = 0;
 }
 
 // x or -x, limb-wise (m = 0 / -1)
@@ -113,45 +112,62 @@ SNARKV_HD Fq29 wt_cneg(const Fq29& x, int32_t m) {
   return r;
 }
 
+// What a lane needs of an operation, as far as it does not depend on the operation: computed once per kernel.
+// Offsets are in values from the operand's base; -1: the lane has no task in that addressing mode.
+struct WtLaneC {
+  int a_dense, a_line, a_pw;         // A's coefficient (u^0 component; u^1 follows it)
+  int b_dense, b_line, b_pw, b_pwb;  // B's component y0; y1 lies at y0 + dy
+  int dy;                            // +1 (e = 0) / -1 (e = 1)
+  int32_t m1;                        // sign of the second term: -1 (e = 0: a0 y0 - a1 y1) / 0
+  int32_t odd_a, odd_b, odd_k;       // -1 where the power of w taken from A / from B / of the output is odd (conj flags)
+};
+SNARKV_HD WtLaneC wt_lane_c(int half, int lane) {
+  const WtLane L = wt_lane(half, lane);
+  WtLaneC C;
+  const bool mul = L.group && L.j < 6, pw = L.group && L.j == 0;
+  C.a_dense = mul ? 2 * L.j : -1;
+  C.a_line = mul && wt_line_has(L.j) ? 2 * wt_line_slot(L.j) : -1;
+  C.a_pw = pw ? 2 * L.k : -1;
+  C.b_dense = mul ? (L.xi ? 12 : 0) + 2 * L.i2 + L.e : -1;
+  C.b_line = mul && wt_line_has(L.i2) ? (L.xi ? 6 : 0) + 2 * wt_line_slot(L.i2) + L.e : -1;
+  C.b_pw = pw ? 2 * L.k + L.e : -1;
+  C.b_pwb = pw ? L.e : -1;
+  C.dy = L.e ? -1 : 1;
+  C.m1 = L.e ? 0 : -1;
+  C.odd_a = (L.j & 1) ? -1 : 0;
+  C.odd_b = (L.i2 & 1) ? -1 : 0;
+  C.odd_k = (L.k & 1) ? -1 : 0;
+  return C;
+}
+
 // The lane's contribution to its output coefficient: one fused two-product Montgomery step, or zero.
 //   e = 0:  a0 y0 - a1 y1      e = 1:  a0 y0 + a1 y1       with (y0, y1) = (b_e, b_(1-e)) of the chosen B coefficient
 // Every operand is carry-normalised (|limb| < 2^29): plain values within 1.5 p, xi copies within 15 p, so the sum of the
 // two products is below 45 p^2 and the step's output within (-0.3 p, 1.3 p).
-SNARKV_HD Fq29 wt_task(const Fq29P* lds, const WtOp op, int half, int lane) {
-  const WtLane L = wt_lane(half, lane);
-  bool active = L.group && op.kind != WT_IDLE && op.kind != WT_FQ2INV;
-  int ia, ib, ja = L.j, jb = L.i2;
-  if (op.kind == WT_PW) {
-    active = active && L.j == 0;
-    ja = L.k;
-    jb = (op.flags & WT_B_BCAST) ? 0 : L.k;
-    ia = op.a + 2 * ja;
-    ib = op.b + 2 * jb;
-  } else {
-    active = active && L.j < 6;
-    if (op.flags & WT_A_LINE) {
-      active = active && wt_line_has(ja);
-      ia = op.a + 2 * wt_line_slot(ja);
-    } else {
-      ia = op.a + 2 * ja;
-    }
-    if (op.flags & WT_B_LINE) {
-      active = active && wt_line_has(jb);
-      ib = op.b + (L.xi ? 6 : 0) + 2 * wt_line_slot(jb);
-    } else {
-      ib = op.b + (L.xi ? 12 : 0) + 2 * jb;
-    }
+SNARKV_HD Fq29 wt_task_c(const Fq29P* lds, const WtOp op, const WtLaneC& C) {
+  const bool pw = op.kind == WT_PW;
+  // the offset of the operation's addressing mode, picked with uniform masks (an indexed pick would put the lane's
+  // constants on the stack: a scratch load at the head of every round)
+  const int m_pw = pw ? -1 : 0, m_al = (!pw && (op.flags & WT_A_LINE)) ? -1 : 0, m_ad = ~(m_pw | m_al);
+  const int m_pb = (pw && (op.flags & WT_B_BCAST)) ? -1 : 0, m_pp = m_pw & ~m_pb;
+  const int m_bl = (!pw && (op.flags & WT_B_LINE)) ? -1 : 0, m_bd = ~(m_pw | m_bl);
+  const int ia = (C.a_pw & m_pw) | (C.a_line & m_al) | (C.a_dense & m_ad);
+  const int ib = (C.b_pwb & m_pb) | (C.b_pw & m_pp) | (C.b_line & m_bl) | (C.b_dense & m_bd);
+  if (ia < 0 || ib < 0 || (op.kind != WT_MUL && op.kind != WT_PW)) return fq29_zero();
+  Fq29 a0 = wt_load(lds, op.a + ia), a1 = wt_load(lds, op.a + ia + 1);
+  const Fq29 y0 = wt_load(lds, op.b + ib), y1 = wt_load(lds, op.b + ib + C.dy);
+  int32_t m1 = C.m1;
+  if (op.flags & (WT_A_CONJ | WT_B_CONJ | WT_A_UCONJ)) {  // (uniform; a fifth of the hard part's operations)
+    int32_t m0 = 0;
+    if (op.flags & WT_A_CONJ) m0 ^= pw ? C.odd_k : C.odd_a;
+    if (op.flags & WT_B_CONJ) m0 ^= C.odd_b;
+    m1 ^= m0;
+    if (op.flags & WT_A_UCONJ) m1 = ~m1;
+    a0 = wt_cneg(a0, m0);
   }
-  if (!active) return fq29_zero();
-  const Fq29 a0 = wt_load(lds, ia), a1 = wt_load(lds, ia + 1);
-  const Fq29 y0 = wt_load(lds, ib + L.e), y1 = wt_load(lds, ib + 1 - L.e);
-  // signs of the two terms
-  int s0 = 0, s1 = L.e ? 0 : -1;
-  if ((op.flags & WT_A_CONJ) && (ja & 1)) s0 = ~s0, s1 = ~s1;
-  if ((op.flags & WT_B_CONJ) && (jb & 1)) s0 = ~s0, s1 = ~s1;
-  if (op.flags & WT_A_UCONJ) s1 = ~s1;
-  return fq29_mul2(wt_cneg(a0, s0), y0, wt_cneg(a1, s1), y1);
+  return fq29_mul2(a0, y0, wt_cneg(a1, m1), y1);
 }
+SNARKV_HD Fq29 wt_task(const Fq29P* lds, const WtOp op, int half, int lane) { return wt_task_c(lds, op, wt_lane_c(half, lane)); }
 
 // s = limb-wise sum of <= 6 task outputs (limbs 0..7 read as unsigned: < 6 * 2^29; limb 8 signed).  Returns the
 // carry-normalised representative within 0.5 p (+ the estimate's slack: < 1.5 p) of the same residue: the quotient is

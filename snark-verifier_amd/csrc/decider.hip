@@ -448,6 +448,7 @@ __global__ void __launch_bounds__(256)
     wt_eval_line(wt_lds, prep, pair, rem / 3, rem % 3, pt[pair][0], pt[pair][1], live[pair] != 0);
   }
   __syncthreads();
+  const WtLaneC LC = wt_lane_c(half, lane);
   uint2 raw = prog_lds[duo];
   for (int r = 0; r < rounds; ++r) {
     WtOp op;
@@ -459,7 +460,7 @@ __global__ void __launch_bounds__(256)
     if (op.kind == WT_FQ2INV) {
       if (half == 0 && lane == 0) wt_fq2inv(wt_lds, op);
     } else if (op.kind != WT_IDLE) {
-      const Fq29 own = wt_squeeze(group8_sum(wt_task(wt_lds, op, half, lane)));
+      const Fq29 own = wt_squeeze(group8_sum(wt_task_c(wt_lds, op, LC)));
       Fq29 other;  // the other u-component of the same power of w: 8 lanes away in the row
 #pragma unroll
       for (int q = 0; q < 9; ++q) other.v[q] = (int32_t)dpp_u32<0x128>((uint32_t)own.v[q]);  // row_ror:8
