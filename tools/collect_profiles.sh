@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): every record the round's profiles/ directory keeps, written under gpurun_out/<tag>_*
 # (gpurun merges only gpurun_out/ back; copy what you want judged into profiles/).
-#   tools/collect_profiles.sh r03
+#   tools/collect_profiles.sh r04
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
@@ -13,7 +13,6 @@ python tools/pmc_traffic.py --tag $TAG --out-dir $O --log2n 24 > /dev/null
 cp $O/${TAG}_pmc_hbm_traffic*.json profiles/
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python bench.py --steps 40 --warmup 4 --no-secondary --no-cpu-baseline > $O/${TAG}_bench_40steps.json 2>/dev/null
-python bench.py --inflight 4 --no-secondary --no-cpu-baseline > $O/${TAG}_bench_4inflight.json 2>/dev/null   # four single calls in flight (the earlier submission)
 python bench.py --log2n 22 --inflight 1 --steps 10 --warmup 2 --no-secondary --cpu-sample-log2 18 > $O/${TAG}_bench_2p22.json 2>/dev/null
 python bench.py --log2n 24 --inflight 1 --steps 6 --warmup 2 --no-secondary --cpu-sample-log2 18 > $O/${TAG}_bench_2p24.json 2>/dev/null
 cd /tmp
@@ -25,14 +24,13 @@ stats() {  # name, bench args...
   if [ -n "$db" ]; then python $R/tools/rocpd_top_kernels.py $db $O/${TAG}_rocprofv3_kernel_stats_$name.csv; else
     f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_rocprofv3_kernel_stats_$name.csv; fi
 }
-stats batch --steps 20 --warmup 5 --no-cpu-baseline --no-secondary
-stats 4inflight --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --inflight 4
+stats batch --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-host-resident
 stats sequential --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --inflight 1
-stats with_secondary --steps 4 --warmup 1 --no-cpu-baseline
+stats with_secondary --steps 4 --warmup 1 --no-cpu-baseline --no-host-resident
 stats 2p24_single --log2n 24 --inflight 1 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary
 # the timed batch as a kernel timeline (who overlaps whom): the window from the 45th k_prepare (2 x 20 initialisation / warm-up
 # jobs + the 4 slot calls) to the end of the batch's k_final
-rm -rf /tmp/prof_trace; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_trace -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+rm -rf /tmp/prof_trace; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_trace -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-host-resident > /dev/null 2>&1
 python $R/tools/trace_overlap.py /tmp/prof_trace --first 44 --count 20 --until-prepare 64 > $O/${TAG}_overlap_batch.txt 2>&1
 # the aggregation job alone (bench.py's second metric): kernel shares for secondary.aggregate_*.roofline.dominant_kernel
 for m in 64 1024; do
@@ -43,7 +41,7 @@ for m in 64 1024; do
 done
 # ... and with jobs in flight: by hardware-queue count, and the kernel durations under 16-fold overlap
 cd $R
-for q in 4 16; do GPU_MAX_HW_QUEUES=$q python tools/aggregate_inflight.py --inflight 1 8 16 32 2>/dev/null | grep queues=; done > $O/${TAG}_agg_hw_queues_final.txt
+GPU_MAX_HW_QUEUES=16 python tools/aggregate_inflight.py --inflight 1 8 16 32 2>/dev/null | grep queues= > $O/${TAG}_agg_inflight.txt
 cd /tmp
 for m in 64 1024; do
   rm -rf /tmp/prof_a; rocprofv3 --kernel-trace --stats -d /tmp/prof_a -- python $R/tools/aggregate_inflight.py --proofs $m --inflight 16 > /dev/null 2>&1
@@ -52,5 +50,4 @@ for m in 64 1024; do
     f=$(find /tmp/prof_a -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_rocprofv3_kernel_stats_aggregate_inflight16_$m.csv; fi
 done
 cd $R
-timeout 120 tools/ubench_issue > $O/${TAG}_ubench_issue.txt 2>&1
 ls -la $O | grep $TAG
