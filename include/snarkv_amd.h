@@ -293,6 +293,21 @@ int snarkv_poseidon_transcript_batch(snarkv_ctx* ctx, const snarkv_poseidon* ps,
                                      size_t L, const uint32_t* seg_len, size_t S, uint8_t* out);
 int snarkv_poseidon_transcript_batch_dev(snarkv_ctx* ctx, const snarkv_poseidon* ps, const void* d_elems, size_t n,
                                          size_t L, const void* d_seg_len, size_t S, void* d_out);
+/* The same hashing for n PROOFS of one protocol, read where they are: what a native PoseidonTranscript absorbs while it
+ * reads a proof (system/halo2/transcript/halo2.rs:215-275) is, in the protocol's order, a value the caller brought
+ * (initial state, instances), a scalar of the proof, or a coordinate of one of its compressed points reduced mod r
+ * (`fe_to_fe`).  layout[k] (k < L) names the source of absorbed element k:  kind << 28 | value  with kind 0 = lead element
+ * `value` of this proof (lead + 32 (n_lead i + value), canonical Fr), 1 = the 32-byte scalar at byte `value` of the proof,
+ * 2 / 3 = x / y of point `value`, the compressed point (halo2curves bn256 `G1Affine::from_bytes`) at byte
+ * point_offsets[value].  Proof i lies at proofs + stride i (stride and point offsets multiples of 16, scalar offsets of 4).
+ * One pipeline on the device: every point decompressed, every transcript's input assembled, all transcripts hashed.
+ * Out: n x S challenges; the n x P decompressed points (64 bytes, canonical whatever the context's flags) and a validity
+ * byte each -- a proof with an invalid point or a non-canonical scalar gets meaningless challenges: the caller, who parses
+ * the proof with them, rejects it there (host/aggregation.hpp does).                                                    */
+int snarkv_poseidon_read_batch(snarkv_ctx* ctx, const snarkv_poseidon* ps, const uint8_t* proofs, size_t n, size_t stride,
+                               const uint8_t* lead, size_t n_lead, const uint32_t* layout, size_t L,
+                               const uint32_t* point_offsets, size_t P, const uint32_t* seg_len, size_t S,
+                               uint8_t* challenges, uint8_t* points64, uint8_t* ok);
 
 /* context-free forms (process-global context, thread-safe) */
 int bn254_poseidon_create(uint32_t t, uint32_t rate, uint32_t r_f, uint32_t r_p, const uint8_t* start,
@@ -300,6 +315,9 @@ int bn254_poseidon_create(uint32_t t, uint32_t rate, uint32_t r_f, uint32_t r_p,
                           const uint8_t* sparse_rows, const uint8_t* sparse_col_hats, snarkv_poseidon** out);
 int bn254_poseidon_transcript_batch(const snarkv_poseidon* ps, const uint8_t* elems, size_t n, size_t L,
                                     const uint32_t* seg_len, size_t S, uint8_t* out);
+int bn254_poseidon_read_batch(const snarkv_poseidon* ps, const uint8_t* proofs, size_t n, size_t stride, const uint8_t* lead,
+                              size_t n_lead, const uint32_t* layout, size_t L, const uint32_t* point_offsets, size_t P,
+                              const uint32_t* seg_len, size_t S, uint8_t* challenges, uint8_t* points64, uint8_t* ok);
 
 /* ---- multi-GPU in ONE process (SURVEY.md 8b `*_multi_gpu`, 8e) -----------------
  * For a caller without torchrun -- the reference's `NativeLoader` is a unit struct

@@ -121,6 +121,8 @@ _SIGNATURES = {
     "snarkv_poseidon_transcript_batch_dev": (_int, [_vp, _vp, _vp, _sz, _sz, _vp, _sz, _vp]),
     "bn254_poseidon_create": (_int, [_u32, _u32, _u32, _u32, _cp, _cp, _cp, _cp, _cp, _cp, _cp, _pp]),
     "bn254_poseidon_transcript_batch": (_int, [_vp, _cp, _sz, _sz, _vp, _sz, _vp]),
+    "snarkv_poseidon_read_batch": (_int, [_vp, _vp, _cp, _sz, _sz, _cp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "bn254_poseidon_read_batch": (_int, [_vp, _cp, _sz, _sz, _cp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "snarkv_set_stage_timing": (_int, [_vp, _int]),
     "snarkv_get_stage_timing": (_int, [_vp, _vp]),
 }
@@ -579,6 +581,24 @@ class Context:
         _check(self._lib.snarkv_poseidon_transcript_batch(self._h, spec._h, elems if elems else b"\x00", n, L,
                                                           ctypes.c_void_p(addr), len(seg_len), out))
         return out.raw
+
+    def poseidon_read_batch(self, spec, proofs, n, stride, lead, n_lead, layout, point_offsets, seg_len):
+        """n proofs (stride bytes each) hashed where they are: layout[k] = kind << 28 | value names the source of absorbed
+        element k (0 lead element, 1 scalar at that byte of the proof, 2 / 3 x / y of that point); returns (challenges,
+        points64, ok) -- include/snarkv_amd.h snarkv_poseidon_read_batch."""
+        import array
+
+        proofs, lead = _as_bytes(proofs), _as_bytes(lead)
+        assert len(proofs) == n * stride and len(lead) == 32 * n * n_lead and sum(seg_len) == len(layout)
+        lay, offs, segs = array.array("I", layout), array.array("I", point_offsets), array.array("I", seg_len)
+        P, S = len(point_offsets), len(seg_len)
+        ch = ctypes.create_string_buffer(max(1, 32 * n * S))
+        pts = ctypes.create_string_buffer(max(1, 64 * n * P))
+        ok = ctypes.create_string_buffer(max(1, n * P))
+        _check(self._lib.snarkv_poseidon_read_batch(
+            self._h, spec._h, proofs, n, stride, lead if lead else b"\x00", n_lead, ctypes.c_void_p(lay.buffer_info()[0]), len(layout),
+            ctypes.c_void_p(offs.buffer_info()[0]) if P else None, P, ctypes.c_void_p(segs.buffer_info()[0]), S, ch, pts, ok))
+        return ch.raw[:32 * n * S], pts.raw[:64 * n * P], ok.raw[:n * P]
 
     def ubench_valu(self, which, iters=400):
         v = ctypes.c_double()

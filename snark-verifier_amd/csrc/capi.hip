@@ -896,4 +896,14 @@ int bn254_poseidon_transcript_batch(const snarkv_poseidon* ps, const uint8_t* el
   return snarkv_poseidon_transcript_batch(c, ps, elems, n, L, seg_len, S, out);
 }
 
+int bn254_poseidon_read_batch(const snarkv_poseidon* ps, const uint8_t* proofs, size_t n, size_t stride, const uint8_t* lead,
+                              size_t n_lead, const uint32_t* layout, size_t L, const uint32_t* point_offsets, size_t P,
+                              const uint32_t* seg_len, size_t S, uint8_t* challenges, uint8_t* points64, uint8_t* ok) {
+  SNARKV_DEFAULT_CALL_LOCK();
+  snarkv_ctx* c;
+  SNARKV_TRY(default_ctx(&c));
+  return snarkv_poseidon_read_batch(c, ps, proofs, n, stride, lead, n_lead, layout, L, point_offsets, P, seg_len, S, challenges,
+                                    points64, ok);
+}
+
 }  // extern "C"

@@ -377,19 +377,19 @@ __global__ void __launch_bounds__(64) k_g2_prepare_w(const uint32_t* __restrict_
     const int p = lane >> 2, c = lane & 3;  // c: x.c0, x.c1, y.c0, y.c1
     Fq29 v = fq29_canon_residue(fq29_from_words(g2x2 + 32 * p + 8 * c, mont != 0));
     if (p == 1 && c >= 2) v = fq29_canon_residue(fq29_neg(v));
-    sl[p][c < 2 ? kG2wSlotQX : kG2wSlotQY].c[c & 1] = v;
-    sl[p][c < 2 ? kG2wSlotTX : kG2wSlotTYA].c[c & 1] = v;
+    g2w_put(sl[p], c < 2 ? kG2wSlotQX : kG2wSlotQY, c & 1, v);
+    g2w_put(sl[p], c < 2 ? kG2wSlotTX : kG2wSlotTYA, c & 1, v);
   } else if (lane < 8 + 24) {  // the constants of the program
     const int q = lane - 8, p = q / 12, k = (q % 12) >> 1, ee = q & 1;
-    sl[p][k].c[ee] = g2w_const(k, ee);  // slots 0 .. 5: ONE, B3, G12, G13, G22, G23
+    g2w_put(sl[p], k, ee, g2w_const(k, ee));  // slots 0 .. 5: ONE, B3, G12, G13, G22, G23
   } else if (lane < 8 + 24 + 8) {
     const int q = lane - 32, p = q >> 2, k = (q >> 1) & 1, ee = q & 1;
-    sl[p][k ? kG2wSlotTZ : kG2wSlotTYB].c[ee] = (k && !ee) ? fq29_one() : fq29_zero();  // Z = 1, YB = 0
+    g2w_put(sl[p], k ? kG2wSlotTZ : kG2wSlotTYB, ee, (k && !ee) ? fq29_one() : fq29_zero());  // Z = 1, YB = 0
   }
   __syncthreads();
   if (lane < 2) {
-    const Fq2_29P &x = sl[lane][kG2wSlotQX], &y = sl[lane][kG2wSlotQY];
-    ident[lane] = fq29_limbs_all_zero(x.c[0]) && fq29_limbs_all_zero(x.c[1]) && fq29_limbs_all_zero(y.c[0]) && fq29_limbs_all_zero(y.c[1]);
+    ident[lane] = fq29_limbs_all_zero(g2w_get(sl[lane], kG2wSlotQX, 0)) && fq29_limbs_all_zero(g2w_get(sl[lane], kG2wSlotQX, 1)) &&
+                  fq29_limbs_all_zero(g2w_get(sl[lane], kG2wSlotQY, 0)) && fq29_limbs_all_zero(g2w_get(sl[lane], kG2wSlotQY, 1));
     out[lane].is_identity = (uint32_t)ident[lane];
   }
   __syncthreads();
@@ -402,11 +402,20 @@ __global__ void __launch_bounds__(64) k_g2_prepare_w(const uint32_t* __restrict_
     const G2wTask tk = nxt;
     if (worker && lv + 1 < kG2wLevels) nxt = prog[(lv + 1) * kG2wTasks + t];  // fetched under this level's products
     const bool act = worker && tk.used && !ident[pt];
-    if (act) val = g2w_task(sl[pt], tk, e);
+    if (act) {  // (a task's two lanes are neighbours and active together: the swap stays inside the pair)
+      Fq29 am, bm, ap, bp;
+      g2w_mine(sl[pt], tk, e, am, bm);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        ap.v[i] = (int32_t)dpp_u32<0xB1>((uint32_t)am.v[i]);  // quad_perm [1,0,3,2]
+        bp.v[i] = (int32_t)dpp_u32<0xB1>((uint32_t)bm.v[i]);
+      }
+      val = g2w_product(am, bm, ap, bp, e);
+    }
     __syncthreads();  // (one wavefront: no barrier instruction -- the loads of the level are done before its stores)
     if (act) {
       if (tk.dst >= 0) {
-        sl[pt][tk.dst].c[e] = val;
+        g2w_put(sl[pt], tk.dst, e, val);
       } else {  // a line coefficient: canonical residue into the table
         const Fq29 cv = fq29_canon_of_product(val);
         out[pt].line[tk.out / 3].c[2 * (tk.out % 3) + e] = cv;

@@ -36,11 +36,14 @@ __device__ __noinline__ Fq29 fq29_pow_p_plus_1_over_4(const Fq29 a) {  // by val
   return res;
 }
 
+// `offs` == nullptr: encoding i at in + 8 i words.  Otherwise the encodings lie inside records of `stride_words` words
+// (proofs): encoding i = point i % P of record i / P, at word offs[i % P] of it (16-byte aligned).
 __global__ void __launch_bounds__(64) k_g1_decompress(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                       uint8_t* __restrict__ ok, uint32_t n, uint32_t mont) {
+                                                       uint8_t* __restrict__ ok, uint32_t n, uint32_t mont,
+                                                       const uint32_t* __restrict__ offs, uint32_t P, uint32_t stride_words) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint4* src = reinterpret_cast<const uint4*>(in + (size_t)i * 8);
+  const uint4* src = reinterpret_cast<const uint4*>(offs ? in + (size_t)(i / P) * stride_words + offs[i % P] : in + (size_t)i * 8);
   const uint4 a = src[0], b = src[1];
   uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   const uint32_t is_inf = w[7] >> 31, ysign = (w[7] >> 30) & 1u;
@@ -96,7 +99,18 @@ __global__ void __launch_bounds__(64) k_g1_decompress(const uint32_t* __restrict
 
 int launch_g1_decompress(snarkv_ctx* ctx, const void* d_in32, size_t n, void* d_out64, void* d_ok) {
   hipLaunchKernelGGL(k_g1_decompress, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const uint32_t*)d_in32,
-                     (uint32_t*)d_out64, (uint8_t*)d_ok, (uint32_t)n, ctx->mont ? 1u : 0u);
+                     (uint32_t*)d_out64, (uint8_t*)d_ok, (uint32_t)n, ctx->mont ? 1u : 0u, (const uint32_t*)nullptr, 1u, 0u);
+  SNARKV_HIP(hipGetLastError());
+  return SNARKV_OK;
+}
+
+// the P points of each of n_rec records (canonical output whatever the context's flags: these feed a transcript)
+int launch_g1_decompress_records(snarkv_ctx* ctx, const void* d_records, size_t n_rec, size_t stride_words, const void* d_offs_words,
+                                 size_t P, void* d_out64, void* d_ok) {
+  const size_t n = n_rec * P;
+  hipLaunchKernelGGL(k_g1_decompress, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const uint32_t*)d_records,
+                     (uint32_t*)d_out64, (uint8_t*)d_ok, (uint32_t)n, 0u, (const uint32_t*)d_offs_words, (uint32_t)P,
+                     (uint32_t)stride_words);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }

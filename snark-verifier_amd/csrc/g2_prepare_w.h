@@ -14,18 +14,20 @@ namespace snarkv {
 
 #include "g2_prepare_prog.inc"
 
-struct Fq2_29P {  // one LDS slot: an Fq2 value, components carry-normalised
-  Fq29 c[2];
+struct Fq2_29P {  // one LDS slot: an Fq2 value, components carry-normalised (8-byte aligned: 64-bit LDS reads)
+  Fq29P c[2];
 };
+SNARKV_HD Fq29 g2w_get(const Fq2_29P* sl, int slot, int e) { return wt_load(sl[slot].c, e); }
+SNARKV_HD void g2w_put(Fq2_29P* sl, int slot, int e, const Fq29& x) { wt_store(sl[slot].c, e, x); }
 
-// sum_k coeff_k * slot_k (component e), carry-normalised; coefficients in -3 .. 3, values within ~1.5 p: the sum within ~9 p
-SNARKV_HD Fq29 g2w_comb(const Fq2_29P* sl, const int8_t s[3], const int8_t c[3], int e) {
+// sgn * sum_k coeff_k * slot_k (component e), carry-normalised; coefficients in -3 .. 3, values within ~1.5 p: the sum within ~9 p
+SNARKV_HD Fq29 g2w_comb(const Fq2_29P* sl, const int8_t s[3], const int8_t c[3], int e, int32_t sgn) {
   Fq29 r = fq29_zero();
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const int32_t ck = c[k];
+    const int32_t ck = c[k] * sgn;
     if (ck != 0) {
-      const Fq29& v = sl[s[k]].c[e];
+      const Fq29 v = g2w_get(sl, s[k], e);
 #pragma unroll
       for (int i = 0; i < 9; ++i) r.v[i] += ck * v.v[i];
     }
@@ -33,13 +35,32 @@ SNARKV_HD Fq29 g2w_comb(const Fq2_29P* sl, const int8_t s[3], const int8_t c[3],
   return fq29_norm(r);
 }
 
-// component e of the task's product (before the store / the canonical output)
+// A lane (task, e) builds component e of BOTH operands (the conjugate of A folded into its coefficients' sign); its
+// neighbour builds the other component, and the two swap (one DPP move per limb on the device) instead of each building
+// all four.
+SNARKV_HD void g2w_mine(const Fq2_29P* sl, const G2wTask& t, int e, Fq29& am, Fq29& bm) {
+  am = g2w_comb(sl, t.as, t.ac, e, (t.conj && e) ? -1 : 1);
+  bm = g2w_comb(sl, t.bs, t.bc, e, 1);
+}
+// (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u, component e from my (am, bm) and my neighbour's (ap, bp)
+// components: e = 0: am bm + (-ap) bp;  e = 1: ap bm + am bp -- ONE fused two-product step, its operands selected per lane
+// (both forms behind a branch on e cost the wavefront two steps).
+SNARKV_HD Fq29 g2w_product(const Fq29& am, const Fq29& bm, const Fq29& ap, const Fq29& bp, int e) {
+  Fq29 x1, x2;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    x1.v[i] = e ? ap.v[i] : am.v[i];
+    x2.v[i] = e ? am.v[i] : -ap.v[i];
+  }
+  return fq29_mul2(x1, bm, x2, bp);
+}
+
+// component e of the task's product, all on one lane (host emulation; the kernel swaps with the neighbour instead)
 SNARKV_HD Fq29 g2w_task(const Fq2_29P* sl, const G2wTask& t, int e) {
-  Fq29 a0 = g2w_comb(sl, t.as, t.ac, 0), a1 = g2w_comb(sl, t.as, t.ac, 1);
-  if (t.conj) a1 = fq29_neg(a1);
-  const Fq29 b0 = g2w_comb(sl, t.bs, t.bc, 0), b1 = g2w_comb(sl, t.bs, t.bc, 1);
-  // (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u
-  return e ? fq29_mul2(a0, b1, a1, b0) : fq29_mul2(a0, b0, fq29_neg(a1), b1);
+  Fq29 am, bm, ap, bp;
+  g2w_mine(sl, t, e, am, bm);
+  g2w_mine(sl, t, e ^ 1, ap, bp);
+  return g2w_product(am, bm, ap, bp, e);
 }
 
 // the constants of the program as 29-bit Montgomery residues (from the 8 x 32 Montgomery tables of bn254_consts.h)

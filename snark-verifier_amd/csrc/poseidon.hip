@@ -243,6 +243,49 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- proof-shaped transcripts: the absorbed elements assembled on the device ------------------------------------------
+// What a native PoseidonTranscript absorbs while reading a proof (halo2.rs:215-275) is, element by element, one of: a
+// value the caller brought (initial state, instances: LEAD), a scalar of the proof (32 bytes at a fixed offset), or a
+// coordinate of a point of the proof reduced mod r (`fe_to_fe`; p < 2r: one conditional subtraction).  The order is the
+// protocol's, so a batch needs it once (`layout`), and the device can build every transcript's input from the proofs
+// as they are and the points it has just decompressed -- no host pass over the batch before the hashing.
+constexpr uint32_t kPsrcLead = 0u, kPsrcScalar = 1u, kPsrcPx = 2u, kPsrcPy = 3u;  // layout code = kind << 28 | value
+
+__global__ void __launch_bounds__(256)
+    k_poseidon_gather(const uint32_t* __restrict__ proofs, uint32_t stride_words, const uint32_t* __restrict__ lead, uint32_t n_lead,
+                      const uint32_t* __restrict__ layout, uint32_t L, const uint32_t* __restrict__ pts, uint32_t P, uint32_t n,
+                      uint32_t* __restrict__ elems) {
+  const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= n * L) return;
+  const uint32_t i = id / L, k = id % L, code = layout[k], kind = code >> 28, v = code & 0x0FFFFFFFu;
+  const uint32_t* src = kind == kPsrcLead     ? lead + ((size_t)i * n_lead + v) * 8
+                        : kind == kPsrcScalar ? proofs + (size_t)i * stride_words + (v >> 2)
+                                              : pts + ((size_t)i * P + v) * 16 + (kind == kPsrcPy ? 8 : 0);
+  uint32_t w[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) w[j] = src[j];
+  if (kind >= kPsrcPx) {  // a coordinate (< p < 2r) as an element of Fr
+    constexpr uint32_t r[8] = SNARKV_FR_R_LIMBS;
+    uint32_t d[8], borrow = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint64_t x = (uint64_t)w[j] - r[j] - borrow;
+      d[j] = (uint32_t)x;
+      borrow = (uint32_t)(x >> 63);
+    }
+    if (!borrow) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = d[j];
+    }
+  }
+  uint32_t* dst = elems + (size_t)id * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dst[j] = w[j];
+}
+
+int launch_g1_decompress_records(snarkv_ctx* ctx, const void* d_records, size_t n_rec, size_t stride_words, const void* d_offs_words,
+                                 size_t P, void* d_out64, void* d_ok);
+
 }  // namespace snarkv
 
 using namespace snarkv;
@@ -351,6 +394,71 @@ int snarkv_poseidon_transcript_batch(snarkv_ctx* ctx, const snarkv_poseidon* ps,
   SNARKV_TRY(snarkv_poseidon_transcript_batch_dev(ctx, ps, d_e, n, L, d_s, S, d_o));
   SNARKV_HIP(hipMemcpyAsync(out, d_o, n * S * 32, hipMemcpyDeviceToHost, ctx->stream));
   SNARKV_HIP(hipStreamSynchronize(ctx->stream));
+  return SNARKV_OK;
+}
+
+int snarkv_poseidon_read_batch(snarkv_ctx* ctx, const snarkv_poseidon* ps, const uint8_t* proofs, size_t n, size_t stride,
+                               const uint8_t* lead, size_t n_lead, const uint32_t* layout, size_t L,
+                               const uint32_t* point_offsets, size_t P, const uint32_t* seg_len, size_t S, uint8_t* challenges,
+                               uint8_t* points64, uint8_t* ok) {
+  if (!ctx || !ps || !proofs || !layout || !seg_len || !challenges || (n_lead && !lead) || (P && (!point_offsets || !points64 || !ok)))
+    return SNARKV_ERR_ARG;
+  if (n == 0 || S == 0 || L == 0) return SNARKV_ERR_EMPTY;
+  if (n >= ((size_t)1 << 24) || L >= ((size_t)1 << 16) || stride >= ((size_t)1 << 28) || (stride & 15) || P >= ((size_t)1 << 16))
+    return SNARKV_ERR_LENGTH;
+  size_t sum = 0;
+  for (size_t q = 0; q < S; ++q) sum += seg_len[q];
+  if (sum != L) return SNARKV_ERR_LENGTH;
+  std::vector<uint32_t> head(L + P + S);  // layout | point offsets in words | segment lengths: one small upload
+  for (size_t k = 0; k < L; ++k) {
+    const uint32_t kind = layout[k] >> 28, v = layout[k] & 0x0FFFFFFFu;
+    if (kind > kPsrcPy) return SNARKV_ERR_ARG;
+    if (kind == kPsrcLead && v >= n_lead) return SNARKV_ERR_ARG;
+    if (kind == kPsrcScalar && ((v & 3) || (size_t)v + 32 > stride)) return SNARKV_ERR_ARG;
+    if (kind >= kPsrcPx && v >= P) return SNARKV_ERR_ARG;
+    head[k] = layout[k];
+  }
+  for (size_t q = 0; q < P; ++q) {
+    if ((point_offsets[q] & 15) || (size_t)point_offsets[q] + 32 > stride) return SNARKV_ERR_ARG;
+    head[L + q] = point_offsets[q] >> 2;
+  }
+  for (size_t q = 0; q < S; ++q) head[L + P + q] = seg_len[q];
+  SNARKV_HIP(hipSetDevice(ctx->device));
+  void *d_proofs = nullptr, *d_lead = nullptr, *d_head = nullptr, *d_pts = nullptr, *d_elems = nullptr, *d_out = nullptr;
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_IN_POINTS, n * stride, &d_proofs));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_POINTS_MONT, std::max<size_t>(32, n * n_lead * 32), &d_lead));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_IN_OFFSETS, head.size() * 4, &d_head));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_PARTIALS, std::max<size_t>(80, n * P * 65), &d_pts));  // points, then a flag each
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_IN_SCALARS, n * L * 32, &d_elems));
+  SNARKV_TRY(ctx_reserve(ctx, SLOT_OUT, n * S * 32, &d_out));
+  SNARKV_HIP(hipMemcpyAsync(d_proofs, proofs, n * stride, hipMemcpyHostToDevice, ctx->stream));
+  if (n_lead) SNARKV_HIP(hipMemcpyAsync(d_lead, lead, n * n_lead * 32, hipMemcpyHostToDevice, ctx->stream));
+  SNARKV_HIP(hipMemcpyAsync(d_head, head.data(), head.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  const uint32_t* dh = (const uint32_t*)d_head;
+  uint8_t* d_ok = (uint8_t*)d_pts + n * P * 64;
+  if (P) SNARKV_TRY(launch_g1_decompress_records(ctx, d_proofs, n, stride / 4, dh + L, P, d_pts, d_ok));
+  hipLaunchKernelGGL(k_poseidon_gather, dim3((uint32_t)((n * L + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_proofs,
+                     (uint32_t)(stride / 4), (const uint32_t*)d_lead, (uint32_t)n_lead, dh, (uint32_t)L, (const uint32_t*)d_pts,
+                     (uint32_t)P, (uint32_t)n, (uint32_t*)d_elems);
+  SNARKV_HIP(hipGetLastError());
+  if (P) {  // the points go home under the hashing (the context's copy stream, ordered behind the gather by an event)
+    if (!ctx->copy_ready) {
+      SNARKV_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+      ctx->copy_ready = true;
+    }
+    if (!ctx->sorted_ev_ready) {
+      SNARKV_HIP(hipEventCreateWithFlags(&ctx->sorted_ev, hipEventDisableTiming));
+      ctx->sorted_ev_ready = true;
+    }
+    SNARKV_HIP(hipEventRecord(ctx->sorted_ev, ctx->stream));
+    SNARKV_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->sorted_ev, 0));
+    SNARKV_HIP(hipMemcpyAsync(points64, d_pts, n * P * 64, hipMemcpyDeviceToHost, ctx->copy_stream));
+    SNARKV_HIP(hipMemcpyAsync(ok, d_ok, n * P, hipMemcpyDeviceToHost, ctx->copy_stream));
+  }
+  SNARKV_TRY(snarkv_poseidon_transcript_batch_dev(ctx, ps, d_elems, n, L, dh + L + P, S, d_out));
+  SNARKV_HIP(hipMemcpyAsync(challenges, d_out, n * S * 32, hipMemcpyDeviceToHost, ctx->stream));
+  SNARKV_HIP(hipStreamSynchronize(ctx->stream));
+  if (P) SNARKV_HIP(hipStreamSynchronize(ctx->copy_stream));
   return SNARKV_OK;
 }
 

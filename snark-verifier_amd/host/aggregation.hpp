@@ -7,6 +7,7 @@
 // of all proofs runs on `threads` host threads, ALL their MSMs go out as one
 // segmented launch, the accumulation step is a second launch, the pairing a third.
 #pragma once
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -69,45 +70,145 @@ struct Aggregator {
     };
     double t_pass1 = 0, t_pack = 0, t_dev = 0;
     std::vector<Error> errs(n);
+    // The usual batch -- proofs of one length, instances absorbed as scalars -- is ONE device pipeline on the proof bytes
+    // as they are (`snarkv_poseidon_read_batch`: decompress every point, assemble every transcript's input, hash), between
+    // a parse of proof 0 for the layout and the parse of every proof with its challenges.  Anything else takes the
+    // three-pass route below.
+    if (n >= 2 && !pr.instance_committing_key) {
+      bool fused = true;
+      const size_t len0 = proofs[0].size(), stride = (len0 + 15) & ~(size_t)15;
+      for (size_t i = 1; i < n && fused; ++i) fused = proofs[i].size() == len0;
+      PoseidonTranscriptT<RecordingSponge> t0(proofs[0], T, RATE, R_F, R_P);
+      t0.record_layout();
+      fused = fused && len0 > 0 && SV::read_proof(svk, pr, instances[0], t0).ok();
+      std::vector<uint32_t> offs;
+      size_t n_lead = 0;
+      if (fused) {
+        // the lead elements are the initial state (if any) and the instances, in order: the same construction for every proof
+        auto lead_of = [&](size_t i, std::vector<Fr>& out) {
+          out.clear();
+          if (pr.transcript_initial_state) out.push_back(*pr.transcript_initial_state);
+          for (auto& col : instances[i])
+            for (auto& x : col) out.push_back(x);
+        };
+        std::vector<Fr> l0;
+        lead_of(0, l0);
+        n_lead = l0.size();
+        fused = l0.size() == t0.lead_values().size();
+        for (size_t k = 0; k < n_lead && fused; ++k) fused = l0[k] == t0.lead_values()[k];
+        for (size_t i = 1; i < n && fused; ++i) {
+          size_t c = pr.transcript_initial_state ? 1 : 0;
+          for (auto& col : instances[i]) c += col.size();
+          fused = c == n_lead;
+        }
+        for (size_t o : t0.point_offsets()) {
+          fused = fused && (o & 15) == 0;
+          offs.push_back((uint32_t)o);
+        }
+        for (uint32_t code : t0.layout())
+          if ((code >> 28) == PoseidonTranscriptT<RecordingSponge>::kSrcScalar) fused = fused && ((code & 3) == 0);
+        if (fused) {
+          const std::vector<uint32_t>& layout = t0.layout();
+          const std::vector<uint32_t>& seg = t0.sponge().seg_len;
+          const size_t L = layout.size(), S = seg.size(), P = offs.size();
+          std::vector<uint8_t> chal(32 * S * n), pts(64 * P * n + 64), okv(P * n + 1);
+          double t_fill = 0;
+          const snarkv_poseidon* ps = device_poseidon(T, RATE, R_F, R_P);  // (takes the device lock itself on first use)
+          {
+            std::lock_guard<std::mutex> dev(device_mutex());  // (also guards the default context's pinned buffers)
+            uint8_t *hp = nullptr, *hl = nullptr;
+            if (bn254_host_buffer(0, stride * n, (void**)&hp) != SNARKV_OK || bn254_host_buffer(1, std::max<size_t>(32, 32 * n_lead * n), (void**)&hl) != SNARKV_OK)
+              throw std::runtime_error(std::string("bn254_host_buffer: ") + snarkv_last_error());
+            parallel_for(n, threads, [&](size_t i) {
+              memcpy(hp + stride * i, proofs[i].data(), len0);
+              if (stride != len0) memset(hp + stride * i + len0, 0, stride - len0);
+              uint8_t* dst = hl + 32 * n_lead * i;
+              if (pr.transcript_initial_state) pr.transcript_initial_state->to_bytes(dst), dst += 32;
+              for (auto& col : instances[i])
+                for (auto& x : col) x.to_bytes(dst), dst += 32;
+            }, 64);
+            t_fill = lap();
+            if (bn254_poseidon_read_batch(ps, hp, n, stride, hl, n_lead, layout.data(), L, offs.data(), P, seg.data(), S, chal.data(),
+                                          pts.data(), okv.data()) != SNARKV_OK)
+              throw std::runtime_error(std::string("bn254_poseidon_read_batch: ") + snarkv_last_error());
+          }
+          t_dev = lap();
+          // parse every proof with its challenges; a point is taken from the device only if it IS the decoding of the proof's
+          // bytes, and scalars are range-checked here: a proof the device hashed blindly (invalid point, scalar >= r) fails
+          // in this pass exactly as it does on the host-hashed route
+          parallel_for(n, threads, [&](size_t i) {
+            PoseidonTranscriptT<ReplaySponge> t(proofs[i], T, RATE, R_F, R_P);
+            t.set_point_hints(&pts[64 * P * i], &okv[P * i], P);
+            t.sponge().challenges.resize(S);
+            for (size_t q = 0; q < S; ++q) Fr::from_bytes(&chal[32 * (i * S + q)], &t.sponge().challenges[q]);
+            auto pf = SV::read_proof(svk, pr, instances[i], t);
+            if (!pf.ok()) {
+              errs[i] = pf.err;
+              return;
+            }
+            pfs[i] = std::move(*pf.value);
+          }, 4);
+          if (trace)
+            fprintf(stderr, "read_proofs_device_hashed (fused): %zu proofs x %zu elements (%zu lead), %zu points, %zu squeezes: fill %.3f device %.3f parse %.3f ms\n",
+                    n, L, n_lead, P, S, t_fill, t_dev, lap());
+          for (auto& e : errs)
+            if (!e.ok()) return e;
+          return Error{};
+        }
+      }
+      lap();
+    }
     std::vector<std::vector<Fr>> elems(n);
     std::vector<std::vector<uint32_t>> segs(n);
     std::vector<std::vector<G1Affine>> decoded(n);
     // pass 0: every compressed point of the batch decompressed in ONE device launch (a square root each: ~13 per
     // proof, 0.15 ms of host time per proof otherwise).  Where the points sit in a proof is fixed by the protocol:
     // proof 0 is parsed once on the host for the layout, proofs of another length keep the host path.
-    std::vector<std::vector<G1Affine>> hints(n);
+    std::vector<uint8_t> hint_pts, hint_ok;  // the device's decodings, 64 bytes + a flag per point, proof-major
+    std::vector<size_t> hint_row(n, (size_t)-1);
+    size_t P = 0;
     double t_pass0 = 0;
     if (n >= 2) {
       PoseidonTranscriptT<RecordingSponge> t0(proofs[0], T, RATE, R_F, R_P);
       if (SV::read_proof(svk, pr, instances[0], t0).ok()) {
         const std::vector<size_t> offs = t0.point_offsets();
-        const size_t P = offs.size(), len0 = proofs[0].size();
+        const size_t len0 = proofs[0].size();
+        P = offs.size();
         std::vector<size_t> who;
         for (size_t i = 0; i < n; ++i)
-          if (proofs[i].size() == len0) who.push_back(i);
+          if (proofs[i].size() == len0) hint_row[i] = who.size(), who.push_back(i);
         if (P && !who.empty()) {
-          std::vector<uint8_t> in(32 * P * who.size()), out(64 * P * who.size()), okv(P * who.size());
-          for (size_t k = 0; k < who.size(); ++k)
+          std::vector<uint8_t> in(32 * P * who.size());
+          hint_pts.resize(64 * P * who.size());
+          hint_ok.resize(P * who.size());
+          parallel_for(who.size(), threads, [&](size_t k) {
             for (size_t q = 0; q < P; ++q) memcpy(&in[32 * (k * P + q)], proofs[who[k]].data() + offs[q], 32);
-          {
-            std::lock_guard<std::mutex> dev(device_mutex());
-            if (bn254_g1_decompress(in.data(), P * who.size(), out.data(), okv.data()) != SNARKV_OK)
-              throw std::runtime_error(std::string("bn254_g1_decompress: ") + snarkv_last_error());
-          }
-          for (size_t k = 0; k < who.size(); ++k) {
-            auto& h = hints[who[k]];
-            h.resize(P);  // (0, 0) = no hint: an invalid encoding is re-examined (and rejected) by the host function
-            for (size_t q = 0; q < P; ++q)
-              if (okv[k * P + q]) h[q] = G1Affine::from_bytes(&out[64 * (k * P + q)]);
-          }
+          }, 64);
+          std::lock_guard<std::mutex> dev(device_mutex());
+          if (bn254_g1_decompress(in.data(), P * who.size(), hint_pts.data(), hint_ok.data()) != SNARKV_OK)
+            throw std::runtime_error(std::string("bn254_g1_decompress: ") + snarkv_last_error());
         }
       }
       t_pass0 = lap();
     }
     // pass 1: parse (points not covered by pass 0 are decompressed here) and record what the sponge would see
+    std::atomic<uint64_t> ns_pass1{0}, ns_pass1_max{0};
     parallel_for(n, threads, [&](size_t i) {
+      auto tt0 = clk::now();
+      struct Tick {
+        clk::time_point t0; std::atomic<uint64_t>&sum, &mx;
+        ~Tick() {
+          if (!trace) return;
+          uint64_t d = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count();
+          sum += d;
+          uint64_t m = mx.load();
+          while (d > m && !mx.compare_exchange_weak(m, d)) {}
+        }
+      } tick{tt0, ns_pass1, ns_pass1_max};
       PoseidonTranscriptT<RecordingSponge> t(proofs[i], T, RATE, R_F, R_P);
-      t.set_point_hints(std::move(hints[i]));
+      // (a flag of 0 = no hint: an invalid encoding is re-examined, and rejected, by the host function)
+      if (hint_row[i] != (size_t)-1 && !hint_ok.empty())
+        t.set_point_hints(&hint_pts[64 * P * hint_row[i]], &hint_ok[P * hint_row[i]], P);
       auto pf = SV::read_proof(svk, pr, instances[i], t);
       if (!pf.ok()) {
         errs[i] = pf.err;
@@ -138,7 +239,7 @@ struct Aggregator {
     // pass 2: parse again with the real challenges
     parallel_for(n, threads, [&](size_t i) {
       PoseidonTranscriptT<ReplaySponge> t(proofs[i], T, RATE, R_F, R_P);
-      t.set_decoded_points(std::move(decoded[i]));
+      t.set_decoded_points(decoded[i].data(), decoded[i].size());
       t.sponge().challenges.resize(S);
       for (size_t q = 0; q < S; ++q) Fr::from_bytes(&out[32 * (i * S + q)], &t.sponge().challenges[q]);
       auto pf = SV::read_proof(svk, pr, instances[i], t);
@@ -149,8 +250,8 @@ struct Aggregator {
       pfs[i] = std::move(*pf.value);
     }, 4);
     if (trace)
-      fprintf(stderr, "read_proofs_device_hashed: %zu proofs x %zu elements, %zu squeezes: pass0 %.3f pass1 %.3f pack %.3f device %.3f pass2 %.3f ms\n",
-              n, L, S, t_pass0, t_pass1, t_pack, t_dev, lap());
+      fprintf(stderr, "read_proofs_device_hashed: %zu proofs x %zu elements, %zu squeezes: pass0 %.3f pass1 %.3f (per proof %.1f us, max %.1f) pack %.3f device %.3f pass2 %.3f ms\n",
+              n, L, S, t_pass0, t_pass1, ns_pass1.load() / 1e3 / n, ns_pass1_max.load() / 1e3, t_pack, t_dev, lap());
     for (auto& e : errs)
       if (!e.ok()) return e;
     return Error{};

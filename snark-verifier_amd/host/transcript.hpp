@@ -756,7 +756,10 @@ struct RecordingSponge {
   std::vector<Fr> elems;          // every absorbed element, in order
   std::vector<uint32_t> seg_len;  // elements absorbed before each squeeze
   uint32_t cur = 0;
-  RecordingSponge(int, int, int, int) {}
+  RecordingSponge(int, int, int, int) {
+    elems.reserve(64);
+    seg_len.reserve(8);
+  }
   void update(const std::vector<Fr>& e) {
     elems.insert(elems.end(), e.begin(), e.end());
     cur += (uint32_t)e.size();
@@ -788,6 +791,15 @@ class PoseidonTranscriptT : public Transcript {
 
   Fr squeeze_challenge() override { return buf_.squeeze(); }  // halo2.rs:211-213
   Error common_scalar(const Fr& s) override {                 // halo2.rs:215-218
+    if (record_layout_) {
+      if (pending_src_ != kNoSrc) {
+        layout_.push_back(pending_src_);
+      } else {
+        layout_.push_back((kSrcLead << 28) | (uint32_t)lead_.size());
+        lead_.push_back(s);
+      }
+      pending_src_ = kNoSrc;
+    }
     buf_.update({s});
     return Error{};
   }
@@ -799,6 +811,18 @@ class PoseidonTranscriptT : public Transcript {
     Fr x = grain::fr_from_words_mod_r(w);  // p < 2r: one conditional subtraction
     memcpy(w, p.b + 32, 32);
     Fr y = grain::fr_from_words_mod_r(w);
+    if (record_layout_) {
+      if (pending_src_ != kNoSrc) {  // point number q of the proof: its x, then its y
+        layout_.push_back((kSrcPx << 28) | pending_src_);
+        layout_.push_back((kSrcPy << 28) | pending_src_);
+      } else {
+        layout_.push_back((kSrcLead << 28) | (uint32_t)lead_.size());
+        layout_.push_back((kSrcLead << 28) | (uint32_t)(lead_.size() + 1));
+        lead_.push_back(x);
+        lead_.push_back(y);
+      }
+      pending_src_ = kNoSrc;
+    }
     buf_.update({x, y});
     return Error{};
   }
@@ -808,6 +832,7 @@ class PoseidonTranscriptT : public Transcript {
     bool ok = Fr::from_bytes(stream_.data() + pos_, &s);
     pos_ += 32;
     if (!ok) return Result<Fr>::Err(Error{Error::Transcript, "Invalid scalar encoding in proof"});
+    if (record_layout_) pending_src_ = (kSrcScalar << 28) | (uint32_t)(pos_ - 32);
     common_scalar(s);
     return Result<Fr>::Ok(s);
   }
@@ -819,17 +844,19 @@ class PoseidonTranscriptT : public Transcript {
     const uint8_t* enc = stream_.data() + pos_;
     const size_t read_index = point_offsets_.size();
     point_offsets_.push_back(pos_);
-    if (next_decoded_ < decoded_in_.size()) {
+    if (next_decoded_ < n_decoded_in_) {
       p = decoded_in_[next_decoded_++];  // second parsing pass: the square root was taken in the first
-    } else if (read_index < hints_.size() && hint_matches(hints_[read_index], enc)) {
-      p = hints_[read_index];  // decompressed by the device for the whole batch (snarkv_g1_decompress)
+    } else if (read_index < n_hints_ && hint_ok_[read_index] && hint_matches(hint_pts_ + 64 * read_index, enc)) {
+      memcpy(p.b, hint_pts_ + 64 * read_index, 64);  // decompressed by the device for the whole batch (snarkv_g1_decompress)
     } else {
       ok = g1_decompress(enc, &p);
     }
     pos_ += 32;
     if (!ok) return Result<G1Affine>::Err(Error{Error::Transcript, "Invalid elliptic curve point encoding in proof"});
     decoded_.push_back(p);
+    if (record_layout_) pending_src_ = (uint32_t)read_index;
     Error e = common_ec_point(p);  // the identity decodes but has no coordinates to absorb
+    pending_src_ = kNoSrc;
     if (!e.ok()) return Result<G1Affine>::Err(e);
     return Result<G1Affine>::Ok(p);
   }
@@ -856,29 +883,44 @@ class PoseidonTranscriptT : public Transcript {
   std::vector<uint8_t> stream_;
   size_t pos_ = 0;
   Sponge buf_;
-  std::vector<G1Affine> decoded_, decoded_in_;  // points decompressed by this pass / handed over by an earlier one
-  size_t next_decoded_ = 0;
+  std::vector<G1Affine> decoded_;               // points decompressed by this pass ...
+  const G1Affine* decoded_in_ = nullptr;        // ... / handed over by an earlier one (borrowed: the caller keeps them alive)
+  size_t n_decoded_in_ = 0, next_decoded_ = 0;
   std::vector<size_t> point_offsets_;           // stream position of every point read so far
-  std::vector<G1Affine> hints_;                 // candidate decodings by read index; (0, 0) = none
+  const uint8_t* hint_pts_ = nullptr;           // candidate decodings by read index (64 bytes each) and their validity
+  const uint8_t* hint_ok_ = nullptr;            // flags: borrowed views of the device's answer for the whole batch --
+  size_t n_hints_ = 0;                          // no per-proof copies, nothing for a pool worker to free
+  bool record_layout_ = false;
+  uint32_t pending_src_ = 0xFFFFFFFFu;          // the source of the element(s) the next common_* call absorbs
+  std::vector<uint32_t> layout_;
+  std::vector<Fr> lead_;
   // A hint is used only if it IS the decoding of these 32 bytes: a finite point whose x equals the encoded x and whose
   // y has the encoded parity (on the curve by construction: the device checks y^2 = x^3 + 3 before answering).
   // Identities, invalid encodings and anything that does not match go through g1_decompress as before.
-  static bool hint_matches(const G1Affine& h, const uint8_t enc[32]) {
+  static bool hint_matches(const uint8_t h[64], const uint8_t enc[32]) {
     if (enc[31] >> 7) return false;
-    if (h.is_identity()) return false;
-    return memcmp(enc, h.b, 31) == 0 && (enc[31] & 0x3F) == h.b[31] && ((enc[31] >> 6) & 1) == (h.b[32] & 1);
+    bool zero = true;
+    for (int i = 0; i < 64 && zero; ++i) zero = h[i] == 0;
+    if (zero) return false;
+    return memcmp(enc, h, 31) == 0 && (enc[31] & 0x3F) == h[31] && ((enc[31] >> 6) & 1) == (h[32] & 1);
   }
 
  public:
   std::vector<G1Affine>& decoded_points() { return decoded_; }
-  void set_decoded_points(std::vector<G1Affine> pts) {
-    decoded_in_ = std::move(pts);
-    next_decoded_ = 0;
+  void set_decoded_points(const G1Affine* pts, size_t n) {
+    decoded_in_ = pts, n_decoded_in_ = n, next_decoded_ = 0;
   }
   // where this pass read its points (the layout is the protocol's: the same for every proof of it)
   const std::vector<size_t>& point_offsets() const { return point_offsets_; }
+  // Where every absorbed element came from, in the codes of `snarkv_poseidon_read_batch` (include/snarkv_amd.h):
+  // kind << 28 | value, kind 0 = a value the caller brought (`lead_values()[value]`: initial state, instances),
+  // 1 = the proof's scalar at byte `value`, 2 / 3 = x / y of the proof's point number `value`.
+  static constexpr uint32_t kSrcLead = 0, kSrcScalar = 1, kSrcPx = 2, kSrcPy = 3, kNoSrc = 0xFFFFFFFFu;
+  void record_layout() { record_layout_ = true; }
+  const std::vector<uint32_t>& layout() const { return layout_; }
+  const std::vector<Fr>& lead_values() const { return lead_; }
   // decodings computed elsewhere for the k-th point read, checked against the bytes before use
-  void set_point_hints(std::vector<G1Affine> pts) { hints_ = std::move(pts); }
+  void set_point_hints(const uint8_t* pts64, const uint8_t* ok, size_t n) { hint_pts_ = pts64, hint_ok_ = ok, n_hints_ = n; }
 };
 using PoseidonTranscript = PoseidonTranscriptT<Poseidon>;
 

@@ -372,19 +372,19 @@ int ht_g2_prepare_w(const uint8_t* q, int negate_y) {
     return -1;
   }
   std::vector<Fq2_29P> sl(kG2wSlots);
-  for (auto& x : sl) x.c[0] = x.c[1] = fq29_zero();
+  for (int k = 0; k < kG2wSlots; ++k) g2w_put(sl.data(), k, 0, fq29_zero()), g2w_put(sl.data(), k, 1, fq29_zero());
   auto put = [&](int slot, const Fq2& v) {
     const Fq* c[2] = {&v.c0, &v.c1};
     for (int e = 0; e < 2; ++e) {
       uint32_t w[8];
       fq_to_canonical(*c[e], w);
-      sl[slot].c[e] = fq29_canon_residue(fq29_from_canonical(w));
+      g2w_put(sl.data(), slot, e, fq29_canon_residue(fq29_from_canonical(w)));
     }
   };
   put(kG2wSlotQX, qa.x), put(kG2wSlotQY, qa.y), put(kG2wSlotTX, qa.x), put(kG2wSlotTYA, qa.y);
   for (int k = 0; k < 6; ++k)
-    for (int e = 0; e < 2; ++e) sl[k].c[e] = g2w_const(k, e);
-  sl[kG2wSlotTZ].c[0] = fq29_one();
+    for (int e = 0; e < 2; ++e) g2w_put(sl.data(), k, e, g2w_const(k, e));
+  g2w_put(sl.data(), kG2wSlotTZ, 0, fq29_one());
   std::vector<Fq29> lines(kLinesPerG2 * 6, fq29_zero());
   for (int lv = 0; lv < kG2wLevels; ++lv) {
     Fq29 val[kG2wTasks][2];
@@ -395,7 +395,7 @@ int ht_g2_prepare_w(const uint8_t* q, int negate_y) {
       const G2wTask& tk = kG2wProg[lv][t];
       if (!tk.used) continue;
       for (int e = 0; e < 2; ++e) {
-        if (tk.dst >= 0) sl[tk.dst].c[e] = val[t][e];
+        if (tk.dst >= 0) g2w_put(sl.data(), tk.dst, e, val[t][e]);
         else lines[(tk.out / 3) * 6 + 2 * (tk.out % 3) + e] = fq29_canon_of_product(val[t][e]);
       }
     }

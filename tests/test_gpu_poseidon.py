@@ -125,3 +125,83 @@ def test_g1_decompress_batch_vs_oracle(gpu_ctx):
     for i, w in enumerate(want):
         assert got[64 * i:64 * i + 64] == w, i
     assert gpu_ctx.g1_decompress(b"") == (b"", [])
+
+
+def test_read_batch_assembles_decompresses_and_hashes_like_the_pieces(gpu_ctx):
+    """`snarkv_poseidon_read_batch`: the transcript input of proof-shaped byte records built ON THE DEVICE (lead elements,
+    scalars at offsets, point coordinates mod r from the device's own decompression) == the oracle's sponge over the
+    elements a native PoseidonTranscript absorbs (halo2.rs:215-275), incl. a coordinate >= r (one subtraction), an
+    invalid point (flag 0; that record's challenges are meaningless and unchecked) and a lead-only segment."""
+    import coracle as C
+
+    spec = _spec(gpu_ctx, 5, 4, 8, 60)
+    rng = random.Random(77)
+    n, n_lead, stride = 37, 3, 7 * 32 + 16  # a record: scalar, point, point, scalar, scalar, point, scalar (+ 16 bytes of padding)
+    kinds = "spPssps".replace("P", "p")
+    pts_off = [32 * k for k, c in enumerate(kinds) if c == "p"]
+    sc_off = [32 * k for k, c in enumerate(kinds) if c == "s"]
+    # absorbed order: lead 0, lead 1 | point 0 (x, y), scalar 0 | lead 2, point 1, scalar 1, scalar 2, point 2, scalar 3 | (nothing)
+    layout = [(0 << 28) | 0, (0 << 28) | 1, (2 << 28) | 0, (3 << 28) | 0, (1 << 28) | sc_off[0], (0 << 28) | 2, (2 << 28) | 1, (3 << 28) | 1,
+              (1 << 28) | sc_off[1], (1 << 28) | sc_off[2], (2 << 28) | 2, (3 << 28) | 2, (1 << 28) | sc_off[3]]
+    seg = [2, 3, 8, 0]
+    raw = C.sample_points(0x99, 3 * n)
+    # a point whose x is >= r (p > r: such x exist) so that the reduction is exercised
+    big = None
+    x = O.R
+    while big is None:
+        y2 = (x * x * x + 3) % O.P
+        y = pow(y2, (O.P + 1) // 4, O.P)
+        if y * y % O.P == y2:
+            big = (x, y)
+        x += 1
+    recs, leads, exp_elems, exp_pts, exp_ok = [], [], [], [], []
+    for i in range(n):
+        P3 = []
+        for q in range(3):
+            o = 64 * (3 * i + q)
+            P3.append((int.from_bytes(raw[o:o + 32], "little"), int.from_bytes(raw[o + 32:o + 64], "little")))
+        if i == 5:
+            P3[1] = big
+        sc = [rng.choice([0, 1, O.R - 1, rng.randrange(O.R)]) for _ in range(4)]
+        ld = [rng.randrange(O.R) for _ in range(n_lead)]
+        enc = [T.g1_compress(p) for p in P3]
+        okf = [1, 1, 1]
+        if i == 9:  # an x with no point on the curve
+            xb = 0
+            while pow((xb ** 3 + 3) % O.P, (O.P - 1) // 2, O.P) == 1:
+                xb += 1
+            enc[2] = xb.to_bytes(32, "little")
+            okf[2] = 0
+        rec = bytearray(stride)
+        it_p, it_s = iter(enc), iter(sc)
+        for k, c in enumerate(kinds):
+            rec[32 * k:32 * k + 32] = next(it_p) if c == "p" else next(it_s).to_bytes(32, "little")
+        recs.append(bytes(rec))
+        leads.append(b"".join(v.to_bytes(32, "little") for v in ld))
+        exp_elems.append([ld[0], ld[1], P3[0][0] % O.R, P3[0][1] % O.R, sc[0], ld[2], P3[1][0] % O.R, P3[1][1] % O.R, sc[1], sc[2],
+                          P3[2][0] % O.R, P3[2][1] % O.R, sc[3]])
+        exp_pts.append(P3)
+        exp_ok.append(okf)
+    ch, pts, ok = gpu_ctx.poseidon_read_batch(spec, b"".join(recs), n, stride, b"".join(leads), n_lead, layout, pts_off, seg)
+    assert list(ok) == [f for row in exp_ok for f in row]
+    for i in range(n):
+        for q in range(3):
+            o = 64 * (3 * i + q)
+            if exp_ok[i][q]:
+                assert pts[o:o + 64] == exp_pts[i][q][0].to_bytes(32, "little") + exp_pts[i][q][1].to_bytes(32, "little"), (i, q)
+            else:
+                assert pts[o:o + 64] == bytes(64)
+        if all(exp_ok[i]):
+            exp = T.poseidon_transcript_challenges(exp_elems[i], seg)
+            for q, e in enumerate(exp):
+                o = 32 * (i * len(seg) + q)
+                assert int.from_bytes(ch[o:o + 32], "little") == e, (i, q)
+    # the argument checks
+    import snark_verifier_amd as sv
+
+    for bad in ([(1 << 28) | 2] + layout[1:], [(2 << 28) | 3] + layout[1:], [(0 << 28) | 3] + layout[1:]):
+        with pytest.raises(sv.SnarkvError):  # a scalar offset not a multiple of 4, a point / lead index out of range
+            gpu_ctx.poseidon_read_batch(spec, b"".join(recs), n, stride, b"".join(leads), n_lead, bad, pts_off, seg)
+    with pytest.raises(sv.SnarkvError):  # a point offset not a multiple of 16
+        gpu_ctx.poseidon_read_batch(spec, b"".join(recs), n, stride, b"".join(leads), n_lead, layout, [pts_off[0] + 4] + pts_off[1:], seg)
+    spec.close()
