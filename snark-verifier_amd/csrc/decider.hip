@@ -209,7 +209,7 @@ static __device__ __noinline__ void coop_scale(int dst, int a) {
 // dst = a^-1 through the norms Fq12 -> Fq6 -> Fq2 -> Fq:
 //   N = a conj(a) in Fq6;  adj = N^(p^2) N^(p^4);  d = N adj in Fq2;
 //   a^-1 = conj(a) adj / d.      (uses RT0, RT1, RY0 as scratch; one Fq inversion chain on lane 0)
-static __device__ __noinline__ void coop_inv(int dst, int a) {
+static __device__ __forceinline__ void coop_inv(int dst, int a) {
   coop_conj(RT0, a);                 // RT0 = conj(a)
   coop_mulr(RT1, a, RT0);         // RT1 = N
   coop_frob(RY0, RT1, 2);            // N^(p^2)
@@ -228,7 +228,7 @@ static __device__ __noinline__ void coop_inv(int dst, int a) {
   coop_scale(dst, dst);              // / d
 }
 
-static __device__ __noinline__ void coop_exp_by_x(int dst, int a) {
+static __device__ __forceinline__ void coop_exp_by_x(int dst, int a) {
   // dst != a
   if (threadIdx.x < 12) g_sh.r[dst].v[threadIdx.x] = g_sh.r[a].v[threadIdx.x];
   __syncthreads();

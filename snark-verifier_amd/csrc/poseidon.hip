@@ -187,15 +187,16 @@ __global__ void __launch_bounds__(256)
       // Lanes run in lockstep, so the three products of lane 0's x^5 are issued by every lane anyway:
       // the first one doubles as  row[j] * s_j  in lanes 1.. (operands picked per lane).
       const bool w0 = j == 0;
-      const Fr29 rowj = (uint32_t)j < t ? tab[sh.o_rows + r * t + (uint32_t)j] : fr29_zero();
+      // (lanes >= t read row[0] / compute products nobody uses: one table read by index, no per-lane struct selection)
+      const Fr29 rowj = tab[sh.o_rows + r * t + ((uint32_t)j < t ? (uint32_t)j : 0u)];
       Fr29 p1 = fr29_mul(w0 ? s : rowj, s);  // lane 0: x^2      lanes 1..: row[j] * s_j
       Fr29 x4 = fr29_mul(p1, p1);            // lane 0: x^4
       Fr29 x5 = fr29_mul(x4, s);             // lane 0: x^5
       Fr29 s0 = fr29_norm(fr29_add(x5, tab[sh.o_partial + r]));
       s0 = shfl8(s0, 0);
       // second shared product: lane 0: row[0] * s0      lanes 1..: col_hat[j-1] * s0
-      const Fr29 cj = (j >= 1 && (uint32_t)j < t) ? tab[sh.o_cols + r * (t - 1) + (uint32_t)j - 1] : rowj;
-      Fr29 p2 = fr29_mul(cj, s0);  // lane 0: rowj = row[0]
+      const Fr29 cj = tab[(j >= 1 && (uint32_t)j < t) ? sh.o_cols + r * (t - 1) + (uint32_t)j - 1 : sh.o_rows + r * t];
+      Fr29 p2 = fr29_mul(cj, s0);  // lane 0: row[0]
       // word 0: row . state  (butterfly over the 8 lanes; lanes >= t contribute zero)
       Fr29 sum = w0 ? p2 : p1;
       if ((uint32_t)j >= t) sum = fr29_zero();

@@ -342,6 +342,82 @@ int hd_transcript_script(int kind, const uint8_t* script, size_t script_len, con
   });
 }
 
+// The provenance record of a Poseidon transcript (transcript.hpp `record_layout`: what `snarkv_poseidon_read_batch` is told
+// about a batch of proofs).  Runs ops 1-5 of the script above on a recording transcript, then rebuilds every absorbed
+// element from its layout code -- lead value / the proof's scalar at that byte / coordinate of that point mod r -- and
+// compares with what the sponge was actually given.  out: n_elems (u32) || layout codes (u32 each) || n_points (u32) ||
+// point offsets (u32 each) || n_segments (u32) || segment lengths.  Returns 0, 1000 + op index for a transcript error,
+// 2000 + k if element k does not rebuild.
+int hd_poseidon_layout_script(const uint8_t* script, size_t script_len, const uint8_t* proof, size_t proof_len, uint8_t* out,
+                              size_t out_cap, size_t* out_len) {
+  return guarded([&] {
+    using TR = PoseidonTranscriptT<RecordingSponge>;
+    TR t(std::vector<uint8_t>(proof, proof + proof_len));
+    t.record_layout();
+    size_t i = 0;
+    int opi = 0;
+    while (i < script_len) {
+      uint8_t op = script[i++];
+      Error e;
+      switch (op) {
+        case 1: t.squeeze_challenge(); break;
+        case 2: {
+          Fr x;
+          if (!Fr::from_bytes(script + i, &x)) return -3;
+          i += 32;
+          e = t.common_scalar(x);
+          break;
+        }
+        case 3: e = t.common_ec_point(G1Affine::from_bytes(script + i)), i += 64; break;
+        case 4: {
+          auto r = t.read_scalar();
+          if (!r.ok()) e = r.err;
+          break;
+        }
+        case 5: {
+          auto r = t.read_ec_point();
+          if (!r.ok()) e = r.err;
+          break;
+        }
+        default: return -2;
+      }
+      if (!e.ok()) return 1000 + opi;
+      ++opi;
+    }
+    const auto& lay = t.layout();
+    const auto& el = t.sponge().elems;
+    if (lay.size() != el.size()) return -7;
+    for (size_t k = 0; k < lay.size(); ++k) {
+      const uint32_t kind = lay[k] >> 28, v = lay[k] & 0x0FFFFFFFu;
+      Fr x;
+      if (kind == TR::kSrcLead) {
+        if (v >= t.lead_values().size()) return 2000 + (int)k;
+        x = t.lead_values()[v];
+      } else if (kind == TR::kSrcScalar) {
+        if ((size_t)v + 32 > proof_len || !Fr::from_bytes(proof + v, &x)) return 2000 + (int)k;
+      } else {
+        if (v >= t.decoded_points().size()) return 2000 + (int)k;
+        uint64_t w[4];
+        memcpy(w, t.decoded_points()[v].b + (kind == TR::kSrcPy ? 32 : 0), 32);
+        x = grain::fr_from_words_mod_r(w);
+      }
+      if (!(x == el[k])) return 2000 + (int)k;
+    }
+    std::vector<uint32_t> o;
+    o.push_back((uint32_t)lay.size());
+    o.insert(o.end(), lay.begin(), lay.end());
+    o.push_back((uint32_t)t.point_offsets().size());
+    for (size_t q : t.point_offsets()) o.push_back((uint32_t)q);
+    std::vector<uint32_t> seg = t.sponge().seg_len;
+    o.push_back((uint32_t)seg.size());
+    o.insert(o.end(), seg.begin(), seg.end());
+    if (o.size() * 4 > out_cap) return -6;
+    memcpy(out, o.data(), o.size() * 4);
+    *out_len = o.size() * 4;
+    return 0;
+  });
+}
+
 int hd_evm_transcript_script(const uint8_t* script, size_t script_len, const uint8_t* proof, size_t proof_len,
                              uint8_t* out, size_t out_cap, size_t* out_len) {
   return hd_transcript_script(0, script, script_len, proof, proof_len, out, out_cap, out_len);

@@ -261,3 +261,55 @@ def test_cost_estimation_of_the_standard_plonk_shape(H):
     assert list(out) == [2, 9 + 4, 19, 8 + 9 + 1 + 4, 2]
     assert H.hd_plonk_estimate_cost(1, pb, len(pb), out) == 0
     assert list(out) == [2, 9 + 2, 19, 8 + 9 + 1 + 2, 2]
+
+
+def test_poseidon_transcript_layout_record_rebuilds_every_absorbed_element(H):
+    """transcript.hpp `record_layout`: the provenance a batch of proofs is described with to `snarkv_poseidon_read_batch`
+    (lead value / scalar at a byte of the proof / coordinate of point q).  Random scripts: the C++ hook rebuilds every
+    absorbed element from its code and compares with what the sponge got; here the codes, point offsets and segment
+    lengths are checked against the script itself."""
+    import importlib.util
+    import struct
+
+    spec = importlib.util.spec_from_file_location("gen_t", os.path.join(ROOT, "tests", "golden", "gen_golden_transcript.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    H.hd_poseidon_layout_script.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p,
+                                            ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    rng = random.Random(4242)
+    pts = [O.g1_mul(O.G1_GEN, rng.randrange(1, O.R)) for _ in range(6)]
+    for _ in range(60):
+        ops, proof = [], b""
+        want_codes, want_offs, want_seg, cur, lead, q = [], [], [], 0, 0, 0
+        for _ in range(rng.randrange(1, 30)):
+            op = rng.choice([1, 2, 3, 4, 4, 5, 5])
+            if op == 1:
+                ops.append((1, None)); want_seg.append(cur); cur = 0
+            elif op == 2:
+                ops.append((2, rng.choice([0, 1, O.R - 1, rng.randrange(O.R)]))); want_codes.append((0 << 28) | lead); lead += 1; cur += 1
+            elif op == 3:
+                ops.append((3, rng.choice(pts))); want_codes += [(0 << 28) | lead, (0 << 28) | (lead + 1)]; lead += 2; cur += 2
+            elif op == 4:
+                ops.append((4, None)); want_codes.append((1 << 28) | len(proof)); cur += 1
+                proof += rng.choice([0, O.R - 1, rng.randrange(O.R)]).to_bytes(32, "little")
+            else:
+                ops.append((5, None)); want_codes += [(2 << 28) | q, (3 << 28) | q]; q += 1; cur += 2
+                want_offs.append(len(proof))
+                proof += T.g1_compress(rng.choice(pts))
+        out = ctypes.create_string_buffer(1 << 14)
+        n = ctypes.c_size_t(0)
+        script = gen.pack_script(ops)
+        assert H.hd_poseidon_layout_script(script, len(script), proof, len(proof), out, len(out), ctypes.byref(n)) == 0
+        w = struct.unpack("<%dI" % (n.value // 4), out.raw[:n.value])
+        L = w[0]
+        codes = list(w[1:1 + L])
+        P = w[1 + L]
+        offs = list(w[2 + L:2 + L + P])
+        S = w[2 + L + P]
+        seg = list(w[3 + L + P:3 + L + P + S])
+        assert (codes, offs, seg) == (want_codes, want_offs, want_seg)
+    # a scalar out of range / an invalid point stop the recording pass like any transcript (the fused route then never starts)
+    bad = gen.pack_script([(4, None)])
+    out = ctypes.create_string_buffer(64)
+    n = ctypes.c_size_t(0)
+    assert H.hd_poseidon_layout_script(bad, len(bad), (O.R + 1).to_bytes(32, "little"), 32, out, len(out), ctypes.byref(n)) == 1000
