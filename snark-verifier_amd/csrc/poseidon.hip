@@ -183,20 +183,31 @@ __global__ void __launch_bounds__(256)
       s = dense_row(tab, r + 1 < h ? sh.o_mds : sh.o_pre, t, j, x);
     }
     // partial rounds: S-box on word 0 only, sparse matrix [[row], [col_hat | I]]
+    // The three table entries of a round (row[j], col_hat[j-1] / row[0], the round constant) are read one round AHEAD:
+    // the LDS latency of round r + 1's operands passes under round r's products instead of in front of its first one.
+    // (lanes >= t read row[0] / compute products nobody uses: one table read by index, no per-lane struct selection)
+    const uint32_t jr = (uint32_t)j < t ? (uint32_t)j : 0u;
+    const bool has_col = j >= 1 && (uint32_t)j < t;
+    auto col_index = [&](uint32_t r) { return has_col ? sh.o_cols + r * (t - 1) + (uint32_t)j - 1 : sh.o_rows + r * t; };
+    Fr29 rowj_next = tab[sh.o_rows + jr], cj_next = tab[col_index(0)], kc_next = tab[sh.o_partial];
     for (uint32_t r = 0; r < sh.r_p; ++r) {
       // Lanes run in lockstep, so the three products of lane 0's x^5 are issued by every lane anyway:
       // the first one doubles as  row[j] * s_j  in lanes 1.. (operands picked per lane).
       const bool w0 = j == 0;
-      // (lanes >= t read row[0] / compute products nobody uses: one table read by index, no per-lane struct selection)
-      const Fr29 rowj = tab[sh.o_rows + r * t + ((uint32_t)j < t ? (uint32_t)j : 0u)];
+      const Fr29 rowj = rowj_next, cj = cj_next, kc = kc_next;
+      {
+        const uint32_t rn = r + 1 < sh.r_p ? r + 1 : r;
+        rowj_next = tab[sh.o_rows + rn * t + jr];
+        cj_next = tab[col_index(rn)];
+        kc_next = tab[sh.o_partial + rn];
+      }
       Fr29 p1 = fr29_mul(w0 ? s : rowj, s);  // lane 0: x^2      lanes 1..: row[j] * s_j
       Fr29 x4 = fr29_mul(p1, p1);            // lane 0: x^4
       Fr29 x5 = fr29_mul(x4, s);             // lane 0: x^5
-      Fr29 s0 = fr29_norm(fr29_add(x5, tab[sh.o_partial + r]));
+      Fr29 s0 = fr29_norm(fr29_add(x5, kc));
       s0 = shfl8(s0, 0);
       // second shared product: lane 0: row[0] * s0      lanes 1..: col_hat[j-1] * s0
-      const Fr29 cj = tab[(j >= 1 && (uint32_t)j < t) ? sh.o_cols + r * (t - 1) + (uint32_t)j - 1 : sh.o_rows + r * t];
-      Fr29 p2 = fr29_mul(cj, s0);  // lane 0: row[0]
+      Fr29 p2 = fr29_mul(cj, s0);  // lane 0: cj = row[0]
       // word 0: row . state  (butterfly over the 8 lanes; lanes >= t contribute zero)
       Fr29 sum = w0 ? p2 : p1;
       if ((uint32_t)j >= t) sum = fr29_zero();
