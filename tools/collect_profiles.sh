@@ -8,18 +8,18 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
 # PMC records first (and into profiles/ of THIS tree) so that the bench lines below quote the traffic of these very kernels
-python tools/pmc_traffic.py --tag $TAG --out-dir $O > /dev/null
-python tools/pmc_traffic.py --tag $TAG --out-dir $O --log2n 24 > /dev/null
+timeout 600 python tools/pmc_traffic.py --tag $TAG --out-dir $O > /dev/null
+timeout 600 python tools/pmc_traffic.py --tag $TAG --out-dir $O --log2n 24 > /dev/null
 cp $O/${TAG}_pmc_hbm_traffic*.json profiles/
-python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-python bench.py --steps 40 --warmup 4 --no-secondary --no-cpu-baseline > $O/${TAG}_bench_40steps.json 2>/dev/null
-python bench.py --log2n 22 --inflight 1 --steps 10 --warmup 2 --no-secondary --cpu-sample-log2 18 > $O/${TAG}_bench_2p22.json 2>/dev/null
-python bench.py --log2n 24 --inflight 1 --steps 6 --warmup 2 --no-secondary --cpu-sample-log2 18 > $O/${TAG}_bench_2p24.json 2>/dev/null
+timeout 600 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+timeout 300 python bench.py --steps 40 --warmup 4 --no-secondary --no-cpu-baseline > $O/${TAG}_bench_40steps.json 2>/dev/null
+timeout 300 python bench.py --log2n 22 --inflight 1 --steps 10 --warmup 2 --no-secondary --cpu-sample-log2 18 > $O/${TAG}_bench_2p22.json 2>/dev/null
+timeout 300 python bench.py --log2n 24 --inflight 1 --steps 6 --warmup 2 --no-secondary --cpu-sample-log2 18 > $O/${TAG}_bench_2p24.json 2>/dev/null
 cd /tmp
 stats() {  # name, bench args...
   name=$1; shift
   rm -rf /tmp/prof_$name
-  rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -- python $R/bench.py "$@" > /dev/null 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -- python $R/bench.py "$@" > /dev/null 2>&1
   db=$(find /tmp/prof_$name -name "*.db" | head -1)
   if [ -n "$db" ]; then python $R/tools/rocpd_top_kernels.py $db $O/${TAG}_rocprofv3_kernel_stats_$name.csv; else
     f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_rocprofv3_kernel_stats_$name.csv; fi
@@ -30,24 +30,26 @@ stats with_secondary --steps 4 --warmup 1 --no-cpu-baseline --no-host-resident
 stats 2p24_single --log2n 24 --inflight 1 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary
 # the timed batch as a kernel timeline (who overlaps whom): the window from the 45th k_prepare (2 x 20 initialisation / warm-up
 # jobs + the 4 slot calls) to the end of the batch's k_final
-rm -rf /tmp/prof_trace; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_trace -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-host-resident > /dev/null 2>&1
+rm -rf /tmp/prof_trace; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_trace -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-host-resident > /dev/null 2>&1
 python $R/tools/trace_overlap.py /tmp/prof_trace --first 44 --count 20 --until-prepare 64 > $O/${TAG}_overlap_batch.txt 2>&1
 # the aggregation job alone (bench.py's second metric): kernel shares for secondary.aggregate_*.roofline.dominant_kernel
 for m in 64 1024; do
-  rm -rf /tmp/prof_a; rocprofv3 --kernel-trace --stats -d /tmp/prof_a -- python $R/tools/aggregate_job.py --proofs $m > /dev/null 2>&1
+  rm -rf /tmp/prof_a; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_a -- python $R/tools/aggregate_job.py --proofs $m > /dev/null 2>&1
   db=$(find /tmp/prof_a -name "*.db" | head -1)
   if [ -n "$db" ]; then python $R/tools/rocpd_top_kernels.py $db $O/${TAG}_rocprofv3_kernel_stats_aggregate_$m.csv; else
     f=$(find /tmp/prof_a -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_rocprofv3_kernel_stats_aggregate_$m.csv; fi
 done
 # ... and with jobs in flight: by hardware-queue count, and the kernel durations under 16-fold overlap
 cd $R
-GPU_MAX_HW_QUEUES=16 python tools/aggregate_inflight.py --inflight 1 8 16 32 2>/dev/null | grep queues= > $O/${TAG}_agg_inflight.txt
+GPU_MAX_HW_QUEUES=16 timeout 600 python tools/aggregate_inflight.py --inflight 1 8 16 32 2>/dev/null | grep queues= > $O/${TAG}_agg_inflight.txt
 cd /tmp
 for m in 64 1024; do
-  rm -rf /tmp/prof_a; rocprofv3 --kernel-trace --stats -d /tmp/prof_a -- python $R/tools/aggregate_inflight.py --proofs $m --inflight 16 > /dev/null 2>&1
+  rm -rf /tmp/prof_a; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_a -- python $R/tools/aggregate_inflight.py --proofs $m --inflight 16 > /dev/null 2>&1
   db=$(find /tmp/prof_a -name "*.db" | head -1)
   if [ -n "$db" ]; then python $R/tools/rocpd_top_kernels.py $db $O/${TAG}_rocprofv3_kernel_stats_aggregate_inflight16_$m.csv; else
     f=$(find /tmp/prof_a -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_rocprofv3_kernel_stats_aggregate_inflight16_$m.csv; fi
 done
 cd $R
+timeout 120 python tools/dk_create_time.py 2>/dev/null | grep -v amdgpu.ids > $O/${TAG}_dk_create.txt
+timeout 300 python tools/ab_decide.py --sizes 1,16,256,1024 2>/dev/null | grep -v amdgpu.ids > $O/${TAG}_ab_decide_now.txt
 ls -la $O | grep $TAG
