@@ -179,6 +179,20 @@ def test_validation_and_decompression_in_memory_form(gpu_ctx):
     ctx.set_flags(sv.SNARKV_FLAG_MONTGOMERY)
     out, ok = ctx.g1_decompress(comp + (1 << 255).to_bytes(32, "little"))
     assert all(ok) and out == pm + bytes(64)
+    # ... but a proof is wire data on both sides: snarkv_poseidon_read_batch answers in canonical bytes under either flag
+    # (its points feed a transcript and the host's parser, include/snarkv_amd.h)
+    import transcript as T
+
+    spec = sv.PoseidonSpec(ctx, 5, 4, 8, 60, T.poseidon_opt_tables(5, 8, 60))
+    recs = b"".join(comp[32 * i:32 * i + 32] + s[32 * i:32 * i + 32] for i in range(n))  # a record: one point, one scalar
+    layout, seg = [(2 << 28) | 0, (3 << 28) | 0, (1 << 28) | 32], [3]
+    ch_m, pts_m, ok_m = ctx.poseidon_read_batch(spec, recs, n, 64, b"", 0, layout, [0], seg)
+    ctx.set_flags(0)
+    ch_c, pts_c, ok_c = ctx.poseidon_read_batch(spec, recs, n, 64, b"", 0, layout, [0], seg)
+    assert (ch_m, pts_m, ok_m) == (ch_c, pts_c, ok_c) and pts_c == p and all(ok_c)
+    x0, y0 = int.from_bytes(p[:32], "little"), int.from_bytes(p[32:64], "little")
+    assert int.from_bytes(ch_c[:32], "little") == T.poseidon_transcript_challenges([x0 % O.R, y0 % O.R, int.from_bytes(s[:32], "little")], seg)[0]
+    spec.close()
     ctx.close()
 
 
