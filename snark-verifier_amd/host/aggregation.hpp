@@ -192,19 +192,7 @@ struct Aggregator {
       t_pass0 = lap();
     }
     // pass 1: parse (points not covered by pass 0 are decompressed here) and record what the sponge would see
-    std::atomic<uint64_t> ns_pass1{0}, ns_pass1_max{0};
     parallel_for(n, threads, [&](size_t i) {
-      auto tt0 = clk::now();
-      struct Tick {
-        clk::time_point t0; std::atomic<uint64_t>&sum, &mx;
-        ~Tick() {
-          if (!trace) return;
-          uint64_t d = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count();
-          sum += d;
-          uint64_t m = mx.load();
-          while (d > m && !mx.compare_exchange_weak(m, d)) {}
-        }
-      } tick{tt0, ns_pass1, ns_pass1_max};
       PoseidonTranscriptT<RecordingSponge> t(proofs[i], T, RATE, R_F, R_P);
       // (a flag of 0 = no hint: an invalid encoding is re-examined, and rejected, by the host function)
       if (hint_row[i] != (size_t)-1 && !hint_ok.empty())
@@ -250,8 +238,8 @@ struct Aggregator {
       pfs[i] = std::move(*pf.value);
     }, 4);
     if (trace)
-      fprintf(stderr, "read_proofs_device_hashed: %zu proofs x %zu elements, %zu squeezes: pass0 %.3f pass1 %.3f (per proof %.1f us, max %.1f) pack %.3f device %.3f pass2 %.3f ms\n",
-              n, L, S, t_pass0, t_pass1, ns_pass1.load() / 1e3 / n, ns_pass1_max.load() / 1e3, t_pack, t_dev, lap());
+      fprintf(stderr, "read_proofs_device_hashed: %zu proofs x %zu elements, %zu squeezes: pass0 %.3f pass1 %.3f pack %.3f device %.3f pass2 %.3f ms\n",
+              n, L, S, t_pass0, t_pass1, t_pack, t_dev, lap());
     for (auto& e : errs)
       if (!e.ok()) return e;
     return Error{};
