@@ -225,7 +225,7 @@ int snarkv_g1_msm_batched_dev(snarkv_ctx* ctx, const void* d_scalars32, const vo
 //
 // Beyond ~2^21 points the single-launch Pippenger degrades: the Montgomery point table (64 B x 2n) outgrows the
 // 256 MiB Infinity Cache, so every bucket-accumulate gather goes to HBM (k_accumulate +11 % per point at 2^24), the
-// level-1 partition scatters 8-byte entries into thousands of streams (k_sort_scatter: 3.5x write amplification), and
+// level-1 partition scatters 8-byte entries into thousands of streams (k_sort_scatter_staged: 3.5x write amplification), and
 // level-2 slices no longer fit LDS.  MSM is linear (the reference's own chunking, util/msm.rs:311-336), so n points are
 // cut into 2^20-point chunks that all use the window size of a 2^20-point MSM; every chunk runs the efficient small-n
 // stages (prepare, partition, sort, bucket accumulate, combine) on one of three worker lanes (private sub-contexts: one

@@ -5,7 +5,7 @@
 // gen_g2_prepare_prog.py): a lane computes ONE component of one product as a fused two-product Montgomery step on the lazy
 // 29-bit field, its operands small integer combinations of LDS slots, so additions and subtractions cost no level.  Both
 // points of a key (g2, -s_g2) run side by side in one wavefront, 14 lanes each: 448 levels of ~600 instructions.
-// The output is the 29-bit table the decide kernels read (G2Prepared29), bit for bit what k_g2_to29(g2_prepare()) gave.
+// The output is the 29-bit table the decide kernels read (G2Prepared29), bit for bit what the one-lane g2_prepare() of rounds 1-3 gave, converted to 29-bit limbs.
 // Host-compilable: tests/hosttest emulates the lanes against pairing.h.
 #pragma once
 #include "decide_w.h"

@@ -15,7 +15,7 @@
 //                        signed c-bit digits (half the buckets of msm.rs:269),
 //                        per-tile LDS histogram of (window, high digit bits)
 //   S2 k_scan_*          exclusive scan of the key x tile matrix
-//   S3 k_sort_scatter    stable partition of (bucket, point, sign) by
+//   S3 k_sort_scatter_staged  stable partition of (bucket, point, sign) by
 //                        (window, high bits) -- LDS cursors, no global atomics
 //   S4 k_sort_level2     one workgroup per (window, high bits): LDS counting
 //                        sort by the low digit bits; emits the bucket-sorted
@@ -69,7 +69,7 @@ namespace snarkv {
 #define SNARKV_KCHUNK 8
 #endif
 #ifndef SNARKV_TILE_THREADS
-// Tile workgroups of k_prepare / k_sort_scatter*: 256 lanes on 2 048 scalars, i.e. ONE wavefront per SIMD, and registers
+// Tile workgroups of k_prepare / k_sort_scatter_staged: 256 lanes on 2 048 scalars, i.e. ONE wavefront per SIMD, and registers
 // capped so that one fits beside three resident k_accumulate wavefronts (3 x 136 VGPRs leave 104 per SIMD): with several
 // MSMs in flight the sorts of the next MSM then run UNDER the accumulation instead of waiting for its wavefronts to
 // retire.  Measured against 512 lanes on 4 096 scalars (two wavefronts per SIMD, 120 VGPRs): batch of 40 MSMs -1.5 to
@@ -92,7 +92,7 @@ namespace snarkv {
 #define SNARKV_XCD_TILES 1  // tiles -> workgroups so that an XCD owns a contiguous tile range (xcd_tile)
 #endif
 #ifndef SNARKV_TILE_BASE
-#define SNARKV_TILE_BASE 2048  // smallest tile (scalars per k_prepare / k_sort_scatter workgroup)
+#define SNARKV_TILE_BASE 2048  // smallest tile (scalars per k_prepare / k_sort_scatter_staged workgroup)
 #endif
 #ifndef SNARKV_ACC_WAVES
 #define SNARKV_ACC_WAVES 3

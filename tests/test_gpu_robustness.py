@@ -330,8 +330,8 @@ def test_inputs_in_pinned_host_buffers(gpu_ctx):
 
 def test_joint_fixed_window_form_of_large_segmented_launches(gpu_ctx):
     """Above 16 384 terms a segmented launch multiplies with the fixed-window kernel; with the context's throughput hint
-    (or from 49 152 terms) it takes the JOINT form -- one lane per term, both GLV halves on shared doublings
-    (k_term_scalar_mul_joint).  Ragged segments, scalars that stress the two digit streams (0, 1, r - 1, lambda and small
+    (or from 49 152 terms) it takes the GROUP form -- K <= 4 terms of a segment per lane, all their GLV halves on shared
+    doublings (k_term_scalar_mul_group).  Ragged segments, scalars that stress the two digit streams (0, 1, r - 1, lambda and small
     combinations a + b lambda whose halves are tiny, 2^k, all-ones), repeated and opposite points, identities."""
     rng = random.Random(77)
     n = 20000
