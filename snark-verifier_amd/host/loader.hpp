@@ -95,6 +95,13 @@ struct G2Affine {
 // evaluation) is spread over host threads.  A persistent pool: starting a thread costs
 // about as much as the host work of one Keccak-transcript proof, and an aggregation
 // makes several passes.
+//
+// One job at a time.  The job lives IN the pool (stable memory), identified by a generation number; a worker joins it by
+// a compare-and-swap on `state_` = generation << 32 | closed << 31 | workers inside, so joining, leaving and the caller's
+// "everybody out" need no lock, and a worker that arrives late finds another generation (or the closed bit) and never
+// touches the job's fields.  Workers spin briefly for the next generation before they sleep on the condition variable:
+// an aggregation runs five or six parallel passes of a few hundred microseconds back to back, and waking 64 sleepers
+// through one mutex cost each pass a good part of its own duration.  The caller works on the items too.
 class HostPool {
  public:
   static HostPool& get() {
@@ -102,47 +109,58 @@ class HostPool {
     return p;
   }
   unsigned size() const { return (unsigned)workers_.size(); }
-  // runs fn(i) for i in [0, n) on up to `threads` pool workers (the caller blocks); the first exception wins
+  // runs fn(i) for i in [0, n) on up to `threads` threads, the caller among them (it returns when all are done); the
+  // first exception wins
   template <class F>
   void run(size_t n, unsigned threads, F&& fn) {
-    threads = std::min<unsigned>(threads, size());
+    threads = std::min<unsigned>(threads, size() + 1);
     if (threads <= 1 || n <= 1 || in_worker()) {  // a task that itself fans out runs its items inline
       for (size_t i = 0; i < n; ++i) fn(i);
       return;
     }
-    std::lock_guard<std::mutex> one_job(submit_mu_);  // one job at a time keeps the bookkeeping trivial
-    Job job;
-    job.n = n;
-    job.fn = [&](size_t i) { fn(i); };
-    job.slots = threads;
+    std::lock_guard<std::mutex> one_job(submit_mu_);
+    // (the previous job is closed and empty: nobody reads these fields now)
+    n_.store(n, std::memory_order_relaxed);
+    chunk_.store(std::max<size_t>(1, n / ((size_t)threads * 8)), std::memory_order_relaxed);  // items per claim: 8 claims per thread
+    fn_ = [&](size_t i) { fn(i); };
+    next_.store(0, std::memory_order_relaxed);
+    max_workers_.store(threads - 1, std::memory_order_relaxed);
+    failed_.store(false, std::memory_order_relaxed);
+    err_ = nullptr;
+    const uint64_t gen = (state_.load(std::memory_order_relaxed) >> 32) + 1;
+    state_.store(gen << 32, std::memory_order_seq_cst);  // open
     {
-      std::lock_guard<std::mutex> lk(mu_);
-      job_ = &job;
-      ++generation_;
+      std::lock_guard<std::mutex> lk(mu_);  // a worker between its predicate and its wait holds mu_: no lost wake-up
     }
     cv_.notify_all();
-    std::unique_lock<std::mutex> lk(mu_);
-    done_cv_.wait(lk, [&] { return job.finished == job.started && job.next.load() >= n && job.slots_left() == false; });
-    job_ = nullptr;
-    lk.unlock();
-    if (job.err) std::rethrow_exception(job.err);
+    in_worker() = true;  // the caller's share: its tasks are pool tasks like any other (no device lock, no nested fan-out)
+    work();
+    in_worker() = false;
+    // close the job, then wait until the workers inside have left
+    uint64_t st = state_.load(std::memory_order_acquire);
+    while (!state_.compare_exchange_weak(st, st | kClosed, std::memory_order_acq_rel)) {
+    }
+    for (unsigned spins = 0; (state_.load(std::memory_order_acquire) & kCountMask) != 0; ++spins) {
+      if (spins < 4096) cpu_relax();
+      else std::this_thread::yield();
+    }
+    fn_ = nullptr;
+    if (err_) std::rethrow_exception(err_);
   }
-  // true on the pool's own threads (a task that fans out runs inline; a task must never take the device lock)
+  // true on the pool's own threads and on a caller while it works on its job (a task that fans out runs inline; a task
+  // must never take the device lock)
   static bool& in_worker() {
     static thread_local bool flag = false;
     return flag;
   }
 
  private:
-  struct Job {
-    size_t n = 0;
-    std::function<void(size_t)> fn;
-    std::atomic<size_t> next{0};
-    unsigned slots = 0, started = 0, finished = 0;  // guarded by mu_
-    std::exception_ptr err;
-    std::atomic<bool> failed{false};
-    bool slots_left() const { return started < slots && next.load() < n; }
-  };
+  static constexpr uint64_t kClosed = 1ull << 31, kCountMask = kClosed - 1;
+  static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+  }
   HostPool() {
     unsigned hc = std::max(1u, std::thread::hardware_concurrency());
     unsigned k = std::min(64u, hc);
@@ -152,48 +170,69 @@ class HostPool {
   ~HostPool() {
     {
       std::lock_guard<std::mutex> lk(mu_);
-      stop_ = true;
+      stop_.store(true);
     }
     cv_.notify_all();
     for (auto& w : workers_) w.join();
   }
+  // runs of items until none are left (or a task threw)
+  void work() {
+    const size_t n = n_.load(std::memory_order_relaxed), chunk = chunk_.load(std::memory_order_relaxed);
+    for (;;) {
+      const size_t i0 = next_.fetch_add(chunk, std::memory_order_relaxed);
+      if (i0 >= n || failed_.load(std::memory_order_relaxed)) break;
+      try {
+        for (size_t i = i0, e = std::min(n, i0 + chunk); i < e; ++i) fn_(i);
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(err_mu_);
+        if (!failed_.exchange(true)) err_ = std::current_exception();
+        next_.store(n, std::memory_order_relaxed);  // nothing more to hand out
+        break;
+      }
+    }
+  }
   void loop() {
     in_worker() = true;
-    uint64_t seen = 0;
+    uint64_t seen = 0;  // generation this worker has dealt with
     for (;;) {
-      Job* job = nullptr;
-      {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return stop_ || (job_ && generation_ != seen && job_->slots_left()); });
-        if (stop_) return;
-        seen = generation_;
-        job = job_;
-        ++job->started;
+      // wait for another generation: spin first (the next pass of an aggregation is usually microseconds away)
+      uint64_t st = state_.load(std::memory_order_acquire);
+      for (unsigned spins = 0; (st >> 32) == seen && spins < 5000 && !stop_.load(std::memory_order_relaxed); ++spins) {
+        cpu_relax();
+        st = state_.load(std::memory_order_acquire);
       }
-      for (;;) {
-        size_t i = job->next.fetch_add(1);
-        if (i >= job->n || job->failed.load()) break;
-        try {
-          job->fn(i);
-        } catch (...) {
-          if (!job->failed.exchange(true)) job->err = std::current_exception();
-          job->next.store(job->n);  // nothing more to hand out
+      if ((st >> 32) == seen) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_.load() || (state_.load(std::memory_order_acquire) >> 32) != seen; });
+        st = state_.load(std::memory_order_acquire);
+      }
+      if (stop_.load()) return;
+      seen = st >> 32;
+      // join unless the job is closed, full, or already another one
+      bool joined = false;
+      while ((st >> 32) == seen && !(st & kClosed) && (st & kCountMask) < max_workers_.load(std::memory_order_relaxed) &&
+             next_.load(std::memory_order_relaxed) < n_.load(std::memory_order_relaxed)) {
+        if (state_.compare_exchange_weak(st, st + 1, std::memory_order_acq_rel)) {
+          joined = true;
           break;
         }
       }
-      {
-        std::lock_guard<std::mutex> lk(mu_);
-        ++job->finished;
-      }
-      done_cv_.notify_all();
+      if (!joined) continue;
+      work();
+      state_.fetch_sub(1, std::memory_order_acq_rel);
     }
   }
   std::vector<std::thread> workers_;
-  std::mutex mu_, submit_mu_;
-  std::condition_variable cv_, done_cv_;
-  Job* job_ = nullptr;
-  uint64_t generation_ = 0;
-  bool stop_ = false;
+  std::mutex mu_, submit_mu_, err_mu_;
+  std::condition_variable cv_;
+  std::atomic<uint64_t> state_{0};
+  std::atomic<bool> stop_{false}, failed_{false};
+  // the job (valid for the generation in state_ while it is open or a worker is inside)
+  std::atomic<size_t> n_{0}, chunk_{1};
+  std::function<void(size_t)> fn_;
+  std::atomic<size_t> next_{0};
+  std::atomic<unsigned> max_workers_{0};
+  std::exception_ptr err_;
 };
 
 // `grain`: items per thread below which another thread is not worth waking.

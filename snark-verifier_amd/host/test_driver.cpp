@@ -418,6 +418,56 @@ int hd_poseidon_layout_script(const uint8_t* script, size_t script_len, const ui
   });
 }
 
+// The host pool (loader.hpp HostPool): every item exactly once for many (n, threads, grain) shapes, nested fan-out runs
+// inline, the first exception reaches the caller and the pool survives it, several submitting threads take turns.
+// Returns 0, or the number of the check that failed.
+int hd_pool_selftest(int rounds) {
+  return guarded([&] {
+    for (int rep = 0; rep < rounds; ++rep) {
+      const size_t n = 1 + (size_t)(rep * 7919) % 3000;
+      const unsigned th = 1 + rep % 70;
+      std::vector<std::atomic<int>> v(n);
+      for (auto& x : v) x = 0;
+      parallel_for(n, th, [&](size_t i) {
+        v[i]++;
+        if ((i & 255) == 0) parallel_for(4, 8, [&](size_t) {}, 1);
+      }, 1 + rep % 5);
+      for (size_t i = 0; i < n; ++i)
+        if (v[i] != 1) return 1;
+    }
+    int caught = 0;
+    for (int rep = 0; rep < 50; ++rep) {
+      try {
+        parallel_for(500, 64, [&](size_t i) {
+          if (i == (size_t)(rep * 7) % 500) throw std::runtime_error("task failed");
+        }, 1);
+      } catch (const std::runtime_error&) {
+        ++caught;
+      }
+    }
+    if (caught != 50) return 2;
+    std::vector<std::thread> subs;
+    std::atomic<long> total{0};
+    for (int t = 0; t < 4; ++t)
+      subs.emplace_back([&] {
+        for (int r = 0; r < 100; ++r) parallel_for(200, 16, [&](size_t) { total++; }, 1);
+      });
+    for (auto& t : subs) t.join();
+    if (total != 4 * 100 * 200) return 3;
+    bool refused = false;  // a pool task must not take the device lock (lock order: device -> pool)
+    parallel_for(64, 8, [&](size_t i) {
+      if (i == 5) {
+        try {
+          device_mutex();
+        } catch (const std::logic_error&) {
+          refused = true;
+        }
+      }
+    }, 1);
+    return refused ? 0 : 4;
+  });
+}
+
 int hd_evm_transcript_script(const uint8_t* script, size_t script_len, const uint8_t* proof, size_t proof_len,
                              uint8_t* out, size_t out_cap, size_t* out_len) {
   return hd_transcript_script(0, script, script_len, proof, proof_len, out, out_cap, out_len);

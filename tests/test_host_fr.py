@@ -29,3 +29,14 @@ def test_fr_mul_inv():
         assert O.fe_from_bytes(o.raw) == pow(a, -1, O.R)
         assert L.hd_fr_inv_fermat(O.fe_to_bytes(a), o2) == 1 and o2.raw == o.raw
     assert L.hd_fr_inv(O.fe_to_bytes(0), o) == 0
+
+
+def test_host_pool_selftest():
+    """The host pool (host/loader.hpp `HostPool`, round 4: lock-free joining, spinning workers, the caller works too):
+    every item exactly once over many (n, threads, grain) shapes, nested fan-out inline, exceptions reach the caller and the
+    pool survives them, several submitters take turns, a pool task is refused the device lock."""
+    from hostfmt import load_host_lib
+
+    L = load_host_lib()
+    L.hd_pool_selftest.argtypes = [ctypes.c_int]
+    assert L.hd_pool_selftest(600) == 0
