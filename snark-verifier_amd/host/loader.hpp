@@ -329,9 +329,9 @@ struct GpuNativeLoader {
       }
     };
     if (total >= 4096) {
-      const size_t per = 64;  // MSMs per task
+      const size_t per = 16;  // MSMs per task (a few hundred terms: ~10 us of conversions and copies)
       const size_t tasks = (msms.size() + per - 1) / per;
-      parallel_for(tasks, 16, [&](size_t k) { pack(k * per, std::min(msms.size(), (k + 1) * per)); }, 1);
+      parallel_for(tasks, 64, [&](size_t k) { pack(k * per, std::min(msms.size(), (k + 1) * per)); }, 1);
     } else {
       pack(0, msms.size());
     }
