@@ -714,6 +714,51 @@ extern "C" int hd_plonk_succinct_verify(int mos, int tkind, const uint8_t* proto
                                               accs_cap, n_accs, false);
 }
 
+// dev aid (CPU only, one thread): microseconds per proof of the host half's phases for Gwc19 + Keccak transcripts --
+// out[0..6] = read_proof, CommonPolyEval, evaluations_map, commitments, queries, pcs_msms, pairs.  tools/host_phases.py
+extern "C" int hd_plonk_host_phases(const uint8_t* protocol, size_t plen, const uint8_t* instances, size_t ilen,
+                                    const uint8_t* proofs, size_t prlen, uint32_t n, const uint8_t* dk320, int reps, double* out7) {
+  return guarded([&] {
+    using clk = std::chrono::steady_clock;
+    PlonkProtocol pr = parse_protocol(protocol, plen);
+    KzgDecidingKey dk(G1Affine::from_bytes(dk320), G2Affine::from_bytes(dk320 + 64), G2Affine::from_bytes(dk320 + 192));
+    std::vector<std::vector<std::vector<Fr>>> insts;
+    std::vector<std::vector<uint8_t>> pbytes;
+    wire::split_batch(instances, ilen, proofs, prlen, n, insts, pbytes);
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    auto lap = [&](clk::time_point& t, int k) {
+      auto now = clk::now();
+      acc[k] += std::chrono::duration<double, std::micro>(now - t).count();
+      t = now;
+    };
+    size_t sink = 0;
+    for (int r = 0; r < reps; ++r)
+      for (uint32_t i = 0; i < n; ++i) {
+        auto t = clk::now();
+        EvmTranscript tr(pbytes[i]);
+        auto pf = PlonkSuccinctVerifier<Gwc19>::read_proof(dk.svk, pr, insts[i], tr);
+        if (!pf.ok()) return error_code(pf.err);
+        const auto& proof = *pf.value;
+        lap(t, 0);
+        CommonPolyEval cpe(pr.domain, pr.langranges(), proof.z);
+        lap(t, 1);
+        auto evals = proof.evaluations_map(pr, insts[i], cpe);
+        lap(t, 2);
+        auto cm = proof.commitments(pr, cpe, evals);
+        lap(t, 3);
+        auto queries = proof.queries(pr, evals);
+        lap(t, 4);
+        auto [lhs, rhs] = plonk_detail::pcs_msms(cm, proof.z, queries, proof.pcs);
+        lap(t, 5);
+        auto a = lhs.pairs(dk.svk.g), b = rhs.pairs(dk.svk.g);
+        sink += a.size() + b.size();
+        lap(t, 6);
+      }
+    for (int k = 0; k < 7; ++k) out7[k] = acc[k] / ((double)reps * n);
+    return sink ? 0 : -1;
+  });
+}
+
 // KzgAs::create_proof (non-zk, fresh Keccak transcript) over m accumulators, then decide: the combine
 // step every rank runs on the gathered accumulators.  Returns 1 / 0; acc_out128 = the folded accumulator.
 extern "C" int hd_kzg_as_accumulate_and_decide(const uint8_t* accs128, uint32_t m, const uint8_t* dk320,
