@@ -233,10 +233,9 @@ class EvmTranscript : public Transcript {
 
   // evm.rs:184-198
   Fr squeeze_challenge() override {
-    std::vector<uint8_t> data = buf_;
-    if (buf_.size() == 0x20) data.push_back(1);
+    if (buf_.size() == 0x20) buf_.push_back(1);  // (the buffer is replaced by the digest below: no copy needed)
     uint8_t h[32];
-    keccak::keccak256(data.data(), data.size(), h);
+    keccak::keccak256(buf_.data(), buf_.size(), h);
     buf_.assign(h, h + 32);
     return fr_from_be_mod_r(h);
   }
@@ -263,7 +262,7 @@ class EvmTranscript : public Transcript {
     if (!read_be(le)) return Result<Fr>::Err(Error{Error::Transcript, "failed to fill whole buffer"});
     Fr s;
     if (!Fr::from_bytes(le, &s)) return Result<Fr>::Err(Error{Error::Transcript, "Invalid scalar encoding in proof"});
-    common_scalar(s);
+    push_be(le);  // = common_scalar(s): `le` is the canonical encoding of s (from_bytes accepted it)
     return Result<Fr>::Ok(s);
   }
 
@@ -302,7 +301,9 @@ class EvmTranscript : public Transcript {
 
  private:
   static void append_be(std::vector<uint8_t>& v, const uint8_t le[32]) {
-    for (int i = 31; i >= 0; --i) v.push_back(le[i]);
+    const size_t o = v.size();
+    v.resize(o + 32);
+    for (int i = 0; i < 32; ++i) v[o + i] = le[31 - i];
   }
   void push_be(const uint8_t le[32]) { append_be(buf_, le); }
   bool read_be(uint8_t le[32]) {
