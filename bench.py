@@ -475,6 +475,300 @@ def cpu_baseline_aggregate(ds, dp, offs, n1, nproofs, n2):
                       "pairing decide (%.1f ms), 1 thread, %.2f s in all; not a halo2curves measurement" % (nproofs, n1 + n2, dt_dec * 1e3, dt)}
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _last_json_line(text):
+    for ln in reversed(text.splitlines()):
+        if ln.startswith("{"):
+            try:
+                return json.loads(ln)
+            except Exception:
+                continue
+    return None
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks under torch.distributed.run ourselves and relay
+    rank 0's ONE line, with a ladder so that a lease on a multi-GPU node never ends without a figure:
+      1. one process per GPU, RCCL over xGMI (each rank probes the communicator; a failure falls back in-process to 2.)
+      2. one process per GPU, host-staged gloo exchange (a fresh launch, should 1. have died or hung)
+      3. ONE process driving all GPUs through snarkv_mgpu_* with peer copies (no collective library, no launcher)
+    Every attempt is recorded in config.launch of the line that is printed."""
+    import subprocess
+
+    limit = float(os.environ.get("SNARKV_BENCH_LAUNCH_TIMEOUT", "1500"))
+    attempts = []
+    base = [a for a in argv]
+    for label, extra in (("torch.distributed.run, transport auto (RCCL, in-process fallback to gloo)", []),
+                         ("torch.distributed.run, transport gloo (host-staged)", ["--transport", "gloo"])):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + base + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=limit, cwd=ROOT)
+            rc, out, err = r.returncode, r.stdout, r.stderr
+        except subprocess.TimeoutExpired as e:
+            rc, out, err = "timeout after %.0f s" % limit, (e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or ""), \
+                (e.stderr or b"").decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
+        line = _last_json_line(out) if rc == 0 else None
+        attempts.append({"how": label, "rc": rc, "seconds": round(time.perf_counter() - t0, 1),
+                         "stderr_tail": None if line else err[-1500:]})
+        if line:
+            line.setdefault("config", {})["launch"] = {"self_launched": True, "attempts": attempts}
+            print(json.dumps(line), flush=True)
+            return 0
+        sys.stderr.write("bench.py: attempt failed (%s): rc %s\n%s\n" % (label, rc, err[-3000:]))
+        if args.dry_run_doubles:
+            break  # (the dry run is gloo either way)
+    if not args.dry_run_doubles:
+        leg = run_mgpu_leg_subprocess(args.gpus, args.steps, args.log2n, args.window_bits, limit)
+        best = max((leg.get(k) for k in ("peer_copy", "rccl") if isinstance(leg.get(k), dict) and "value" in leg[k]),
+                   key=lambda d: d["value"], default=None)
+        attempts.append({"how": "single process, snarkv_mgpu_* (no launcher)", "rc": 0 if best else "failed"})
+        if best:
+            n = 1 << args.log2n
+            line = {"metric": "BN254 G1 MSM points/sec at 2^%d" % args.log2n, "value": best["value"], "unit": "points/s",
+                    "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": best["ms_per_step"],
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "i32x9 (254-bit Montgomery Fq as 9 x 29-bit signed lazy limbs on the integer VALU)", "data": "synthetic",
+                    "config": {"workload": "BN254 G1 Pippenger MSM, 2^%d random points/scalars per GPU, inputs resident in HBM, "
+                                           "affine result (configs[1])" % args.log2n, "points_per_gpu": n,
+                               "parallelism": "point-sharded x%d in ONE process (snarkv_g1_msm_pippenger_many_mgpu_dev), transport %s"
+                                              % (args.gpus, best["transport"]),
+                               "FALLBACK": "both one-process-per-GPU launches failed; this is the single-process leg",
+                               "launch": {"self_launched": True, "attempts": attempts}},
+                    "single_process_mgpu": leg}
+            print(json.dumps(line), flush=True)
+            return 0
+    sys.stderr.write("bench.py: every launch attempt failed: %s\n" % json.dumps(attempts))
+    return 1
+
+
+def open_data_plane(torch, dist, want, local_rank, world):
+    """The group the 144-byte partials travel on.  `auto` / `rccl`: an RCCL ("nccl") group next to the gloo default
+    group, opened and PROBED here (an all-reduce of ones, on a helper thread with a deadline: communicator set-up is where a
+    misconfigured node fails or hangs); the ranks then agree over gloo -- if ANY rank failed, ALL use the host-staged gloo
+    all-gather, and the reason goes into the line.  Returns {"kind": "rccl" | "gloo", "group": ..., "why": ..., ...}."""
+    import datetime
+    import threading
+
+    from snark_verifier_amd.distributed import set_data_group
+
+    info = {"kind": "gloo", "group": None, "why": None, "requested": want}
+    if want == "gloo":
+        info["why"] = "requested"
+        return info
+    res = {"ok": False, "err": None, "group": None}
+
+    def probe():
+        try:
+            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
+            res["group"] = g
+            t = torch.ones(1, dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, group=g)
+            torch.cuda.synchronize()
+            res["ok"] = int(t.item()) == world
+            if not res["ok"]:
+                res["err"] = "sum of ones over the RCCL group = %d, world = %d" % (int(t.item()), world)
+        except Exception as e:  # noqa: BLE001 -- whatever RCCL raises, the ranks fall back together
+            res["err"] = "%s: %s" % (type(e).__name__, str(e)[:400])
+
+    def run():
+        try:
+            with torch.cuda.device(local_rank):
+                probe()
+        except Exception as e:  # noqa: BLE001
+            res["ok"], res["err"] = False, res["err"] or "%s: %s" % (type(e).__name__, str(e)[:400])
+
+    th = threading.Thread(target=run, daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    th.join(float(os.environ.get("SNARKV_BENCH_RCCL_PROBE_TIMEOUT", "240")))
+    if th.is_alive():
+        res["ok"], res["err"] = False, "RCCL probe still running after %.0f s (abandoned)" % (time.perf_counter() - t0)
+        info["probe_hung"] = True  # main() leaves through os._exit: the stuck thread must not block interpreter shutdown
+    flag = torch.tensor([1 if res["ok"] else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # gloo: every rank learns whether EVERY rank has RCCL
+    errs = [None] * world
+    dist.all_gather_object(errs, res["err"])
+    info["probe_seconds"] = round(time.perf_counter() - t0, 2)
+    if int(flag.item()) == 1:
+        info.update(kind="rccl", group=res["group"])
+        set_data_group(res["group"])
+        return info
+    info["why"] = "RCCL unavailable on rank(s) %s: %s" % ([r for r, e in enumerate(errs) if e], next((e for e in errs if e), "?"))
+    if want == "rccl":
+        raise SystemExit("--transport rccl: " + info["why"])
+    return info
+
+
+def run_mgpu_leg_subprocess(gpus, steps, log2n, window_bits, limit=900.0):
+    """the single-process leg in a process of its own (no torchrun environment, its own deadline): a hang or a crash of
+    RCCL's single-process communicator there cannot take the main line with it"""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                        "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "GROUP_WORLD_SIZE",
+                        "ROLE_WORLD_SIZE", "ROLE_NAME", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING",
+                        "TORCHELASTIC_ERROR_FILE")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--mgpu-leg", "--gpus", str(gpus), "--steps", str(steps), "--log2n", str(log2n),
+           "--window-bits", str(window_bits)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=limit, cwd=ROOT, env=env)
+    except subprocess.TimeoutExpired:
+        return {"error": "single-process leg timed out after %.0f s" % limit}
+    d = _last_json_line(r.stdout)
+    if r.returncode != 0 or d is None:
+        return {"error": "single-process leg failed: rc %s" % r.returncode, "stderr_tail": r.stderr[-1500:]}
+    return d
+
+
+def mgpu_leg(gpus, steps, log2n, window_bits):
+    """The path a Rust / C caller reaches WITHOUT a launcher (include/snarkv_amd.h "multi-GPU in ONE process"): the same
+    K-job batch as the main line -- every job 2^log2n points per GPU, resident on its GPU -- through
+    snarkv_g1_msm_pippenger_many_mgpu_dev over devices 0..gpus-1, once per transport: one grouped RCCL all-gather of
+    K x 144 B per rank (`ncclCommInitAll`), and plain peer copies.  A transport that fails is reported with the
+    library's error text and the other one still runs."""
+    import torch
+
+    import snark_verifier_amd as sv
+
+    n = 1 << log2n
+    out = {"ranks": gpus, "devices": list(range(gpus)), "jobs": steps, "points_per_gpu_per_job": n,
+           "entry_point": "snarkv_g1_msm_pippenger_many_mgpu_dev", "estimator": "min", "calls": 3}
+    try:
+        mg = sv.MultiGpu(list(range(gpus)))
+    except Exception as e:  # noqa: BLE001
+        return dict(out, error="snarkv_mgpu_create: %s" % e)
+    en, un, fl = mg.peer_access()
+    out["peer_access"] = {"enabled": en, "unavailable": un, "failed": fl,
+                          "last_error": sv.last_error() if (un or fl) else None}
+    nsets = min(steps, 8)
+    keep, ds, dp = [], [], []
+    for g in range(gpus):
+        c = mg.rank_context(g)
+        rs, rp = [], []
+        with torch.cuda.device(g):
+            for k in range(nsets):
+                s = torch.empty(32 * n, dtype=torch.uint8, device="cuda:%d" % g)
+                p = torch.empty(64 * n, dtype=torch.uint8, device="cuda:%d" % g)
+                torch.cuda.synchronize()
+                first = (k * gpus + g) * n  # job k over all ranks = points [k G n, (k + 1) G n) of the seeded streams
+                c.sample_scalars_dev(0x5EED0001, n, s.data_ptr(), first=first)
+                c.sample_points_dev(0x5EED0002, n, p.data_ptr(), first=first)
+                c.sync()
+                keep += [s, p]
+                rs.append(s.data_ptr()), rp.append(p.data_ptr())
+        ds.append([rs[i % nsets] for i in range(steps)])
+        dp.append([rp[i % nsets] for i in range(steps)])
+    cn = [[n] * steps for _ in range(gpus)]
+    results = {}
+    for name, tr in (("rccl", sv.MultiGpu.RCCL), ("peer_copy", sv.MultiGpu.PEER_COPY)):
+        try:
+            mg.set_transport(tr)
+            res = mg.msm_pippenger_many_dev(ds, dp, cn, window_bits)  # initialisation: scratch of every rank's job contexts
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                res = mg.msm_pippenger_many_dev(ds, dp, cn, window_bits)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            results[name] = res
+            out[name] = {"value": gpus * n * steps / best, "unit": "points/s", "ms_per_step": best / steps * 1e3,
+                         "transport": name, "timing": "wall time of the whole call (results on the host), min of 3 calls"}
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": str(e)[:600], "snarkv_last_error": sv.last_error()}
+    if len(results) == 2:
+        out["transports_agree"] = results["rccl"] == results["peer_copy"]
+    if results:
+        r = next(iter(results.values()))
+        out["results_distinct_per_input_set"] = len(set(r)) == nsets
+        out["result_job0"] = r[0].hex()
+        # job 0 again on ONE GPU: rank 0 samples all G n points of it and reduces them alone
+        c0 = mg.rank_context(0)
+        with torch.cuda.device(0):
+            s = torch.empty(32 * n * gpus, dtype=torch.uint8, device="cuda:0")
+            p = torch.empty(64 * n * gpus, dtype=torch.uint8, device="cuda:0")
+            o = torch.zeros(64, dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()
+            c0.sample_scalars_dev(0x5EED0001, n * gpus, s.data_ptr(), first=0)
+            c0.sample_points_dev(0x5EED0002, n * gpus, p.data_ptr(), first=0)
+            c0.msm_pippenger_dev(s.data_ptr(), p.data_ptr(), n * gpus, o.data_ptr(), 0)
+            c0.sync()
+            out["job0_matches_one_gpu_recompute"] = bytes(o.cpu().numpy()) == r[0]
+    mg.close()
+    return out
+
+
+def strong_leg(torch, dist, sv, ctx, stream, world, rank, total_log2n, steps, window_bits, dry, dev, dev_sync):
+    """BASELINE config 4 in the same run as the weak line: 2^total_log2n points IN TOTAL, sharded evenly over the ranks,
+    `steps` such MSMs as one batch (one all-gather of steps x 144 B per rank).  Rank 0 then reduces MSM 0's whole input
+    alone on its GPU and compares: the N-GPU result must be the 1-GPU result."""
+    from snark_verifier_amd.distributed import gpu_sharded_msm_batch
+
+    total = 1 << total_log2n
+    if total % world:
+        return {"skipped": "the world size does not divide 2^%d" % total_log2n}
+    n = total // world
+    nsets = min(steps, 3)
+    d_s = [torch.empty(32 * n, dtype=torch.uint8, device=dev) for _ in range(nsets)]
+    d_p = [torch.empty(64 * n, dtype=torch.uint8, device=dev) for _ in range(nsets)]
+    dev_sync()
+    for k in range(nsets):  # MSM k = points [k total, (k + 1) total) of the seeded streams; this rank holds its n of them
+        ctx.sample_scalars_dev(0x5EED0011, n, d_s[k].data_ptr(), first=k * total + rank * n)
+        ctx.sample_points_dev(0x5EED0012, n, d_p[k].data_ptr(), first=k * total + rank * n)
+    ctx.sync()
+
+    def run():
+        return gpu_sharded_msm_batch(ctx, [d_s[i % nsets] for i in range(steps)], [d_p[i % nsets] for i in range(steps)],
+                                     [n] * steps, window_bits, stream=stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        dev_sync()
+
+    res = run()  # initialisation (scratch) + warm-up
+    barrier()
+    res = run()
+    barrier()
+    t0 = time.perf_counter()
+    res = run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    got = bytes(res.cpu().numpy())
+    out = {"metric": "BN254 G1 MSM points/sec at 2^%d IN TOTAL (BASELINE configs[3])" % total_log2n, "scaling": "strong",
+           "value": total * steps / dt, "unit": "points/s", "n_gpus": world, "points_per_gpu": n, "steps": steps,
+           "ms_per_step": dt / steps * 1e3, "estimator": "one timed region of %d MSMs after one warm-up region, max over ranks" % steps,
+           "result": got[:64].hex()}
+    if rank == 0 and not dry:
+        if world > 1:  # the whole of MSM 0 on this one GPU
+            s = torch.empty(32 * total, dtype=torch.uint8, device=dev)
+            p = torch.empty(64 * total, dtype=torch.uint8, device=dev)
+            dev_sync()
+            ctx.sample_scalars_dev(0x5EED0011, total, s.data_ptr(), first=0)
+            ctx.sample_points_dev(0x5EED0012, total, p.data_ptr(), first=0)
+        else:
+            s, p = d_s[0], d_p[0]
+        o = torch.zeros(64, dtype=torch.uint8, device=dev)
+        dev_sync()
+        ctx.msm_pippenger_dev(s.data_ptr(), p.data_ptr(), total, o.data_ptr(), window_bits)
+        ctx.sync()
+        out["matches_one_gpu_single_call"] = bytes(o.cpu().numpy()) == got[:64]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -500,7 +794,23 @@ def main():
                     help="0 (default): the K timed steps are ONE batch call (snarkv_g1_msm_pippenger_many_dev: the library "
                          "pipelines them).  N >= 1: N independent single-MSM calls kept in flight instead (one context + HIP "
                          "stream each; 1 = strictly sequential) -- the round-1 / early round-2 way, kept for comparison")
+    ap.add_argument("--transport", choices=("auto", "rccl", "gloo"), default=None,
+                    help="N > 1: how the 144-byte partials travel between the ranks.  auto (default): RCCL (torch's \"nccl\" "
+                         "backend) over xGMI, probed at start-up (the dry run defaults to gloo); if any rank cannot open it, ALL ranks fall back to a "
+                         "host-staged gloo all-gather, and the line says so.  rccl: no fallback.  gloo: host-staged only")
+    ap.add_argument("--no-strong", action="store_true", help="skip the config-4 leg (2^24 points IN TOTAL over the ranks)")
+    ap.add_argument("--strong-total-log2n", type=int, default=24)
+    ap.add_argument("--no-mgpu-leg", action="store_true", help="skip the single-process snarkv_mgpu_* leg")
+    ap.add_argument("--mgpu-leg", action="store_true",
+                    help="INTERNAL: run only the single-process multi-GPU leg over devices 0..gpus-1 and print its JSON")
     args = ap.parse_args()
+
+    if args.mgpu_leg:
+        print(json.dumps(mgpu_leg(args.gpus, args.steps, args.log2n, args.window_bits)), flush=True)
+        return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # a plain `python bench.py --gpus N`: launch the N ranks ourselves and relay rank 0's line
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     import contextlib
 
@@ -512,9 +822,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if args.gpus != world and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is what runs\n" % (args.gpus, world))
     dry = bool(args.dry_run_doubles)
     if dry:  # CPU doubles of the device context: the control flow of the N > 1 path without a GPU (see --dry-run-doubles)
         import importlib.util
@@ -540,15 +849,20 @@ def main():
     use_dist = world > 1 or args.force_dist
     if dry and not use_dist:
         raise SystemExit("--dry-run-doubles exercises the multi-process path: launch with torch.distributed.run or add --force-dist")
+    transport = {"kind": None}
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if dry:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # control plane (barriers, max-over-ranks, the fallback agreement): gloo, which needs nothing from the GPUs;
+        # data plane (the partials): RCCL, opened and probed behind it -- see open_data_plane
+        import datetime
+
+        # a probe that hangs is abandoned by open_data_plane; RCCL's watchdog must not take the process down meanwhile
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=30))
+        transport = open_data_plane(torch, dist, args.transport or ("gloo" if dry else "auto"), local_rank, world)
 
     strong = args.total_log2n > 0
     if strong:
@@ -626,6 +940,8 @@ def main():
                                         args.window_bits, stream=streams[0])
             run_batch.last = res
 
+    from snark_verifier_amd.distributed import all_gather_bytes
+
     def step():
         k = step_no[0] % inflight
         step_no[0] += 1
@@ -637,7 +953,7 @@ def main():
             with on_stream(streams[k]):
                 ctxs[k].msm_pippenger_partial_dev(d_scalars_k[k].data_ptr(), d_points_k[k].data_ptr(), n,
                                                   partials[k].data_ptr(), args.window_bits)
-                dist.all_gather_into_tensor(gathereds[k], partials[k])
+                gathereds[k].copy_(all_gather_bytes(partials[k]))  # RCCL, or host-staged gloo: both ordered on this stream
                 ctxs[k].fold_partials_dev(gathereds[k].data_ptr(), world, outs[k].data_ptr())
 
     def barrier():
@@ -734,15 +1050,24 @@ def main():
         host_res = host_resident_metrics(sv, torch, ctx, d_scalars_k, d_points_k, n, args.steps, slot_results, nsets)
     rccl_ranks_seen = None
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # (control plane)
         dt = float(t.item())
-        # how many ranks the communicator really spans: a sum of ones over RCCL (gloo in the dry run)
-        ones = torch.ones(1, dtype=torch.int32, device=dev)
-        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        # how many ranks the DATA plane really spans: a sum of ones over the group the partials travelled on
+        ones = torch.ones(1, dtype=torch.int32, device=dev if transport["kind"] == "rccl" else "cpu")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM, group=transport.get("group"))
         rccl_ranks_seen = int(ones.item())
     result_hex = bytes(out.cpu().numpy()).hex()
 
+    # BASELINE config 4 (2^24 points IN TOTAL, strong scaling) in the same run, on every world size
+    strong_res = None
+    if not strong and not args.no_strong and batch and (not dry or args.strong_total_log2n < 20):
+        for c in ctxs[1:]:
+            c.sync()
+        strong_res = strong_leg(torch, dist, sv, ctx, streams[0], world, rank, args.strong_total_log2n, max(2, min(args.steps, 5)),
+                                args.window_bits, dry, dev, dev_sync)
+
+    line = None
     if rank == 0:
         stages = {k: v / stage_cnt for k, v in stage_sum.items()}
         dom = max((k for k in stages if k != "total"), key=lambda k: stages[k])
@@ -789,7 +1114,13 @@ def main():
                                                            # in-flight contexts; always on a batch's jobs); the single-MSM latency and
                                                            # the sequential stage times are taken without it
                 "single_msm_latency_ms": lat_ms,
-                "rccl_ranks_seen": rccl_ranks_seen,  # sum of ones over the process group (null: single process, no collective)
+                "rccl_ranks_seen": rccl_ranks_seen if transport["kind"] == "rccl" else None,  # sum of ones over the RCCL group
+                "data_plane_ranks_seen": rccl_ranks_seen,  # ... over whatever group the partials travelled on (null: one process)
+                "transport": None if not use_dist else {
+                    "kind": "RCCL all-gather over xGMI (torch.distributed backend nccl)" if transport["kind"] == "rccl"
+                            else "gloo all-gather, HOST-STAGED (partials copied to the host and back)",
+                    "requested": transport.get("requested"), "fallback_reason": transport.get("why"),
+                    "probe_seconds": transport.get("probe_seconds"), "control_plane": "gloo"},
                 "result": result_hex,
             },
             "roofline": {
@@ -919,11 +1250,37 @@ def main():
                     "aggregate_1024_proofs_pipelined": sec.get("aggregate_1024_proofs_pipelined", {}).get("proofs_per_s"),
                     "aggregate_1024_proofs_merged": sec.get("aggregate_1024_proofs_merged", {}).get("proofs_per_s")},
             }
-        print(json.dumps(line), flush=True)
+        if use_dist and not dry and world > 1 and batch:
+            # the N-GPU result against ONE GPU: rank 0 samples job 0's points of ALL ranks ([0, N n) of the seeded streams)
+            # and reduces them alone
+            s_all = torch.empty(32 * n * world, dtype=torch.uint8, device=dev)
+            p_all = torch.empty(64 * n * world, dtype=torch.uint8, device=dev)
+            o_all = torch.zeros(64, dtype=torch.uint8, device=dev)
+            dev_sync()
+            ctx.sample_scalars_dev(0x5EED0001, n * world, s_all.data_ptr(), first=0)
+            ctx.sample_points_dev(0x5EED0002, n * world, p_all.data_ptr(), first=0)
+            ctx.msm_pippenger_dev(s_all.data_ptr(), p_all.data_ptr(), n * world, o_all.data_ptr(), args.window_bits)
+            ctx.sync()
+            line["config"]["result_matches_one_gpu_recompute"] = bytes(o_all.cpu().numpy()).hex() == result_hex
+            del s_all, p_all
+        if strong_res is not None:
+            line["config4_strong"] = strong_res
 
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if not dry and not args.no_mgpu_leg:
+            # the single-process form of the same batch (snarkv_mgpu_*), in a process of its own, after the ranks have left
+            if use_dist:
+                time.sleep(2.0)  # the other ranks' processes release their GPUs
+            line["single_process_mgpu"] = run_mgpu_leg_subprocess(world, args.steps, args.log2n, args.window_bits)
+        if "named_configs" in line:  # keep it the LAST key of the line
+            line["named_configs"] = line.pop("named_configs")
+        print(json.dumps(line), flush=True)
+    if transport.get("probe_hung"):
+        sys.stdout.flush()
+        os._exit(0)  # an abandoned RCCL probe thread must not hold the interpreter at shutdown
 
 
 if __name__ == "__main__":

@@ -358,6 +358,16 @@ int snarkv_g1_msm_pippenger_mgpu(snarkv_mgpu* mg, const uint8_t* scalars32, cons
 /* shards already resident: d_scalars32[g] / d_points64[g] on rank g's device, counts[g] points (0 allowed) */
 int snarkv_g1_msm_pippenger_mgpu_dev(snarkv_mgpu* mg, const void* const* d_scalars32, const void* const* d_points64,
                                      const size_t* counts, int window_bits, int variant, uint8_t out64[64]);
+/* A BATCH of `jobs` MSMs, every one sharded over the ranks, with ONE exchange for the whole batch (jobs x 144 bytes per
+ * rank) -- the single-process form of what `bench.py --gpus N` times with one process per GPU.  Rank g's shard of job j:
+ * d_scalars32[g * jobs + j] / d_points64[g * jobs + j] on rank g's device, counts[g * jobs + j] points (0 allowed as long
+ * as every job has a point somewhere).  Each rank runs the batch pipeline of snarkv_g1_msm_pippenger_many_partial_dev
+ * (enqueued by a host thread of its own), the partials travel by the handle's transport, out64s[j] = job j's affine
+ * result (host memory, jobs x 64 bytes); every rank's device holds the results too (snarkv_mgpu_results_many_dev). */
+int snarkv_g1_msm_pippenger_many_mgpu_dev(snarkv_mgpu* mg, size_t jobs, const void* const* d_scalars32,
+                                          const void* const* d_points64, const size_t* counts, int window_bits,
+                                          uint8_t* out64s);
+const void* snarkv_mgpu_results_many_dev(const snarkv_mgpu* mg, int rank);
 /* decide_all with the accumulators sharded over the ranks; returns 1 iff all accepted, ok[i] per accumulator */
 int snarkv_kzg_decide_batch_mgpu(snarkv_mgpu* mg, const uint8_t g1_64[64], const uint8_t g2_128[128],
                                  const uint8_t s_g2_128[128], const uint8_t* accs128, size_t m, uint8_t* ok);

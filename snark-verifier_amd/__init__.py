@@ -15,7 +15,8 @@ import os as _os
 # one-workgroup pairing deciders) that only fill the GPU when many jobs overlap: with 16 queues 16 jobs in flight verify
 # 2.9 x 10^5 proofs/s in 64-proof jobs against 1.15 x 10^5 with 4 (profiles/r03_agg_hw_queues.txt); the large-MSM batch
 # (5 streams) is level to 1 % better.  Read by the HIP runtime at its first call, so it is set here, before the library
-# is loaded; an explicit setting of the caller wins.  C / Rust callers: libsnarkv_amd.so does the same in a constructor.
+# is loaded; an explicit setting of the caller wins.  C / Rust callers set it themselves before their first HIP call
+# (INTEGRATION.md): the library does NOT touch the environment (csrc/capi.hip).
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from ._lib import (  # noqa: F401,E402
@@ -25,6 +26,7 @@ from ._lib import (  # noqa: F401,E402
     MultiGpu,
     PoseidonSpec,
     SnarkvError,
+    last_error,
     lib_path,
     load_library,
     SNARKV_FLAG_VALIDATE,
@@ -49,6 +51,7 @@ __all__ = [
     "MultiGpu",
     "PoseidonSpec",
     "SnarkvError",
+    "last_error",
     "lib_path",
     "load_library",
     "SNARKV_FLAG_VALIDATE",

@@ -102,6 +102,8 @@ _SIGNATURES = {
     "snarkv_mgpu_result_dev": (_vp, [_vp, _int]),
     "snarkv_g1_msm_pippenger_mgpu": (_int, [_vp, _cp, _cp, _sz, _int, _vp]),
     "snarkv_g1_msm_pippenger_mgpu_dev": (_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_sz), _int, _int, _vp]),
+    "snarkv_g1_msm_pippenger_many_mgpu_dev": (_int, [_vp, _sz, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_sz), _int, _vp]),
+    "snarkv_mgpu_results_many_dev": (_vp, [_vp, _int]),
     "snarkv_kzg_decide_batch_mgpu": (_int, [_vp, _cp, _cp, _cp, _cp, _sz, _vp]),
     "snarkv_g1_msm_bucket_geometry": (_int, [_sz, _int, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
     "snarkv_g1_msm_fill_buckets_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
@@ -162,6 +164,11 @@ def load_library():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def last_error():
+    """text of the calling thread's last library error (`snarkv_last_error()`)"""
+    return load_library().snarkv_last_error().decode(errors="replace")
 
 
 def _check(rc):
@@ -252,6 +259,23 @@ class MultiGpu:
         out = ctypes.create_string_buffer(64)
         _check(self._lib.snarkv_g1_msm_pippenger_mgpu_dev(self._h, ds, dp, cn, window_bits, variant, out))
         return out.raw
+
+    def msm_pippenger_many_dev(self, d_scalars, d_points, counts, window_bits=0):
+        """A batch of K MSMs, every one sharded over the ranks, ONE exchange for the batch.  `d_scalars[g][j]` /
+        `d_points[g][j]` = rank g's shard of job j (device pointers on rank g's device), `counts[g][j]` its points.
+        Returns the K affine results (64 bytes each)."""
+        w, k = self.world, len(counts[0])
+        flat = lambda rows: [rows[g][j] for g in range(w) for j in range(k)]  # noqa: E731
+        ds = (ctypes.c_void_p * (w * k))(*[int(x) if x else None for x in flat(d_scalars)])
+        dp = (ctypes.c_void_p * (w * k))(*[int(x) if x else None for x in flat(d_points)])
+        cn = (ctypes.c_size_t * (w * k))(*flat(counts))
+        out = ctypes.create_string_buffer(64 * k)
+        _check(self._lib.snarkv_g1_msm_pippenger_many_mgpu_dev(self._h, k, ds, dp, cn, window_bits, out))
+        return [out.raw[64 * j:64 * j + 64] for j in range(k)]
+
+    def results_many_dev(self, rank):
+        """device pointer of rank's copy of the last batch's results (K x 64 bytes)"""
+        return self._lib.snarkv_mgpu_results_many_dev(self._h, rank)
 
     def decide_batch(self, g1, g2, s_g2, accs):
         accs = _as_bytes(accs)

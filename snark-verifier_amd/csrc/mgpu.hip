@@ -35,6 +35,7 @@
 #include <algorithm>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "ctx.hpp"
 
@@ -46,6 +47,12 @@ struct snarkv_mgpu {
   std::vector<void*> d_part;        // per rank: its 144-byte partial
   std::vector<void*> d_result;      // per rank: the 64-byte affine result of the last MSM (all-reduce semantics)
   std::vector<void*> d_gather_all;  // RCCL transport: per rank world x 144 B
+  // the batch entry point (snarkv_g1_msm_pippenger_many_mgpu_dev): per rank `many_cap` jobs' worth of
+  std::vector<void*> d_parts_many;   //   its own partials                 [job][144]
+  std::vector<void*> d_gather_many;  //   every rank's partials as gathered [rank][job][144]   (rank 0 only with peer copies)
+  std::vector<void*> d_byjob_many;   //   ... transposed for the fold       [job][rank][144]   (rank 0 only with peer copies)
+  std::vector<void*> d_results_many; //   the affine results                [job][64]
+  size_t many_cap = 0;
   std::vector<snarkv_dk*> dk;       // decide: one prepared key per rank (lazily, keyed by the last key bytes)
   uint8_t dk_bytes[320];
   bool dk_valid = false;
@@ -235,6 +242,148 @@ static int msm_bucket_sharded(snarkv_mgpu* mg, const void* const* d_s, const voi
   return rc;
 }
 
+// [rank][job][144 B] -> [job][rank][144 B]: one 4-byte word per lane (the gathered partials of a batch, before the folds)
+__global__ void k_transpose_partials(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t world, uint32_t jobs) {
+  constexpr uint32_t W = SNARKV_G1_PARTIAL_BYTES / 4;
+  const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= world * jobs * W) return;
+  const uint32_t w = id % W, j = (id / W) % jobs, g = id / (W * jobs);
+  out[((size_t)j * world + g) * W + w] = in[id];
+}
+
+static int many_reserve(snarkv_mgpu* mg, size_t jobs) {
+  if (jobs <= mg->many_cap) return SNARKV_OK;
+  const int world = (int)mg->ctx.size();
+  for (int g = 0; g < world; ++g) {  // queued work may still read the old buffers
+    SNARKV_HIP(hipSetDevice(mg->ctx[g]->device));
+    SNARKV_HIP(hipStreamSynchronize(mg->ctx[g]->stream));
+  }
+  auto regrow = [&](std::vector<void*>& v, size_t bytes) -> int {
+    v.resize(world, nullptr);
+    for (int g = 0; g < world; ++g) {
+      SNARKV_HIP(hipSetDevice(mg->ctx[g]->device));
+      if (v[g]) SNARKV_HIP(hipFree(v[g]));
+      v[g] = nullptr;
+      SNARKV_HIP(hipMalloc(&v[g], bytes));
+    }
+    return SNARKV_OK;
+  };
+  const size_t cap = std::max<size_t>(jobs, 32);
+  mg->many_cap = 0;
+  SNARKV_TRY(regrow(mg->d_parts_many, cap * SNARKV_G1_PARTIAL_BYTES));
+  SNARKV_TRY(regrow(mg->d_gather_many, cap * world * SNARKV_G1_PARTIAL_BYTES));
+  SNARKV_TRY(regrow(mg->d_byjob_many, cap * world * SNARKV_G1_PARTIAL_BYTES));
+  SNARKV_TRY(regrow(mg->d_results_many, cap * 64));
+  mg->many_cap = cap;
+  return SNARKV_OK;
+}
+
+// rank g's K partials (its shard of every job): one batch call when every shard is non-empty, else job by job with the
+// identity (ZZ = 0) in the empty slots -- an empty shard must never reach the batch call (SNARKV_ERR_EMPTY)
+static int many_partials_rank(snarkv_mgpu* mg, int g, size_t jobs, const void* const* d_s, const void* const* d_p,
+                              const size_t* counts, int window_bits) {
+  snarkv_ctx* c = mg->ctx[g];
+  SNARKV_HIP(hipSetDevice(c->device));
+  bool all_live = true;
+  for (size_t j = 0; j < jobs; ++j) all_live = all_live && counts[j] != 0;
+  if (all_live) return launch_msm_pippenger_many(c, jobs, d_s, d_p, counts, window_bits, mg->d_parts_many[g], true);
+  SNARKV_HIP(hipMemsetAsync(mg->d_parts_many[g], 0, jobs * SNARKV_G1_PARTIAL_BYTES, c->stream));
+  for (size_t j = 0; j < jobs; ++j)
+    if (counts[j])
+      SNARKV_TRY(launch_msm_pippenger_auto(c, d_s[j], d_p[j], counts[j], window_bits,
+                                           (uint8_t*)mg->d_parts_many[g] + j * SNARKV_G1_PARTIAL_BYTES, true));
+  return SNARKV_OK;
+}
+
+static int transpose_fold(snarkv_mgpu* mg, int g, size_t jobs) {
+  const int world = (int)mg->ctx.size();
+  snarkv_ctx* c = mg->ctx[g];
+  SNARKV_HIP(hipSetDevice(c->device));
+  const uint32_t words = (uint32_t)(world * jobs * (SNARKV_G1_PARTIAL_BYTES / 4));
+  hipLaunchKernelGGL(k_transpose_partials, dim3((words + 255) / 256), dim3(256), 0, c->stream,
+                     (const uint32_t*)mg->d_gather_many[g], (uint32_t*)mg->d_byjob_many[g], (uint32_t)world, (uint32_t)jobs);
+  SNARKV_HIP(hipGetLastError());
+  return launch_fold_partials_many(c, mg->d_byjob_many[g], (size_t)world, jobs, mg->d_results_many[g]);
+}
+
+// K jobs, each sharded over the ranks, ONE exchange for the whole batch (K x 144 B per rank): the single-process form of
+// snark-verifier_amd/distributed.py::gpu_sharded_msm_batch.  The ranks' batches are enqueued by one host thread each --
+// a 20-job batch is ~400 launches per rank, and one thread walking eight ranks would start the last of them several
+// milliseconds after the first.
+static int msm_many_point_sharded(snarkv_mgpu* mg, size_t jobs, const void* const* d_s, const void* const* d_p,
+                                  const size_t* counts, int window_bits, uint8_t* out64s) {
+  const int world = (int)mg->ctx.size();
+  SNARKV_TRY(many_reserve(mg, jobs));
+  std::vector<int> rcs(world, SNARKV_OK);
+  std::vector<std::string> errs(world);
+  auto run_rank = [&](int g) {
+    rcs[g] = many_partials_rank(mg, g, jobs, d_s + (size_t)g * jobs, d_p + (size_t)g * jobs, counts + (size_t)g * jobs, window_bits);
+    if (rcs[g] < 0) errs[g] = snarkv_last_error();  // (thread-local: carried to the caller's thread below)
+  };
+  if (world == 1) {
+    run_rank(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int g = 0; g < world; ++g) th.emplace_back(run_rank, g);
+    for (auto& t : th) t.join();
+  }
+  for (int g = 0; g < world; ++g)
+    if (rcs[g] < 0) {
+      set_last_error("mgpu rank %d: %s", g, errs[g].c_str());
+      for (int h = 0; h < world; ++h) {  // nothing of the failed batch stays queued behind the caller's back
+        (void)hipSetDevice(mg->ctx[h]->device);
+        (void)hipStreamSynchronize(mg->ctx[h]->stream);
+      }
+      return rcs[g];
+    }
+  const size_t row = jobs * SNARKV_G1_PARTIAL_BYTES;
+  snarkv_ctx* c0 = mg->ctx[0];
+  if (mg->transport == SNARKV_MGPU_TRANSPORT_RCCL) {
+    RcclApi* nc = rccl_api();
+    if (!nc || (int)mg->comms.size() != world) {
+      set_last_error("mgpu: RCCL transport selected but not initialised");
+      return SNARKV_ERR_DEVICE;
+    }
+    int rc = nc->GroupStart();
+    hipError_t herr = hipSuccess;
+    for (int g = 0; g < world && rc == 0 && herr == hipSuccess; ++g) {
+      herr = hipSetDevice(mg->ctx[g]->device);
+      if (herr != hipSuccess) break;
+      rc = nc->AllGather(mg->d_parts_many[g], mg->d_gather_many[g], row, kNcclUint8, mg->comms[g], mg->ctx[g]->stream);
+    }
+    int rc2 = nc->GroupEnd();
+    if (herr != hipSuccess) {
+      set_last_error("mgpu: hipSetDevice inside the all-gather group: %s", hipGetErrorString(herr));
+      return SNARKV_ERR_DEVICE;
+    }
+    if (rc != 0 || rc2 != 0) {
+      set_last_error("mgpu: ncclAllGather failed: %s", nc->GetErrorString ? nc->GetErrorString(rc ? rc : rc2) : "?");
+      return SNARKV_ERR_DEVICE;
+    }
+    for (int g = 0; g < world; ++g) SNARKV_TRY(transpose_fold(mg, g, jobs));  // every rank folds: identical results everywhere
+  } else {
+    for (int g = 0; g < world; ++g) {
+      snarkv_ctx* c = mg->ctx[g];
+      SNARKV_HIP(hipSetDevice(c->device));
+      SNARKV_HIP(hipMemcpyPeerAsync((char*)mg->d_gather_many[0] + (size_t)g * row, c0->device, mg->d_parts_many[g], c->device, row,
+                                    c->stream));
+      if (g != 0) SNARKV_TRY(wait_for(mg, 0, g));
+    }
+    SNARKV_TRY(transpose_fold(mg, 0, jobs));
+    for (int g = 1; g < world; ++g)
+      SNARKV_HIP(hipMemcpyPeerAsync(mg->d_results_many[g], mg->ctx[g]->device, mg->d_results_many[0], c0->device, jobs * 64, c0->stream));
+  }
+  SNARKV_HIP(hipSetDevice(c0->device));
+  SNARKV_HIP(hipMemcpyAsync(out64s, mg->d_results_many[0], jobs * 64, hipMemcpyDeviceToHost, c0->stream));
+  SNARKV_HIP(hipStreamSynchronize(c0->stream));
+  if (mg->transport == SNARKV_MGPU_TRANSPORT_RCCL)
+    for (int g = 1; g < world; ++g) {
+      SNARKV_HIP(hipSetDevice(mg->ctx[g]->device));
+      SNARKV_HIP(hipStreamSynchronize(mg->ctx[g]->stream));
+    }
+  return SNARKV_OK;
+}
+
 }  // namespace snarkv
 
 using namespace snarkv;
@@ -372,6 +521,11 @@ void snarkv_mgpu_destroy(snarkv_mgpu* mg) {
     (void)hipSetDevice(mg->ctx[g]->device);
     (void)hipFree(mg->d_gather_all[g]);
   }
+  for (auto* v : {&mg->d_parts_many, &mg->d_gather_many, &mg->d_byjob_many, &mg->d_results_many})
+    for (size_t g = 0; g < v->size(); ++g) {
+      (void)hipSetDevice(mg->ctx[g]->device);
+      if ((*v)[g]) (void)hipFree((*v)[g]);
+    }
   if (RcclApi* nc = mg->comms.empty() ? nullptr : rccl_api())
     for (void* c : mg->comms)
       if (c) (void)nc->CommDestroy(c);
@@ -409,6 +563,28 @@ int snarkv_g1_msm_pippenger_mgpu_dev(snarkv_mgpu* mg, const void* const* d_scala
   if (total == 0) return SNARKV_ERR_EMPTY;  // reference panics: msm.rs:265
   return variant == 0 ? msm_point_sharded(mg, d_scalars32, d_points64, counts, window_bits, out64)
                       : msm_bucket_sharded(mg, d_scalars32, d_points64, counts, total, window_bits, out64);
+}
+
+int snarkv_g1_msm_pippenger_many_mgpu_dev(snarkv_mgpu* mg, size_t jobs, const void* const* d_scalars32,
+                                          const void* const* d_points64, const size_t* counts, int window_bits,
+                                          uint8_t* out64s) {
+  if (!mg || !d_scalars32 || !d_points64 || !counts || !out64s) return SNARKV_ERR_ARG;
+  if (jobs == 0) return SNARKV_ERR_EMPTY;
+  const int world = (int)mg->ctx.size();
+  for (size_t j = 0; j < jobs; ++j) {
+    size_t total = 0;
+    for (int g = 0; g < world; ++g) {
+      const size_t i = (size_t)g * jobs + j;
+      if (counts[i] && (!d_scalars32[i] || !d_points64[i])) return SNARKV_ERR_ARG;
+      total += counts[i];
+    }
+    if (total == 0) return SNARKV_ERR_EMPTY;  // reference panics on an empty MSM: msm.rs:265
+  }
+  return msm_many_point_sharded(mg, jobs, d_scalars32, d_points64, counts, window_bits, out64s);
+}
+
+const void* snarkv_mgpu_results_many_dev(const snarkv_mgpu* mg, int rank) {
+  return (mg && rank >= 0 && rank < (int)mg->d_results_many.size()) ? mg->d_results_many[rank] : nullptr;
 }
 
 int snarkv_g1_msm_pippenger_mgpu(snarkv_mgpu* mg, const uint8_t* scalars32, const uint8_t* points64, size_t n, int variant,

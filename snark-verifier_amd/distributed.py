@@ -16,6 +16,16 @@ from dataclasses import dataclass
 from typing import Callable
 
 
+_DATA_GROUP = None  # process group the device payloads travel on (None: the default group)
+
+
+def set_data_group(group):
+    """Route the device-side all-gathers over `group` (e.g. an RCCL group next to a gloo default group that carries the
+    control traffic: barriers, timings, the fallback agreement of bench.py).  None restores the default group."""
+    global _DATA_GROUP
+    _DATA_GROUP = group
+
+
 def all_gather_bytes(part):
     """every rank's `part` (uint8, same length), concatenated in rank order, on `part`'s device.  RCCL ("nccl") gathers device
     tensors directly; any other backend (gloo: CPU ranks, or several processes sharing ONE GPU, which RCCL refuses) is
@@ -24,14 +34,15 @@ def all_gather_bytes(part):
     import torch.distributed as dist
 
     world = dist.get_world_size()
-    if part.device.type != "cuda" or dist.get_backend() == "nccl":
+    group = _DATA_GROUP if part.device.type == "cuda" else None
+    if part.device.type != "cuda" or dist.get_backend(group) == "nccl":
         out = torch.empty(world * part.numel(), dtype=torch.uint8, device=part.device)
-        dist.all_gather_into_tensor(out, part)
+        dist.all_gather_into_tensor(out, part, group=group)
         return out
     torch.cuda.current_stream().synchronize()
     host = part.cpu()
     out = torch.empty(world * host.numel(), dtype=torch.uint8)
-    dist.all_gather_into_tensor(out, host)
+    dist.all_gather_into_tensor(out, host, group=group)
     return out.to(part.device)
 
 

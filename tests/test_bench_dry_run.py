@@ -16,11 +16,14 @@ import coracle as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(world, extra, port):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world),
-           "--dry-run-doubles", os.path.join(ROOT, "tests", "bench_doubles.py")] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+def _run(world, extra, port, launcher=True):
+    cmd = [sys.executable]
+    if launcher:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dry-run-doubles", os.path.join(ROOT, "tests", "bench_doubles.py")] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # ONE line, from rank 0 only
@@ -39,7 +42,9 @@ def test_weak_scaling_line_from_n_ranks(world):
     assert abs(d["value"] - world * n * steps / (d["ms_per_step"] * steps * 1e-3)) < 1e-6 * d["value"]  # whole-job aggregate
     assert "DRY RUN" in d["data"] and "cpu_baseline" not in d and "secondary" not in d
     assert "point-sharded x%d" % world in d["config"]["parallelism"]
-    assert d["config"]["rccl_ranks_seen"] == world  # the sum of ones over the process group: the communicator spans every rank
+    # the sum of ones over the group the partials travelled on: it spans every rank -- gloo here, so the RCCL count stays null
+    assert d["config"]["data_plane_ranks_seen"] == world and d["config"]["rccl_ranks_seen"] is None
+    assert "HOST-STAGED" in d["config"]["transport"]["kind"] and d["config"]["transport"]["control_plane"] == "gloo"
     # slot 0 of rank r holds points [r n, (r + 1) n) of the seeded streams: the reported result is the MSM over [0, N n)
     s, p = C.sample_scalars(0x5EED0001, world * n), C.sample_points(0x5EED0002, world * n)
     assert d["config"]["result"] == C.msm_pippenger(s, p, 4).hex()
@@ -57,5 +62,39 @@ def test_inflight_mode_under_dist():
     """`--inflight 2`: single-MSM calls (partial -> all-gather -> fold per step) instead of the batch"""
     d = _run(2, ["--steps", "3", "--warmup", "1", "--log2n", "7", "--inflight", "2"], 38000 + os.getpid() % 1000)
     assert d["n_gpus"] == 2 and d["config"]["msms_in_flight"] == 2
+    s, p = C.sample_scalars(0x5EED0001, 256), C.sample_points(0x5EED0002, 256)
+    assert d["config"]["result"] == C.msm_pippenger(s, p, 4).hex()
+
+
+def test_plain_launch_without_torchrun_starts_the_ranks_itself():
+    """`python bench.py --gpus 2 ...` with WORLD_SIZE unset must MEASURE, not exit: it launches the two
+    ranks under torch.distributed.run itself and relays rank 0's one line, with the launch attempts recorded."""
+    log2n, steps = 8, 2
+    d = _run(2, ["--steps", str(steps), "--warmup", "1", "--log2n", str(log2n)], 0, launcher=False)
+    assert d["n_gpus"] == 2 and d["config"]["data_plane_ranks_seen"] == 2
+    la = d["config"]["launch"]
+    assert la["self_launched"] is True and la["attempts"][0]["rc"] == 0 and len(la["attempts"]) == 1
+    s, p = C.sample_scalars(0x5EED0001, 2 << log2n), C.sample_points(0x5EED0002, 2 << log2n)
+    assert d["config"]["result"] == C.msm_pippenger(s, p, 4).hex()
+
+
+def test_config4_strong_leg_rides_in_the_same_run():
+    """the weak line and BASELINE config 4 (2^k points IN TOTAL over the ranks) come out of ONE run"""
+    d = _run(2, ["--steps", "2", "--warmup", "1", "--log2n", "7", "--strong-total-log2n", "9"], 39000 + os.getpid() % 1000)
+    assert d["scaling"] == "weak"
+    c4 = d["config4_strong"]
+    assert c4["scaling"] == "strong" and c4["n_gpus"] == 2 and c4["points_per_gpu"] == 256
+    assert abs(c4["value"] - 512 * c4["steps"] / (c4["ms_per_step"] * c4["steps"] * 1e-3)) < 1e-6 * c4["value"]
+    s, p = C.sample_scalars(0x5EED0011, 512), C.sample_points(0x5EED0012, 512)
+    assert c4["result"] == C.msm_pippenger(s, p, 4).hex()
+
+
+def test_rccl_probe_failure_makes_every_rank_fall_back_to_gloo():
+    """`--transport auto` on a box where RCCL cannot come up (here: no GPU at all) -- every rank's probe
+    fails, the ranks agree over the gloo control plane, the partials travel host-staged, and the line carries the reason."""
+    d = _run(2, ["--steps", "2", "--warmup", "1", "--log2n", "7", "--transport", "auto", "--no-strong"], 40000 + os.getpid() % 1000)
+    tr = d["config"]["transport"]
+    assert "HOST-STAGED" in tr["kind"] and tr["requested"] == "auto" and "RCCL unavailable on rank(s) [0, 1]" in tr["fallback_reason"]
+    assert d["config"]["data_plane_ranks_seen"] == 2 and d["config"]["rccl_ranks_seen"] is None
     s, p = C.sample_scalars(0x5EED0001, 256), C.sample_points(0x5EED0002, 256)
     assert d["config"]["result"] == C.msm_pippenger(s, p, 4).hex()

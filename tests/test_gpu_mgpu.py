@@ -194,3 +194,77 @@ def test_mgpu_rccl_transport_world_1_and_its_refusals():
     assert "distinct devices" in str(e.value)
     assert mg.msm_pippenger(s, p, 0) == exp  # still on peer copies
     mg.close()
+
+
+def _rank_shards(mg, world, jobs, sizes):
+    """rank g's shard of job j: the reference's ceil chunking of job j's `sizes[j]` points, sampled in place on rank g's
+    device from disjoint ranges of one seeded stream per job; returns (tensors, pointers, counts, whole-job bytes)"""
+    import torch
+
+    keep, ds, dp, cn = [], [], [], []
+    whole = [(C.sample_scalars(0x900 + j, sizes[j]), C.sample_points(0xA00 + j, sizes[j])) for j in range(jobs)]
+    for g in range(world):
+        c = mg.rank_context(g)
+        rs, rp, rc = [], [], []
+        for j in range(jobs):
+            lo, hi = mg.shard(sizes[j], g)
+            m = hi - lo
+            if m == 0:
+                rs.append(None), rp.append(None), rc.append(0)
+                continue
+            s = torch.empty(32 * m, dtype=torch.uint8, device="cuda")
+            p = torch.empty(64 * m, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            c.sample_scalars_dev(0x900 + j, m, s.data_ptr(), first=lo)
+            c.sample_points_dev(0xA00 + j, m, p.data_ptr(), first=lo)
+            c.sync()
+            keep += [s, p]
+            rs.append(s.data_ptr()), rp.append(p.data_ptr()), rc.append(m)
+        ds.append(rs), dp.append(rp), cn.append(rc)
+    return keep, ds, dp, cn, whole
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_mgpu_batch_of_msms_one_exchange_vs_oracle(world):
+    """`snarkv_g1_msm_pippenger_many_mgpu_dev` (the bench's `single_process_mgpu` leg): K jobs, each sharded over the
+    ranks, ONE exchange of K x 144 B per rank, transposed and folded per job -- job by job the bytes of the C oracle on
+    the whole job, on every rank's device too; uniform sizes take the batch pipeline on every rank."""
+    import ctypes
+
+    import torch
+
+    import snark_verifier_amd as sv
+
+    mg = sv.MultiGpu([0] * world)
+    jobs = 5
+    sizes = [1 << 14] * jobs
+    keep, ds, dp, cn, whole = _rank_shards(mg, world, jobs, sizes)
+    exp = [C.msm_pippenger(s, p, 8) for s, p in whole]
+    got = mg.msm_pippenger_many_dev(ds, dp, cn)
+    assert got == exp and len(set(got)) == jobs
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    for r in range(world):
+        tmp = torch.empty(64 * jobs, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        assert hip.hipMemcpy(ctypes.c_void_p(tmp.data_ptr()), ctypes.c_void_p(mg.results_many_dev(r)), 64 * jobs, 3) == 0
+        assert bytes(tmp.cpu().numpy()) == b"".join(exp), r
+    # a second batch on the same handle, more jobs than before (the buffers grow), ragged sizes (every job its own tail)
+    jobs = 37
+    sizes = [1 + 97 * j for j in range(jobs)]  # job 0 has ONE point: with world > 1 the trailing ranks hold empty shards
+    keep, ds, dp, cn, whole = _rank_shards(mg, world, jobs, sizes)
+    assert mg.msm_pippenger_many_dev(ds, dp, cn) == [C.msm_pippenger(s, p, 8) for s, p in whole]
+    mg.close()
+
+
+def test_mgpu_batch_rccl_transport_world_1_and_errors():
+    import snark_verifier_amd as sv
+
+    mg = sv.MultiGpu([0])
+    mg.set_transport(sv.MultiGpu.RCCL)
+    keep, ds, dp, cn, whole = _rank_shards(mg, 1, 3, [5000, 5000, 5000])
+    assert mg.msm_pippenger_many_dev(ds, dp, cn) == [C.msm_pippenger(s, p, 8) for s, p in whole]
+    with pytest.raises(sv.SnarkvError) as e:  # a job with no point on any rank: the reference panics (msm.rs:265)
+        mg.msm_pippenger_many_dev([[ds[0][0], None]], [[dp[0][0], None]], [[5000, 0]])
+    assert e.value.code == -1
+    mg.close()
