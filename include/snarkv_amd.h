@@ -84,8 +84,8 @@ const char* snarkv_last_error(void);
 const char* snarkv_version(void);
 /* Default flags of a context (SNARKV_FLAG_*): OR-ed into the `flags` argument of every call on it, and THE flags of the
  * entry points that have no such argument (`*_dev`, `*_many_*`, the sampling utilities, `snarkv_g1_decompress`).  A
- * `snarkv_mgpu` handle's ranks are contexts of their own (`snarkv_mgpu_ctx`); `bn254_set_flags` sets the process-global
- * context's.  Unknown bits are SNARKV_ERR_ARG. */
+ * `snarkv_mgpu` handle's ranks are contexts of their own (`snarkv_mgpu_ctx`); `bn254_set_flags` /
+ * `bn254_set_thread_flags` set those of the context-free calls.  Unknown bits are SNARKV_ERR_ARG. */
 int snarkv_ctx_set_flags(snarkv_ctx* ctx, uint32_t flags);
 uint32_t snarkv_ctx_get_flags(const snarkv_ctx* ctx);
 
@@ -191,14 +191,31 @@ int snarkv_g1_validate(snarkv_ctx* ctx, const uint8_t* points64, size_t n);
  * front half of a 1 024-proof aggregation spent 2.4 ms there.  SNARKV_OK, or an error code for bad arguments.   */
 int snarkv_g1_decompress(snarkv_ctx* ctx, const uint8_t* in32, size_t n, uint8_t* out64, uint8_t* ok);
 
-/* ---- context-free entry points (process-global default context) -------- */
-int bn254_set_flags(uint32_t flags); /* e.g. SNARKV_FLAG_MONTGOMERY once at start-up: every bn254_* call then speaks halo2curves' in-memory form */
+/* ---- context-free entry points ------------------------------------------ *
+ * `EcPointLoader::multi_scalar_multiplication` has no `&self` (loader.rs:108; the native loader is a unit struct,
+ * native.rs:11-19), so a trait-bound caller reaches the device without a handle.  These forms draw a context (stream +
+ * scratch) from a process-wide POOL per call: SNARKV_DEFAULT_CONTEXTS of them, else GPU_MAX_HW_QUEUES, else 4, created
+ * on demand on device 0.  Calls from different host threads therefore run CONCURRENTLY on different contexts (16
+ * rayon workers in flight = the `aggregate_*_pipelined` figures of bench.py); a thread returns to the context it used
+ * last when that is free; with every context busy a call waits its turn.  All of them are synchronous (results are on
+ * the host on return) and thread-safe. */
+/* process default flags of the context-free calls, e.g. SNARKV_FLAG_MONTGOMERY once at start-up: every bn254_* call then
+ * speaks halo2curves' in-memory form.  Takes effect for calls that START after it returns. */
+int bn254_set_flags(uint32_t flags);
+/* ... and an override for the CALLING THREAD only: flags >= 0 replace the process default for this thread's bn254_*
+ * calls, -1 removes the override.  Returns the previous value (-1 = none).  What a library that shares the process
+ * with other bn254_* users needs (libsnarkv_host.so passes wire-form bytes whatever the application chose above). */
+int64_t bn254_set_thread_flags(int64_t flags);
+uint32_t bn254_get_flags(void); /* what the calling thread's next bn254_* call will use */
+int bn254_default_contexts(int* created, int* cap); /* pool status: contexts created so far / the limit */
 int bn254_g1_msm_naive(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]);
 int bn254_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, const uint32_t* offsets, size_t n_msm,
                          uint8_t* out);
 int bn254_g1_msm_pippenger(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]);
 int bn254_g1_decompress(const uint8_t* in32, size_t n, uint8_t* out64, uint8_t* ok);
-/* snarkv_ctx_host_buffer of the default context (callers serialise their use of it, as they do its calls) */
+/* pinned host memory for the inputs of the context-free calls, owned by the CALLING THREAD (SNARKV_HOST_BUFFERS slots,
+ * grow-only; a pointer stays valid until the same thread asks for the same slot with a larger size): threads pack
+ * side by side without a lock, whatever pool context their calls land on */
 int bn254_host_buffer(int slot, size_t bytes, void** out);
 int bn254_kzg_decide(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],
                      const uint8_t acc128[128]);

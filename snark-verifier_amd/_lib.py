@@ -53,6 +53,9 @@ _SIGNATURES = {
     "bn254_host_buffer": (_int, [_int, _sz, _pp]),
     "snarkv_g1_decompress": (_int, [_vp, _cp, _sz, _vp, _vp]),
     "bn254_g1_decompress": (_int, [_cp, _sz, _vp, _vp]),
+    "bn254_set_thread_flags": (ctypes.c_int64, [ctypes.c_int64]),
+    "bn254_get_flags": (ctypes.c_uint32, []),
+    "bn254_default_contexts": (_int, [ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "snarkv_last_error": (_cp, []),
     "snarkv_version": (_cp, []),
     "snarkv_g1_msm_naive": (_int, [_vp, _cp, _cp, _sz, _u32, _vp]),

@@ -4,6 +4,9 @@
 #include <stdarg.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <vector>
 #include <stdlib.h>
@@ -45,36 +48,113 @@ static int fetch_out(snarkv_ctx* ctx, const void* d, void* host, size_t bytes) {
 // call, so the library does NOT touch it when it is loaded: the caller exports GPU_MAX_HW_QUEUES=16 before its first HIP
 // call (the Python package does so on import unless the variable is set, INTEGRATION.md shows the Rust line).
 
-// The encoding of a call = the context's default flags | the call's own: kept in ctx->mont while the call enqueues its
-// kernels (every launcher reads it), restored on the way out.
-struct CallFlags {
-  snarkv_ctx* c;
-  bool saved;
-  CallFlags(snarkv_ctx* ctx, uint32_t call_flags) : c(ctx), saved(ctx ? ctx->mont : false) {
-    if (c) c->mont = ((c->flags | call_flags) & SNARKV_FLAG_MONTGOMERY) != 0;
+// ---- the context-free entry points' contexts ------------------------------------------------------------------------
+// `EcPointLoader::multi_scalar_multiplication` has no `&self` (loader.rs:108), so a trait-bound Rust caller can only reach
+// the `bn254_*` forms -- and round 4 gave them ONE context behind one mutex: a rayon-parallel caller got one job at a
+// time, a sixteenth of what sixteen explicit contexts deliver.  Now they draw from a POOL of default
+// contexts (a stream + scratch each), checked out per call:
+//   * size: SNARKV_DEFAULT_CONTEXTS, else GPU_MAX_HW_QUEUES (the hardware queues the process's streams are spread over),
+//     else 4 (the runtime's default queue count); contexts are created on demand, never destroyed;
+//   * affinity: a thread comes back to the context it used last when that one is free (warm scratch), else any free
+//     one, else a new one while the pool may grow, else it waits;
+//   * nesting: bn254_kzg_decide -> bn254_kzg_decide_batch runs on the context the outer call holds;
+//   * flags: the process default (bn254_set_flags) or the calling thread's override (bn254_set_thread_flags) is applied
+//     to the context at check-out;
+//   * pinned host buffers (bn254_host_buffer) belong to the calling THREAD, not to a context: what a thread packs is
+//     its own until it asks again, whatever context its next call lands on.
+struct DefaultPool {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<snarkv_ctx*> ctx;
+  std::vector<char> busy;
+  int cap = 0;
+  std::atomic<uint32_t> flags{0};
+};
+static DefaultPool g_pool;
+static thread_local int tl_slot = -1, tl_depth = 0;
+static thread_local snarkv_ctx* tl_held = nullptr;
+static thread_local int64_t tl_flags = -1;  // -1: the process default
+
+static int pool_cap() {
+  for (const char* name : {"SNARKV_DEFAULT_CONTEXTS", "GPU_MAX_HW_QUEUES"})
+    if (const char* e = getenv(name)) {
+      int v = atoi(e);
+      if (v > 0) return std::min(v, 64);
+    }
+  return 4;
+}
+
+struct DefaultLease {
+  snarkv_ctx* c = nullptr;
+  int rc = SNARKV_OK;
+  DefaultLease() {
+    if (tl_depth > 0) {  // nested context-free call: the context the outer call holds
+      c = tl_held;
+      ++tl_depth;
+      return;
+    }
+    std::unique_lock<std::mutex> lk(g_pool.mu);
+    if (g_pool.cap == 0) g_pool.cap = pool_cap();
+    int slot = -1;
+    for (;;) {
+      if (tl_slot >= 0 && tl_slot < (int)g_pool.ctx.size() && !g_pool.busy[tl_slot]) slot = tl_slot;
+      for (int i = 0; slot < 0 && i < (int)g_pool.ctx.size(); ++i)
+        if (!g_pool.busy[i]) slot = i;
+      if (slot >= 0) break;
+      if ((int)g_pool.ctx.size() < g_pool.cap) {
+        snarkv_ctx* fresh = nullptr;
+        rc = snarkv_ctx_create(0, nullptr, &fresh);  // (under the pool lock: at most `cap` times per process)
+        if (rc < 0) return;
+        g_pool.ctx.push_back(fresh);
+        g_pool.busy.push_back(0);
+        slot = (int)g_pool.ctx.size() - 1;
+        break;
+      }
+      g_pool.cv.wait(lk);
+    }
+    g_pool.busy[slot] = 1;
+    c = g_pool.ctx[slot];
+    lk.unlock();
+    tl_slot = slot;
+    tl_held = c;
+    tl_depth = 1;
+    const uint32_t f = tl_flags >= 0 ? (uint32_t)tl_flags : g_pool.flags.load();
+    c->flags = f;
+    c->mont = (f & SNARKV_FLAG_MONTGOMERY) != 0;
   }
-  ~CallFlags() {
-    if (c) c->mont = saved;
+  ~DefaultLease() {
+    if (!c) return;
+    if (--tl_depth > 0) return;
+    tl_held = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(g_pool.mu);
+      g_pool.busy[tl_slot] = 0;
+    }
+    g_pool.cv.notify_one();
   }
 };
-#define SNARKV_CALL_FLAGS(ctx, f) CallFlags _call_flags((ctx), (f))
+#define SNARKV_DEFAULT_LEASE(c)   \
+  DefaultLease _lease;            \
+  if (_lease.rc < 0) return _lease.rc; \
+  snarkv_ctx* c = _lease.c
 
-static std::mutex g_default_mu;
-static snarkv_ctx* g_default_ctx = nullptr;
-// The context-free entry points share ONE context (stream + scratch): calls from different host
-// threads take turns.  Recursive: bn254_kzg_decide -> bn254_kzg_decide_batch.
-static std::recursive_mutex g_default_call_mu;
-#define SNARKV_DEFAULT_CALL_LOCK() std::lock_guard<std::recursive_mutex> _default_call_lock(g_default_call_mu)
-
-static int default_ctx(snarkv_ctx** out) {
-  std::lock_guard<std::mutex> lk(g_default_mu);
-  if (!g_default_ctx) {
-    int rc = snarkv_ctx_create(0, nullptr, &g_default_ctx);
-    if (rc < 0) return rc;
+// pinned host buffers of the context-free callers, one set per THREAD (slots reused when a thread ends; the memory is
+// never returned: like the contexts, it lives as long as the process)
+struct ThreadHostBufs {
+  void* buf[SNARKV_HOST_BUFFERS] = {};
+  size_t cap[SNARKV_HOST_BUFFERS] = {};
+};
+static std::mutex g_hb_mu;
+static std::vector<ThreadHostBufs*> g_hb_free;
+struct ThreadHostBufsRef {
+  ThreadHostBufs* p = nullptr;
+  ~ThreadHostBufsRef() {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_hb_mu);
+    g_hb_free.push_back(p);  // no HIP call at thread exit: the set goes to the next thread that asks
   }
-  *out = g_default_ctx;
-  return SNARKV_OK;
-}
+};
+static thread_local ThreadHostBufsRef tl_hb;
 
 }  // namespace snarkv
 
@@ -770,90 +850,121 @@ int snarkv_g1_validate(snarkv_ctx* ctx, const uint8_t* points64, size_t n) {
 
 // ---- context-free entry points -------------------------------------------
 int bn254_set_flags(uint32_t flags) {
-  SNARKV_DEFAULT_CALL_LOCK();
-  snarkv_ctx* c;
-  SNARKV_TRY(default_ctx(&c));
-  return snarkv_ctx_set_flags(c, flags);
+  if (flags & ~(SNARKV_FLAG_VALIDATE | SNARKV_FLAG_MONTGOMERY)) return SNARKV_ERR_ARG;
+  g_pool.flags.store(flags);  // applied to a pool context when a call checks it out; calls in flight keep theirs
+  return SNARKV_OK;
+}
+
+uint32_t bn254_get_flags(void) { return tl_flags >= 0 ? (uint32_t)tl_flags : g_pool.flags.load(); }
+
+int64_t bn254_set_thread_flags(int64_t flags) {
+  const int64_t before = tl_flags;
+  if (flags >= 0 && (flags & ~(int64_t)(SNARKV_FLAG_VALIDATE | SNARKV_FLAG_MONTGOMERY))) return SNARKV_ERR_ARG;
+  tl_flags = flags < 0 ? -1 : flags;
+  return before;
+}
+
+int bn254_default_contexts(int* created, int* cap) {
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  if (g_pool.cap == 0) g_pool.cap = pool_cap();
+  if (created) *created = (int)g_pool.ctx.size();
+  if (cap) *cap = g_pool.cap;
+  return SNARKV_OK;
 }
 
 int bn254_g1_validate(const uint8_t* points64, size_t n) {
-  SNARKV_DEFAULT_CALL_LOCK();
-  snarkv_ctx* c;
-  SNARKV_TRY(default_ctx(&c));
+  SNARKV_DEFAULT_LEASE(c);
   return snarkv_g1_validate(c, points64, n);
 }
 
 int bn254_kzg_dk_create(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],
                         snarkv_dk** out) {
-  SNARKV_DEFAULT_CALL_LOCK();
-  snarkv_ctx* c;
-  SNARKV_TRY(default_ctx(&c));
+  SNARKV_DEFAULT_LEASE(c);
   return snarkv_dk_create(c, g1_64, g2_128, s_g2_128, 0, out);
 }
 
 int bn254_kzg_dk_decide_batch(const snarkv_dk* dk, const uint8_t* accs128, size_t m, uint8_t* ok) {
-  SNARKV_DEFAULT_CALL_LOCK();
-  snarkv_ctx* c;
-  SNARKV_TRY(default_ctx(&c));
+  SNARKV_DEFAULT_LEASE(c);
   return snarkv_kzg_decide_batch(c, dk, accs128, m, 0, ok);
 }
 
 int bn254_g1_msm_naive(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]) {
-  SNARKV_DEFAULT_CALL_LOCK();
-  snarkv_ctx* c;
-  SNARKV_TRY(default_ctx(&c));
+  SNARKV_DEFAULT_LEASE(c);
   return snarkv_g1_msm_naive(c, scalars32, points64, n, 0, out64);
 }
 
 int bn254_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, const uint32_t* offsets, size_t n_msm,
                          uint8_t* out) {
-  SNARKV_DEFAULT_CALL_LOCK();
-  snarkv_ctx* c;
-  SNARKV_TRY(default_ctx(&c));
+  SNARKV_DEFAULT_LEASE(c);
   return snarkv_g1_msm_batched(c, scalars32, points64, offsets, n_msm, 0, out);
 }
 
 int bn254_g1_decompress(const uint8_t* in32, size_t n, uint8_t* out64, uint8_t* ok) {
-  SNARKV_DEFAULT_CALL_LOCK();
-  snarkv_ctx* c;
-  SNARKV_TRY(default_ctx(&c));
+  SNARKV_DEFAULT_LEASE(c);
   return snarkv_g1_decompress(c, in32, n, out64, ok);
 }
 
 int bn254_host_buffer(int slot, size_t bytes, void** out) {
-  SNARKV_DEFAULT_CALL_LOCK();
-  snarkv_ctx* c;
-  SNARKV_TRY(default_ctx(&c));
-  return snarkv_ctx_host_buffer(c, slot, bytes, out);
+  if (slot < 0 || slot >= SNARKV_HOST_BUFFERS || !out) return SNARKV_ERR_ARG;
+  if (!tl_hb.p) {
+    std::lock_guard<std::mutex> lk(g_hb_mu);
+    if (!g_hb_free.empty()) {
+      tl_hb.p = g_hb_free.back();
+      g_hb_free.pop_back();
+    } else {
+      tl_hb.p = new ThreadHostBufs();
+    }
+  }
+  ThreadHostBufs* hb = tl_hb.p;
+  if (bytes == 0) bytes = 16;
+  if (hb->cap[slot] < bytes) {
+    {
+      SNARKV_DEFAULT_LEASE(c);  // (a HIP device must exist; the allocation itself is not tied to a context)
+      SNARKV_HIP(hipSetDevice(c->device));
+    }
+    if (hb->buf[slot]) SNARKV_HIP(hipHostFree(hb->buf[slot]));
+    hb->buf[slot] = nullptr;
+    hb->cap[slot] = 0;
+    // (no copy out of the old buffer can be queued: the context-free calls return after their result is on the host)
+    const size_t cap = bytes + bytes / 4 + 4096;
+    SNARKV_HIP(hipHostMalloc(&hb->buf[slot], cap, hipHostMallocDefault));
+    hb->cap[slot] = cap;
+  }
+  *out = hb->buf[slot];
+  return SNARKV_OK;
 }
 
 int bn254_g1_msm_pippenger(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]) {
-  SNARKV_DEFAULT_CALL_LOCK();
-  snarkv_ctx* c;
-  SNARKV_TRY(default_ctx(&c));
+  SNARKV_DEFAULT_LEASE(c);
   return snarkv_g1_msm_pippenger(c, scalars32, points64, n, 0, out64);
 }
 
 int bn254_kzg_decide_batch(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],
                            const uint8_t* accs128, size_t m, uint8_t* ok) {
-  SNARKV_DEFAULT_CALL_LOCK();
-  snarkv_ctx* c;
-  SNARKV_TRY(default_ctx(&c));
+  SNARKV_DEFAULT_LEASE(c);
   if (!g1_64 || !g2_128 || !s_g2_128) return SNARKV_ERR_ARG;
   // The reference rebuilds `G2Prepared` on every decide (decider.rs:74); a verifier decides against ONE key, so the last
   // key's line tables are kept (the 320 key bytes + the encoding they were given in are the cache tag).
-  static snarkv_dk* cached = nullptr;
+  // Shared by the pool's contexts (the tables are read-only device memory): looked up under a lock, used outside it; a
+  // replaced key's tables are freed when the last call using them returns.
+  static std::mutex cache_mu;
+  static std::shared_ptr<snarkv_dk> cached;
   static uint8_t tag[321];
   uint8_t now[321];
   memcpy(now, g1_64, 64), memcpy(now + 64, g2_128, 128), memcpy(now + 192, s_g2_128, 128);
   now[320] = c->mont ? 1 : 0;
-  if (!cached || memcmp(tag, now, sizeof now) != 0) {
-    if (cached) snarkv_dk_destroy(cached);
-    cached = nullptr;
-    SNARKV_TRY(snarkv_dk_create(c, g1_64, g2_128, s_g2_128, 0, &cached));
-    memcpy(tag, now, sizeof now);
+  std::shared_ptr<snarkv_dk> dk;
+  {
+    std::lock_guard<std::mutex> lk(cache_mu);
+    if (!cached || memcmp(tag, now, sizeof now) != 0) {
+      snarkv_dk* fresh = nullptr;
+      SNARKV_TRY(snarkv_dk_create(c, g1_64, g2_128, s_g2_128, 0, &fresh));
+      cached = std::shared_ptr<snarkv_dk>(fresh, [](snarkv_dk* p) { snarkv_dk_destroy(p); });
+      memcpy(tag, now, sizeof now);
+    }
+    dk = cached;
   }
-  return snarkv_kzg_decide_batch(c, cached, accs128, m, 0, ok);
+  return snarkv_kzg_decide_batch(c, dk.get(), accs128, m, 0, ok);
 }
 
 int bn254_kzg_decide(const uint8_t g1_64[64], const uint8_t g2_128[128], const uint8_t s_g2_128[128],
@@ -867,41 +978,31 @@ int bn254_kzg_decide(const uint8_t g1_64[64], const uint8_t g2_128[128], const u
 int bn254_poseidon_create(uint32_t t, uint32_t rate, uint32_t r_f, uint32_t r_p, const uint8_t* start,
                           const uint8_t* partial, const uint8_t* end, const uint8_t* mds, const uint8_t* pre_sparse_mds,
                           const uint8_t* sparse_rows, const uint8_t* sparse_col_hats, snarkv_poseidon** out) {
-  SNARKV_DEFAULT_CALL_LOCK();
-  snarkv_ctx* c;
-  SNARKV_TRY(default_ctx(&c));
+  SNARKV_DEFAULT_LEASE(c);
   return snarkv_poseidon_create(c, t, rate, r_f, r_p, start, partial, end, mds, pre_sparse_mds, sparse_rows,
                                 sparse_col_hats, out);
 }
 
 int bn254_ipa_dk_create(const uint8_t* g_points64, size_t n, snarkv_ipa_dk** out) {
-  SNARKV_DEFAULT_CALL_LOCK();
-  snarkv_ctx* c;
-  SNARKV_TRY(default_ctx(&c));
+  SNARKV_DEFAULT_LEASE(c);
   return snarkv_ipa_dk_create(c, g_points64, n, out);
 }
 
 int bn254_ipa_decide_batch(const snarkv_ipa_dk* dk, const uint8_t* xi32, const uint8_t* u64, size_t m, uint8_t* ok) {
-  SNARKV_DEFAULT_CALL_LOCK();
-  snarkv_ctx* c;
-  SNARKV_TRY(default_ctx(&c));
+  SNARKV_DEFAULT_LEASE(c);
   return snarkv_ipa_decide_batch(c, dk, xi32, u64, m, ok);
 }
 
 int bn254_poseidon_transcript_batch(const snarkv_poseidon* ps, const uint8_t* elems, size_t n, size_t L,
                                     const uint32_t* seg_len, size_t S, uint8_t* out) {
-  SNARKV_DEFAULT_CALL_LOCK();
-  snarkv_ctx* c;
-  SNARKV_TRY(default_ctx(&c));
+  SNARKV_DEFAULT_LEASE(c);
   return snarkv_poseidon_transcript_batch(c, ps, elems, n, L, seg_len, S, out);
 }
 
 int bn254_poseidon_read_batch(const snarkv_poseidon* ps, const uint8_t* proofs, size_t n, size_t stride, const uint8_t* lead,
                               size_t n_lead, const uint32_t* layout, size_t L, const uint32_t* point_offsets, size_t P,
                               const uint32_t* seg_len, size_t S, uint8_t* challenges, uint8_t* points64, uint8_t* ok) {
-  SNARKV_DEFAULT_CALL_LOCK();
-  snarkv_ctx* c;
-  SNARKV_TRY(default_ctx(&c));
+  SNARKV_DEFAULT_LEASE(c);
   return snarkv_poseidon_read_batch(c, ps, proofs, n, stride, lead, n_lead, layout, L, point_offsets, P, seg_len, S, challenges,
                                     points64, ok);
 }

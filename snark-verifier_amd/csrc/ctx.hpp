@@ -116,6 +116,33 @@ struct snarkv_dk {
 
 namespace snarkv {
 
+// The encoding of a call = the context's default flags | the call's own: kept in ctx->mont while the call enqueues its
+// kernels (every launcher reads it), restored on the way out.
+struct CallFlags {
+  snarkv_ctx* c;
+  bool saved;
+  CallFlags(snarkv_ctx* ctx, uint32_t call_flags) : c(ctx), saved(ctx ? ctx->mont : false) {
+    if (c) c->mont = ((c->flags | call_flags) & SNARKV_FLAG_MONTGOMERY) != 0;
+  }
+  ~CallFlags() {
+    if (c) c->mont = saved;
+  }
+};
+#define SNARKV_CALL_FLAGS(ctx, f) ::snarkv::CallFlags _call_flags((ctx), (f))
+// Entry points SNARKV_FLAG_MONTGOMERY does NOT cover (the IPA, the Poseidon transcripts: include/snarkv_amd.h): their
+// kernels run in the wire form whatever the context's default says
+struct WireFormScope {
+  snarkv_ctx* c;
+  bool saved;
+  explicit WireFormScope(snarkv_ctx* ctx) : c(ctx), saved(ctx ? ctx->mont : false) {
+    if (c) c->mont = false;
+  }
+  ~WireFormScope() {
+    if (c) c->mont = saved;
+  }
+};
+#define SNARKV_WIRE_FORM(ctx) ::snarkv::WireFormScope _wire_form((ctx))
+
 // Ensure slot capacity; returns device pointer through *out.
 int ctx_reserve(snarkv_ctx* ctx, int slot, size_t bytes, void** out);
 // four lanes (the context's stream + three private sub-contexts) for independent launches: ctx_impl.inc

@@ -93,6 +93,7 @@ int SNARKV_API(ipa_commit_partial_dev)(snarkv_ctx* ctx, const snarkv_ipa_dk* dk,
   if (!ctx || !dk || !xi32 || !d_partial) return SNARKV_ERR_ARG;
   if (dk->device != ctx->device) return SNARKV_ERR_ARG;
   SNARKV_HIP(hipSetDevice(ctx->device));
+  SNARKV_WIRE_FORM(ctx);  // the IPA speaks the wire form whatever the context's default flags say (include/snarkv_amd.h)
   const uint32_t k = dk->k;
   void *d_xi, *d_h;
   SNARKV_TRY(ctx_reserve(ctx, SLOT_IPA_XI, (size_t)k * 32, &d_xi));
@@ -120,6 +121,7 @@ int SNARKV_API(ipa_decide_batch)(snarkv_ctx* ctx, const snarkv_ipa_dk* dk, const
   if (dk->device != ctx->device) return SNARKV_ERR_ARG;
   if (dk->first != 0 || dk->count != ((size_t)1 << dk->k)) return SNARKV_ERR_LENGTH;  // a shard cannot decide alone
   SNARKV_HIP(hipSetDevice(ctx->device));
+  SNARKV_WIRE_FORM(ctx);  // (the lanes take the call's encoding at the fork: ctx_lanes_fork)
   const uint32_t k = dk->k;
   const size_t n = (size_t)1 << k;
   void *d_xi, *d_out;

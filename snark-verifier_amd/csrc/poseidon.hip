@@ -418,6 +418,8 @@ int snarkv_poseidon_read_batch(snarkv_ctx* ctx, const snarkv_poseidon* ps, const
   if (n == 0 || S == 0 || L == 0) return SNARKV_ERR_EMPTY;
   if (n >= ((size_t)1 << 24) || L >= ((size_t)1 << 16) || stride >= ((size_t)1 << 28) || (stride & 15) || P >= ((size_t)1 << 16))
     return SNARKV_ERR_LENGTH;
+  // the gather and decompress kernels index elements / points with 32 bits
+  if (n * L >= ((size_t)1 << 32) || n * P >= ((size_t)1 << 32)) return SNARKV_ERR_LENGTH;
   size_t sum = 0;
   for (size_t q = 0; q < S; ++q) sum += seg_len[q];
   if (sum != L) return SNARKV_ERR_LENGTH;
@@ -467,10 +469,15 @@ int snarkv_poseidon_read_batch(snarkv_ctx* ctx, const snarkv_poseidon* ps, const
     SNARKV_HIP(hipMemcpyAsync(points64, d_pts, n * P * 64, hipMemcpyDeviceToHost, ctx->copy_stream));
     SNARKV_HIP(hipMemcpyAsync(ok, d_ok, n * P, hipMemcpyDeviceToHost, ctx->copy_stream));
   }
-  SNARKV_TRY(snarkv_poseidon_transcript_batch_dev(ctx, ps, d_elems, n, L, dh + L + P, S, d_out));
-  SNARKV_HIP(hipMemcpyAsync(challenges, d_out, n * S * 32, hipMemcpyDeviceToHost, ctx->stream));
-  SNARKV_HIP(hipStreamSynchronize(ctx->stream));
-  if (P) SNARKV_HIP(hipStreamSynchronize(ctx->copy_stream));
+  int rc = snarkv_poseidon_transcript_batch_dev(ctx, ps, d_elems, n, L, dh + L + P, S, d_out);
+  hipError_t e1 = rc == SNARKV_OK ? hipMemcpyAsync(challenges, d_out, n * S * 32, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+  // success or not, nothing queued above may still write the caller's buffers after the return
+  hipError_t e2 = hipStreamSynchronize(ctx->stream);
+  hipError_t e3 = P ? hipStreamSynchronize(ctx->copy_stream) : hipSuccess;
+  if (rc != SNARKV_OK) return rc;
+  SNARKV_HIP(e1);
+  SNARKV_HIP(e2);
+  SNARKV_HIP(e3);
   return SNARKV_OK;
 }
 

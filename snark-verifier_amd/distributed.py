@@ -430,7 +430,8 @@ def gpu_sharded_aggregation(protocol, dk, instances_packed, proofs, mos=0, trans
         return H.plonk_succinct_verify_batch(protocol, dk, ib, H.pack_proofs(proofs[lo:hi]), hi - lo, mos, transcript)
 
     def combine_fn(allb):
-        acc, _ = H.kzg_as_accumulate(allb)
+        # the accumulation transcript is of the proofs' family, as host/aggregation.hpp (Keccak | Poseidon)
+        acc = H.kzg_as_create_proof(allb, H.TRANSCRIPT_EVM if transcript == H.TRANSCRIPT_EVM else H.TRANSCRIPT_POSEIDON)[0]
         return acc, H.kzg_decide(dk, acc)
 
     return ShardedAggregation(verify_fn, combine_fn).run(len(proofs))

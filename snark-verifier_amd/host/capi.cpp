@@ -433,7 +433,7 @@ int snarkv_host_kzg_decide_all(const snarkv_host_dk* dk, const uint8_t* accs128,
     std::vector<uint8_t> ok(m);
     snarkv_dk* h = dk->dk.handle();
     {
-      std::lock_guard<std::mutex> lock(device_mutex());
+      DeviceScope lock;
       int rc = bn254_kzg_dk_decide_batch(h, accs128, m, ok.data());
       if (rc < 0) throw std::runtime_error(std::string("bn254_kzg_dk_decide_batch: ") + snarkv_last_error());
     }

@@ -255,7 +255,7 @@ struct IpaDecidingKey {
         throw Panic("IpaDecidingKey: g must hold 2^k points (reference: assert_eq!(scalars.len(), bases.len()), msm.rs:309)");
       static_assert(sizeof(G1Affine) == 64, "G1Affine is the 64-byte wire form");
       snarkv_ipa_dk* h = nullptr;
-      std::lock_guard<std::mutex> lock(device_mutex());
+      DeviceScope lock;
       if (SNARKV_DEV(ipa_dk_create)(g[0].b, g.size(), &h) != SNARKV_OK)
         throw std::runtime_error(std::string("ipa_dk_create: ") + SNARKV_DEV_LAST_ERROR());
       dk_ = std::shared_ptr<snarkv_ipa_dk>(h, [](snarkv_ipa_dk* p) { SNARKV_DEV_IPA_DK_DESTROY(p); });
@@ -321,7 +321,7 @@ struct IpaAs {
       memcpy(&u[64 * a], accs[a].u.b, 64);
     }
     snarkv_ipa_dk* h = dk.handle();
-    std::lock_guard<std::mutex> lock(device_mutex());
+    DeviceScope lock;
     int rc = SNARKV_DEV(ipa_decide_batch)(h, xi.data(), u.data(), accs.size(), ok.data());
     if (rc != SNARKV_OK) throw std::runtime_error(std::string("ipa_decide_batch: ") + SNARKV_DEV_LAST_ERROR());
     for (uint8_t b : ok)

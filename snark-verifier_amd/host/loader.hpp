@@ -9,7 +9,7 @@
 //   `LoadedEcPoint = C`, `LoadedScalar = F`           G1Affine (64 canonical bytes), Fr
 //
 // `multi_scalar_multiplication` has no `&self` in the reference (loader.rs:108),
-// so the device state is process-global here too (the C ABI's default context).
+// so the device state is process-global here too (the C ABI's pool of default contexts).
 #pragma once
 #include <cstdint>
 #include <algorithm>
@@ -133,7 +133,7 @@ class HostPool {
       std::lock_guard<std::mutex> lk(mu_);  // a worker between its predicate and its wait holds mu_: no lost wake-up
     }
     cv_.notify_all();
-    in_worker() = true;  // the caller's share: its tasks are pool tasks like any other (no device lock, no nested fan-out)
+    in_worker() = true;  // the caller's share: its tasks are pool tasks like any other (no device scope, no nested fan-out)
     work();
     in_worker() = false;
     // close the job, then wait until the workers inside have left
@@ -148,7 +148,7 @@ class HostPool {
     if (err_) std::rethrow_exception(err_);
   }
   // true on the pool's own threads and on a caller while it works on its job (a task that fans out runs inline; a task
-  // must never take the device lock)
+  // must never open a device scope)
   static bool& in_worker() {
     static thread_local bool flag = false;
     return flag;
@@ -242,18 +242,45 @@ inline void parallel_for(size_t n, unsigned threads, F&& fn, size_t grain = 16) 
   HostPool::get().run(n, threads, std::forward<F>(fn));
 }
 
-// The context-free C-ABI entry points share one process-global device context
-// (`multi_scalar_multiplication` has no `&self`, loader.rs:108): host threads
-// that reach the device through the loader take turns.  The lock also covers the default context's pinned host
-// buffers (packing happens under it), and `parallel_for` may be called while holding it: tasks of the pool therefore
-// never take this lock (they are host-only parsing and field algebra).
-inline std::mutex& device_mutex() {
-  static std::mutex m;
-  // lock order: device_mutex -> the pool's submit lock (packing fans out under the device lock).  A pool task that took
-  // the device lock would close the cycle: refuse it loudly instead of deadlocking some day.
-  if (HostPool::in_worker()) throw std::logic_error("device_mutex() from a pool worker: tasks of the host pool must stay host-only");
-  return m;
-}
+// A scope in which the calling thread talks to the device through the context-free C-ABI entry points
+// (`multi_scalar_multiplication` has no `&self`, loader.rs:108).
+//   bn254 flavour: the device library keeps a POOL of default contexts and hands one out per call, and the pinned host
+//     buffers of `bn254_host_buffer` belong to the calling thread -- so host threads reach the device side by side and
+//     the scope is NOT a lock (round 4: one process-wide mutex = one job at a time through the trait boundary).  What it
+//     does: pin THIS thread's bn254_* calls to the wire form (flags 0) whatever the application set with
+//     `bn254_set_flags` -- the mirror hands canonical bytes to the device -- and restore on the way out.
+//   pasta flavour: libsnarkv_pallas.so still has one default context; there the scope is the process-wide lock.
+// Either way tasks of the host pool stay host-only: a worker that blocked on the device would stall every job that
+// shares the pool, so a scope opened from a worker is refused loudly.
+struct DeviceScope {
+  DeviceScope() {
+    if (HostPool::in_worker()) throw std::logic_error("DeviceScope from a pool worker: tasks of the host pool must stay host-only");
+#if defined(SNARKV_HOST_PALLAS)
+    mu().lock();
+#else
+    saved_ = bn254_set_thread_flags(0);
+#endif
+  }
+  ~DeviceScope() {
+#if defined(SNARKV_HOST_PALLAS)
+    mu().unlock();
+#else
+    bn254_set_thread_flags(saved_);
+#endif
+  }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+
+ private:
+#if defined(SNARKV_HOST_PALLAS)
+  static std::mutex& mu() {
+    static std::mutex m;
+    return m;
+  }
+#else
+  int64_t saved_ = -1;
+#endif
+};
 
 struct GpuNativeLoader {
   using LoadedScalar = Fr;
@@ -295,7 +322,7 @@ struct GpuNativeLoader {
       memcpy(&p[64 * i], pairs[i].second->b, 64);
     }
     G1Affine out;
-    std::lock_guard<std::mutex> lock(device_mutex());
+    DeviceScope lock;
     int rc = SNARKV_DEV(g1_msm_naive)(s.data(), p.data(), pairs.size(), out.b);
     if (rc != SNARKV_OK) throw std::runtime_error(std::string("g1_msm_naive: ") + SNARKV_DEV_LAST_ERROR());
     return out;
@@ -312,9 +339,9 @@ struct GpuNativeLoader {
     }
     const size_t total = offs.back();
     // the terms are packed straight into the device library's pinned host buffers (the copy to the device is then a
-    // DMA, not the runtime's bounce copy of pageable memory); they belong to the default context, so the device lock
+    // DMA, not the runtime's bounce copy of pageable memory); they belong to THIS thread, so the device scope
     // is taken before packing
-    std::lock_guard<std::mutex> lock(device_mutex());
+    DeviceScope lock;
     uint8_t *s = nullptr, *p = nullptr;
     if (SNARKV_DEV(host_buffer)(0, 32 * total, (void**)&s) != SNARKV_OK || SNARKV_DEV(host_buffer)(1, 64 * total, (void**)&p) != SNARKV_OK)
       throw std::runtime_error(std::string("host_buffer: ") + SNARKV_DEV_LAST_ERROR());

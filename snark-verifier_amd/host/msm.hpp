@@ -189,9 +189,9 @@ inline G1Affine multi_scalar_multiplication(const std::vector<Fr>& scalars, cons
   if (scalars.size() != bases.size()) throw Panic("multi_scalar_multiplication: scalars.len() != bases.len() (msm.rs:309)");
   if (scalars.empty()) throw Panic("multi_scalar_multiplication of no terms (reference: scalars[0], msm.rs:265)");
   const size_t n = scalars.size();
-  // packed into the default context's pinned host buffers (loader.hpp `device_mutex`): 96 B per term reach the device
+  // packed into this thread's pinned host buffers (`bn254_host_buffer`; loader.hpp `DeviceScope`): 96 B per term reach the device
   // by DMA, and a repeated call does not fault in 96 B per term of fresh pageable memory first
-  std::lock_guard<std::mutex> lock(device_mutex());
+  DeviceScope lock;
   uint8_t *s = nullptr, *p = nullptr;
   if (SNARKV_DEV(host_buffer)(0, 32 * n, (void**)&s) != SNARKV_OK || SNARKV_DEV(host_buffer)(1, 64 * n, (void**)&p) != SNARKV_OK)
     throw std::runtime_error(std::string("host_buffer: ") + SNARKV_DEV_LAST_ERROR());

@@ -114,7 +114,7 @@ struct KzgDecidingKey {
     std::lock_guard<std::mutex> init(init_mu);
     if (!dk_) {
       snarkv_dk* h = nullptr;
-      std::lock_guard<std::mutex> lock(device_mutex());
+      DeviceScope lock;
       if (bn254_kzg_dk_create(svk.g.b, g2.b, s_g2.b, &h) != SNARKV_OK)
         throw std::runtime_error(std::string("bn254_kzg_dk_create: ") + snarkv_last_error());
       dk_ = std::shared_ptr<snarkv_dk>(h, [](snarkv_dk* p) { snarkv_dk_destroy(p); });
@@ -247,7 +247,7 @@ struct KzgAs {
     uint8_t a[128], ok = 0;
     acc.to_bytes(a);
     snarkv_dk* h = dk.handle();
-    std::lock_guard<std::mutex> lock(device_mutex());
+    DeviceScope lock;
     int rc = bn254_kzg_dk_decide_batch(h, a, 1, &ok);
     if (rc < 0) throw std::runtime_error(std::string("bn254_kzg_dk_decide_batch: ") + snarkv_last_error());
     return ok ? Error{} : Error::assertion("e(lhs, g2)\xc2\xb7" "e(rhs, -s_g2) == O");
@@ -258,7 +258,7 @@ struct KzgAs {
     std::vector<uint8_t> a(128 * accs.size()), ok(accs.size());
     for (size_t i = 0; i < accs.size(); ++i) accs[i].to_bytes(&a[128 * i]);
     snarkv_dk* h = dk.handle();
-    std::lock_guard<std::mutex> lock(device_mutex());
+    DeviceScope lock;
     int rc = bn254_kzg_dk_decide_batch(h, a.data(), accs.size(), ok.data());
     if (rc < 0) throw std::runtime_error(std::string("bn254_kzg_dk_decide_batch: ") + snarkv_last_error());
     for (uint8_t o : ok)
@@ -588,7 +588,7 @@ struct LimbsEncoding {
     static const uint8_t zero64[64] = {0};
     if (!memcmp(pts, zero64, 64) || !memcmp(pts + 64, zero64, 64))
       throw Panic("accumulator point (0, 0) is not on the curve (reference: from_xy().unwrap())");
-    std::lock_guard<std::mutex> lock(device_mutex());
+    DeviceScope lock;
     if (bn254_g1_validate(pts, 2) != SNARKV_OK)
       throw Panic("accumulator point is non-canonical or off-curve (reference: from_xy().unwrap())");
     return Result<KzgAccumulator>::Ok(KzgAccumulator{G1Affine::from_bytes(pts), G1Affine::from_bytes(pts + 64)});

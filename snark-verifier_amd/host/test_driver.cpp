@@ -454,11 +454,11 @@ int hd_pool_selftest(int rounds) {
       });
     for (auto& t : subs) t.join();
     if (total != 4 * 100 * 200) return 3;
-    bool refused = false;  // a pool task must not take the device lock (lock order: device -> pool)
+    bool refused = false;  // a pool task must not open a device scope (tasks of the pool stay host-only)
     parallel_for(64, 8, [&](size_t i) {
       if (i == 5) {
         try {
-          device_mutex();
+          DeviceScope probe;
         } catch (const std::logic_error&) {
           refused = true;
         }

@@ -851,6 +851,12 @@ class PoseidonTranscriptT : public Transcript {
       memcpy(p.b, hint_pts_ + 64 * read_index, 64);  // decompressed by the device for the whole batch (snarkv_g1_decompress)
     } else {
       ok = g1_decompress(enc, &p);
+      // Fused device route: the challenges were hashed over the DEVICE's decoding of these bytes.  A finite point the host
+      // decodes where the device's answer was unusable means the two disagree -- the proof would be checked under
+      // challenges that are not the hash of what is parsed here.  Refuse it (defence in depth: unreachable while the two
+      // decoders agree on every encoding, tests/test_gpu_poseidon.py).
+      if (ok && strict_hints_ && read_index < n_hints_ && !p.is_identity())
+        return Result<G1Affine>::Err(Error{Error::Transcript, "device and host disagree on a compressed point of the proof"});
     }
     pos_ += 32;
     if (!ok) return Result<G1Affine>::Err(Error{Error::Transcript, "Invalid elliptic curve point encoding in proof"});
@@ -891,6 +897,7 @@ class PoseidonTranscriptT : public Transcript {
   const uint8_t* hint_pts_ = nullptr;           // candidate decodings by read index (64 bytes each) and their validity
   const uint8_t* hint_ok_ = nullptr;            // flags: borrowed views of the device's answer for the whole batch --
   size_t n_hints_ = 0;                          // no per-proof copies, nothing for a pool worker to free
+  bool strict_hints_ = false;
   bool record_layout_ = false;
   uint32_t pending_src_ = 0xFFFFFFFFu;          // the source of the element(s) the next common_* call absorbs
   std::vector<uint32_t> layout_;
@@ -921,7 +928,10 @@ class PoseidonTranscriptT : public Transcript {
   const std::vector<uint32_t>& layout() const { return layout_; }
   const std::vector<Fr>& lead_values() const { return lead_; }
   // decodings computed elsewhere for the k-th point read, checked against the bytes before use
-  void set_point_hints(const uint8_t* pts64, const uint8_t* ok, size_t n) { hint_pts_ = pts64, hint_ok_ = ok, n_hints_ = n; }
+  // `strict`: the caller's challenges depend on these decodings (the fused device route): see read_ec_point
+  void set_point_hints(const uint8_t* pts64, const uint8_t* ok, size_t n, bool strict = false) {
+    hint_pts_ = pts64, hint_ok_ = ok, n_hints_ = n, strict_hints_ = strict;
+  }
 };
 using PoseidonTranscript = PoseidonTranscriptT<Poseidon>;
 

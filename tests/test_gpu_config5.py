@@ -1,7 +1,7 @@
 """BASELINE.json configs[4] at size under `-m gpu`: 1 024 DISTINCT proofs through the whole native pipeline
 (the call pattern of snark-verifier/examples/evm-verifier-with-accumulator.rs:357-385, x1024) and the pairing
 decider over 1 024 distinct accumulators (`decide_all`, pcs/kzg/decider.rs:84-93), against what the oracle
-computed for the committed fixture tests/golden/bench_plonk_gwc19_evm_1024.bin (gen_bench_proofs.py 1024)
+computed for the committed fixtures tests/golden/bench_plonk_gwc19_{evm,poseidon}_1024.bin (gen_bench_proofs.py 1024)
 and against the C oracle's pairing on the box's host cores.  Everything goes through the C APIs
 (include/snarkv_host.h over include/snarkv_amd.h)."""
 import os
@@ -16,9 +16,28 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# the C5 workload on BOTH transcripts: Keccak proofs (the outer EVM flow) and Poseidon proofs with a Poseidon accumulation
+# transcript -- the reference example's own native route (evm-verifier-with-accumulator.rs:361,375).  For Poseidon every
+# route of the host mirror must give the same bytes: hashed on the host, on the device (one fused pipeline), auto.
+FIXTURES = {"evm": ("bench_plonk_gwc19_evm_1024.bin", H.MOS_GWC19, [H.TRANSCRIPT_EVM]),
+            "poseidon": ("bench_plonk_gwc19_poseidon_1024.bin", H.MOS_GWC19,
+                         [H.TRANSCRIPT_POSEIDON_DEVICE, H.TRANSCRIPT_POSEIDON, H.TRANSCRIPT_POSEIDON_AUTO])}
+
+
+def _load(kind):
+    f = H.read_fixture(os.path.join(ROOT, "tests", "golden", FIXTURES[kind][0]))
+    f["mos"], f["tkinds"], f["kind"] = FIXTURES[kind][1], FIXTURES[kind][2], kind
+    return f
+
+
 @pytest.fixture(scope="module")
 def fx():
-    return H.read_fixture(os.path.join(ROOT, "tests", "golden", "bench_plonk_gwc19_evm_1024.bin"))
+    return _load("evm")
+
+
+@pytest.fixture(scope="module", params=["evm", "poseidon"])
+def fxk(request):
+    return _load(request.param)
 
 
 @pytest.fixture(scope="module")
@@ -29,41 +48,85 @@ def handles(fx):
     hdk.close()
 
 
-def test_1024_distinct_proofs_per_proof_accumulators_equal_oracle(fx, handles):
-    hp, hdk = handles
-    assert fx["n"] == 1024 and len(fx["accs"]) == 128 * 1024
-    accs = H.plonk_succinct_verify_batch(hp, hdk, fx["instances"], fx["proofs"], fx["n"], strict=True)
-    assert accs == fx["accs"]  # 1 024 x (lhs, rhs), byte for byte what oracle/plonk.py's succinct verifier computed
+@pytest.fixture(scope="module")
+def handlesk(fxk):
+    hp, hdk = H.Protocol(fxk["protocol"]), H.DecidingKey(fxk["dk"])
+    yield hp, hdk
+    hp.close()
+    hdk.close()
+
+
+def test_1024_distinct_proofs_per_proof_accumulators_equal_oracle(fxk, handlesk):
+    hp, hdk = handlesk
+    assert fxk["n"] == 1024 and len(fxk["accs"]) == 128 * 1024
+    for tk in fxk["tkinds"]:
+        accs = H.plonk_succinct_verify_batch(hp, hdk, fxk["instances"], fxk["proofs"], fxk["n"], fxk["mos"], tk, strict=True)
+        assert accs == fxk["accs"], tk  # 1 024 x (lhs, rhs), byte for byte what oracle/plonk.py's succinct verifier computed
     assert len({accs[128 * i:128 * i + 128] for i in range(1024)}) == 1024
 
 
-def test_1024_distinct_proofs_aggregate_and_decide(fx, handles):
-    hp, hdk = handles
-    ok, acc = H.aggregate(hp, hdk, fx["instances"], fx["proofs"], fx["n"])
-    assert ok and acc == fx["expected_acc"]  # KzgAs over 1 024 accumulators == oracle/kzg.py's, then the pairing accepts
-    # the two halves separately: accumulate the fixture's accumulators, decide the result
-    acc2, r = H.kzg_as_accumulate(fx["accs"])
-    assert acc2 == fx["expected_acc"] and H.kzg_decide(hdk, acc2)
+def test_1024_distinct_proofs_aggregate_and_decide(fxk, handlesk):
+    hp, hdk = handlesk
+    for tk in fxk["tkinds"]:
+        ok, acc = H.aggregate(hp, hdk, fxk["instances"], fxk["proofs"], fxk["n"], fxk["mos"], tk)
+        # KzgAs over 1 024 accumulators on a transcript of the proofs' family == oracle/kzg.py's, then the pairing accepts
+        assert ok and acc == fxk["expected_acc"], tk
+    if fxk["kind"] == "evm":  # the two halves separately: accumulate the fixture's accumulators (Keccak), decide the result
+        acc2, r = H.kzg_as_accumulate(fxk["accs"])
+        assert acc2 == fxk["expected_acc"]
+    else:  # `As::create_proof` on a Poseidon transcript through its own C API
+        acc2, as_proof, r = H.kzg_as_create_proof(fxk["accs"], H.TRANSCRIPT_POSEIDON)
+        assert acc2 == fxk["expected_acc"] and as_proof == b""  # non-zk: the proof carries nothing (accumulation.rs:181-196)
+    assert H.kzg_decide(hdk, acc2)
     # the CPU restatement of the decider agrees on that accumulator (C oracle pairing, decider.rs:70-82)
-    assert C.kzg_decide(fx["dk"][64:192], fx["dk"][192:320], acc2)
+    assert C.kzg_decide(fxk["dk"][64:192], fxk["dk"][192:320], acc2)
     # PlonkVerifier::verify on all 1 024: succinct verify + ONE decide_all over 1 024 accumulators
-    assert H.plonk_verify(hp, hdk, fx["instances"], fx["proofs"], fx["n"])
+    assert H.plonk_verify(hp, hdk, fxk["instances"], fxk["proofs"], fxk["n"], fxk["mos"], fxk["tkinds"][0])
+    # 16 jobs of 64 proofs in one call: every job's accumulator = one call on its 64 proofs
+    oka, accs, oks = H.aggregate_many(hp, hdk, fxk["instances"], fxk["proofs"], [64] * 16, fxk["mos"], fxk["tkinds"][0])
+    assert oka and all(oks) and len(set(accs)) == 16
 
 
-def test_1024_proofs_with_a_corrupted_one_reject(fx, handles):
-    hp, hdk = handles
-    prb = bytearray(fx["proofs"])
+def test_1024_proofs_with_a_corrupted_one_reject(fxk, handlesk):
+    hp, hdk = handlesk
+    prb = bytearray(fxk["proofs"])
     # flip one bit inside the 700th proof's evaluation section: still parses, no longer verifies
     off = 0
     for _ in range(700):
         off += 4 + int.from_bytes(prb[off:off + 4], "little")
     ln = int.from_bytes(prb[off:off + 4], "little")
     prb[off + 4 + ln - 200] ^= 4
-    try:
-        ok, _ = H.aggregate(hp, hdk, fx["instances"], bytes(prb), fx["n"])
-        assert not ok
-    except H.HostError as e:  # or the flipped byte made a non-canonical scalar: Error::Transcript
-        assert e.code == H.ERR_TRANSCRIPT
+    for tk in fxk["tkinds"]:
+        try:
+            ok, _ = H.aggregate(hp, hdk, fxk["instances"], bytes(prb), fxk["n"], fxk["mos"], tk)
+            assert not ok, tk
+        except H.HostError as e:  # or the flipped byte made a non-canonical scalar: Error::Transcript
+            assert e.code == H.ERR_TRANSCRIPT
+
+
+def test_shplonk_shape_64_proofs_bdfg21_poseidon_every_route():
+    """The SDK's default scheme: SHPLONK = KzgAs<Bn256, Bdfg21> on Poseidon transcripts (snark-verifier-sdk/src/lib.rs:41,
+    src/halo2.rs:296-306): 64 proofs of the committed fixture.  Bdfg21 reads W' AFTER its last squeeze (bdfg21.rs:64-66), so
+    the transcript has trailing absorbs that feed no challenge -- the case that made the device-hashed routes abort
+    (ADVICE r4): every route now gives the oracle's bytes."""
+    f = H.read_fixture(os.path.join(ROOT, "tests", "golden", "bench_plonk_bdfg21_poseidon_64.bin"))
+    hp, hdk = H.Protocol(f["protocol"]), H.DecidingKey(f["dk"])
+    for tk in (H.TRANSCRIPT_POSEIDON, H.TRANSCRIPT_POSEIDON_DEVICE, H.TRANSCRIPT_POSEIDON_AUTO):
+        accs = H.plonk_succinct_verify_batch(hp, hdk, f["instances"], f["proofs"], f["n"], H.MOS_BDFG21, tk, strict=True)
+        assert accs == f["accs"], tk
+        ok, acc = H.aggregate(hp, hdk, f["instances"], f["proofs"], f["n"], H.MOS_BDFG21, tk)
+        assert ok and acc == f["expected_acc"], tk
+    # proofs of DIFFERENT lengths cannot take the fused pipeline: drop the last byte of one proof -> Error::Transcript from
+    # the three-pass route, not a crash
+    prb = bytearray(f["proofs"])
+    ln0 = int.from_bytes(prb[:4], "little")
+    cut = prb[:4 + ln0 - 1]
+    cut[:4] = (ln0 - 1).to_bytes(4, "little")
+    with pytest.raises(H.HostError) as e:
+        H.aggregate(hp, hdk, f["instances"], bytes(cut + prb[4 + ln0:]), f["n"], H.MOS_BDFG21, H.TRANSCRIPT_POSEIDON_DEVICE)
+    assert e.value.code == H.ERR_TRANSCRIPT
+    hp.close()
+    hdk.close()
 
 
 @pytest.mark.parametrize("teams", ["1", "3"])

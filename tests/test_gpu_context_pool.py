@@ -1,0 +1,182 @@
+"""GPU: the context-free `bn254_*` boundary -- the only form a trait-bound caller reaches (`EcPointLoader::
+multi_scalar_multiplication` has no `&self`, loader.rs:108) -- draws from a POOL of default contexts (csrc/capi.hip), so
+host threads run side by side: 16 threads x 64-proof aggregation jobs, bytes equal to the oracle's, and per-job wall time
+comparable to 16 explicit contexts.  Plus the flag scoping around it: the per-thread
+override the host library uses, IPA under a MONTGOMERY default, IPA after a chunk-pipelined MONTGOMERY MSM."""
+import ctypes
+import os
+import threading
+import time
+
+import pytest
+
+import bn254 as O
+import coracle as C
+import mont_util as M
+
+pytestmark = pytest.mark.gpu
+SECRET = 0x51F3
+
+
+def _job(seed, nproofs=64):
+    """one 64-proof aggregation job in the shapes of BASELINE config 3: per proof a 21- and a 3-term MSM, then the two
+    (m + 1)-term KzgAs MSMs; expected bytes from the C oracle"""
+    offs = [0]
+    for _ in range(nproofs):
+        offs += [offs[-1] + 21, offs[-1] + 24]
+    n1 = offs[-1]
+    s, p = C.sample_scalars(seed, n1), C.sample_points(seed + 1, n1)
+    exp1 = C.msm_batched(s, p, offs)
+    n2 = 2 * (nproofs + 1)
+    s2, p2 = C.sample_scalars(seed + 2, n2), C.sample_points(seed + 3, n2)
+    exp2 = C.msm_batched(s2, p2, [0, nproofs + 1, n2])
+    return (s, p, offs, exp1), (s2, p2, [0, nproofs + 1, n2], exp2)
+
+
+def test_16_threads_of_64_proof_jobs_through_the_context_free_boundary():
+    import snark_verifier_amd as sv
+
+    lib = sv.load_library()
+    g1 = O.g1_to_bytes(O.G1_GEN)
+    g2, sg2 = O.g2_to_bytes(O.G2_GEN), O.g2_to_bytes(O.g2_mul(O.G2_GEN, SECRET))
+    dk = ctypes.c_void_p()
+    assert lib.bn254_kzg_dk_create(g1, g2, sg2, ctypes.byref(dk)) == 0
+    good = O.g1_to_bytes(O.g1_mul(O.G1_GEN, SECRET)) + g1
+    bad = O.g1_to_bytes(O.g1_mul(O.G1_GEN, SECRET + 1)) + g1
+    T = 16
+    jobs = [_job(0x7000 + 16 * k) for k in range(T)]
+    errs, walls = [], [0.0] * T
+
+    def run(k, reps):
+        (s, p, offs, exp1), (s2, p2, offs2, exp2) = jobs[k]
+        o1 = (ctypes.c_uint32 * len(offs))(*offs)
+        o2 = (ctypes.c_uint32 * len(offs2))(*offs2)
+        out1, out2 = ctypes.create_string_buffer(64 * (len(offs) - 1)), ctypes.create_string_buffer(128)
+        ok = ctypes.create_string_buffer(2)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rc1 = lib.bn254_g1_msm_batched(s, p, o1, len(offs) - 1, out1)
+            rc2 = lib.bn254_g1_msm_batched(s2, p2, o2, 2, out2)
+            rc3 = lib.bn254_kzg_dk_decide_batch(dk, good + bad, 2, ok)
+            if (rc1, rc2) != (0, 0) or rc3 < 0 or out1.raw != exp1 or out2.raw != exp2 or ok.raw != b"\x01\x00":
+                errs.append((k, rc1, rc2, rc3))
+        walls[k] = (time.perf_counter() - t0) / reps
+
+    def wave(reps):
+        ts = [threading.Thread(target=run, args=(k, reps)) for k in range(T)]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return time.perf_counter() - t0
+
+    wave(2)  # the pool's contexts come into being and allocate their scratch
+    assert not errs
+    created, cap = ctypes.c_int(0), ctypes.c_int(0)
+    assert lib.bn254_default_contexts(ctypes.byref(created), ctypes.byref(cap)) == 0
+    assert cap.value == int(os.environ.get("SNARKV_DEFAULT_CONTEXTS") or os.environ.get("GPU_MAX_HW_QUEUES") or 4)
+    assert 2 <= created.value <= cap.value  # several contexts in use at once, never more than the limit
+    reps = 6
+    wall = min(wave(reps) for _ in range(3))
+    assert not errs
+    per_job_concurrent = wall / (T * reps)
+    # the same jobs one at a time from ONE thread (= the round-4 behaviour of this boundary: one context, one mutex)
+    t0 = time.perf_counter()
+    for k in range(T):
+        run(k, 1)
+    per_job_serial = (time.perf_counter() - t0) / T
+    assert not errs
+    print("context-free boundary: %.3f ms per 64-proof job with 16 threads in flight, %.3f ms one at a time (%d contexts)"
+          % (per_job_concurrent * 1e3, per_job_serial * 1e3, created.value))
+    if cap.value >= 8:
+        assert per_job_concurrent < 0.5 * per_job_serial  # concurrency is real, not a convoy behind one mutex
+    lib.snarkv_dk_destroy(dk)
+
+
+def test_thread_flags_override_and_the_host_library_under_a_montgomery_default(golden_msm):
+    """an application that sets `bn254_set_flags(MONTGOMERY)` once at start-up and ALSO calls
+    the host library: the mirror pins its own calls to the wire form per thread, so both keep working."""
+    import snark_verifier_amd as sv
+    from snark_verifier_amd import host_api as H
+
+    lib = sv.load_library()
+    c = next(c for c in golden_msm if len(c["scalars"]) // 64 >= 3)
+    s, p, exp = bytes.fromhex(c["scalars"]), bytes.fromhex(c["points"]), bytes.fromhex(c["expected"])
+    out = ctypes.create_string_buffer(64)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fx = H.read_fixture(os.path.join(root, "tests", "golden", "bench_plonk_gwc19_evm_64.bin"))
+    hp, hdk = H.Protocol(fx["protocol"]), H.DecidingKey(fx["dk"])
+    try:
+        assert lib.bn254_set_flags(sv.SNARKV_FLAG_MONTGOMERY) == 0 and lib.bn254_get_flags() == sv.SNARKV_FLAG_MONTGOMERY
+        assert lib.bn254_g1_msm_naive(M.scalars_to_mont(s), M.coords_to_mont(p), len(s) // 32, out) == 0
+        assert out.raw == M.coords_to_mont(exp)
+        # the host library on the same thread, wire-form bytes in and out
+        ok, acc = H.aggregate(hp, hdk, fx["instances"], fx["proofs"], fx["n"])
+        assert ok and acc == fx["expected_acc"]
+        assert lib.bn254_get_flags() == sv.SNARKV_FLAG_MONTGOMERY  # the mirror restored what it found
+        # a thread's own override: wire form on this thread only
+        assert lib.bn254_set_thread_flags(0) == -1 and lib.bn254_get_flags() == 0
+        assert lib.bn254_g1_msm_naive(s, p, len(s) // 32, out) == 0 and out.raw == exp
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(lib.bn254_get_flags()))
+        t.start()
+        t.join()
+        assert seen == [sv.SNARKV_FLAG_MONTGOMERY]  # other threads still see the process default
+        assert lib.bn254_set_thread_flags(-1) == 0 and lib.bn254_get_flags() == sv.SNARKV_FLAG_MONTGOMERY
+        assert lib.bn254_set_thread_flags(8) == sv.SNARKV_ERR_ARG  # unknown bit
+    finally:
+        lib.bn254_set_thread_flags(-1)
+        assert lib.bn254_set_flags(0) == 0
+        hp.close()
+        hdk.close()
+    assert lib.bn254_g1_msm_naive(s, p, len(s) // 32, out) == 0 and out.raw == exp
+
+
+def _ipa_case(k=6):
+    import ipa as I
+
+    xi = [(0x9E3779B97F4A7C15 * (i + 1)) % O.R for i in range(k)]
+    g = C.sample_points(0x3131, 1 << k)
+    u = C.msm_pippenger(b"".join(O.fe_to_bytes(c) for c in I.h_coeffs(xi, 1)), g, 1)
+    xb = b"".join(O.fe_to_bytes(x) for x in xi)
+    return g, xb, u
+
+
+def test_ipa_speaks_the_wire_form_whatever_the_context_default_says(monkeypatch):
+    """the IPA entry points are NOT covered by SNARKV_FLAG_MONTGOMERY.  (1) On a context whose default
+    is MONTGOMERY a valid accumulator must still be accepted; (2) after a chunk-pipelined MONTGOMERY MSM (which sets the
+    worker lanes' encoding) an `ipa_decide_batch` with m >= 2 on the same context -- its accumulators run on those lanes --
+    must still compute in the wire form."""
+    import torch
+
+    import snark_verifier_amd as sv
+
+    g, xb, u = _ipa_case()
+    wrong = C.g1_add(u, g[:64])
+    ctx = sv.Context(0)
+    dk = sv.IpaDecidingKey(ctx, g)
+    assert ctx.ipa_decide_batch(dk, xb * 3, u + wrong + u) == [True, False, True]
+    ctx.set_flags(sv.SNARKV_FLAG_MONTGOMERY)
+    assert ctx.ipa_decide_batch(dk, xb, u) == [True]
+    assert ctx.ipa_decide_batch(dk, xb * 3, u + wrong + u) == [True, False, True]
+    # a chunk-pipelined MSM in the in-memory form on this context (SNARKV_PIP_SPLIT=2: two chunks already), checked
+    per = 1 << 20
+    monkeypatch.setenv("SNARKV_PIP_SPLIT", "2")
+    ds = torch.empty(32 * 2 * per, dtype=torch.uint8, device="cuda")
+    dp = torch.empty(64 * 2 * per, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.sample_scalars_dev(0x51, 2 * per, ds.data_ptr())  # (the samplers follow the context's flags: in-memory form)
+    ctx.sample_points_dev(0x52, 2 * per, dp.data_ptr())
+    ctx.msm_pippenger_dev(ds.data_ptr(), dp.data_ptr(), 2 * per, out.data_ptr())
+    ctx.sync()
+    exp = C.msm_pippenger(C.sample_scalars(0x51, 2 * per), C.sample_points(0x52, 2 * per), os.cpu_count() or 8)
+    assert bytes(out.cpu().numpy()) == M.coords_to_mont(exp)
+    monkeypatch.delenv("SNARKV_PIP_SPLIT")
+    ctx.set_flags(0)  # back on the wire form: the lanes must not remember the pipeline's encoding
+    assert ctx.ipa_decide_batch(dk, xb * 3, u + wrong + u) == [True, False, True]
+    ctx.set_flags(sv.SNARKV_FLAG_MONTGOMERY)
+    assert ctx.ipa_decide_batch(dk, xb * 3, u + wrong + u) == [True, False, True]
+    dk.close()
+    ctx.close()

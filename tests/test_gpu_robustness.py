@@ -212,7 +212,7 @@ def test_sharded_msm_batch_wiring_on_a_one_rank_rccl_group():
 
 
 def test_context_free_entry_points_from_many_threads(golden_msm):
-    """`bn254_*` share one process-global context; concurrent callers must take turns, not race."""
+    """`bn254_*` draw from the pool of default contexts (csrc/capi.hip): concurrent callers run side by side, no races."""
     import ctypes
     import threading
 
