@@ -533,6 +533,7 @@ def context_free_metrics(sv, nproofs=64, T=16):
             return
         ctypes.memmove(ps, hs, 32 * n1)
         ctypes.memmove(pp, hp, 64 * n1)
+        ps, pp = ctypes.cast(ps, ctypes.c_char_p), ctypes.cast(pp, ctypes.c_char_p)  # (the argtypes of the byte-pointer parameters)
         out1, acc, ok = ctypes.create_string_buffer(64 * (len(offs) - 1)), ctypes.create_string_buffer(128), ctypes.create_string_buffer(1)
         for _ in range(reps):
             rc = lib.bn254_g1_msm_batched(ps, pp, o1, len(offs) - 1, out1) or lib.bn254_g1_msm_batched(ps, pp, o2, 2, acc)

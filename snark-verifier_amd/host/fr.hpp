@@ -224,6 +224,82 @@ class Fr {
     }
     return out;
   }
+  // Lazy dot products for chains of multiply-adds whose terms are known together (the Poseidon rounds of the accumulation
+  // transcript: one sponge over 4 m elements, m + 1 dependent permutations on ONE thread): the 512-bit products are
+  // summed as integers and reduced ONCE -- sum_j a_j b_j costs 16 limb products per term + 16 for the reduction instead
+  // of 32 per term.  `add_shifted(x)` adds x 2^256, i.e. the Montgomery residue x itself after the reduction.
+  // At most kWideTerms terms per accumulator (the sum stays below 2^512 for both curves' moduli).
+  struct Wide {
+    static constexpr int kWideTerms = 6;
+    uint64_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    inline void add_product(const Fr& a, const Fr& b) {
+      // the 512-bit product in locals (registers), then ONE carry chain into the accumulator
+      uint64_t p[8];
+      unsigned __int128 c = 0;
+      for (int j = 0; j < 4; ++j) {
+        c += (unsigned __int128)a.v[0] * b.v[j];
+        p[j] = (uint64_t)c;
+        c >>= 64;
+      }
+      p[4] = (uint64_t)c;
+      for (int i = 1; i < 4; ++i) {
+        c = 0;
+        for (int j = 0; j < 4; ++j) {
+          c += (unsigned __int128)a.v[i] * b.v[j] + p[i + j];
+          p[i + j] = (uint64_t)c;
+          c >>= 64;
+        }
+        p[i + 4] = (uint64_t)c;
+      }
+      c = 0;
+      for (int k = 0; k < 8; ++k) {
+        c += (unsigned __int128)w[k] + p[k];
+        w[k] = (uint64_t)c;
+        c >>= 64;
+      }
+    }
+    inline void add_shifted(const Fr& x) {
+      unsigned __int128 c = 0;
+      for (int k = 0; k < 4; ++k) {
+        c += (unsigned __int128)w[4 + k] + x.v[k];
+        w[4 + k] = (uint64_t)c;
+        c >>= 64;
+      }
+    }
+    // (sum) / 2^256 mod r, fully reduced
+    inline Fr reduce() const {
+      uint64_t t[9];
+      memcpy(t, w, 64);
+      uint64_t carry = 0;  // the carry out of position i + 4, due at position i + 5
+      for (int i = 0; i < 4; ++i) {
+        const uint64_t m = t[i] * INV;
+        unsigned __int128 c = 0;
+        for (int j = 0; j < 4; ++j) {
+          c += (unsigned __int128)m * MOD[j] + t[i + j];
+          t[i + j] = (uint64_t)c;
+          c >>= 64;
+        }
+        c += (unsigned __int128)t[i + 4] + carry;
+        t[i + 4] = (uint64_t)c;
+        carry = (uint64_t)(c >> 64);
+      }
+      t[8] = carry;
+      Fr r;
+      memcpy(r.v, t + 4, 32);
+      uint64_t hi = t[8];
+      while (hi || !lt_mod(r.v)) {  // < 4 r by the term bound: a few subtractions at most
+        unsigned __int128 br = 0;
+        for (int i = 0; i < 4; ++i) {
+          unsigned __int128 x = (unsigned __int128)r.v[i] - MOD[i] - (uint64_t)br;
+          r.v[i] = (uint64_t)x;
+          br = (x >> 64) & 1;
+        }
+        hi -= (uint64_t)br;
+      }
+      return r;
+    }
+  };
+
   // total order on canonical values (the reference needs `Ord` for BTreeSet/Map keys)
   bool operator<(const Fr& o) const {
     uint8_t a[32], b[32];

@@ -591,45 +591,69 @@ inline const PoseidonOpt& poseidon_opt(int t, int r_f, int r_p) {
   return cache.emplace(key, std::move(o)).first->second;
 }
 
-// state <- permutation(state): identical values to poseidon_permute_plain, about half the products
-inline void poseidon_permute(std::vector<Fr>& state, const PoseidonSpec& sp) {
+// state <- permutation(state): identical values to poseidon_permute_plain, about half the products -- and the products of a
+// matrix row are summed as 512-bit integers and reduced once (Fr::Wide): the accumulation transcript of an aggregation is
+// ONE sponge (4 m elements, m + 1 DEPENDENT permutations on one thread; 1 025 of them at m = 1 024), so the permutation's
+// own speed is what that step costs.  No allocation inside: the state and the scratch row live on the stack.
+inline void poseidon_permute(std::vector<Fr>& state_v, const PoseidonSpec& sp) {
   const PoseidonOpt& o = poseidon_opt(sp.t, sp.r_f, sp.r_p);
   const int t = o.t, h = o.r_f / 2;
-  std::vector<Fr> next((size_t)t);
+  constexpr int kMaxT = 16;
+  if (t > kMaxT) throw Panic("poseidon: state wider than this implementation's stack arrays");
+  Fr state[kMaxT], next[kMaxT];
+  for (int i = 0; i < t; ++i) state[i] = state_v[(size_t)i];
   auto sbox = [](const Fr& x) {
     Fr x2 = x.square();
     return x2.square() * x;
   };
-  auto dense = [&](const std::vector<Fr>& m) {
-    for (int i = 0; i < t; ++i) {
-      Fr acc = Fr::zero();
-      for (int j = 0; j < t; ++j) acc = acc + m[(size_t)i * t + j] * state[j];
-      next[i] = acc;
+  // sum_j m[j] s[j] (+ extra 2^256-shifted addend), in chunks of Wide::kWideTerms terms
+  auto dot = [&](const Fr* m, const Fr* sv, int n) {
+    Fr::Wide w;
+    int used = 0;
+    for (int j = 0; j < n; ++j) {
+      if (used == Fr::Wide::kWideTerms - 1) {  // fold what is there and carry it on as one shifted term
+        Fr part = w.reduce();
+        w = Fr::Wide();
+        w.add_shifted(part);
+        used = 1;
+      }
+      w.add_product(m[j], sv[j]);
+      ++used;
     }
-    state = next;
+    return w.reduce();
   };
-  for (int i = 0; i < t; ++i) state[i] = state[i] + o.pre[i];
+  auto dense = [&](const std::vector<Fr>& m) {
+    for (int i = 0; i < t; ++i) next[i] = dot(&m[(size_t)i * t], state, t);
+    for (int i = 0; i < t; ++i) state[i] = next[i];
+  };
+  for (int i = 0; i < t; ++i) state[i] = state[i] + o.pre[(size_t)i];
   size_t fk = 0;
   for (int r = 0; r < h; ++r) {  // first half: full rounds, the last one with the pre-sparse matrix
-    for (int i = 0; i < t; ++i) state[i] = sbox(state[i]) + o.full_k[fk][i];
+    for (int i = 0; i < t; ++i) state[i] = sbox(state[i]) + o.full_k[fk][(size_t)i];
     ++fk;
     dense(r + 1 < h ? o.mds : o.pre_sparse);
   }
   for (int r = 0; r < o.r_p; ++r) {  // partial rounds: one S-box, sparse matrix
     state[0] = sbox(state[0]) + o.partial_k[(size_t)r];
-    const auto& row = o.sparse_row[(size_t)r];
-    const auto& col = o.sparse_col[(size_t)r];
-    Fr s0 = state[0], acc = row[0] * s0;
-    for (int j = 1; j < t; ++j) acc = acc + row[(size_t)j] * state[j];
-    for (int i = 1; i < t; ++i) state[i] = state[i] + col[(size_t)i - 1] * s0;
+    const Fr* row = o.sparse_row[(size_t)r].data();
+    const Fr* col = o.sparse_col[(size_t)r].data();
+    const Fr s0 = state[0];
+    const Fr acc = dot(row, state, t);
+    for (int i = 1; i < t; ++i) {  // state[i] + col[i - 1] s0: one product, the addend rides along as state[i] 2^256
+      Fr::Wide w;
+      w.add_shifted(state[i]);
+      w.add_product(col[i - 1], s0);
+      state[i] = w.reduce();
+    }
     state[0] = acc;
   }
   for (int r = 0; r < h; ++r) {  // second half: full rounds, no constant after the last S-box
     const bool last = r + 1 == h;
-    for (int i = 0; i < t; ++i) state[i] = last ? sbox(state[i]) : sbox(state[i]) + o.full_k[fk][i];
+    for (int i = 0; i < t; ++i) state[i] = last ? sbox(state[i]) : sbox(state[i]) + o.full_k[fk][(size_t)i];
     if (!last) ++fk;
     dense(o.mds);
   }
+  for (int i = 0; i < t; ++i) state_v[(size_t)i] = state[i];
 }
 
 // poseidon.rs:115-202: sponge framing over the plain permutation
