@@ -22,6 +22,7 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 from ._lib import (  # noqa: F401,E402
     Context,
     DecidingKey,
+    FixedTable,
     IpaDecidingKey,
     MultiGpu,
     PoseidonSpec,
@@ -47,6 +48,7 @@ __all__ = [
     "host_api",
     "Context",
     "DecidingKey",
+    "FixedTable",
     "IpaDecidingKey",
     "MultiGpu",
     "PoseidonSpec",
