@@ -10,15 +10,17 @@
 // table is by construction what those kernels compute), and a fixed term s B becomes 33 table additions -- no doubling:
 //   k_fixed_digits   lane per fixed term: the scalar (wire or in-memory form) recoded into signed 8-bit digits
 //                    s = sum_j d_j 2^(8 j), d_j in [-128, 128]
-//   k_fixed_terms    16 lanes per SEGMENT walk its (term, window) pairs -- a mixed XYZZ addition each, careful flavour
-//                    (identity bases, duplicate bases and B next to -B are legal inputs) --, a 4-level tree adds the
-//                    lanes' sums, lane 0 stores the segment's fixed part (one XYZZ point)
+//   k_fixed_terms    16 (latency) or 4 (throughput) lanes per SEGMENT walk its (term, window) pairs -- a branch-free mixed
+//                    XYZZ addition each, the next table entry in flight --, a tree adds the lanes' sums, lane 0 stores
+//                    the segment's fixed part (one XYZZ point); identity bases, duplicate bases and B next to -B are legal
+//                    inputs: an exceptional case shows up as ZZ = 0 and the segment is redone with the careful adders
 //   k_segment_fold   (msm_naive.hip) adds that point to the segment's variable-base partials before `to_affine`
 // ~10 field products per (term, window) against ~1 200 - 3 600 per variable-base term; the kernels run on a side stream
 // next to the variable-base ones.  Results are the bytes of snarkv_g1_msm_batched on the same terms (tests/test_gpu_fixed_base.py).
 #include "ctx.hpp"
 #include "g1_29.h"
 #include "fr29.h"
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -32,7 +34,6 @@ namespace snarkv {
 
 constexpr uint32_t kFixedWindows = 33;   // 8-bit windows of a 256-bit integer + the carry out of the top one
 constexpr uint32_t kFixedEntries = 128;  // |digit| = 1 .. 128
-constexpr uint32_t kFixedLanes = 16;     // lanes per segment in k_fixed_terms
 
 
 // canonical / in-memory words -> canonical affine words (the table is built in the wire form)
@@ -101,39 +102,102 @@ __global__ void k_fixed_digits(const uint32_t* __restrict__ scalars, uint32_t n_
   signs[t] = s0;
 }
 
-// 16 lanes per segment, four segments per wavefront
+// One (term, window) pair of segment `seg`'s fixed list: the table entry its digit selects, negated for a negative digit;
+// `none` for a zero digit, an id outside the table or an identity base (all-zero entry).
+struct FixedPick {
+  G1Packed e;
+  bool neg, none;
+};
+__device__ __forceinline__ FixedPick fixed_pick(const G1Packed* __restrict__ table, const uint32_t* __restrict__ ids,
+                                                const uint8_t* __restrict__ mags, const uint32_t* __restrict__ signs,
+                                                uint32_t n_bases, uint32_t f0, uint32_t q) {
+  FixedPick r;
+  const uint32_t t = f0 + q / kFixedWindows, j = q % kFixedWindows;
+  const uint32_t mag = mags[(size_t)t * 36 + j];
+  const uint32_t b = ids[t];
+  r.none = mag == 0 || b >= n_bases;  // (ids are checked on the host for host-pointer calls; out of range adds nothing)
+  r.neg = j < 32 && ((signs[t] >> j) & 1u);
+  if (!r.none) {
+    r.e = table[((size_t)b * kFixedWindows + j) * kFixedEntries + (mag - 1)];
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) any |= r.e.w[k];
+    r.none = any == 0;
+  }
+  return r;
+}
+
+// G lanes per SEGMENT (64 / G segments per wavefront) walk its (term, window) pairs with the branch-free mixed addition,
+// the next table entry in flight while the current one is added; a G-wide tree adds the lanes' sums.  A lane or a tree
+// step that met an exceptional case (an accumulator equal to +- the entry: repeated or opposite bases, crafted scalars)
+// shows up as ZZ = 0 (sticky) -- the segment is then redone by ONE lane with the careful adders.
+//   G = 16: latency (one job: a segment's 297 pairs are 19 additions + 4 tree levels per lane)
+//   G = 4:  throughput (many jobs merged: 75 additions + 2 levels; the tree's idle lanes cost 6 % instead of 25 %)
+template <uint32_t G>
 __global__ void __launch_bounds__(64) k_fixed_terms(const G1Packed* __restrict__ table, const uint32_t* __restrict__ ids,
                                                      const uint32_t* __restrict__ foffs, const uint8_t* __restrict__ mags,
                                                      const uint32_t* __restrict__ signs, uint32_t n_msm, uint32_t n_bases,
                                                      G1Xyzz29* __restrict__ out) {
   __shared__ G1Xyzz29 sh[64];
-  const uint32_t tid = threadIdx.x, lane = tid % kFixedLanes;
-  const uint32_t seg = blockIdx.x * (64 / kFixedLanes) + tid / kFixedLanes;
+  __shared__ uint32_t redo[64 / G];
+  const uint32_t tid = threadIdx.x, lane = tid % G, sl = tid / G;
+  const uint32_t seg = blockIdx.x * (64 / G) + sl;
   const bool live = seg < n_msm;
   const uint32_t f0 = live ? foffs[seg] : 0, f1 = live ? foffs[seg + 1] : 0;
   const uint32_t pairs = (f1 - f0) * kFixedWindows;
+  if (lane == 0) redo[sl] = 0;
   G1Xyzz29 acc = xyzz29_identity();
-  for (uint32_t q = lane; q < pairs; q += kFixedLanes) {
-    const uint32_t t = f0 + q / kFixedWindows, j = q % kFixedWindows;
-    const uint32_t mag = mags[(size_t)t * 36 + j];
-    if (mag == 0) continue;
-    const uint32_t b = ids[t];
-    if (b >= n_bases) continue;  // (checked on the host for host-pointer calls; a device-resident id out of range adds nothing)
-    G1Affine29 p = g1a29_unpack(table[((size_t)b * kFixedWindows + j) * kFixedEntries + (mag - 1)]);
-    if (j < 32 && ((signs[t] >> j) & 1u)) p = g1a29_neg(p);
-    xyzz29_madd_careful(acc, p);
+  bool started = false;
+  if (lane < pairs) {
+    FixedPick cur = fixed_pick(table, ids, mags, signs, n_bases, f0, lane);
+    for (uint32_t q = lane; q < pairs; q += G) {
+      FixedPick nxt;
+      nxt.none = true;
+      if (q + G < pairs) nxt = fixed_pick(table, ids, mags, signs, n_bases, f0, q + G);  // in flight under the addition below
+      if (!cur.none) {
+        G1Affine29 p = g1a29_unpack(cur.e);
+        if (cur.neg) p = g1a29_neg(p);
+        if (started) {
+          xyzz29_madd_fast(acc, p);
+        } else {
+          acc = xyzz29_from_affine(p);
+          started = true;
+        }
+      }
+      cur = nxt;
+    }
   }
+  bool bad = started && xyzz29_is_degenerate(acc);
   sh[tid] = acc;
   __syncthreads();
-  for (uint32_t s = kFixedLanes / 2; s >= 1; s >>= 1) {
+  for (uint32_t s = G / 2; s >= 1; s >>= 1) {
     if (lane < s) {
       G1Xyzz29 a = sh[tid];
-      xyzz29_add_careful(a, sh[tid + s]);
+      xyzz29_add_skipid_fast(a, sh[tid + s], bad);
       sh[tid] = a;
     }
     __syncthreads();
   }
-  if (lane == 0 && live) out[seg] = xyzz29_sanitize(sh[tid]);
+  if (lane == 0) {
+    const G1Xyzz29 r = sh[tid];
+    bad = bad || (!xyzz29_is_identity(r) && xyzz29_is_degenerate(r));
+  }
+  if (bad) atomicOr(&redo[sl], 1u);
+  __syncthreads();
+  if (lane == 0 && live) {
+    G1Xyzz29 r = sh[tid];
+    if (redo[sl]) {  // rare: the whole segment again, carefully, on this lane
+      r = xyzz29_identity();
+      for (uint32_t q = 0; q < pairs; ++q) {
+        FixedPick c = fixed_pick(table, ids, mags, signs, n_bases, f0, q);
+        if (c.none) continue;
+        G1Affine29 p = g1a29_unpack(c.e);
+        if (c.neg) p = g1a29_neg(p);
+        xyzz29_madd_careful(r, p);
+      }
+    }
+    out[seg] = xyzz29_sanitize(r);
+  }
 }
 
 // the scalars d 256^j mod r, d = 1 .. 128, j = 0 .. 32, canonical little-endian, [j][d - 1]
@@ -257,9 +321,17 @@ int launch_fixed_terms(snarkv_ctx* ctx, hipStream_t st, const snarkv_fixed_table
   if (n_fixed)
     hipLaunchKernelGGL(k_fixed_digits, dim3((uint32_t)((n_fixed + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_fixed_scalars,
                        (uint32_t)n_fixed, (uint8_t*)d_mags, (uint32_t*)d_signs, mont);
-  hipLaunchKernelGGL(k_fixed_terms, dim3((uint32_t)((n_msm + 3) / 4)), dim3(64), 0, st, (const G1Packed*)tab->d_table,
-                     (const uint32_t*)d_fixed_ids, (const uint32_t*)d_fixed_offsets, (const uint8_t*)d_mags,
-                     (const uint32_t*)d_signs, (uint32_t)n_msm, (uint32_t)tab->n, (G1Xyzz29*)d_extra);
+  // lanes per segment: 16 while the launch is a latency chain (a few thousand segments), 4 when it has to be cheap
+  const char* eg = getenv("SNARKV_FIXED_LANES");  // A/B knob: 4 | 16
+  const int g = eg ? atoi(eg) : (n_msm > 8192 || ctx->throughput_mode ? 4 : 16);
+  if (g == 4)
+    hipLaunchKernelGGL((k_fixed_terms<4>), dim3((uint32_t)((n_msm + 15) / 16)), dim3(64), 0, st, (const G1Packed*)tab->d_table,
+                       (const uint32_t*)d_fixed_ids, (const uint32_t*)d_fixed_offsets, (const uint8_t*)d_mags,
+                       (const uint32_t*)d_signs, (uint32_t)n_msm, (uint32_t)tab->n, (G1Xyzz29*)d_extra);
+  else
+    hipLaunchKernelGGL((k_fixed_terms<16>), dim3((uint32_t)((n_msm + 3) / 4)), dim3(64), 0, st, (const G1Packed*)tab->d_table,
+                       (const uint32_t*)d_fixed_ids, (const uint32_t*)d_fixed_offsets, (const uint8_t*)d_mags,
+                       (const uint32_t*)d_signs, (uint32_t)n_msm, (uint32_t)tab->n, (G1Xyzz29*)d_extra);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }

@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256) k_gmap_count(const uint32_t* __restrict__
 
 // one block: totals per K, the choice, and the exclusive scan of the chosen K's block sums (in place in its row)
 __global__ void __launch_bounds__(1024) k_gmap_choose(uint32_t* __restrict__ bsum, uint32_t nblk, uint32_t* __restrict__ choice,
-                                                      uint32_t force_k) {
+                                                      uint32_t force_k, uint32_t slots) {
   __shared__ uint32_t sh[1024];
   __shared__ uint32_t tot[3], run, kk;
   const uint32_t tid = threadIdx.x;
@@ -273,7 +273,12 @@ __global__ void __launch_bounds__(1024) k_gmap_choose(uint32_t* __restrict__ bsu
     uint32_t best = 0;
     unsigned long long bc = ~0ull;
     for (uint32_t k = 0; k < 3; ++k) {
-      const unsigned long long cost = (unsigned long long)tot[k] * (1160ull + (k + 2) * 830ull);
+      // duration ~ (passes of the resident grid over the lanes) x (one lane's chain): a launch that does not fill the
+      // machine is as long as its chain, whatever its total work (round 5: 16 x 1 024 proofs with 12 + 3-term segments took
+      // K = 4 by total work and ran 4.0 ms on one wavefront per SIMD; K = 2 fills the same slots with a chain 0.63x as long)
+      const unsigned long long waves = ((unsigned long long)tot[k] + 63) / 64;
+      const unsigned long long passes = slots ? (waves + slots - 1) / slots : 1;
+      const unsigned long long cost = (passes ? passes : 1) * (1160ull + (k + 2) * 830ull) * 1000000ull + tot[k];  // ties: less work
       if (cost < bc) bc = cost, best = k;
     }
     if (force_k >= 2 && force_k <= 4) best = force_k - 2;
@@ -794,7 +799,7 @@ int launch_msm_batched_ex(snarkv_ctx* ctx, const void* d_scalars, const void* d_
       uint32_t* base = choice + 8;
       SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_CHAIN, (size_t)grid * kGroupMax * kGroupRows * 64 * 4, &d_tab));
       hipLaunchKernelGGL(k_gmap_count, dim3(nblk), dim3(256), 0, ctx->stream, (const uint32_t*)d_offsets, (uint32_t)n_msm, bsum);
-      hipLaunchKernelGGL(k_gmap_choose, dim3(1), dim3(1024), 0, ctx->stream, bsum, nblk, choice, (uint32_t)(jmode >= 2 ? jmode : 0));
+      hipLaunchKernelGGL(k_gmap_choose, dim3(1), dim3(1024), 0, ctx->stream, bsum, nblk, choice, (uint32_t)(jmode >= 2 ? jmode : 0), (uint32_t)slots);
       hipLaunchKernelGGL(k_gmap_fill, dim3(nblk), dim3(256), 0, ctx->stream, (const uint32_t*)d_offsets, (uint32_t)n_msm,
                          (const uint32_t*)bsum, (const uint32_t*)choice, base);
       hipLaunchKernelGGL(k_term_scalar_mul_group, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,
