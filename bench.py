@@ -141,13 +141,6 @@ def secondary_metrics(sv, torch, ctxs, cpu=True):
     g1 = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
     dks = [sv.DecidingKey(c, g1, g2, g2) for c in ctxs]  # s = 1: (P, P) is a valid accumulator
     dk = dks[0]
-    fb = torch.empty(64 * 9, dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
-    ctx.sample_points_dev(0x5EED0006, 9, fb.data_ptr())
-    ctx.sync()
-    t0 = time.perf_counter()
-    ftab = sv.FixedTable(ctx, bytes(fb.cpu().numpy()))  # the protocol's shared bases: built once per protocol
-    out["fixed_table_create_9_bases_ms"] = (time.perf_counter() - t0) * 1e3
     for nproofs in (64, 1024):
         offs = [0]
         for _ in range(nproofs):
@@ -170,37 +163,6 @@ def secondary_metrics(sv, torch, ctxs, cpu=True):
             c.msm_batched_dev(ds.data_ptr(), dp.data_ptr(), o2.data_ptr(), 2, n2, acc[k].data_ptr())
             c.decide_batch_dev(dks[k], acc[k].data_ptr(), 1, ok[k].data_ptr())
 
-        # the same job with the 9 bases every proof of a protocol shares (8 preprocessed commitments + the generator: 9 of the
-        # 21 terms of Gwc19's left MSM) served from window tables (snarkv_g1_msm_batched_fixed_dev): 12 + 3 variable-base
-        # terms per proof, 9 fixed-base ones
-        voffs, foffs = [0], [0]
-        for _ in range(nproofs):
-            voffs += [voffs[-1] + 12, voffs[-1] + 15]
-            foffs += [foffs[-1] + 9, foffs[-1] + 9]
-        nv, nf = voffs[-1], foffs[-1]
-        vo = torch.tensor(voffs, dtype=torch.int32, device="cuda")
-        fo = torch.tensor(foffs, dtype=torch.int32, device="cuda")
-        fids = torch.tensor([i % 9 for i in range(nf)], dtype=torch.int32, device="cuda")
-        out1f = torch.zeros(64 * (len(voffs) - 1), dtype=torch.uint8, device="cuda")
-
-        def job_fixed():
-            ctx.msm_batched_fixed_dev(ftab, ds.data_ptr(), dp.data_ptr(), vo.data_ptr(), nv, ds.data_ptr() + 32 * nv, fids.data_ptr(),
-                                      fo.data_ptr(), nf, len(voffs) - 1, out1f.data_ptr())
-            ctx.msm_batched_dev(ds.data_ptr(), dp.data_ptr(), o2.data_ptr(), 2, n2, acc[0].data_ptr())
-            ctx.decide_batch_dev(dks[0], acc[0].data_ptr(), 1, ok[0].data_ptr())
-
-        ms_f = t_ms(job_fixed, reps=10)
-        ms_s1 = t_ms(lambda: ctx.msm_batched_dev(ds.data_ptr(), dp.data_ptr(), o1.data_ptr(), len(offs) - 1, n1, out1[0].data_ptr()), reps=10)
-        ms_s1f = t_ms(lambda: ctx.msm_batched_fixed_dev(ftab, ds.data_ptr(), dp.data_ptr(), vo.data_ptr(), nv, ds.data_ptr() + 32 * nv,
-                                                        fids.data_ptr(), fo.data_ptr(), nf, len(voffs) - 1, out1f.data_ptr()), reps=10)
-        out["aggregate_%d_proofs_fixed_base" % nproofs] = {
-            "ms": ms_f, "proofs_per_s": nproofs / ms_f * 1e3, "estimator": "mean", "calls": 10, "jobs_in_flight": 1,
-            "variable_terms": nv + n2, "fixed_terms": nf, "fixed_bases": 9, "includes_decide": True,
-            "ms_stage1_plain": ms_s1, "ms_stage1_fixed_base": ms_s1f,
-            "timing": "mean of 10 calls enqueued back to back on one stream, ONE job at a time",
-            "what": "the 21 + 3-term MSMs of every proof with 9 of the 21 bases from a snarkv_fixed_table (the host mirror routes a "
-                    "protocol's preprocessed commitments and the generator there), then KzgAs, then one decide",
-            "per_call": t_each(job_fixed, 25)}
         ms = t_ms(lambda: job(0), reps=10)
         out["aggregate_%d_proofs" % nproofs] = {"ms": ms, "proofs_per_s": nproofs / ms * 1e3,
                                                  "msm_terms": n1 + n2, "includes_decide": True,
@@ -249,28 +211,6 @@ def secondary_metrics(sv, torch, ctxs, cpu=True):
             ctx.msm_batched_dev(dsm.data_ptr(), dpm.data_ptr(), o2m.data_ptr(), 2 * J, n2m, accm.data_ptr())
             ctx.decide_batch_dev(dk, accm.data_ptr(), J, okm.data_ptr())
 
-        voffs_m, foffs_m = [0], [0]
-        for _ in range(nproofs * J):
-            voffs_m += [voffs_m[-1] + 12, voffs_m[-1] + 15]
-            foffs_m += [foffs_m[-1] + 9, foffs_m[-1] + 9]
-        nvm, nfm = voffs_m[-1], foffs_m[-1]
-        vom = torch.tensor(voffs_m, dtype=torch.int32, device="cuda")
-        fom = torch.tensor(foffs_m, dtype=torch.int32, device="cuda")
-        fidm = (torch.arange(nfm, dtype=torch.int32, device="cuda") % 9).contiguous()
-        torch.cuda.synchronize()
-
-        def merged_fixed():
-            ctx.msm_batched_fixed_dev(ftab, dsm.data_ptr(), dpm.data_ptr(), vom.data_ptr(), nvm, dsm.data_ptr() + 32 * nvm,
-                                      fidm.data_ptr(), fom.data_ptr(), nfm, len(voffs_m) - 1, out1m.data_ptr())
-            ctx.msm_batched_dev(dsm.data_ptr(), dpm.data_ptr(), o2m.data_ptr(), 2 * J, n2m, accm.data_ptr())
-            ctx.decide_batch_dev(dk, accm.data_ptr(), J, okm.data_ptr())
-
-        msf = min(t_ms(merged_fixed, reps=2, warm=1) for _ in range(3)) / J
-        out["aggregate_%d_proofs_merged_fixed_base" % nproofs] = {
-            "ms_per_job": msf, "proofs_per_s": nproofs / msf * 1e3, "jobs_merged": J, "includes_decide": True,
-            "variable_terms": (nvm + n2m) // J, "fixed_terms": nfm // J, "estimator": "min", "calls": 3,
-            "timing": "best of 3 timed regions of 2 merged calls",
-            "NOT_the_named_config": "16 jobs merged into one set of launches, 9 of 21 bases from the fixed table: a throughput figure"}
         ms = min(t_ms(merged, reps=2, warm=1) for _ in range(3)) / J
         out["aggregate_%d_proofs_merged" % nproofs] = {
             "ms_per_job": ms, "proofs_per_s": nproofs / ms * 1e3, "msm_terms": (n1m + n2m) // J, "includes_decide": True,
@@ -292,7 +232,6 @@ def secondary_metrics(sv, torch, ctxs, cpu=True):
         out["decide_all_1"]["cpu_baseline"], out["decide_all_1024"]["cpu_baseline"] = cpu_baseline_decide(g2, g1 + g1)
     for d in dks:
         d.close()
-    ftab.close()
     # `IpaAs::decide` (pcs/ipa/decider.rs:47-55) at k = 20: the other consumer of the 2^20-point MSM --
     # committing key resident on the device, h_coeffs built by a kernel, 20 scalars in / 64 bytes out
     k = 20

@@ -183,30 +183,6 @@ int snarkv_kzg_pairing_value(snarkv_ctx* ctx, const snarkv_dk* dk, const uint8_t
  * SNARKV_ERR_ENCODING.                                                      */
 int snarkv_g1_validate(snarkv_ctx* ctx, const uint8_t* points64, size_t n);
 
-/* ---- fixed-base rows: the bases every proof of a protocol shares ------------- *
- * Nine of the 21 terms of `Gwc19::verify`'s left MSM (pcs/kzg/multiopen/gwc19.rs:124-139: the protocol's preprocessed
- * commitments, and the generator that carries the evaluations) are THE SAME POINTS for every proof of one protocol, and
- * `NativeLoader::multi_scalar_multiplication` (loader/native.rs:61-71) pays a 254-step double-and-add for each of them per
- * proof.  The reference's in-circuit loader already separates fixed- from variable-base terms
- * (loader/halo2/loader.rs:637-720).  A `snarkv_fixed_table` holds d 2^(8 j) B for every such base B (device memory,
- * 264 KiB per base, built once per protocol by the variable-base kernels themselves); `snarkv_g1_msm_batched_fixed` is
- * `snarkv_g1_msm_batched` whose segments have a second list of terms  fixed_scalars32[i] * base fixed_ids[i]  evaluated by
- * 33 table additions each, without doublings.  Segment k = variable terms [offsets[k], offsets[k+1]) + fixed terms
- * [fixed_offsets[k], fixed_offsets[k+1]); either list may be empty for a segment, not both (SNARKV_ERR_EMPTY).  Same
- * bytes as the plain call on the same (scalar, point) pairs, in either encoding (the table's bases are given in the
- * encoding of the create call, terms and results follow the msm call's); identity, repeated and opposite bases are fine. */
-typedef struct snarkv_fixed_table snarkv_fixed_table;
-int snarkv_g1_fixed_table_create(snarkv_ctx* ctx, const uint8_t* points64, size_t n, uint32_t flags, snarkv_fixed_table** out);
-void snarkv_g1_fixed_table_destroy(snarkv_fixed_table* tab);
-size_t snarkv_g1_fixed_table_size(const snarkv_fixed_table* tab); /* bases */
-int snarkv_g1_msm_batched_fixed(snarkv_ctx* ctx, const snarkv_fixed_table* tab, const uint8_t* scalars32, const uint8_t* points64,
-                                const uint32_t* offsets, const uint8_t* fixed_scalars32, const uint32_t* fixed_ids,
-                                const uint32_t* fixed_offsets, size_t n_msm, uint32_t flags, uint8_t* out);
-/* device-resident form: every array in HBM (offsets: n_msm + 1 u32 each), asynchronous on the context's stream */
-int snarkv_g1_msm_batched_fixed_dev(snarkv_ctx* ctx, const snarkv_fixed_table* tab, const void* d_scalars32, const void* d_points64,
-                                    const void* d_offsets, size_t n_terms, const void* d_fixed_scalars32, const void* d_fixed_ids,
-                                    const void* d_fixed_offsets, size_t n_fixed, size_t n_msm, void* d_out);
-
 /* ---- compressed points of a Poseidon transcript ----------------------------- *
  * `C::from_bytes(&data)` of `PoseidonTranscript::read_ec_point`
  * (snark-verifier/src/system/halo2/transcript/halo2.rs:260-273) for a whole batch: n x 32 bytes (x little-endian,
@@ -237,10 +213,6 @@ int bn254_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, cons
                          uint8_t* out);
 int bn254_g1_msm_pippenger(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]);
 int bn254_g1_decompress(const uint8_t* in32, size_t n, uint8_t* out64, uint8_t* ok);
-int bn254_g1_fixed_table_create(const uint8_t* points64, size_t n, snarkv_fixed_table** out);
-int bn254_g1_msm_batched_fixed(const snarkv_fixed_table* tab, const uint8_t* scalars32, const uint8_t* points64,
-                               const uint32_t* offsets, const uint8_t* fixed_scalars32, const uint32_t* fixed_ids,
-                               const uint32_t* fixed_offsets, size_t n_msm, uint8_t* out);
 /* pinned host memory for the inputs of the context-free calls, owned by the CALLING THREAD (SNARKV_HOST_BUFFERS slots,
  * grow-only; a pointer stays valid until the same thread asks for the same slot with a larger size): threads pack
  * side by side without a lock, whatever pool context their calls land on */

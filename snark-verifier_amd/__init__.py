@@ -22,7 +22,6 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 from ._lib import (  # noqa: F401,E402
     Context,
     DecidingKey,
-    FixedTable,
     IpaDecidingKey,
     MultiGpu,
     PoseidonSpec,
@@ -48,7 +47,6 @@ __all__ = [
     "host_api",
     "Context",
     "DecidingKey",
-    "FixedTable",
     "IpaDecidingKey",
     "MultiGpu",
     "PoseidonSpec",

@@ -56,13 +56,6 @@ _SIGNATURES = {
     "bn254_set_thread_flags": (ctypes.c_int64, [ctypes.c_int64]),
     "bn254_get_flags": (ctypes.c_uint32, []),
     "bn254_default_contexts": (_int, [ctypes.POINTER(_int), ctypes.POINTER(_int)]),
-    "snarkv_g1_fixed_table_create": (_int, [_vp, _cp, _sz, _u32, _pp]),
-    "snarkv_g1_fixed_table_destroy": (None, [_vp]),
-    "snarkv_g1_fixed_table_size": (_sz, [_vp]),
-    "snarkv_g1_msm_batched_fixed": (_int, [_vp, _vp, _cp, _cp, _vp, _cp, _vp, _vp, _sz, _u32, _vp]),
-    "snarkv_g1_msm_batched_fixed_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz, _vp]),
-    "bn254_g1_fixed_table_create": (_int, [_cp, _sz, _pp]),
-    "bn254_g1_msm_batched_fixed": (_int, [_vp, _cp, _cp, _vp, _cp, _vp, _vp, _sz, _vp]),
     "snarkv_last_error": (_cp, []),
     "snarkv_version": (_cp, []),
     "snarkv_g1_msm_naive": (_int, [_vp, _cp, _cp, _sz, _u32, _vp]),
@@ -319,28 +312,6 @@ class DecidingKey:
             pass
 
 
-class FixedTable:
-    """Window tables of the bases every proof of a protocol shares (include/snarkv_amd.h "fixed-base rows")."""
-
-    def __init__(self, ctx, points, flags=0):
-        self._lib = load_library()
-        points = _as_bytes(points)
-        self._h = ctypes.c_void_p()
-        _check(self._lib.snarkv_g1_fixed_table_create(ctx._h, points, len(points) // 64, flags, ctypes.byref(self._h)))
-        self.n = len(points) // 64
-
-    def close(self):
-        if self._h:
-            self._lib.snarkv_g1_fixed_table_destroy(self._h)
-            self._h = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-
 class IpaDecidingKey:
     """Device-resident committing key of `IpaDecidingKey` (reference pcs/ipa/decider.rs:5-9;
     include/snarkv_amd.h `snarkv_ipa_dk_create`): `g` = 2^k points, 64 bytes each."""
@@ -512,25 +483,6 @@ class Context:
         addr, _ = offs.buffer_info()
         _check(self._lib.snarkv_g1_msm_batched(self._h, s, p, ctypes.c_void_p(addr), n_msm, flags, out))
         return out.raw[: 64 * n_msm]
-
-    def msm_batched_fixed(self, tab, scalars, points, offsets, fixed_scalars, fixed_ids, fixed_offsets, flags=0):
-        """segmented MSM whose segments carry a second list of terms on the bases of `tab` (a FixedTable)"""
-        scalars, points, fixed_scalars = _as_bytes(scalars), _as_bytes(points), _as_bytes(fixed_scalars)
-        n_msm = len(offsets) - 1
-        if len(fixed_offsets) != n_msm + 1 or len(points) != 2 * len(scalars) or len(fixed_ids) * 32 != len(fixed_scalars):
-            raise SnarkvError(SNARKV_ERR_LENGTH, "list lengths disagree")
-        o = (ctypes.c_uint32 * (n_msm + 1))(*offsets)
-        fo = (ctypes.c_uint32 * (n_msm + 1))(*fixed_offsets)
-        fi = (ctypes.c_uint32 * max(1, len(fixed_ids)))(*fixed_ids)
-        out = ctypes.create_string_buffer(64 * max(1, n_msm))
-        _check(self._lib.snarkv_g1_msm_batched_fixed(self._h, tab._h, scalars or None, points or None, o, fixed_scalars or None, fi, fo,
-                                                     n_msm, flags, out))
-        return out.raw[: 64 * n_msm]
-
-    def msm_batched_fixed_dev(self, tab, d_scalars, d_points, d_offsets, n_terms, d_fixed_scalars, d_fixed_ids, d_fixed_offsets,
-                              n_fixed, n_msm, d_out):
-        _check(self._lib.snarkv_g1_msm_batched_fixed_dev(self._h, tab._h, d_scalars, d_points, d_offsets, n_terms, d_fixed_scalars,
-                                                         d_fixed_ids, d_fixed_offsets, n_fixed, n_msm, d_out))
 
     def msm_pippenger(self, scalars, points, flags=0):
         """`util::msm::multi_scalar_multiplication` (msm.rs:308-343), affine."""

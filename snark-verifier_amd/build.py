@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libsnarkv_amd.so")
-UNITS = ["capi", "msm_naive", "msm_fixed", "msm_pippenger", "decider", "sample", "poseidon", "ipa", "mgpu", "decompress"]
+UNITS = ["capi", "msm_naive", "msm_pippenger", "decider", "sample", "poseidon", "ipa", "mgpu", "decompress"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 FLAGS += os.environ.get("SNARKV_EXTRA_FLAGS", "").split()

@@ -270,113 +270,6 @@ int snarkv_g1_msm_batched(snarkv_ctx* ctx, const uint8_t* scalars32, const uint8
   return fetch_out(ctx, d_out, out, n_msm * 64);
 }
 
-// ---- fixed-base rows (msm_fixed.hip) ------------------------------------------------------------------------------
-int snarkv_g1_fixed_table_create(snarkv_ctx* ctx, const uint8_t* points64, size_t n, uint32_t flags, snarkv_fixed_table** out) {
-  if (!ctx || !points64 || !out) return SNARKV_ERR_ARG;
-  *out = nullptr;
-  if (n == 0) return SNARKV_ERR_EMPTY;
-  if (n > 4096) return SNARKV_ERR_LENGTH;  // 264 KiB of table per base
-  SNARKV_HIP(hipSetDevice(ctx->device));
-  SNARKV_CALL_FLAGS(ctx, flags);
-  void* d_p;
-  SNARKV_TRY(stage_in(ctx, SLOT_IN_POINTS, points64, n * 64, &d_p));
-  if ((flags | ctx->flags) & SNARKV_FLAG_VALIDATE) {
-    int bad = 0;
-    SNARKV_TRY(launch_validate(ctx, nullptr, d_p, n, &bad));
-    if (bad) {
-      set_last_error("%d of %zu fixed bases are non-canonical or off-curve", bad, n);
-      return SNARKV_ERR_ENCODING;
-    }
-  }
-  return fixed_table_create(ctx, d_p, n, out);
-}
-
-void snarkv_g1_fixed_table_destroy(snarkv_fixed_table* tab) {
-  if (!tab) return;
-  (void)hipSetDevice(fixed_table_device(tab));
-  fixed_table_free(tab);
-}
-
-size_t snarkv_g1_fixed_table_size(const snarkv_fixed_table* tab) { return tab ? fixed_table_bases(tab) : 0; }
-
-// the shared launch sequence: fixed parts on a side stream next to the variable-base kernels, one fold
-static int msm_batched_fixed_launch(snarkv_ctx* ctx, const snarkv_fixed_table* tab, const void* d_s, const void* d_p,
-                                    const void* d_o, size_t n_terms, const void* d_fs, const void* d_fi, const void* d_fo,
-                                    size_t n_fixed, size_t n_msm, void* d_out) {
-  void *d_mags, *d_signs, *d_sums;
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_FIXED_DIGITS, std::max<size_t>(36, n_fixed * 36), &d_mags));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_FIXED_SIGNS, std::max<size_t>(4, n_fixed * 4), &d_signs));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_FIXED_SUMS, n_msm * SNARKV_G1_PARTIAL_BYTES, &d_sums));
-  hipStream_t side = ctx->stream;
-  hipEvent_t ready = nullptr;
-  if (!ctx->is_lane && n_terms) {  // (a lane context never starts lanes of its own: its fixed parts run in line)
-    SNARKV_TRY(ctx_lanes(ctx));
-    SNARKV_TRY(ctx_lanes_fork(ctx));  // the side stream waits for the inputs staged on the context's stream
-    side = ctx->sub[0]->stream;
-    ready = ctx->sub_ev[0];
-  }
-  SNARKV_TRY(launch_fixed_terms(ctx, side, tab, d_fs, d_fi, d_fo, n_msm, n_fixed, d_mags, d_signs, d_sums));
-  if (ready) SNARKV_HIP(hipEventRecord(ready, side));
-  return launch_msm_batched_ex(ctx, d_s, d_p, d_o, n_msm, n_terms, d_out, d_sums, ready);
-}
-
-int snarkv_g1_msm_batched_fixed(snarkv_ctx* ctx, const snarkv_fixed_table* tab, const uint8_t* scalars32, const uint8_t* points64,
-                                const uint32_t* offsets, const uint8_t* fixed_scalars32, const uint32_t* fixed_ids,
-                                const uint32_t* fixed_offsets, size_t n_msm, uint32_t flags, uint8_t* out) {
-  if (!ctx || !tab || !offsets || !fixed_offsets || !out) return SNARKV_ERR_ARG;
-  if (n_msm == 0) return SNARKV_ERR_EMPTY;
-  if (offsets[0] != 0 || fixed_offsets[0] != 0) return SNARKV_ERR_LENGTH;
-  if (fixed_table_device(tab) != ctx->device) return SNARKV_ERR_ARG;
-  for (size_t k = 0; k < n_msm; ++k) {
-    if (offsets[k + 1] < offsets[k] || fixed_offsets[k + 1] < fixed_offsets[k]) return SNARKV_ERR_LENGTH;
-    if (offsets[k + 1] == offsets[k] && fixed_offsets[k + 1] == fixed_offsets[k]) return SNARKV_ERR_EMPTY;  // native.rs:69
-  }
-  const size_t n = offsets[n_msm], nf = fixed_offsets[n_msm];
-  if ((n && (!scalars32 || !points64)) || (nf && (!fixed_scalars32 || !fixed_ids))) return SNARKV_ERR_ARG;
-  for (size_t i = 0; i < nf; ++i)
-    if (fixed_ids[i] >= fixed_table_bases(tab)) {
-      set_last_error("fixed term %zu names base %u of a table of %zu", i, fixed_ids[i], fixed_table_bases(tab));
-      return SNARKV_ERR_ARG;
-    }
-  SNARKV_HIP(hipSetDevice(ctx->device));
-  SNARKV_CALL_FLAGS(ctx, flags);
-  void *d_s = nullptr, *d_p = nullptr, *d_o, *d_fs = nullptr, *d_fi = nullptr, *d_fo, *d_out;
-  if (n) {
-    SNARKV_TRY(stage_in(ctx, SLOT_IN_SCALARS, scalars32, n * 32, &d_s));
-    SNARKV_TRY(stage_in(ctx, SLOT_IN_POINTS, points64, n * 64, &d_p));
-  }
-  SNARKV_TRY(stage_in(ctx, SLOT_IN_OFFSETS, offsets, (n_msm + 1) * 4, &d_o));
-  if (nf) {
-    SNARKV_TRY(stage_in(ctx, SLOT_FIXED_SCALARS, fixed_scalars32, nf * 32, &d_fs));
-    SNARKV_TRY(stage_in(ctx, SLOT_FIXED_IDS, fixed_ids, nf * 4, &d_fi));
-  }
-  SNARKV_TRY(stage_in(ctx, SLOT_FIXED_OFFSETS, fixed_offsets, (n_msm + 1) * 4, &d_fo));
-  SNARKV_TRY(ctx_reserve(ctx, SLOT_OUT, n_msm * 64, &d_out));
-  if (n) SNARKV_TRY(check_validate(ctx, d_s, d_p, n, flags));
-  if (nf && ((flags | ctx->flags) & SNARKV_FLAG_VALIDATE)) {
-    int bad = 0;
-    SNARKV_TRY(launch_validate(ctx, d_fs, nullptr, nf, &bad));
-    if (bad) {
-      set_last_error("%d of %zu fixed-term scalars are non-canonical", bad, nf);
-      return SNARKV_ERR_ENCODING;
-    }
-  }
-  SNARKV_TRY(msm_batched_fixed_launch(ctx, tab, d_s, d_p, d_o, n, d_fs, d_fi, d_fo, nf, n_msm, d_out));
-  return fetch_out(ctx, d_out, out, n_msm * 64);
-}
-
-int snarkv_g1_msm_batched_fixed_dev(snarkv_ctx* ctx, const snarkv_fixed_table* tab, const void* d_scalars32, const void* d_points64,
-                                    const void* d_offsets, size_t n_terms, const void* d_fixed_scalars32, const void* d_fixed_ids,
-                                    const void* d_fixed_offsets, size_t n_fixed, size_t n_msm, void* d_out) {
-  if (!ctx || !tab || !d_offsets || !d_fixed_offsets || !d_out) return SNARKV_ERR_ARG;
-  if ((n_terms && (!d_scalars32 || !d_points64)) || (n_fixed && (!d_fixed_scalars32 || !d_fixed_ids))) return SNARKV_ERR_ARG;
-  if (n_msm == 0 || n_terms + n_fixed == 0) return SNARKV_ERR_EMPTY;
-  if (fixed_table_device(tab) != ctx->device) return SNARKV_ERR_ARG;
-  SNARKV_HIP(hipSetDevice(ctx->device));
-  return msm_batched_fixed_launch(ctx, tab, d_scalars32, d_points64, d_offsets, n_terms, d_fixed_scalars32, d_fixed_ids,
-                                  d_fixed_offsets, n_fixed, n_msm, d_out);
-}
-
 int snarkv_g1_decompress(snarkv_ctx* ctx, const uint8_t* in32, size_t n, uint8_t* out64, uint8_t* ok) {
   if (!ctx || (n && (!in32 || !out64 || !ok))) return SNARKV_ERR_ARG;
   if (n == 0) return SNARKV_OK;
@@ -1004,18 +897,6 @@ int bn254_g1_msm_batched(const uint8_t* scalars32, const uint8_t* points64, cons
                          uint8_t* out) {
   SNARKV_DEFAULT_LEASE(c);
   return snarkv_g1_msm_batched(c, scalars32, points64, offsets, n_msm, 0, out);
-}
-
-int bn254_g1_fixed_table_create(const uint8_t* points64, size_t n, snarkv_fixed_table** out) {
-  SNARKV_DEFAULT_LEASE(c);
-  return snarkv_g1_fixed_table_create(c, points64, n, 0, out);
-}
-
-int bn254_g1_msm_batched_fixed(const snarkv_fixed_table* tab, const uint8_t* scalars32, const uint8_t* points64,
-                               const uint32_t* offsets, const uint8_t* fixed_scalars32, const uint32_t* fixed_ids,
-                               const uint32_t* fixed_offsets, size_t n_msm, uint8_t* out) {
-  SNARKV_DEFAULT_LEASE(c);
-  return snarkv_g1_msm_batched_fixed(c, tab, scalars32, points64, offsets, fixed_scalars32, fixed_ids, fixed_offsets, n_msm, 0, out);
 }
 
 int bn254_g1_decompress(const uint8_t* in32, size_t n, uint8_t* out64, uint8_t* ok) {

@@ -66,12 +66,6 @@ enum Slot {
   SLOT_IPA_OUT,
   SLOT_MGPU_GRID,
   SLOT_MGPU_RECV,
-  SLOT_FIXED_SCALARS,
-  SLOT_FIXED_IDS,
-  SLOT_FIXED_OFFSETS,
-  SLOT_FIXED_DIGITS,
-  SLOT_FIXED_SIGNS,
-  SLOT_FIXED_SUMS,
   SLOT_COUNT
 };
 
@@ -114,7 +108,6 @@ struct snarkv_ctx {
   bool hi_ready;
 };
 
-struct snarkv_fixed_table;
 struct snarkv_dk {
   int device;
   void* d_prep;  // 2 x G2Prepared29 (g2, -s_g2): the line tables the decide kernels read
@@ -161,16 +154,6 @@ inline snarkv_ctx* ctx_lane(snarkv_ctx* ctx, size_t i) { return (i % 4 == 3) ? c
 // kernels' host-side launchers (each enqueues on ctx->stream)
 int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, const void* d_offsets,
                        size_t n_msm, size_t n_terms, void* d_out);
-int launch_msm_batched_ex(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, const void* d_offsets,
-                          size_t n_msm, size_t n_terms, void* d_out, const void* d_extra, hipEvent_t extra_ready);
-// fixed-base rows (msm_fixed.hip): table of d 2^(8 j) B per base, and the fixed part of every segment as one point
-int fixed_table_create(snarkv_ctx* ctx, const void* d_points_call_encoding, size_t n, snarkv_fixed_table** out);
-void fixed_table_free(snarkv_fixed_table* tab);
-int fixed_table_device(const snarkv_fixed_table* tab);
-size_t fixed_table_bases(const snarkv_fixed_table* tab);
-int launch_fixed_terms(snarkv_ctx* ctx, hipStream_t st, const snarkv_fixed_table* tab, const void* d_fixed_scalars,
-                       const void* d_fixed_ids, const void* d_fixed_offsets, size_t n_msm, size_t n_fixed, void* d_mags,
-                       void* d_signs, void* d_extra);
 int launch_g1_decompress(snarkv_ctx* ctx, const void* d_in32, size_t n, void* d_out64, void* d_ok);
 int launch_msm_pippenger(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, size_t n, int window_bits,
                          void* d_out, bool partial_out, void* d_buckets_out = nullptr);

@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(64, SNARKV_NAIVE_WAVES) k_term_scalar_mul(cons
 // launches in flight: the context's throughput hint).  Round 3 had the K = 1 case with projective tables (one lane per
 // term: 2 360 products); measured steps: profiles/r04_ab_naive_group.txt.
 //   lanes     segment s of L_s terms gets ceil(L_s / K) lanes; K in {2, 3, 4} is chosen ON THE DEVICE (the offsets live
-//             there) as the cheapest by  lanes x (1 160 + K x 830): three small kernels count, choose + scan, fill the
+//             there) as the shortest by  passes of the resident grid x (1 160 + K x 830): three small kernels count, choose + scan, fill the
 //             lane -> segment map, and a lane finds its segment by binary search
 //   grid      at most the machine's resident wavefronts; a block walks its share of the lanes, so the table scratch is
 //             sized by the machine, not by the launch
@@ -274,11 +274,12 @@ __global__ void __launch_bounds__(1024) k_gmap_choose(uint32_t* __restrict__ bsu
     unsigned long long bc = ~0ull;
     for (uint32_t k = 0; k < 3; ++k) {
       // duration ~ (passes of the resident grid over the lanes) x (one lane's chain): a launch that does not fill the
-      // machine is as long as its chain, whatever its total work (round 5: 16 x 1 024 proofs with 12 + 3-term segments took
-      // K = 4 by total work and ran 4.0 ms on one wavefront per SIMD; K = 2 fills the same slots with a chain 0.63x as long)
+      // machine is as long as its chain, whatever its total work (profiles/r05_ab_fixed_base.txt: 16 x 1 024 proofs with
+      // 12 + 3-term segments took K = 4 by total work and ran 4.3 ms on one wavefront per SIMD; K = 2 fills the same slots
+      // with a chain 0.63x as long: 3.0 ms).  Ties go to the smaller total.
       const unsigned long long waves = ((unsigned long long)tot[k] + 63) / 64;
       const unsigned long long passes = slots ? (waves + slots - 1) / slots : 1;
-      const unsigned long long cost = (passes ? passes : 1) * (1160ull + (k + 2) * 830ull) * 1000000ull + tot[k];  // ties: less work
+      const unsigned long long cost = (passes ? passes : 1) * (1160ull + (k + 2) * 830ull) * 1000000ull + tot[k];
       if (cost < bc) bc = cost, best = k;
     }
     if (force_k >= 2 && force_k <= 4) best = force_k - 2;
@@ -678,8 +679,7 @@ __global__ void __launch_bounds__(64) k_term_chunks(const G1Xyzz29* __restrict__
 template <int THREADS, int G>
 __global__ void __launch_bounds__(THREADS) k_segment_fold(const G1Xyzz29* __restrict__ parts,
                                                            const uint32_t* __restrict__ offsets,
-                                                           uint32_t* __restrict__ out, uint32_t n_msm, uint32_t mont,
-                                                           const G1Xyzz29* __restrict__ extra) {
+                                                           uint32_t* __restrict__ out, uint32_t n_msm, uint32_t mont) {
   static_assert(THREADS % G == 0 && (G & (G - 1)) == 0, "G lanes per MSM: a power of two dividing the workgroup");
   __shared__ G1Xyzz29 sh[THREADS];
   const uint32_t tid = threadIdx.x, lane = tid % G;
@@ -687,7 +687,6 @@ __global__ void __launch_bounds__(THREADS) k_segment_fold(const G1Xyzz29* __rest
   const bool live = k < n_msm;
   const uint32_t lo = live ? 2 * offsets[k] : 0, hi = live ? 2 * offsets[k + 1] : 0;
   G1Xyzz29 acc = xyzz29_identity();
-  if (extra && live && lane == 0) acc = extra[k];  // the segment's fixed-base part (msm_fixed.hip), one point
   for (uint32_t i = lo + lane; i < hi; i += G) xyzz29_add_careful(acc, parts[i]);
   sh[tid] = acc;
   __syncthreads();
@@ -762,21 +761,11 @@ static uint32_t chunks_for(size_t n_terms) {
 
 int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, const void* d_offsets,
                        size_t n_msm, size_t n_terms, void* d_out) {
-  return launch_msm_batched_ex(ctx, d_scalars, d_points, d_offsets, n_msm, n_terms, d_out, nullptr, nullptr);
-}
-
-// ... with `d_extra` (optional): one XYZZ point per segment added to its sum -- the fixed-base part (msm_fixed.hip).  A
-// segment may then have no variable-base term at all, and n_terms may be 0.  `extra_ready` (optional): the event after
-// which d_extra is complete (its kernels run on a side stream next to the ones below); the fold waits for it.
-int launch_msm_batched_ex(snarkv_ctx* ctx, const void* d_scalars, const void* d_points, const void* d_offsets,
-                          size_t n_msm, size_t n_terms, void* d_out, const void* d_extra, hipEvent_t extra_ready) {
   void* d_terms = nullptr;
   const uint32_t mont = ctx->mont ? 1u : 0u;  // SNARKV_FLAG_MONTGOMERY: terms in and points out in halo2curves' in-memory form
   SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_PARTIALS, 2 * n_terms * sizeof(G1Xyzz29), &d_terms));
   const uint32_t J = chunks_for(n_terms);
-  if (n_terms == 0) {
-    // nothing to multiply: the fold below adds the fixed parts alone
-  } else if (J == 1) {
+  if (J == 1) {
     // throughput-bound launches (tens of thousands of terms, or other launches in flight next to this context's: its
     // throughput hint) take the grouped form: a third of the issued work on a chain K times as long
     const char* ej = getenv("SNARKV_NAIVE_JOINT");  // 0 two lanes per term / 1 groups (K chosen on the device) / 2, 3, 4: groups of that K (test / A-B knob)
@@ -832,16 +821,15 @@ int launch_msm_batched_ex(snarkv_ctx* ctx, const void* d_scalars, const void* d_
                        (const G1Xyzz29*)d_chain, (const uint4*)d_mags, (G1Xyzz29*)d_terms, n_lanes, J, bits);
   }
   const uint32_t nm = (uint32_t)n_msm;
-  if (extra_ready) SNARKV_HIP(hipStreamWaitEvent(ctx->stream, extra_ready, 0));
   if (n_terms >= 128 * n_msm)
     hipLaunchKernelGGL((k_segment_fold<256, 256>), dim3(nm), dim3(256), 0, ctx->stream, (const G1Xyzz29*)d_terms,
-                       (const uint32_t*)d_offsets, (uint32_t*)d_out, nm, mont, (const G1Xyzz29*)d_extra);
+                       (const uint32_t*)d_offsets, (uint32_t*)d_out, nm, mont);
   else if (n_terms > 32 * n_msm)
     hipLaunchKernelGGL((k_segment_fold<64, 64>), dim3(nm), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_terms,
-                       (const uint32_t*)d_offsets, (uint32_t*)d_out, nm, mont, (const G1Xyzz29*)d_extra);
+                       (const uint32_t*)d_offsets, (uint32_t*)d_out, nm, mont);
   else  // <= 64 partials per MSM on average: four MSMs per wavefront
     hipLaunchKernelGGL((k_segment_fold<64, 16>), dim3((nm + 3) / 4), dim3(64), 0, ctx->stream, (const G1Xyzz29*)d_terms,
-                       (const uint32_t*)d_offsets, (uint32_t*)d_out, nm, mont, (const G1Xyzz29*)d_extra);
+                       (const uint32_t*)d_offsets, (uint32_t*)d_out, nm, mont);
   SNARKV_HIP(hipGetLastError());
   return SNARKV_OK;
 }
