@@ -371,7 +371,8 @@ E2E_CALLS = 25  # individually timed calls behind every end_to_end_* key
 def _e2e_entry(run, calls, nproofs, extra):
     """`run()` -> (ok, accumulator(s), timings dict): `calls` calls, each timed by the library's own wall clock around the whole
     job; the headline `ms` is the MEDIAN call, with its phase split; min / p95 / max beside it"""
-    run()  # warm (pools, scratch, pinned buffers)
+    for _ in range(3):  # warm: pools, scratch, pinned buffers, the first touch of this fixture's buffers (profiles/r05_host_outliers.txt)
+        run()
     recs = []
     for _ in range(calls):
         r = run()
