@@ -1,0 +1,303 @@
+// The Poseidon permutation on AVX-512 IFMA (vpmadd52luq / vpmadd52huq): the HOST side of the transcripts.
+//
+// A transcript is a sponge -- a chain of dependent permutations on one thread -- and the accumulation transcript of an
+// aggregation (`As::create_proof` over m accumulators, examples/evm-verifier-with-accumulator.rs:375) is ONE sponge over
+// 4 m field elements: m + 1 permutations back to back, 1 025 of them at m = 1 024.  Neither more host threads nor the GPU
+// shorten that chain (one permutation is ~270 DEPENDENT field products: a lone GPU lane needs ~150 us for it); what does
+// is the width of one core.  The state (t <= 8 words) lives across the 8 lanes of zmm registers, one 260-bit value per
+// lane in five 52-bit limbs, Montgomery with R = 2^260:
+//   S-box          three lane-wise products (all words at once in a full round)
+//   dense matrix   sum_j column_j * broadcast(state_j): t lane-wise products summed as 64-bit column accumulators, ONE
+//                  Montgomery reduction for the t x t products of a round
+//   sparse matrix  (partial rounds) row * state summed across the lanes + column * broadcast(s0) + state 2^260: two
+//                  lane-wise products, one reduction
+//   constants      ride along as value * 2^260 in the accumulators of the product that precedes them
+// Operands of vpmadd52 must be below 2^52 per limb: every reduction ends in a carry pass; values stay below 4 r < 2^256
+// (r < 2^254, R = 2^260: a product of two such values reduces to below 1.3 r without a conditional subtraction), and the
+// canonical residue is taken once, when a challenge leaves the sponge.  Same values as `poseidon_permute` (the scalar
+// schedule it mirrors), word for word: tests/hosttest + tests/test_transcript.py pin one against the other.
+// Selected at run time (`available()`): the library is built without -mavx512*, these functions carry their own target.
+#pragma once
+#if defined(__x86_64__) && defined(__GNUC__)
+#include <immintrin.h>
+
+#include "fr.hpp"
+
+#define SNARKV_IFMA __attribute__((target("avx512f,avx512ifma,avx512dq,avx512bw,avx512vl"), always_inline)) inline
+#define SNARKV_IFMA_FN __attribute__((target("avx512f,avx512ifma,avx512dq,avx512bw,avx512vl")))
+
+namespace snarkv_host {
+namespace poseidon_ifma {
+
+inline bool available() {
+  static const bool ok = [] {
+    if (getenv("SNARKV_HOST_NO_IFMA")) return false;  // A/B and test knob: the scalar schedule
+    __builtin_cpu_init();
+    return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512ifma") && __builtin_cpu_supports("avx512dq") &&
+           __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl");
+  }();
+  return ok;
+}
+
+constexpr uint64_t kMask52 = (1ull << 52) - 1;
+
+// 8 values, limb k of all of them in l[k]
+struct alignas(64) V {
+  uint64_t l[5][8];
+};
+
+inline void split52(const uint64_t v[4], uint64_t out[5]) {
+  out[0] = v[0] & kMask52;
+  out[1] = ((v[0] >> 52) | (v[1] << 12)) & kMask52;
+  out[2] = ((v[1] >> 40) | (v[2] << 24)) & kMask52;
+  out[3] = ((v[2] >> 28) | (v[3] << 36)) & kMask52;
+  out[4] = v[3] >> 16;
+}
+inline void join52(const uint64_t in[5], uint64_t v[4]) {  // limbs below 2^52, value below 2^256
+  v[0] = in[0] | (in[1] << 52);
+  v[1] = (in[1] >> 12) | (in[2] << 40);
+  v[2] = (in[2] >> 24) | (in[3] << 28);
+  v[3] = (in[3] >> 36) | (in[4] << 16);
+}
+
+// Fr (a 2^256 mod r) -> the limbs of a 2^260 mod r: four modular doublings
+inline void fr_to_limbs(const Fr& x, uint64_t out[5]) {
+  Fr y = x + x;
+  y = y + y;
+  y = y + y;
+  y = y + y;
+  split52(y.v, out);
+}
+// limbs of (a 2^260 mod r) + multiples of r, value below 2^256 -> Fr
+inline Fr fr_from_limbs(const uint64_t in[5]) {
+  static const Fr inv16 = [] {
+    Fr s = Fr::from_u64(16), i;
+    s.invert(&i);
+    return i;
+  }();
+  Fr t;
+  join52(in, t.v);
+  // below 4 r: the canonical residue by at most three subtractions
+  for (int k = 0; k < 3; ++k) {
+    bool lt = false;
+    for (int i = 3; i >= 0; --i)
+      if (t.v[i] != Fr::MOD[i]) {
+        lt = t.v[i] < Fr::MOD[i];
+        break;
+      }
+    if (lt) break;
+    unsigned __int128 br = 0;
+    for (int i = 0; i < 4; ++i) {
+      unsigned __int128 d = (unsigned __int128)t.v[i] - Fr::MOD[i] - (uint64_t)br;
+      t.v[i] = (uint64_t)d;
+      br = (d >> 64) & 1;
+    }
+  }
+  return t * inv16;  // t reads as the Montgomery form of 16 a
+}
+
+inline void set_lane(V& v, int lane, const Fr& x) {
+  uint64_t l[5];
+  fr_to_limbs(x, l);
+  for (int k = 0; k < 5; ++k) v.l[k][lane] = l[k];
+}
+inline V zero() {
+  V v;
+  memset(&v, 0, sizeof v);
+  return v;
+}
+
+// The tables of one parameter set in the lane layout (built once from the scalar schedule's tables).
+struct Tables {
+  int t = 0, r_f = 0, r_p = 0;
+  V p;                      // the modulus in every lane
+  V one;                    // 2^260 mod r in every lane (the Montgomery form of 1)
+  uint64_t np = 0;          // -r^-1 mod 2^52
+  V pre;                    // constants added with the input
+  std::vector<V> full_k;    // post-S-box constants of the full rounds
+  std::vector<V> mds_col, pre_sparse_col;  // column j of the matrix: lane i = M[i][j]
+  std::vector<V> partial_k;  // lane 0 only
+  std::vector<V> row;        // lane j = row[j]
+  std::vector<V> col;        // lane 0 = 0, lane i >= 1 = col_hat[i - 1]
+};
+
+struct Acc {  // ten 64-bit column accumulators per lane
+  __m512i t[10];
+};
+
+SNARKV_IFMA void acc_zero(Acc& a) {
+  for (int i = 0; i < 10; ++i) a.t[i] = _mm512_setzero_si512();
+}
+SNARKV_IFMA void load(const V& v, __m512i x[5]) {
+  for (int k = 0; k < 5; ++k) x[k] = _mm512_load_si512((const void*)v.l[k]);
+}
+SNARKV_IFMA void store(V& v, const __m512i x[5]) {
+  for (int k = 0; k < 5; ++k) _mm512_store_si512((void*)v.l[k], x[k]);
+}
+// a.t += x * y (lane-wise 260 x 260 -> 520 bits as column sums)
+SNARKV_IFMA void acc_mul(Acc& a, const __m512i x[5], const __m512i y[5]) {
+#pragma GCC unroll 5
+  for (int i = 0; i < 5; ++i) {
+#pragma GCC unroll 5
+    for (int j = 0; j < 5; ++j) {
+      a.t[i + j] = _mm512_madd52lo_epu64(a.t[i + j], x[i], y[j]);
+      a.t[i + j + 1] = _mm512_madd52hi_epu64(a.t[i + j + 1], x[i], y[j]);
+    }
+  }
+}
+// a.t += x 2^260 (x rides through the reduction unchanged)
+SNARKV_IFMA void acc_shifted(Acc& a, const __m512i x[5]) {
+  for (int k = 0; k < 5; ++k) a.t[5 + k] = _mm512_add_epi64(a.t[5 + k], x[k]);
+}
+// Montgomery reduction of the column sums: out = a / 2^260 mod r (+ r at most), limbs carried below 2^52
+SNARKV_IFMA void reduce(Acc& a, const __m512i p[5], __m512i np, __m512i out[5]) {
+  const __m512i zero = _mm512_setzero_si512(), mask = _mm512_set1_epi64((long long)kMask52);
+#pragma GCC unroll 5
+  for (int i = 0; i < 5; ++i) {
+    const __m512i m = _mm512_madd52lo_epu64(zero, a.t[i], np);  // (low 52 bits of t_i) * np mod 2^52
+#pragma GCC unroll 5
+    for (int j = 0; j < 5; ++j) {
+      a.t[i + j] = _mm512_madd52lo_epu64(a.t[i + j], m, p[j]);
+      a.t[i + j + 1] = _mm512_madd52hi_epu64(a.t[i + j + 1], m, p[j]);
+    }
+    a.t[i + 1] = _mm512_add_epi64(a.t[i + 1], _mm512_srli_epi64(a.t[i], 52));  // t_i is now 0 mod 2^52: its carry moves up
+  }
+  __m512i c = zero;
+#pragma GCC unroll 5
+  for (int k = 0; k < 5; ++k) {
+    const __m512i s = _mm512_add_epi64(a.t[5 + k], c);
+    out[k] = k < 4 ? _mm512_and_si512(s, mask) : s;
+    c = _mm512_srli_epi64(s, 52);
+  }
+}
+SNARKV_IFMA void mul(const __m512i x[5], const __m512i y[5], const __m512i p[5], __m512i np, __m512i out[5]) {
+  Acc a;
+  acc_zero(a);
+  acc_mul(a, x, y);
+  reduce(a, p, np, out);
+}
+// x^5 + k (k may be null): the constant rides in the last product's accumulators
+SNARKV_IFMA void sbox(const __m512i x[5], const __m512i* k, const __m512i p[5], __m512i np, __m512i out[5]) {
+  __m512i x2[5], x4[5];
+  mul(x, x, p, np, x2);
+  mul(x2, x2, p, np, x4);
+  Acc a;
+  acc_zero(a);
+  acc_mul(a, x4, x);
+  if (k) acc_shifted(a, k);
+  reduce(a, p, np, out);
+}
+SNARKV_IFMA void bcast(const __m512i x[5], int lane, __m512i out[5]) {
+  const __m512i idx = _mm512_set1_epi64(lane);
+  for (int k = 0; k < 5; ++k) out[k] = _mm512_permutexvar_epi64(idx, x[k]);
+}
+// lane 0 <- the sum of lanes 0 .. t-1 (the other lanes are zero by construction of the operands), lanes >= 1 <- 0
+SNARKV_IFMA __m512i hsum_to_lane0(__m512i x) {
+  const __m512i s = _mm512_set1_epi64((long long)_mm512_reduce_add_epi64(x));
+  return _mm512_maskz_mov_epi64(0x01, s);
+}
+
+// s <- M s for the matrix given by its columns: t lane-wise products, one reduction
+SNARKV_IFMA void dense(__m512i s[5], const V* cols, int t, const __m512i p[5], __m512i np) {
+  Acc a;
+  acc_zero(a);
+  for (int j = 0; j < t; ++j) {
+    __m512i c[5], b[5];
+    load(cols[j], c);
+    bcast(s, j, b);
+    acc_mul(a, c, b);
+  }
+  reduce(a, p, np, s);
+}
+
+// state <- permutation(state); `state` holds the t words in lanes 0 .. t-1, limbs carried, values below 4 r
+inline SNARKV_IFMA_FN void permute(V& state_v, const Tables& T) {
+  const int t = T.t, h = T.r_f / 2;
+  __m512i p[5], s[5];
+  load(T.p, p);
+  load(state_v, s);
+  const __m512i np = _mm512_set1_epi64((long long)T.np);
+  const __mmask8 live = (__mmask8)((1u << t) - 1);
+  {  // s += pre, carried (the sum of two carried values: one carry pass)
+    __m512i k[5];
+    load(T.pre, k);
+    const __m512i mask = _mm512_set1_epi64((long long)kMask52);
+    __m512i c = _mm512_setzero_si512();
+    for (int i = 0; i < 5; ++i) {
+      const __m512i v = _mm512_add_epi64(_mm512_add_epi64(s[i], k[i]), c);
+      s[i] = i < 4 ? _mm512_and_si512(v, mask) : v;
+      c = _mm512_srli_epi64(v, 52);
+    }
+  }
+  size_t fk = 0;
+  for (int r = 0; r < h; ++r) {
+    __m512i k[5];
+    load(T.full_k[fk++], k);
+    sbox(s, k, p, np, s);
+    dense(s, (r + 1 < h ? T.mds_col : T.pre_sparse_col).data(), t, p, np);
+  }
+  for (int r = 0; r < T.r_p; ++r) {
+    __m512i k[5], sb[5], row[5], col[5], b0[5];
+    load(T.partial_k[(size_t)r], k);
+    sbox(s, k, p, np, sb);  // (every lane computes; only lane 0 is kept)
+    for (int i = 0; i < 5; ++i) s[i] = _mm512_mask_mov_epi64(s[i], 0x01, sb[i]);
+    load(T.row[(size_t)r], row);
+    load(T.col[(size_t)r], col);
+    Acc d;  // the dot product row . state, lane by lane, then across the lanes into lane 0
+    acc_zero(d);
+    acc_mul(d, row, s);
+    bcast(s, 0, b0);
+    Acc a;  // lanes i >= 1: col_hat[i - 1] s0 + state_i 2^260; lane 0: the dot product
+    acc_zero(a);
+    acc_mul(a, col, b0);
+    for (int i = 0; i < 5; ++i) a.t[5 + i] = _mm512_add_epi64(a.t[5 + i], _mm512_maskz_mov_epi64((__mmask8)(live & ~1u), s[i]));
+    for (int i = 0; i < 10; ++i) a.t[i] = _mm512_add_epi64(a.t[i], hsum_to_lane0(d.t[i]));
+    reduce(a, p, np, s);
+    // words 1 .. t-1 pass through the reduction as value 2^260 and pick up to + r per round (nothing subtracts here):
+    // every eighth round a product with 1 (= 2^260 mod r) brings every word back below 1.3 r
+    if ((r & 7) == 7) {
+      __m512i one[5];
+      load(T.one, one);
+      mul(s, one, p, np, s);
+    }
+  }
+  for (int r = 0; r < h; ++r) {
+    const bool last = r + 1 == h;
+    if (last) {
+      sbox(s, nullptr, p, np, s);
+    } else {
+      __m512i k[5];
+      load(T.full_k[fk++], k);
+      sbox(s, k, p, np, s);
+    }
+    dense(s, T.mds_col.data(), t, p, np);
+  }
+  for (int i = 0; i < 5; ++i) s[i] = _mm512_maskz_mov_epi64(live, s[i]);
+  store(state_v, s);
+}
+
+// state lanes 1 .. n += inputs, lane n + 1 += 1 (the sponge's padding word, if it fits), carried
+inline SNARKV_IFMA_FN void absorb(V& state_v, const V& addend) {
+  __m512i s[5], k[5];
+  load(state_v, s);
+  load(addend, k);
+  const __m512i mask = _mm512_set1_epi64((long long)kMask52);
+  __m512i c = _mm512_setzero_si512();
+  for (int i = 0; i < 5; ++i) {
+    const __m512i v = _mm512_add_epi64(_mm512_add_epi64(s[i], k[i]), c);
+    s[i] = i < 4 ? _mm512_and_si512(v, mask) : v;
+    c = _mm512_srli_epi64(v, 52);
+  }
+  store(state_v, s);
+}
+
+}  // namespace poseidon_ifma
+}  // namespace snarkv_host
+#else
+namespace snarkv_host {
+namespace poseidon_ifma {
+struct Tables {};
+inline bool available() { return false; }
+}  // namespace poseidon_ifma
+}  // namespace snarkv_host
+#endif

@@ -556,6 +556,17 @@ int hd_poseidon_permute2(int t, int r_f, int r_p, int plain, uint8_t* state) {
     return 0;
   });
 }
+// the same permutation on the AVX-512 IFMA path (host/poseidon_ifma.hpp): 0 ok, 1 = this CPU has no IFMA (state untouched)
+int hd_poseidon_permute_ifma(int t, int r_f, int r_p, uint8_t* state) {
+  return guarded([&] {
+    std::vector<Fr> st((size_t)t);
+    for (int i = 0; i < t; ++i)
+      if (!Fr::from_bytes(state + 32 * i, &st[i])) return -3;
+    if (!poseidon_permute_ifma(st, r_f, r_p)) return 1;
+    for (int i = 0; i < t; ++i) st[i].to_bytes(state + 32 * i);
+    return 0;
+  });
+}
 int hd_poseidon_permute(int t, int r_f, int r_p, uint8_t* state) {
   return guarded([&] {
     std::vector<Fr> st((size_t)t);

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "pcs.hpp"
+#include "poseidon_ifma.hpp"
 
 namespace snarkv_host {
 
@@ -656,14 +657,100 @@ inline void poseidon_permute(std::vector<Fr>& state_v, const PoseidonSpec& sp) {
   for (int i = 0; i < t; ++i) state_v[(size_t)i] = state[i];
 }
 
-// poseidon.rs:115-202: sponge framing over the plain permutation
+// the lane-layout tables of poseidon_ifma.hpp, from the optimised schedule's
+inline const poseidon_ifma::Tables* poseidon_ifma_tables(int t, int r_f, int r_p) {
+#if defined(__x86_64__) && defined(__GNUC__)
+  namespace pi = poseidon_ifma;
+  if (!pi::available() || t > 8) return nullptr;
+  static std::map<std::tuple<int, int, int>, pi::Tables> cache;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_tuple(t, r_f, r_p);
+  auto it = cache.find(key);
+  if (it != cache.end()) return &it->second;
+  const PoseidonOpt& o = poseidon_opt(t, r_f, r_p);
+  pi::Tables T;
+  T.t = t, T.r_f = r_f, T.r_p = r_p;
+  T.np = Fr::INV & pi::kMask52;  // -r^-1 mod 2^64, cut to 2^52
+  uint64_t pl[5];
+  pi::split52(Fr::MOD, pl);
+  T.p = pi::zero(), T.one = pi::zero(), T.pre = pi::zero();
+  for (int lane = 0; lane < 8; ++lane) {
+    for (int k = 0; k < 5; ++k) T.p.l[k][lane] = pl[k];
+    pi::set_lane(T.one, lane, Fr::one());
+  }
+  auto vec = [&](const std::vector<Fr>& src) {  // lane i = src[i]
+    pi::V v = pi::zero();
+    for (size_t i = 0; i < src.size() && i < 8; ++i) pi::set_lane(v, (int)i, src[i]);
+    return v;
+  };
+  T.pre = vec(o.pre);
+  for (auto& k : o.full_k) T.full_k.push_back(vec(k));
+  auto cols = [&](const std::vector<Fr>& m) {
+    std::vector<pi::V> out;
+    for (int j = 0; j < t; ++j) {
+      pi::V v = pi::zero();
+      for (int i = 0; i < t; ++i) pi::set_lane(v, i, m[(size_t)i * t + j]);
+      out.push_back(v);
+    }
+    return out;
+  };
+  T.mds_col = cols(o.mds);
+  T.pre_sparse_col = cols(o.pre_sparse);
+  for (int r = 0; r < r_p; ++r) {
+    pi::V k = pi::zero();
+    pi::set_lane(k, 0, o.partial_k[(size_t)r]);
+    T.partial_k.push_back(k);
+    T.row.push_back(vec(o.sparse_row[(size_t)r]));
+    pi::V c = pi::zero();
+    for (int i = 1; i < t; ++i) pi::set_lane(c, i, o.sparse_col[(size_t)r][(size_t)i - 1]);
+    T.col.push_back(c);
+  }
+  return &cache.emplace(key, std::move(T)).first->second;
+#else
+  (void)t, (void)r_f, (void)r_p;
+  return nullptr;
+#endif
+}
+
+// state <- permutation(state) on the IFMA path (test hook and the sponge below); false if the CPU has no AVX-512 IFMA
+inline bool poseidon_permute_ifma(std::vector<Fr>& state, int r_f, int r_p) {
+#if defined(__x86_64__) && defined(__GNUC__)
+  const poseidon_ifma::Tables* T = poseidon_ifma_tables((int)state.size(), r_f, r_p);
+  if (!T) return false;
+  poseidon_ifma::V v = poseidon_ifma::zero();
+  for (size_t i = 0; i < state.size(); ++i) poseidon_ifma::set_lane(v, (int)i, state[i]);
+  poseidon_ifma::permute(v, *T);
+  for (size_t i = 0; i < state.size(); ++i) {
+    uint64_t l[5];
+    for (int k = 0; k < 5; ++k) l[k] = v.l[k][i];
+    state[i] = poseidon_ifma::fr_from_limbs(l);
+  }
+  return true;
+#else
+  (void)state, (void)r_f, (void)r_p;
+  return false;
+#endif
+}
+
+// poseidon.rs:115-202: sponge framing over the permutation.  On a CPU with AVX-512 IFMA the state lives in the lane layout
+// of poseidon_ifma.hpp for the life of the sponge (inputs converted on the way in, a challenge on the way out).
 class Poseidon {
  public:
-  Poseidon(int t, int rate, int r_f, int r_p) : t_(t), rate_(rate), spec_(&poseidon_spec(t, r_f, r_p)) {
-    state_.assign((size_t)t, Fr::zero());
+  Poseidon(int t, int rate, int r_f, int r_p)
+      : t_(t), rate_(rate), spec_(&poseidon_spec(t, r_f, r_p)), ifma_(poseidon_ifma_tables(t, r_f, r_p)) {
     // poseidon::State::default(): first word 2^64
     Fr two32 = Fr::from_u64(1ull << 32);
-    state_[0] = two32 * two32;
+    const Fr w0 = two32 * two32;
+#if defined(__x86_64__) && defined(__GNUC__)
+    if (ifma_) {
+      vstate_ = poseidon_ifma::zero();
+      poseidon_ifma::set_lane(vstate_, 0, w0);
+      return;
+    }
+#endif
+    state_.assign((size_t)t, Fr::zero());
+    state_[0] = w0;
   }
   void update(const std::vector<Fr>& elements) { buf_.insert(buf_.end(), elements.begin(), elements.end()); }  // :145-147
   Fr squeeze() {                                                                                               // :151-164
@@ -675,17 +762,38 @@ class Poseidon {
       permutation(buf.data() + i, n);
     }
     if (exact) permutation(nullptr, 0);
+#if defined(__x86_64__) && defined(__GNUC__)
+    if (ifma_) {
+      uint64_t l[5];
+      for (int k = 0; k < 5; ++k) l[k] = vstate_.l[k][1];
+      return poseidon_ifma::fr_from_limbs(l);
+    }
+#endif
     return state_[1];
   }
 
  private:
   void permutation(const Fr* inputs, size_t n) {  // :44-75 (absorb + the 1 after the last input), :166-201
+#if defined(__x86_64__) && defined(__GNUC__)
+    if (ifma_) {
+      poseidon_ifma::V add = poseidon_ifma::zero();
+      for (size_t i = 0; i < n; ++i) poseidon_ifma::set_lane(add, 1 + (int)i, inputs[i]);
+      if (1 + n < (size_t)t_) poseidon_ifma::set_lane(add, 1 + (int)n, Fr::one());
+      poseidon_ifma::absorb(vstate_, add);
+      poseidon_ifma::permute(vstate_, *ifma_);
+      return;
+    }
+#endif
     for (size_t i = 0; i < n; ++i) state_[1 + i] = state_[1 + i] + inputs[i];
     if (1 + n < (size_t)t_) state_[1 + n] = state_[1 + n] + Fr::one();  // nothing after a full-rate chunk (:61-74)
     poseidon_permute(state_, *spec_);
   }
   int t_, rate_;
   const PoseidonSpec* spec_;
+  const poseidon_ifma::Tables* ifma_;
+#if defined(__x86_64__) && defined(__GNUC__)
+  poseidon_ifma::V vstate_;
+#endif
   std::vector<Fr> state_;
   std::vector<Fr> buf_;
 };

@@ -313,3 +313,41 @@ def test_poseidon_transcript_layout_record_rebuilds_every_absorbed_element(H):
     out = ctypes.create_string_buffer(64)
     n = ctypes.c_size_t(0)
     assert H.hd_poseidon_layout_script(bad, len(bad), (O.R + 1).to_bytes(32, "little"), 32, out, len(out), ctypes.byref(n)) == 1000
+
+
+def test_ifma_permutation_equals_the_scalar_schedule_and_the_oracle(H):
+    """host/poseidon_ifma.hpp (the state across AVX-512 lanes, 52-bit limbs, R = 2^260, no conditional subtraction on the
+    way) against the scalar schedule and the Python oracle: random and extreme states, both parameter sets.  Skips where
+    the CPU has no AVX-512 IFMA (the sponge then runs the scalar schedule, which the tests above pin)."""
+    _setup_poseidon(H)
+    H.hd_poseidon_permute_ifma.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    probe = ctypes.create_string_buffer(bytes(96), 96)
+    if H.hd_poseidon_permute_ifma(3, 8, 57, probe) == 1:
+        pytest.skip("no AVX-512 IFMA on this CPU")
+    rng = random.Random(52)
+    for (t, rf, rp) in ((3, 8, 57), (5, 8, 60)):
+        states = [[0] * t, [O.R - 1] * t, [1] + [0] * (t - 1), [O.R - 1 - i for i in range(t)]]
+        states += [[rng.randrange(O.R) for _ in range(t)] for _ in range(200)]
+        for k, st in enumerate(states):
+            a = ctypes.create_string_buffer(b"".join(O.fe_to_bytes(x) for x in st), 32 * t)
+            b = ctypes.create_string_buffer(a.raw, 32 * t)
+            assert H.hd_poseidon_permute(t, rf, rp, a) == 0 and H.hd_poseidon_permute_ifma(t, rf, rp, b) == 0
+            assert a.raw == b.raw, (t, k)
+            if k < 8:
+                got = [int.from_bytes(b.raw[32 * i:32 * i + 32], "little") for i in range(t)]
+                assert got == T.poseidon_permute(st, rf, rp)
+
+
+def test_poseidon_transcripts_on_the_scalar_schedule_too():
+    """the sponge picks the IFMA path at run time; the same transcript tests with SNARKV_HOST_NO_IFMA=1 keep the scalar
+    schedule covered on a CPU that has IFMA (a child interpreter: the choice is made once per process)"""
+    import subprocess
+    import sys
+
+    if os.environ.get("SNARKV_HOST_NO_IFMA"):
+        pytest.skip("already the scalar run")
+    env = dict(os.environ, SNARKV_HOST_NO_IFMA="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-k", "poseidon and not scalar_schedule", "-p",
+                        "no:cacheprovider"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
