@@ -23,7 +23,11 @@ def test_two_processes_one_device():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
-    lines = [json.loads(ln.split("RANKLINE ", 1)[1]) for ln in r.stdout.splitlines() if "RANKLINE " in ln]
+    # (the two ranks share one stdout pipe: decode at every marker, wherever the other rank's bytes landed around it)
+    dec, lines, pos = json.JSONDecoder(), [], 0
+    while (pos := r.stdout.find("RANKLINE ", pos)) >= 0:
+        pos += len("RANKLINE ")
+        lines.append(dec.raw_decode(r.stdout, pos)[0])
     assert sorted(d["rank"] for d in lines) == list(range(world)) and len({d["pid"] for d in lines}) == world
     totals = [200_000, 4097, 1]
     exp = b"".join(C.msm_pippenger(C.sample_scalars(0x7A00 + i, n), C.sample_points(0x7B00 + i, n), 8) for i, n in enumerate(totals))

@@ -25,8 +25,8 @@ stats() {  # name, bench args...
 stats batch --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-host-resident --no-strong --no-mgpu-leg
 stats sequential --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --inflight 1 --no-strong --no-mgpu-leg
 # the hash sidecar bench.py reads `kernel_us_profile` from (keyed to THESE sources), into profiles/ of this tree
-cp $O/${TAG}_rocprofv3_kernel_stats_sequential.csv profiles/ && python tools/stats_sidecar.py profiles/${TAG}_rocprofv3_kernel_stats_sequential.csv \
-  && cp profiles/${TAG}_kernel_stats_sequential.json $O/
+cp $O/${TAG}_rocprofv3_kernel_stats_sequential.csv $R/profiles/ && python $R/tools/stats_sidecar.py $R/profiles/${TAG}_rocprofv3_kernel_stats_sequential.csv \
+  && cp $R/profiles/${TAG}_kernel_stats_sequential.json $O/
 stats with_secondary --steps 4 --warmup 1 --no-cpu-baseline --no-host-resident --no-strong --no-mgpu-leg
 stats 2p24_single --log2n 24 --inflight 1 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --no-strong --no-mgpu-leg
 cd $R
