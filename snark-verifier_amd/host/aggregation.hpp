@@ -58,6 +58,44 @@ struct Aggregator {
   using SV = PlonkSuccinctVerifier<MOS>;
   using AsTR = typename std::conditional<std::is_same<TR, EvmTranscript>::value, EvmTranscript, PoseidonTranscript>::type;
 
+  // Every compressed point of a batch decompressed in ONE device launch (a square root each: ~13 per proof, 0.13 ms of host
+  // time per proof otherwise).  Where the points sit in a proof is fixed by the protocol: proof 0 is parsed once on the
+  // host for the layout; proofs of another length get no hints and keep the host path.  The transcripts take a hint only
+  // if it IS the decoding of the proof's bytes (`hint_matches`), so verdicts and error texts stay the host path's.
+  struct PointHints {
+    std::vector<uint8_t> pts, ok;  // the device's decodings, 64 bytes + a flag per point, proof-major
+    std::vector<size_t> row;       // proof i's row in them, or -1
+    size_t P = 0;                  // points per proof
+    bool any() const { return P != 0 && !ok.empty(); }
+  };
+  static void decompress_hints(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
+                               const std::vector<std::vector<std::vector<Fr>>>& instances,
+                               const std::vector<std::vector<uint8_t>>& proofs, unsigned threads, PointHints& h) {
+    const size_t n = proofs.size();
+    const int T = 5, RATE = 4, R_F = 8, R_P = 60;
+    h.row.assign(n, (size_t)-1);
+    h.P = 0;
+    PoseidonTranscriptT<RecordingSponge> t0(proofs[0], T, RATE, R_F, R_P);
+    if (!SV::read_proof(svk, pr, instances[0], t0).ok()) return;
+    const std::vector<size_t> offs = t0.point_offsets();
+    const size_t len0 = proofs[0].size();
+    h.P = offs.size();
+    const size_t P = h.P;
+    std::vector<size_t> who;
+    for (size_t i = 0; i < n; ++i)
+      if (proofs[i].size() == len0) h.row[i] = who.size(), who.push_back(i);
+    if (!P || who.empty()) return;
+    std::vector<uint8_t> in(32 * P * who.size());
+    h.pts.resize(64 * P * who.size());
+    h.ok.resize(P * who.size());
+    parallel_for(who.size(), threads, [&](size_t k) {
+      for (size_t q = 0; q < P; ++q) memcpy(&in[32 * (k * P + q)], proofs[who[k]].data() + offs[q], 32);
+    }, 64);
+    DeviceScope dev;
+    if (bn254_g1_decompress(in.data(), P * who.size(), h.pts.data(), h.ok.data()) != SNARKV_OK)
+      throw std::runtime_error(std::string("bn254_g1_decompress: ") + snarkv_last_error());
+  }
+
   // `read_proof` of every proof with the hashing on the device.  Fills pfs; returns the first error.
   static Error read_proofs_device_hashed(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
                                          const std::vector<std::vector<std::vector<Fr>>>& instances,
@@ -173,33 +211,15 @@ struct Aggregator {
     // pass 0: every compressed point of the batch decompressed in ONE device launch (a square root each: ~13 per
     // proof, 0.15 ms of host time per proof otherwise).  Where the points sit in a proof is fixed by the protocol:
     // proof 0 is parsed once on the host for the layout, proofs of another length keep the host path.
-    std::vector<uint8_t> hint_pts, hint_ok;  // the device's decodings, 64 bytes + a flag per point, proof-major
-    std::vector<size_t> hint_row(n, (size_t)-1);
-    size_t P = 0;
+    PointHints hints;
     double t_pass0 = 0;
     if (n >= 2) {
-      PoseidonTranscriptT<RecordingSponge> t0(proofs[0], T, RATE, R_F, R_P);
-      if (SV::read_proof(svk, pr, instances[0], t0).ok()) {
-        const std::vector<size_t> offs = t0.point_offsets();
-        const size_t len0 = proofs[0].size();
-        P = offs.size();
-        std::vector<size_t> who;
-        for (size_t i = 0; i < n; ++i)
-          if (proofs[i].size() == len0) hint_row[i] = who.size(), who.push_back(i);
-        if (P && !who.empty()) {
-          std::vector<uint8_t> in(32 * P * who.size());
-          hint_pts.resize(64 * P * who.size());
-          hint_ok.resize(P * who.size());
-          parallel_for(who.size(), threads, [&](size_t k) {
-            for (size_t q = 0; q < P; ++q) memcpy(&in[32 * (k * P + q)], proofs[who[k]].data() + offs[q], 32);
-          }, 64);
-          DeviceScope dev;
-          if (bn254_g1_decompress(in.data(), P * who.size(), hint_pts.data(), hint_ok.data()) != SNARKV_OK)
-            throw std::runtime_error(std::string("bn254_g1_decompress: ") + snarkv_last_error());
-        }
-      }
+      decompress_hints(svk, pr, instances, proofs, threads, hints);
       t_pass0 = lap();
     }
+    const std::vector<uint8_t>&hint_pts = hints.pts, &hint_ok = hints.ok;
+    const std::vector<size_t>& hint_row = hints.row;
+    const size_t P = hints.P;
     // pass 1: parse (points not covered by pass 0 are decompressed here) and record what the sponge would see
     parallel_for(n, threads, [&](size_t i) {
       PoseidonTranscriptT<RecordingSponge> t(proofs[i], T, RATE, R_F, R_P);
@@ -283,11 +303,25 @@ struct Aggregator {
       if (!e.ok()) return R::Err(e);
       device_hash_ms = ms(t0, clk::now());
     }
+    // Poseidon proofs hashed on the HOST (round 5: the sponge on AVX-512 IFMA makes 64 threads faster at it than the
+    // device's one-lane-per-transcript kernel): the batch's compressed points are still decompressed by ONE device launch
+    // and offered to the transcripts as hints -- the square roots were half of a host-read proof
+    PointHints hints;
+    constexpr bool kHostPoseidon = std::is_same<TR, PoseidonTranscript>::value;
+    if constexpr (kHostPoseidon) {
+      size_t min_batch = 32;
+      if (const char* e = getenv("SNARKV_HOST_HINT_MIN")) min_batch = (size_t)std::max(2, atoi(e));  // tuning / A-B knob
+      if (n >= min_batch) decompress_hints(svk, pr, instances, proofs, threads, hints);
+    }
     // one pass per proof: read_proof, then the host half of verify (the pair lists of its two MSMs)
     parallel_for(n, threads, [&](size_t i) {
       auto a = clk::now();
       if constexpr (!kDeviceHash) {
         TR t(proofs[i]);
+        if constexpr (kHostPoseidon) {
+          if (hints.any() && hints.row[i] != (size_t)-1)
+            t.set_point_hints(&hints.pts[64 * hints.P * hints.row[i]], &hints.ok[hints.P * hints.row[i]], hints.P);
+        }
         auto pf = SV::read_proof(svk, pr, instances[i], t);
         if (!pf.ok()) {
           errs[i] = pf.err;

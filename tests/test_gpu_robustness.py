@@ -12,6 +12,14 @@ import coracle as C
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def test_batched_random_segmentations(gpu_ctx):
     rng = random.Random(21)
     n = 700
@@ -139,7 +147,7 @@ def test_sharded_msm_over_rccl_world_of_one_is_ordered():
     from snark_verifier_amd import distributed as D
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = "29617"
+    os.environ["MASTER_PORT"] = str(_free_port())  # (a fixed port can still be in TIME_WAIT from an earlier run on the box)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         ctx = sv.Context(0)  # private stream
@@ -187,7 +195,7 @@ def test_sharded_msm_batch_wiring_on_a_one_rank_rccl_group():
     from snark_verifier_amd import distributed as D
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = "29619"
+    os.environ["MASTER_PORT"] = str(_free_port())
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         side = torch.cuda.Stream()
@@ -252,7 +260,7 @@ def test_bucket_sharded_msm_world1_rccl_wiring():
     created = False
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29655")
+        os.environ["MASTER_PORT"] = str(_free_port())
         dist.init_process_group("nccl", rank=0, world_size=1)
         created = True
     try:
