@@ -468,6 +468,22 @@ int hd_pool_selftest(int rounds) {
   });
 }
 
+// The hint policy of the Poseidon transcript's `read_ec_point`: one compressed point in `proof32`, a device
+// answer (`hint64`, `hint_ok`) beside it.  Returns 1 the point was read (from the hint or by the host's own decoding),
+// 0 Error::Transcript.  `strict` = the caller's challenges were hashed over the hint (the fused device route): a finite
+// point the host decodes where the hint was unusable must then be REFUSED, never silently accepted.
+int hd_poseidon_hint_policy(const uint8_t* proof32, const uint8_t* hint64, int hint_ok, int strict, uint8_t* out64) {
+  return guarded([&] {
+    PoseidonTranscriptT<ReplaySponge> t(std::vector<uint8_t>(proof32, proof32 + 32));
+    const uint8_t okb = (uint8_t)(hint_ok ? 1 : 0);
+    t.set_point_hints(hint64, &okb, 1, strict != 0);
+    auto p = t.read_ec_point();
+    if (!p.ok()) return 0;
+    memcpy(out64, p.value->b, 64);
+    return 1;
+  });
+}
+
 int hd_evm_transcript_script(const uint8_t* script, size_t script_len, const uint8_t* proof, size_t proof_len,
                              uint8_t* out, size_t out_cap, size_t* out_len) {
   return hd_transcript_script(0, script, script_len, proof, proof_len, out, out_cap, out_len);

@@ -204,4 +204,14 @@ def test_read_batch_assembles_decompresses_and_hashes_like_the_pieces(gpu_ctx):
             gpu_ctx.poseidon_read_batch(spec, b"".join(recs), n, stride, b"".join(leads), n_lead, bad, pts_off, seg)
     with pytest.raises(sv.SnarkvError):  # a point offset not a multiple of 16
         gpu_ctx.poseidon_read_batch(spec, b"".join(recs), n, stride, b"".join(leads), n_lead, layout, [pts_off[0] + 4] + pts_off[1:], seg)
+    # n * L beyond the kernels' 32-bit element index (n < 2^24 and L < 2^16 each pass): refused before anything is staged
+    import array
+    import ctypes
+
+    big_n, big_l = 70000, 65000  # 4.55e9 elements
+    lay, sg = array.array("I", [0] * big_l), array.array("I", [big_l])
+    rc = gpu_ctx._lib.snarkv_poseidon_read_batch(gpu_ctx._h, spec._h, b"\x00" * 64, big_n, 64, b"\x00" * 32, 1,
+                                                 ctypes.c_void_p(lay.buffer_info()[0]), big_l, None, 0,
+                                                 ctypes.c_void_p(sg.buffer_info()[0]), 1, ctypes.create_string_buffer(32), None, None)
+    assert rc == sv.SNARKV_ERR_LENGTH
     spec.close()

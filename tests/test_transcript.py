@@ -351,3 +351,27 @@ def test_poseidon_transcripts_on_the_scalar_schedule_too():
                         "no:cacheprovider"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_device_point_hints_are_checked_and_strict_mode_refuses_a_disagreement(H):
+    """`PoseidonTranscript::read_ec_point` with a device-decoded hint beside the bytes (host/transcript.hpp): a hint is used
+    only if it IS the decoding of the 32 bytes; an unusable hint falls back to the host's own decoding -- EXCEPT in strict
+    mode (the fused device route, whose challenges were hashed over the device's decodings): there a finite point the host
+    decodes although the device's answer was unusable is a disagreement and must be refused."""
+    H.hd_poseidon_hint_policy.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    rng = random.Random(91)
+    p = O.g1_mul(O.G1_GEN, rng.randrange(1, O.R))
+    q = O.g1_mul(O.G1_GEN, rng.randrange(1, O.R))
+    enc, pb, qb = T.g1_compress(p), O.g1_to_bytes(p), O.g1_to_bytes(q)
+    out = ctypes.create_string_buffer(64)
+    for strict in (0, 1):
+        assert H.hd_poseidon_hint_policy(enc, pb, 1, strict, out) == 1 and out.raw == pb  # the right hint: taken
+    # a wrong point with ok = 1, or the right point flagged unusable: the host decodes itself ... unless strict
+    for hint, ok in ((qb, 1), (pb, 0), (bytes(64), 1)):
+        assert H.hd_poseidon_hint_policy(enc, hint, ok, 0, out) == 1 and out.raw == pb
+        assert H.hd_poseidon_hint_policy(enc, hint, ok, 1, out) == 0
+    # an invalid encoding is Error::Transcript either way (x = 7 is not on the curve: 343 + 3 is a non-residue? found by search)
+    x = next(x for x in range(2, 50) if pow((x ** 3 + 3) % O.P, (O.P - 1) // 2, O.P) != 1)
+    bad = x.to_bytes(32, "little")
+    for strict in (0, 1):
+        assert H.hd_poseidon_hint_policy(bad, bytes(64), 0, strict, out) == 0
