@@ -212,6 +212,7 @@ struct Aggregator {
     // proof, 0.15 ms of host time per proof otherwise).  Where the points sit in a proof is fixed by the protocol:
     // proof 0 is parsed once on the host for the layout, proofs of another length keep the host path.
     PointHints hints;
+    hints.row.assign(n, (size_t)-1);  // (a batch of one proof asks for no hints: every row stays "none")
     double t_pass0 = 0;
     if (n >= 2) {
       decompress_hints(svk, pr, instances, proofs, threads, hints);
