@@ -797,10 +797,12 @@ def mgpu_leg(gpus, steps, log2n, window_bits):
     import snark_verifier_amd as sv
 
     n = 1 << log2n
-    out = {"ranks": gpus, "devices": list(range(gpus)), "jobs": steps, "points_per_gpu_per_job": n,
+    ndev = max(1, torch.cuda.device_count())
+    devices = [g % ndev for g in range(gpus)]  # (fewer GPUs than ranks: a test box; ranks then share devices and RCCL refuses)
+    out = {"ranks": gpus, "devices": devices, "jobs": steps, "points_per_gpu_per_job": n,
            "entry_point": "snarkv_g1_msm_pippenger_many_mgpu_dev", "estimator": "min", "calls": 3}
     try:
-        mg = sv.MultiGpu(list(range(gpus)))
+        mg = sv.MultiGpu(devices)
     except Exception as e:  # noqa: BLE001
         return dict(out, error="snarkv_mgpu_create: %s" % e)
     en, un, fl = mg.peer_access()
@@ -811,10 +813,10 @@ def mgpu_leg(gpus, steps, log2n, window_bits):
     for g in range(gpus):
         c = mg.rank_context(g)
         rs, rp = [], []
-        with torch.cuda.device(g):
+        with torch.cuda.device(devices[g]):
             for k in range(nsets):
-                s = torch.empty(32 * n, dtype=torch.uint8, device="cuda:%d" % g)
-                p = torch.empty(64 * n, dtype=torch.uint8, device="cuda:%d" % g)
+                s = torch.empty(32 * n, dtype=torch.uint8, device="cuda:%d" % devices[g])
+                p = torch.empty(64 * n, dtype=torch.uint8, device="cuda:%d" % devices[g])
                 torch.cuda.synchronize()
                 first = (k * gpus + g) * n  # job k over all ranks = points [k G n, (k + 1) G n) of the seeded streams
                 c.sample_scalars_dev(0x5EED0001, n, s.data_ptr(), first=first)
@@ -994,11 +996,18 @@ def main():
         dev_sync = lambda: None  # noqa: E731
         on_stream = lambda st: contextlib.nullcontext()  # noqa: E731
         launch_points = doubles.Context.launch_points
+        shared_devices = False
     else:
-        torch.cuda.set_device(local_rank)
+        # a box with fewer GPUs than ranks (the 1-GPU test box running the N-rank path: tests/test_gpu_bench_ranks.py): the
+        # ranks share devices round robin -- RCCL refuses that, so the probe fails on every rank and the run goes on
+        # host-staged; the line says `ranks_share_devices`
+        ndev = torch.cuda.device_count()
+        dev_index = local_rank % max(1, ndev)
+        shared_devices = world > ndev
+        torch.cuda.set_device(dev_index)
         dev = "cuda"
         make_stream = torch.cuda.Stream
-        make_ctx = lambda st: sv.Context(local_rank, stream=st.cuda_stream)  # noqa: E731
+        make_ctx = lambda st: sv.Context(dev_index, stream=st.cuda_stream)  # noqa: E731
         dev_sync = torch.cuda.synchronize
         on_stream = torch.cuda.stream
         launch_points = sv.Context.launch_points
@@ -1018,7 +1027,7 @@ def main():
         # a probe that hangs is abandoned by open_data_plane; RCCL's watchdog must not take the process down meanwhile
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
         dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=30))
-        transport = open_data_plane(torch, dist, args.transport or ("gloo" if dry else "auto"), local_rank, world)
+        transport = open_data_plane(torch, dist, args.transport or ("gloo" if dry else "auto"), local_rank if dry else dev_index, world)
 
     strong = args.total_log2n > 0
     if strong:
@@ -1271,6 +1280,7 @@ def main():
                                                            # the sequential stage times are taken without it
                 "single_msm_latency_ms": lat_ms,
                 "rccl_ranks_seen": rccl_ranks_seen if transport["kind"] == "rccl" else None,  # sum of ones over the RCCL group
+                "ranks_share_devices": (not dry) and shared_devices,  # true only on a test box with fewer GPUs than ranks
                 "data_plane_ranks_seen": rccl_ranks_seen,  # ... over whatever group the partials travelled on (null: one process)
                 "transport": None if not use_dist else {
                     "kind": "RCCL all-gather over xGMI (torch.distributed backend nccl)" if transport["kind"] == "rccl"

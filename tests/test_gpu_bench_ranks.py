@@ -1,0 +1,51 @@
+"""GPU: `bench.py --gpus 2` for real, before the driver finds a multi-GPU node: a PLAIN launch (no
+torchrun) on the box's one device.  bench.py starts the two ranks itself; both land on device 0 (`ranks_share_devices`), so
+every rank's RCCL probe fails -- two ranks of one communicator on one device is exactly what RCCL refuses -- the ranks agree
+over the gloo control plane, and the partials travel host-staged: the whole fallback path on hardware, with real kernels,
+checked against the C oracle.  In the same line: BASELINE config 4 in shape (2^k points IN TOTAL over the ranks), the
+one-GPU recompute of the sharded result, and the single-process `snarkv_mgpu_*` leg with two ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import coracle as C
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_plain_launch_two_ranks_one_device_measures_and_says_how():
+    log2n, steps = 14, 3
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SNARKV_BENCH_RCCL_PROBE_TIMEOUT"] = "120"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "1", "--log2n", str(log2n),
+           "--strong-total-log2n", "16", "--no-cpu-baseline", "--no-secondary"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    n = 1 << log2n
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["points_per_gpu"] == n
+    assert abs(d["value"] - 2 * n * steps / (d["ms_per_step"] * steps * 1e-3)) < 1e-6 * d["value"]
+    cfg = d["config"]
+    assert cfg["launch"]["self_launched"] is True and cfg["launch"]["attempts"][0]["rc"] == 0
+    assert cfg["ranks_share_devices"] is True
+    tr = cfg["transport"]
+    assert "HOST-STAGED" in tr["kind"] and tr["requested"] == "auto" and "RCCL unavailable on rank(s)" in tr["fallback_reason"]
+    assert cfg["rccl_ranks_seen"] is None and cfg["data_plane_ranks_seen"] == 2
+    # the sharded result: the MSM over BOTH ranks' points, by the C oracle and by rank 0's own one-GPU recompute
+    s, p = C.sample_scalars(0x5EED0001, 2 * n), C.sample_points(0x5EED0002, 2 * n)
+    assert cfg["result"] == C.msm_pippenger(s, p, 8).hex() and cfg["result_matches_one_gpu_recompute"] is True
+    c4 = d["config4_strong"]
+    assert c4["n_gpus"] == 2 and c4["points_per_gpu"] == 1 << 15 and c4["matches_one_gpu_single_call"] is True
+    s, p = C.sample_scalars(0x5EED0011, 1 << 16), C.sample_points(0x5EED0012, 1 << 16)
+    assert c4["result"] == C.msm_pippenger(s, p, 8).hex()
+    # the single-process leg: two ranks on device 0 -- RCCL refuses the duplicate LOUDLY, peer copies deliver
+    mg = d["single_process_mgpu"]
+    assert mg["ranks"] == 2 and mg["devices"] == [0, 0]
+    assert "distinct devices" in mg["rccl"]["error"] and mg["peer_copy"]["value"] > 0
+    assert mg["job0_matches_one_gpu_recompute"] is True and mg["result_job0"] == cfg["result"]
