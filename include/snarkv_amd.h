@@ -380,7 +380,8 @@ int snarkv_g1_msm_pippenger_mgpu_dev(snarkv_mgpu* mg, const void* const* d_scala
  * d_scalars32[g * jobs + j] / d_points64[g * jobs + j] on rank g's device, counts[g * jobs + j] points (0 allowed as long
  * as every job has a point somewhere).  Each rank runs the batch pipeline of snarkv_g1_msm_pippenger_many_partial_dev
  * (enqueued by a host thread of its own), the partials travel by the handle's transport, out64s[j] = job j's affine
- * result (host memory, jobs x 64 bytes); every rank's device holds the results too (snarkv_mgpu_results_many_dev). */
+ * result (host memory, jobs x 64 bytes); every rank's device holds the results too (snarkv_mgpu_results_many_dev).
+ * jobs <= 65 536 (SNARKV_ERR_LENGTH beyond). */
 int snarkv_g1_msm_pippenger_many_mgpu_dev(snarkv_mgpu* mg, size_t jobs, const void* const* d_scalars32,
                                           const void* const* d_points64, const size_t* counts, int window_bits,
                                           uint8_t* out64s);

@@ -324,7 +324,11 @@ static int msm_many_point_sharded(snarkv_mgpu* mg, size_t jobs, const void* cons
     run_rank(0);
   } else {
     std::vector<std::thread> th;
-    for (int g = 0; g < world; ++g) th.emplace_back(run_rank, g);
+    try {
+      for (int g = 0; g < world; ++g) th.emplace_back(run_rank, g);
+    } catch (const std::exception& e) {  // (no thread to be had: the ranks that have none run here, one after the other)
+      for (int g = (int)th.size(); g < world; ++g) run_rank(g);
+    }
     for (auto& t : th) t.join();
   }
   for (int g = 0; g < world; ++g)
@@ -570,6 +574,7 @@ int snarkv_g1_msm_pippenger_many_mgpu_dev(snarkv_mgpu* mg, size_t jobs, const vo
                                           uint8_t* out64s) {
   if (!mg || !d_scalars32 || !d_points64 || !counts || !out64s) return SNARKV_ERR_ARG;
   if (jobs == 0) return SNARKV_ERR_EMPTY;
+  if (jobs > 65536) return SNARKV_ERR_LENGTH;  // (the exchange buffers and the transposing kernel index jobs x ranks x 36 words in 32 bits)
   const int world = (int)mg->ctx.size();
   for (size_t j = 0; j < jobs; ++j) {
     size_t total = 0;
