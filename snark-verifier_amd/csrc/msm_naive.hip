@@ -788,7 +788,11 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
       uint32_t* base = choice + 8;
       SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_CHAIN, (size_t)grid * kGroupMax * kGroupRows * 64 * 4, &d_tab));
       hipLaunchKernelGGL(k_gmap_count, dim3(nblk), dim3(256), 0, ctx->stream, (const uint32_t*)d_offsets, (uint32_t)n_msm, bsum);
-      hipLaunchKernelGGL(k_gmap_choose, dim3(1), dim3(1024), 0, ctx->stream, bsum, nblk, choice, (uint32_t)(jmode >= 2 ? jmode : 0), (uint32_t)slots);
+      // the slots THIS launch can count on: the whole machine when it runs alone; under the throughput hint other launches
+      // share it (16 contexts in flight in bench.py), so a sixteenth -- the choice then goes by total work, as it should
+      // when the machine is full whatever this launch does
+      const uint32_t my_slots = ctx->throughput_mode ? (uint32_t)std::max(1, slots / 16) : (uint32_t)slots;
+      hipLaunchKernelGGL(k_gmap_choose, dim3(1), dim3(1024), 0, ctx->stream, bsum, nblk, choice, (uint32_t)(jmode >= 2 ? jmode : 0), my_slots);
       hipLaunchKernelGGL(k_gmap_fill, dim3(nblk), dim3(256), 0, ctx->stream, (const uint32_t*)d_offsets, (uint32_t)n_msm,
                          (const uint32_t*)bsum, (const uint32_t*)choice, base);
       hipLaunchKernelGGL(k_term_scalar_mul_group, dim3(grid), dim3(64), 0, ctx->stream, (const uint32_t*)d_scalars,
