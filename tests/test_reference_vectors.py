@@ -73,6 +73,38 @@ def test_ref_kzg_as_and_limbs_pin_the_kzg_oracle():
     assert b"".join(O.fe_to_bytes(x) for x in limbs) == bytes.fromhex(lm["limbs"])
 
 
+def test_ref_kzg_as_over_a_poseidon_transcript_pins_the_sponge():
+    """`As::create_proof` over a fresh PoseidonTranscript (the example's accumulation proof,
+    evm-verifier-with-accumulator.rs:375): the one vector that pins the external `poseidon` crate's constants,
+    `State::default()` and how a point enters the sponge -- in the Python oracle AND in the C++ mirror's sponge (scalar
+    schedule or AVX-512 IFMA, whichever this CPU runs)."""
+    import ctypes
+
+    import kzg as K
+    import transcript as T
+
+    d = _load("ref_kzg_as_poseidon.json")
+    ab = bytes.fromhex(d["accumulators"])
+    accs = [(O.g1_from_bytes(ab[128 * i:128 * i + 64]), O.g1_from_bytes(ab[128 * i + 64:128 * i + 128])) for i in range(len(ab) // 128)]
+    t = T.PoseidonTranscript()
+    for lhs, rhs in accs:
+        t.common_ec_point(lhs)
+        t.common_ec_point(rhs)
+    r = t.squeeze_challenge()
+    got = K.kzg_as_verify(accs, r)
+    assert O.g1_to_bytes(got[0]) + O.g1_to_bytes(got[1]) == bytes.fromhex(d["result"])
+    # the C++ sponge squeezes the same challenge from the same absorptions (host only: test hooks, no device)
+    from hostfmt import load_host_lib
+
+    H = load_host_lib()
+    H.hd_transcript_script.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                       ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    script = b"".join(bytes([3]) + O.g1_to_bytes(p) for a in accs for p in a) + bytes([1])  # common_ec_point ..., squeeze
+    out, n = ctypes.create_string_buffer(4096), ctypes.c_size_t(0)
+    assert H.hd_transcript_script(1, script, len(script), b"", 0, out, len(out), ctypes.byref(n)) == 0
+    assert int.from_bytes(out.raw[:32], "little") == r
+
+
 def test_ref_snark_loads_in_both_serialisations():
     from snark_verifier_amd import host_api as H
 
@@ -107,6 +139,9 @@ def test_ref_kzg_layer_on_device(gpu_ctx):
     a = _load("ref_kzg_as.json")
     acc, _ = H.kzg_as_accumulate(bytes.fromhex(a["accumulators"]))
     assert acc == bytes.fromhex(a["result"])
+    if os.path.exists(os.path.join(G, "ref_kzg_as_poseidon.json")):  # (written by refgen from round 5 on)
+        ap = _load("ref_kzg_as_poseidon.json")
+        assert H.kzg_as_create_proof(bytes.fromhex(ap["accumulators"]), H.TRANSCRIPT_POSEIDON)[0] == bytes.fromhex(ap["result"])
     lm = _load("ref_limbs.json")
     assert H.accumulator_to_limbs(bytes.fromhex(lm["accumulator"])) == bytes.fromhex(lm["limbs"])
     assert H.accumulator_from_limbs(bytes.fromhex(lm["limbs"])) == bytes.fromhex(lm["accumulator"])
@@ -138,4 +173,4 @@ def test_refgen_schema_selftest(tmp_path):
     env = dict(os.environ, SNARKV_REF_VECTORS=str(tmp_path))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "not gpu", "-k", "test_ref_",
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, cwd=ROOT)
-    assert r.returncode == 0 and "4 passed" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "5 passed" in r.stdout, r.stdout + r.stderr

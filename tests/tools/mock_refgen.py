@@ -46,6 +46,13 @@ def main(out):
     folded = K.kzg_as_verify(accs, t.squeeze_challenge())
     json.dump({"generator": MOCK, "accumulators": b"".join(accb(a) for a in accs).hex(), "result": accb(folded).hex()},
               open(os.path.join(out, "ref_kzg_as.json"), "w"))
+    tp = T.PoseidonTranscript()
+    for lhs, rhs in accs:
+        tp.common_ec_point(lhs)
+        tp.common_ec_point(rhs)
+    folded_p = K.kzg_as_verify(accs, tp.squeeze_challenge())
+    json.dump({"generator": MOCK, "accumulators": b"".join(accb(a) for a in accs).hex(), "result": accb(folded_p).hex()},
+              open(os.path.join(out, "ref_kzg_as_poseidon.json"), "w"))
     dc = [{"name": "valid_0", "acc": accb(accs[0]).hex(), "accept": True},
           {"name": "folded", "acc": accb(folded).hex(), "accept": True},
           {"name": "invalid_0", "acc": accb((O.g1_add(accs[1][0], O.G1_GEN), accs[1][1])).hex(), "accept": False}]

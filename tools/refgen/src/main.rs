@@ -7,6 +7,9 @@
 //!                         (util/msm.rs:308-343, `.to_affine()`) at 2^10 and 2^16 -- schema of tests/golden/g1_msm.json
 //!   ref_kzg_as.json       `KzgAs::create_proof` (non-zk, fresh EvmTranscript; pcs/kzg/accumulation.rs:148-197) over 64
 //!                         valid accumulators -- {accumulators, result}
+//!   ref_kzg_as_poseidon.json  the same call over a fresh PoseidonTranscript (T = 5, RATE = 4, R_F = 8, R_P = 60), the
+//!                         transcript the reference's example uses for its accumulation proof
+//!                         (examples/evm-verifier-with-accumulator.rs:375) -- {accumulators, result}
 //!   ref_kzg_decider.json  `KzgAs::decide` (pcs/kzg/decider.rs:70-82) accept / reject cases -- schema of kzg_decider.json
 //!   ref_limbs.json        `LimbsEncoding::<4, 68>` / `fe_to_limbs` (pcs/kzg/accumulator.rs:57-81, util/arithmetic.rs:286-298)
 //!   ref_snark.bin / .json a REAL halo2 proof: bincode / serde_json of the SDK's `Snark { protocol, instances, proof }`
@@ -46,7 +49,11 @@ use snark_verifier::{
         kzg::{Gwc19, KzgAccumulator, KzgAs, KzgAsProvingKey, KzgDecidingKey, LimbsEncoding},
         AccumulationDecider, AccumulationSchemeProver, AccumulatorEncoding,
     },
-    system::halo2::{compile, transcript::evm::EvmTranscript, Config},
+    system::halo2::{
+        compile,
+        transcript::{evm::EvmTranscript, halo2::PoseidonTranscript},
+        Config,
+    },
     util::{arithmetic::fe_to_limbs, msm::multi_scalar_multiplication},
     verifier::{
         plonk::{PlonkProtocol, PlonkSuccinctVerifier, PlonkVerifier},
@@ -189,6 +196,19 @@ fn main() {
         "generator": "tools/refgen", "api": "KzgAs::<Bn256, Gwc19>::create_proof (non-zk, EvmTranscript over an empty stream)",
         "accumulators": hex::encode(accs.iter().flat_map(acc_bytes).collect::<Vec<u8>>()),
         "result": hex::encode(acc_bytes(&folded)),
+    }));
+
+    // ... and over a fresh POSEIDON transcript, as the reference's own example writes its accumulation proof
+    // (examples/evm-verifier-with-accumulator.rs:36-39,375: T = 5, RATE = 4, R_F = 8, R_P = 60).  This is the vector that pins
+    // what cannot be read off the reference's sources: the external `poseidon` crate's round constants / MDS and
+    // `State::default()`, and how a G1 point's coordinates enter the sponge (`fe_to_fe`, halo2.rs:220-236).
+    let mut tp = PoseidonTranscript::<G1Affine, NativeLoader, _, 5, 4, 8, 60>::new(Vec::new());
+    let folded_poseidon = As::create_proof(&KzgAsProvingKey::new(None), &accs, &mut tp, &mut rng).unwrap();
+    write("ref_kzg_as_poseidon.json", &json!({
+        "generator": "tools/refgen",
+        "api": "KzgAs::<Bn256, Gwc19>::create_proof (non-zk, PoseidonTranscript<_, NativeLoader, _, 5, 4, 8, 60> over an empty stream)",
+        "accumulators": hex::encode(accs.iter().flat_map(acc_bytes).collect::<Vec<u8>>()),
+        "result": hex::encode(acc_bytes(&folded_poseidon)),
     }));
 
     let mut cases = Vec::new();
