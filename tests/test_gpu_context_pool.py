@@ -180,3 +180,44 @@ def test_ipa_speaks_the_wire_form_whatever_the_context_default_says(monkeypatch)
     assert ctx.ipa_decide_batch(dk, xb * 3, u + wrong + u) == [True, False, True]
     dk.close()
     ctx.close()
+
+
+def test_a_small_pool_makes_callers_wait_not_fail():
+    """SNARKV_DEFAULT_CONTEXTS=2 with 8 calling threads: never more than two contexts, every call still answers with the
+    oracle's bytes (the others wait their turn), and the nested form `bn254_kzg_decide` -> `bn254_kzg_decide_batch` runs on
+    the context the outer call holds (a second check-out from a full pool of ONE would deadlock).  A child interpreter: the
+    pool's size is read once per process."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import ctypes, os, sys, threading
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle"))
+import bn254 as O, coracle as C
+import snark_verifier_amd as sv
+lib = sv.load_library()
+s, p = C.sample_scalars(0x91, 300), C.sample_points(0x92, 300)
+offs = [0, 21, 24, 300]
+exp = C.msm_batched(s, p, offs)
+o = (ctypes.c_uint32 * 4)(*offs)
+g1 = O.g1_to_bytes(O.G1_GEN); g2 = O.g2_to_bytes(O.G2_GEN); sg2 = O.g2_to_bytes(O.g2_mul(O.G2_GEN, 77))
+good = O.g1_to_bytes(O.g1_mul(O.G1_GEN, 77)) + g1
+errs = []
+def work(k):
+    out = ctypes.create_string_buffer(192)
+    for _ in range(6):
+        if lib.bn254_g1_msm_batched(s, p, o, 3, out) != 0 or out.raw != exp: errs.append(("msm", k))
+        if lib.bn254_kzg_decide(g1, g2, sg2, good) != 1: errs.append(("decide", k))
+ts = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+[t.start() for t in ts]; [t.join() for t in ts]
+a, b = ctypes.c_int(0), ctypes.c_int(0)
+lib.bn254_default_contexts(ctypes.byref(a), ctypes.byref(b))
+print("RESULT", len(errs), a.value, b.value)
+''' % (root, root)
+    for cap in ("1", "2"):
+        env = dict(os.environ, SNARKV_DEFAULT_CONTEXTS=cap)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0].split()
+        assert line[1] == "0" and int(line[2]) <= int(cap) and line[3] == cap, (cap, line)
