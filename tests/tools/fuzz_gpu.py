@@ -1,6 +1,6 @@
 """Dev tool: randomized differential run of the C-ABI MSM entry points against the C oracle
 (random sizes, special scalars, identity / repeated / opposite bases, random segmentations)."""
-import os, random, sys, time
+import ctypes, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import bn254 as O
@@ -9,7 +9,10 @@ import snark_verifier_amd as sv
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+import torch
 ctx = sv.Context(0)
+lib = sv.load_library()
+mgs = {}
 R = O.R
 special = [0, 1, 2, R - 1, R - 2, (R - 1) // 2, 1 << 127, (1 << 127) - 1, 1 << 128, (1 << 253), 0xFFFFFFFF, 1 << 64]
 t0 = time.time(); cases = 0; terms = 0
@@ -37,5 +40,30 @@ while time.time() - t0 < secs:
         cuts = sorted(rng.sample(range(1, n), k - 1)) if k > 1 else []
         offs = [0] + cuts + [n]
         assert ctx.msm_batched(s, p, offs) == C.msm_batched(s, p, offs), ("batched", n, seed, offs)
+    # round 5: the same inputs through the context-free boundary (a pool context per call) ...
+    out = ctypes.create_string_buffer(64)
+    assert lib.bn254_g1_msm_pippenger(s, p, n, out) == 0 and out.raw == exp, ("bn254 pippenger", n, seed)
+    # ... and, every few cases, sharded over 1-4 emulated ranks as a BATCH of two jobs through the single-process multi-GPU
+    # entry point (job 1 = the same points with the scalars reversed)
+    if cases % 5 == 0 and n <= 6000:
+        world = rng.randrange(1, 5)
+        mg = mgs.setdefault(world, sv.MultiGpu([0] * world))
+        s2 = b"".join(s[32 * i:32 * i + 32] for i in reversed(range(n)))
+        keep, ds, dp, cn = [], [], [], []
+        for g in range(world):
+            lo, hi = mg.shard(n, g)
+            row_s, row_p, row_n = [], [], []
+            for sj in (s, s2):
+                if hi > lo:
+                    ts = torch.frombuffer(bytearray(sj[32 * lo:32 * hi]), dtype=torch.uint8).cuda()
+                    tp = torch.frombuffer(bytearray(p[64 * lo:64 * hi]), dtype=torch.uint8).cuda()
+                    keep += [ts, tp]
+                    row_s.append(ts.data_ptr()), row_p.append(tp.data_ptr())
+                else:
+                    row_s.append(None), row_p.append(None)
+                row_n.append(hi - lo)
+            ds.append(row_s), dp.append(row_p), cn.append(row_n)
+        torch.cuda.synchronize()
+        assert mg.msm_pippenger_many_dev(ds, dp, cn) == [exp, C.msm_pippenger(s2, p, 8)], ("mgpu batch", n, seed, world)
     cases += 1; terms += n
 print("fuzz ok: %d cases, %d terms, %.0f s" % (cases, terms, time.time() - t0))
