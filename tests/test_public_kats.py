@@ -124,6 +124,11 @@ def test_keccak_and_poseidon_public_values(kats):
         buf = ctypes.create_string_buffer(b"".join(O.fe_to_bytes(x) for x in st), 32 * c["t"])
         assert H.hd_poseidon_permute(c["t"], c["r_f"], c["r_p"], buf) == 0
         assert int.from_bytes(buf.raw[:32], "little") == exp
+        # ... and the AVX-512 IFMA permutation the sponge runs where the CPU has it (rc 1: it has not)
+        H.hd_poseidon_permute_ifma.argtypes = H.hd_poseidon_permute.argtypes
+        buf = ctypes.create_string_buffer(b"".join(O.fe_to_bytes(x) for x in st), 32 * c["t"])
+        rc = H.hd_poseidon_permute_ifma(c["t"], c["r_f"], c["r_p"], buf)
+        assert rc in (0, 1) and (rc == 1 or int.from_bytes(buf.raw[:32], "little") == exp)
 
 
 # ------------------------------------------------------------------ device
