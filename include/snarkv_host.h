@@ -57,7 +57,8 @@ extern "C" {
 #define SNARKV_HOST_TRANSCRIPT_POSEIDON_DEVICE 2 /* the same transcript, hashed for the whole batch on the device       */
 /* the same transcript, hashed wherever the batch is faster: on the host threads below SNARKV_HOST_POSEIDON_DEVICE_MIN
  * proofs (the device launch is one latency chain of ~3 ms whatever the batch: measured 2 x slower than 64 host threads at
- * 64 proofs, 1.4 x faster at 1 024), on the device from there on.  Same bytes either way. */
+ * 64 proofs, 1.4 x faster at 1 024), on the device from there on; twice that threshold on a CPU with AVX-512 IFMA, whose
+ * sponge is three times faster (host/poseidon_ifma.hpp).  Same bytes either way. */
 #define SNARKV_HOST_TRANSCRIPT_POSEIDON_AUTO 3
 #define SNARKV_HOST_POSEIDON_DEVICE_MIN 512
 

@@ -28,6 +28,15 @@ struct snarkv_host_snark {
 };
 
 namespace {
+// SNARKV_HOST_TRANSCRIPT_POSEIDON_AUTO: where a batch of n Poseidon proofs is hashed.  The device launch is one latency chain
+// of ~3 ms whatever the batch; the host threads' time grows with n.  On the scalar sponge they cross at ~512 proofs
+// (SNARKV_HOST_POSEIDON_DEVICE_MIN); with the AVX-512 IFMA sponge and the batch's points decompressed by the device as
+// hints the host reads 512 proofs in ~1.2 ms and 1 024 in 2.3 ms (device: 3.3 / 3.6 ms), level end to end at 1 024 with
+// the wider tail -- so there the host keeps batches below 1 024 (profiles/r05_host_poseidon.txt).
+static int poseidon_auto_route(size_t n) {
+  const size_t device_min = poseidon_ifma::available() ? 2 * (size_t)SNARKV_HOST_POSEIDON_DEVICE_MIN : (size_t)SNARKV_HOST_POSEIDON_DEVICE_MIN;
+  return n >= device_min ? SNARKV_HOST_TRANSCRIPT_POSEIDON_DEVICE : SNARKV_HOST_TRANSCRIPT_POSEIDON;
+}
 
 thread_local std::string g_last_error;
 
@@ -106,7 +115,7 @@ int succinct_verify_batch(const PlonkProtocol& pr, const KzgDecidingKey& dk, int
   bool trailing = false;
   Error e;
   if (transcript == SNARKV_HOST_TRANSCRIPT_POSEIDON_AUTO)
-    transcript = n >= SNARKV_HOST_POSEIDON_DEVICE_MIN ? SNARKV_HOST_TRANSCRIPT_POSEIDON_DEVICE : SNARKV_HOST_TRANSCRIPT_POSEIDON;
+    transcript = poseidon_auto_route(n);
   if (transcript == SNARKV_HOST_TRANSCRIPT_EVM) {
     e = read_all<MOS, EvmTranscript>(dk.svk, pr, insts, pbytes, strict, pfs, &trailing);
   } else if (transcript == SNARKV_HOST_TRANSCRIPT_POSEIDON) {
@@ -187,7 +196,7 @@ int aggregate_many_mos(const PlonkProtocol& pr, const KzgDecidingKey& dk, int tr
   wire::split_batch(instances, ilen, proofs, prlen, (uint32_t)n, insts, pbytes);
   if (threads == 0) threads = HostPool::get().size();
   if (transcript == SNARKV_HOST_TRANSCRIPT_POSEIDON_AUTO)
-    transcript = n >= SNARKV_HOST_POSEIDON_DEVICE_MIN ? SNARKV_HOST_TRANSCRIPT_POSEIDON_DEVICE : SNARKV_HOST_TRANSCRIPT_POSEIDON;
+    transcript = poseidon_auto_route(n);
   switch (transcript) {
     case SNARKV_HOST_TRANSCRIPT_EVM:
       return aggregate_many_run<MOS, EvmTranscript>(pr, dk, insts, pbytes, sizes, threads, timings_ms, accs_out, ok_out);
@@ -207,7 +216,7 @@ int aggregate_mos(const PlonkProtocol& pr, const KzgDecidingKey& dk, int transcr
   wire::split_batch(instances, ilen, proofs, prlen, n, insts, pbytes);
   if (threads == 0) threads = HostPool::get().size();
   if (transcript == SNARKV_HOST_TRANSCRIPT_POSEIDON_AUTO)
-    transcript = n >= SNARKV_HOST_POSEIDON_DEVICE_MIN ? SNARKV_HOST_TRANSCRIPT_POSEIDON_DEVICE : SNARKV_HOST_TRANSCRIPT_POSEIDON;
+    transcript = poseidon_auto_route(n);
   switch (transcript) {
     case SNARKV_HOST_TRANSCRIPT_EVM: return aggregate_run<MOS, EvmTranscript>(pr, dk, insts, pbytes, threads, timings_ms, acc_out);
     case SNARKV_HOST_TRANSCRIPT_POSEIDON: return aggregate_run<MOS, PoseidonTranscript>(pr, dk, insts, pbytes, threads, timings_ms, acc_out);

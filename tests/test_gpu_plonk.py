@@ -310,13 +310,14 @@ def test_random_protocol_shapes_cpp_vs_oracle(H, seed):
 def test_poseidon_auto_transcript_picks_by_batch_size():
     """SNARKV_HOST_TRANSCRIPT_POSEIDON_AUTO (include/snarkv_host.h): host-hashed below SNARKV_HOST_POSEIDON_DEVICE_MIN
     proofs, device-hashed from there on -- the same accumulator and verdict as either explicit kind on both sides of
-    the threshold (64 proofs; the same 64 replicated to 512)."""
+    the threshold (64 proofs; the same 64 replicated to 512 and to 1 024: the threshold is 512 on the scalar sponge and
+    1 024 where the host sponge runs on AVX-512 IFMA)."""
     from snark_verifier_amd import host_api as HA
 
     fx = HA.read_fixture(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
                                       "bench_plonk_gwc19_poseidon_64.bin"))
     hp, hdk = HA.Protocol(fx["protocol"]), HA.DecidingKey(fx["dk"])
-    for rep in (1, 8):
+    for rep in (1, 8, 16):
         got = {}
         for kind in (HA.TRANSCRIPT_POSEIDON, HA.TRANSCRIPT_POSEIDON_DEVICE, HA.TRANSCRIPT_POSEIDON_AUTO):
             ok, acc, tm = HA.aggregate(hp, hdk, fx["instances"] * rep, fx["proofs"] * rep, fx["n"] * rep, HA.MOS_GWC19, kind, 8,
