@@ -503,9 +503,9 @@ def end_to_end_metrics():
 def context_free_metrics(sv, nproofs=64, T=16):
     """The trait boundary's own throughput (VERDICT r4 item 5): `EcPointLoader::multi_scalar_multiplication` has no `&self`
     (loader.rs:108), so a Rust caller binds the context-free `bn254_*` entry points.  T host threads (a rayon pool's
-    workers) each run 64-proof aggregation jobs through them -- bn254_g1_msm_batched x2 + bn254_kzg_dk_decide_batch, inputs
+    workers) each run `nproofs`-proof aggregation jobs through them -- bn254_g1_msm_batched x2 + bn254_kzg_dk_decide_batch, inputs
     packed in the calling thread's pinned buffers (bn254_host_buffer), results on the host after every call -- and the
-    library hands every call a context of its pool.  Compare `aggregate_64_proofs_pipelined` (16 explicit contexts,
+    library hands every call a context of its pool.  Compare `aggregate_<n>_proofs_pipelined` (16 explicit contexts,
     device-resident inputs, asynchronous calls)."""
     import ctypes
     import threading
@@ -1411,6 +1411,7 @@ def main():
         if not use_dist and not args.no_secondary:
             line["secondary"] = secondary_metrics(sv, torch, agg_ctxs, cpu=not args.no_cpu_baseline)
             line["secondary"]["aggregate_64_proofs_context_free_16_threads"] = context_free_metrics(sv)
+            line["secondary"]["aggregate_1024_proofs_context_free_16_threads"] = context_free_metrics(sv, nproofs=1024)
             e2e = end_to_end_metrics()
             if e2e:
                 line["secondary"].update(e2e)
@@ -1432,6 +1433,7 @@ def main():
                     "aggregate_64_proofs_context_free_16_threads": sec.get("aggregate_64_proofs_context_free_16_threads", {}).get("proofs_per_s"),
                     "aggregate_64_proofs_merged": sec.get("aggregate_64_proofs_merged", {}).get("proofs_per_s"),
                     "aggregate_1024_proofs_pipelined": sec.get("aggregate_1024_proofs_pipelined", {}).get("proofs_per_s"),
+                    "aggregate_1024_proofs_context_free_16_threads": sec.get("aggregate_1024_proofs_context_free_16_threads", {}).get("proofs_per_s"),
                     "aggregate_1024_proofs_merged": sec.get("aggregate_1024_proofs_merged", {}).get("proofs_per_s")},
             }
         if use_dist and not dry and world > 1 and batch:

@@ -59,7 +59,7 @@ static int fetch_out(snarkv_ctx* ctx, const void* d, void* host, size_t bytes) {
 //     one, else a new one while the pool may grow, else it waits;
 //   * nesting: bn254_kzg_decide -> bn254_kzg_decide_batch runs on the context the outer call holds;
 //   * flags: the process default (bn254_set_flags) or the calling thread's override (bn254_set_thread_flags) is applied
-//     to the context at check-out;
+//     to the context at check-out, and so is the throughput hint (on while eight or more contexts are checked out);
 //   * pinned host buffers (bn254_host_buffer) belong to the calling THREAD, not to a context: what a thread packs is
 //     its own until it asks again, whatever context its next call lands on.
 struct DefaultPool {
@@ -114,7 +114,13 @@ struct DefaultLease {
     }
     g_pool.busy[slot] = 1;
     c = g_pool.ctx[slot];
+    int in_use = 0;
+    for (char b : g_pool.busy) in_use += b ? 1 : 0;
     lk.unlock();
+    // the throughput hint, by what the pool sees: with eight or more calls in flight the GPU is shared and the forms that
+    // do less work on a longer chain pay (1 024-proof jobs: 0.83 -> 0.75 ms per job at 8 in flight, 0.70 -> 0.49 at 16);
+    // below that they lose (1.35 -> 2.06 at 2, 1.04 -> 1.22 at 4: tools/aggregate_inflight.py --hint-from)
+    c->throughput_mode = in_use >= 8;
     tl_slot = slot;
     tl_held = c;
     tl_depth = 1;

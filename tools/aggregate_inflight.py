@@ -18,6 +18,7 @@ ap.add_argument("--inflight", type=int, nargs="*", default=[1, 4, 8, 16, 32])
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--dummy-streams", type=int, default=0, help="streams created (and kept) before the jobs' own: does their queue mapping matter?")
 ap.add_argument("--dummy-priority", type=int, default=0)
+ap.add_argument("--hint-from", type=int, default=2, help="jobs in flight from which the contexts get the throughput hint")
 a = ap.parse_args()
 g2 = bytes.fromhex(
     "edf692d95cbdde46ddda5ef7d422436779445c5e66006a42761e1f12efde0018c212f3aeb785e49712e7a9353349aaf1255dfb31b7bf60723a480d9293938e19"
@@ -55,7 +56,7 @@ for nproofs in a.proofs:
 
     for N in a.inflight:
         for c in ctxs:  # as bench.py does: the library's throughput hint while several jobs share the GPU
-            c.set_throughput_hint(N > 1)
+            c.set_throughput_hint(N >= a.hint_from)
 
         def wave():
             for _ in range(a.rounds):
@@ -73,6 +74,6 @@ for nproofs in a.proofs:
             best = min(best, (time.perf_counter() - t0) / (N * a.rounds) * 1e3)
             submit = min(submit, (t1 - t0) / (N * a.rounds) * 1e3)
         print("queues=%s proofs=%d inflight=%d throughput_hint=%d ms_per_job=%.4f proofs_per_s=%.3e host_submit_ms_per_job=%.4f" % (
-            os.environ.get("GPU_MAX_HW_QUEUES"), nproofs, N, int(N > 1), best, nproofs / best * 1e3, submit), flush=True)
+            os.environ.get("GPU_MAX_HW_QUEUES"), nproofs, N, int(N >= a.hint_from), best, nproofs / best * 1e3, submit), flush=True)
 for d in dks:
     d.close()
