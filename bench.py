@@ -458,6 +458,40 @@ def end_to_end_metrics():
             out["end_to_end_aggregate_16_jobs_of_64_proofs_one_call"] = e
         hp.close()
         hdk.close()
+    # ... and 16 APPLICATION threads each aggregating 64 proofs end to end through the host C API at the same time (round 5:
+    # no process-wide device lock any more -- the mirror's device calls go through the device library's context pool; the
+    # host passes still take turns on the one host pool)
+    if os.path.exists(path):
+        import threading
+
+        fx = H.read_fixture(path)
+        hp, hdk = H.Protocol(fx["protocol"]), H.DecidingKey(fx["dk"])
+        T, reps, bad = 16, 6, []
+
+        def app(k, reps_):
+            for _ in range(reps_):
+                ok, acc = H.aggregate(hp, hdk, fx["instances"], fx["proofs"], fx["n"], H.MOS_GWC19, 0, 4)
+                if not ok or acc != fx["expected_acc"]:
+                    bad.append(k)
+
+        def wave(reps_):
+            ts = [threading.Thread(target=app, args=(k, reps_)) for k in range(T)]
+            t0 = time.perf_counter()
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            return (time.perf_counter() - t0) * 1e3
+
+        wave(2)
+        ms = min(wave(reps) for _ in range(3)) / (T * reps)
+        out["end_to_end_aggregate_64_proofs_16_app_threads"] = {
+            "ms_per_job": ms, "proofs_per_s": fx["n"] / ms * 1e3, "app_threads": T, "jobs_per_thread": reps, "host_threads_per_call": 4,
+            "estimator": "min", "calls": 3, "timing": "wall time of 16 threads x %d calls of snarkv_host_aggregate, best of 3 regions" % reps,
+            "matches_fixture_accumulator": not bad, "input": os.path.basename(path),
+            "NOT_the_named_config": "16 jobs in flight through the host C API: a throughput figure; one call alone: end_to_end_aggregate_64_proofs"}
+        hp.close()
+        hdk.close()
     # config 5 on its own inputs: 1 024 DISTINCT proofs.  The reference's example hashes with POSEIDON, the snarks and the
     # accumulation proof alike (evm-verifier-with-accumulator.rs:361,375): that fixture is the named figure; the Keccak one
     # (what an outer EVM flow would feed) beside it.
