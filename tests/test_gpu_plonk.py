@@ -484,3 +484,45 @@ def test_aggregate_many_equals_one_call_per_job():
             HA.aggregate_many(hp, hdk, b"".join(insts), b"".join(proofs), [5, 1, 30, 0, 28], HA.MOS_GWC19, kind, 8)
         hp.close()
         hdk.close()
+
+
+def test_host_hashed_poseidon_with_and_without_device_hints(monkeypatch):
+    """Round 5: batches of >= SNARKV_HOST_HINT_MIN (32) host-hashed Poseidon proofs get their compressed points decompressed by
+    ONE device launch and offered to the transcripts as hints (checked against the bytes before use).  Same accumulator with
+    the hints, without them (threshold raised), and for a batch with one proof of another length (no hint for that one,
+    Error::Transcript from the host path as before)."""
+    from snark_verifier_amd import host_api as HA
+
+    fx = HA.read_fixture(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                                      "bench_plonk_gwc19_poseidon_64.bin"))
+    hp, hdk = HA.Protocol(fx["protocol"]), HA.DecidingKey(fx["dk"])
+    ok, with_hints = HA.aggregate(hp, hdk, fx["instances"], fx["proofs"], fx["n"], HA.MOS_GWC19, HA.TRANSCRIPT_POSEIDON, 8)
+    assert ok and with_hints == fx["expected_acc"]
+    monkeypatch.setenv("SNARKV_HOST_HINT_MIN", "100000")
+    ok, without = HA.aggregate(hp, hdk, fx["instances"], fx["proofs"], fx["n"], HA.MOS_GWC19, HA.TRANSCRIPT_POSEIDON, 8)
+    assert ok and without == fx["expected_acc"]
+    monkeypatch.delenv("SNARKV_HOST_HINT_MIN")
+    # a corrupted point in proof 40 (its first commitment's x made a non-residue candidate by flipping a low bit until the
+    # oracle's decompression fails): rejected with the hints in play exactly as without
+    import transcript as T
+
+    prb = bytearray(fx["proofs"])
+    off = 0
+    for _ in range(40):
+        off += 4 + int.from_bytes(prb[off:off + 4], "little")
+    for bit in range(8):
+        cand = bytearray(prb)
+        cand[off + 4] ^= 1 << bit
+        try:
+            T.g1_decompress(bytes(cand[off + 4:off + 36]))
+        except T.TranscriptError:
+            break
+    else:
+        pytest.skip("no invalid encoding found by flipping one byte")
+    for hint_min in ("2", "100000"):
+        monkeypatch.setenv("SNARKV_HOST_HINT_MIN", hint_min)
+        with pytest.raises(HA.HostError) as e:
+            HA.aggregate(hp, hdk, fx["instances"], bytes(cand), fx["n"], HA.MOS_GWC19, HA.TRANSCRIPT_POSEIDON, 8)
+        assert e.value.code == HA.ERR_TRANSCRIPT
+    hp.close()
+    hdk.close()
