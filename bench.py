@@ -667,6 +667,16 @@ def cpu_baseline_aggregate(ds, dp, offs, n1, nproofs, n2):
                       "pairing decide (%.1f ms), 1 thread, %.2f s in all; not a halo2curves measurement" % (nproofs, n1 + n2, dt_dec * 1e3, dt)}
 
 
+def _flush_c_stdio():
+    """what C libraries of this process have buffered for stdout / stderr (RCCL's banner) goes out NOW"""
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001 -- cosmetic
+        pass
+
+
 def _free_port():
     import socket
 
@@ -1000,7 +1010,9 @@ def main():
     args = ap.parse_args()
 
     if args.mgpu_leg:
-        print(json.dumps(mgpu_leg(args.gpus, args.steps, args.log2n, args.window_bits)), flush=True)
+        res = mgpu_leg(args.gpus, args.steps, args.log2n, args.window_bits)
+        _flush_c_stdio()
+        print(json.dumps(res), flush=True)
         return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # a plain `python bench.py --gpus N`: launch the N ranks ourselves and relay rank 0's line
@@ -1062,6 +1074,11 @@ def main():
 
         # a probe that hangs is abandoned by open_data_plane; RCCL's watchdog must not take the process down meanwhile
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+        # ONE node: RCCL's bootstrap (the out-of-band exchange that sets the communicator up; the data goes over xGMI) needs
+        # no network interface beyond loopback and no InfiniBand probe -- the container's hostname may not resolve and its
+        # other interfaces are none of this job's business.  An explicit setting of the caller wins.
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
         dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=30))
         transport = open_data_plane(torch, dist, args.transport or ("gloo" if dry else "auto"), local_rank if dry else dev_index, world)
 
@@ -1322,7 +1339,8 @@ def main():
                     "kind": "RCCL all-gather over xGMI (torch.distributed backend nccl)" if transport["kind"] == "rccl"
                             else "gloo all-gather, HOST-STAGED (partials copied to the host and back)",
                     "requested": transport.get("requested"), "fallback_reason": transport.get("why"),
-                    "probe_seconds": transport.get("probe_seconds"), "control_plane": "gloo"},
+                    "probe_seconds": transport.get("probe_seconds"), "control_plane": "gloo",
+                    "rccl_env": {k: os.environ.get(k) for k in ("NCCL_SOCKET_IFNAME", "NCCL_IB_DISABLE", "HSA_ENABLE_IPC_MODE_LEGACY")}},
                 "result": result_hex,
             },
             "roofline": {
@@ -1499,6 +1517,7 @@ def main():
             line["single_process_mgpu"] = run_mgpu_leg_subprocess(world, args.steps, args.log2n, args.window_bits)
         if "named_configs" in line:  # keep it the LAST key of the line
             line["named_configs"] = line.pop("named_configs")
+        _flush_c_stdio()  # RCCL prints a version banner through C stdio: out now, so that the JSON line is the LAST line
         print(json.dumps(line), flush=True)
     if transport.get("probe_hung"):
         sys.stdout.flush()

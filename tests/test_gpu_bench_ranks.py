@@ -49,3 +49,21 @@ def test_plain_launch_two_ranks_one_device_measures_and_says_how():
     assert mg["ranks"] == 2 and mg["devices"] == [0, 0]
     assert "distinct devices" in mg["rccl"]["error"] and mg["peer_copy"]["value"] > 0
     assert mg["job0_matches_one_gpu_recompute"] is True and mg["result_job0"] == cfg["result"]
+
+
+def test_rccl_data_plane_at_world_one_and_the_line_is_the_last_line():
+    """`--force-dist` on one rank: gloo control plane + a REAL RCCL group for the partials (a communicator of one), and the
+    JSON line is the LAST line of stdout -- RCCL prints a version banner through C stdio that used to land after it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MASTER_PORT"] = str(41000 + os.getpid() % 1000)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "3", "--warmup", "1", "--log2n", "14", "--no-cpu-baseline",
+           "--no-secondary", "--no-strong", "--no-mgpu-leg"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    last = [ln for ln in r.stdout.splitlines() if ln.strip()][-1]
+    d = json.loads(last)
+    tr = d["config"]["transport"]
+    assert "RCCL all-gather" in tr["kind"] and tr["fallback_reason"] is None and d["config"]["rccl_ranks_seen"] == 1
+    assert tr["rccl_env"]["NCCL_SOCKET_IFNAME"] == os.environ.get("NCCL_SOCKET_IFNAME", "lo")
+    n = 1 << 14
+    assert d["config"]["result"] == C.msm_pippenger(C.sample_scalars(0x5EED0001, n), C.sample_points(0x5EED0002, n), 8).hex()
