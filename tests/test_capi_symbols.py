@@ -68,3 +68,35 @@ def test_pallas_library_exports_every_declared_symbol():
         with pytest.raises(sv.SnarkvError) as e:
             PL.PallasContext(0)
         assert e.value.code == -4
+
+
+def test_headers_are_plain_c_and_a_c_program_links(tmp_path):
+    """The drop-in boundary is a C ABI: every header under include/ compiles as strict C99 (no C++ types, no torch types in
+    a signature), and a C program that names one entry point of each family links against the libraries with gcc alone."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc, libdir = os.path.join(root, "include"), os.path.join(root, "snark-verifier_amd")
+    for h in ("snarkv_amd.h", "snarkv_host.h", "snarkv_pallas.h"):
+        r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, h)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, h + ": " + r.stderr
+    src = tmp_path / "link.c"
+    src.write_text('''#include "snarkv_amd.h"
+#include "snarkv_host.h"
+#include <stdio.h>
+int main(void) {
+  /* addresses only: no device call without a GPU */
+  void* f[] = {(void*)snarkv_ctx_create, (void*)snarkv_g1_msm_pippenger_many_dev, (void*)bn254_g1_msm_batched,
+               (void*)bn254_set_thread_flags, (void*)snarkv_kzg_decide_batch, (void*)snarkv_g1_msm_pippenger_many_mgpu_dev,
+               (void*)snarkv_host_aggregate};
+  printf("%s %d\\n", snarkv_version(), (int)(sizeof f / sizeof f[0]));
+  return 0;
+}
+''')
+    exe = tmp_path / "link"
+    r = subprocess.run(["gcc", "-std=gnu99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lsnarkv_host", "-lsnarkv_amd",
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath-link," + libdir + ":/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", "")))
+    assert r.returncode == 0 and r.stdout.split()[-1] == "7", r.stdout + r.stderr
