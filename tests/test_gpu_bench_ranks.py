@@ -67,3 +67,31 @@ def test_rccl_data_plane_at_world_one_and_the_line_is_the_last_line():
     assert tr["rccl_env"]["NCCL_SOCKET_IFNAME"] == os.environ.get("NCCL_SOCKET_IFNAME", "lo")
     n = 1 << 14
     assert d["config"]["result"] == C.msm_pippenger(C.sample_scalars(0x5EED0001, n), C.sample_points(0x5EED0002, n), 8).hex()
+
+
+def test_the_default_line_keeps_the_drivers_contract():
+    """`python bench.py` (N = 1, small size here): ONE JSON line, the last of stdout, with every key the driver's contract
+    names -- metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype /
+    data / config.workload (no model keys), `roofline` {bound, achieved, peak, unit, frac, traffic} and `cpu_baseline`
+    {value, unit, cores, kind, sample} -- and the GPU agreeing with the CPU restatement on the whole workload."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--log2n", "14", "--no-secondary", "--no-host-resident",
+           "--strong-total-log2n", "16"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert sum(ln.startswith("{") for ln in lines) == 1 and lines[-1].startswith("{")
+    d = json.loads(lines[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "points/s" and d["scaling"] == "weak" and d["data"] == "synthetic" and "model" not in d["config"]
+    assert "workload" in d["config"] and abs(d["value"] - (1 << 14) * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert "traffic" in rf and rf["achieved"] * 1e9 * rf["kernel_ms"] * 1e-3 == pytest.approx(96 * (1 << 14), rel=1e-9)
+    cb = d["cpu_baseline"]
+    assert all(k in cb for k in ("value", "unit", "cores", "kind", "sample")) and cb["kind"] == "port"
+    assert cb["gpu_matches_on_sample"] is True and cb["sample_is_the_whole_workload"] is True
+    assert d["config4_strong"]["matches_one_gpu_single_call"] is True and d["single_process_mgpu"]["job0_matches_one_gpu_recompute"] is True
