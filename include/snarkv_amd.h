@@ -73,6 +73,18 @@ typedef struct snarkv_poseidon snarkv_poseidon;
 int snarkv_ctx_create(int device, void* hip_stream, snarkv_ctx** out);
 void snarkv_ctx_destroy(snarkv_ctx* ctx);
 int snarkv_ctx_sync(snarkv_ctx* ctx);
+/* Stream ordering WITHOUT a host round trip (SURVEY.md 8b "Threading": the `_dev` entry points are asynchronous on the
+ * context's stream; a caller that fills the inputs or reads the outputs on ANOTHER stream orders the two here):
+ *   snarkv_ctx_wait_stream   everything enqueued on `hip_stream` so far happens-before whatever the context enqueues next
+ *                            (inputs written by the caller's stream: call it BEFORE the `_dev` entry point);
+ *   snarkv_stream_wait_ctx   everything the context has enqueued so far happens-before whatever `hip_stream` runs next
+ *                            (outputs read by the caller's stream / a collective on it: call it AFTER the entry point).
+ * `hip_stream` = a hipStream_t; NULL is the legacy default stream.  Both are an event record + hipStreamWaitEvent: they
+ * return at once and cost no host synchronisation.  A context that was created ON `hip_stream` is ordered already: no-op.
+ * `snarkv_ctx_stream` returns the hipStream_t the context enqueues on (for callers that bring their own events).     */
+int snarkv_ctx_wait_stream(snarkv_ctx* ctx, void* hip_stream);
+int snarkv_stream_wait_ctx(snarkv_ctx* ctx, void* hip_stream);
+void* snarkv_ctx_stream(snarkv_ctx* ctx);
 /* Pinned host memory owned by the context, for callers that assemble their inputs themselves: the host-pointer
  * entry points (`snarkv_g1_msm_batched`, `snarkv_g1_msm_pippenger`, ...) copy with hipMemcpyAsync, which is a DMA
  * out of pinned memory and a bounce copy out of pageable memory (2.4 MB of MSM terms: ~0.1 ms against ~0.3 ms).
@@ -203,7 +215,9 @@ int snarkv_g1_decompress(snarkv_ctx* ctx, const uint8_t* in32, size_t n, uint8_t
  * speaks halo2curves' in-memory form.  Takes effect for calls that START after it returns. */
 int bn254_set_flags(uint32_t flags);
 /* ... and an override for the CALLING THREAD only: flags >= 0 replace the process default for this thread's bn254_*
- * calls, -1 removes the override.  Returns the previous value (-1 = none).  What a library that shares the process
+ * calls, -1 removes the override.  Returns the previous value (>= -1; -1 = none), or SNARKV_ERR_ARG (-5) when `flags`
+ * has unknown bits or is below -1 -- the override is then UNCHANGED, and -5 must not be passed back as "the previous
+ * value" (restore only what was returned with a value >= -1).  What a library that shares the process
  * with other bn254_* users needs (libsnarkv_host.so passes wire-form bytes whatever the application chose above). */
 int64_t bn254_set_thread_flags(int64_t flags);
 uint32_t bn254_get_flags(void); /* what the calling thread's next bn254_* call will use */
@@ -392,7 +406,9 @@ int snarkv_kzg_decide_batch_mgpu(snarkv_mgpu* mg, const uint8_t g1_64[64], const
 
 /* Hint: the caller keeps SEVERAL large MSMs in flight on several contexts (one context + stream each).  The Pippenger then cuts
  * the sorted stream into longer runs per lane -- less total work per MSM (-3.5 % at 2^20 with 4 in flight) at the price of a
- * longer single-MSM latency (+4 %), because one MSM alone no longer fills every wave slot.  Same bytes either way. */
+ * longer single-MSM latency (+4 %), because one MSM alone no longer fills every wave slot.  Same bytes either way.
+ * `enabled`: 0 off; 1 on (the number of contexts in flight unknown: 16 assumed where it matters -- the batched small-MSM
+ * launch sizes its lane groups by the share of the GPU it can count on); n >= 2: on, with n contexts in flight. */
 int snarkv_ctx_set_throughput_hint(snarkv_ctx* ctx, int enabled);
 /* points ONE launch of the Pippenger kernels processes for an n-point MSM: n itself, or the 2^20-point chunk of the
  * chunk pipeline large MSMs run as (csrc/capi.hip pippenger_maybe_split) -- what a per-launch roofline divides by */

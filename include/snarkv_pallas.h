@@ -22,6 +22,10 @@ extern "C" {
 int snarkv_pallas_ctx_create(int device, void* hip_stream, snarkv_ctx** out);
 void snarkv_pallas_ctx_destroy(snarkv_ctx* ctx);
 int snarkv_pallas_ctx_sync(snarkv_ctx* ctx);
+/* stream ordering without a host round trip, as snarkv_ctx_wait_stream / snarkv_stream_wait_ctx / snarkv_ctx_stream */
+int snarkv_pallas_ctx_wait_stream(snarkv_ctx* ctx, void* hip_stream);
+int snarkv_pallas_stream_wait_ctx(snarkv_ctx* ctx, void* hip_stream);
+void* snarkv_pallas_ctx_stream(snarkv_ctx* ctx);
 int snarkv_pallas_ctx_host_buffer(snarkv_ctx* ctx, int slot, size_t bytes, void** out); /* as snarkv_ctx_host_buffer */
 const char* snarkv_pallas_last_error(void);
 const char* snarkv_pallas_version(void);

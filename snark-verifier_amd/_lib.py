@@ -49,6 +49,9 @@ _SIGNATURES = {
     "snarkv_ctx_create": (_int, [_int, _vp, _pp]),
     "snarkv_ctx_destroy": (None, [_vp]),
     "snarkv_ctx_sync": (_int, [_vp]),
+    "snarkv_ctx_wait_stream": (_int, [_vp, _vp]),
+    "snarkv_stream_wait_ctx": (_int, [_vp, _vp]),
+    "snarkv_ctx_stream": (_vp, [_vp]),
     "snarkv_ctx_host_buffer": (_int, [_vp, _int, _sz, _pp]),
     "bn254_host_buffer": (_int, [_int, _sz, _pp]),
     "snarkv_g1_decompress": (_int, [_vp, _cp, _sz, _vp, _vp]),
@@ -379,6 +382,18 @@ class PoseidonSpec:
             pass
 
 
+def stream_handle(stream):
+    """hipStream_t as an int: a raw handle stays, a `torch.cuda.Stream` gives its `cuda_stream`, None = torch's CURRENT
+    stream (0 = the legacy default stream, which is what torch runs on unless told otherwise)."""
+    if stream is None:
+        import torch
+
+        return int(torch.cuda.current_stream().cuda_stream)
+    if isinstance(stream, int):
+        return stream
+    return int(stream.cuda_stream)
+
+
 class Context:
     """One HIP stream + scratch (see include/snarkv_amd.h "Threading").
 
@@ -407,6 +422,23 @@ class Context:
 
     def sync(self):
         _check(self._lib.snarkv_ctx_sync(self._h))
+
+    def wait_stream(self, stream=None):
+        """`snarkv_ctx_wait_stream`: whatever this context enqueues next runs after everything queued on `stream` so far
+        (a HIP stream handle, a `torch.cuda.Stream`, or None = torch's current stream).  No host synchronisation.  Call it
+        after filling inputs with torch and before the `_dev` entry point that reads them."""
+        _check(self._lib.snarkv_ctx_wait_stream(self._h, ctypes.c_void_p(stream_handle(stream))))
+
+    def stream_wait(self, stream=None):
+        """`snarkv_stream_wait_ctx`: whatever `stream` runs next (torch ops, an RCCL collective) runs after everything this
+        context has enqueued so far.  No host synchronisation.  Call it after the `_dev` entry point whose output the
+        stream reads."""
+        _check(self._lib.snarkv_stream_wait_ctx(self._h, ctypes.c_void_p(stream_handle(stream))))
+
+    @property
+    def stream(self):
+        """the hipStream_t (as an int) this context enqueues on (`snarkv_ctx_stream`)"""
+        return int(self._lib.snarkv_ctx_stream(self._h) or 0)
 
     def g1_decompress(self, compressed):
         """Batch `G1Affine::from_bytes` (halo2.rs:260-273): n x 32 bytes -> (n x 64 bytes, [valid])."""

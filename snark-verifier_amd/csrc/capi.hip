@@ -121,6 +121,7 @@ struct DefaultLease {
     // do less work on a longer chain pay (1 024-proof jobs: 0.83 -> 0.75 ms per job at 8 in flight, 0.70 -> 0.49 at 16);
     // below that they lose (1.35 -> 2.06 at 2, 1.04 -> 1.22 at 4: tools/aggregate_inflight.py --hint-from)
     c->throughput_mode = in_use >= 8;
+    c->throughput_peers = in_use;  // the pool KNOWS how many calls share the GPU (not a fixed sixteenth)
     tl_slot = slot;
     tl_held = c;
     tl_depth = 1;
@@ -186,6 +187,7 @@ uint32_t snarkv_ctx_get_flags(const snarkv_ctx* ctx) { return ctx ? ctx->flags :
 int snarkv_ctx_set_throughput_hint(snarkv_ctx* ctx, int enabled) {
   if (!ctx) return SNARKV_ERR_ARG;
   ctx->throughput_mode = enabled != 0;
+  ctx->throughput_peers = enabled > 1 ? enabled : 0;  // n >= 2: that many contexts in flight; 1: unknown (16 assumed)
   return SNARKV_OK;
 }
 
@@ -865,8 +867,10 @@ uint32_t bn254_get_flags(void) { return tl_flags >= 0 ? (uint32_t)tl_flags : g_p
 
 int64_t bn254_set_thread_flags(int64_t flags) {
   const int64_t before = tl_flags;
-  if (flags >= 0 && (flags & ~(int64_t)(SNARKV_FLAG_VALIDATE | SNARKV_FLAG_MONTGOMERY))) return SNARKV_ERR_ARG;
-  tl_flags = flags < 0 ? -1 : flags;
+  // unknown bits, or a negative value other than -1 (e.g. an error code of this very function handed back as "the
+  // previous value"): refused, the override stays what it was
+  if (flags < -1 || (flags >= 0 && (flags & ~(int64_t)(SNARKV_FLAG_VALIDATE | SNARKV_FLAG_MONTGOMERY)))) return SNARKV_ERR_ARG;
+  tl_flags = flags;
   return before;
 }
 
@@ -949,26 +953,58 @@ int bn254_kzg_decide_batch(const uint8_t g1_64[64], const uint8_t g2_128[128], c
                            const uint8_t* accs128, size_t m, uint8_t* ok) {
   SNARKV_DEFAULT_LEASE(c);
   if (!g1_64 || !g2_128 || !s_g2_128) return SNARKV_ERR_ARG;
-  // The reference rebuilds `G2Prepared` on every decide (decider.rs:74); a verifier decides against ONE key, so the last
-  // key's line tables are kept (the 320 key bytes + the encoding they were given in are the cache tag).
-  // Shared by the pool's contexts (the tables are read-only device memory): looked up under a lock, used outside it; a
-  // replaced key's tables are freed when the last call using them returns.
+  // The reference rebuilds `G2Prepared` on every decide (decider.rs:74); a verifier decides against ONE key (or a few:
+  // one per recursion layer / encoding), so the line tables of the last DK_CACHE keys are kept; the 320 key bytes + the
+  // encoding they were given in are the tag.  Shared by the pool's contexts (the tables are read-only device memory).
+  // The lock covers the lookup and the publication only: a miss builds its tables (G2 preparation on the GPU + a
+  // synchronisation) OUTSIDE it, so concurrent callers with other keys -- or the same key: the loser of the race drops
+  // its copy -- never queue behind a build.  A replaced key's tables are freed when the last call using
+  // them returns (shared_ptr).
+  enum { DK_CACHE = 4 };
+  struct Entry {
+    std::shared_ptr<snarkv_dk> dk;
+    uint8_t tag[321];
+    uint64_t used;
+  };
   static std::mutex cache_mu;
-  static std::shared_ptr<snarkv_dk> cached;
-  static uint8_t tag[321];
+  static Entry cache[DK_CACHE];
+  static uint64_t tick = 0;
   uint8_t now[321];
   memcpy(now, g1_64, 64), memcpy(now + 64, g2_128, 128), memcpy(now + 192, s_g2_128, 128);
   now[320] = c->mont ? 1 : 0;
+  auto lookup = [&]() -> std::shared_ptr<snarkv_dk> {  // (under cache_mu)
+    for (auto& e : cache)
+      if (e.dk && memcmp(e.tag, now, sizeof now) == 0) {
+        e.used = ++tick;
+        return e.dk;
+      }
+    return nullptr;
+  };
   std::shared_ptr<snarkv_dk> dk;
   {
     std::lock_guard<std::mutex> lk(cache_mu);
-    if (!cached || memcmp(tag, now, sizeof now) != 0) {
-      snarkv_dk* fresh = nullptr;
-      SNARKV_TRY(snarkv_dk_create(c, g1_64, g2_128, s_g2_128, 0, &fresh));
-      cached = std::shared_ptr<snarkv_dk>(fresh, [](snarkv_dk* p) { snarkv_dk_destroy(p); });
-      memcpy(tag, now, sizeof now);
+    dk = lookup();
+  }
+  if (!dk) {
+    snarkv_dk* fresh = nullptr;
+    SNARKV_TRY(snarkv_dk_create(c, g1_64, g2_128, s_g2_128, 0, &fresh));
+    std::shared_ptr<snarkv_dk> mine(fresh, [](snarkv_dk* p) { snarkv_dk_destroy(p); });
+    std::lock_guard<std::mutex> lk(cache_mu);
+    dk = lookup();  // somebody else published the same key meanwhile: use theirs, `mine` is freed on return
+    if (!dk) {
+      Entry* victim = &cache[0];
+      for (auto& e : cache) {  // a free slot, else the least recently used
+        if (!e.dk) {
+          victim = &e;
+          break;
+        }
+        if (e.used < victim->used) victim = &e;
+      }
+      victim->dk = mine;
+      memcpy(victim->tag, now, sizeof now);
+      victim->used = ++tick;
+      dk = mine;
     }
-    dk = cached;
   }
   return snarkv_kzg_decide_batch(c, dk.get(), accs128, m, 0, ok);
 }

@@ -95,6 +95,7 @@ struct snarkv_ctx {
   bool sorted_ev_ready;
   int last_split_workers;  // > 0: the last Pippenger ran as a chunk pipeline on that many worker lanes (stage timing)
   bool throughput_mode;  // several MSMs are kept in flight next to this context's (snarkv_ctx_set_throughput_hint; always on lanes)
+  int throughput_peers;  // how many launches share the GPU under the hint (0 = unknown: 16, what bench.py keeps in flight)
   bool is_lane;          // a private sub-context of another context (never starts lanes of its own)
   // job contexts of the batch entry point (snarkv_g1_msm_pippenger_many_dev): scratch of one MSM each
   snarkv_ctx* jobs[SNARKV_MANY_MAX_JOBS];
@@ -104,6 +105,8 @@ struct snarkv_ctx {
   hipStream_t copy_stream;   // host-resident batches (snarkv_g1_msm_pippenger_many): the uploads, one event per job
   bool copy_ready;
   hipEvent_t many_ev[2];
+  hipEvent_t order_ev;  // snarkv_ctx_wait_stream / snarkv_stream_wait_ctx: the record-and-wait event
+  bool order_ev_ready;
   hipStream_t hi_stream[2];  // high-priority streams of the batch pipeline (the sorts) + their join events (many_ev)
   bool hi_ready;
 };

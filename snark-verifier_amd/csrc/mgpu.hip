@@ -310,6 +310,18 @@ static int transpose_fold(snarkv_mgpu* mg, int g, size_t jobs) {
 // snark-verifier_amd/distributed.py::gpu_sharded_msm_batch.  The ranks' batches are enqueued by one host thread each --
 // a 20-job batch is ~400 launches per rank, and one thread walking eight ranks would start the last of them several
 // milliseconds after the first.
+static int many_exchange_and_fold(snarkv_mgpu* mg, size_t jobs, uint8_t* out64s);
+
+// nothing of a failed batch stays queued behind the caller's back: the partial kernels (~400 launches per rank) read the
+// caller's d_scalars / d_points, and a caller that frees or reuses them after an error return must not race with the device
+static void drain_all_ranks(snarkv_mgpu* mg) {
+  for (size_t h = 0; h < mg->ctx.size(); ++h) {
+    (void)hipSetDevice(mg->ctx[h]->device);
+    (void)hipStreamSynchronize(mg->ctx[h]->stream);
+  }
+  (void)hipGetLastError();
+}
+
 static int msm_many_point_sharded(snarkv_mgpu* mg, size_t jobs, const void* const* d_s, const void* const* d_p,
                                   const size_t* counts, int window_bits, uint8_t* out64s) {
   const int world = (int)mg->ctx.size();
@@ -334,12 +346,18 @@ static int msm_many_point_sharded(snarkv_mgpu* mg, size_t jobs, const void* cons
   for (int g = 0; g < world; ++g)
     if (rcs[g] < 0) {
       set_last_error("mgpu rank %d: %s", g, errs[g].c_str());
-      for (int h = 0; h < world; ++h) {  // nothing of the failed batch stays queued behind the caller's back
-        (void)hipSetDevice(mg->ctx[h]->device);
-        (void)hipStreamSynchronize(mg->ctx[h]->stream);
-      }
+      drain_all_ranks(mg);
       return rcs[g];
     }
+  // every error exit of the exchange (RCCL not initialised, hipSetDevice / AllGather / GroupEnd, a peer copy) leaves through
+  // the same drain as a failed rank
+  int rc = many_exchange_and_fold(mg, jobs, out64s);
+  if (rc < 0) drain_all_ranks(mg);
+  return rc;
+}
+
+static int many_exchange_and_fold(snarkv_mgpu* mg, size_t jobs, uint8_t* out64s) {
+  const int world = (int)mg->ctx.size();
   const size_t row = jobs * SNARKV_G1_PARTIAL_BYTES;
   snarkv_ctx* c0 = mg->ctx[0];
   if (mg->transport == SNARKV_MGPU_TRANSPORT_RCCL) {

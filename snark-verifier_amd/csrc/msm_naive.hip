@@ -272,6 +272,7 @@ __global__ void __launch_bounds__(1024) k_gmap_choose(uint32_t* __restrict__ bsu
   if (tid == 0) {
     uint32_t best = 0;
     unsigned long long bc = ~0ull;
+    uint32_t bt = ~0u;
     for (uint32_t k = 0; k < 3; ++k) {
       // duration ~ (passes of the resident grid over the lanes) x (one lane's chain): a launch that does not fill the
       // machine is as long as its chain, whatever its total work (profiles/r05_ab_fixed_base.txt: 16 x 1 024 proofs with
@@ -279,8 +280,10 @@ __global__ void __launch_bounds__(1024) k_gmap_choose(uint32_t* __restrict__ bsu
       // with a chain 0.63x as long: 3.0 ms).  Ties go to the smaller total.
       const unsigned long long waves = ((unsigned long long)tot[k] + 63) / 64;
       const unsigned long long passes = slots ? (waves + slots - 1) / slots : 1;
-      const unsigned long long cost = (passes ? passes : 1) * (1160ull + (k + 2) * 830ull) * 1000000ull + tot[k];
-      if (cost < bc) bc = cost, best = k;
+      const unsigned long long cost = (passes ? passes : 1) * (1160ull + (k + 2) * 830ull);
+      // (cost, total work) compared lexicographically: `tot` is a lane count that can exceed any fixed weight of the
+      // primary term, so it is never packed into it
+      if (cost < bc || (cost == bc && tot[k] < bt)) bc = cost, bt = tot[k], best = k;
     }
     if (force_k >= 2 && force_k <= 4) best = force_k - 2;
     kk = best;
@@ -789,9 +792,10 @@ int launch_msm_batched(snarkv_ctx* ctx, const void* d_scalars, const void* d_poi
       SNARKV_TRY(ctx_reserve(ctx, SLOT_TERM_CHAIN, (size_t)grid * kGroupMax * kGroupRows * 64 * 4, &d_tab));
       hipLaunchKernelGGL(k_gmap_count, dim3(nblk), dim3(256), 0, ctx->stream, (const uint32_t*)d_offsets, (uint32_t)n_msm, bsum);
       // the slots THIS launch can count on: the whole machine when it runs alone; under the throughput hint other launches
-      // share it (16 contexts in flight in bench.py), so a sixteenth -- the choice then goes by total work, as it should
-      // when the machine is full whatever this launch does
-      const uint32_t my_slots = ctx->throughput_mode ? (uint32_t)std::max(1, slots / 16) : (uint32_t)slots;
+      // share it -- as many as the hint / the context pool says (16 when it does not: what bench.py keeps in flight) -- and
+      // the choice then goes by total work, as it should when the machine is full whatever this launch does
+      const int peers = ctx->throughput_peers > 1 ? ctx->throughput_peers : 16;
+      const uint32_t my_slots = ctx->throughput_mode ? (uint32_t)std::max(1, slots / peers) : (uint32_t)slots;
       hipLaunchKernelGGL(k_gmap_choose, dim3(1), dim3(1024), 0, ctx->stream, bsum, nblk, choice, (uint32_t)(jmode >= 2 ? jmode : 0), my_slots);
       hipLaunchKernelGGL(k_gmap_fill, dim3(nblk), dim3(256), 0, ctx->stream, (const uint32_t*)d_offsets, (uint32_t)n_msm,
                          (const uint32_t*)bsum, (const uint32_t*)choice, base);

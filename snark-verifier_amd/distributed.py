@@ -11,6 +11,15 @@ affine result (all-reduce semantics; `ncclAllReduce` itself cannot be used: EC
 addition is not an RCCL reduction operator).  SURVEY.md section 8(e).
 
 One process per GPU; `torch.distributed` is only the transport.
+
+Stream ordering.  The context enqueues on ITS stream (a private non-blocking one unless it was created on the caller's);
+torch allocates, fills and runs the collective on torch's CURRENT stream.  Every step below that hands a buffer from one
+to the other is bracketed by `ctx.wait_stream()` (the context's next launch runs after what torch has queued: fills,
+the landed collective) and `ctx.stream_wait()` (torch's next op -- the collective, a copy, the caching allocator's reuse
+of a freed block -- runs after what the context has queued): two event record/wait pairs, no host synchronisation
+(include/snarkv_amd.h `snarkv_ctx_wait_stream` / `snarkv_stream_wait_ctx`).  A context created on torch's current stream
+makes both a no-op.  The results these helpers return are therefore ordered on torch's current stream: `.cpu()` or
+any torch op on them is safe; `ctx.sync()` alone is NOT needed (and would not be enough for torch-side consumers).
 """
 from dataclasses import dataclass
 from typing import Callable
@@ -85,14 +94,12 @@ def gpu_msm_partial(ctx, part, d_scalars, d_points, count, window_bits=0):
     `part`.  An EMPTY shard contributes the identity: ceil chunking leaves trailing ranks empty when n is small against
     the world size (n = 9, world = 8: ranks 5-7); the device call would return SNARKV_ERR_EMPTY on that rank only and
     the peers would hang in the all-gather."""
-    import torch
-
     if count == 0:
-        part.zero_()  # all-zero partial: ZZ = 0 is the identity
-        torch.cuda.current_stream().synchronize()
+        part.zero_()  # all-zero partial: ZZ = 0 is the identity (on torch's stream, where the collective runs)
         return part
+    ctx.wait_stream()  # `part`'s allocation / fill and the inputs (torch's stream) before the context's writes
     ctx.msm_pippenger_partial_dev(d_scalars.data_ptr(), d_points.data_ptr(), count, part.data_ptr(), window_bits)
-    ctx.sync()  # the partial is in memory before the all-gather reads it
+    ctx.stream_wait()  # the partial is written before the all-gather (torch's stream) reads it
     return part
 
 
@@ -108,13 +115,14 @@ def gpu_sharded_msm(ctx, d_scalars, d_points, n_total, window_bits=0):
 
     # The context's HIP stream need not be torch's current stream (a context
     # created without a stream owns a private one), and the collective is ordered
-    # against torch's current stream only -- so order the three steps explicitly.
+    # against torch's current stream only -- so order the three steps explicitly (module docstring).
     def partial_fn(lo, hi):
         return gpu_msm_partial(ctx, part, d_scalars, d_points, hi - lo, window_bits)
 
     def fold_fn(gathered, world):
-        torch.cuda.current_stream().synchronize()  # the all-gather has landed before the fold reads it
+        ctx.wait_stream()  # the all-gather has landed (and `out` is zero-filled) before the fold reads / writes
         ctx.fold_partials_dev(gathered.data_ptr(), world, out.data_ptr())
+        ctx.stream_wait()  # `out` is valid for whatever torch's stream does with it; `gathered` may be freed
         return out
 
     return ShardedMsm(partial_fn, fold_fn, G1_PARTIAL_BYTES).run(n_total)
@@ -159,9 +167,10 @@ class ShardedMsmBatch:
 
 def gpu_sharded_msm_batch(ctx, d_scalars, d_points, counts, window_bits=0, stream=None):
     """Product wiring of ShardedMsmBatch: `d_scalars[i]` / `d_points[i]` hold THIS rank's shard of MSM i (`counts[i]`
-    points; 0 = an empty shard, which contributes the identity).  Everything is enqueued on the context's stream, which must be torch's current stream for the
-    collective to be ordered after the partials (create the context with `stream=torch_stream.cuda_stream` and pass that
-    torch stream here); returns the device tensor of the K affine results (64 B each), valid after that stream."""
+    points; 0 = an empty shard, which contributes the identity).  The launches go to the context's stream, the collective
+    to `stream` (default: torch's current stream); the two are ordered by events (module docstring) -- free when the
+    context was created on that very stream (`stream=torch_stream.cuda_stream`), which is what bench.py does.  Returns
+    the device tensor of the K affine results (64 B each), valid on `stream`."""
     import contextlib
 
     import torch
@@ -178,22 +187,28 @@ def gpu_sharded_msm_batch(ctx, d_scalars, d_points, counts, window_bits=0, strea
         parts = torch.zeros(G1_PARTIAL_BYTES * k, dtype=torch.uint8, device=d_scalars[0].device)
         keep.append(parts)
         live = [i for i, (lo, hi) in enumerate(ranges) if hi > lo]
+        ctx.wait_stream()  # the zero fill of `parts` and the caller's inputs before the context's launches
         if len(live) == k:
             ctx.msm_pippenger_many_partial_dev([t.data_ptr() for t in d_scalars], [t.data_ptr() for t in d_points],
                                                [hi - lo for lo, hi in ranges], parts.data_ptr(), window_bits)
         elif live:
             dense = torch.zeros(G1_PARTIAL_BYTES * len(live), dtype=torch.uint8, device=parts.device)
             keep.append(dense)
+            ctx.wait_stream()
             ctx.msm_pippenger_many_partial_dev([d_scalars[i].data_ptr() for i in live], [d_points[i].data_ptr() for i in live],
                                                [ranges[i][1] - ranges[i][0] for i in live], dense.data_ptr(), window_bits)
+            ctx.stream_wait()
             idx = torch.tensor(live, dtype=torch.int64, device=parts.device)
             parts.view(k, G1_PARTIAL_BYTES).index_copy_(0, idx, dense.view(len(live), G1_PARTIAL_BYTES))
+        ctx.stream_wait()  # the partials are written before the all-gather reads them
         return parts
 
     def fold_fn(by_job, world, k_):
         out = torch.zeros(64 * k_, dtype=torch.uint8, device=by_job.device)
         keep.append(by_job)
+        ctx.wait_stream()  # the gathered partials (and their transpose) have landed
         ctx.fold_partials_many_dev(by_job.data_ptr(), world, k_, out.data_ptr())
+        ctx.stream_wait()
         return out
 
     with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
@@ -285,26 +300,28 @@ def gpu_bucket_sharded_msm(ctx, d_scalars, d_points, n_total, window_bits=0):
 
     def fill_fn(lo, hi):
         if hi > lo:
+            ctx.wait_stream()  # the inputs and the grid's allocation before the fill
             ctx.fill_buckets_dev(d_scalars.data_ptr(), d_points.data_ptr(), hi - lo, c, grid.data_ptr())
-            ctx.sync()  # the grid is in memory before the all-to-all reads it
+            ctx.stream_wait()  # the grid is written before the all-to-all reads it
         else:
             grid.zero_()
-            torch.cuda.current_stream().synchronize()
         return grid
 
     def add_fn(dst, src):
-        torch.cuda.current_stream().synchronize()  # the exchange has landed
+        ctx.wait_stream()  # the exchange has landed
         ctx.buckets_add_dev(dst.data_ptr(), src.data_ptr(), dst.numel() // G1_PARTIAL_BYTES)
+        ctx.stream_wait()
 
     def reduce_fn(buckets, w0, wcount):
-        torch.cuda.current_stream().synchronize()
+        ctx.wait_stream()
         ctx.buckets_reduce_dev(buckets.data_ptr(), c, w0, wcount, part.data_ptr())
-        ctx.sync()
+        ctx.stream_wait()
         return part
 
     def fold_fn(gathered, world):
-        torch.cuda.current_stream().synchronize()
+        ctx.wait_stream()
         ctx.fold_partials_dev(gathered.data_ptr(), world, out.data_ptr())
+        ctx.stream_wait()
         return out
 
     return BucketShardedMsm(windows, bpw, fill_fn, add_fn, reduce_fn, fold_fn, G1_PARTIAL_BYTES,
@@ -352,14 +369,15 @@ def gpu_sharded_ipa_decide(ctx, dk_shard, xi, u):
     out = torch.zeros(64, dtype=torch.uint8, device="cuda")
 
     def partial_fn(lo, hi, xi_):
+        ctx.wait_stream()
         ctx.ipa_commit_partial_dev(dk_shard, xi_, part.data_ptr())
-        ctx.sync()  # the partial is in memory before the all-gather reads it
+        ctx.stream_wait()  # the partial is written before the all-gather reads it
         return part
 
     def fold_fn(gathered, world):
-        torch.cuda.current_stream().synchronize()
+        ctx.wait_stream()
         ctx.fold_partials_dev(gathered.data_ptr(), world, out.data_ptr())
-        ctx.sync()
+        ctx.stream_wait()
         return out
 
     return ShardedIpaDecide(dk_shard.k, partial_fn, fold_fn, G1_PARTIAL_BYTES).run(xi, u)

@@ -12,9 +12,16 @@
 //   sparse matrix  (partial rounds) row * state summed across the lanes + column * broadcast(s0) + state 2^260: two
 //                  lane-wise products, one reduction
 //   constants      ride along as value * 2^260 in the accumulators of the product that precedes them
-// Operands of vpmadd52 must be below 2^52 per limb: every reduction ends in a carry pass; values stay below 4 r < 2^256
-// (r < 2^254, R = 2^260: a product of two such values reduces to below 1.3 r without a conditional subtraction), and the
-// canonical residue is taken once, when a challenge leaves the sponge.  Same values as `poseidon_permute` (the scalar
+// Operands of vpmadd52 must be below 2^52 per limb: every reduction ends in a carry pass.  Value bounds (r < 2^254,
+// R = 2^260: a product of two values below 2^260 / 2^3 reduces to below 1.3 r without a conditional subtraction):
+//   * AT PERMUTATION BOUNDARIES (what `fr_from_limbs` / `join52` may be given): below 4 r < 2^256;
+//   * INSIDE the partial rounds words 1 .. t-1 are NOT multiplied: they gain up to + r per round and are brought back
+//     only every eighth round, so they reach ~9.5 r -- above 2^256, below 2^260: the limbs stay below 2^52 and every
+//     vpmadd52 operand is legal, but such a mid-permutation state must never reach `join52`.  Lengthening
+//     the renormalisation period past 8 rounds needs this bound re-derived: 2^260 / r > 64, minus the 1.3 r + k r growth.
+//   The worst case (all-(r-1) states, both parameter sets) is pinned against the scalar schedule in
+//   tests/test_transcript.py::test_ifma_permutation_equals_the_scalar_schedule_and_the_oracle.
+// The canonical residue is taken once, when a challenge leaves the sponge.  Same values as `poseidon_permute` (the scalar
 // schedule it mirrors), word for word: tests/hosttest + tests/test_transcript.py pin one against the other.
 // Selected at run time (`available()`): the library is built without -mavx512*, these functions carry their own target.
 #pragma once
@@ -210,7 +217,8 @@ SNARKV_IFMA void dense(__m512i s[5], const V* cols, int t, const __m512i p[5], _
   reduce(a, p, np, s);
 }
 
-// state <- permutation(state); `state` holds the t words in lanes 0 .. t-1, limbs carried, values below 4 r
+// state <- permutation(state); `state` holds the t words in lanes 0 .. t-1, limbs carried, values below 4 r on entry AND on
+// exit (inside the partial rounds up to ~9.5 r < 2^260: header)
 inline SNARKV_IFMA_FN void permute(V& state_v, const Tables& T) {
   const int t = T.t, h = T.r_f / 2;
   __m512i p[5], s[5];

@@ -25,6 +25,9 @@ def load_library():
             "snarkv_pallas_ctx_create": (ctypes.c_int, [ctypes.c_int, vp, ctypes.POINTER(vp)]),
             "snarkv_pallas_ctx_destroy": (None, [vp]),
             "snarkv_pallas_ctx_sync": (ctypes.c_int, [vp]),
+            "snarkv_pallas_ctx_wait_stream": (ctypes.c_int, [vp, vp]),
+            "snarkv_pallas_stream_wait_ctx": (ctypes.c_int, [vp, vp]),
+            "snarkv_pallas_ctx_stream": (vp, [vp]),
             "snarkv_pallas_ctx_host_buffer": (ctypes.c_int, [vp, ctypes.c_int, sz, ctypes.POINTER(vp)]),
             "snarkv_pallas_last_error": (ctypes.c_char_p, []),
             "snarkv_pallas_version": (ctypes.c_char_p, []),
@@ -43,6 +46,12 @@ def load_library():
             fn.restype, fn.argtypes = res, args
         _LIB = lib
     return _LIB
+
+
+def _stream_handle(stream):
+    from ._lib import stream_handle
+
+    return stream_handle(stream)
 
 
 def _check(rc):
@@ -72,6 +81,15 @@ class PallasContext:
 
     def sync(self):
         _check(self._lib.snarkv_pallas_ctx_sync(self._h))
+
+    def wait_stream(self, stream=None):
+        """`snarkv_pallas_ctx_wait_stream`: the context's next work runs after everything queued on `stream` (a HIP stream
+        handle or a torch stream; None = torch's current stream)."""
+        _check(self._lib.snarkv_pallas_ctx_wait_stream(self._h, ctypes.c_void_p(_stream_handle(stream))))
+
+    def stream_wait(self, stream=None):
+        """`snarkv_pallas_stream_wait_ctx`: `stream`'s next work runs after everything this context has queued."""
+        _check(self._lib.snarkv_pallas_stream_wait_ctx(self._h, ctypes.c_void_p(_stream_handle(stream))))
 
     def msm_pippenger(self, scalars, points):
         """`util::msm::multi_scalar_multiplication` on pallas (msm.rs:308-343), affine bytes."""

@@ -23,6 +23,12 @@ class Context:
     def sample_points_dev(self, seed, n, d_out, first=0):
         ctypes.memmove(d_out, C.sample_points(seed, n, first=first), 64 * n)
 
+    def wait_stream(self, stream=None):  # `snarkv_ctx_wait_stream` / `snarkv_stream_wait_ctx`: nothing to order on the CPU
+        pass
+
+    def stream_wait(self, stream=None):
+        pass
+
     def sync(self):
         pass
 

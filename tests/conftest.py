@@ -14,6 +14,29 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Order of the test FILES under `-x`: the parity evidence first -- public known-answer vectors, the
+# reference-generated vectors when present, then the full-size / MSM / decider / PLONK parity tests -- and the edge,
+# robustness and multi-process tests last, so that one flaky edge test can no longer erase the KAT evidence of a round.
+# Files not listed keep their alphabetical place between the two groups.
+_FIRST = ["test_public_kats.py", "test_reference_vectors.py", "test_gpu_fullsize.py", "test_gpu_msm.py", "test_gpu_msm_many.py",
+          "test_gpu_montgomery.py", "test_gpu_decider.py", "test_gpu_host_mirror.py", "test_gpu_plonk.py", "test_gpu_config5.py",
+          "test_pallas_host_mirror.py", "test_gpu_pallas.py", "test_gpu_ipa.py", "test_gpu_poseidon.py"]
+_LAST = ["test_gpu_mgpu.py", "test_gpu_context_pool.py", "test_gpu_robustness.py", "test_gpu_stream_order.py",
+         "test_gpu_two_ranks.py", "test_gpu_bench_ranks.py"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(item):
+        name = os.path.basename(str(item.fspath))
+        if name in _FIRST:
+            return (0, _FIRST.index(name))
+        if name in _LAST:
+            return (2, _LAST.index(name))
+        return (1, 0)
+
+    items.sort(key=key)  # stable: the order inside a file, and of the unlisted files, is pytest's own
+
+
 def pytest_sessionstart(session):
     """The C-ABI libraries are build artefacts (git-ignored): in a tree where `__graft_entry__.build()` has not
     run yet, build them once (hipcc cross-compiles gfx950 without a GPU) instead of failing the symbol tests."""

@@ -4,13 +4,14 @@ with `--dry-run-doubles tests/bench_doubles.py` putting oracle-backed CPU double
 place of RCCL.  What is checked: the rendezvous, the disjoint shards, the batch submission + ONE all-gather + folds, the
 max-over-ranks timing, and the single JSON line rank 0 prints: metric / unit / n_gpus / steps / scaling / the aggregate value
 N * n * K / t / config labels -- and that the result it reports equals the single-process MSM over all ranks' points."""
-import json
 import os
 import subprocess
 import sys
+import tempfile
 
 import pytest
 
+import bench_line
 import coracle as C
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,11 +24,15 @@ def _run(world, extra, port, launcher=True):
                 "--master-port", str(port)]
     cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dry-run-doubles", os.path.join(ROOT, "tests", "bench_doubles.py")] + extra
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]  # ONE line, from rank 0 only
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as tmp:
+        env["SNARKV_BENCH_DETAILS"] = os.path.join(tmp, "details.json")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        # ONE compact line (< 4 KB, the last of stdout: what the driver parses); the tests below read the full record it names
+        compact, full = bench_line.parse(r.stdout)
+    assert compact["config"]["points_per_gpu"] == full["config"]["points_per_gpu"]
+    full["_compact"] = compact
+    return full
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -74,6 +79,7 @@ def test_plain_launch_without_torchrun_starts_the_ranks_itself():
     assert d["n_gpus"] == 2 and d["config"]["data_plane_ranks_seen"] == 2
     la = d["config"]["launch"]
     assert la["self_launched"] is True and la["attempts"][0]["rc"] == 0 and len(la["attempts"]) == 1
+    assert d["_compact"]["config"]["launch"] == {"self_launched": True, "attempts": 1, "how": la["attempts"][0]["how"][:80]}
     s, p = C.sample_scalars(0x5EED0001, 2 << log2n), C.sample_points(0x5EED0002, 2 << log2n)
     assert d["config"]["result"] == C.msm_pippenger(s, p, 4).hex()
 

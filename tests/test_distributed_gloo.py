@@ -141,6 +141,13 @@ class _HostCtx:
 
     def __init__(self):
         self.calls = []
+        self.trace = []  # the order of stream-ordering calls and launches ("wait", "launch", "release")
+
+    def wait_stream(self, stream=None):  # `snarkv_ctx_wait_stream`: nothing to order on the CPU, but the ORDER is checked
+        self.trace.append("wait")
+
+    def stream_wait(self, stream=None):  # `snarkv_stream_wait_ctx`
+        self.trace.append("release")
 
     def msm_pippenger_many_partial_dev(self, ds, dp, counts, out_ptr, window_bits=0):
         import ctypes
@@ -148,6 +155,7 @@ class _HostCtx:
         import coracle as C
 
         self.calls.append(list(counts))
+        self.trace.append("launch")
         if any(c <= 0 for c in counts):
             raise RuntimeError("SNARKV_ERR_EMPTY")
         for i, (s, p, c) in enumerate(zip(ds, dp, counts)):
@@ -159,6 +167,7 @@ class _HostCtx:
 
         import coracle as C
 
+        self.trace.append("launch")
         raw = ctypes.string_at(ptr, 144 * world * k)
         for i in range(k):
             acc = bytes(64)
@@ -189,6 +198,11 @@ def _product_batch_worker(rank, world, port, sizes, q):
         counts.append(hi - lo)
     ctx = _HostCtx()
     out = gpu_sharded_msm_batch(ctx, ds, dp, counts)
+    # every launch is bracketed: the context waits for torch's stream before it, torch's stream for the context after it
+    # (a context on a private stream races with torch's fills and with the collective otherwise: VERDICT r5)
+    for i, ev in enumerate(ctx.trace):
+        if ev == "launch":
+            assert ctx.trace[i - 1] == "wait" and "release" in ctx.trace[i + 1:i + 2], ctx.trace
     q.put((rank, bytes(out.numpy()), counts, ctx.calls))
     dist.barrier()
     dist.destroy_process_group()

@@ -4,30 +4,35 @@ every rank's RCCL probe fails -- two ranks of one communicator on one device is 
 over the gloo control plane, and the partials travel host-staged: the whole fallback path on hardware, with real kernels,
 checked against the C oracle.  In the same line: BASELINE config 4 in shape (2^k points IN TOTAL over the ranks), the
 one-GPU recompute of the sharded result, and the single-process `snarkv_mgpu_*` leg with two ranks."""
-import json
 import os
 import subprocess
 import sys
 
 import pytest
 
+import bench_line
 import coracle as C
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_plain_launch_two_ranks_one_device_measures_and_says_how():
+def test_plain_launch_two_ranks_one_device_measures_and_says_how(tmp_path):
     log2n, steps = 14, 3
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["SNARKV_BENCH_RCCL_PROBE_TIMEOUT"] = "120"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "1", "--log2n", str(log2n),
            "--strong-total-log2n", "16", "--no-cpu-baseline", "--no-secondary"]
+    env["SNARKV_BENCH_DETAILS"] = os.path.join(str(tmp_path), "details.json")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-4000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    compact, d = bench_line.parse(r.stdout)
+    # what the driver reads off the line itself on its first N > 1 contact (VERDICT r5 item 4)
+    assert compact["n_gpus"] == 2 and compact["config"]["launch"]["self_launched"] is True
+    assert compact["config"]["ranks_share_devices"] is True and compact["config"]["data_plane_ranks_seen"] == 2
+    assert "HOST-STAGED" in compact["config"]["transport"]["kind"] and "RCCL unavailable" in compact["config"]["transport"]["fallback_reason"]
+    assert compact["config4_strong"]["matches_one_gpu_single_call"] is True and compact["config"]["result_matches_one_gpu_recompute"] is True
+    assert compact["single_process_mgpu"]["job0_matches_one_gpu_recompute"] is True and compact["single_process_mgpu"]["peer_copy"] > 0
     n = 1 << log2n
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["points_per_gpu"] == n
     assert abs(d["value"] - 2 * n * steps / (d["ms_per_step"] * steps * 1e-3)) < 1e-6 * d["value"]
@@ -51,17 +56,18 @@ def test_plain_launch_two_ranks_one_device_measures_and_says_how():
     assert mg["job0_matches_one_gpu_recompute"] is True and mg["result_job0"] == cfg["result"]
 
 
-def test_rccl_data_plane_at_world_one_and_the_line_is_the_last_line():
+def test_rccl_data_plane_at_world_one_and_the_line_is_the_last_line(tmp_path):
     """`--force-dist` on one rank: gloo control plane + a REAL RCCL group for the partials (a communicator of one), and the
     JSON line is the LAST line of stdout -- RCCL prints a version banner through C stdio that used to land after it."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["MASTER_PORT"] = str(41000 + os.getpid() % 1000)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "3", "--warmup", "1", "--log2n", "14", "--no-cpu-baseline",
            "--no-secondary", "--no-strong", "--no-mgpu-leg"]
+    env["SNARKV_BENCH_DETAILS"] = os.path.join(str(tmp_path), "details.json")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    last = [ln for ln in r.stdout.splitlines() if ln.strip()][-1]
-    d = json.loads(last)
+    compact, d = bench_line.parse(r.stdout)  # (asserts that the line is the last one)
+    assert compact["config"]["rccl_ranks_seen"] == 1 and "RCCL all-gather" in compact["config"]["transport"]["kind"]
     tr = d["config"]["transport"]
     assert "RCCL all-gather" in tr["kind"] and tr["fallback_reason"] is None and d["config"]["rccl_ranks_seen"] == 1
     assert tr["rccl_env"]["NCCL_SOCKET_IFNAME"] == os.environ.get("NCCL_SOCKET_IFNAME", "lo")
@@ -69,7 +75,7 @@ def test_rccl_data_plane_at_world_one_and_the_line_is_the_last_line():
     assert d["config"]["result"] == C.msm_pippenger(C.sample_scalars(0x5EED0001, n), C.sample_points(0x5EED0002, n), 8).hex()
 
 
-def test_the_default_line_keeps_the_drivers_contract():
+def test_the_default_line_keeps_the_drivers_contract(tmp_path):
     """`python bench.py` (N = 1, small size here): ONE JSON line, the last of stdout, with every key the driver's contract
     names -- metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype /
     data / config.workload (no model keys), `roofline` {bound, achieved, peak, unit, frac, traffic} and `cpu_baseline`
@@ -77,11 +83,12 @@ def test_the_default_line_keeps_the_drivers_contract():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--log2n", "14", "--no-secondary", "--no-host-resident",
            "--strong-total-log2n", "16"]
+    env["SNARKV_BENCH_DETAILS"] = os.path.join(str(tmp_path), "details.json")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert sum(ln.startswith("{") for ln in lines) == 1 and lines[-1].startswith("{")
-    d = json.loads(lines[-1])
+    d, full = bench_line.parse(r.stdout)  # d = the LINE ITSELF: < 4 KB, last of stdout -- everything below is read off it
+    assert "stages_ms" in full and "stages_ms" not in d  # the tables live in the record the line names
+    assert d["config"]["single_msm_latency_ms"] > 0 and d["config"]["single_msm_points_per_s"] > 0 and "D2H" in d["config"]["timed_region"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k

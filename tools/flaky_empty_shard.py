@@ -1,0 +1,141 @@
+"""Root-cause experiment for the round-5 red test `test_empty_shard_contributes_the_identity`.
+
+The driver's fresh box returned b'~7\\x8c\\x809' ... b'6\\x9b\\xf1\\x16' where the oracle says b'`i\\x1e\\xa3' ... -- not any
+small-coefficient combination of the five one-point partials (checked on the CPU with the oracle), so some partial held
+bytes that are no group element.  This script runs, on the GPU box:
+
+  legacy      the round-5 wiring (kept HERE only, to reproduce): `torch.full(0xAB)` on torch's stream, then the context on
+              its private non-blocking stream writes the same 144 bytes with no ordering, `ctx.sync()`, torch copies
+  legacy+sync `torch.cuda.synchronize()` between the fill and the context's launch
+  legacy+zero the 0xAB fill replaced by zeros
+  events      the round-6 wiring (`snarkv_ctx_wait_stream` / `snarkv_stream_wait_ctx`, distributed.gpu_msm_partial)
+  each alone (ITERS times) and directly after `gpu_bucket_sharded_msm` (the test that preceded it in the suite), plus
+  legacy+ballast  a 256 MiB torch fill in front of the 0xAB fill: delays torch's stream the way a busy box would
+  poison r    the suspected outcome made deterministic: rank r's partial overwritten with 0xAB AFTER the context wrote
+              it; the fold's bytes are compared with the driver's failure bytes
+
+Also times the world-1 step (`gpu_sharded_msm`, n = 5) with host syncs (legacy) against events.
+Usage: python tools/flaky_empty_shard.py [iters] > profiles/r06_flaky_empty_shard.txt"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import torch  # noqa: E402
+
+import coracle as C  # noqa: E402
+import snark_verifier_amd as sv  # noqa: E402
+from snark_verifier_amd import distributed as D  # noqa: E402
+
+ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+FAIL_HEAD, FAIL_TAIL = bytes([0x7E, 0x37, 0x8C, 0x80, 0x39]), bytes([0x36, 0x9B, 0xF1, 0x16])
+n, world = 5, 8
+s, p = C.sample_scalars(0x91, n), C.sample_points(0x92, n)
+want = C.msm_pippenger(s, p, 1)
+ds = torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda()
+dp = torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda()
+ballast = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+torch.cuda.synchronize()
+
+
+def legacy_partial(ctx, part, d_s, d_p, count):
+    if count == 0:
+        part.zero_()
+        torch.cuda.current_stream().synchronize()
+        return
+    ctx.msm_pippenger_partial_dev(d_s.data_ptr(), d_p.data_ptr(), count, part.data_ptr(), 0)
+    ctx.sync()
+
+
+def one_round(ctx, variant, poison=-1):
+    gathered = torch.zeros(world, sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+    for r in range(world):
+        lo, hi = D.shard_range(n, r, world)
+        if variant == "legacy+ballast":
+            ballast.fill_(r)
+        fill = 0 if variant == "legacy+zero" else 0xAB
+        part = torch.full((sv.G1_PARTIAL_BYTES,), fill, dtype=torch.uint8, device="cuda")
+        if variant == "legacy+sync":
+            torch.cuda.synchronize()
+        if variant == "events":
+            D.gpu_msm_partial(ctx, part, ds[32 * lo:], dp[64 * lo:], hi - lo)
+        else:
+            legacy_partial(ctx, part, ds[32 * lo:], dp[64 * lo:], hi - lo)
+        if r == poison:
+            torch.cuda.synchronize()
+            part.fill_(0xAB)
+        gathered[r] = part
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.fold_partials_dev(gathered.data_ptr(), world, out.data_ptr())
+    ctx.sync()
+    return bytes(out.cpu().numpy())
+
+
+def bucket_sharded_first(ctx):
+    m = 30000
+    a = torch.empty(32 * m, dtype=torch.uint8, device="cuda")
+    b = torch.empty(64 * m, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.sample_scalars_dev(3, m, a.data_ptr())
+    ctx.sample_points_dev(4, m, b.data_ptr())
+    ctx.sync()
+    D.gpu_bucket_sharded_msm(ctx, a, b, m)
+    torch.cuda.synchronize()
+
+
+print("device:", torch.cuda.get_device_name(0), "| iters per variant:", ITERS)
+print("oracle bytes      :", want[:5].hex(), "...", want[-4:].hex())
+print("driver's r05 bytes:", FAIL_HEAD.hex(), "...", FAIL_TAIL.hex())
+ctx = sv.Context(0)
+print("\n-- each variant alone, %d rounds (8 emulated ranks, fold, compare with the oracle) --" % ITERS)
+for variant in ("legacy", "legacy+sync", "legacy+zero", "events", "legacy+ballast"):
+    bad, seen_driver = 0, 0
+    for it in range(ITERS):
+        got = one_round(ctx, variant)
+        bad += got != want
+        seen_driver += got[:5] == FAIL_HEAD and got[-4:] == FAIL_TAIL
+    print("%-15s mismatches %4d / %d   (equal to the driver's failure bytes: %d)" % (variant, bad, ITERS, seen_driver))
+print("\n-- directly after gpu_bucket_sharded_msm (the preceding test of the suite), 50 times each --")
+for variant in ("legacy", "events"):
+    bad = 0
+    for it in range(50):
+        bucket_sharded_first(ctx)
+        bad += one_round(ctx, variant) != want
+    print("%-15s mismatches %4d / 50" % (variant, bad))
+print("\n-- the suspected outcome made deterministic: rank r's partial = 0xAB bytes after the context wrote it --")
+for r in range(5):
+    got = one_round(ctx, "legacy+sync", poison=r)
+    print("poison rank %d -> %s ... %s   %s" % (r, got[:5].hex(), got[-4:].hex(),
+                                              "== the driver's failure bytes" if got[:5] == FAIL_HEAD and got[-4:] == FAIL_TAIL else ""))
+
+print("\n-- world-1 step latency, gpu_sharded_msm at n = 5 (host time per call, result left on the device) --")
+
+
+def legacy_sharded(ctx, d_s, d_p, cnt):
+    part = torch.zeros(sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    legacy_partial(ctx, part, d_s, d_p, cnt)
+    torch.cuda.current_stream().synchronize()
+    ctx.fold_partials_dev(part.data_ptr(), 1, out.data_ptr())
+    return out
+
+
+for name, fn in (("host syncs (r05)", lambda: legacy_sharded(ctx, ds, dp, n)), ("events (r06)", lambda: D.gpu_sharded_msm(ctx, ds, dp, n))):
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(300):
+        r = fn()
+    t_issue = (time.perf_counter() - t0) / 300
+    torch.cuda.synchronize()
+    ctx.sync()
+    t_all = (time.perf_counter() - t0) / 300
+    assert bytes(r.cpu().numpy()) == want
+    print("%-18s issue %.1f us / call, complete %.1f us / call" % (name, 1e6 * t_issue, 1e6 * t_all))
+ctx.close()
