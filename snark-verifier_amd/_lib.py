@@ -246,6 +246,7 @@ class MultiGpu:
         c._lib = self._lib
         c._h = ctypes.c_void_p(self._lib.snarkv_mgpu_ctx(self._h, rank))
         c._borrowed = True
+        c.ordered = False  # (a rank of the handle, possibly on another device than torch's current one: the caller orders)
         return c
 
     def msm_pippenger(self, scalars, points, variant=0):
@@ -400,14 +401,23 @@ class Context:
     `stream`: a HIP stream handle (e.g. `torch.cuda.Stream().cuda_stream`) the context
     launches on; None (or the NULL handle of torch's legacy default stream) makes the
     context create a private non-blocking stream.  `_dev` calls are asynchronous on
-    that stream: order them against other streams yourself (`ctx.sync()`, or run inside
+    that stream; against torch's stream they are ordered by events (`wait_stream` /
+    `stream_wait`, i.e. `snarkv_ctx_wait_stream` / `snarkv_stream_wait_ctx`) -- automatically
+    when `ordered` (the default for a private stream), by the caller otherwise (or run inside
     `torch.cuda.stream(s)` with the context created on `s.cuda_stream`)."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, ordered=None):
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         _check(self._lib.snarkv_ctx_create(int(device), ctypes.c_void_p(stream or 0), ctypes.byref(self._h)))
         self.device = int(device)
+        # `ordered`: bracket every `*_dev` method with wait_stream() / stream_wait() against torch's CURRENT stream, so
+        # that device tensors torch has just allocated / filled are ready when the context reads them and the outputs
+        # are ready when torch touches them -- no host synchronisation.  Default: on for a context on its PRIVATE
+        # stream (the caller did not think about streams: safe by default), off when the caller passed a stream (it
+        # manages the ordering, e.g. runs inside `torch.cuda.stream(s)`: bench.py).  Pass ordered=False to keep SEVERAL
+        # private-stream contexts concurrent from one host thread (ordering through torch's stream would chain them).
+        self.ordered = (not stream) if ordered is None else bool(ordered)
 
     def close(self):
         if self._h and not getattr(self, "_borrowed", False):
@@ -671,3 +681,24 @@ class Context:
         arr = (ctypes.c_float * SNARKV_PIP_STAGES)()
         _check(self._lib.snarkv_get_stage_timing(self._h, arr))
         return dict(zip(PIP_STAGE_NAMES, [float(x) for x in arr]))
+
+
+def _ordered_call(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def call(self, *a, **k):
+        if not getattr(self, "ordered", False):
+            return fn(self, *a, **k)
+        self.wait_stream()
+        try:
+            return fn(self, *a, **k)
+        finally:
+            self.stream_wait()
+
+    return call
+
+
+for _name, _fn in list(vars(Context).items()):
+    if _name.endswith("_dev") and callable(_fn):
+        setattr(Context, _name, _ordered_call(_fn))

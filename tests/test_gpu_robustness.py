@@ -273,6 +273,7 @@ def test_bucket_sharded_msm_world1_rccl_wiring():
         ctx.sample_scalars_dev(3, n, ds.data_ptr())
         ctx.sample_points_dev(4, n, dp.data_ptr())
         ref = torch.zeros(64, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # (the zero fill runs on torch's stream, the context on `st`)
         ctx.msm_pippenger_dev(ds.data_ptr(), dp.data_ptr(), n, ref.data_ptr())
         ctx.sync()
         out = gpu_bucket_sharded_msm(ctx, ds, dp, n)

@@ -36,7 +36,7 @@ def test_the_primitives_order_a_private_stream_against_torch():
 
     import snark_verifier_amd as sv
 
-    ctx = sv.Context(0)  # private non-blocking stream
+    ctx = sv.Context(0, ordered=False)  # private non-blocking stream, NO automatic ordering: the explicit calls below are the only one
     assert ctx.stream != 0 and ctx.stream != torch.cuda.current_stream().cuda_stream
     n = 2048
     sets = _sets(n, 3, 0x600)
@@ -91,7 +91,7 @@ def test_sharded_wiring_with_a_private_stream_and_slow_torch_fills(wiring):
     import snark_verifier_amd as sv
     from snark_verifier_amd import distributed as D
 
-    ctx = sv.Context(0)
+    ctx = sv.Context(0, ordered=False)  # the helpers' own wait_stream / stream_wait calls are the only ordering
     n = 1500
     sets = _sets(n, 3, 0x700)
     ds = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
@@ -132,7 +132,7 @@ def test_the_per_rank_step_with_poisoned_partials():
     import snark_verifier_amd as sv
     from snark_verifier_amd.distributed import gpu_msm_partial, shard_range
 
-    ctx = sv.Context(0)
+    ctx = sv.Context(0, ordered=False)
     n, world = 5, 8
     s, p = C.sample_scalars(0x91, n), C.sample_points(0x92, n)
     want = C.msm_pippenger(s, p, 1)
@@ -152,4 +152,35 @@ def test_the_per_rank_step_with_poisoned_partials():
     torch.cuda.synchronize()
     got = bytes(outs.cpu().numpy())
     assert all(got[64 * it:64 * it + 64] == want for it in range(ITERS))
+    ctx.close()
+
+
+def test_a_private_stream_context_is_ordered_by_default():
+    """`sv.Context(0)` (no stream passed) brackets every `*_dev` method with the two calls itself: the loop of the first
+    test without any explicit ordering; `ordered=False` / an explicit stream leave the ordering to the caller."""
+    import torch
+
+    import snark_verifier_amd as sv
+
+    ctx = sv.Context(0)
+    assert ctx.ordered is True and sv.Context(0, ordered=False).ordered is False
+    assert sv.Context(0, stream=torch.cuda.Stream().cuda_stream).ordered is False
+    n = 2048
+    sets = _sets(n, 3, 0x600)
+    ds = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+    dp = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+    ballast = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    kept = torch.zeros(ITERS, 64, dtype=torch.uint8, device="cuda")
+    for it in range(ITERS):
+        s, p, _ = sets[it % 3]
+        ballast.fill_(it & 0xFF)
+        ds.copy_(s)
+        dp.copy_(p)
+        out = torch.full((64,), 0xAB, dtype=torch.uint8, device="cuda")
+        ctx.msm_pippenger_dev(ds.data_ptr(), dp.data_ptr(), n, out.data_ptr())
+        kept[it] = out
+    torch.cuda.synchronize()
+    got = bytes(kept.cpu().numpy())
+    for it in range(ITERS):
+        assert got[64 * it:64 * it + 64] == sets[it % 3][2], it
     ctx.close()

@@ -8,7 +8,7 @@ for r in $(seq 1 $ROUNDS); do
     name=${spec%%=*}; vars=${spec#*=}
     env $(echo $vars | tr ',' ' ') python bench.py --steps ${STEPS:-40} --warmup 4 --no-cpu-baseline --no-secondary ${EXTRA:-} 2>/dev/null | python -c "
 import sys,json
-d=json.loads(sys.stdin.read()); st=d.get('stages_ms') or {}
+c=json.loads(sys.stdin.read().strip().splitlines()[-1]); d=json.load(open(c["details"])); st=d.get('stages_ms') or {}
 print('AB %-10s ms=%.4f lat=%.4f acc_in_batch=%.4f comb_in_batch=%.4f' % ('$name', d['ms_per_step'], d['config']['single_msm_latency_ms'] or 0, st.get('bucket_accumulate',0), st.get('bucket_combine',0)))"
   done
 done | tee /tmp/ab_env.txt

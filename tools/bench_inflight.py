@@ -9,7 +9,7 @@ ds = torch.empty(32 * n, dtype=torch.uint8, device="cuda"); dp = torch.empty(64 
 base.sample_scalars_dev(1, n, ds.data_ptr()); base.sample_points_dev(2, n, dp.data_ptr()); base.sync()
 res = []
 for K in (1, 2, 3, 4, 6, 8):
-    ctxs = [sv.Context(0) for _ in range(K)]
+    ctxs = [sv.Context(0, ordered=False) for _ in range(K)]
     outs = [torch.zeros(64, dtype=torch.uint8, device="cuda") for _ in range(K)]
     reps = 24
     for rep in range(2):

@@ -34,7 +34,7 @@ t0 = timed(single); ref = bytes(out.cpu().numpy())
 os.environ["SNARKV_PIP_SPLIT"] = "2"
 t1 = timed(single); assert bytes(out.cpu().numpy()) == ref
 os.environ["SNARKV_PIP_SPLIT"] = "0"
-cs = [sv.Context(0) for _ in range(lanes)]
+cs = [sv.Context(0, ordered=False) for _ in range(lanes)]
 chunk = 1 << 20
 nch = n // chunk
 parts = torch.zeros(nch * sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")

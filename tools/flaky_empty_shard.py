@@ -90,7 +90,7 @@ def bucket_sharded_first(ctx):
 print("device:", torch.cuda.get_device_name(0), "| iters per variant:", ITERS)
 print("oracle bytes      :", want[:5].hex(), "...", want[-4:].hex())
 print("driver's r05 bytes:", FAIL_HEAD.hex(), "...", FAIL_TAIL.hex())
-ctx = sv.Context(0)
+ctx = sv.Context(0, ordered=False)  # the r05 Context: a private stream and NO automatic ordering
 print("\n-- each variant alone, %d rounds (8 emulated ranks, fold, compare with the oracle) --" % ITERS)
 for variant in ("legacy", "legacy+sync", "legacy+zero", "events", "legacy+ballast"):
     bad, seen_driver = 0, 0
@@ -106,11 +106,103 @@ for variant in ("legacy", "events"):
         bucket_sharded_first(ctx)
         bad += one_round(ctx, variant) != want
     print("%-15s mismatches %4d / 50" % (variant, bad))
+print("\n-- directly after the LIFE of a 1-rank RCCL group (init_process_group(nccl) + gpu_bucket_sharded_msm + destroy: what")
+print("   test_bucket_sharded_msm_world1_rccl_wiring did right before the red test), 30 times each --")
+import torch.distributed as dist  # noqa: E402
+
+
+def rccl_group_life(ctx):
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        bucket_sharded_first(ctx)
+    finally:
+        dist.destroy_process_group()
+
+
+for variant in ("legacy", "events"):
+    bad, seen_driver, t_stall = 0, 0, []
+    for it in range(30):
+        rccl_group_life(ctx)
+        t0 = time.perf_counter()
+        torch.zeros(1, device="cuda")  # how long torch's stream is held up after the group's teardown
+        got = one_round(ctx, variant)
+        bad += got != want
+        seen_driver += got[:5] == FAIL_HEAD and got[-4:] == FAIL_TAIL
+    print("%-15s mismatches %4d / 30   (equal to the driver's failure bytes: %d)" % (variant, bad, seen_driver))
+
 print("\n-- the suspected outcome made deterministic: rank r's partial = 0xAB bytes after the context wrote it --")
 for r in range(5):
     got = one_round(ctx, "legacy+sync", poison=r)
     print("poison rank %d -> %s ... %s   %s" % (r, got[:5].hex(), got[-4:].hex(),
                                               "== the driver's failure bytes" if got[:5] == FAIL_HEAD and got[-4:] == FAIL_TAIL else ""))
+
+print("\n-- ... and for a PREFIX of ranks (torch's stream held up while the context ran ahead: its fills of ranks 0 .. k land late) --")
+
+
+def one_round_poison_set(ctx, ranks):
+    gathered = torch.zeros(world, sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+    for r in range(world):
+        lo, hi = D.shard_range(n, r, world)
+        part = torch.zeros(sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        legacy_partial(ctx, part, ds[32 * lo:], dp[64 * lo:], hi - lo)
+        torch.cuda.synchronize()
+        if r in ranks:
+            part.fill_(0xAB)
+        gathered[r] = part
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.fold_partials_dev(gathered.data_ptr(), world, out.data_ptr())
+    ctx.sync()
+    return bytes(out.cpu().numpy())
+
+
+import itertools  # noqa: E402
+
+hits = []
+for k in range(1, 6):
+    for ranks in itertools.combinations(range(5), k):
+        got = one_round_poison_set(ctx, set(ranks))
+        hit = got[:5] == FAIL_HEAD and got[-4:] == FAIL_TAIL
+        if hit:
+            hits.append(ranks)
+        if hit or ranks == tuple(range(k)):
+            print("poison ranks %-16s -> %s ... %s   %s" % (ranks, got[:5].hex(), got[-4:].hex(), "== the driver's failure bytes" if hit else ""))
+print("poison sets equal to the driver's failure bytes:", hits or "none of the 31 subsets of ranks 0..4")
+
+print("\n-- mechanism check: the loop of tests/test_gpu_stream_order.py WITHOUT any ordering (expected to FAIL: it shows the tests can) --")
+nn = 2048
+sets = []
+for i in range(3):
+    a, b = C.sample_scalars(0x600 + 2 * i, nn), C.sample_points(0x601 + 2 * i, nn)
+    sets.append((torch.frombuffer(bytearray(a), dtype=torch.uint8).cuda(), torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda(), C.msm_pippenger(a, b, 2)))
+d_s = torch.empty(32 * nn, dtype=torch.uint8, device="cuda")
+d_p = torch.empty(64 * nn, dtype=torch.uint8, device="cuda")
+for mode in ("no ordering", "wait_stream only", "both (the product wiring)"):
+    kept = torch.zeros(200, 64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for it in range(200):
+        a, b, _ = sets[it % 3]
+        ballast.fill_(it & 0xFF)
+        d_s.copy_(a)
+        d_p.copy_(b)
+        o = torch.full((64,), 0xAB, dtype=torch.uint8, device="cuda")
+        if mode != "no ordering":
+            ctx.wait_stream()
+        ctx.msm_pippenger_dev(d_s.data_ptr(), d_p.data_ptr(), nn, o.data_ptr())
+        if mode.startswith("both"):
+            ctx.stream_wait()
+        kept[it] = o
+    torch.cuda.synchronize()
+    ctx.sync()
+    g = bytes(kept.cpu().numpy())
+    print("%-28s mismatches %3d / 200" % (mode, sum(g[64 * it:64 * it + 64] != sets[it % 3][2] for it in range(200))))
 
 print("\n-- world-1 step latency, gpu_sharded_msm at n = 5 (host time per call, result left on the device) --")
 
