@@ -17,41 +17,49 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_plain_launch_two_ranks_one_device_measures_and_says_how(tmp_path):
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_plain_launch_n_ranks_one_device_measures_and_says_how(tmp_path, ranks):
+    """First-contact hardening for N > 1 without the hardware: N OS processes on the box's one device
+    through a PLAIN `python bench.py --gpus N`; the compact line is the last line, says how the partials travelled, the
+    N-GPU results equal the one-GPU recomputes, and the whole thing is done within two minutes."""
+    import time
+
     log2n, steps = 14, 3
+    t_start = time.perf_counter()
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["SNARKV_BENCH_RCCL_PROBE_TIMEOUT"] = "120"
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "1", "--log2n", str(log2n),
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", str(steps), "--warmup", "1", "--log2n", str(log2n),
            "--strong-total-log2n", "16", "--no-cpu-baseline", "--no-secondary"]
     env["SNARKV_BENCH_DETAILS"] = os.path.join(str(tmp_path), "details.json")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-4000:]
     compact, d = bench_line.parse(r.stdout)
     # what the driver reads off the line itself on its first N > 1 contact (VERDICT r5 item 4)
-    assert compact["n_gpus"] == 2 and compact["config"]["launch"]["self_launched"] is True
-    assert compact["config"]["ranks_share_devices"] is True and compact["config"]["data_plane_ranks_seen"] == 2
+    assert time.perf_counter() - t_start < 120.0, "the N-rank launch took %.0f s" % (time.perf_counter() - t_start)
+    assert compact["n_gpus"] == ranks and compact["config"]["launch"]["self_launched"] is True
+    assert compact["config"]["ranks_share_devices"] is True and compact["config"]["data_plane_ranks_seen"] == ranks
     assert "HOST-STAGED" in compact["config"]["transport"]["kind"] and "RCCL unavailable" in compact["config"]["transport"]["fallback_reason"]
     assert compact["config4_strong"]["matches_one_gpu_single_call"] is True and compact["config"]["result_matches_one_gpu_recompute"] is True
     assert compact["single_process_mgpu"]["job0_matches_one_gpu_recompute"] is True and compact["single_process_mgpu"]["peer_copy"] > 0
     n = 1 << log2n
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["points_per_gpu"] == n
-    assert abs(d["value"] - 2 * n * steps / (d["ms_per_step"] * steps * 1e-3)) < 1e-6 * d["value"]
+    assert d["n_gpus"] == ranks and d["scaling"] == "weak" and d["config"]["points_per_gpu"] == n
+    assert abs(d["value"] - ranks * n * steps / (d["ms_per_step"] * steps * 1e-3)) < 1e-6 * d["value"]
     cfg = d["config"]
     assert cfg["launch"]["self_launched"] is True and cfg["launch"]["attempts"][0]["rc"] == 0
     assert cfg["ranks_share_devices"] is True
     tr = cfg["transport"]
     assert "HOST-STAGED" in tr["kind"] and tr["requested"] == "auto" and "RCCL unavailable on rank(s)" in tr["fallback_reason"]
-    assert cfg["rccl_ranks_seen"] is None and cfg["data_plane_ranks_seen"] == 2
-    # the sharded result: the MSM over BOTH ranks' points, by the C oracle and by rank 0's own one-GPU recompute
-    s, p = C.sample_scalars(0x5EED0001, 2 * n), C.sample_points(0x5EED0002, 2 * n)
+    assert cfg["rccl_ranks_seen"] is None and cfg["data_plane_ranks_seen"] == ranks
+    # the sharded result: the MSM over ALL ranks' points, by the C oracle and by rank 0's own one-GPU recompute
+    s, p = C.sample_scalars(0x5EED0001, ranks * n), C.sample_points(0x5EED0002, ranks * n)
     assert cfg["result"] == C.msm_pippenger(s, p, 8).hex() and cfg["result_matches_one_gpu_recompute"] is True
     c4 = d["config4_strong"]
-    assert c4["n_gpus"] == 2 and c4["points_per_gpu"] == 1 << 15 and c4["matches_one_gpu_single_call"] is True
+    assert c4["n_gpus"] == ranks and c4["points_per_gpu"] == (1 << 16) // ranks and c4["matches_one_gpu_single_call"] is True
     s, p = C.sample_scalars(0x5EED0011, 1 << 16), C.sample_points(0x5EED0012, 1 << 16)
     assert c4["result"] == C.msm_pippenger(s, p, 8).hex()
-    # the single-process leg: two ranks on device 0 -- RCCL refuses the duplicate LOUDLY, peer copies deliver
+    # the single-process leg: N ranks on device 0 -- RCCL refuses the duplicate LOUDLY, peer copies deliver
     mg = d["single_process_mgpu"]
-    assert mg["ranks"] == 2 and mg["devices"] == [0, 0]
+    assert mg["ranks"] == ranks and mg["devices"] == [0] * ranks
     assert "distinct devices" in mg["rccl"]["error"] and mg["peer_copy"]["value"] > 0
     assert mg["job0_matches_one_gpu_recompute"] is True and mg["result_job0"] == cfg["result"]
 
@@ -102,3 +110,20 @@ def test_the_default_line_keeps_the_drivers_contract(tmp_path):
     assert all(k in cb for k in ("value", "unit", "cores", "kind", "sample")) and cb["kind"] == "port"
     assert cb["gpu_matches_on_sample"] is True and cb["sample_is_the_whole_workload"] is True
     assert d["config4_strong"]["matches_one_gpu_single_call"] is True and d["single_process_mgpu"]["job0_matches_one_gpu_recompute"] is True
+
+
+def test_single_process_mgpu_leg_with_eight_emulated_ranks():
+    """`snarkv_mgpu_*` with 8 ranks on the box's one device (what `bench.py --gpus 8` falls back to when no launcher
+    works, and the form a Rust caller reaches without one): RCCL refuses eight ranks on one device loudly, the peer-copy
+    transport delivers, job 0 equals the one-GPU recompute and the oracle."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mgpu-leg", "--gpus", "8", "--steps", "3", "--log2n", "12"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    mg = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert mg["ranks"] == 8 and mg["devices"] == [0] * 8 and "error" in mg["rccl"] and mg["peer_copy"]["value"] > 0
+    assert mg["job0_matches_one_gpu_recompute"] is True and mg["results_distinct_per_input_set"] is True
+    n = 8 << 12
+    assert mg["result_job0"] == C.msm_pippenger(C.sample_scalars(0x5EED0001, n), C.sample_points(0x5EED0002, n), 8).hex()

@@ -176,6 +176,43 @@ for k in range(1, 6):
             print("poison ranks %-16s -> %s ... %s   %s" % (ranks, got[:5].hex(), got[-4:].hex(), "== the driver's failure bytes" if hit else ""))
 print("poison sets equal to the driver's failure bytes:", hits or "none of the 31 subsets of ranks 0..4")
 
+print("\n-- (c) the per-rank partials themselves: rank r's 144 bytes folded alone == the oracle's s_r * P_r --")
+real = []
+for r in range(5):
+    part = torch.zeros(sv.G1_PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
+    o1 = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    legacy_partial(ctx, part, ds[32 * r:], dp[64 * r:], 1)
+    ctx.fold_partials_dev(part.data_ptr(), 1, o1.data_ptr())
+    ctx.sync()
+    real.append(bytes(part.cpu().numpy()))
+    ok = bytes(o1.cpu().numpy()) == C.msm_pippenger(s[32 * r:32 * r + 32], p[64 * r:64 * r + 64], 1)
+    print("rank %d: partial -> affine %s the oracle" % (r, "==" if ok else "!="))
+
+print("\n-- a fill landing BETWEEN the context's stores of one partial: every 4-byte split of one rank's 144 bytes, 0xAB on either side --")
+
+
+def fold_bytes(parts):
+    g = torch.frombuffer(bytearray(b"".join(parts)), dtype=torch.uint8).cuda()
+    o1 = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.fold_partials_dev(g.data_ptr(), len(parts), o1.data_ptr())
+    ctx.sync()
+    return bytes(o1.cpu().numpy())
+
+
+assert fold_bytes(real + [bytes(144)] * 3) == want
+split_hits, tried = [], 0
+for r in range(5):
+    for j in range(4, 144, 4):
+        for side in (0, 1):
+            mixed = (b"\xab" * j + real[r][j:]) if side == 0 else (real[r][:j] + b"\xab" * (144 - j))
+            got = fold_bytes(real[:r] + [mixed] + real[r + 1:] + [bytes(144)] * 3)
+            tried += 1
+            if got[:5] == FAIL_HEAD and got[-4:] == FAIL_TAIL:
+                split_hits.append((r, j, side))
+print("split overwrites equal to the driver's failure bytes: %s of %d tried" % (split_hits or "none", tried))
+
 print("\n-- mechanism check: the loop of tests/test_gpu_stream_order.py WITHOUT any ordering (expected to FAIL: it shows the tests can) --")
 nn = 2048
 sets = []
