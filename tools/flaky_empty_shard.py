@@ -213,6 +213,25 @@ for r in range(5):
                 split_hits.append((r, j, side))
 print("split overwrites equal to the driver's failure bytes: %s of %d tried" % (split_hits or "none", tried))
 
+print("\n-- every mixture: gathered[r] in {its own partial, any other rank's partial, 0xAB bytes, zeros} for r = 0..4 (7^5 folds in one launch) --")
+opts = real + [b"\xab" * 144, bytes(144)]
+combos = list(itertools.product(range(7), repeat=5))
+blob = bytearray()
+for cmb in combos:
+    for r, o in enumerate(cmb):
+        blob += opts[o]
+    blob += bytes(144) * 3
+gm = torch.frombuffer(blob, dtype=torch.uint8).cuda()
+om = torch.zeros(64 * len(combos), dtype=torch.uint8, device="cuda")
+torch.cuda.synchronize()
+ctx.fold_partials_many_dev(gm.data_ptr(), 8, len(combos), om.data_ptr())
+ctx.sync()
+res = bytes(om.cpu().numpy())
+mix_hits = [combos[i] for i in range(len(combos)) if res[64 * i:64 * i + 5] == FAIL_HEAD and res[64 * i + 60:64 * i + 64] == FAIL_TAIL]
+ident = combos.index((0, 1, 2, 3, 4))
+assert res[64 * ident:64 * ident + 64] == want
+print("mixtures equal to the driver's failure bytes: %s of %d (index: 0-4 = rank's partial, 5 = 0xAB, 6 = zeros)" % (mix_hits or "none", len(combos)))
+
 print("\n-- mechanism check: the loop of tests/test_gpu_stream_order.py WITHOUT any ordering (expected to FAIL: it shows the tests can) --")
 nn = 2048
 sets = []
