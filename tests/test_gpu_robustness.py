@@ -311,7 +311,17 @@ def test_empty_shard_contributes_the_identity(gpu_ctx):
     torch.cuda.synchronize()
     gpu_ctx.fold_partials_dev(gathered.data_ptr(), world, out.data_ptr())
     gpu_ctx.sync()
-    assert bytes(out.cpu().numpy()) == C.msm_pippenger(s, p, 1)
+    got, want = bytes(out.cpu().numpy()), C.msm_pippenger(s, p, 1)
+    if got != want:  # (round 5: red once on the driver's box, never reproduced -- profiles/r06_flaky_empty_shard.txt; say WHICH rank)
+        raw = bytes(gathered.cpu().numpy())
+        report = []
+        for r in range(world):
+            one = torch.zeros(64, dtype=torch.uint8, device="cuda")
+            gpu_ctx.fold_partials_dev(gathered[r].data_ptr(), 1, one.data_ptr())
+            lo, hi = shard_range(n, r, world)
+            exp_r = C.msm_pippenger(s[32 * lo:32 * hi], p[64 * lo:64 * hi], 1) if hi > lo else bytes(64)
+            report.append("rank %d %s: %s" % (r, "ok" if bytes(one.cpu().numpy()) == exp_r else "WRONG", raw[144 * r:144 * r + 144].hex()))
+        raise AssertionError("fold %s != oracle %s\n%s" % (got.hex(), want.hex(), "\n".join(report)))
 
 
 def test_inputs_in_pinned_host_buffers(gpu_ctx):
