@@ -104,3 +104,35 @@ def test_rccl_probe_failure_makes_every_rank_fall_back_to_gloo():
     assert d["config"]["data_plane_ranks_seen"] == 2 and d["config"]["rccl_ranks_seen"] is None
     s, p = C.sample_scalars(0x5EED0001, 256), C.sample_points(0x5EED0002, 256)
     assert d["config"]["result"] == C.msm_pippenger(s, p, 4).hex()
+
+
+def test_the_contract_line_never_outgrows_the_drivers_log_tail(tmp_path, capsys, monkeypatch):
+    """Round 5's line was 26.5 KB, the driver's log tail kept ~8 KB of it and the round went unmeasured.  `bench.emit`
+    prints an extract of the record under 4 KB and, should a future key push it over, drops the OPTIONAL parts (and says
+    so in the line) instead of failing or growing -- the contract keys, `roofline` and `cpu_baseline` stay."""
+    import importlib.util
+    import json
+
+    spec = importlib.util.spec_from_file_location("_bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("SNARKV_BENCH_DETAILS", str(tmp_path / "details.json"))
+    line = {"metric": "m", "value": 1.0, "unit": "points/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "data": "synthetic", "dtype": "x" * 5000,
+            "config": {"workload": "w", "points_per_gpu": 1, "notes": "n" * 20000},
+            "roofline": {"bound": "hbm", "kernel": "k", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "traffic": None, "note": "z" * 9000},
+            "cpu_baseline": {"value": 1.0, "unit": "points/s", "cores": 1, "kind": "port", "sample": "s" * 3000},
+            "stages_ms": {("stage%d" % i): 0.1 * i for i in range(300)},
+            "named_configs": {("config_%d" % i): 1.23456789 * i for i in range(400)}}
+    bench.emit(line)
+    out = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    assert len(out) == 1 and len(out[0]) < bench.LINE_LIMIT == 4096
+    c = json.loads(out[0])
+    assert c["dropped_for_size"] == ["named_configs"] and c["named_configs"] == "see details"
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in c
+    assert c["roofline"]["frac"] == 0.1 and "note" not in c["roofline"] and c["cpu_baseline"]["kind"] == "port"
+    assert len(c["cpu_baseline"]["sample"]) <= 260 and "notes" not in c["config"] and "stages_ms" not in c
+    with open(str(tmp_path / "details.json")) as f:
+        assert json.load(f) == line  # the whole record is in the file the line names
+    assert c["details"] == str(tmp_path / "details.json")

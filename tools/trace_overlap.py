@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--count", type=int, default=20, help="... to the end of the (N+count)-th k_final")
     ap.add_argument("--until-prepare", type=int, default=-1,
                     help="... or (batch mode: one k_final per batch) to the end of the last kernel started before the M-th k_prepare")
+    ap.add_argument("--gaps", type=float, default=0.0, help="also list every interval of at least this many us with NO kernel running")
+    ap.add_argument("--edges", type=int, default=0, help="also list the first / last N dispatches of the window (relative times)")
     a = ap.parse_args()
     files = [a.path] if os.path.isfile(a.path) else glob.glob(os.path.join(a.path, "**", "*kernel_trace.csv"), recursive=True)
     ev = []
@@ -66,6 +68,19 @@ def main():
                 only[running[0]] = only.get(running[0], 0) + dt
         live[n] = live.get(n, 0) + d
         prev = t
+    if a.gaps > 0:
+        cur_end, last_name = ev[0][0], "(window start)"
+        print("idle intervals >= %.0f us (offset from the window start, length, kernel that ended -> kernel that starts):" % a.gaps)
+        for s_, e_, n_ in ev:
+            if s_ - cur_end >= a.gaps * 1e3:
+                print("  +%9.1f us  %7.1f us   %s -> %s" % ((cur_end - t0) / 1e3, (s_ - cur_end) / 1e3, last_name, n_))
+            if e_ > cur_end:
+                cur_end, last_name = e_, n_
+    if a.edges > 0:
+        for label, part in (("first", ev[:a.edges]), ("last", ev[-a.edges:])):
+            print("%s %d dispatches (start, end in us from the window start):" % (label, len(part)))
+            for s_, e_, n_ in part:
+                print("  %9.1f %9.1f  %s" % ((s_ - t0) / 1e3, (e_ - t0) / 1e3, n_))
     wall = (t1 - t0) / 1e6
     print("steady-state window: %.3f ms, %d dispatches, %d %s" % (wall, len(ev), sum(1 for e in ev if e[2] == a.focus), a.focus))
     print("time with k %s resident: " % a.focus + "  ".join("%d: %.1f%%" % (k, 100 * v / (t1 - t0)) for k, v in sorted(hist.items())))
