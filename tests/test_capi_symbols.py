@@ -89,7 +89,9 @@ int main(void) {
   /* addresses only: no device call without a GPU */
   void* f[] = {(void*)snarkv_ctx_create, (void*)snarkv_g1_msm_pippenger_many_dev, (void*)bn254_g1_msm_batched,
                (void*)bn254_set_thread_flags, (void*)snarkv_kzg_decide_batch, (void*)snarkv_g1_msm_pippenger_many_mgpu_dev,
-               (void*)snarkv_host_aggregate};
+               (void*)snarkv_host_aggregate, (void*)snarkv_ctx_wait_stream, (void*)snarkv_stream_wait_ctx, (void*)snarkv_ctx_stream};
+  /* argument checks that need no device: a NULL context is SNARKV_ERR_ARG, never a crash */
+  if (snarkv_ctx_wait_stream(0, 0) != SNARKV_ERR_ARG || snarkv_stream_wait_ctx(0, 0) != SNARKV_ERR_ARG || snarkv_ctx_stream(0) != 0) return 3;
   printf("%s %d\\n", snarkv_version(), (int)(sizeof f / sizeof f[0]));
   return 0;
 }
@@ -99,4 +101,4 @@ int main(void) {
                         "-Wl,-rpath," + libdir, "-Wl,-rpath-link," + libdir + ":/opt/rocm/lib"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", "")))
-    assert r.returncode == 0 and r.stdout.split()[-1] == "7", r.stdout + r.stderr
+    assert r.returncode == 0 and r.stdout.split()[-1] == "10", r.stdout + r.stderr

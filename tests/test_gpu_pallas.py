@@ -216,3 +216,37 @@ def test_ipa_succinct_check_msms_on_the_device(pctx, on_pallas):
     s, pp = _pack([a for a, _ in lhs + rhs], [b for _, b in lhs + rhs])
     out = pctx.msm_batched(s, pp, [0, len(lhs), len(lhs) + len(rhs)])
     assert out[:64] != out[64:]
+
+
+def test_stream_ordering_primitives_on_the_pasta_library(pctx):
+    """`snarkv_pallas_ctx_wait_stream` / `snarkv_pallas_stream_wait_ctx`: the device-resident pallas MSM with inputs torch
+    has just written (behind a large fill) and the output copied away by torch at once, 60 times without a host sync."""
+    import torch
+
+    rng = random.Random(77)
+    n = 600
+    sets = []
+    for k in range(2):
+        sc = [rng.randrange(PA.R) for _ in range(n)]
+        pts = PA.sample_points(31 + k, n)
+        sb, pb = _pack(sc, pts)
+        sets.append((torch.frombuffer(bytearray(sb), dtype=torch.uint8).cuda(), torch.frombuffer(bytearray(pb), dtype=torch.uint8).cuda(),
+                     PA.g1_to_bytes(PA.g1_msm_pippenger(sc, pts))))
+    ds = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+    dp = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+    ballast = torch.empty(128 << 20, dtype=torch.uint8, device="cuda")
+    kept = torch.zeros(60, 64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for it in range(60):
+        s, p, _ = sets[it % 2]
+        ballast.fill_(it)
+        ds.copy_(s)
+        dp.copy_(p)
+        out = torch.full((64,), 0xAB, dtype=torch.uint8, device="cuda")
+        pctx.wait_stream()
+        pctx.msm_pippenger_dev(ds.data_ptr(), dp.data_ptr(), n, out.data_ptr())
+        pctx.stream_wait()
+        kept[it] = out
+    torch.cuda.synchronize()
+    got = bytes(kept.cpu().numpy())
+    assert all(got[64 * it:64 * it + 64] == sets[it % 2][2] for it in range(60))
