@@ -117,7 +117,7 @@ SNARKV_HD Fq29 fq29_norm(const Fq29& a) {
 // instruction costs the same issue slot (profiles/r01_ubench_isa_rates.txt).  So fq29_mul / fq29_mul2 /
 // fq29_sqr take their device bodies from gen_fq29_mul_asm.py: every column of the product scanning loop is
 // ONE chain of `v_mad_i64_i32` on the column accumulator (carry-out to VCC, dead), 2 276 instructions per
-// entry of k_accumulate.  Stepping stones, kept in DESIGN.md section 4: one asm statement per operand product
+// entry of k_accumulate.  Stepping stones (rounds 1-2, measured): one asm statement per operand product
 // (-12 %), one statement per product of either kind (slower again: the compiler pads consecutive
 // VCC-writing asm statements with s_nop), one statement per column (this form).
 // -DSNARKV_NO_SMAD_ASM keeps the plain C below (host builds always use it).  The pairing (decider.hip), a few
