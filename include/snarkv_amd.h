@@ -220,6 +220,11 @@ int bn254_set_flags(uint32_t flags);
  * value" (restore only what was returned with a value >= -1).  What a library that shares the process
  * with other bn254_* users needs (libsnarkv_host.so passes wire-form bytes whatever the application chose above). */
 int64_t bn254_set_thread_flags(int64_t flags);
+/* Releases what the context-free calls keep for the life of the process: the pool's contexts (streams + scratch), the
+ * cached deciding-key line tables, the pinned buffers (bn254_host_buffer) of the calling thread and of threads that have
+ * ended -- pointers handed out by bn254_host_buffer to THIS thread are invalid afterwards; buffers of other live threads
+ * stay theirs.  SNARKV_ERR_ARG while a context-free call is in flight.  Later bn254_* calls start over lazily. */
+int bn254_shutdown(void);
 uint32_t bn254_get_flags(void); /* what the calling thread's next bn254_* call will use */
 int bn254_default_contexts(int* created, int* cap); /* pool status: contexts created so far / the limit */
 int bn254_g1_msm_naive(const uint8_t* scalars32, const uint8_t* points64, size_t n, uint8_t out64[64]);

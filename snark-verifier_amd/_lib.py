@@ -58,6 +58,7 @@ _SIGNATURES = {
     "bn254_g1_decompress": (_int, [_cp, _sz, _vp, _vp]),
     "bn254_set_thread_flags": (ctypes.c_int64, [ctypes.c_int64]),
     "bn254_get_flags": (ctypes.c_uint32, []),
+    "bn254_shutdown": (_int, []),
     "bn254_default_contexts": (_int, [ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "snarkv_last_error": (_cp, []),
     "snarkv_version": (_cp, []),

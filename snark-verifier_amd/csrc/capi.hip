@@ -163,6 +163,17 @@ struct ThreadHostBufsRef {
 };
 static thread_local ThreadHostBufsRef tl_hb;
 
+// line tables of the last DK_CACHE deciding keys of bn254_kzg_decide[_batch] (file scope: bn254_shutdown releases them)
+enum { DK_CACHE = 4 };
+struct DkCacheEntry {
+  std::shared_ptr<snarkv_dk> dk;
+  uint8_t tag[321];
+  uint64_t used;
+};
+static std::mutex g_dk_cache_mu;
+static DkCacheEntry g_dk_cache[DK_CACHE];
+static uint64_t g_dk_tick = 0;
+
 }  // namespace snarkv
 
 using namespace snarkv;
@@ -932,15 +943,57 @@ int bn254_host_buffer(int slot, size_t bytes, void** out) {
       SNARKV_DEFAULT_LEASE(c);  // (a HIP device must exist; the allocation itself is not tied to a context)
       SNARKV_HIP(hipSetDevice(c->device));
     }
+    const size_t old_cap = hb->cap[slot];
     if (hb->buf[slot]) SNARKV_HIP(hipHostFree(hb->buf[slot]));
     hb->buf[slot] = nullptr;
     hb->cap[slot] = 0;
     // (no copy out of the old buffer can be queued: the context-free calls return after their result is on the host)
-    const size_t cap = bytes + bytes / 4 + 4096;
+    // geometric growth: hipHostFree / hipHostMalloc synchronise the whole device (other pool contexts are in flight), so a
+    // thread whose requests creep up must not reallocate on every call
+    const size_t cap = std::max(bytes + bytes / 4 + 4096, 2 * old_cap);
     SNARKV_HIP(hipHostMalloc(&hb->buf[slot], cap, hipHostMallocDefault));
     hb->cap[slot] = cap;
   }
   *out = hb->buf[slot];
+  return SNARKV_OK;
+}
+
+// Everything the context-free entry points keep for the life of the process, released: the pool's contexts (streams +
+// scratch), the deciding-key line tables, the pinned buffer sets of the calling thread and of threads that have ended.
+// Refused (SNARKV_ERR_ARG) while any context-free call is in flight.  The next bn254_* call starts over lazily.
+int bn254_shutdown(void) {
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    if (tl_depth > 0) {
+      set_last_error("bn254_shutdown: called from inside a context-free call");
+      return SNARKV_ERR_ARG;
+    }
+    for (char b : g_pool.busy)
+      if (b) {
+        set_last_error("bn254_shutdown: a context-free call is in flight on another thread");
+        return SNARKV_ERR_ARG;
+      }
+    for (snarkv_ctx* c : g_pool.ctx) snarkv_ctx_destroy(c);
+    g_pool.ctx.clear();
+    g_pool.busy.clear();
+  }
+  tl_slot = -1;
+  {
+    std::lock_guard<std::mutex> lk(g_dk_cache_mu);
+    for (auto& e : g_dk_cache) e.dk.reset();
+  }
+  std::vector<ThreadHostBufs*> sets;
+  {
+    std::lock_guard<std::mutex> lk(g_hb_mu);
+    sets.swap(g_hb_free);
+  }
+  if (tl_hb.p) sets.push_back(tl_hb.p), tl_hb.p = nullptr;
+  for (ThreadHostBufs* hb : sets) {
+    for (int i = 0; i < SNARKV_HOST_BUFFERS; ++i)
+      if (hb->buf[i]) (void)hipHostFree(hb->buf[i]);
+    delete hb;
+  }
+  (void)hipGetLastError();
   return SNARKV_OK;
 }
 
@@ -960,18 +1013,12 @@ int bn254_kzg_decide_batch(const uint8_t g1_64[64], const uint8_t g2_128[128], c
   // synchronisation) OUTSIDE it, so concurrent callers with other keys -- or the same key: the loser of the race drops
   // its copy -- never queue behind a build.  A replaced key's tables are freed when the last call using
   // them returns (shared_ptr).
-  enum { DK_CACHE = 4 };
-  struct Entry {
-    std::shared_ptr<snarkv_dk> dk;
-    uint8_t tag[321];
-    uint64_t used;
-  };
-  static std::mutex cache_mu;
-  static Entry cache[DK_CACHE];
-  static uint64_t tick = 0;
   uint8_t now[321];
   memcpy(now, g1_64, 64), memcpy(now + 64, g2_128, 128), memcpy(now + 192, s_g2_128, 128);
   now[320] = c->mont ? 1 : 0;
+  auto& cache_mu = g_dk_cache_mu;
+  auto& cache = g_dk_cache;
+  auto& tick = g_dk_tick;
   auto lookup = [&]() -> std::shared_ptr<snarkv_dk> {  // (under cache_mu)
     for (auto& e : cache)
       if (e.dk && memcmp(e.tag, now, sizeof now) == 0) {
@@ -992,7 +1039,7 @@ int bn254_kzg_decide_batch(const uint8_t g1_64[64], const uint8_t g2_128[128], c
     std::lock_guard<std::mutex> lk(cache_mu);
     dk = lookup();  // somebody else published the same key meanwhile: use theirs, `mine` is freed on return
     if (!dk) {
-      Entry* victim = &cache[0];
+      DkCacheEntry* victim = &cache[0];
       for (auto& e : cache) {  // a free slot, else the least recently used
         if (!e.dk) {
           victim = &e;

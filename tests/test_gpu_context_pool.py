@@ -125,6 +125,9 @@ def test_thread_flags_override_and_the_host_library_under_a_montgomery_default(g
         assert seen == [sv.SNARKV_FLAG_MONTGOMERY]  # other threads still see the process default
         assert lib.bn254_set_thread_flags(-1) == 0 and lib.bn254_get_flags() == sv.SNARKV_FLAG_MONTGOMERY
         assert lib.bn254_set_thread_flags(8) == sv.SNARKV_ERR_ARG  # unknown bit
+        # ... and an error code handed back as "the previous value" is refused, the override stays what it was
+        assert lib.bn254_set_thread_flags(0) == -1 and lib.bn254_set_thread_flags(sv.SNARKV_ERR_ARG) == sv.SNARKV_ERR_ARG
+        assert lib.bn254_get_flags() == 0 and lib.bn254_set_thread_flags(-1) == 0
     finally:
         lib.bn254_set_thread_flags(-1)
         assert lib.bn254_set_flags(0) == 0
@@ -221,3 +224,49 @@ print("RESULT", len(errs), a.value, b.value)
         assert r.returncode == 0, r.stderr[-3000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0].split()
         assert line[1] == "0" and int(line[2]) <= int(cap) and line[3] == cap, (cap, line)
+
+
+def test_shutdown_releases_the_pool_and_the_next_call_starts_over(golden_msm, golden_decider):
+    """`bn254_shutdown`: contexts, cached deciding-key tables and this thread's pinned buffers are released; the
+    context-free calls work again afterwards (lazily re-created); refused while a call is in flight on another thread."""
+    import snark_verifier_amd as sv
+
+    lib = sv.load_library()
+    c = next(c for c in golden_msm if len(c["scalars"]) // 64 >= 3)
+    s, p, exp = bytes.fromhex(c["scalars"]), bytes.fromhex(c["points"]), bytes.fromhex(c["expected"])
+    out = ctypes.create_string_buffer(64)
+    g = golden_decider
+    g1, g2, sg2 = bytes.fromhex(g["g1"]), bytes.fromhex(g["g2"]), bytes.fromhex(g["s_g2"])
+    case = g["cases"][0]
+    created, cap = ctypes.c_int(), ctypes.c_int()
+    ptr = ctypes.c_void_p()
+    for _ in range(2):
+        assert lib.bn254_g1_msm_naive(s, p, len(s) // 32, out) == 0 and out.raw == exp
+        assert lib.bn254_kzg_decide(g1, g2, sg2, bytes.fromhex(case["acc"])) == (1 if case["accept"] else 0)
+        assert lib.bn254_host_buffer(0, 1 << 16, ctypes.byref(ptr)) == 0 and ptr.value
+        lib.bn254_default_contexts(ctypes.byref(created), ctypes.byref(cap))
+        assert created.value >= 1
+        assert lib.bn254_shutdown() == 0
+        lib.bn254_default_contexts(ctypes.byref(created), ctypes.byref(cap))
+        assert created.value == 0
+    # a call in flight on another thread: refused, nothing released under it
+    n = 1 << 16
+    bs, bp = C.sample_scalars(5, n), C.sample_points(6, n)
+    want = C.msm_pippenger(bs, bp, 8)
+    res, refused = [], []
+
+    def long_call():
+        o = ctypes.create_string_buffer(64)
+        for _ in range(6):
+            rc = lib.bn254_g1_msm_pippenger(bs, bp, n, o)
+            res.append((rc, o.raw))
+
+    t = threading.Thread(target=long_call)
+    t.start()
+    while t.is_alive():
+        rc = lib.bn254_shutdown()
+        refused.append(rc)
+    t.join()
+    assert all(r == (0, want) for r in res) and sv.SNARKV_ERR_ARG in refused
+    assert lib.bn254_shutdown() == 0
+    assert lib.bn254_g1_msm_naive(s, p, len(s) // 32, out) == 0 and out.raw == exp
