@@ -79,7 +79,7 @@ int snarkv_ctx_sync(snarkv_ctx* ctx);
  *                            (inputs written by the caller's stream: call it BEFORE the `_dev` entry point);
  *   snarkv_stream_wait_ctx   everything the context has enqueued so far happens-before whatever `hip_stream` runs next
  *                            (outputs read by the caller's stream / a collective on it: call it AFTER the entry point).
- * `hip_stream` = a hipStream_t; NULL is the legacy default stream.  Both are an event record + hipStreamWaitEvent: they
+ * `hip_stream` = a hipStream_t OF THE CONTEXT'S DEVICE; NULL is the legacy default stream.  Both are an event record + hipStreamWaitEvent: they
  * return at once and cost no host synchronisation.  A context that was created ON `hip_stream` is ordered already: no-op.
  * `snarkv_ctx_stream` returns the hipStream_t the context enqueues on (for callers that bring their own events).     */
 int snarkv_ctx_wait_stream(snarkv_ctx* ctx, void* hip_stream);

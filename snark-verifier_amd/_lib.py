@@ -384,13 +384,14 @@ class PoseidonSpec:
             pass
 
 
-def stream_handle(stream):
+def stream_handle(stream, device=None):
     """hipStream_t as an int: a raw handle stays, a `torch.cuda.Stream` gives its `cuda_stream`, None = torch's CURRENT
-    stream (0 = the legacy default stream, which is what torch runs on unless told otherwise)."""
+    stream ON `device` (the context's: the ordering calls want a stream of the context's own device; 0 = the legacy
+    default stream, which is what torch runs on unless told otherwise)."""
     if stream is None:
         import torch
 
-        return int(torch.cuda.current_stream().cuda_stream)
+        return int(torch.cuda.current_stream(device).cuda_stream)
     if isinstance(stream, int):
         return stream
     return int(stream.cuda_stream)
@@ -438,13 +439,13 @@ class Context:
         """`snarkv_ctx_wait_stream`: whatever this context enqueues next runs after everything queued on `stream` so far
         (a HIP stream handle, a `torch.cuda.Stream`, or None = torch's current stream).  No host synchronisation.  Call it
         after filling inputs with torch and before the `_dev` entry point that reads them."""
-        _check(self._lib.snarkv_ctx_wait_stream(self._h, ctypes.c_void_p(stream_handle(stream))))
+        _check(self._lib.snarkv_ctx_wait_stream(self._h, ctypes.c_void_p(stream_handle(stream, getattr(self, "device", None)))))
 
     def stream_wait(self, stream=None):
         """`snarkv_stream_wait_ctx`: whatever `stream` runs next (torch ops, an RCCL collective) runs after everything this
         context has enqueued so far.  No host synchronisation.  Call it after the `_dev` entry point whose output the
         stream reads."""
-        _check(self._lib.snarkv_stream_wait_ctx(self._h, ctypes.c_void_p(stream_handle(stream))))
+        _check(self._lib.snarkv_stream_wait_ctx(self._h, ctypes.c_void_p(stream_handle(stream, getattr(self, "device", None)))))
 
     @property
     def stream(self):
