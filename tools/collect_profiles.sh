@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): every record the round's profiles/ directory keeps, written under gpurun_out/<tag>_*
 # (gpurun merges only gpurun_out/ back; copy what you want judged into profiles/).
-#   tools/collect_profiles.sh r05
+#   tools/collect_profiles.sh r06
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
