@@ -9,10 +9,13 @@
 #pragma once
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <iterator>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <tuple>
 #include <type_traits>
 
@@ -367,6 +370,212 @@ struct Aggregator {
     return R::Ok(std::move(out));
   }
 
+  // A large job on Poseidon transcripts is bounded by ONE host thread: the accumulation transcript is one sponge over
+  // 4 m field elements, m + 1 dependent permutations (1 024 proofs: 6.7 of 13.6 ms), and `aggregate` below starts it only
+  // when every proof has been read and every MSM has come back.  But the sponge absorbs the accumulators IN PROOF ORDER
+  // (`KzgAsProof::read`, accumulation.rs:122-128), so accumulator i can go in as soon as proofs 0..i are done.  The job as a
+  // three-stage pipeline over chunks of `chunk` proofs:
+  //   reader thread   read_proof + the host half of verify of chunk k on the host pool  (what succinct_verify_all does)
+  //   device thread   chunk k's 2 x chunk MSMs, one segmented launch
+  //   the caller      absorbs chunk k's accumulators into the accumulation transcript
+  // then r, the two KzgAs MSMs and (by the caller of this function) the pairing.  Same accumulators in the same order
+  // into the same sponge: the result is `aggregate`'s bit for bit, and so is the error of a batch with a bad proof (the
+  // first one in proof order: chunks are read in order and a failing chunk stops the pipeline behind it).
+  // Timings: `read_proofs`, `fr_algebra`, `msm_device` are the helper threads' BUSY times and run under `accumulate`
+  // (the caller's wall time from the first wait to the accumulated point); `total` is wall time.
+  static size_t pipeline_min() {
+    if (const char* e = getenv("SNARKV_HOST_PIPELINE_MIN")) return (size_t)std::max(0, atoi(e));  // 0: never
+    return 256;
+  }
+  static Result<KzgAccumulator> aggregate_pipelined(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
+                                                    const std::vector<std::vector<std::vector<Fr>>>& instances,
+                                                    const std::vector<std::vector<uint8_t>>& proofs, unsigned threads,
+                                                    AggregationTimings* tm) {
+    using R = Result<KzgAccumulator>;
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const size_t n = proofs.size();
+    if (n == 0 || instances.size() != n) return R::Err(Error{Error::InvalidInstances, "one instance set per proof"});
+    size_t chunk = 128;  // 2 proofs per pool thread; 3 072 MSM terms: packed inline by the device thread (no second pool job)
+    if (const char* e = getenv("SNARKV_HOST_PIPELINE_CHUNK")) chunk = (size_t)std::max(1, atoi(e));  // tuning knob
+    // chunk boundaries: the FIRST chunk is half a chunk -- the sponge, which bounds the job, idles until the first
+    // accumulators arrive (a read pass + a launch), and both are shorter for fewer proofs
+    std::vector<size_t> cut(1, 0);
+    if (n > 2 * chunk && chunk >= 2 && !getenv("SNARKV_HOST_PIPELINE_NO_RAMP")) cut.push_back(chunk / 2);
+    while (cut.back() < n) cut.push_back(std::min(n, cut.back() + chunk));
+    const size_t K = cut.size() - 1;
+    auto t0 = clk::now();
+    PointHints hints;
+    {
+      size_t min_batch = 32;
+      if (const char* e = getenv("SNARKV_HOST_HINT_MIN")) min_batch = (size_t)std::max(2, atoi(e));
+      if (n >= min_batch) decompress_hints(svk, pr, instances, proofs, threads, hints);
+    }
+    std::vector<PlonkProof<MOS>> pfs(n);
+    std::vector<Error> errs(n);
+    std::vector<typename SV::Pairs> jobs(2 * n);
+    std::vector<std::vector<KzgAccumulator>> out(n);
+    // device threads: chunk k goes to thread k % D.  A chunk's launch is a latency chain (0.75 ms for 128 proofs against
+    // 1.25 for all 1 024), so ONE thread issuing them back to back is as slow as the sponge (8 x 0.75 ms against 6.4) and
+    // every hiccup of it starves the absorber; two keep two launches in flight on their own default contexts.
+    size_t D = 2;
+    if (const char* e = getenv("SNARKV_HOST_PIPELINE_DEVICE_THREADS")) D = (size_t)std::max(1, std::min(8, atoi(e)));
+    D = std::min(D, K);
+    std::atomic<size_t> read_done{0};
+    std::vector<std::atomic<size_t>> msm_ready(K);  // 1 = chunk k's accumulators are in `out`
+    for (auto& f : msm_ready) f.store(0, std::memory_order_relaxed);
+    std::atomic<bool> stop{false};
+    std::vector<std::exception_ptr> thrown(1 + D);
+    double busy_read = 0, busy_algebra = 0;  // written by the reader, read after the join
+    std::vector<double> busy_msm(D, 0.0);    // one per device thread
+    // Hand-overs between the stages: a short spin (the next chunk is usually microseconds away), then a sleep on the
+    // pipeline's condition variable -- a helper that spun through its whole wait would burn a CPU for the length of the
+    // job, and under a container's CPU quota that is time taken from the threads that do the work.
+    std::mutex pmu;
+    std::condition_variable pcv;
+    auto publish = [&](std::atomic<size_t>& counter, size_t v) {
+      {
+        std::lock_guard<std::mutex> lk(pmu);
+        counter.store(v, std::memory_order_release);
+      }
+      pcv.notify_all();
+    };
+    auto halt = [&] {
+      {
+        std::lock_guard<std::mutex> lk(pmu);
+        stop.store(true, std::memory_order_release);
+      }
+      pcv.notify_all();
+    };
+    auto wait_for = [&](std::atomic<size_t>& counter, size_t k) {  // counter > k (chunk k published), or the pipeline stopped
+      for (unsigned spins = 0; spins < 400; ++spins) {
+        if (counter.load(std::memory_order_acquire) > k) return true;
+        if (stop.load(std::memory_order_acquire)) return counter.load(std::memory_order_acquire) > k;
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+      }
+      std::unique_lock<std::mutex> lk(pmu);
+      pcv.wait(lk, [&] { return counter.load(std::memory_order_acquire) > k || stop.load(std::memory_order_acquire); });
+      return counter.load(std::memory_order_acquire) > k;
+    };
+    std::thread reader([&] {
+      try {
+        std::vector<double> t_read(n, 0.0);
+        for (size_t k = 0; k < K && !stop.load(std::memory_order_acquire); ++k) {
+          const size_t lo = cut[k], hi = cut[k + 1];
+          auto a = clk::now();
+          parallel_for(hi - lo, threads, [&](size_t j) {
+            const size_t i = lo + j;
+            auto b = clk::now();
+            TR t(proofs[i]);
+            if (hints.any() && hints.row[i] != (size_t)-1)
+              t.set_point_hints(&hints.pts[64 * hints.P * hints.row[i]], &hints.ok[hints.P * hints.row[i]], hints.P);
+            auto pf = SV::read_proof(svk, pr, instances[i], t);
+            if (!pf.ok()) {
+              errs[i] = pf.err;
+              return;
+            }
+            pfs[i] = std::move(*pf.value);
+            t_read[i] = ms(b, clk::now());
+            auto p2 = SV::msm_pairs(svk, pr, instances[i], pfs[i]);
+            if (!p2.ok()) {
+              errs[i] = p2.err;
+              return;
+            }
+            jobs[2 * i] = std::move(p2.value->first);
+            jobs[2 * i + 1] = std::move(p2.value->second);
+          }, 1);
+          const double wall = ms(a, clk::now());
+          double rs = 0;
+          for (size_t i = lo; i < hi; ++i) rs += t_read[i];
+          const unsigned used = std::max(1u, std::min<unsigned>(threads, (unsigned)(hi - lo)));
+          const double frac = std::min(1.0, std::max(0.0, (rs / used) / std::max(wall, 1e-9)));
+          busy_read += wall * frac;
+          busy_algebra += wall * (1.0 - frac);
+          bool bad = false;
+          for (size_t i = lo; i < hi && !bad; ++i) bad = !errs[i].ok();
+          if (bad) {
+            halt();
+            break;
+          }
+          publish(read_done, k + 1);
+        }
+      } catch (...) {
+        thrown[0] = std::current_exception();
+        halt();
+      }
+    });
+    std::vector<std::thread> device;
+    for (size_t d = 0; d < D; ++d)
+      device.emplace_back([&, d] {
+        try {
+          for (size_t k = d; k < K; k += D) {
+            if (!wait_for(read_done, k)) break;
+            const size_t lo = cut[k], hi = cut[k + 1];
+            auto a = clk::now();
+            std::vector<typename SV::Pairs> part(std::make_move_iterator(jobs.begin() + 2 * lo), std::make_move_iterator(jobs.begin() + 2 * hi));
+            auto pts = L::multi_scalar_multiplication_batch(part);
+            for (size_t i = lo; i < hi; ++i) {
+              out[i].push_back(KzgAccumulator{pts[2 * (i - lo)], pts[2 * (i - lo) + 1]});
+              out[i].insert(out[i].end(), pfs[i].old_accumulators.begin(), pfs[i].old_accumulators.end());
+            }
+            busy_msm[d] += ms(a, clk::now());
+            publish(msm_ready[k], 1);
+          }
+        } catch (...) {
+          thrown[1 + d] = std::current_exception();
+          halt();
+        }
+      });
+    // the caller: `KzgAs::create_proof` without a blind (accumulation.rs:148-197), its absorbs fed chunk by chunk
+    auto t1 = clk::now();
+    AsTR at;
+    at.sponge().set_eager(true);  // the permutations run as the accumulators arrive, not inside the squeeze (transcript.hpp)
+    std::vector<KzgAccumulator> accs;
+    accs.reserve(n);
+    Error absorb_err;
+    std::exception_ptr thrown_here;
+    try {
+      for (size_t k = 0; k < K && absorb_err.ok(); ++k) {
+        if (!wait_for(msm_ready[k], 0)) break;
+        const size_t lo = cut[k], hi = cut[k + 1];
+        for (size_t i = lo; i < hi && absorb_err.ok(); ++i)
+          for (auto& a : out[i]) {
+            absorb_err = at.common_ec_point(a.lhs);
+            if (absorb_err.ok()) absorb_err = at.common_ec_point(a.rhs);
+            if (!absorb_err.ok()) break;
+            accs.push_back(a);
+          }
+      }
+    } catch (...) {
+      thrown_here = std::current_exception();
+    }
+    if (!absorb_err.ok() || thrown_here) halt();
+    reader.join();
+    for (auto& th : device) th.join();
+    for (auto& e : thrown)
+      if (e) std::rethrow_exception(e);
+    if (thrown_here) std::rethrow_exception(thrown_here);
+    for (auto& e : errs)
+      if (!e.ok()) return R::Err(e);
+    if (!absorb_err.ok()) return R::Err(absorb_err);
+    if (accs.empty()) throw Panic("create_proof with no instances (reference: assert!, accumulation.rs:159)");
+    KzgAsProof proof;
+    proof.r = at.squeeze_challenge();
+    auto acc = KzgAs<MOS>::verify(KzgAsVerifyingKey{}, accs, proof);
+    if (tm) {
+      auto t2 = clk::now();
+      tm->read_proofs = busy_read;
+      tm->fr_algebra = busy_algebra;
+      tm->msm_device = 0;
+      for (double b : busy_msm) tm->msm_device += b;
+      tm->accumulate = ms(t1, t2);
+      tm->total = ms(t0, t2);
+    }
+    return acc;
+  }
+
   // succinct-verify every proof and fold the accumulators into one
   static Result<KzgAccumulator> aggregate(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
                                           const std::vector<std::vector<std::vector<Fr>>>& instances,
@@ -374,6 +583,11 @@ struct Aggregator {
                                           AggregationTimings* tm = nullptr) {
     using R = Result<KzgAccumulator>;
     using clk = std::chrono::steady_clock;
+    if constexpr (std::is_same<TR, PoseidonTranscript>::value) {
+      const size_t pmin = pipeline_min();
+      if (pmin && proofs.size() >= pmin && threads > 1 && !HostPool::in_worker())
+        return aggregate_pipelined(svk, pr, instances, proofs, threads, tm);
+    }
     auto per_proof = succinct_verify_all(svk, pr, instances, proofs, threads, tm);
     if (!per_proof.ok()) return R::Err(per_proof.err);
     auto t3 = clk::now();

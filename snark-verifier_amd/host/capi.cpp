@@ -33,7 +33,15 @@ namespace {
 // (SNARKV_HOST_POSEIDON_DEVICE_MIN); with the AVX-512 IFMA sponge and the batch's points decompressed by the device as
 // hints the host reads 512 proofs in ~1.2 ms and 1 024 in 2.3 ms (device: 3.3 / 3.6 ms), level end to end at 1 024 with
 // the wider tail -- so there the host keeps batches below 1 024 (profiles/r05_host_poseidon.txt).
-static int poseidon_auto_route(size_t n) {
+// `pipelined`: the caller is `snarkv_host_aggregate` (ONE job), whose host route overlaps the reading, the MSMs and the
+// accumulation sponge from SNARKV_HOST_PIPELINE_MIN proofs on (host/aggregation.hpp `aggregate_pipelined`): the job is
+// then bounded by the one thread that absorbs the accumulators whatever hashed the proofs, and the device launch's 3 ms
+// would only delay its start -- as long as the pool has the threads to read a chunk faster than the sponge absorbs one.
+static int poseidon_auto_route(size_t n, bool pipelined = false) {
+  if (pipelined && HostPool::get().size() >= 32) {
+    const size_t pmin = Aggregator<Gwc19, PoseidonTranscript>::pipeline_min();
+    if (pmin && n >= pmin) return SNARKV_HOST_TRANSCRIPT_POSEIDON;
+  }
   const size_t device_min = poseidon_ifma::available() ? 2 * (size_t)SNARKV_HOST_POSEIDON_DEVICE_MIN : (size_t)SNARKV_HOST_POSEIDON_DEVICE_MIN;
   return n >= device_min ? SNARKV_HOST_TRANSCRIPT_POSEIDON_DEVICE : SNARKV_HOST_TRANSCRIPT_POSEIDON;
 }
@@ -216,7 +224,7 @@ int aggregate_mos(const PlonkProtocol& pr, const KzgDecidingKey& dk, int transcr
   wire::split_batch(instances, ilen, proofs, prlen, n, insts, pbytes);
   if (threads == 0) threads = HostPool::get().size();
   if (transcript == SNARKV_HOST_TRANSCRIPT_POSEIDON_AUTO)
-    transcript = poseidon_auto_route(n);
+    transcript = poseidon_auto_route(n, true);
   switch (transcript) {
     case SNARKV_HOST_TRANSCRIPT_EVM: return aggregate_run<MOS, EvmTranscript>(pr, dk, insts, pbytes, threads, timings_ms, acc_out);
     case SNARKV_HOST_TRANSCRIPT_POSEIDON: return aggregate_run<MOS, PoseidonTranscript>(pr, dk, insts, pbytes, threads, timings_ms, acc_out);

@@ -48,6 +48,16 @@ inline bool available() {
 
 constexpr uint64_t kMask52 = (1ull << 52) - 1;
 
+// A/B and test knob: 3 = the three-product partial round (default), 4 = the four-product form it replaced (the S-box's
+// three products, then the row's): same values word for word (tests/test_transcript.py runs both)
+inline int& partial_round_form() {
+  static int form = [] {
+    const char* e = getenv("SNARKV_HOST_IFMA_FORM");
+    return e && atoi(e) == 4 ? 4 : 3;
+  }();
+  return form;
+}
+
 // 8 values, limb k of all of them in l[k]
 struct alignas(64) V {
   uint64_t l[5][8];
@@ -126,6 +136,10 @@ struct Tables {
   std::vector<V> partial_k;  // lane 0 only
   std::vector<V> row;        // lane j = row[j]
   std::vector<V> col;        // lane 0 = 0, lane i >= 1 = col_hat[i - 1]
+  // the three-product form of a partial round (t <= 7: lane 7 is free for the square), see `permute`
+  std::vector<V> cvec;      // lane 0 = row[0], lane i >= 1 = col_hat[i - 1]
+  std::vector<V> ck;        // cvec * partial_k  (the round's constant, already multiplied through)
+  std::vector<V> row_rest;  // row with lane 0 cleared
 };
 
 struct Acc {  // ten 64-bit column accumulators per lane
@@ -156,18 +170,25 @@ SNARKV_IFMA void acc_mul(Acc& a, const __m512i x[5], const __m512i y[5]) {
 SNARKV_IFMA void acc_shifted(Acc& a, const __m512i x[5]) {
   for (int k = 0; k < 5; ++k) a.t[5 + k] = _mm512_add_epi64(a.t[5 + k], x[k]);
 }
-// Montgomery reduction of the column sums: out = a / 2^260 mod r (+ r at most), limbs carried below 2^52
+// Montgomery reduction of the column sums: out = a / 2^260 mod r (+ r at most), limbs carried below 2^52.
+// Step i clears column i with m = t_i np mod 2^52 and hands its carry up.  The next step's m waits for column i + 1, i.e.
+// for  t_{i+1} + lo(m p_1) + hi(m p_0) + carry(t_i + lo(m p_0)) : the two products go into SEPARATE registers and are
+// joined by additions (4 + 2 cycles after m instead of two chained fused multiply-adds and an addition, 8 + 2); the
+// remaining eight products of the step accumulate in place, off that path.  A sponge is one dependency chain of these.
 SNARKV_IFMA void reduce(Acc& a, const __m512i p[5], __m512i np, __m512i out[5]) {
   const __m512i zero = _mm512_setzero_si512(), mask = _mm512_set1_epi64((long long)kMask52);
 #pragma GCC unroll 5
   for (int i = 0; i < 5; ++i) {
     const __m512i m = _mm512_madd52lo_epu64(zero, a.t[i], np);  // (low 52 bits of t_i) * np mod 2^52
-#pragma GCC unroll 5
-    for (int j = 0; j < 5; ++j) {
-      a.t[i + j] = _mm512_madd52lo_epu64(a.t[i + j], m, p[j]);
+    const __m512i ti = _mm512_madd52lo_epu64(a.t[i], m, p[0]);  // 0 mod 2^52: only its carry lives on
+    const __m512i u = _mm512_madd52lo_epu64(a.t[i + 1], m, p[1]);
+    const __m512i v = _mm512_madd52hi_epu64(zero, m, p[0]);
+    a.t[i + 1] = _mm512_add_epi64(_mm512_add_epi64(u, v), _mm512_srli_epi64(ti, 52));
+#pragma GCC unroll 4
+    for (int j = 1; j < 5; ++j) {
+      if (j >= 2) a.t[i + j] = _mm512_madd52lo_epu64(a.t[i + j], m, p[j]);
       a.t[i + j + 1] = _mm512_madd52hi_epu64(a.t[i + j + 1], m, p[j]);
     }
-    a.t[i + 1] = _mm512_add_epi64(a.t[i + 1], _mm512_srli_epi64(a.t[i], 52));  // t_i is now 0 mod 2^52: its carry moves up
   }
   __m512i c = zero;
 #pragma GCC unroll 5
@@ -177,10 +198,32 @@ SNARKV_IFMA void reduce(Acc& a, const __m512i p[5], __m512i np, __m512i out[5]) 
     c = _mm512_srli_epi64(s, 52);
   }
 }
+// a.t = x * y, the low and the high halves of the 52 x 52 products summed in separate registers and joined at the end:
+// a column's dependent chain is 5 fused multiply-adds instead of 9-10 (a product ON a dependency chain -- the S-box --
+// is latency, not throughput)
+SNARKV_IFMA void acc_mul_fresh(Acc& a, const __m512i x[5], const __m512i y[5]) {
+  const __m512i zero = _mm512_setzero_si512();
+  __m512i lo[9], hi[9];
+#pragma GCC unroll 9
+  for (int c = 0; c < 9; ++c) {
+    bool first = true;
+#pragma GCC unroll 5
+    for (int i = 0; i < 5; ++i) {
+      const int j = c - i;
+      if (j < 0 || j > 4) continue;
+      lo[c] = _mm512_madd52lo_epu64(first ? zero : lo[c], x[i], y[j]);
+      hi[c] = _mm512_madd52hi_epu64(first ? zero : hi[c], x[i], y[j]);
+      first = false;
+    }
+  }
+  a.t[0] = lo[0];
+#pragma GCC unroll 8
+  for (int c = 1; c < 9; ++c) a.t[c] = _mm512_add_epi64(lo[c], hi[c - 1]);
+  a.t[9] = hi[8];
+}
 SNARKV_IFMA void mul(const __m512i x[5], const __m512i y[5], const __m512i p[5], __m512i np, __m512i out[5]) {
   Acc a;
-  acc_zero(a);
-  acc_mul(a, x, y);
+  acc_mul_fresh(a, x, y);
   reduce(a, p, np, out);
 }
 // x^5 + k (k may be null): the constant rides in the last product's accumulators
@@ -206,14 +249,16 @@ SNARKV_IFMA __m512i hsum_to_lane0(__m512i x) {
 
 // s <- M s for the matrix given by its columns: t lane-wise products, one reduction
 SNARKV_IFMA void dense(__m512i s[5], const V* cols, int t, const __m512i p[5], __m512i np) {
-  Acc a;
+  Acc a, b;  // columns alternate between two sets of accumulators: half the dependent chain per register
   acc_zero(a);
+  acc_zero(b);
   for (int j = 0; j < t; ++j) {
-    __m512i c[5], b[5];
+    __m512i c[5], bc[5];
     load(cols[j], c);
-    bcast(s, j, b);
-    acc_mul(a, c, b);
+    bcast(s, j, bc);
+    acc_mul((j & 1) ? b : a, c, bc);
   }
+  for (int i = 0; i < 10; ++i) a.t[i] = _mm512_add_epi64(a.t[i], b.t[i]);
   reduce(a, p, np, s);
 }
 
@@ -244,6 +289,44 @@ inline SNARKV_IFMA_FN void permute(V& state_v, const Tables& T) {
     sbox(s, k, p, np, s);
     dense(s, (r + 1 < h ? T.mds_col : T.pre_sparse_col).data(), t, p, np);
   }
+  if (t <= 7 && partial_round_form() == 3) {
+    // A partial round is  x <- s_0^5 + k ;  s_0 <- row . s ;  s_i <- s_i + col_i x  (i >= 1): on a chain, the three
+    // products of the S-box and then the row's.  With c = (row_0, col_1 .. col_{t-1}) the new state is
+    //     c x^5  +  [ c k  +  (sum_{j >= 1} row_j s_j ,  s_1 .. s_{t-1}) ]        and   c x^5 = (c x) x^4 :
+    //   P1 = bcast(s_0) * (c | s_0 in lane 7)     lanes 0 .. t-1: c_i s_0, lane 7: s_0^2          product 1
+    //   x4 = bcast(P1[7])^2                                                                       product 2
+    //   s  = P1 * x4 + the bracket                 (the bracket does not depend on this round's S-box: off the chain)   product 3
+    // THREE dependent products per round instead of four, and 365 fused multiply-adds instead of 470.  Words 1 .. t-1
+    // now gain up to 2 r per round (c_i k rides along with s_i): they are brought back below 1.3 r every FOURTH round,
+    // by a product with 1 that the chain does not wait for (lane 0 is a fresh product anyway, below 3 r, and skips it),
+    // so the bound of the header holds as it stands: 1.3 r + 4 x 2 r < 9.5 r.  Lane 7 carries a by-product (s_0^6) that
+    // nothing reads; the final store clears it.
+    for (int r = 0; r < T.r_p; ++r) {
+      __m512i bx[5], y[5], c[5], p1[5], b2[5], x4[5], rr[5], ck[5];
+      bcast(s, 0, bx);
+      load(T.cvec[(size_t)r], c);
+      for (int i = 0; i < 5; ++i) y[i] = _mm512_mask_mov_epi64(c[i], 0x80, bx[i]);
+      mul(bx, y, p, np, p1);
+      bcast(p1, 7, b2);
+      mul(b2, b2, p, np, x4);
+      load(T.row_rest[(size_t)r], rr);
+      load(T.ck[(size_t)r], ck);
+      Acc d;  // sum_{j >= 1} row_j s_j, lane by lane (lane 0 of the row is cleared), then across the lanes into lane 0
+      acc_mul_fresh(d, rr, s);
+      Acc a;
+      acc_mul_fresh(a, p1, x4);
+      for (int i = 0; i < 5; ++i)
+        a.t[5 + i] = _mm512_add_epi64(a.t[5 + i], _mm512_add_epi64(ck[i], _mm512_maskz_mov_epi64((__mmask8)(live & ~1u), s[i])));
+      for (int i = 0; i < 10; ++i) a.t[i] = _mm512_add_epi64(a.t[i], hsum_to_lane0(d.t[i]));
+      reduce(a, p, np, s);
+      if ((r & 3) == 3) {
+        __m512i one[5], n[5];
+        load(T.one, one);
+        mul(s, one, p, np, n);
+        for (int i = 0; i < 5; ++i) s[i] = _mm512_mask_mov_epi64(n[i], 0x01, s[i]);
+      }
+    }
+  } else
   for (int r = 0; r < T.r_p; ++r) {
     __m512i k[5], sb[5], row[5], col[5], b0[5];
     load(T.partial_k[(size_t)r], k);

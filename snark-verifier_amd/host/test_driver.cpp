@@ -260,7 +260,8 @@ int hd_transcript_script(int kind, const uint8_t* script, size_t script_len, con
                          uint8_t* out, size_t out_cap, size_t* out_len) {
   return guarded([&] {
     EvmTranscript te(kind == 0 ? std::vector<uint8_t>(proof, proof + proof_len) : std::vector<uint8_t>());
-    PoseidonTranscript tp(kind == 1 ? std::vector<uint8_t>(proof, proof + proof_len) : std::vector<uint8_t>());
+    PoseidonTranscript tp(kind != 0 ? std::vector<uint8_t>(proof, proof + proof_len) : std::vector<uint8_t>());
+    if (kind == 2) tp.sponge().set_eager(true);  // kind 2: the Poseidon transcript with the eager sponge (same bytes as kind 1)
     Transcript& t = kind == 0 ? static_cast<Transcript&>(te) : static_cast<Transcript&>(tp);
     std::vector<uint8_t> o;
     size_t i = 0;
@@ -572,6 +573,18 @@ int hd_poseidon_permute2(int t, int r_f, int r_p, int plain, uint8_t* state) {
     return 0;
   });
 }
+// selects the partial-round form of the IFMA permutation (3 = default, 4 = the form it replaced); returns the previous one
+int hd_poseidon_ifma_form(int form) {
+#if defined(__x86_64__) && defined(__GNUC__)
+  int prev = poseidon_ifma::partial_round_form();
+  if (form == 3 || form == 4) poseidon_ifma::partial_round_form() = form;
+  return prev;
+#else
+  (void)form;
+  return 0;
+#endif
+}
+
 // the same permutation on the AVX-512 IFMA path (host/poseidon_ifma.hpp): 0 ok, 1 = this CPU has no IFMA (state untouched)
 int hd_poseidon_permute_ifma(int t, int r_f, int r_p, uint8_t* state) {
   return guarded([&] {

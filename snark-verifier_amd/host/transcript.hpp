@@ -705,6 +705,16 @@ inline const poseidon_ifma::Tables* poseidon_ifma_tables(int t, int r_f, int r_p
     pi::V c = pi::zero();
     for (int i = 1; i < t; ++i) pi::set_lane(c, i, o.sparse_col[(size_t)r][(size_t)i - 1]);
     T.col.push_back(c);
+    // the three-product form: c = (row_0, col_1 .. col_{t-1}), c k, the row without its first entry
+    pi::V cv = c, ckv = pi::zero(), rr = T.row.back();
+    const Fr& kr = o.partial_k[(size_t)r];
+    pi::set_lane(cv, 0, o.sparse_row[(size_t)r][0]);
+    pi::set_lane(ckv, 0, o.sparse_row[(size_t)r][0] * kr);
+    for (int i = 1; i < t; ++i) pi::set_lane(ckv, i, o.sparse_col[(size_t)r][(size_t)i - 1] * kr);
+    for (int k = 0; k < 5; ++k) rr.l[k][0] = 0;
+    T.cvec.push_back(cv);
+    T.ck.push_back(ckv);
+    T.row_rest.push_back(rr);
   }
   return &cache.emplace(key, std::move(T)).first->second;
 #else
@@ -752,7 +762,21 @@ class Poseidon {
     state_.assign((size_t)t, Fr::zero());
     state_[0] = w0;
   }
-  void update(const std::vector<Fr>& elements) { buf_.insert(buf_.end(), elements.begin(), elements.end()); }  // :145-147
+  // :145-147.  The reference only buffers here and runs every permutation inside `squeeze`.  A complete chunk of `rate`
+  // elements is absorbed the same way whenever it is absorbed (no padding word after a full-rate chunk, :61-74), so an
+  // EAGER sponge -- `set_eager(true)`: permute as soon as a chunk is complete -- leaves `squeeze` the partial chunk (or the
+  // empty permutation after an exact multiple: `buf_` is then empty, and `exact` below is decided by the same remainder)
+  // and returns the same challenge.  It is what lets a long absorb overlap the work that produces its input
+  // (aggregation.hpp: the accumulation transcript of a pipelined job).
+  void set_eager(bool on) { eager_ = on; }
+  void update(const std::vector<Fr>& elements) {
+    buf_.insert(buf_.end(), elements.begin(), elements.end());
+    if (eager_ && buf_.size() >= (size_t)rate_) {
+      size_t i = 0;
+      for (; i + (size_t)rate_ <= buf_.size(); i += (size_t)rate_) permutation(buf_.data() + i, (size_t)rate_);
+      buf_.erase(buf_.begin(), buf_.begin() + (ptrdiff_t)i);
+    }
+  }
   Fr squeeze() {                                                                                               // :151-164
     std::vector<Fr> buf;
     buf.swap(buf_);
@@ -796,6 +820,7 @@ class Poseidon {
 #endif
   std::vector<Fr> state_;
   std::vector<Fr> buf_;
+  bool eager_ = false;
 };
 
 namespace fq_host {

@@ -104,6 +104,81 @@ def test_1024_proofs_with_a_corrupted_one_reject(fxk, handlesk):
             assert e.code == H.ERR_TRANSCRIPT
 
 
+def _proof_offsets(blob, n):
+    offs, off = [], 0
+    for _ in range(n):
+        ln = int.from_bytes(blob[off:off + 4], "little")
+        offs.append((off + 4, ln))
+        off += 4 + ln
+    return offs
+
+
+def _outcome(call):
+    try:
+        ok, acc = call()
+        return ("ok", ok, acc)
+    except H.HostError as e:
+        return ("err", e.code, str(e))
+
+
+def test_pipelined_poseidon_job_is_the_unpipelined_job_bit_for_bit(monkeypatch):
+    """The pipelined form of a large Poseidon job (host/aggregation.hpp `aggregate_pipelined`: reading, MSMs and the
+    accumulation sponge overlapped chunk by chunk) against the same job with the pipeline switched off and against the
+    oracle's accumulator: ragged last chunks, one chunk, one proof per chunk-thread; and a bad proof in the first, a
+    middle and the last chunk ends the job with the unpipelined job's outcome (first error in proof order)."""
+    f = _load("poseidon")
+    hp, hdk = H.Protocol(f["protocol"]), H.DecidingKey(f["dk"])
+    n, tk = f["n"], H.TRANSCRIPT_POSEIDON
+    monkeypatch.setenv("SNARKV_HOST_PIPELINE_MIN", "0")  # never
+    ok0, acc0, tm0 = H.aggregate(hp, hdk, f["instances"], f["proofs"], n, f["mos"], tk, timings=True)
+    assert ok0 and acc0 == f["expected_acc"]
+    for chunk, pmin in (("128", "256"), ("100", "2"), ("1000", "2"), ("4096", "2"), ("37", "2")):
+        monkeypatch.setenv("SNARKV_HOST_PIPELINE_MIN", pmin)
+        monkeypatch.setenv("SNARKV_HOST_PIPELINE_CHUNK", chunk)
+        ok, acc, tm = H.aggregate(hp, hdk, f["instances"], f["proofs"], n, f["mos"], tk, timings=True)
+        assert ok and acc == acc0, chunk
+        # the phases of the pipelined job overlap: the helpers' busy times run under `accumulate`; total is wall time
+        assert tm["total"] > 0 and tm["accumulate"] <= tm["total"] and tm["read_proofs"] > 0 and tm["msm_device"] > 0
+    monkeypatch.setenv("SNARKV_HOST_PIPELINE_CHUNK", "128")
+    # a sub-batch (n < the fixture's 1 024: its own accumulator) and a batch below the threshold
+    offs = _proof_offsets(f["proofs"], n)
+    ioffs, off = [], 0
+    inst = f["instances"]
+    for _ in range(n):  # per proof: u32 columns, per column u32 m, m x Fr
+        start = off
+        cols = int.from_bytes(inst[off:off + 4], "little")
+        off += 4
+        for _c in range(cols):
+            m = int.from_bytes(inst[off:off + 4], "little")
+            off += 4 + 32 * m
+        ioffs.append((start, off))
+    for m in (300, 257):
+        sub_p, sub_i = f["proofs"][:offs[m][0] - 4], inst[:ioffs[m][0]]
+        monkeypatch.setenv("SNARKV_HOST_PIPELINE_MIN", "0")
+        a = _outcome(lambda: H.aggregate(hp, hdk, sub_i, sub_p, m, f["mos"], tk))
+        monkeypatch.setenv("SNARKV_HOST_PIPELINE_MIN", "256")
+        b = _outcome(lambda: H.aggregate(hp, hdk, sub_i, sub_p, m, f["mos"], tk))
+        assert a == b and a[0] == "ok" and a[1] is True, m
+    # failures: truncate-free corruptions at chosen proofs (a flipped evaluation bit -> reject or Error::Transcript; a
+    # broken compressed point -> Error::Transcript), one per chunk position, and two at once (the FIRST one decides)
+    for bad in ([5], [700], [1023], [900, 130]):
+        prb = bytearray(f["proofs"])
+        for j, i in enumerate(bad):
+            o, ln = offs[i]
+            if j % 2 == 0:
+                prb[o + ln - 200] ^= 4
+            else:
+                prb[o + 31] ^= 0x3F  # the flag / top bits of the first compressed point
+        outs = []
+        for pmin in ("0", "256"):
+            monkeypatch.setenv("SNARKV_HOST_PIPELINE_MIN", pmin)
+            outs.append(_outcome(lambda: H.aggregate(hp, hdk, f["instances"], bytes(prb), n, f["mos"], tk)))
+        assert outs[0] == outs[1], (bad, outs)
+        assert outs[0][0] == "err" or outs[0][1] is False, bad
+    hp.close()
+    hdk.close()
+
+
 def test_shplonk_shape_64_proofs_bdfg21_poseidon_every_route():
     """The SDK's default scheme: SHPLONK = KzgAs<Bn256, Bdfg21> on Poseidon transcripts (snark-verifier-sdk/src/lib.rs:41,
     src/halo2.rs:296-306): 64 proofs of the committed fixture.  Bdfg21 reads W' AFTER its last squeeze (bdfg21.rs:64-66), so

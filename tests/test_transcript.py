@@ -215,6 +215,38 @@ def test_poseidon_transcript_random_scripts_cpp_vs_oracle(H):
                 proof += T.g1_compress(rng.choice(pts)) if rng.random() < 0.9 else (7).to_bytes(32, "little")
         exp = gen.run_script(ops, proof, kind=1)
         assert run_cpp_kind(H, 1, gen.pack_script(ops), proof) == exp
+        assert run_cpp_kind(H, 2, gen.pack_script(ops), proof) == exp  # the eager sponge: same challenges, same stream
+
+
+def test_poseidon_eager_sponge_equals_the_buffered_one_on_long_absorbs(H):
+    """transcript.hpp `Poseidon::set_eager`: complete chunks of RATE elements are permuted as they arrive instead of inside
+    `squeeze` (what lets the accumulation transcript of a pipelined aggregation job run under the work that feeds it,
+    aggregation.hpp).  Every absorb count mod RATE before a squeeze, squeezes back to back, absorbs after a squeeze:
+    the same challenges as the buffered sponge (the reference's shape, poseidon.rs:145-164) and as the oracle."""
+    import importlib.util
+
+    _setup_poseidon(H)
+    spec = importlib.util.spec_from_file_location("gen_t", os.path.join(ROOT, "tests", "golden", "gen_golden_transcript.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    rng = random.Random(2026)
+    pts = [O.g1_mul(O.G1_GEN, rng.randrange(1, O.R)) for _ in range(4)]
+    for case in range(12):
+        ops = []
+        for seg in range(rng.randrange(1, 5)):
+            for _ in range(rng.choice([0, 1, 3, 4, 5, 8, 9, 17, 40])):
+                if rng.random() < 0.5:
+                    ops.append((2, rng.randrange(O.R)))
+                else:
+                    ops.append((3, rng.choice(pts)))
+            ops.append((1, None))
+            if rng.random() < 0.3:
+                ops.append((1, None))
+        script = gen.pack_script(ops)
+        buffered, eager = run_cpp_kind(H, 1, script, b""), run_cpp_kind(H, 2, script, b"")
+        assert buffered == eager and buffered[0] == 0 and len(buffered[1]) >= 32
+        if case < 3:
+            assert buffered == gen.run_script(ops, b"", kind=1)
 
 
 def test_compressed_point_roundtrip():
