@@ -10,15 +10,18 @@
 //   dense matrix   sum_j column_j * broadcast(state_j): t lane-wise products summed as 64-bit column accumulators, ONE
 //                  Montgomery reduction for the t x t products of a round
 //   sparse matrix  (partial rounds) row * state summed across the lanes + column * broadcast(s0) + state 2^260: two
-//                  lane-wise products, one reduction
+//                  lane-wise products, one reduction -- folded with the S-box into THREE dependent products per round
+//                  (`permute`: c x^5 = (c x) x^4 with c = (row_0, col_1 ..), everything else off the chain)
 //   constants      ride along as value * 2^260 in the accumulators of the product that precedes them
 // Operands of vpmadd52 must be below 2^52 per limb: every reduction ends in a carry pass.  Value bounds (r < 2^254,
 // R = 2^260: a product of two values below 2^260 / 2^3 reduces to below 1.3 r without a conditional subtraction):
 //   * AT PERMUTATION BOUNDARIES (what `fr_from_limbs` / `join52` may be given): below 4 r < 2^256;
-//   * INSIDE the partial rounds words 1 .. t-1 are NOT multiplied: they gain up to + r per round and are brought back
-//     only every eighth round, so they reach ~9.5 r -- above 2^256, below 2^260: the limbs stay below 2^52 and every
-//     vpmadd52 operand is legal, but such a mid-permutation state must never reach `join52`.  Lengthening
-//     the renormalisation period past 8 rounds needs this bound re-derived: 2^260 / r > 64, minus the 1.3 r + k r growth.
+//   * INSIDE the partial rounds words 1 .. t-1 are NOT multiplied: they gain up to + r per round (four-product form:
+//     brought back every eighth round) or + 2 r per round (three-product form, the default: the round constant rides
+//     along multiplied through; brought back every FOURTH round), so they reach ~9.5 r -- above 2^256, below 2^260:
+//     the limbs stay below 2^52 and every vpmadd52 operand is legal, but such a mid-permutation state must never
+//     reach `join52`.  Lengthening either period needs this bound re-derived: 2^260 / r > 64, minus the
+//     1.3 r + k r growth.
 //   The worst case (all-(r-1) states, both parameter sets) is pinned against the scalar schedule in
 //   tests/test_transcript.py::test_ifma_permutation_equals_the_scalar_schedule_and_the_oracle.
 // The canonical residue is taken once, when a challenge leaves the sponge.  Same values as `poseidon_permute` (the scalar

@@ -362,9 +362,15 @@ def test_ifma_permutation_equals_the_scalar_schedule_and_the_oracle(H):
         states += [[rng.randrange(O.R) for _ in range(t)] for _ in range(200)]
         for k, st in enumerate(states):
             a = ctypes.create_string_buffer(b"".join(O.fe_to_bytes(x) for x in st), 32 * t)
-            b = ctypes.create_string_buffer(a.raw, 32 * t)
-            assert H.hd_poseidon_permute(t, rf, rp, a) == 0 and H.hd_poseidon_permute_ifma(t, rf, rp, b) == 0
-            assert a.raw == b.raw, (t, k)
+            assert H.hd_poseidon_permute(t, rf, rp, a) == 0
+            # both forms of the partial round: the three-product form (default; words 1 .. t-1 renormalised every fourth
+            # round) and the four-product form it replaced (still the route of a state of eight words)
+            for form in (3, 4):
+                assert H.hd_poseidon_ifma_form(form) in (3, 4)
+                b = ctypes.create_string_buffer(b"".join(O.fe_to_bytes(x) for x in st), 32 * t)
+                assert H.hd_poseidon_permute_ifma(t, rf, rp, b) == 0
+                assert a.raw == b.raw, (t, k, form)
+            H.hd_poseidon_ifma_form(3)
             if k < 8:
                 got = [int.from_bytes(b.raw[32 * i:32 * i + 32], "little") for i in range(t)]
                 assert got == T.poseidon_permute(st, rf, rp)
