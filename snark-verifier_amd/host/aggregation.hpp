@@ -12,6 +12,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <iterator>
 #include <map>
 #include <mutex>
@@ -73,7 +74,8 @@ struct Aggregator {
   };
   static void decompress_hints(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
                                const std::vector<std::vector<std::vector<Fr>>>& instances,
-                               const std::vector<std::vector<uint8_t>>& proofs, unsigned threads, PointHints& h) {
+                               const std::vector<std::vector<uint8_t>>& proofs, unsigned threads, PointHints& h,
+                               bool use_pool = true) {  // false: the caller must not wait for the host pool (it is busy reading)
     const size_t n = proofs.size();
     const int T = 5, RATE = 4, R_F = 8, R_P = 60;
     h.row.assign(n, (size_t)-1);
@@ -91,9 +93,14 @@ struct Aggregator {
     std::vector<uint8_t> in(32 * P * who.size());
     h.pts.resize(64 * P * who.size());
     h.ok.resize(P * who.size());
-    parallel_for(who.size(), threads, [&](size_t k) {
+    auto gather = [&](size_t k) {
       for (size_t q = 0; q < P; ++q) memcpy(&in[32 * (k * P + q)], proofs[who[k]].data() + offs[q], 32);
-    }, 64);
+    };
+    if (use_pool) {
+      parallel_for(who.size(), threads, gather, 64);
+    } else {
+      for (size_t k = 0; k < who.size(); ++k) gather(k);
+    }
     DeviceScope dev;
     if (bn254_g1_decompress(in.data(), P * who.size(), h.pts.data(), h.ok.data()) != SNARKV_OK)
       throw std::runtime_error(std::string("bn254_g1_decompress: ") + snarkv_last_error());
@@ -371,16 +378,21 @@ struct Aggregator {
   }
 
   // A large job on Poseidon transcripts is bounded by ONE host thread: the accumulation transcript is one sponge over
-  // 4 m field elements, m + 1 dependent permutations (1 024 proofs: 6.7 of 13.6 ms), and `aggregate` below starts it only
-  // when every proof has been read and every MSM has come back.  But the sponge absorbs the accumulators IN PROOF ORDER
-  // (`KzgAsProof::read`, accumulation.rs:122-128), so accumulator i can go in as soon as proofs 0..i are done.  The job as a
-  // three-stage pipeline over chunks of `chunk` proofs:
-  //   reader thread   read_proof + the host half of verify of chunk k on the host pool  (what succinct_verify_all does)
-  //   device thread   chunk k's 2 x chunk MSMs, one segmented launch
-  //   the caller      absorbs chunk k's accumulators into the accumulation transcript
+  // 4 m field elements, m + 1 dependent permutations (1 024 proofs: 5.3 ms at 5.2 us each), and `aggregate` below starts
+  // it only when every proof has been read and every MSM has come back.  But the sponge absorbs the accumulators IN PROOF
+  // ORDER (`KzgAsProof::read`, accumulation.rs:122-128), so accumulator i can go in as soon as proofs 0..i are done.  The
+  // job as a three-stage pipeline over chunks of `chunk` proofs (the first one half a chunk):
+  //   reader thread    ONE pass of the host pool over all proofs (read_proof + the host half of verify, what
+  //                    succinct_verify_all does); the pool claims proofs in index order, so chunks complete in order, and
+  //                    the worker that finishes a chunk's last proof publishes the chunk
+  //   device threads   (two) chunk k's 2 x chunk MSMs, one segmented launch, on thread k mod 2
+  //   the caller       absorbs chunk k's accumulators into the accumulation transcript -- an EAGER sponge
+  //                    (transcript.hpp `Poseidon::set_eager`: the reference's sponge only buffers until the squeeze)
   // then r, the two KzgAs MSMs and (by the caller of this function) the pairing.  Same accumulators in the same order
   // into the same sponge: the result is `aggregate`'s bit for bit, and so is the error of a batch with a bad proof (the
-  // first one in proof order: chunks are read in order and a failing chunk stops the pipeline behind it).
+  // pass reads every proof whatever happens, and the first error in proof order is the one returned).
+  // 1 024 distinct proofs end to end: 10.8 ms (this route unpipelined; 12.0 with the proofs hashed on the device) -> 8.65 ms
+  // at LESS CPU time (160 against 170 CPU-ms per job): profiles/r06_ab_pipeline.txt.
   // Timings: `read_proofs`, `fr_algebra`, `msm_device` are the helper threads' BUSY times and run under `accumulate`
   // (the caller's wall time from the first wait to the accumulated point); `total` is wall time.
   static size_t pipeline_min() {
@@ -411,6 +423,9 @@ struct Aggregator {
       if (const char* e = getenv("SNARKV_HOST_HINT_MIN")) min_batch = (size_t)std::max(2, atoi(e));
       if (n >= min_batch) decompress_hints(svk, pr, instances, proofs, threads, hints);
     }
+    // (Measured and dropped: the hint launch on a thread of its own while the first proofs are read without hints, and a
+    // first chunk of a quarter chunk -- the first accumulators are bounded by the launch latency of a small MSM (~0.65 ms)
+    // either way, the early proofs pay 13 host square roots each, and the job came out level at +12 % CPU time.)
     std::vector<PlonkProof<MOS>> pfs(n);
     std::vector<Error> errs(n);
     std::vector<typename SV::Pairs> jobs(2 * n);
@@ -421,7 +436,6 @@ struct Aggregator {
     size_t D = 2;
     if (const char* e = getenv("SNARKV_HOST_PIPELINE_DEVICE_THREADS")) D = (size_t)std::max(1, std::min(8, atoi(e)));
     D = std::min(D, K);
-    std::atomic<size_t> read_done{0};
     std::vector<std::atomic<size_t>> msm_ready(K);  // 1 = chunk k's accumulators are in `out`
     for (auto& f : msm_ready) f.store(0, std::memory_order_relaxed);
     std::atomic<bool> stop{false};
@@ -459,48 +473,63 @@ struct Aggregator {
       pcv.wait(lk, [&] { return counter.load(std::memory_order_acquire) > k || stop.load(std::memory_order_acquire); });
       return counter.load(std::memory_order_acquire) > k;
     };
+    // The reader: ONE pass of the host pool over all the proofs.  Its workers claim proofs in index order, so the chunks
+    // complete (about) in order, and the worker that finishes a chunk's last proof publishes it -- no barrier between the
+    // chunks (nine short passes left most of the pool spinning at every one of them: +25 % CPU time per job, and under a
+    // container's CPU quota that is what freezes a process).  A bad proof stops the DEVICE side of the pipeline; the pass
+    // itself runs on, so that the error reported is the first one in proof order, as without the pipeline.
+    std::vector<uint32_t> chunk_of(n);
+    std::vector<std::atomic<size_t>> read_left(K), read_ready(K);
+    for (size_t k = 0; k < K; ++k) {
+      for (size_t i = cut[k]; i < cut[k + 1]; ++i) chunk_of[i] = (uint32_t)k;
+      read_left[k].store(cut[k + 1] - cut[k], std::memory_order_relaxed);
+      read_ready[k].store(0, std::memory_order_relaxed);
+    }
     std::thread reader([&] {
       try {
         std::vector<double> t_read(n, 0.0);
-        for (size_t k = 0; k < K && !stop.load(std::memory_order_acquire); ++k) {
-          const size_t lo = cut[k], hi = cut[k + 1];
-          auto a = clk::now();
-          parallel_for(hi - lo, threads, [&](size_t j) {
-            const size_t i = lo + j;
-            auto b = clk::now();
-            TR t(proofs[i]);
-            if (hints.any() && hints.row[i] != (size_t)-1)
-              t.set_point_hints(&hints.pts[64 * hints.P * hints.row[i]], &hints.ok[hints.P * hints.row[i]], hints.P);
-            auto pf = SV::read_proof(svk, pr, instances[i], t);
-            if (!pf.ok()) {
-              errs[i] = pf.err;
-              return;
+        auto a = clk::now();
+        parallel_for(n, threads, [&](size_t i) {
+          const size_t k = chunk_of[i];
+          bool good = false;
+          struct Done {  // whatever way the task ends: the chunk's count goes down, its last GOOD proof publishes it
+            std::function<void()> f;
+            ~Done() { f(); }
+          } done{[&] {
+            if (!good) halt();
+            if (read_left[k].fetch_sub(1, std::memory_order_acq_rel) == 1 && !stop.load(std::memory_order_acquire)) {
+              bool bad = false;
+              for (size_t q = cut[k]; q < cut[k + 1] && !bad; ++q) bad = !errs[q].ok();
+              if (!bad) publish(read_ready[k], 1);
             }
-            pfs[i] = std::move(*pf.value);
-            t_read[i] = ms(b, clk::now());
-            auto p2 = SV::msm_pairs(svk, pr, instances[i], pfs[i]);
-            if (!p2.ok()) {
-              errs[i] = p2.err;
-              return;
-            }
-            jobs[2 * i] = std::move(p2.value->first);
-            jobs[2 * i + 1] = std::move(p2.value->second);
-          }, 1);
-          const double wall = ms(a, clk::now());
-          double rs = 0;
-          for (size_t i = lo; i < hi; ++i) rs += t_read[i];
-          const unsigned used = std::max(1u, std::min<unsigned>(threads, (unsigned)(hi - lo)));
-          const double frac = std::min(1.0, std::max(0.0, (rs / used) / std::max(wall, 1e-9)));
-          busy_read += wall * frac;
-          busy_algebra += wall * (1.0 - frac);
-          bool bad = false;
-          for (size_t i = lo; i < hi && !bad; ++i) bad = !errs[i].ok();
-          if (bad) {
-            halt();
-            break;
+          }};
+          auto b = clk::now();
+          TR t(proofs[i]);
+          if (hints.any() && hints.row[i] != (size_t)-1)
+            t.set_point_hints(&hints.pts[64 * hints.P * hints.row[i]], &hints.ok[hints.P * hints.row[i]], hints.P);
+          auto pf = SV::read_proof(svk, pr, instances[i], t);
+          if (!pf.ok()) {
+            errs[i] = pf.err;
+            return;
           }
-          publish(read_done, k + 1);
-        }
+          pfs[i] = std::move(*pf.value);
+          t_read[i] = ms(b, clk::now());
+          auto p2 = SV::msm_pairs(svk, pr, instances[i], pfs[i]);
+          if (!p2.ok()) {
+            errs[i] = p2.err;
+            return;
+          }
+          jobs[2 * i] = std::move(p2.value->first);
+          jobs[2 * i + 1] = std::move(p2.value->second);
+          good = true;
+        }, 1);
+        const double wall = ms(a, clk::now());
+        double rs = 0;
+        for (size_t i = 0; i < n; ++i) rs += t_read[i];
+        const unsigned used = std::max(1u, std::min<unsigned>(threads, (unsigned)n));
+        const double frac = std::min(1.0, std::max(0.0, (rs / used) / std::max(wall, 1e-9)));
+        busy_read = wall * frac;
+        busy_algebra = wall * (1.0 - frac);
       } catch (...) {
         thrown[0] = std::current_exception();
         halt();
@@ -511,7 +540,7 @@ struct Aggregator {
       device.emplace_back([&, d] {
         try {
           for (size_t k = d; k < K; k += D) {
-            if (!wait_for(read_done, k)) break;
+            if (!wait_for(read_ready[k], 0)) break;
             const size_t lo = cut[k], hi = cut[k + 1];
             auto a = clk::now();
             std::vector<typename SV::Pairs> part(std::make_move_iterator(jobs.begin() + 2 * lo), std::make_move_iterator(jobs.begin() + 2 * hi));
@@ -536,9 +565,14 @@ struct Aggregator {
     accs.reserve(n);
     Error absorb_err;
     std::exception_ptr thrown_here;
+    const bool ptrace = getenv("SNARKV_HOST_PIPELINE_TRACE") != nullptr;  // dev aid: the caller's timeline on stderr
+    double t_first = 0, t_waited = 0;
     try {
       for (size_t k = 0; k < K && absorb_err.ok(); ++k) {
+        auto w0 = clk::now();
         if (!wait_for(msm_ready[k], 0)) break;
+        if (k == 0) t_first = ms(t0, clk::now());
+        else t_waited += ms(w0, clk::now());
         const size_t lo = cut[k], hi = cut[k + 1];
         for (size_t i = lo; i < hi && absorb_err.ok(); ++i)
           for (auto& a : out[i]) {
@@ -561,9 +595,14 @@ struct Aggregator {
       if (!e.ok()) return R::Err(e);
     if (!absorb_err.ok()) return R::Err(absorb_err);
     if (accs.empty()) throw Panic("create_proof with no instances (reference: assert!, accumulation.rs:159)");
+    auto t_abs = clk::now();
     KzgAsProof proof;
     proof.r = at.squeeze_challenge();
     auto acc = KzgAs<MOS>::verify(KzgAsVerifyingKey{}, accs, proof);
+    if (ptrace)
+      fprintf(stderr, "aggregate_pipelined: %zu proofs, %zu chunks: threads up %.3f, first accumulators %.3f, starved later %.3f, "
+                      "absorbed + joined %.3f, squeeze + KzgAs::verify %.3f ms\n", n, K, ms(t0, t1), t_first, t_waited, ms(t0, t_abs),
+              ms(t_abs, clk::now()));
     if (tm) {
       auto t2 = clk::now();
       tm->read_proofs = busy_read;
