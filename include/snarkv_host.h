@@ -58,7 +58,9 @@ extern "C" {
 /* the same transcript, hashed wherever the batch is faster: on the host threads below SNARKV_HOST_POSEIDON_DEVICE_MIN
  * proofs (the device launch is one latency chain of ~3 ms whatever the batch: measured 2 x slower than 64 host threads at
  * 64 proofs, 1.4 x faster at 1 024), on the device from there on; twice that threshold on a CPU with AVX-512 IFMA, whose
- * sponge is three times faster (host/poseidon_ifma.hpp).  Same bytes either way. */
+ * sponge is three times faster (host/poseidon_ifma.hpp).  ONE job (snarkv_host_aggregate) on a host with 32 or more pool
+ * threads stays on the host route at every size from SNARKV_HOST_PIPELINE_MIN proofs on: there the route is a pipeline
+ * bounded by the accumulation sponge alone (see snarkv_host_aggregate).  Same bytes either way. */
 #define SNARKV_HOST_TRANSCRIPT_POSEIDON_AUTO 3
 #define SNARKV_HOST_POSEIDON_DEVICE_MIN 512
 
@@ -120,7 +122,12 @@ int snarkv_host_kzg_decide_all(const snarkv_host_dk* dk, const uint8_t* accs128,
 
 /* succinct-verify N proofs, accumulate, decide.  host_threads: threads for the transcript / Fr front half (0 = all).
  * timings_ms (optional, 6 doubles): read_proofs, fr_algebra, msm_device, accumulate, decide, total.
- * acc_out (optional): the aggregated accumulator (also written on reject). */
+ * acc_out (optional): the aggregated accumulator (also written on reject).
+ * Poseidon proofs hashed on the host, SNARKV_HOST_PIPELINE_MIN (environment; default 256; 0 = never) proofs or more: the
+ * job runs as a pipeline -- proofs read on the host pool, their MSMs launched chunk by chunk, the accumulation transcript
+ * (one sponge over 4 n field elements: n + 1 dependent permutations on one thread) absorbing under both.  Same accumulator,
+ * same verdict, same error for a bad batch (the first bad proof in proof order) as the unpipelined job; read_proofs,
+ * fr_algebra and msm_device are then the helper threads' busy times (they run under `accumulate`), total is wall time. */
 int snarkv_host_aggregate(const snarkv_host_protocol* protocol, const snarkv_host_dk* dk, int mos, int transcript,
                           const uint8_t* instances, size_t instances_len, const uint8_t* proofs, size_t proofs_len,
                           uint32_t n, unsigned host_threads, double* timings_ms, uint8_t* acc_out);
