@@ -320,7 +320,10 @@ struct Aggregator {
     PointHints hints;
     constexpr bool kHostPoseidon = std::is_same<TR, PoseidonTranscript>::value;
     if constexpr (kHostPoseidon) {
-      size_t min_batch = 32;
+      // The launch costs ~0.35 ms whatever the batch and saves each proof 13 host square roots (0.13 ms): worth it from
+      // the third proof per thread on (64 proofs on 64 threads: 2.62 ms with hints, 2.43 without; 128: level; 256: -4 %
+      // and a fifth of the CPU time; profiles/r06_ab_pipeline.txt)
+      size_t min_batch = std::max<size_t>(32, 2 * (size_t)threads + 1);
       if (const char* e = getenv("SNARKV_HOST_HINT_MIN")) min_batch = (size_t)std::max(2, atoi(e));  // tuning / A-B knob
       if (n >= min_batch) decompress_hints(svk, pr, instances, proofs, threads, hints);
     }

@@ -487,7 +487,8 @@ def test_aggregate_many_equals_one_call_per_job():
 
 
 def test_host_hashed_poseidon_with_and_without_device_hints(monkeypatch):
-    """Round 5: batches of >= SNARKV_HOST_HINT_MIN (32) host-hashed Poseidon proofs get their compressed points decompressed by
+    """Round 5: batches of >= SNARKV_HOST_HINT_MIN (default: 32, and more than two proofs per host thread -- 8 threads here)
+    host-hashed Poseidon proofs get their compressed points decompressed by
     ONE device launch and offered to the transcripts as hints (checked against the bytes before use).  Same accumulator with
     the hints, without them (threshold raised), and for a batch with one proof of another length (no hint for that one,
     Error::Transcript from the host path as before)."""
