@@ -72,6 +72,15 @@ struct Aggregator {
     size_t P = 0;                  // points per proof
     bool any() const { return P != 0 && !ok.empty(); }
   };
+  // From how many host-hashed proofs on the device decodes the batch's points.  The launch costs ~0.35-0.55 ms whatever
+  // the batch and saves each proof 13 host square roots (0.13 ms in scalar code): worth it from the third proof per thread
+  // on.  On a CPU with AVX-512 IFMA a transcript decodes the points of one `read_n_ec_points` TOGETHER (transcript.hpp
+  // `g1_decompress_x8`: one square-root chain per group, ~35 us per proof instead of 124) and the launch never pays:
+  // 64 proofs 2.77 -> 2.31 ms, 256: 4.22 -> 3.98, 1 024 (pipelined): 8.9 -> 8.2 ms (profiles/r06_ab_pipeline.txt).
+  static size_t hint_min_default(unsigned threads) {
+    if (poseidon_ifma::available() && !getenv("SNARKV_HOST_NO_POINT_PREFETCH")) return (size_t)-1;
+    return std::max<size_t>(32, 2 * (size_t)threads + 1);
+  }
   static void decompress_hints(const KzgSuccinctVerifyingKey& svk, const PlonkProtocol& pr,
                                const std::vector<std::vector<std::vector<Fr>>>& instances,
                                const std::vector<std::vector<uint8_t>>& proofs, unsigned threads, PointHints& h,
@@ -320,10 +329,7 @@ struct Aggregator {
     PointHints hints;
     constexpr bool kHostPoseidon = std::is_same<TR, PoseidonTranscript>::value;
     if constexpr (kHostPoseidon) {
-      // The launch costs ~0.35 ms whatever the batch and saves each proof 13 host square roots (0.13 ms): worth it from
-      // the third proof per thread on (64 proofs on 64 threads: 2.62 ms with hints, 2.43 without; 128: level; 256: -4 %
-      // and a fifth of the CPU time; profiles/r06_ab_pipeline.txt)
-      size_t min_batch = std::max<size_t>(32, 2 * (size_t)threads + 1);
+      size_t min_batch = hint_min_default(threads);
       if (const char* e = getenv("SNARKV_HOST_HINT_MIN")) min_batch = (size_t)std::max(2, atoi(e));  // tuning / A-B knob
       if (n >= min_batch) decompress_hints(svk, pr, instances, proofs, threads, hints);
     }
@@ -394,8 +400,8 @@ struct Aggregator {
   // then r, the two KzgAs MSMs and (by the caller of this function) the pairing.  Same accumulators in the same order
   // into the same sponge: the result is `aggregate`'s bit for bit, and so is the error of a batch with a bad proof (the
   // pass reads every proof whatever happens, and the first error in proof order is the one returned).
-  // 1 024 distinct proofs end to end: 10.8 ms (this route unpipelined; 12.0 with the proofs hashed on the device) -> 8.65 ms
-  // at LESS CPU time (160 against 170 CPU-ms per job): profiles/r06_ab_pipeline.txt.
+  // 1 024 distinct proofs end to end: 10.9 ms (this route unpipelined; 11.8 with the proofs hashed on the device) -> 8.4 ms
+  // at the same CPU time: profiles/r06_ab_pipeline.txt.
   // Timings: `read_proofs`, `fr_algebra`, `msm_device` are the helper threads' BUSY times and run under `accumulate`
   // (the caller's wall time from the first wait to the accumulated point); `total` is wall time.
   static size_t pipeline_min() {
@@ -422,7 +428,7 @@ struct Aggregator {
     auto t0 = clk::now();
     PointHints hints;
     {
-      size_t min_batch = 32;
+      size_t min_batch = hint_min_default(threads);
       if (const char* e = getenv("SNARKV_HOST_HINT_MIN")) min_batch = (size_t)std::max(2, atoi(e));
       if (n >= min_batch) decompress_hints(svk, pr, instances, proofs, threads, hints);
     }

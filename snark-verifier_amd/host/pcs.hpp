@@ -76,8 +76,12 @@ struct Transcript {
     for (size_t i = 0; i < n; ++i) v.push_back(squeeze_challenge());
     return v;
   }
+  // called before `n` consecutive point reads: a transcript may decode them together (transcript.hpp: the Poseidon
+  // transcript's compressed points on AVX-512 IFMA) -- an optimisation only, every read still checks what it takes
+  virtual void prefetch_points(size_t) {}
   Result<std::vector<G1Affine>> read_n_ec_points(size_t n) {
     std::vector<G1Affine> v;
+    if (n >= 2) prefetch_points(n);
     for (size_t i = 0; i < n; ++i) {
       auto r = read_ec_point();
       if (!r.ok()) return Result<std::vector<G1Affine>>::Err(r.err);

@@ -385,6 +385,63 @@ inline SNARKV_IFMA_FN void absorb(V& state_v, const V& addend) {
   store(state_v, s);
 }
 
+
+// Lane-wise  y = (x^3 + b)^e  for canonical x (limbs of plain integers below the modulus), the result as PLAIN integers
+// below 4 p (limbs carried): the vector half of a batch of point decompressions (transcript.hpp `g1_decompress_x8`).
+// `e` = four 64-bit words (below 2^253 for BN254's (p + 1) / 4); r2 = R^2, one_m = R, b_m = b R (mod p, R = 2^260).
+inline SNARKV_IFMA_FN void sqrt_x3_plus_b(const V& x_plain, const V& pv, uint64_t np64, const V& r2v, const V& one_mv, const V& b_mv,
+                                          const V& one_plainv, const uint64_t e[4], V& out) {
+  __m512i p[5], x[5], r2[5], xm[5], x2[5], a[5], bm[5];
+  load(pv, p);
+  load(x_plain, x);
+  load(r2v, r2);
+  load(b_mv, bm);
+  const __m512i np = _mm512_set1_epi64((long long)np64), mask = _mm512_set1_epi64((long long)kMask52);
+  mul(x, r2, p, np, xm);  // x R
+  mul(xm, xm, p, np, x2);
+  {
+    Acc t;  // x^3 + b: the constant rides in the product's accumulators
+    acc_mul_fresh(t, x2, xm);
+    acc_shifted(t, bm);
+    reduce(t, p, np, a);
+  }
+  // 4-bit fixed window: table[k] = a^k, k = 0 .. 15 (in memory: 16 x 5 registers do not fit the file)
+  V table[16];
+  {
+    __m512i one[5], cur[5];
+    load(one_mv, one);
+    store(table[0], one);
+    store(table[1], a);
+    for (int k = 0; k < 5; ++k) cur[k] = a[k];
+    for (int k = 2; k < 16; ++k) {
+      mul(cur, a, p, np, cur);
+      store(table[k], cur);
+    }
+  }
+  __m512i acc[5];
+  bool started = false;
+  for (int w = 63; w >= 0; --w) {
+    const unsigned d = (unsigned)((e[w >> 4] >> (4 * (w & 15))) & 15u);
+    if (started) {
+      for (int q = 0; q < 4; ++q) mul(acc, acc, p, np, acc);
+      if (d) {
+        __m512i tk[5];
+        load(table[d], tk);
+        mul(acc, tk, p, np, acc);
+      }
+    } else if (d) {
+      load(table[d], acc);
+      started = true;
+    }
+  }
+  if (!started) load(one_mv, acc);
+  __m512i onep[5], y[5];
+  load(one_plainv, onep);
+  mul(acc, onep, p, np, y);  // out of the Montgomery domain (below 1.3 p)
+  (void)mask;
+  store(out, y);
+}
+
 }  // namespace poseidon_ifma
 }  // namespace snarkv_host
 #else

@@ -573,6 +573,22 @@ int hd_poseidon_permute2(int t, int r_f, int r_p, int plain, uint8_t* state) {
     return 0;
   });
 }
+// up to 8 compressed points decoded together on AVX-512 IFMA (transcript.hpp g1_decompress_x8): 0 ok, 1 = no IFMA here
+int hd_g1_decompress_x8(const uint8_t* enc32s, size_t n, uint8_t* out64s, uint8_t* ok_out) {
+  return guarded([&] {
+    const uint8_t* enc[8];
+    for (size_t i = 0; i < n && i < 8; ++i) enc[i] = enc32s + 32 * i;
+    G1Affine pts[8];
+    uint8_t ok[8];
+    if (!g1_decompress_x8(enc, n, pts, ok)) return 1;
+    for (size_t i = 0; i < n; ++i) {
+      ok_out[i] = ok[i];
+      memcpy(out64s + 64 * i, ok[i] ? pts[i].b : G1Affine().b, 64);
+    }
+    return 0;
+  });
+}
+
 // selects the partial-round form of the IFMA permutation (3 = default, 4 = the form it replaced); returns the previous one
 int hd_poseidon_ifma_form(int form) {
 #if defined(__x86_64__) && defined(__GNUC__)

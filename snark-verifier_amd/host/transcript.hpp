@@ -866,6 +866,11 @@ inline bool sqrt_mod(uint64_t r[4], const uint64_t a[4]) {
   return true;
 }
 }  // namespace fq_host
+// (p + 1) / 4, the exponent of the square root (four 64-bit words, little-endian)
+inline const uint64_t* fq_host_sqrt_exponent() {
+  static const uint64_t E[4] = {0x4f082305b61f3f52ull, 0x65e05aa45a1c72a3ull, 0x6e14116da0605617ull, 0x0c19139cb84c680aull};
+  return E;
+}
 
 // halo2curves 0.6.0 bn256 `G1Affine::{to_bytes, from_bytes}` (compressed, 32 bytes) as recalled
 inline void g1_compress(const G1Affine& p, uint8_t out[32]) {
@@ -903,6 +908,110 @@ inline bool g1_decompress(const uint8_t in[32], G1Affine* out) {
   memcpy(out->b, x, 32);
   memcpy(out->b + 32, y, 32);
   return true;
+}
+
+// Up to 8 compressed points decoded TOGETHER on AVX-512 IFMA: the square roots -- a^((p+1)/4), 253 squarings and 64 products
+// with a 4-bit window, a dependency chain of ~6.5 us -- run one per lane (poseidon_ifma.hpp's lane-wise Montgomery
+// product, modulus p, R = 2^260), so a group of points costs what ONE costs in scalar code (9.5 us each).  A transcript
+// uses this for the points it is about to read in one go (`read_n_ec_points`: a proof's witness / quotient / opening
+// commitments), as HINTS: read_ec_point takes a decoding only if it is the decoding of the bytes (`hint_matches`), and
+// identities, invalid encodings and non-residues are left to `g1_decompress` -- verdicts and error texts are its own.
+// ok[i] = 1: out[i] is a finite curve point whose x / parity are the encoded ones.  False if the CPU has no IFMA.
+inline bool g1_decompress_x8(const uint8_t* const enc[8], size_t n, G1Affine out[8], uint8_t ok[8]) {
+#if defined(__x86_64__) && defined(__GNUC__)
+  namespace pi = poseidon_ifma;
+  if (!pi::available() || n == 0 || n > 8) return false;
+  struct Consts {
+    pi::V p, r2, one_m, three_m, one_plain;
+    uint64_t np;
+  };
+  static const Consts C = [] {
+    Consts c;
+    uint64_t pl[5];
+    pi::split52(fq_host::P, pl);
+    // -p^-1 mod 2^52 by Newton's iteration on the low limb
+    uint64_t inv = 1;
+    for (int i = 0; i < 6; ++i) inv *= 2 - pl[0] * inv;
+    c.np = (0 - inv) & pi::kMask52;
+    auto pow2 = [](int e, uint64_t out4[4]) {  // 2^e mod p by doublings
+      uint64_t v[4] = {1, 0, 0, 0};
+      for (int i = 0; i < e; ++i) fq_host::add_mod(v, v, v);
+      memcpy(out4, v, 32);
+    };
+    uint64_t r1[4], r2[4], three[4];
+    pow2(260, r1);
+    pow2(520, r2);
+    fq_host::add_mod(three, r1, r1);
+    fq_host::add_mod(three, three, r1);
+    uint64_t l[5], lr2[5], l3[5];
+    pi::split52(r1, l);
+    pi::split52(r2, lr2);
+    pi::split52(three, l3);
+    for (int lane = 0; lane < 8; ++lane)
+      for (int k = 0; k < 5; ++k) {
+        c.p.l[k][lane] = pl[k];
+        c.r2.l[k][lane] = lr2[k];
+        c.one_m.l[k][lane] = l[k];
+        c.three_m.l[k][lane] = l3[k];
+        c.one_plain.l[k][lane] = k == 0 ? 1 : 0;
+      }
+    return c;
+  }();
+  uint64_t xs[8][4];
+  int ysign[8];
+  pi::V xv = pi::zero();
+  for (size_t i = 0; i < 8; ++i) {
+    ok[i] = 0;
+    if (i >= n) continue;
+    uint8_t xb[32];
+    memcpy(xb, enc[i], 32);
+    const int is_inf = xb[31] >> 7;
+    ysign[i] = (xb[31] >> 6) & 1;
+    xb[31] &= 0x3F;
+    memcpy(xs[i], xb, 32);
+    if (is_inf || !fq_host::lt_p(xs[i])) continue;  // (left to g1_decompress)
+    ok[i] = 1;
+    uint64_t l[5];
+    pi::split52(xs[i], l);
+    for (int k = 0; k < 5; ++k) xv.l[k][i] = l[k];
+  }
+  pi::V yv;
+  pi::sqrt_x3_plus_b(xv, C.p, C.np, C.r2, C.one_m, C.three_m, C.one_plain, fq_host_sqrt_exponent(), yv);
+  for (size_t i = 0; i < n; ++i) {
+    if (!ok[i]) continue;
+    uint64_t l[5], y[4];
+    for (int k = 0; k < 5; ++k) l[k] = yv.l[k][i];
+    pi::join52(l, y);  // below 4 p: canonical by at most three subtractions
+    for (int k = 0; k < 3 && !fq_host::lt_p(y); ++k) {
+      unsigned __int128 br = 0;
+      for (int w = 0; w < 4; ++w) {
+        unsigned __int128 d = (unsigned __int128)y[w] - fq_host::P[w] - (uint64_t)br;
+        y[w] = (uint64_t)d;
+        br = (d >> 64) & 1;
+      }
+    }
+    // y^2 = x^3 + 3 in scalar arithmetic: a non-residue (or any slip of the vector path) leaves the point to the scalar decoder
+    uint64_t x2[4], x3[4], rhs[4], three[4] = {3, 0, 0, 0}, chk[4];
+    fq_host::mul_mod(x2, xs[i], xs[i]);
+    fq_host::mul_mod(x3, x2, xs[i]);
+    fq_host::add_mod(rhs, x3, three);
+    fq_host::mul_mod(chk, y, y);
+    if (!fq_host::lt_p(y) || memcmp(chk, rhs, 32) != 0) {
+      ok[i] = 0;
+      continue;
+    }
+    if ((int)(y[0] & 1) != ysign[i]) {
+      uint64_t zero[4] = {0, 0, 0, 0};
+      fq_host::sub_mod(y, zero, y);
+    }
+    memcpy(out[i].b, xs[i], 32);
+    memcpy(out[i].b + 32, y, 32);
+  }
+  return true;
+#else
+  (void)enc, (void)n, (void)out, (void)ok;
+  return false;
+#endif
 }
 
 // Sponge policies for the transcript below.  `Poseidon` (above) hashes on the host.  The other
@@ -994,6 +1103,18 @@ class PoseidonTranscriptT : public Transcript {
     common_scalar(s);
     return Result<Fr>::Ok(s);
   }
+  // The next n points sit side by side in the stream: decode (up to 8 of) them together -- one square-root chain for the
+  // group instead of one per point.  Skipped when the decodings come from elsewhere (a replay pass, device hints).
+  void prefetch_points(size_t n) override {
+    pf_n_ = 0;
+    const size_t first = point_offsets_.size();
+    if (next_decoded_ < n_decoded_in_ || first < n_hints_ || getenv("SNARKV_HOST_NO_POINT_PREFETCH")) return;
+    n = std::min<size_t>(std::min<size_t>(n, 8), (stream_.size() - std::min(pos_, stream_.size())) / 32);
+    if (n < 2) return;
+    const uint8_t* enc[8];
+    for (size_t i = 0; i < n; ++i) enc[i] = stream_.data() + pos_ + 32 * i;
+    if (g1_decompress_x8(enc, n, pf_pts_, pf_ok_)) pf_pos_ = pos_, pf_n_ = n;
+  }
   Result<G1Affine> read_ec_point() override {  // halo2.rs:262-275: compressed `C::from_bytes`
     if (pos_ + 32 > stream_.size())
       return Result<G1Affine>::Err(Error{Error::Transcript, "failed to fill whole buffer"});
@@ -1006,6 +1127,9 @@ class PoseidonTranscriptT : public Transcript {
       p = decoded_in_[next_decoded_++];  // second parsing pass: the square root was taken in the first
     } else if (read_index < n_hints_ && hint_ok_[read_index] && hint_matches(hint_pts_ + 64 * read_index, enc)) {
       memcpy(p.b, hint_pts_ + 64 * read_index, 64);  // decompressed by the device for the whole batch (snarkv_g1_decompress)
+    } else if (pf_n_ && pos_ >= pf_pos_ && (pos_ - pf_pos_) % 32 == 0 && (pos_ - pf_pos_) / 32 < pf_n_ &&
+               pf_ok_[(pos_ - pf_pos_) / 32] && hint_matches(pf_pts_[(pos_ - pf_pos_) / 32].b, enc)) {
+      p = pf_pts_[(pos_ - pf_pos_) / 32];  // decoded with its neighbours by `prefetch_points` (g1_decompress_x8)
     } else {
       ok = g1_decompress(enc, &p);
       // Fused device route: the challenges were hashed over the DEVICE's decoding of these bytes.  A finite point the host
@@ -1054,6 +1178,10 @@ class PoseidonTranscriptT : public Transcript {
   const uint8_t* hint_pts_ = nullptr;           // candidate decodings by read index (64 bytes each) and their validity
   const uint8_t* hint_ok_ = nullptr;            // flags: borrowed views of the device's answer for the whole batch --
   size_t n_hints_ = 0;                          // no per-proof copies, nothing for a pool worker to free
+  // the points of the current `read_n_ec_points`, decoded together (prefetch_points): bytes [pf_pos_, pf_pos_ + 32 pf_n_)
+  G1Affine pf_pts_[8];
+  uint8_t pf_ok_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  size_t pf_pos_ = 0, pf_n_ = 0;
   bool strict_hints_ = false;
   bool record_layout_ = false;
   uint32_t pending_src_ = 0xFFFFFFFFu;          // the source of the element(s) the next common_* call absorbs

@@ -497,9 +497,15 @@ def test_host_hashed_poseidon_with_and_without_device_hints(monkeypatch):
     fx = HA.read_fixture(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
                                       "bench_plonk_gwc19_poseidon_64.bin"))
     hp, hdk = HA.Protocol(fx["protocol"]), HA.DecidingKey(fx["dk"])
+    monkeypatch.setenv("SNARKV_HOST_HINT_MIN", "2")  # (the default on a CPU with AVX-512 IFMA is "never": transcript.hpp g1_decompress_x8)
     ok, with_hints = HA.aggregate(hp, hdk, fx["instances"], fx["proofs"], fx["n"], HA.MOS_GWC19, HA.TRANSCRIPT_POSEIDON, 8)
     assert ok and with_hints == fx["expected_acc"]
+    # ... without device hints and without the transcript's own grouped decoding: the scalar square roots
     monkeypatch.setenv("SNARKV_HOST_HINT_MIN", "100000")
+    monkeypatch.setenv("SNARKV_HOST_NO_POINT_PREFETCH", "1")
+    ok, scalar = HA.aggregate(hp, hdk, fx["instances"], fx["proofs"], fx["n"], HA.MOS_GWC19, HA.TRANSCRIPT_POSEIDON, 8)
+    assert ok and scalar == fx["expected_acc"]
+    monkeypatch.delenv("SNARKV_HOST_NO_POINT_PREFETCH")
     ok, without = HA.aggregate(hp, hdk, fx["instances"], fx["proofs"], fx["n"], HA.MOS_GWC19, HA.TRANSCRIPT_POSEIDON, 8)
     assert ok and without == fx["expected_acc"]
     monkeypatch.delenv("SNARKV_HOST_HINT_MIN")

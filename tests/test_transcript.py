@@ -413,3 +413,57 @@ def test_device_point_hints_are_checked_and_strict_mode_refuses_a_disagreement(H
     bad = x.to_bytes(32, "little")
     for strict in (0, 1):
         assert H.hd_poseidon_hint_policy(bad, bytes(64), 0, strict, out) == 0
+
+
+def test_ifma_batched_point_decompression_is_a_checked_hint(H):
+    """transcript.hpp `g1_decompress_x8`: up to eight compressed points decoded together on AVX-512 IFMA (one square-root
+    chain for the group) -- what a Poseidon transcript does for the points of one `read_n_ec_points`.  Against the oracle's
+    decompression: random points of both parities in every group size, and the encodings it must LEAVE to the scalar decoder
+    (flag 0): the identity, x >= p, x with no square root on the curve, the identity flag over a non-zero x."""
+    H.hd_g1_decompress_x8.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p]
+    probe_out, probe_ok = ctypes.create_string_buffer(64), ctypes.create_string_buffer(1)
+    if H.hd_g1_decompress_x8(T.g1_compress(O.G1_GEN), 1, probe_out, probe_ok) == 1:
+        pytest.skip("no AVX-512 IFMA on this CPU")
+    rng = random.Random(88)
+
+    def non_residue_x():
+        while True:
+            x = rng.randrange(O.P)
+            if pow((x * x * x + 3) % O.P, (O.P - 1) // 2, O.P) != 1:
+                return x
+
+    for n in list(range(1, 9)) * 6:
+        encs, exp = [], []
+        for _ in range(n):
+            kind = rng.choice(["pt", "pt", "pt", "neg", "inf", "big", "nonres", "inf_garbage", "small"])
+            if kind in ("pt", "neg", "small"):
+                p = O.g1_mul(O.G1_GEN, rng.randrange(1, 50) if kind == "small" else rng.randrange(1, O.R))
+                if kind == "neg":
+                    p = O.g1_neg(p)
+                encs.append(T.g1_compress(p))
+                exp.append(p)
+            elif kind == "inf":
+                encs.append(T.g1_compress(None))
+                exp.append(None)
+            elif kind == "big":
+                encs.append((O.P + rng.randrange(1 << 60)).to_bytes(32, "little"))
+                exp.append(None)
+            elif kind == "nonres":
+                e = bytearray(non_residue_x().to_bytes(32, "little"))
+                e[31] |= rng.randrange(2) << 6
+                encs.append(bytes(e))
+                exp.append(None)
+            else:
+                e = bytearray(rng.randrange(1, O.P).to_bytes(32, "little"))
+                e[31] |= 0x80
+                encs.append(bytes(e))
+                exp.append(None)
+        out, ok = ctypes.create_string_buffer(64 * n), ctypes.create_string_buffer(n)
+        assert H.hd_g1_decompress_x8(b"".join(encs), n, out, ok) == 0
+        for i in range(n):
+            if exp[i] is None:
+                assert ok.raw[i] == 0, (n, i)
+            else:
+                assert ok.raw[i] == 1, (n, i)
+                assert out.raw[64 * i:64 * i + 64] == O.g1_to_bytes(exp[i]), (n, i)
+                assert T.g1_decompress(encs[i]) == exp[i]
