@@ -57,8 +57,8 @@ extern "C" {
 #define SNARKV_HOST_TRANSCRIPT_POSEIDON_DEVICE 2 /* the same transcript, hashed for the whole batch on the device       */
 /* the same transcript, hashed wherever the batch is faster: on the host threads below SNARKV_HOST_POSEIDON_DEVICE_MIN
  * proofs (the device launch is one latency chain of ~3 ms whatever the batch: measured 2 x slower than 64 host threads at
- * 64 proofs, 1.4 x faster at 1 024), on the device from there on; twice that threshold on a CPU with AVX-512 IFMA, whose
- * sponge is three times faster (host/poseidon_ifma.hpp).  ONE job (snarkv_host_aggregate) on a host with 32 or more pool
+ * 64 proofs, 1.4 x faster at 1 024), on the device from there on; three times that threshold on a CPU with AVX-512 IFMA,
+ * whose sponge is four times faster (host/poseidon_ifma.hpp).  ONE job (snarkv_host_aggregate) on a host with 32 or more pool
  * threads stays on the host route at every size from SNARKV_HOST_PIPELINE_MIN proofs on: there the route is a pipeline
  * bounded by the accumulation sponge alone (see snarkv_host_aggregate).  Same bytes either way. */
 #define SNARKV_HOST_TRANSCRIPT_POSEIDON_AUTO 3

@@ -311,7 +311,8 @@ def test_poseidon_auto_transcript_picks_by_batch_size():
     """SNARKV_HOST_TRANSCRIPT_POSEIDON_AUTO (include/snarkv_host.h): host-hashed below SNARKV_HOST_POSEIDON_DEVICE_MIN
     proofs, device-hashed from there on -- the same accumulator and verdict as either explicit kind on both sides of
     the threshold (64 proofs; the same 64 replicated to 512 and to 1 024: the threshold is 512 on the scalar sponge and
-    1 024 where the host sponge runs on AVX-512 IFMA)."""
+    1 536 where the host sponge runs on AVX-512 IFMA; ONE job on a host with 32+ pool threads stays on the host, pipelined,
+    from 256 proofs on)."""
     from snark_verifier_amd import host_api as HA
 
     fx = HA.read_fixture(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
