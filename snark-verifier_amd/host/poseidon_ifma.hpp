@@ -26,6 +26,10 @@
 //   tests/test_transcript.py::test_ifma_permutation_equals_the_scalar_schedule_and_the_oracle.
 // The canonical residue is taken once, when a challenge leaves the sponge.  Same values as `poseidon_permute` (the scalar
 // schedule it mirrors), word for word: tests/hosttest + tests/test_transcript.py pin one against the other.
+// Where the time goes (EPYC 9575F, Zen 5): a dependent lane-wise product is 19.2 ns = 96 cycles (`mul_chain`), the
+// permutation's chain is 60 x 3 + 8 x 4 = 212 of them = 4.1 us, measured 5.2 us: a partial round issues 365 fused
+// multiply-adds and the core retires about one 512-bit vpmadd52 per cycle, so the round is bound by ISSUE (~370 cycles),
+// not by the chain (~290).  On a core with two IFMA ports the chain is the bound.
 // Selected at run time (`available()`): the library is built without -mavx512*, these functions carry their own target.
 #pragma once
 #if defined(__x86_64__) && defined(__GNUC__)
@@ -385,6 +389,16 @@ inline SNARKV_IFMA_FN void absorb(V& state_v, const V& addend) {
   store(state_v, s);
 }
 
+
+// dev aid (tools / test hook): n DEPENDENT lane-wise products x <- x * x, the latency a sponge is made of
+inline SNARKV_IFMA_FN void mul_chain(V& xv, const V& pv, uint64_t np64, size_t n) {
+  __m512i p[5], x[5];
+  load(pv, p);
+  load(xv, x);
+  const __m512i np = _mm512_set1_epi64((long long)np64);
+  for (size_t i = 0; i < n; ++i) mul(x, x, p, np, x);
+  store(xv, x);
+}
 
 // Lane-wise  y = (x^3 + b)^e  for canonical x (limbs of plain integers below the modulus), the result as PLAIN integers
 // below 4 p (limbs carried): the vector half of a batch of point decompressions (transcript.hpp `g1_decompress_x8`).

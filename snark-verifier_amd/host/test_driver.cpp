@@ -589,6 +589,24 @@ int hd_g1_decompress_x8(const uint8_t* enc32s, size_t n, uint8_t* out64s, uint8_
   });
 }
 
+// nanoseconds per DEPENDENT lane-wise Montgomery product on this CPU (poseidon_ifma.hpp mul_chain), or -1 without IFMA
+double hd_ifma_mul_latency_ns(size_t n) {
+#if defined(__x86_64__) && defined(__GNUC__)
+  const poseidon_ifma::Tables* T = poseidon_ifma_tables(5, 8, 60);
+  if (!T) return -1.0;
+  poseidon_ifma::V x = T->one;
+  auto t0 = std::chrono::steady_clock::now();
+  poseidon_ifma::mul_chain(x, T->p, T->np, n);
+  double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
+  volatile uint64_t sink = x.l[0][0];
+  (void)sink;
+  return ns / (double)n;
+#else
+  (void)n;
+  return -1.0;
+#endif
+}
+
 // selects the partial-round form of the IFMA permutation (3 = default, 4 = the form it replaced); returns the previous one
 int hd_poseidon_ifma_form(int form) {
 #if defined(__x86_64__) && defined(__GNUC__)
