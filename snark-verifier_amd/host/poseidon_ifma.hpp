@@ -11,25 +11,26 @@
 //                  Montgomery reduction for the t x t products of a round
 //   sparse matrix  (partial rounds) row * state summed across the lanes + column * broadcast(s0) + state 2^260: two
 //                  lane-wise products, one reduction -- folded with the S-box into THREE dependent products per round
-//                  (`permute`: c x^5 = (c x) x^4 with c = (row_0, col_1 ..), everything else off the chain)
+//                  (`permute`: c x^5 = (c x) x^4 with c = (row_0, col_1 ..); the row's products share the fourth power's)
 //   constants      ride along as value * 2^260 in the accumulators of the product that precedes them
 // Operands of vpmadd52 must be below 2^52 per limb: every reduction ends in a carry pass.  Value bounds (r < 2^254,
 // R = 2^260: a product of two values below 2^260 / 2^3 reduces to below 1.3 r without a conditional subtraction):
 //   * AT PERMUTATION BOUNDARIES (what `fr_from_limbs` / `join52` may be given): below 4 r < 2^256;
 //   * INSIDE the partial rounds words 1 .. t-1 are NOT multiplied: they gain up to + r per round (four-product form:
-//     brought back every eighth round) or + 2 r per round (three-product form, the default: the round constant rides
-//     along multiplied through; brought back every FOURTH round), so they reach ~9.5 r -- above 2^256, below 2^260:
+//     brought back every eighth round, ~9.5 r) or + 2 r per round (three-product form, the default: the round constant
+//     rides along multiplied through; brought back every SIXTEENTH round, < 34 r) -- above 2^256, below 2^260 = 64.9 r:
 //     the limbs stay below 2^52 and every vpmadd52 operand is legal, but such a mid-permutation state must never
-//     reach `join52`.  Lengthening either period needs this bound re-derived: 2^260 / r > 64, minus the
-//     1.3 r + k r growth.
+//     reach `join52`.  Lengthening either period needs this bound re-derived (`permute` has the
+//     derivation for the default form).
 //   The worst case (all-(r-1) states, both parameter sets) is pinned against the scalar schedule in
 //   tests/test_transcript.py::test_ifma_permutation_equals_the_scalar_schedule_and_the_oracle.
 // The canonical residue is taken once, when a challenge leaves the sponge.  Same values as `poseidon_permute` (the scalar
 // schedule it mirrors), word for word: tests/hosttest + tests/test_transcript.py pin one against the other.
 // Where the time goes (EPYC 9575F, Zen 5): a dependent lane-wise product is 19.2 ns = 96 cycles (`mul_chain`), the
-// permutation's chain is 60 x 3 + 8 x 4 = 212 of them = 4.1 us, measured 5.2 us: a partial round issues 365 fused
-// multiply-adds and the core retires about one 512-bit vpmadd52 per cycle, so the round is bound by ISSUE (~370 cycles),
-// not by the chain (~290).  On a core with two IFMA ports the chain is the bound.
+// permutation's chain is 60 x 3 + 8 x 4 = 212 of them = 4.1 us, measured 5.1 us.  The rest is the chain's own glue
+// (three cross-lane broadcasts and two blends per partial round, the dense rounds' five accumulated products) -- NOT
+// issue: folding the row's products into the fourth power's (365 -> 315 fused multiply-adds per round) moved the
+// permutation from 5.17 to 5.06 us only.
 // Selected at run time (`available()`): the library is built without -mavx512*, these functions carry their own target.
 #pragma once
 #if defined(__x86_64__) && defined(__GNUC__)
@@ -300,33 +301,41 @@ inline SNARKV_IFMA_FN void permute(V& state_v, const Tables& T) {
     // A partial round is  x <- s_0^5 + k ;  s_0 <- row . s ;  s_i <- s_i + col_i x  (i >= 1): on a chain, the three
     // products of the S-box and then the row's.  With c = (row_0, col_1 .. col_{t-1}) the new state is
     //     c x^5  +  [ c k  +  (sum_{j >= 1} row_j s_j ,  s_1 .. s_{t-1}) ]        and   c x^5 = (c x) x^4 :
-    //   P1 = bcast(s_0) * (c | s_0 in lane 7)     lanes 0 .. t-1: c_i s_0, lane 7: s_0^2          product 1
-    //   x4 = bcast(P1[7])^2                                                                       product 2
-    //   s  = P1 * x4 + the bracket                 (the bracket does not depend on this round's S-box: off the chain)   product 3
-    // THREE dependent products per round instead of four, and 365 fused multiply-adds instead of 470.  Words 1 .. t-1
-    // now gain up to 2 r per round (c_i k rides along with s_i): they are brought back below 1.3 r every FOURTH round,
-    // by a product with 1 that the chain does not wait for (lane 0 is a fresh product anyway, below 3 r, and skips it),
-    // so the bound of the header holds as it stands: 1.3 r + 4 x 2 r < 9.5 r.  Lane 7 carries a by-product (s_0^6) that
-    // nothing reads; the final store clears it.
+    //   P1 = bcast(s_0) * (c | s_0 in lane 7)       lanes 0 .. t-1: c_i s_0, lane 7: s_0^2                          product 1
+    //   M2 = (s_0^2 | s_1 ..) * (s_0^2 | row_1 ..)  lane 0: s_0^4, lanes j >= 1: row_j s_j -- the row's products ride in
+    //                                               the lanes the fourth power leaves idle, reduced with it            product 2
+    //   s  = P1 * bcast(M2[0]) + the bracket        (the sum of M2's lanes 1 .. t-1 enters as a 2^260-shifted addend)    product 3
+    // THREE dependent products per round instead of four, and 315 fused multiply-adds instead of 470.
+    // Bounds: lane 0 comes out below 8 r (a product, c_0 k, four reduced row products, the reduction's + r); words
+    // 1 .. t-1 gain up to 2 r per round (c_i k rides along with s_i) and are brought back below 1.3 r every SIXTEENTH
+    // round by a product with 1 that the chain does not wait for (lane 0 skips it): 1.3 r + 16 x 2 r < 34 r < 2^260 / r = 64,
+    // so every limb stays below 2^52, and as an operand such a word only meets a table entry below r (34 r^2 / 2^260 < r).
+    // The full rounds that follow multiply every word (x^2 of 34 r is below 14 r), so the permutation still ends below
+    // 4 r.  Lane 7 carries a by-product (s_0^6) that nothing reads; the final store clears it.
     for (int r = 0; r < T.r_p; ++r) {
-      __m512i bx[5], y[5], c[5], p1[5], b2[5], x4[5], rr[5], ck[5];
+      __m512i bx[5], y[5], c[5], p1[5], b2[5], a2[5], y2[5], m2[5], x4[5], rr[5], ck[5];
       bcast(s, 0, bx);
       load(T.cvec[(size_t)r], c);
       for (int i = 0; i < 5; ++i) y[i] = _mm512_mask_mov_epi64(c[i], 0x80, bx[i]);
       mul(bx, y, p, np, p1);
       bcast(p1, 7, b2);
-      mul(b2, b2, p, np, x4);
       load(T.row_rest[(size_t)r], rr);
+      for (int i = 0; i < 5; ++i) {
+        a2[i] = _mm512_mask_mov_epi64(s[i], 0x01, b2[i]);
+        y2[i] = _mm512_mask_mov_epi64(rr[i], 0x01, b2[i]);
+      }
+      mul(a2, y2, p, np, m2);
+      bcast(m2, 0, x4);
       load(T.ck[(size_t)r], ck);
-      Acc d;  // sum_{j >= 1} row_j s_j, lane by lane (lane 0 of the row is cleared), then across the lanes into lane 0
-      acc_mul_fresh(d, rr, s);
       Acc a;
       acc_mul_fresh(a, p1, x4);
-      for (int i = 0; i < 5; ++i)
-        a.t[5 + i] = _mm512_add_epi64(a.t[5 + i], _mm512_add_epi64(ck[i], _mm512_maskz_mov_epi64((__mmask8)(live & ~1u), s[i])));
-      for (int i = 0; i < 10; ++i) a.t[i] = _mm512_add_epi64(a.t[i], hsum_to_lane0(d.t[i]));
+      for (int i = 0; i < 5; ++i) {
+        const __m512i rows = hsum_to_lane0(_mm512_maskz_mov_epi64(0xFE, m2[i]));  // sum_{j >= 1} row_j s_j (each reduced), into lane 0
+        const __m512i ride = _mm512_add_epi64(ck[i], _mm512_maskz_mov_epi64((__mmask8)(live & ~1u), s[i]));
+        a.t[5 + i] = _mm512_add_epi64(a.t[5 + i], _mm512_add_epi64(ride, rows));
+      }
       reduce(a, p, np, s);
-      if ((r & 3) == 3) {
+      if ((r & 15) == 15) {
         __m512i one[5], n[5];
         load(T.one, one);
         mul(s, one, p, np, n);
