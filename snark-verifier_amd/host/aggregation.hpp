@@ -417,7 +417,7 @@ struct Aggregator {
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const size_t n = proofs.size();
     if (n == 0 || instances.size() != n) return R::Err(Error{Error::InvalidInstances, "one instance set per proof"});
-    size_t chunk = 128;  // 2 proofs per pool thread; 3 072 MSM terms: packed inline by the device thread (no second pool job)
+    size_t chunk = 128;  // 2 proofs per pool thread
     if (const char* e = getenv("SNARKV_HOST_PIPELINE_CHUNK")) chunk = (size_t)std::max(1, atoi(e));  // tuning knob
     // chunk boundaries: the FIRST chunk is half a chunk -- the sponge, which bounds the job, idles until the first
     // accumulators arrive (a read pass + a launch), and both are shorter for fewer proofs
@@ -494,7 +494,23 @@ struct Aggregator {
       read_left[k].store(cut[k + 1] - cut[k], std::memory_order_relaxed);
       read_ready[k].store(0, std::memory_order_relaxed);
     }
-    std::thread reader([&] {
+    std::thread reader;
+    std::vector<std::thread> device;
+    struct JoinAll {  // whatever way this function is left (a std::thread that cannot be started, say): stop and join
+      std::thread& r;
+      std::vector<std::thread>& d;
+      std::function<void()> stop_all;
+      ~JoinAll() {
+        bool any = r.joinable();
+        for (auto& t : d) any = any || t.joinable();
+        if (!any) return;
+        stop_all();
+        if (r.joinable()) r.join();
+        for (auto& t : d)
+          if (t.joinable()) t.join();
+      }
+    } join_all{reader, device, halt};
+    reader = std::thread([&] {
       try {
         std::vector<double> t_read(n, 0.0);
         auto a = clk::now();
@@ -544,7 +560,6 @@ struct Aggregator {
         halt();
       }
     });
-    std::vector<std::thread> device;
     for (size_t d = 0; d < D; ++d)
       device.emplace_back([&, d] {
         try {
@@ -553,7 +568,7 @@ struct Aggregator {
             const size_t lo = cut[k], hi = cut[k + 1];
             auto a = clk::now();
             std::vector<typename SV::Pairs> part(std::make_move_iterator(jobs.begin() + 2 * lo), std::make_move_iterator(jobs.begin() + 2 * hi));
-            auto pts = L::multi_scalar_multiplication_batch(part);
+            auto pts = L::multi_scalar_multiplication_batch(part, /*use_pool=*/false);  // (the pool is the reader's)
             for (size_t i = lo; i < hi; ++i) {
               out[i].push_back(KzgAccumulator{pts[2 * (i - lo)], pts[2 * (i - lo) + 1]});
               out[i].insert(out[i].end(), pfs[i].old_accumulators.begin(), pfs[i].old_accumulators.end());

@@ -330,8 +330,10 @@ struct GpuNativeLoader {
 
   // Beyond the reference surface: several deferred MSMs in ONE segmented launch
   // (what makes the GPU worthwhile for the many small MSMs of accumulation).
+  // `use_pool`: false = pack on the calling thread whatever the size (a caller whose host pool is busy with another pass:
+  // the pool runs one job at a time, and waiting for it would serialise the two -- aggregation.hpp's device threads)
   static std::vector<G1Affine> multi_scalar_multiplication_batch(
-      const std::vector<std::vector<std::pair<Fr, G1Affine>>>& msms) {
+      const std::vector<std::vector<std::pair<Fr, G1Affine>>>& msms, bool use_pool = true) {
     std::vector<uint32_t> offs(1, 0);
     for (auto& m : msms) {
       if (m.empty()) throw Panic("empty MSM in batch (reference: native.rs:69)");
@@ -355,7 +357,7 @@ struct GpuNativeLoader {
         }
       }
     };
-    if (total >= 4096) {
+    if (total >= 4096 && use_pool) {
       const size_t per = 16;  // MSMs per task (a few hundred terms: ~10 us of conversions and copies)
       const size_t tasks = (msms.size() + per - 1) / per;
       parallel_for(tasks, 64, [&](size_t k) { pack(k * per, std::min(msms.size(), (k + 1) * per)); }, 1);
