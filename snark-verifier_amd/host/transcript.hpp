@@ -1109,11 +1109,15 @@ class PoseidonTranscriptT : public Transcript {
     pf_n_ = 0;
     const size_t first = point_offsets_.size();
     if (next_decoded_ < n_decoded_in_ || first < n_hints_ || getenv("SNARKV_HOST_NO_POINT_PREFETCH")) return;
-    n = std::min<size_t>(std::min<size_t>(n, 8), (stream_.size() - std::min(pos_, stream_.size())) / 32);
+    n = std::min<size_t>(std::min<size_t>(n, kPrefetchMax), (stream_.size() - std::min(pos_, stream_.size())) / 32);
     if (n < 2) return;
-    const uint8_t* enc[8];
-    for (size_t i = 0; i < n; ++i) enc[i] = stream_.data() + pos_ + 32 * i;
-    if (g1_decompress_x8(enc, n, pf_pts_, pf_ok_)) pf_pos_ = pos_, pf_n_ = n;
+    for (size_t g = 0; g < n; g += 8) {  // groups of eight lanes
+      const size_t m = std::min<size_t>(8, n - g);
+      const uint8_t* enc[8];
+      for (size_t i = 0; i < m; ++i) enc[i] = stream_.data() + pos_ + 32 * (g + i);
+      if (!g1_decompress_x8(enc, m, pf_pts_ + g, pf_ok_ + g)) return;  // (no IFMA: pf_n_ stays 0)
+    }
+    pf_pos_ = pos_, pf_n_ = n;
   }
   Result<G1Affine> read_ec_point() override {  // halo2.rs:262-275: compressed `C::from_bytes`
     if (pos_ + 32 > stream_.size())
@@ -1179,8 +1183,9 @@ class PoseidonTranscriptT : public Transcript {
   const uint8_t* hint_ok_ = nullptr;            // flags: borrowed views of the device's answer for the whole batch --
   size_t n_hints_ = 0;                          // no per-proof copies, nothing for a pool worker to free
   // the points of the current `read_n_ec_points`, decoded together (prefetch_points): bytes [pf_pos_, pf_pos_ + 32 pf_n_)
-  G1Affine pf_pts_[8];
-  uint8_t pf_ok_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static constexpr size_t kPrefetchMax = 32;
+  G1Affine pf_pts_[kPrefetchMax];
+  uint8_t pf_ok_[kPrefetchMax] = {};
   size_t pf_pos_ = 0, pf_n_ = 0;
   bool strict_hints_ = false;
   bool record_layout_ = false;
