@@ -510,11 +510,27 @@ struct Aggregator {
           if (t.joinable()) t.join();
       }
     } join_all{reader, device, halt};
+    // Item order of the pass: the pool hands out `claim` consecutive items at a time, so with the proofs in plain order the
+    // first chunk (64 proofs) would go to 32 workers, two proofs each, while the other 32 start on the second chunk.  The
+    // FIRST item of every early claim is a proof of the first chunk instead: every worker's first proof belongs to it, and
+    // the sponge gets its first accumulators one proof-time (0.2 ms) earlier.  Later proofs keep their order.
+    std::vector<uint32_t> order(n);
+    {
+      const unsigned eff = std::max(1u, std::min<unsigned>(std::min<unsigned>(threads, (unsigned)n), HostPool::get().size() + 1));
+      const size_t claim = HostPool::claim_size(n, eff), F = cut[1];
+      size_t next = F, t = 0;
+      for (size_t b = 0; b < F; ++b) {
+        order[t++] = (uint32_t)b;
+        for (size_t q = 1; q < claim && next < n; ++q) order[t++] = (uint32_t)next++;
+      }
+      while (next < n) order[t++] = (uint32_t)next++;
+    }
     reader = std::thread([&] {
       try {
         std::vector<double> t_read(n, 0.0);
         auto a = clk::now();
-        parallel_for(n, threads, [&](size_t i) {
+        parallel_for(n, threads, [&](size_t item) {
+          const size_t i = order[item];
           const size_t k = chunk_of[i];
           bool good = false;
           struct Done {  // whatever way the task ends: the chunk's count goes down, its last GOOD proof publishes it

@@ -109,6 +109,9 @@ class HostPool {
     return p;
   }
   unsigned size() const { return (unsigned)workers_.size(); }
+  // consecutive items a worker takes per claim when `run(n, threads, ..)` hands them out (a caller that orders its items
+  // for the claims: aggregation.hpp)
+  static size_t claim_size(size_t n, unsigned threads) { return std::max<size_t>(1, n / ((size_t)std::max(1u, threads) * 8)); }
   // runs fn(i) for i in [0, n) on up to `threads` threads, the caller among them (it returns when all are done); the
   // first exception wins
   template <class F>
@@ -121,7 +124,7 @@ class HostPool {
     std::lock_guard<std::mutex> one_job(submit_mu_);
     // (the previous job is closed and empty: nobody reads these fields now)
     n_.store(n, std::memory_order_relaxed);
-    chunk_.store(std::max<size_t>(1, n / ((size_t)threads * 8)), std::memory_order_relaxed);  // items per claim: 8 claims per thread
+    chunk_.store(claim_size(n, threads), std::memory_order_relaxed);  // items per claim: 8 claims per thread
     fn_ = [&](size_t i) { fn(i); };
     next_.store(0, std::memory_order_relaxed);
     max_workers_.store(threads - 1, std::memory_order_relaxed);
